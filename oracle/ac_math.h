@@ -1,0 +1,104 @@
+/*
+ * oracle/ac_math.h -- TEST INFRASTRUCTURE (CPU oracle), never linked into the product.
+ *
+ * Deterministic fp32 transcendental functions used by the oracle.  The HIP
+ * kernels carry their own, independently written, device versions of the same
+ * published algorithms (avatarcraft_amd/csrc/ac_devmath.hpp); both sides use
+ * only IEEE-754 correctly rounded +,-,*,/,fma and integer bit operations, so
+ * the CPU oracle and the gfx950 kernels agree bit for bit.  Against the
+ * reference (torch CPU, Sleef) they differ by <= 1-2 ulp, which is what the
+ * golden-vector tolerances in tests/ absorb.
+ *
+ *   orc_expf   : Cody-Waite range reduction + degree-6 polynomial (Cephes expf
+ *                coefficients), result scaled by two exact powers of two.
+ *   orc_log1pf : the fdlibm / Sun Microsystems log1pf scheme (k, f, s=f/(2+f),
+ *                even/odd minimax polynomial Lg1..Lg4, rounding-correction c).
+ *                Constants from FreeBSD msun s_log1pf.c ("Copyright (C) 1993 by
+ *                Sun Microsystems, Inc. ... Permission to use, copy, modify,
+ *                and distribute this software is freely granted, provided that
+ *                this notice is preserved.").
+ *   orc_softplus100, orc_sigmoid: compositions following torch's formulas
+ *                (reference: models/instant_nsr.py:231,239-240,591).
+ */
+#ifndef ORC_AC_MATH_H
+#define ORC_AC_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline float orc_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t orc_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static inline float orc_expf(float x)
+{
+    if (x > 88.72283f) return INFINITY;
+    if (!(x >= -87.33654f)) return (x != x) ? x : 0.0f; /* flush below min normal */
+    /* n = nearest integer to x/ln2 via the 1.5*2^23 trick (exact in RN mode) */
+    float t = fmaf(x, 1.44269504f, 12582912.0f);
+    float n = t - 12582912.0f;
+    float r = fmaf(n, -0.693359375f, x);       /* ln2 high part: 0x3f318000 */
+    r = fmaf(n, 2.12194440e-4f, r);            /* minus ln2 low part */
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float e = fmaf(p, r2, r) + 1.0f;
+    int ni = (int)n;
+    int n1 = ni >> 1;          /* arithmetic shift: floor(n/2) */
+    int n2 = ni - n1;
+    float s1 = orc_bits2f((uint32_t)(n1 + 127) << 23);
+    float s2 = orc_bits2f((uint32_t)(n2 + 127) << 23);
+    return (e * s1) * s2;
+}
+
+static inline float orc_log1pf(float x)
+{
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f,
+                Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
+    if (!(x > -1.0f)) return (x == -1.0f) ? -INFINITY : NAN;
+    if (fabsf(x) < 5.9604645e-08f) return x;          /* |x| < 2^-24 */
+    if (x == INFINITY) return x;
+    float u = 1.0f + x;
+    uint32_t iu = orc_f2bits(u);
+    iu += 0x3f800000u - 0x3f3504f3u;
+    int k = (int)(iu >> 23) - 127;
+    float c;
+    if (k < 25) {
+        c = (k >= 2) ? 1.0f - (u - x) : x - (u - 1.0f);
+        c = c / u;
+    } else {
+        c = 0.0f;
+    }
+    iu = (iu & 0x007fffffu) + 0x3f3504f3u;
+    float f = orc_bits2f(iu) - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * fmaf(w, Lg4, Lg2);
+    float t2 = z * fmaf(w, Lg3, Lg1);
+    float R = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float dk = (float)k;
+    return fmaf(s, hfsq + R, fmaf(dk, ln2_lo, c)) - hfsq + f + dk * ln2_hi;
+}
+
+/* torch.nn.Softplus(beta=100, threshold=20): x if x*beta > 20 else log1p(exp(x*beta))/beta */
+static inline float orc_softplus100(float x)
+{
+    float t = x * 100.0f;
+    if (t > 20.0f) return x;
+    return orc_log1pf(orc_expf(t)) / 100.0f;
+}
+
+/* torch.sigmoid: 1 / (1 + exp(-x)) */
+static inline float orc_sigmoid(float x)
+{
+    return 1.0f / (1.0f + orc_expf(-x));
+}
+
+#endif

@@ -1,0 +1,685 @@
+/*
+ * oracle/ac_oracle.c -- TEST INFRASTRUCTURE.  CPU restatement of the reference
+ * algorithm of the AvatarCraft hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (avatarcraft_amd/) never does.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the reference checkout).  Plain C99, scalar, fp32; optional OpenMP over
+ * independent rays / points only (never inside a reduction, so results do not
+ * depend on the thread count).
+ *
+ * Pinning (see DESIGN.md "Oracle"):
+ *   - integer pieces (pcg32, fast_hash, grid index, level table, march_rays_train
+ *     slot layout) against the known-answer values of SURVEY.md Appendix A.4/B,
+ *     which were produced by the reference's own kernel bodies;
+ *   - the float path (run(): sampling, up-sampling, SDF/colour MLP, NeuS alpha,
+ *     compositing) against golden vectors generated in this container by
+ *     importing the reference's Python (tests/golden/make_golden.py).
+ *   - the reference CUDA sources need cuda.h/cuda_fp16.h/ATen CUDA headers that
+ *     this image lacks, so oracle/_ref is NOT built (unbuildable without
+ *     stand-in headers); the hash/SH/raymarching kernels are pinned by the
+ *     KATs above only: "parity pinned by KAT + Python goldens, kernels'
+ *     float output unpinned against a compiled reference".
+ *
+ * Floating-point order conventions (the HIP kernels follow the same ones, so
+ * GPU == oracle bit for bit; versus the reference these are ulp-level
+ * re-associations):
+ *   - dot products of the MLPs are fp32 fma chains in the k-order documented
+ *     at orc_sdf_mlp()/orc_color_mlp() (= the MFMA 16x16x4 f32 k-order);
+ *   - per-ray cumprod / cumsum / sums run in tiles of 16 samples: a
+ *     Kogge-Stone inclusive scan inside the tile (offsets 1,2,4,8) and a
+ *     sequential carry across tiles (orc_tilescan());
+ *   - exp/log1p are the deterministic versions of ac_math.h.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "ac_math.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* pcg32  (reference: raymarching/src/pcg32.h:44-116)                  */
+/* ------------------------------------------------------------------ */
+typedef struct { uint64_t state, inc; } orc_pcg32;
+
+static uint32_t pcg_next_uint(orc_pcg32 *g)
+{
+    uint64_t old = g->state;
+    g->state = old * 0x5851f42d4c957f2dULL + g->inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+}
+static void pcg_seed(orc_pcg32 *g, uint64_t initstate, uint64_t initseq)
+{
+    g->state = 0u;
+    g->inc = (initseq << 1u) | 1u;
+    pcg_next_uint(g);
+    g->state += initstate;
+    pcg_next_uint(g);
+}
+static float pcg_next_float(orc_pcg32 *g)
+{
+    return orc_bits2f((pcg_next_uint(g) >> 9) | 0x3f800000u) - 1.0f;
+}
+ORC_API void orc_pcg32_seed(uint64_t *st, uint64_t initstate, uint64_t initseq)
+{ orc_pcg32 g; pcg_seed(&g, initstate, initseq); st[0] = g.state; st[1] = g.inc; }
+ORC_API uint32_t orc_pcg32_next_uint(uint64_t *st)
+{ orc_pcg32 g = { st[0], st[1] }; uint32_t r = pcg_next_uint(&g); st[0] = g.state; return r; }
+ORC_API float orc_pcg32_next_float(uint64_t *st)
+{ orc_pcg32 g = { st[0], st[1] }; float r = pcg_next_float(&g); st[0] = g.state; return r; }
+
+/* ------------------------------------------------------------------ */
+/* hash grid (reference: encoder/hashencoder/src/hashencoder.cu)        */
+/* ------------------------------------------------------------------ */
+#define ORC_MAX_LEVELS 32
+
+/* hashencoder.cu:35-51 */
+ORC_API uint32_t orc_fast_hash(const uint32_t *pos_grid, uint32_t D)
+{
+    static const uint32_t primes[7] = { 1u, 2654435761u, 805459861u, 3674653429u,
+                                        2097192037u, 1434869437u, 2165219737u };
+    uint32_t h = 0;
+    for (uint32_t i = 0; i < D; ++i) h ^= pos_grid[i] * primes[i];
+    return h;
+}
+
+/* hashencoder.cu:54-70 */
+ORC_API uint32_t orc_grid_index(uint32_t D, uint32_t C, uint32_t ch, uint32_t hashmap_size,
+                                uint32_t resolution, const uint32_t *pos_grid)
+{
+    uint32_t stride = 1, index = 0;
+    for (uint32_t d = 0; d < D && stride <= hashmap_size; d++) {
+        index += pos_grid[d] * stride;
+        stride *= (resolution + 1);
+    }
+    if (stride > hashmap_size) index = orc_fast_hash(pos_grid, D);
+    return (index % hashmap_size) * C + ch;
+}
+
+/* hashencoder.cu:122-123: scale = exp2f(level*S)*H - 1 ; resolution = ceil(scale)+1.
+ * exp2f is evaluated as the correctly rounded fp32 value of 2^(level*S) (double exp2,
+ * one rounding) so the table is identical on every host; both the oracle and the HIP
+ * library receive this host-side table (SURVEY.md section 7 "hard part ii"). */
+ORC_API void orc_hash_level_table(uint32_t L, float S, uint32_t H, float *scale, uint32_t *res)
+{
+    for (uint32_t l = 0; l < L; ++l) {
+        float e = (float)l * S;
+        float p2 = (float)exp2((double)e);
+        float sc = p2 * (float)H - 1.0f;
+        scale[l] = sc;
+        res[l] = (uint32_t)ceilf(sc) + 1u;
+    }
+}
+
+/* one (point, level): hashencoder.cu:94-219.  Convention: the CUDA compiler contracts
+ * x*scale+0.5 and acc += w*g into fma; we state them as explicit fmaf. */
+static void hash_point_level(const float *x, uint32_t D, uint32_t C, const float *grid_l,
+                             uint32_t hashmap_size, float scale, uint32_t resolution,
+                             float *out, int calc_grad, float *dydx /* [D*C] */)
+{
+    int oob = 0;
+    for (uint32_t d = 0; d < D; d++) if (x[d] < 0 || x[d] > 1) oob = 1;
+    if (oob) {
+        for (uint32_t c = 0; c < C; c++) out[c] = 0;
+        if (calc_grad) for (uint32_t i = 0; i < D * C; i++) dydx[i] = 0;
+        return;
+    }
+    float pos[3]; uint32_t pg[3];
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = fmaf(x[d], scale, 0.5f);
+        float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= (float)pg[d];
+    }
+    float acc[8] = {0};
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1; uint32_t pl[3];
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        uint32_t index = orc_grid_index(D, C, 0, hashmap_size, resolution, pl);
+        for (uint32_t c = 0; c < C; c++) acc[c] = fmaf(w, grid_l[index + c], acc[c]);
+    }
+    for (uint32_t c = 0; c < C; c++) out[c] = acc[c];
+    if (calc_grad) {
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float rg[8] = {0};
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float w = scale; uint32_t pl[3];
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                pl[gd] = pg[gd];
+                uint32_t il = orc_grid_index(D, C, 0, hashmap_size, resolution, pl);
+                pl[gd] = pg[gd] + 1;
+                uint32_t ir = orc_grid_index(D, C, 0, hashmap_size, resolution, pl);
+                for (uint32_t c = 0; c < C; c++)
+                    rg[c] = fmaf(w, grid_l[ir + c] - grid_l[il + c], rg[c]);
+            }
+            for (uint32_t c = 0; c < C; c++) dydx[gd * C + c] = rg[c];
+        }
+    }
+}
+
+/* _backend.hash_encode_forward (hashencoder.cu:341-367,413-436): outputs [L,B,C],
+ * dy_dx [B, L*D*C].  corner_idx (optional, [L,B,2^D]) exports the table entry index
+ * (before *C) of every corner, the "hash corner indices" parity item. */
+ORC_API int orc_hash_encode_forward(const float *inputs, const float *grid, const int32_t *offsets,
+                                    float *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                    float S, uint32_t H, int calc_grad_inputs, float *dy_dx,
+                                    uint32_t *corner_idx)
+{
+    if (!(D == 2 || D == 3) || !(C == 1 || C == 2 || C == 4 || C == 8) || L > ORC_MAX_LEVELS) return 1;
+    float scale[ORC_MAX_LEVELS]; uint32_t res[ORC_MAX_LEVELS];
+    orc_hash_level_table(L, S, H, scale, res);
+    for (uint32_t l = 0; l < L; l++) {
+        const float *grid_l = grid + (size_t)(uint32_t)offsets[l] * C;
+        uint32_t hs = (uint32_t)(offsets[l + 1] - offsets[l]);
+        #pragma omp parallel for schedule(static)
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            float tmp[24];
+            hash_point_level(inputs + b * D, D, C, grid_l, hs, scale[l], res[l],
+                             outputs + ((size_t)l * B + b) * C, calc_grad_inputs,
+                             calc_grad_inputs ? dy_dx + (size_t)b * D * L * C + (size_t)l * D * C : tmp);
+            if (corner_idx) {
+                const float *x = inputs + b * D;
+                uint32_t *ci = corner_idx + ((size_t)l * B + b) * (1u << D);
+                int oob = 0;
+                for (uint32_t d = 0; d < D; d++) if (x[d] < 0 || x[d] > 1) oob = 1;
+                for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                    if (oob) { ci[idx] = 0xffffffffu; continue; }
+                    uint32_t pl[3];
+                    for (uint32_t d = 0; d < D; d++) {
+                        float p = fmaf(x[d], scale[l], 0.5f);
+                        uint32_t g = (uint32_t)floorf(p);
+                        pl[d] = g + ((idx >> d) & 1u);
+                    }
+                    ci[idx] = orc_grid_index(D, 1, 0, hs, res[l], pl);
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* _backend.hash_encode_backward (hashencoder.cu:223-337,370-409).  grad [L,B,C];
+ * grad_grid accumulates (caller zero-inits, hashgrid.py:61).  Serial in b: this is the
+ * canonical accumulation order; the GPU uses atomics (order-free), compared with a tolerance. */
+ORC_API int orc_hash_encode_backward(const float *grad, const float *inputs, const float *grid,
+                                     const int32_t *offsets, float *grad_grid, uint32_t B, uint32_t D,
+                                     uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                                     const float *dy_dx, float *grad_inputs)
+{
+    (void)grid;
+    if (!(D == 2 || D == 3) || !(C == 1 || C == 2 || C == 4 || C == 8) || L > ORC_MAX_LEVELS) return 1;
+    float scale[ORC_MAX_LEVELS]; uint32_t res[ORC_MAX_LEVELS];
+    orc_hash_level_table(L, S, H, scale, res);
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t l = 0; l < (int64_t)L; l++) {
+        float *gg = grad_grid + (size_t)(uint32_t)offsets[l] * C;
+        uint32_t hs = (uint32_t)(offsets[l + 1] - offsets[l]);
+        for (uint32_t b = 0; b < B; b++) {
+            const float *x = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[3]; uint32_t pg[3];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(x[d], scale[l], 0.5f);
+                pg[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pg[d];
+            }
+            const float *g = grad + ((size_t)l * B + b) * C;
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1; uint32_t pl[3];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                uint32_t index = orc_grid_index(D, C, 0, hs, res[l], pl);
+                for (uint32_t c = 0; c < C; c++) gg[index + c] += w * g[c];
+            }
+        }
+    }
+    if (calc_grad_inputs) { /* kernel_input_backward, hashencoder.cu:311-337 */
+        for (uint32_t t = 0; t < B * D; t++) {
+            uint32_t b = t / D, d = t - b * D;
+            const float *dd = dy_dx + (size_t)b * L * D * C;
+            float r = 0;
+            for (uint32_t l = 0; l < L; l++)
+                for (uint32_t ch = 0; ch < C; ch++)
+                    r = fmaf(grad[((size_t)l * B + b) * C + ch], dd[l * D * C + d * C + ch], r);
+            grad_inputs[t] = r;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Instant-NSR field: SDF MLP, FD normals, colour MLP                   */
+/* (reference: models/instant_nsr.py:627-663,687-704)                   */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    const float *table;        /* embeddings [n_entries, 2] */
+    const int32_t *offsets;    /* [17] */
+    float scale[16];           /* per-level table (orc_hash_level_table) */
+    uint32_t res[16];
+    const float *W1, *b1;      /* effective (weight-normed) sdf_net.0: [64,35], [64] */
+    const float *W2, *b2;      /* sdf_net.1: [16,64], [16] */
+    const float *Wc1;          /* color_net.0: [64,21] */
+    const float *Wc2;          /* color_net.1: [64,64] */
+    const float *Wc3;          /* color_net.2: [3,64] */
+} orc_field;
+
+/* HashEncoder.forward (hashgrid.py:126-142) for L=16,C=2,D=3: enc[2*l+c] */
+static void field_encode(const orc_field *f, const float x[3], float bound, float enc[32])
+{
+    float two_b = (float)(2.0 * (double)bound);
+    float u[3];
+    for (int d = 0; d < 3; d++) u[d] = (x[d] + bound) / two_b;
+    for (int l = 0; l < 16; l++) {
+        uint32_t hs = (uint32_t)(f->offsets[l + 1] - f->offsets[l]);
+        hash_point_level(u, 3, 2, f->table + (size_t)(uint32_t)f->offsets[l] * 2, hs, f->scale[l],
+                         f->res[l], enc + 2 * l, 0, NULL);
+    }
+}
+
+/* forward_sdf (instant_nsr.py:627-642): h = cat[x, enc] (35) -> WN-Linear 64 -> Softplus(100)
+ * -> WN-Linear 16.  fma-chain order = MFMA k-order of the HIP kernel:
+ *   layer 1: acc=b1[u]; k-step 0 feeds (x,y,z,0); k-steps 1..8 feed, for g=0..3,
+ *            the feature (level 4*((s-1)>>1)+g, channel (s-1)&1);
+ *   layer 2: acc=b2[o]; for t=0..3, r=0..3, g=0..3: hidden unit 16t+4g+r. */
+static void orc_sdf_mlp(const orc_field *f, const float x[3], const float enc[32], float out[16])
+{
+    float hid[64];
+    for (int u = 0; u < 64; u++) {
+        const float *w = f->W1 + u * 35;
+        float acc = f->b1[u];
+        acc = fmaf(w[0], x[0], acc);
+        acc = fmaf(w[1], x[1], acc);
+        acc = fmaf(w[2], x[2], acc);
+        acc = fmaf(0.0f, 0.0f, acc);
+        for (int s = 1; s <= 8; s++)
+            for (int g = 0; g < 4; g++) {
+                int lvl = 4 * ((s - 1) >> 1) + g, ch = (s - 1) & 1;
+                acc = fmaf(w[3 + 2 * lvl + ch], enc[2 * lvl + ch], acc);
+            }
+        hid[u] = orc_softplus100(acc);
+    }
+    for (int o = 0; o < 16; o++) {
+        const float *w = f->W2 + o * 64;
+        float acc = f->b2[o];
+        for (int t = 0; t < 4; t++)
+            for (int r = 0; r < 4; r++)
+                for (int g = 0; g < 4; g++) {
+                    int u = 16 * t + 4 * g + r;
+                    acc = fmaf(w[u], hid[u], acc);
+                }
+        out[o] = acc;
+    }
+}
+
+static void field_sdf(const orc_field *f, const float x[3], float bound, float out[16])
+{
+    float enc[32];
+    field_encode(f, x, bound, enc);
+    orc_sdf_mlp(f, x, enc, out);
+}
+
+/* forward_color (instant_nsr.py:644-663), use_viewdirs=False: cat[x, n, feat] (21) ->
+ * 64 ReLU -> 64 ReLU -> 3 -> sigmoid, no biases.  fma-chain order:
+ *   layer 1: acc=0; for r=0..3, g=0..3: SDF-MLP output o=4g+r (o=0, the sdf itself,
+ *            enters with weight 0); then (x,y,z,0); then (nx,ny,nz,0);
+ *   layers 2,3: for t,r,g: hidden unit 16t+4g+r. */
+static void orc_color_mlp(const orc_field *f, const float x[3], const float n[3],
+                          const float sdfout[16], float rgb[3])
+{
+    float h1[64], h2[64];
+    for (int u = 0; u < 64; u++) {
+        const float *w = f->Wc1 + u * 21;
+        float acc = 0.0f;
+        for (int r = 0; r < 4; r++)
+            for (int g = 0; g < 4; g++) {
+                int o = 4 * g + r;
+                float wv = (o == 0) ? 0.0f : w[6 + (o - 1)];
+                acc = fmaf(wv, sdfout[o], acc);
+            }
+        acc = fmaf(w[0], x[0], acc); acc = fmaf(w[1], x[1], acc); acc = fmaf(w[2], x[2], acc);
+        acc = fmaf(0.0f, 0.0f, acc);
+        acc = fmaf(w[3], n[0], acc); acc = fmaf(w[4], n[1], acc); acc = fmaf(w[5], n[2], acc);
+        acc = fmaf(0.0f, 0.0f, acc);
+        h1[u] = acc > 0.0f ? acc : 0.0f;
+    }
+    for (int u = 0; u < 64; u++) {
+        const float *w = f->Wc2 + u * 64;
+        float acc = 0.0f;
+        for (int t = 0; t < 4; t++) for (int r = 0; r < 4; r++) for (int g = 0; g < 4; g++) {
+            int k = 16 * t + 4 * g + r; acc = fmaf(w[k], h1[k], acc);
+        }
+        h2[u] = acc > 0.0f ? acc : 0.0f;
+    }
+    for (int o = 0; o < 3; o++) {
+        const float *w = f->Wc3 + o * 64;
+        float acc = 0.0f;
+        for (int t = 0; t < 4; t++) for (int r = 0; r < 4; r++) for (int g = 0; g < 4; g++) {
+            int k = 16 * t + 4 * g + r; acc = fmaf(w[k], h2[k], acc);
+        }
+        rgb[o] = orc_sigmoid(acc);
+    }
+}
+
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* standalone entry points used by the unit tests */
+ORC_API void orc_field_sdf(const orc_field *f, const float *x, uint32_t B, float bound, float *out16)
+{
+    #pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) field_sdf(f, x + 3 * b, bound, out16 + 16 * b);
+}
+ORC_API void orc_field_color(const orc_field *f, const float *x, const float *n, const float *sdfout,
+                             uint32_t B, float *rgb)
+{
+    #pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++)
+        orc_color_mlp(f, x + 3 * b, n + 3 * b, sdfout + 16 * b, rgb + 3 * b);
+}
+ORC_API float orc_test_expf(float x) { return orc_expf(x); }
+ORC_API float orc_test_log1pf(float x) { return orc_log1pf(x); }
+ORC_API float orc_test_softplus100(float x) { return orc_softplus100(x); }
+ORC_API float orc_test_sigmoid(float x) { return orc_sigmoid(x); }
+
+/* ------------------------------------------------------------------ */
+/* per-ray scans                                                        */
+/* ------------------------------------------------------------------ */
+/* inclusive scan of x[0..m) in tiles of 16: Kogge-Stone inside a tile (pad = identity),
+ * sequential carry across tiles.  op: 0 = add, 1 = mul. */
+static void orc_tilescan(int op, const float *x, int m, float *out)
+{
+    float carry = 0.0f;
+    for (int t0 = 0; t0 < m; t0 += 16) {
+        float v[16], nv[16];
+        for (int i = 0; i < 16; i++) v[i] = (t0 + i < m) ? x[t0 + i] : (op ? 1.0f : 0.0f);
+        for (int off = 1; off < 16; off <<= 1) {
+            for (int i = 0; i < 16; i++)
+                nv[i] = (i >= off) ? (op ? v[i - off] * v[i] : v[i - off] + v[i]) : v[i];
+            memcpy(v, nv, sizeof v);
+        }
+        for (int i = 0; i < 16 && t0 + i < m; i++)
+            out[t0 + i] = (t0 == 0) ? v[i] : (op ? carry * v[i] : carry + v[i]);
+        carry = (t0 == 0) ? v[15] : (op ? carry * v[15] : carry + v[15]);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* NeRFRenderer.run (models/instant_nsr.py:133-299), render_can=True     */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_rays;
+    int32_t num_steps;        /* coarse samples T0: multiple of 16, 16..64  */
+    int32_t upsample_steps;   /* multiple of 16, T0+up <= 128 */
+    float bound;
+    float inv_s;              /* forward_variance(): exp(10*variance).clip(1e-6,1e6) */
+    float cos_anneal_ratio;
+    float fd_eps;             /* 0.005*(1-normal_epsilon_ratio) */
+    int32_t perturb;          /* training && perturb_overwrite: use noise[n, T0] */
+} orc_render_opts;
+
+typedef struct {
+    float *image;        /* [N,3] */
+    float *weights_sum;  /* [N]   */
+    float *depth;        /* [N]   */
+    float *normal_map;   /* [N,3] */
+    float *eik;          /* [N,2] per-ray (sum relax*err, sum relax) */
+    /* optional per-sample exports (NULL = skip), T = num_steps+upsample_steps */
+    float *z_vals;       /* [N,T] */
+    float *weights;      /* [N,T] */
+    float *alpha;        /* [N,T] */
+    float *color;        /* [N,T,3] */
+    float *sdf;          /* [N,T]  sdf at the final mid points */
+    float *gradient;     /* [N,T,3] FD gradient */
+    int32_t *ss_inds;    /* [N, up/16, 16] searchsorted indices of sample_pdf */
+    int32_t *sort_index; /* [N, up/16, 128] torch.sort permutation of cat_z_vals (pad -1) */
+} orc_render_out;
+
+#define ORC_MAXT 128
+
+/* sample_pdf(det=True) + up_sample (instant_nsr.py:21-55,410-459).  lin_u[16] is the
+ * host-made torch.linspace(0.5/16, 1-0.5/16, 16). */
+static void orc_up_sample(const float o[3], const float d[3], const float *z, const float *sdf, int n,
+                          float inv_s, const float *lin_u, float *znew, int32_t *inds_out)
+{
+    float radius[ORC_MAXT];
+    for (int i = 0; i < n; i++) {
+        float p0 = o[0] + d[0] * z[i], p1 = o[1] + d[1] * z[i], p2 = o[2] + d[2] * z[i];
+        radius[i] = sqrtf((p0 * p0 + p1 * p1) + p2 * p2);
+    }
+    int m = n - 1;
+    float alpha[ORC_MAXT], om[ORC_MAXT], cp[ORC_MAXT], w[ORC_MAXT];
+    float prev_cos = 0.0f;
+    for (int i = 0; i < m; i++) {
+        int inside = (radius[i] < 1.0f) | (radius[i + 1] < 1.0f);
+        float mid = (sdf[i] + sdf[i + 1]) * 0.5f;
+        float dist = z[i + 1] - z[i];
+        float cosv = (sdf[i + 1] - sdf[i]) / (dist + 1e-5f);
+        float cmin = prev_cos < cosv ? prev_cos : cosv;  /* torch.min over the stacked pair */
+        prev_cos = cosv;
+        cmin = clampf(cmin, -1e3f, 0.0f) * (inside ? 1.0f : 0.0f);
+        float half = cmin * dist * 0.5f;
+        float pe = mid - half, ne = mid + half;
+        float pc = orc_sigmoid(pe * inv_s), nc = orc_sigmoid(ne * inv_s);
+        alpha[i] = (pc - nc + 1e-5f) / (pc + 1e-5f);
+        om[i] = 1.0f - alpha[i] + 1e-7f;
+    }
+    orc_tilescan(1, om, m, cp);                      /* inclusive cumprod */
+    for (int i = 0; i < m; i++) w[i] = alpha[i] * (i == 0 ? 1.0f : cp[i - 1]) + 1e-5f;
+    float cs[ORC_MAXT];
+    orc_tilescan(0, w, m, cs);
+    float total = cs[m - 1];
+    float pdf[ORC_MAXT], cdf[ORC_MAXT];
+    for (int i = 0; i < m; i++) pdf[i] = w[i] / total;
+    orc_tilescan(0, pdf, m, cdf + 1);
+    cdf[0] = 0.0f;                                   /* n entries */
+    for (int j = 0; j < 16; j++) {
+        float u = lin_u[j];
+        int lo = 0, hi = n;                          /* searchsorted(right=True) */
+        while (lo < hi) { int md = (lo + hi) >> 1; if (cdf[md] <= u) lo = md + 1; else hi = md; }
+        int below = lo - 1 > 0 ? lo - 1 : 0;
+        int above = lo < n - 1 ? lo : n - 1;
+        float den = cdf[above] - cdf[below];
+        if (den < 1e-5f) den = 1.0f;
+        float t = (u - cdf[below]) / den;
+        znew[j] = z[below] + t * (z[above] - z[below]);
+        if (inds_out) inds_out[j] = lo;
+    }
+}
+
+/* cat_z_vals' torch.sort of cat([z, znew]) (instant_nsr.py:466-467), stable: position of
+ * every old / new element, and the permutation "index". */
+static void orc_merge(const float *z, int n, const float *znew, int *pos_old, int *pos_new)
+{
+    for (int i = 0; i < n; i++) {
+        int c = 0;
+        for (int j = 0; j < 16; j++) c += (znew[j] < z[i]);
+        pos_old[i] = i + c;
+    }
+    for (int j = 0; j < 16; j++) {
+        int lo = 0, hi = n;                          /* #old <= znew[j] (old is sorted) */
+        while (lo < hi) { int md = (lo + hi) >> 1; if (z[md] <= znew[j]) lo = md + 1; else hi = md; }
+        int c = 0;
+        for (int j2 = 0; j2 < 16; j2++)
+            c += (znew[j2] < znew[j]) || (znew[j2] == znew[j] && j2 < j);
+        pos_new[j] = lo + c;
+    }
+}
+
+static void render_one_ray(const orc_field *f, const orc_render_opts *op, const float *o, const float *d,
+                           const float *bg, const float *noise, const float *lin_z, const float *lin_u,
+                           int r, const orc_render_out *out)
+{
+    const float bound = op->bound;
+    const int T0 = op->num_steps, nup = op->upsample_steps / 16, T = T0 + 16 * nup;
+    /* near_far_from_bound, cube (instant_nsr.py:58-77) */
+    float near = -INFINITY, far = INFINITY;
+    for (int k = 0; k < 3; k++) {
+        float dd = d[k] + 1e-15f;
+        float tmin = (-bound - o[k]) / dd, tmax = (bound - o[k]) / dd;
+        float lo = tmin < tmax ? tmin : tmax, hi = tmin > tmax ? tmin : tmax;
+        if (k == 0 || lo > near) near = lo;
+        if (k == 0 || hi < far) far = hi;
+    }
+    if (near < 0.05f) near = 0.05f;
+    const float span = far - near;
+    const float sample_dist = span / (float)T0;      /* instant_nsr.py:160 */
+    float z[ORC_MAXT], sdf[ORC_MAXT];
+    for (int i = 0; i < T0; i++) {                   /* :155-162 */
+        float zi = near + span * lin_z[i];
+        if (op->perturb) zi = zi + (noise[i] - 0.5f) * sample_dist;
+        z[i] = zi;
+    }
+    int n = T0;
+    if (nup > 0) {
+        for (int i = 0; i < T0; i++) {               /* :165,173-180 */
+            float p[3], s16[16];
+            for (int k = 0; k < 3; k++) p[k] = clampf(o[k] + d[k] * z[i], -bound, bound);
+            field_sdf(f, p, bound, s16);
+            sdf[i] = s16[0];
+        }
+        for (int it = 0; it < nup; it++) {           /* :182-184 */
+            float znew[16], sdfnew[16];
+            float inv_s = (float)(64 << it);
+            orc_up_sample(o, d, z, sdf, n, inv_s, lin_u, znew,
+                          out->ss_inds ? out->ss_inds + ((size_t)r * nup + it) * 16 : NULL);
+            int last = (it + 1 == nup);
+            if (!last) {
+                for (int j = 0; j < 16; j++) {       /* cat_z_vals :464-469 */
+                    float p[3], s16[16];
+                    for (int k = 0; k < 3; k++) p[k] = clampf(o[k] + d[k] * znew[j], -bound, bound);
+                    field_sdf(f, p, bound, s16);
+                    sdfnew[j] = s16[0];
+                }
+            }
+            int pos_old[ORC_MAXT], pos_new[16];
+            orc_merge(z, n, znew, pos_old, pos_new);
+            float z2[ORC_MAXT], s2[ORC_MAXT];
+            for (int i = 0; i < n; i++) { z2[pos_old[i]] = z[i]; s2[pos_old[i]] = sdf[i]; }
+            for (int j = 0; j < 16; j++) { z2[pos_new[j]] = znew[j]; s2[pos_new[j]] = last ? 0.0f : sdfnew[j]; }
+            if (out->sort_index) {
+                int32_t *si = out->sort_index + ((size_t)r * nup + it) * 128;
+                for (int i = 0; i < 128; i++) si[i] = -1;
+                for (int i = 0; i < n; i++) si[pos_old[i]] = i;
+                for (int j = 0; j < 16; j++) si[pos_new[j]] = n + j;
+            }
+            n += 16;
+            memcpy(z, z2, n * sizeof(float));
+            memcpy(sdf, s2, n * sizeof(float));
+        }
+    }
+    /* render core :190-263 */
+    float alpha[ORC_MAXT], om[ORC_MAXT], cp[ORC_MAXT], wgt[ORC_MAXT];
+    float col[ORC_MAXT][3], nrm[ORC_MAXT][3], zn[ORC_MAXT], eerr[ORC_MAXT], erelax[ORC_MAXT];
+    const float car = op->cos_anneal_ratio, one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
+    const float eps = op->fd_eps;
+    for (int i = 0; i < T; i++) {
+        float delta = (i < T - 1) ? z[i + 1] - z[i] : sample_dist;
+        float zmid = (i < T - 1) ? z[i] + 0.5f * delta : z[i];
+        float p[3], s16[16], g[3];
+        for (int k = 0; k < 3; k++) p[k] = clampf(o[k] + d[k] * zmid, -bound, bound);
+        field_sdf(f, p, bound, s16);
+        for (int k = 0; k < 3; k++) {               /* FD normals :687-704 */
+            float q[3] = { p[0], p[1], p[2] }, sp[16], sn[16];
+            q[k] = clampf(p[k] + eps, -bound, bound);
+            field_sdf(f, q, bound, sp);
+            q[k] = clampf(p[k] + (-eps), -bound, bound);
+            field_sdf(f, q, bound, sn);
+            g[k] = 0.5f * (sp[0] - sn[0]) / eps;
+        }
+        float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+        float nn[3];
+        for (int k = 0; k < 3; k++) nn[k] = g[k] / (1e-5f + gn);        /* :215 */
+        orc_color_mlp(f, p, nn, s16, col[i]);                           /* :217 */
+        float tc = (d[0] * nn[0] + d[1] * nn[1]) + d[2] * nn[2];        /* :222 */
+        float a1 = orc_softplus100(-tc * 0.5f + 0.5f) * one_m_car;
+        float a2 = orc_softplus100(-tc) * car;
+        float iter_cos = -(a1 + a2);                                    /* :232-233 */
+        float half = iter_cos * delta * 0.5f;
+        float en = s16[0] + half, ep = s16[0] - half;                   /* :236-237 */
+        float pc = orc_sigmoid(ep * op->inv_s), nc = orc_sigmoid(en * op->inv_s);
+        alpha[i] = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f); /* :243 */
+        om[i] = 1.0f - alpha[i] + 1e-7f;
+        for (int k = 0; k < 3; k++) nrm[i][k] = nn[k];
+        zn[i] = clampf((z[i] - near) / span, 0.0f, 1.0f);               /* :262 */
+        float pn = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);    /* :266-272 */
+        erelax[i] = pn < 1.2f ? 1.0f : 0.0f;
+        eerr[i] = erelax[i] * ((gn - 1.0f) * (gn - 1.0f));
+        if (out->sdf) out->sdf[(size_t)r * T + i] = s16[0];
+        if (out->gradient) for (int k = 0; k < 3; k++) out->gradient[((size_t)r * T + i) * 3 + k] = g[k];
+    }
+    orc_tilescan(1, om, T, cp);
+    for (int i = 0; i < T; i++) wgt[i] = alpha[i] * (i == 0 ? 1.0f : cp[i - 1]);   /* :250 */
+    /* reductions: tile-scan sums (last element of the inclusive add scan) */
+    float tmp[ORC_MAXT], sc[ORC_MAXT];
+    orc_tilescan(0, wgt, T, sc); float wsum = sc[T - 1];
+    float img[3], nm[3];
+    for (int k = 0; k < 3; k++) {
+        for (int i = 0; i < T; i++) tmp[i] = col[i][k] * wgt[i];
+        orc_tilescan(0, tmp, T, sc); img[k] = sc[T - 1];
+        for (int i = 0; i < T; i++) tmp[i] = nrm[i][k] * wgt[i];
+        orc_tilescan(0, tmp, T, sc); nm[k] = sc[T - 1];
+    }
+    for (int i = 0; i < T; i++) tmp[i] = wgt[i] * zn[i];
+    orc_tilescan(0, tmp, T, sc); float depth = sc[T - 1];
+    orc_tilescan(0, eerr, T, sc); float e_num = sc[T - 1];
+    orc_tilescan(0, erelax, T, sc); float e_den = sc[T - 1];
+    for (int k = 0; k < 3; k++) {
+        float b = bg ? bg[k] : 1.0f;
+        out->image[(size_t)r * 3 + k] = img[k] + (1.0f - wsum) * b;    /* :294 */
+        out->normal_map[(size_t)r * 3 + k] = nm[k];
+    }
+    out->weights_sum[r] = wsum;
+    out->depth[r] = depth;
+    out->eik[2 * (size_t)r] = e_num; out->eik[2 * (size_t)r + 1] = e_den;
+    for (int i = 0; i < T; i++) {
+        if (out->z_vals) out->z_vals[(size_t)r * T + i] = z[i];
+        if (out->weights) out->weights[(size_t)r * T + i] = wgt[i];
+        if (out->alpha) out->alpha[(size_t)r * T + i] = alpha[i];
+        if (out->color) for (int k = 0; k < 3; k++) out->color[((size_t)r * T + i) * 3 + k] = col[i][k];
+    }
+}
+
+/* lin_z[T0] = torch.linspace(0,1,T0); lin_u[16] = torch.linspace(0.5/16, 1-0.5/16, 16)
+ * (made by the host exactly as the reference does, instant_nsr.py:155,34);
+ * bg may be NULL (bg_color = 1); noise [N,T0] U[0,1) only read when opts->perturb. */
+ORC_API int orc_render_rays(const orc_field *f, const orc_render_opts *op, const float *rays_o,
+                            const float *rays_d, const float *bg, const float *noise,
+                            const float *lin_z, const float *lin_u, const orc_render_out *out)
+{
+    if (op->num_steps % 16 || op->upsample_steps % 16 || op->num_steps < 16 ||
+        op->num_steps + op->upsample_steps > ORC_MAXT) return 1;
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t r = 0; r < (int64_t)op->n_rays; r++)
+        render_one_ray(f, op, rays_o + 3 * r, rays_d + 3 * r, bg ? bg + 3 * r : NULL,
+                       noise ? noise + (size_t)r * op->num_steps : NULL, lin_z, lin_u, (int)r, out);
+    return 0;
+}
+
+/* gradient_error (instant_nsr.py:272): fixed-order reduction of the per-ray partials:
+ * 1024 strided sequential partial sums, then a halving tree. */
+ORC_API float orc_eikonal_reduce(const float *eik, int32_t n_rays)
+{
+    float pn[1024], pd[1024];
+    for (int t = 0; t < 1024; t++) {
+        float a = 0.0f, b = 0.0f;
+        for (int r = t; r < n_rays; r += 1024) { a += eik[2 * r]; b += eik[2 * r + 1]; }
+        pn[t] = a; pd[t] = b;
+    }
+    for (int s = 512; s > 0; s >>= 1)
+        for (int t = 0; t < s; t++) { pn[t] += pn[t + s]; pd[t] += pd[t + s]; }
+    return pn[0] / (pd[0] + 1e-5f);
+}

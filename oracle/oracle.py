@@ -1,0 +1,301 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE: numpy/ctypes front end of the CPU oracle.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The product package (avatarcraft_amd) never does.  See ac_oracle.c for what each entry
+restates (reference file:line) and how the oracle is pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+u32p = C.POINTER(C.c_uint32)
+
+
+def build(force=False):
+    """Compile libac_oracle.so with the committed Makefile (gcc, seconds)."""
+    so = os.path.join(_HERE, "libac_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_math.h", "ac_sh_table.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "libac_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libac_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_pcg32_next_uint.restype = C.c_uint32
+        _LIB.orc_pcg32_next_float.restype = C.c_float
+        _LIB.orc_fast_hash.restype = C.c_uint32
+        _LIB.orc_grid_index.restype = C.c_uint32
+        _LIB.orc_eikonal_reduce.restype = C.c_float
+        for n in ("orc_test_expf", "orc_test_log1pf", "orc_test_softplus100", "orc_test_sigmoid"):
+            getattr(_LIB, n).restype = C.c_float
+            getattr(_LIB, n).argtypes = [C.c_float]
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=f32p):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+# ------------------------------------------------------------------ pcg32 / hash helpers
+class Pcg32:
+    def __init__(self, initstate, initseq=1):
+        self.st = (C.c_uint64 * 2)()
+        lib().orc_pcg32_seed(self.st, C.c_uint64(initstate), C.c_uint64(initseq))
+
+    def next_uint(self):
+        return int(lib().orc_pcg32_next_uint(self.st))
+
+    def next_float(self):
+        return float(lib().orc_pcg32_next_float(self.st))
+
+
+def fast_hash(pos):
+    a = (C.c_uint32 * len(pos))(*pos)
+    return int(lib().orc_fast_hash(a, C.c_uint32(len(pos))))
+
+
+def grid_index(D, Cc, ch, hashmap_size, resolution, pos):
+    a = (C.c_uint32 * len(pos))(*pos)
+    return int(lib().orc_grid_index(C.c_uint32(D), C.c_uint32(Cc), C.c_uint32(ch), C.c_uint32(hashmap_size),
+                                    C.c_uint32(resolution), a))
+
+
+def hash_level_table(L, S, H):
+    scale = np.zeros(L, np.float32)
+    res = np.zeros(L, np.uint32)
+    lib().orc_hash_level_table(C.c_uint32(L), C.c_float(S), C.c_uint32(H), _p(scale), _p(res, u32p))
+    return scale, res
+
+
+def hash_offsets(input_dim=3, num_levels=16, level_dim=2, per_level_scale=2.0, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None):
+    """HashEncoder.__init__ allocation rule (encoder/hashencoder/hashgrid.py:83-108)."""
+    if desired_resolution is not None:
+        per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+    offsets, offset = [], 0
+    max_params = 2 ** log2_hashmap_size
+    for i in range(num_levels):
+        resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+        offsets.append(offset)
+        offset += min(max_params, (resolution + 1) ** input_dim)
+    offsets.append(offset)
+    return np.array(offsets, dtype=np.int32), float(per_level_scale)
+
+
+# ------------------------------------------------------------------ hash encoder
+def hash_encode_forward(inputs, grid, offsets, S, H, calc_grad_inputs=False, want_corner_idx=False):
+    inputs = _f(inputs); grid = _f(grid); offsets = np.ascontiguousarray(offsets, np.int32)
+    B, D = inputs.shape
+    L = offsets.shape[0] - 1
+    Cc = grid.shape[1]
+    out = np.empty((L, B, Cc), np.float32)
+    dy_dx = np.empty((B, L * D * Cc), np.float32) if calc_grad_inputs else np.empty(1, np.float32)
+    cidx = np.empty((L, B, 1 << D), np.uint32) if want_corner_idx else None
+    rc = lib().orc_hash_encode_forward(_p(inputs), _p(grid), _p(offsets, i32p), _p(out), C.c_uint32(B), C.c_uint32(D),
+                                       C.c_uint32(Cc), C.c_uint32(L), C.c_float(S), C.c_uint32(H),
+                                       C.c_int(int(calc_grad_inputs)), _p(dy_dx), _p(cidx, u32p))
+    if rc:
+        raise RuntimeError("GridEncoding: unsupported D/C")
+    return out, (dy_dx if calc_grad_inputs else None), cidx
+
+
+def hash_encode_backward(grad, inputs, grid, offsets, S, H, dy_dx=None):
+    grad = _f(grad); inputs = _f(inputs); grid = _f(grid); offsets = np.ascontiguousarray(offsets, np.int32)
+    B, D = inputs.shape
+    L = offsets.shape[0] - 1
+    Cc = grid.shape[1]
+    gg = np.zeros_like(grid)
+    gi = np.zeros_like(inputs) if dy_dx is not None else np.zeros(1, np.float32)
+    dd = _f(dy_dx) if dy_dx is not None else np.zeros(1, np.float32)
+    rc = lib().orc_hash_encode_backward(_p(grad), _p(inputs), _p(grid), _p(offsets, i32p), _p(gg), C.c_uint32(B),
+                                        C.c_uint32(D), C.c_uint32(Cc), C.c_uint32(L), C.c_float(S), C.c_uint32(H),
+                                        C.c_int(int(dy_dx is not None)), _p(dd), _p(gi))
+    if rc:
+        raise RuntimeError("GridEncoding: unsupported D/C")
+    return gg, (gi if dy_dx is not None else None)
+
+
+# ------------------------------------------------------------------ SH
+def sh_encode_forward(inputs, degree, calc_grad_inputs=False):
+    inputs = _f(inputs)
+    B = inputs.shape[0]
+    out = np.empty((B, degree * degree), np.float32)
+    dy_dx = np.empty((B, 3 * degree * degree), np.float32) if calc_grad_inputs else np.empty(1, np.float32)
+    rc = lib().orc_sh_encode_forward(_p(inputs), _p(out), C.c_uint32(B), C.c_uint32(inputs.shape[1]), C.c_uint32(degree),
+                                     C.c_int(int(calc_grad_inputs)), _p(dy_dx))
+    if rc:
+        raise RuntimeError("SH encoder: unsupported input_dim/degree")
+    return out, (dy_dx if calc_grad_inputs else None)
+
+
+def sh_encode_backward(grad, inputs, degree, dy_dx):
+    grad = _f(grad); inputs = _f(inputs); dy_dx = _f(dy_dx)
+    gi = np.zeros_like(inputs)
+    lib().orc_sh_encode_backward(_p(grad), _p(inputs), C.c_uint32(inputs.shape[0]), C.c_uint32(3), C.c_uint32(degree),
+                                 _p(dy_dx), _p(gi))
+    return gi
+
+
+# ------------------------------------------------------------------ raymarching
+def march_rays_train(rays_o, rays_d, grid, mean_density, bound, M=None, perturb=0, counter=None):
+    rays_o = _f(rays_o).reshape(-1, 3); rays_d = _f(rays_d).reshape(-1, 3); grid = _f(grid)
+    N, H = rays_o.shape[0], grid.shape[0]
+    M = N * 1024 if M is None else M
+    xyzs = np.zeros((M, 3), np.float32); dirs = np.zeros((M, 3), np.float32); deltas = np.zeros(M, np.float32)
+    rays = np.zeros((N, 3), np.int32)
+    counter = np.zeros(2, np.int32) if counter is None else counter
+    lib().orc_march_rays_train(_p(rays_o), _p(rays_d), _p(grid), C.c_float(mean_density), C.c_int(0), C.c_float(bound),
+                               C.c_uint32(N), C.c_uint32(H), C.c_uint32(M), _p(xyzs), _p(dirs), _p(deltas),
+                               _p(rays, i32p), _p(counter, i32p), C.c_uint32(int(perturb)))
+    return xyzs, dirs, deltas, rays, counter
+
+
+def composite_rays_train_forward(sigmas, rgbs, deltas, rays, bound=1.0):
+    sigmas = _f(sigmas); rgbs = _f(rgbs); deltas = _f(deltas); rays = np.ascontiguousarray(rays, np.int32)
+    M, N = sigmas.shape[0], rays.shape[0]
+    ws = np.empty(N, np.float32); img = np.empty((N, 3), np.float32)
+    lib().orc_composite_rays_train_forward(_p(sigmas), _p(rgbs), _p(deltas), _p(rays, i32p), C.c_float(bound),
+                                           C.c_uint32(M), C.c_uint32(N), _p(ws), _p(img))
+    return ws, img
+
+
+def composite_rays_train_backward(grad_ws, grad_img, sigmas, rgbs, deltas, rays, ws, img, bound=1.0):
+    args = [_f(a) for a in (grad_ws, grad_img, sigmas, rgbs, deltas)]
+    rays = np.ascontiguousarray(rays, np.int32); ws = _f(ws); img = _f(img)
+    M, N = args[2].shape[0], rays.shape[0]
+    gs = np.zeros(M, np.float32); gc = np.zeros((M, 3), np.float32)
+    lib().orc_composite_rays_train_backward(_p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(args[4]),
+                                            _p(rays, i32p), _p(ws), _p(img), C.c_float(bound), C.c_uint32(M),
+                                            C.c_uint32(N), _p(gs), _p(gc))
+    return gs, gc
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, grid, mean_density, near, far, perturb=0):
+    rays_alive = np.ascontiguousarray(rays_alive, np.int32); rays_t = _f(rays_t)
+    rays_o = _f(rays_o).reshape(-1, 3); rays_d = _f(rays_d).reshape(-1, 3); grid = _f(grid); near = _f(near); far = _f(far)
+    M = n_alive * n_step
+    xyzs = np.zeros((M, 3), np.float32); dirs = np.zeros((M, 3), np.float32); deltas = np.zeros((M, 2), np.float32)
+    lib().orc_march_rays(C.c_uint32(n_alive), C.c_uint32(n_step), _p(rays_alive, i32p), _p(rays_t), _p(rays_o), _p(rays_d),
+                         C.c_float(bound), C.c_uint32(grid.shape[0]), _p(grid), C.c_float(mean_density), _p(near), _p(far),
+                         _p(xyzs), _p(dirs), _p(deltas), C.c_uint32(int(perturb)))
+    return xyzs, dirs, deltas
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, normals, deltas, weights, depth, image, normal_map):
+    """in place on rays_t, weights, depth, image, normal_map (float32 contiguous numpy arrays)"""
+    rays_alive = np.ascontiguousarray(rays_alive, np.int32)
+    lib().orc_composite_rays(C.c_uint32(n_alive), C.c_uint32(n_step), _p(rays_alive, i32p), _p(rays_t), _p(_f(sigmas)),
+                             _p(_f(rgbs)), _p(_f(normals)), _p(_f(deltas)), _p(weights), _p(depth), _p(image), _p(normal_map))
+
+
+def compact_rays(n_alive, rays_alive_old, rays_t_old):
+    rays_alive_old = np.ascontiguousarray(rays_alive_old, np.int32); rays_t_old = _f(rays_t_old)
+    ra = np.zeros_like(rays_alive_old); rt = np.zeros_like(rays_t_old); cnt = np.zeros(1, np.int32)
+    lib().orc_compact_rays(C.c_uint32(n_alive), _p(ra, i32p), _p(rays_alive_old, i32p), _p(rt), _p(rays_t_old), _p(cnt, i32p))
+    return ra, rt, int(cnt[0])
+
+
+# ------------------------------------------------------------------ Instant-NSR field + renderer
+class _Field(C.Structure):
+    _fields_ = [("table", f32p), ("offsets", i32p), ("scale", C.c_float * 16), ("res", C.c_uint32 * 16),
+                ("W1", f32p), ("b1", f32p), ("W2", f32p), ("b2", f32p), ("Wc1", f32p), ("Wc2", f32p), ("Wc3", f32p)]
+
+
+class _Opts(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("num_steps", C.c_int32), ("upsample_steps", C.c_int32), ("bound", C.c_float),
+                ("inv_s", C.c_float), ("cos_anneal_ratio", C.c_float), ("fd_eps", C.c_float), ("perturb", C.c_int32)]
+
+
+class _Out(C.Structure):
+    _fields_ = [("image", f32p), ("weights_sum", f32p), ("depth", f32p), ("normal_map", f32p), ("eik", f32p),
+                ("z_vals", f32p), ("weights", f32p), ("alpha", f32p), ("color", f32p), ("sdf", f32p),
+                ("gradient", f32p), ("ss_inds", i32p), ("sort_index", i32p)]
+
+
+class Field:
+    """Effective (weight-normed) parameters of the default NeRFNetwork (models/instant_nsr.py:478-591):
+    hash table [6119857,2] + offsets[17], W1[64,35], b1[64], W2[16,64], b2[16], Wc1[64,21], Wc2[64,64], Wc3[3,64]."""
+
+    def __init__(self, table, offsets, W1, b1, W2, b2, Wc1, Wc2, Wc3, per_level_scale, base_resolution=16):
+        self.arrs = dict(table=_f(table), W1=_f(W1), b1=_f(b1), W2=_f(W2), b2=_f(b2), Wc1=_f(Wc1), Wc2=_f(Wc2), Wc3=_f(Wc3))
+        self.offsets = np.ascontiguousarray(offsets, np.int32)
+        assert self.offsets.shape[0] == 17 and self.arrs["table"].shape[1] == 2
+        assert self.arrs["W1"].shape == (64, 35) and self.arrs["W2"].shape == (16, 64)
+        assert self.arrs["Wc1"].shape == (64, 21) and self.arrs["Wc2"].shape == (64, 64) and self.arrs["Wc3"].shape == (3, 64)
+        self.S = float(np.log2(per_level_scale))
+        self.H = int(base_resolution)
+        self.scale, self.res = hash_level_table(16, self.S, self.H)
+        s = _Field()
+        s.table = _p(self.arrs["table"]); s.offsets = _p(self.offsets, i32p)
+        for i in range(16):
+            s.scale[i] = float(self.scale[i]); s.res[i] = int(self.res[i])
+        for k in ("W1", "b1", "W2", "b2", "Wc1", "Wc2", "Wc3"):
+            setattr(s, k, _p(self.arrs[k]))
+        self.c = s
+
+    def sdf(self, x, bound):
+        x = _f(x).reshape(-1, 3)
+        out = np.empty((x.shape[0], 16), np.float32)
+        lib().orc_field_sdf(C.byref(self.c), _p(x), C.c_uint32(x.shape[0]), C.c_float(bound), _p(out))
+        return out
+
+    def color(self, x, n, sdfout):
+        x = _f(x).reshape(-1, 3); n = _f(n).reshape(-1, 3); sdfout = _f(sdfout).reshape(-1, 16)
+        out = np.empty((x.shape[0], 3), np.float32)
+        lib().orc_field_color(C.byref(self.c), _p(x), _p(n), _p(sdfout), C.c_uint32(x.shape[0]), _p(out))
+        return out
+
+
+def linspace_tables(num_steps):
+    """The two torch.linspace tables the renderer consumes (instant_nsr.py:155, :34), made by torch on
+    the CPU exactly as the reference makes them."""
+    import torch
+    lin_z = torch.linspace(0.0, 1.0, num_steps).numpy().astype(np.float32)
+    lin_u = torch.linspace(0. + 0.5 / 16, 1. - 0.5 / 16, steps=16).numpy().astype(np.float32)
+    return lin_z, lin_u
+
+
+def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=None, bg=None, noise=None,
+                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=True):
+    """NeRFRenderer.run (models/instant_nsr.py:133-299), render_can=True.  Returns a dict."""
+    rays_o = _f(rays_o).reshape(-1, 3); rays_d = _f(rays_d).reshape(-1, 3)
+    N = rays_o.shape[0]
+    T = num_steps + upsample_steps
+    nup = upsample_steps // 16
+    lin_z, lin_u = linspace_tables(num_steps)
+    op = _Opts(N, num_steps, upsample_steps, bound, float(inv_s), float(cos_anneal_ratio),
+               float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None))
+    res = dict(image=np.empty((N, 3), np.float32), weights_sum=np.empty(N, np.float32), depth=np.empty(N, np.float32),
+               normal_map=np.empty((N, 3), np.float32), eik=np.empty((N, 2), np.float32))
+    if extras:
+        res.update(z_vals=np.empty((N, T), np.float32), weights=np.empty((N, T), np.float32),
+                   alpha=np.empty((N, T), np.float32), color=np.empty((N, T, 3), np.float32),
+                   sdf=np.empty((N, T), np.float32), gradient=np.empty((N, T, 3), np.float32),
+                   ss_inds=np.empty((N, max(nup, 1), 16), np.int32), sort_index=np.empty((N, max(nup, 1), 128), np.int32))
+    o = _Out()
+    for k, v in res.items():
+        setattr(o, k, _p(v, i32p if v.dtype == np.int32 else f32p))
+    bgc = _f(bg).reshape(-1, 3) if bg is not None else None
+    nz = _f(noise).reshape(N, num_steps) if noise is not None else None
+    rc = lib().orc_render_rays(C.byref(field.c), C.byref(op), _p(rays_o), _p(rays_d), _p(bgc), _p(nz), _p(lin_z), _p(lin_u),
+                               C.byref(o))
+    if rc:
+        raise RuntimeError("render_rays: unsupported num_steps/upsample_steps")
+    res["gradient_error"] = float(lib().orc_eikonal_reduce(_p(res["eik"]), C.c_int32(N)))
+    return res

@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors of tests/golden/ by IMPORTING THE REFERENCE'S PYTHON in this
+container (it cannot travel to the GPU box; only the vectors do).
+
+    python tests/golden/make_golden.py [/root/reference]
+
+What is imported from the reference: models/instant_nsr.py (NeRFNetwork, NeRFRenderer.run,
+up_sample, sample_pdf, cat_z_vals, near_far_from_bound), encoder/ (HashEncoder python side,
+get_encoder, freq_encoder), utils/ray_utils.py.  What is NOT the reference: the three JIT-built
+CUDA extension back ends (`encoder.hashencoder.backend`, `encoder.shencoder.backend`,
+`raymarching.backend`) cannot be built here (no CUDA toolkit), so they are pre-seeded in
+sys.modules; the hash back end is served by oracle/ (the CPU restatement).  These goldens therefore
+pin everything in NeRFRenderer.run EXCEPT the hash-grid kernel itself, which is pinned by the
+known-answer values in tests/golden/kat.json.
+
+Large inputs are not stored: the hash table is regenerated from a numpy RandomState seed
+(np.random.RandomState is a frozen stream), see tests/common.py:make_table().
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+from oracle import oracle as O
+from tests.common import make_table, make_rays, smooth_level_amp, TABLE_SEED
+
+torch.set_num_threads(8)
+
+
+# ---------------------------------------------------------------- stubs for absent third-party modules
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+for name in ("mcubes", "trimesh", "igl"):
+    _stub(name)
+
+
+class _HashBackend:
+    """Stands in for the JIT-built `_hash_encoder` extension (encoder/hashencoder/backend.py)."""
+
+    @staticmethod
+    def hash_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx):
+        out, dd, _ = O.hash_encode_forward(inputs.detach().numpy(), embeddings.detach().numpy(), offsets.numpy(),
+                                           np.float32(S), H, calc_grad_inputs)
+        outputs.copy_(torch.from_numpy(out))
+        if calc_grad_inputs:
+            dy_dx.copy_(torch.from_numpy(dd))
+
+    @staticmethod
+    def hash_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs,
+                             dy_dx, grad_inputs):
+        gg, gi = O.hash_encode_backward(grad.numpy(), inputs.detach().numpy(), embeddings.detach().numpy(), offsets.numpy(),
+                                        np.float32(S), H, dy_dx.numpy() if calc_grad_inputs else None)
+        grad_embeddings.copy_(torch.from_numpy(gg))
+        if calc_grad_inputs:
+            grad_inputs.copy_(torch.from_numpy(gi))
+
+
+_stub("encoder.hashencoder.backend", _backend=_HashBackend)
+_stub("encoder.shencoder.backend", _backend=object())
+_stub("raymarching.backend", _backend=object())
+
+import models.instant_nsr as ref_nsr  # noqa: E402  (the reference)
+
+
+def build_reference_net():
+    """NeRFNetwork() with seed-0 init, then table/first-layer randomised so that all 16 levels matter
+    (with the stock geometric init the hash features get zero weight)."""
+    torch.manual_seed(0)
+    net = ref_nsr.NeRFNetwork()
+    rs = np.random.RandomState(1234)
+    with torch.no_grad():
+        scale, _ = O.hash_level_table(16, np.float32(np.log2(net.encoder.per_level_scale)), 16)
+        net.level_amp = smooth_level_amp(scale)
+        net.encoder.embeddings.copy_(torch.from_numpy(make_table(int(net.encoder.offsets[-1]), offsets=net.encoder.offsets.numpy(),
+                                                                  level_amp=net.level_amp)))
+        v = net.sdf_net[0].weight_v
+        v[:, 3:] = torch.from_numpy(rs.normal(0.0, 0.05, size=(64, 32)).astype(np.float32))
+        net.sdf_net[0].bias.copy_(torch.from_numpy(rs.normal(0.0, 0.05, size=64).astype(np.float32)))
+        net.sdf_net[1].bias.copy_(torch.from_numpy(rs.normal(0.0, 0.02, size=16).astype(np.float32)))
+        net.sdf_net[1].bias[0] = -0.45       # sphere-ish SDF: surface near r ~ 0.45
+        net.deviation_net.variance.fill_(0.3)
+    return net
+
+
+def effective_weights(net):
+    def wn(layer):
+        return torch._weight_norm(layer.weight_v, layer.weight_g, 0).detach().numpy().astype(np.float32)
+    return dict(W1=wn(net.sdf_net[0]), b1=net.sdf_net[0].bias.detach().numpy(), W2=wn(net.sdf_net[1]),
+                b2=net.sdf_net[1].bias.detach().numpy(), Wc1=wn(net.color_net[0]), Wc2=wn(net.color_net[1]),
+                Wc3=wn(net.color_net[2]))
+
+
+class Recorder:
+    """Records the outputs of torch.searchsorted / torch.sort made inside run()."""
+
+    def __init__(self):
+        self.ss, self.sort = [], []
+
+    def __enter__(self):
+        self._ss, self._sort = torch.searchsorted, torch.sort
+
+        def ss(*a, **k):
+            r = self._ss(*a, **k); self.ss.append(r.clone()); return r
+
+        def srt(*a, **k):
+            r = self._sort(*a, **k); self.sort.append(r[1].clone()); return r
+        torch.searchsorted, torch.sort = ss, srt
+        return self
+
+    def __exit__(self, *a):
+        torch.searchsorted, torch.sort = self._ss, self._sort
+
+
+def run_case(net, rays_o, rays_d, num_steps, upsample_steps, train, seed, bg):
+    N = rays_o.shape[0]
+    net.train(train)
+    noise = None
+    if train:
+        torch.manual_seed(seed)
+        noise = torch.rand(N, num_steps).numpy().copy()   # the same draw run() makes first (instant_nsr.py:162)
+        torch.manual_seed(seed)
+    with Recorder() as rec, torch.no_grad():
+        out = net.render(torch.from_numpy(rays_o)[None], torch.from_numpy(rays_d)[None], num_steps=num_steps, bound=1.6,
+                         upsample_steps=upsample_steps, staged=False, bg_color=torch.from_numpy(bg),
+                         cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=train)
+    nup = upsample_steps // 16
+    ss = np.stack([t.numpy() for t in rec.ss], 1).astype(np.int32) if nup else np.zeros((N, 0, 16), np.int32)
+    srt = np.full((N, max(nup, 1), 128), -1, np.int32)
+    for i, t in enumerate(rec.sort):
+        srt[:, i, :t.shape[1]] = t.numpy()
+    res = dict(rays_o=rays_o, rays_d=rays_d, bg=bg, image=out["rgb"][0].numpy(), weights_sum=out["weight_sum"][:, 0].numpy(),
+               depth=out["depth"][0].numpy(), normal_map=out["normal"].numpy(), weights=out["weights"].numpy(),
+               alpha=out["pts_alpha"].numpy(), color=out["pts_color"].numpy(), z_vals=out["z_vals"].numpy(),
+               gradient_error=np.float32(out["gradient_error"].item()), ss_inds=ss, sort_index=srt,
+               num_steps=np.int32(num_steps), upsample_steps=np.int32(upsample_steps), train=np.int32(train))
+    if noise is not None:
+        res["noise"] = noise
+    return res
+
+
+def main():
+    net = build_reference_net()
+    ew = effective_weights(net)
+    inv_s = float(net.forward_variance().item())
+    common = dict(table_seed=np.int64(TABLE_SEED), level_amp=net.level_amp, offsets=net.encoder.offsets.numpy(),
+                  per_level_scale=np.float64(net.encoder.per_level_scale), inv_s=np.float32(inv_s), **ew)
+    # raw g/v as the checkpoint stores them (state_dict parity of the host mirror)
+    for i, l in enumerate(net.sdf_net):
+        common[f"sdf_net.{i}.weight_g"] = l.weight_g.detach().numpy(); common[f"sdf_net.{i}.weight_v"] = l.weight_v.detach().numpy()
+        common[f"sdf_net.{i}.bias"] = l.bias.detach().numpy()
+    for i, l in enumerate(net.color_net):
+        common[f"color_net.{i}.weight_g"] = l.weight_g.detach().numpy(); common[f"color_net.{i}.weight_v"] = l.weight_v.detach().numpy()
+    common["deviation_net.variance"] = net.deviation_net.variance.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "nsr_params.npz"), **common)
+
+    rs = np.random.RandomState(7)
+    cases = {}
+    ro, rd = make_rays(8, 8, dist=1.7, f=6.25)                      # 64 rays through the object
+    bg = rs.uniform(0, 1, size=(ro.shape[0], 3)).astype(np.float32)
+    cases["eval_64_64"] = run_case(net, ro, rd, 64, 64, False, 0, bg)
+    cases["train_64_64"] = run_case(net, ro, rd, 64, 64, True, 42, bg)
+    ro2, rd2 = make_rays(6, 6, dist=1.8, f=4.0, jitter_seed=3)
+    bg2 = np.ones((ro2.shape[0], 3), np.float32)
+    cases["eval_32_32"] = run_case(net, ro2, rd2, 32, 32, False, 0, bg2)
+    cases["eval_64_0"] = run_case(net, ro2, rd2, 64, 0, False, 0, bg2)
+    for name, c in cases.items():
+        np.savez_compressed(os.path.join(HERE, f"run_{name}.npz"), **c)
+        print(name, "weights_sum min/mean/max", c["weights_sum"].min(), c["weights_sum"].mean(), c["weights_sum"].max(),
+              "eik", c["gradient_error"])
+
+    # forward_sdf / forward_color / gradient point-wise goldens (instant_nsr.py:627-704)
+    pts = rs.uniform(-1.6, 1.6, size=(257, 3)).astype(np.float32)
+    pts[0] = [1.6, -1.6, 1.6]; pts[1] = [0, 0, 0]
+    with torch.no_grad():
+        net.eval()
+        t = torch.from_numpy(pts)
+        sdf = net.forward_sdf(t, 1.6)
+        grad = net.gradient(t, 1.6, 0.005)
+        nrm = grad / (1e-5 + torch.linalg.norm(grad, ord=2, dim=-1, keepdim=True))
+        col = net.forward_color(t, None, nrm, sdf[:, 1:], 1.6)
+        enc = net.encoder(t, 1.6)
+    np.savez_compressed(os.path.join(HERE, "field_points.npz"), pts=pts, sdf=sdf.numpy(), gradient=grad.numpy(),
+                        normal=nrm.numpy(), color=col.numpy(), enc=enc.numpy())
+
+    # HashEncoder python-side facts (hashgrid.py:79-124): offsets, n_params, output_dim for a few configs
+    from encoder import get_encoder
+    facts = {}
+    for tag, cfg in {"default": dict(hash_num_levels=16, hash_level_dim=2, hash_per_level_scale=1.3819, hash_base_resolution=16,
+                                     hash_log2_hashmap_size=19, hash_desired_resolution=2048),
+                     "small": dict(hash_num_levels=8, hash_level_dim=4, hash_per_level_scale=2.0, hash_base_resolution=4,
+                                   hash_log2_hashmap_size=12, hash_desired_resolution=None)}.items():
+        enc_m, dim = get_encoder("hashgrid", dict(in_dim=3, **cfg))
+        facts[f"{tag}_offsets"] = enc_m.offsets.numpy(); facts[f"{tag}_dim"] = np.int32(dim)
+        facts[f"{tag}_pls"] = np.float64(enc_m.per_level_scale); facts[f"{tag}_nparams"] = np.int64(int(enc_m.n_params))
+    fe, fdim = get_encoder("frequency", dict(in_dim=3, freq_multires=6))
+    x = torch.from_numpy(pts[:16])
+    facts["freq_in"] = pts[:16]; facts["freq_out"] = fe(x).numpy(); facts["freq_dim"] = np.int32(fdim)
+    np.savez_compressed(os.path.join(HERE, "encoder_facts.npz"), **facts)
+    print("n_params", sum(p.numel() for p in net.parameters()))
+
+
+if __name__ == "__main__":
+    main()
+
+
+# ---------------------------------------------------------------- ray generation goldens
+def make_ray_goldens():
+    """Rays from the reference's own camera code: default_360_path -> pose2cap -> shot_rays
+    (utils/render_utils.py:137-154,323-337,363-376; utils/ray_utils.py:25-37), and
+    SMPLDataset.gen_rays_pose's formula is exercised in a separate golden."""
+    import numpy
+    for name in ("pytorch3d", "pytorch3d.structures", "pytorch3d.renderer", "open3d", "cv2", "torchvision", "torchvision.transforms",
+                 "imageio", "lpips", "prompt_toolkit"):
+        if name not in sys.modules:
+            _stub(name)
+    sys.modules["pytorch3d.structures"].Meshes = object
+    for n in ("RasterizationSettings", "MeshRenderer", "MeshRasterizer", "HardPhongShader", "PointLights", "TexturesVertex",
+              "PerspectiveCameras"):
+        setattr(sys.modules["pytorch3d.renderer"], n, object)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    # numpy>=2 rejects np.array(copy=False) used by geometry/transformations.py:1846
+    import geometry.transformations as T
+
+    class _NP:
+        def __getattr__(self, k):
+            return getattr(numpy, k)
+
+        @staticmethod
+        def array(*a, **k):
+            if k.get("copy", True) is False:
+                k.pop("copy"); return numpy.asarray(*a, **k)
+            return numpy.array(*a, **k)
+    T.numpy = _NP()
+    try:
+        import utils.render_utils as RU
+    except Exception as e:   # pragma: no cover
+        print("render_utils import failed:", repr(e)); raise
+    import utils.ray_utils as RY
+    out = {}
+    poses, _ = RU.default_360_path(np.array([0, 0, 0]), np.array([0, 1, 0]), 1.44, 100)
+    cap = RU.pose2cap([64, 64], poses[0])
+    coords = np.argwhere(np.ones(cap.shape))[:, ::-1]
+    o, d = RY.shot_rays(cap, coords)
+    out["kat64_o"], out["kat64_d"] = o.astype(np.float32), d.astype(np.float32)
+    # config 2: 256x256, dist 1.7 (render_canonical.py:34), poses 0 and 17; keep every 16th pixel of the 256^2 grid
+    poses, _ = RU.default_360_path(np.array([0, 0, 0]), np.array([0, 1, 0]), 1.7, 60)
+    for pi in (0, 17):
+        cap = RU.pose2cap([256, 256], poses[pi])
+        coords = np.argwhere(np.ones(cap.shape))[:, ::-1]
+        o, d = RY.shot_rays(cap, coords)
+        out[f"can256_p{pi}_o"] = o.astype(np.float32)[::16]; out[f"can256_p{pi}_d"] = d.astype(np.float32)[::16]
+        out[f"can256_p{pi}_c2w"] = poses[pi].camera_to_world
+    np.savez_compressed(os.path.join(HERE, "rays.npz"), **out)
+    print("rays: centre d", out["kat64_d"][2080], "corner", out["kat64_d"][0], "o", out["kat64_o"][0])
+
+
+if __name__ == "__main__":
+    make_ray_goldens()
