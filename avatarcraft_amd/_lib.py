@@ -1,0 +1,105 @@
+"""ctypes binding of libavatarcraft_hip.so (the C ABI declared in include/avatarcraft_hip.h).
+
+This is the only place where Python touches the native library.  It fails LOUDLY when the
+library is missing or cannot be loaded: there is no CPU / eager fallback for the hot path.
+PyTorch is used by the callers for device memory and streams only; nothing here takes torch
+types -- pointers are plain integers (tensor.data_ptr()).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavatarcraft_hip.so")
+
+_lib = None
+
+vp = C.c_void_p
+u32 = C.c_uint32
+i32 = C.c_int32
+f32 = C.c_float
+
+
+class ac_field(C.Structure):
+    _fields_ = [("table", vp), ("offsets", i32 * 17), ("S", f32), ("H", u32),
+                ("W1", vp), ("b1", vp), ("W2", vp), ("b2", vp), ("Wc1", vp), ("Wc2", vp), ("Wc3", vp)]
+
+
+class ac_render_opts(C.Structure):
+    _fields_ = [("n_rays", i32), ("num_steps", i32), ("upsample_steps", i32), ("bound", f32), ("inv_s", f32),
+                ("cos_anneal_ratio", f32), ("fd_eps", f32), ("perturb", i32)]
+
+
+class ac_render_out(C.Structure):
+    _fields_ = [("image", vp), ("weights_sum", vp), ("depth", vp), ("normal_map", vp), ("eik", vp), ("z_vals", vp),
+                ("weights", vp), ("alpha", vp), ("color", vp), ("sdf", vp), ("gradient", vp), ("ss_inds", vp),
+                ("sort_index", vp)]
+
+
+_SIGS = {
+    "ac_version": ([], C.c_int),
+    "ac_last_error": ([], C.c_char_p),
+    "ac_hash_level_table": ([u32, f32, u32, vp, vp], None),
+    "ac_hash_encode_forward": ([vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp], C.c_int),
+    "ac_hash_encode_backward": ([vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp, vp], C.c_int),
+    "ac_hash_corner_indices": ([vp, vp, vp, u32, u32, u32, f32, u32, vp], C.c_int),
+    "ac_sh_encode_forward": ([vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
+    "ac_sh_encode_backward": ([vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),
+    "ac_march_rays_train": ([vp, vp, vp, f32, C.c_int, f32, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, vp], C.c_int),
+    "ac_composite_rays_train_forward": ([vp, vp, vp, vp, f32, u32, u32, vp, vp, vp], C.c_int),
+    "ac_composite_rays_train_backward": ([vp, vp, vp, vp, vp, vp, vp, vp, f32, u32, u32, vp, vp, vp], C.c_int),
+    "ac_march_rays": ([u32, u32, vp, vp, vp, vp, f32, u32, vp, f32, vp, vp, vp, vp, vp, u32, vp], C.c_int),
+    "ac_composite_rays": ([u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
+    "ac_compact_rays": ([u32, vp, vp, vp, vp, vp, vp, vp], C.c_int),
+    "ac_render_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_render_out), vp], C.c_int),
+    "ac_eikonal_reduce": ([vp, i32, vp, vp], C.c_int),
+    "ac_field_sdf": ([C.POINTER(ac_field), vp, u32, f32, vp, vp], C.c_int),
+    "ac_field_color": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """The loaded library.  Raises RuntimeError (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"avatarcraft_amd: native library {LIB_PATH} is missing. Build it with "
+                f"`python -m avatarcraft_amd.build` (hipcc, gfx950). There is no CPU fallback for the hot path.")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RuntimeError(f"avatarcraft_amd: cannot load {LIB_PATH}: {e}") from e
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
+            fn.argtypes = args
+            fn.restype = res
+        if handle.ac_version() != 1:
+            raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    """Map a non-zero status to the RuntimeError the reference's TORCH_CHECK / std::runtime_error gives."""
+    if rc != 0:
+        msg = lib().ac_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg}" if what else msg)
+
+
+def ptr(t):
+    """device (or host) address of a torch tensor / None"""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("must be a CUDA tensor")      # reference: CHECK_CUDA
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("must be a contiguous tensor")  # reference: CHECK_CONTIGUOUS

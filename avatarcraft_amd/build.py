@@ -1,0 +1,71 @@
+"""Build libavatarcraft_hip.so for gfx950 with hipcc (in-tree, no JIT-on-import).
+
+    python -m avatarcraft_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Flags that are part of the numerics contract:
+  -ffp-contract=off   every fused multiply-add in the kernels is an explicit fma
+  (no -ffast-math; fp32 divide / sqrt stay correctly rounded, denormals are kept)
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libavatarcraft_hip.so")
+SOURCES = ["ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+         "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "avatarcraft_hip.h"))
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(bdir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}")
+        return r.stdout
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(bdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}")
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

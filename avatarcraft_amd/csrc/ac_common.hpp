@@ -1,0 +1,57 @@
+// avatarcraft_amd/csrc/ac_common.hpp -- host-side plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+#include "../../include/avatarcraft_hip.h"
+
+#define AC_API extern "C" __attribute__((visibility("default")))
+
+namespace ac {
+
+void set_error(const char *fmt, ...);   // defined in ac_capi.hip
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(e)); return AC_ERR_LAUNCH; }
+    return AC_OK;
+}
+
+// Per-level launch constants of the multiresolution hash grid (hashencoder.cu:121-123 and
+// get_grid_index :54-70), computed once on the host so that CPU oracle and GPU see the same
+// fp32 scale (level 15 of the default model sits exactly on scale = 2047).
+struct LevelTable {
+    uint32_t L;
+    uint32_t offset[AC_MAX_LEVELS];   // entries
+    uint32_t size[AC_MAX_LEVELS];     // hashmap_size
+    uint32_t res[AC_MAX_LEVELS];      // resolution
+    uint32_t stride1[AC_MAX_LEVELS];  // (res+1)
+    uint32_t hashed[AC_MAX_LEVELS];   // 1: fast_hash, 0: dense
+    uint32_t pow2mask[AC_MAX_LEVELS]; // size-1 if size is a power of two else 0
+    float scale[AC_MAX_LEVELS];
+};
+
+inline float exp2_f32(float e) { return (float)exp2((double)e); }   // correctly rounded 2^e
+
+inline void make_level_table(LevelTable &t, uint32_t L, uint32_t D, float S, uint32_t H, const int32_t *offsets_host)
+{
+    t.L = L;
+    for (uint32_t l = 0; l < L; ++l) {
+        float sc = exp2_f32((float)l * S) * (float)H - 1.0f;
+        uint32_t res = (uint32_t)ceilf(sc) + 1u;
+        t.scale[l] = sc; t.res[l] = res; t.stride1[l] = res + 1u;
+        uint32_t size = offsets_host ? (uint32_t)(offsets_host[l + 1] - offsets_host[l]) : 0u;
+        t.offset[l] = offsets_host ? (uint32_t)offsets_host[l] : 0u;
+        t.size[l] = size;
+        // same early-exit stride walk as get_grid_index (uint32 arithmetic)
+        uint32_t stride = 1;
+        for (uint32_t d = 0; d < D && stride <= size; d++) stride *= (res + 1u);
+        t.hashed[l] = stride > size ? 1u : 0u;
+        t.pow2mask[l] = (size && (size & (size - 1u)) == 0u) ? size - 1u : 0u;
+    }
+}
+
+}  // namespace ac

@@ -1,0 +1,92 @@
+// avatarcraft_amd/csrc/ac_devmath.hpp -- device-side fp32 helpers for the gfx950 kernels.
+//
+// The hot path promises results that are bit-identical to a scalar CPU evaluation of the same
+// arithmetic (DESIGN.md "Numerics contract"): every operation below is an IEEE-754 correctly
+// rounded +,-,*,/ or an explicit fma, plus integer bit manipulation.  No ocml transcendental is
+// used on the parity-critical path because their rounding is not specified.
+//   dv_exp   : Cody-Waite reduction by ln2 (hi/lo split) + degree-6 polynomial (Cephes expf
+//              coefficients), scaled by two exact powers of two.
+//   dv_log1p : fdlibm log1pf scheme (FreeBSD msun s_log1pf.c constants; "Copyright (C) 1993 by
+//              Sun Microsystems, Inc. ... Permission to use, copy, modify, and distribute this
+//              software is freely granted, provided that this notice is preserved.").
+// Build flags required: -ffp-contract=off (no implicit contraction), default correctly rounded
+// fp32 divide/sqrt (do NOT pass -ffast-math / -fno-hip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace acdev {
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float bits2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2bits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ float dv_exp(float x)
+{
+    if (x > 88.72283f) return __builtin_inff();
+    if (!(x >= -87.33654f)) return (x != x) ? x : 0.0f;
+    const float magic = 12582912.0f;                    // 1.5 * 2^23: round-to-nearest-integer trick
+    float t = fma_(x, 1.44269504f, magic);
+    float n = t - magic;
+    float r = fma_(n, -0.693359375f, x);
+    r = fma_(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float e = fma_(p, r2, r) + 1.0f;
+    int ni = (int)n;
+    int n1 = ni >> 1;
+    int n2 = ni - n1;
+    float s1 = bits2f((uint32_t)(n1 + 127) << 23);
+    float s2 = bits2f((uint32_t)(n2 + 127) << 23);
+    return (e * s1) * s2;
+}
+
+__device__ __forceinline__ float dv_log1p(float x)
+{
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
+    if (!(x > -1.0f)) return (x == -1.0f) ? -__builtin_inff() : __builtin_nanf("");
+    if (__builtin_fabsf(x) < 5.9604645e-08f) return x;
+    if (x == __builtin_inff()) return x;
+    float u = 1.0f + x;
+    uint32_t iu = f2bits(u);
+    iu += 0x3f800000u - 0x3f3504f3u;
+    int k = (int)(iu >> 23) - 127;
+    float c;
+    if (k < 25) {
+        c = (k >= 2) ? 1.0f - (u - x) : x - (u - 1.0f);
+        c = c / u;
+    } else {
+        c = 0.0f;
+    }
+    iu = (iu & 0x007fffffu) + 0x3f3504f3u;
+    float f = bits2f(iu) - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * fma_(w, Lg4, Lg2);
+    float t2 = z * fma_(w, Lg3, Lg1);
+    float R = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float dk = (float)k;
+    return fma_(s, hfsq + R, fma_(dk, ln2_lo, c)) - hfsq + f + dk * ln2_hi;
+}
+
+// torch.nn.Softplus(beta=100): reference models/instant_nsr.py:231,591
+__device__ __forceinline__ float dv_softplus100(float x)
+{
+    float t = x * 100.0f;
+    if (t > 20.0f) return x;
+    return dv_log1p(dv_exp(t)) / 100.0f;
+}
+
+// torch.sigmoid
+__device__ __forceinline__ float dv_sigmoid(float x) { return 1.0f / (1.0f + dv_exp(-x)); }
+
+}  // namespace acdev

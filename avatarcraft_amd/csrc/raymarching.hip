@@ -1,0 +1,398 @@
+// avatarcraft_amd/csrc/raymarching.hip -- occupancy-grid ray marcher + packed-sample compositor for gfx950.
+//
+// Replaces the reference's `_raymarching` extension (raymarching/src/raymarching.cu):
+//   kernel_march_rays_train (:56-222)                -> march_count_kernel + scan + march_write_kernel
+//   kernel_composite_rays_train_forward (:232-301)   -> composite_train_fwd_kernel
+//   kernel_composite_rays_train_backward (:315-391)  -> composite_train_bwd_kernel
+//   kernel_march_rays (:497-599)                     -> march_rays_kernel
+//   kernel_composite_rays (:611-707)                 -> composite_rays_kernel
+//   kernel_compact_rays (:730-747)                   -> flags + scan + compact_scatter_kernel
+//
+// Differences by design (MI355X-first, and required for reproducibility):
+//   * the reference reserves output slots with atomicAdd(counter, num_steps) from inside the ray loop,
+//     which makes the packed layout run-dependent.  Here pass 1 only counts, a single-workgroup
+//     exclusive scan (wave64 DPP scan + LDS carry) turns counts into offsets IN RAY ORDER, pass 2
+//     writes.  rays[N,3] = (id, offset, n_steps) is therefore bit-reproducible and equal to the
+//     serial order (the order of the SURVEY A.4 known answers).  Same for compact_rays.
+//   * arithmetic follows the reference without fma contraction (the A.4 KATs were produced that way;
+//     build flag -ffp-contract=off), the `0.5 *` voxel conversion is evaluated in double like the
+//     reference's double literal.
+#include "ac_common.hpp"
+#include "ac_devmath.hpp"
+
+using namespace acdev;
+
+namespace {
+
+constexpr int RM_MAX_STEPS = 1024;
+constexpr float RM_SQRT3 = 1.73205080757f;
+constexpr float RM_MIN_NEAR = 0.05f;
+
+__device__ __forceinline__ float rm_clamp(float x, float lo, float hi) { return __builtin_fminf(hi, __builtin_fmaxf(lo, x)); }
+__device__ __forceinline__ float rm_sign(float x) { return __builtin_copysignf(1.0f, x); }
+
+struct RayCtx {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, bound, rbound, dt_min, dt_max, dt_gamma, thresh;
+    uint32_t H;
+    const float *grid;
+};
+
+__device__ __forceinline__ void rm_setup(RayCtx &c, const float *o, const float *d, const float *grid, float mean_density,
+                                         float bound, uint32_t H)
+{
+    c.ox = o[0]; c.oy = o[1]; c.oz = o[2]; c.dx = d[0]; c.dy = d[1]; c.dz = d[2];
+    c.rdx = 1 / c.dx; c.rdy = 1 / c.dy; c.rdz = 1 / c.dz;
+    c.bound = bound; c.rbound = 1 / bound; c.H = H; c.grid = grid;
+    c.dt_min = (2 * RM_SQRT3 / RM_MAX_STEPS) * bound;
+    c.dt_max = 2 * bound / (float)(H - 1);
+    c.dt_gamma = bound > 1 ? (1.f / 256.f) : 0.0f;
+    c.thresh = __builtin_fminf(10.0f, mean_density);
+}
+__device__ __forceinline__ float rm_density(const RayCtx &c, float t, float &x, float &y, float &z, int &nx, int &ny, int &nz)
+{
+    x = rm_clamp(c.ox + t * c.dx, -c.bound, c.bound);
+    y = rm_clamp(c.oy + t * c.dy, -c.bound, c.bound);
+    z = rm_clamp(c.oz + t * c.dz, -c.bound, c.bound);
+    const float hm1 = (float)(c.H - 1);
+    nx = (int)rm_clamp((float)(0.5 * (double)(x * c.rbound + 1) * (double)c.H), 0.0f, hm1);
+    ny = (int)rm_clamp((float)(0.5 * (double)(y * c.rbound + 1) * (double)c.H), 0.0f, hm1);
+    nz = (int)rm_clamp((float)(0.5 * (double)(z * c.rbound + 1) * (double)c.H), 0.0f, hm1);
+    return c.grid[(uint32_t)nx * c.H * c.H + (uint32_t)ny * c.H + (uint32_t)nz];
+}
+__device__ __forceinline__ float rm_skip(const RayCtx &c, float t, float x, float y, float z, int nx, int ny, int nz)
+{
+    const float hm1 = (float)(c.H - 1);
+    const float tx = (((nx + 0.5f + 0.5f * rm_sign(c.dx)) / hm1 * 2 - 1) * c.bound - x) * c.rdx;
+    const float ty = (((ny + 0.5f + 0.5f * rm_sign(c.dy)) / hm1 * 2 - 1) * c.bound - y) * c.rdy;
+    const float tz = (((nz + 0.5f + 0.5f * rm_sign(c.dz)) / hm1 * 2 - 1) * c.bound - z) * c.rdz;
+    const float tt = t + __builtin_fmaxf(0.0f, __builtin_fminf(tx, __builtin_fminf(ty, tz)));
+    do { t += rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max); } while (t < tt);
+    return t;
+}
+__device__ __forceinline__ void rm_near_far(const RayCtx &c, float &near, float &far)
+{
+    float nx = (-c.bound - c.ox) * c.rdx, fx = (c.bound - c.ox) * c.rdx;
+    if (nx > fx) { float s = nx; nx = fx; fx = s; }
+    float ny = (-c.bound - c.oy) * c.rdy, fy = (c.bound - c.oy) * c.rdy;
+    if (ny > fy) { float s = ny; ny = fy; fy = s; }
+    float nz = (-c.bound - c.oz) * c.rdz, fz = (c.bound - c.oz) * c.rdz;
+    if (nz > fz) { float s = nz; nz = fz; fz = s; }
+    near = __builtin_fmaxf(__builtin_fmaxf(nx, __builtin_fmaxf(ny, nz)), RM_MIN_NEAR);
+    far = __builtin_fminf(fx, __builtin_fminf(fy, fz));
+}
+
+// pcg32(initstate, initseq).next_float()   (raymarching/src/pcg32.h:57-72,107-116)
+__device__ __forceinline__ uint32_t pcg_next(uint64_t &state, uint64_t inc)
+{
+    const uint64_t old = state;
+    state = old * 0x5851f42d4c957f2dULL + inc;
+    const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+}
+__device__ __forceinline__ float pcg_first_float(uint64_t initstate, uint64_t initseq)
+{
+    uint64_t state = 0u; const uint64_t inc = (initseq << 1u) | 1u;
+    pcg_next(state, inc); state += initstate; pcg_next(state, inc);
+    return __uint_as_float((pcg_next(state, inc) >> 9) | 0x3f800000u) - 1.0f;
+}
+
+__device__ __forceinline__ float ray_t0(const RayCtx &c, float near, uint32_t n, uint32_t perturb)
+{
+    float t0 = near;
+    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1);
+    return t0;
+}
+
+// pass 1: number of occupied steps per ray
+__global__ __launch_bounds__(256) void march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                          const float *__restrict__ grid, float mean_density, float bound,
+                                                          uint32_t N, uint32_t H, uint32_t perturb, int32_t *__restrict__ counts)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    RayCtx c; rm_setup(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, mean_density, bound, H);
+    float near, far; rm_near_far(c, near, far);
+    float t = ray_t0(c, near, n, perturb);
+    uint32_t num_steps = 0; float x, y, z; int nx, ny, nz;
+    while (t < far && num_steps < RM_MAX_STEPS) {
+        const float den = rm_density(c, t, x, y, z, nx, ny, nz);
+        if (den > c.thresh) { num_steps++; t += rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max); }
+        else t = rm_skip(c, t, x, y, z, nx, ny, nz);
+    }
+    counts[n] = (int32_t)num_steps;
+}
+
+// single-workgroup exclusive scan of vals[0..n) (in place) starting at base[0]; then base[0] += total,
+// base[1] += add1 (if base1_add >= 0).  1024 threads, sequential chunk per thread + LDS tree.
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(int32_t *__restrict__ vals, uint32_t n, int32_t *__restrict__ base,
+                                                              int32_t base1_add)
+{
+    __shared__ int32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t b0 = t * per, b1 = (b0 + per < n) ? b0 + per : n;
+    int32_t s = 0;
+    for (uint32_t i = b0; i < b1; ++i) s += vals[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan of the partials
+        int32_t v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int32_t start = base[0];
+    int32_t run = start + ((t == 0) ? 0 : part[t - 1]);
+    for (uint32_t i = b0; i < b1; ++i) { const int32_t v = vals[i]; vals[i] = run; run += v; }
+    __syncthreads();
+    if (t == 0) { base[0] = start + part[1023]; if (base1_add >= 0) base[1] += base1_add; }
+}
+
+// pass 2: write samples at the scanned offsets
+__global__ __launch_bounds__(256) void march_write_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                          const float *__restrict__ grid, float mean_density, float bound,
+                                                          uint32_t N, uint32_t H, uint32_t M, uint32_t perturb,
+                                                          const int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
+                                                          const int32_t *__restrict__ ray_base, float *__restrict__ xyzs, float *__restrict__ dirs,
+                                                          float *__restrict__ deltas, int32_t *__restrict__ rays)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t num_steps = (uint32_t)counts[n], point_index = (uint32_t)offsets[n], ray_index = (uint32_t)ray_base[0] + n;
+    rays[ray_index * 3] = (int32_t)n; rays[ray_index * 3 + 1] = (int32_t)point_index; rays[ray_index * 3 + 2] = (int32_t)num_steps;
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= M) return;
+    RayCtx c; rm_setup(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, mean_density, bound, H);
+    float near, far; rm_near_far(c, near, far);
+    float t = ray_t0(c, near, n, perturb);
+    float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3, *pt = deltas + point_index;
+    uint32_t step = 0; float x, y, z; int nx, ny, nz;
+    while (t < far && step < num_steps) {
+        const float den = rm_density(c, t, x, y, z, nx, ny, nz);
+        if (den > c.thresh) {
+            px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+            const float dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+            t += dt; pt[0] = dt; px += 3; pd += 3; pt++; step++;
+        } else t = rm_skip(c, t, x, y, z, nx, ny, nz);
+    }
+}
+
+__global__ __launch_bounds__(256) void composite_train_fwd_kernel(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                                  const int32_t *__restrict__ rays, uint32_t M, uint32_t N,
+                                                                  float *__restrict__ weights_sum, float *__restrict__ image)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps >= M) {
+        weights_sum[index] = 0; image[index * 3] = 0; image[index * 3 + 1] = 0; image[index * 3 + 2] = 0;
+        return;
+    }
+    const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3;
+    float T = 1.0f, r = 0, g = 0, b = 0;
+    for (uint32_t step = 0; step < num_steps; ++step) {
+        if (T < 1e-4f) break;
+        const float alpha = s[step], w = alpha * T;
+        r += w * c[3 * step]; g += w * c[3 * step + 1]; b += w * c[3 * step + 2];
+        T *= 1.0f - alpha;
+    }
+    weights_sum[index] = 1.0f - T;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+__global__ __launch_bounds__(256) void composite_train_bwd_kernel(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad,
+                                                                  const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                                  const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                                                  const float *__restrict__ weights_sum, const float *__restrict__ image,
+                                                                  uint32_t M, uint32_t N, float *__restrict__ grad_sigmas,
+                                                                  float *__restrict__ grad_rgbs)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps >= M) return;
+    const float gws = grad_weights_sum[index];
+    const float g0 = grad[(size_t)index * 3], g1 = grad[(size_t)index * 3 + 1], g2 = grad[(size_t)index * 3 + 2];
+    const float rf = image[index * 3], gf = image[index * 3 + 1], bf = image[index * 3 + 2], Tf = 1 - weights_sum[index];
+    const float *s = sigmas + offset, *c = rgbs + (size_t)offset * 3, *dl = deltas + offset;
+    float *gs = grad_sigmas + offset, *gc = grad_rgbs + (size_t)offset * 3;
+    float T = 1.0f, r = 0, g = 0, b = 0;
+    for (uint32_t step = 0; step < num_steps; ++step) {
+        const float alpha = s[step], w = alpha * T;
+        r += w * c[3 * step]; g += w * c[3 * step + 1]; b += w * c[3 * step + 2];
+        T *= 1.0f - alpha;
+        gc[3 * step] = g0 * w; gc[3 * step + 1] = g1 * w; gc[3 * step + 2] = g2 * w;
+        const float a0 = g0 * (T * c[3 * step] - (rf - r));
+        const float a1 = g1 * (T * c[3 * step + 1] - (gf - g));
+        const float a2 = g2 * (T * c[3 * step + 2] - (bf - b));
+        gs[step] = dl[step] * (((a0 + a1) + a2) + gws * Tf);
+    }
+}
+
+__global__ __launch_bounds__(256) void march_rays_kernel(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                                                         const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                                         const float *__restrict__ rays_d, float bound, uint32_t H,
+                                                         const float *__restrict__ grid, float mean_density,
+                                                         const float *__restrict__ fars, float *__restrict__ xyzs,
+                                                         float *__restrict__ dirs, float *__restrict__ deltas, uint32_t perturb)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    float t = rays_t[n];
+    RayCtx c; rm_setup(c, rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, grid, mean_density, bound, H);
+    const float far = fars[index];
+    float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pt = deltas + (size_t)n * n_step * 2;
+    if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
+    float last_t = t; uint32_t step = 0; float x, y, z; int nx, ny, nz;
+    while (t < far && step < n_step) {
+        const float den = rm_density(c, t, x, y, z, nx, ny, nz);
+        if (den > c.thresh) {
+            px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+            const float dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+            t += dt; pt[0] = dt; pt[1] = t - last_t; last_t = t;
+            px += 3; pd += 3; pt += 2; step++;
+        } else t = rm_skip(c, t, x, y, z, nx, ny, nz);
+    }
+}
+
+__global__ __launch_bounds__(256) void composite_rays_kernel(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                                                             float *__restrict__ rays_t, const float *__restrict__ sigmas,
+                                                             const float *__restrict__ rgbs, const float *__restrict__ normals,
+                                                             const float *__restrict__ deltas, float *__restrict__ weights_sum,
+                                                             float *__restrict__ depth, float *__restrict__ image,
+                                                             float *__restrict__ normal_map)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    float t = rays_t[n];
+    const float *s = sigmas + (size_t)n * n_step, *c = rgbs + (size_t)n * n_step * 3;
+    const float *dl = deltas + (size_t)n * n_step * 2, *nr = normals + (size_t)n * n_step * 3;
+    float ws = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    float nx = normal_map[index * 3], ny = normal_map[index * 3 + 1], nz = normal_map[index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = s[0], T = 1 - ws, w = alpha * T;
+        ws += w;
+        t += dl[1];
+        d += w * t;
+        r += w * c[0]; g += w * c[1]; b += w * c[2];
+        nx += w * nr[0]; ny += w * nr[1]; nz += w * nr[2];
+        if ((double)T < 1e-2) break;
+        s++; c += 3; dl += 2; nr += 3; step++;
+    }
+    rays_t[n] = (step < n_step) ? -1.0f : t;
+    weights_sum[index] = ws; depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    normal_map[index * 3] = nx; normal_map[index * 3 + 1] = ny; normal_map[index * 3 + 2] = nz;
+}
+
+__global__ __launch_bounds__(256) void alive_flags_kernel(uint32_t n_alive, const float *__restrict__ rays_t_old, int32_t *__restrict__ flags)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < n_alive) flags[n] = rays_t_old[n] >= 0 ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void compact_scatter_kernel(uint32_t n_alive, const int32_t *__restrict__ rays_alive_old,
+                                                              const float *__restrict__ rays_t_old, const int32_t *__restrict__ pos,
+                                                              int32_t *__restrict__ rays_alive, float *__restrict__ rays_t)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const float t = rays_t_old[n];
+    if (t >= 0) { const int32_t p = pos[n]; rays_alive[p] = rays_alive_old[n]; rays_t[p] = t; }
+}
+
+}  // namespace
+
+AC_API int ac_march_rays_train(const float *rays_o, const float *rays_d, const float *grid, float mean_density, int iter_density,
+                               float bound, uint32_t N, uint32_t H, uint32_t M, float *xyzs, float *dirs, float *deltas,
+                               int32_t *rays, int32_t *counter, uint32_t perturb, int32_t *scratch, ac_stream_t stream)
+{
+    (void)iter_density;
+    if (N == 0) return AC_OK;
+    if (!rays_o || !rays_d || !grid || !xyzs || !dirs || !deltas || !rays || !counter || !scratch || H < 2) {
+        ac::set_error("march_rays_train: NULL buffer or H < 2"); return AC_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *counts = scratch;                            // [N] occupied steps per ray
+    int32_t *offsets = scratch + N;                       // [N] exclusive scan of counts (+ counter[0] on entry)
+    int32_t *ray_base = scratch + 2 * (size_t)N;          // [1] counter[1] on entry (first free ray slot)
+    hipLaunchKernelGGL(march_count_kernel, dim3((N + 255) / 256), dim3(256), 0, st, rays_o, rays_d, grid, mean_density, bound, N, H,
+                       perturb, counts);
+    hipMemcpyAsync(offsets, counts, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(ray_base, counter + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, offsets, N, counter, (int32_t)N);
+    hipLaunchKernelGGL(march_write_kernel, dim3((N + 255) / 256), dim3(256), 0, st, rays_o, rays_d, grid, mean_density, bound, N, H, M,
+                       perturb, counts, offsets, ray_base, xyzs, dirs, deltas, rays);
+    return ac::check_launch("march_rays_train");
+}
+
+AC_API int ac_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, float bound,
+                                           uint32_t M, uint32_t N, float *weights_sum, float *image, ac_stream_t stream)
+{
+    (void)bound; (void)deltas;
+    if (N == 0) return AC_OK;
+    if (!sigmas || !rgbs || !rays || !weights_sum || !image) { ac::set_error("composite_rays_train_forward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(composite_train_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, sigmas, rgbs, rays, M, N,
+                       weights_sum, image);
+    return ac::check_launch("composite_rays_train_forward");
+}
+
+AC_API int ac_composite_rays_train_backward(const float *grad_weights_sum, const float *grad, const float *sigmas, const float *rgbs,
+                                            const float *deltas, const int32_t *rays, const float *weights_sum, const float *image,
+                                            float bound, uint32_t M, uint32_t N, float *grad_sigmas, float *grad_rgbs, ac_stream_t stream)
+{
+    (void)bound;
+    if (N == 0) return AC_OK;
+    if (!grad_weights_sum || !grad || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image || !grad_sigmas || !grad_rgbs) {
+        ac::set_error("composite_rays_train_backward: NULL buffer"); return AC_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(composite_train_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_weights_sum, grad, sigmas,
+                       rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    return ac::check_launch("composite_rays_train_backward");
+}
+
+AC_API int ac_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                         const float *rays_d, float bound, uint32_t H, const float *grid, float mean_density, const float *near,
+                         const float *far, float *xyzs, float *dirs, float *deltas, uint32_t perturb, ac_stream_t stream)
+{
+    (void)near;
+    if (n_alive == 0) return AC_OK;
+    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !far || !xyzs || !dirs || !deltas || H < 2) {
+        ac::set_error("march_rays: NULL buffer or H < 2"); return AC_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(march_rays_kernel, dim3((n_alive + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t,
+                       rays_o, rays_d, bound, H, grid, mean_density, far, xyzs, dirs, deltas, perturb);
+    return ac::check_launch("march_rays");
+}
+
+AC_API int ac_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, float *rays_t, const float *sigmas,
+                             const float *rgbs, const float *normals, const float *deltas, float *weights_sum, float *depth, float *image,
+                             float *normal_map, ac_stream_t stream)
+{
+    if (n_alive == 0) return AC_OK;
+    if (!rays_alive || !rays_t || !sigmas || !rgbs || !normals || !deltas || !weights_sum || !depth || !image || !normal_map) {
+        ac::set_error("composite_rays: NULL buffer"); return AC_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(composite_rays_kernel, dim3((n_alive + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
+                       rays_t, sigmas, rgbs, normals, deltas, weights_sum, depth, image, normal_map);
+    return ac::check_launch("composite_rays");
+}
+
+AC_API int ac_compact_rays(uint32_t n_alive, int32_t *rays_alive, const int32_t *rays_alive_old, float *rays_t, const float *rays_t_old,
+                           int32_t *alive_counter, int32_t *scratch, ac_stream_t stream)
+{
+    if (n_alive == 0) return AC_OK;
+    if (!rays_alive || !rays_alive_old || !rays_t || !rays_t_old || !alive_counter || !scratch) {
+        ac::set_error("compact_rays: NULL buffer"); return AC_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(alive_flags_kernel, dim3((n_alive + 255) / 256), dim3(256), 0, st, n_alive, rays_t_old, scratch);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, scratch, n_alive, alive_counter, -1);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((n_alive + 255) / 256), dim3(256), 0, st, n_alive, rays_alive_old, rays_t_old, scratch,
+                       rays_alive, rays_t);
+    return ac::check_launch("compact_rays");
+}

@@ -1,0 +1,715 @@
+// avatarcraft_amd/csrc/render_fused.hip -- the fused Instant-NSR ray renderer for MI355X (gfx950).
+//
+// One launch = NeRFRenderer.run (reference models/instant_nsr.py:133-299, render_can=True) for a
+// batch of rays; the reference runs the same work as ~11 forward_sdf calls x ~6 PyTorch kernels
+// plus ~200 small sampling kernels, every intermediate through HBM.
+//
+// Mapping (wave64 / CDNA4 first):
+//   * one wavefront owns one ray at a time; the ray's z / sdf arrays (<=128 entries) live in a
+//     wave-private LDS slab, everything else in registers.
+//   * a wave evaluates the field on TILES OF 16 SAMPLES: lane = (sample n = lane&15, group g = lane>>4).
+//     Group g gathers hash levels {g, 4+g, 8+g, 12+g} (8 of the 32 features), so the features
+//     of one sample are spread over 4 lanes exactly as the B operand of
+//     v_mfma_f32_16x16x4_f32 wants them (B[k=lane>>4][j=lane&15]): NO LDS transpose between the
+//     gather and the MLP.  Layers are computed transposed (D^T = W * X^T), so the D layout of
+//     layer i (row = 4*(lane>>4)+reg) is directly the B operand of layer i+1 with the k-order
+//     (t, r, g) -> unit 16t+4g+r: the whole 35-64-16 SDF MLP and 21-64-64-3 colour MLP chain
+//     through registers.  f32-input MFMA is bit-for-bit an fp32 fma chain in k order, which is
+//     what the CPU oracle evaluates (oracle/ac_oracle.c: orc_sdf_mlp / orc_color_mlp).
+//   * weights are converted once per workgroup from row-major global memory into MFMA A-fragment
+//     order in LDS (40 KB, shared by the 8 waves of the workgroup) and read with conflict-free
+//     lane-linear ds_read_b32.
+//   * per-ray cumprod / cumsum / reductions are 16-lane DPP Kogge-Stone scans (row_shr 1,2,4,8)
+//     with a scalar carry between tiles = "wavefront segmented scan".
+//   * NeuS up-sampling (up_sample + sample_pdf + cat_z_vals) runs inside the wave: 64-lane chunks
+//     for the per-bin math, binary searches in LDS, rank-based stable merge instead of a sort.
+//
+// Numerics contract: see ac_devmath.hpp and DESIGN.md; every value produced here is bit-identical
+// to oracle/ac_oracle.c:orc_render_rays on the same inputs.
+#include "ac_common.hpp"
+#include "ac_devmath.hpp"
+
+using namespace acdev;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 8;
+constexpr int BLOCK = WAVES_PER_BLOCK * 64;
+constexpr int MAXT = 128;
+#ifndef AC_ENC_ROUND
+#define AC_ENC_ROUND 2      // hash levels gathered per round per lane (registers vs loads in flight)
+#endif
+
+// ---- LDS layout (floats) -------------------------------------------------------------------------
+constexpr int OFF_W1F = 0;                       // [4 tiles][9 ksteps][64]
+constexpr int OFF_W2F = OFF_W1F + 4 * 9 * 64;    // [16 ksteps][64]
+constexpr int OFF_C1F = OFF_W2F + 16 * 64;       // [4][6][64]
+constexpr int OFF_C2F = OFF_C1F + 4 * 6 * 64;    // [4][16][64]
+constexpr int OFF_C3F = OFF_C2F + 4 * 16 * 64;   // [16][64]
+constexpr int OFF_B1 = OFF_C3F + 16 * 64;        // [64]
+constexpr int OFF_B2 = OFF_B1 + 64;              // [16]
+constexpr int OFF_LVL = OFF_B2 + 16;             // [16 levels][8 words]
+constexpr int OFF_LIN = OFF_LVL + 16 * 8;        // lin_z[64] + lin_u[16]
+constexpr int OFF_WAVE = OFF_LIN + 80;           // per-wave slabs start here
+constexpr int WAVE_SLAB = 2 * MAXT * 2 + MAXT + 16 + 16;   // zs[2][128], sd[2][128], cdf[128], znew[16], pad
+constexpr int LDS_FLOATS = OFF_WAVE + WAVES_PER_BLOCK * WAVE_SLAB;
+static_assert(OFF_WAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
+
+struct LevelRec { float scale; uint32_t stride1, offset, size, hashed, mask, pad0, pad1; };
+
+struct RenderArgs {
+    const float *table;
+    uint32_t table_bytes;
+    const float *W1, *b1, *W2, *b2, *Wc1, *Wc2, *Wc3;
+    const float *rays_o, *rays_d, *bg, *noise, *lin_z, *lin_u;
+    ac_render_out out;
+    LevelRec lvl[16];
+    int n_rays, T0, nup;
+    float bound, two_bound, inv_s, car, one_m_car, eps;
+    int perturb;
+};
+
+// ---- wave-level helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int OFF> __device__ __forceinline__ float dpp_shr(float ident, float v)
+{
+    // lanes n >= OFF of every 16-lane row receive v[n-OFF]; the others keep `ident`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v),
+                                                                  0x110 + OFF, 0xf, 0xf, false));
+}
+// Kogge-Stone inclusive scan inside every 16-lane row
+template <bool MUL> __device__ __forceinline__ float row_scan(float v)
+{
+    const float id = MUL ? 1.0f : 0.0f;
+    float s;
+    s = dpp_shr<1>(id, v); v = MUL ? s * v : s + v;
+    s = dpp_shr<2>(id, v); v = MUL ? s * v : s + v;
+    s = dpp_shr<4>(id, v); v = MUL ? s * v : s + v;
+    s = dpp_shr<8>(id, v); v = MUL ? s * v : s + v;
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float sel4(int g, float a, float b, float c, float d)
+{
+    return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
+}
+
+// ---- workgroup prologue: weights -> MFMA A-fragment order in LDS -------------------------------------
+__device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
+{
+    for (int e = threadIdx.x; e < 4 * 9 * 64; e += BLOCK) {          // sdf_net.0 [64,35]
+        int l = e & 63, fs = e >> 6, t = fs / 9, s = fs % 9;
+        int u = 16 * t + (l & 15), g = l >> 4;
+        int col = (s == 0) ? (g < 3 ? g : -1) : 3 + 2 * (4 * ((s - 1) >> 1) + g) + ((s - 1) & 1);
+        lds[OFF_W1F + e] = col < 0 ? 0.0f : a.W1[u * 35 + col];
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += BLOCK) {             // sdf_net.1 [16,64]
+        int l = e & 63, kk = e >> 6, t = kk >> 2, r = kk & 3;
+        lds[OFF_W2F + e] = a.W2[(l & 15) * 64 + 16 * t + 4 * (l >> 4) + r];
+    }
+    for (int e = threadIdx.x; e < 4 * 6 * 64; e += BLOCK) {          // color_net.0 [64,21] = [x(3), n(3), feat(15)]
+        int l = e & 63, fs = e >> 6, t = fs / 6, s = fs % 6;
+        int u = 16 * t + (l & 15), g = l >> 4;
+        float v;
+        if (s < 4) { int o = 4 * g + s; v = (o == 0) ? 0.0f : a.Wc1[u * 21 + 6 + (o - 1)]; }
+        else if (s == 4) v = g < 3 ? a.Wc1[u * 21 + g] : 0.0f;
+        else v = g < 3 ? a.Wc1[u * 21 + 3 + g] : 0.0f;
+        lds[OFF_C1F + e] = v;
+    }
+    for (int e = threadIdx.x; e < 4 * 16 * 64; e += BLOCK) {         // color_net.1 [64,64]
+        int l = e & 63, fs = e >> 6, to = fs >> 4, kk = fs & 15, t = kk >> 2, r = kk & 3;
+        lds[OFF_C2F + e] = a.Wc2[(16 * to + (l & 15)) * 64 + 16 * t + 4 * (l >> 4) + r];
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += BLOCK) {             // color_net.2 [3,64]
+        int l = e & 63, kk = e >> 6, t = kk >> 2, r = kk & 3, o = l & 15;
+        lds[OFF_C3F + e] = o < 3 ? a.Wc3[o * 64 + 16 * t + 4 * (l >> 4) + r] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < 64; e += BLOCK) lds[OFF_B1 + e] = a.b1[e];
+    for (int e = threadIdx.x; e < 16; e += BLOCK) lds[OFF_B2 + e] = a.b2[e];
+    {   // level records: static kernarg indexing only (a dynamic index would copy the struct to scratch)
+        uint32_t *lw = reinterpret_cast<uint32_t *>(lds) + OFF_LVL;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            if (threadIdx.x == (unsigned)l) {
+                lw[8 * l + 0] = __float_as_uint(a.lvl[l].scale); lw[8 * l + 1] = a.lvl[l].stride1;
+                lw[8 * l + 2] = a.lvl[l].offset; lw[8 * l + 3] = a.lvl[l].size;
+                lw[8 * l + 4] = a.lvl[l].hashed; lw[8 * l + 5] = a.lvl[l].mask;
+                lw[8 * l + 6] = 0u; lw[8 * l + 7] = 0u;
+            }
+        }
+    }
+    for (int e = threadIdx.x; e < 64; e += BLOCK) lds[OFF_LIN + e] = e < a.T0 ? a.lin_z[e] : 0.0f;
+    for (int e = threadIdx.x; e < 16; e += BLOCK) lds[OFF_LIN + 64 + e] = a.lin_u ? a.lin_u[e] : 0.0f;
+}
+
+// ---- hash-grid features of this lane's 4 levels (HashEncoder.forward + kernel_grid) -------------------
+// p: world position (clamped to +-bound); returns f[j][c] for level 4j+g.  The gathers go through a
+// buffer descriptor (32-bit byte offsets, hardware bounds check) and are issued ROUND levels at a time.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int ROUND>
+__device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t table, int g,
+                                        float px, float py, float pz, float bound, float two_bound, float (&f)[4][2])
+{
+    const float ux = (px + bound) / two_bound, uy = (py + bound) / two_bound, uz = (pz + bound) / two_bound;
+    const bool oob = (ux < 0.0f) | (ux > 1.0f) | (uy < 0.0f) | (uy > 1.0f) | (uz < 0.0f) | (uz > 1.0f);
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0 += ROUND) {
+        float q[ROUND][3];
+        u32x2 v[ROUND][8];
+#pragma unroll
+        for (int jj = 0; jj < ROUND; ++jj) {
+            const int j = j0 + jj;
+            const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8);
+            const uint2 r1 = *reinterpret_cast<const uint2 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
+            const float scale = __uint_as_float(r0.x);
+            const uint32_t stride1 = r0.y, offset = r0.z, size = r0.w, hashed = r1.x, mask = r1.y;
+            float qx = fma_(ux, scale, 0.5f), qy = fma_(uy, scale, 0.5f), qz = fma_(uz, scale, 0.5f);
+            const uint32_t gx = (uint32_t)__builtin_floorf(qx), gy = (uint32_t)__builtin_floorf(qy), gz = (uint32_t)__builtin_floorf(qz);
+            q[jj][0] = qx - (float)gx; q[jj][1] = qy - (float)gy; q[jj][2] = qz - (float)gz;
+            // per-axis partial indices: hashed  -> x, y*P1, z*P2 (xor);  dense -> x, y*s, z*s*s (add)
+            const uint32_t my = hashed ? 2654435761u : stride1, mz = hashed ? 805459861u : stride1 * stride1;
+            const uint32_t ax0 = gx, ax1 = gx + 1u, ay0 = gy * my, ay1 = (gy + 1u) * my, az0 = gz * mz, az1 = (gz + 1u) * mz;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t tx = (c & 1) ? ax1 : ax0, ty = (c & 2) ? ay1 : ay0, tz = (c & 4) ? az1 : az0;
+                uint32_t idx = hashed ? (tx ^ ty ^ tz) : (tx + ty + tz);
+                if (mask) idx &= mask;
+                else if (idx >= size) idx %= size;
+                v[jj][c] = __builtin_amdgcn_raw_buffer_load_b64(table, (offset + idx) * 8u, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < ROUND; ++jj) {
+            const float qx = q[jj][0], qy = q[jj][1], qz = q[jj][2];
+            const float wx0 = 1.0f - qx, wy0 = 1.0f - qy, wz0 = 1.0f - qz;
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = (((c & 1) ? qx : wx0) * ((c & 2) ? qy : wy0)) * ((c & 4) ? qz : wz0);
+                a0 = fma_(w, __uint_as_float(v[jj][c].x), a0);
+                a1 = fma_(w, __uint_as_float(v[jj][c].y), a1);
+            }
+            f[j0 + jj][0] = oob ? 0.0f : a0;
+            f[j0 + jj][1] = oob ? 0.0f : a1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- forward_sdf for a tile of 16 points: returns the 16 outputs as D2^T fragment (o = 4g+r) ----------
+__device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, rsrc_t table, int lane,
+                                          float px, float py, float pz, float bound, float two_bound)
+{
+    const int g = lane >> 4;
+    float f[4][2];
+    encode4<AC_ENC_ROUND>(lds, table, g, px, py, pz, bound, two_bound, f);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = *reinterpret_cast<const f32x4 *>(lds + OFF_B1 + 16 * t + 4 * g);
+    const float bxyz = sel4(g, px, py, pz, 0.0f);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const float b = (s == 0) ? bxyz : f[(s - 1) >> 1][(s - 1) & 1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W1F + (t * 9 + s) * 64 + lane], b, acc[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 o2 = *reinterpret_cast<const f32x4 *>(lds + OFF_B2 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h = dv_softplus100(acc[t][r]);
+            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r) * 64 + lane], h, o2, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return o2;
+}
+
+// ---- forward_color for a tile: rgb (post-sigmoid) valid in lanes g==0 ---------------------------------
+__device__ __forceinline__ void color_tile(const float *__restrict__ lds, int lane, float px, float py, float pz,
+                                           float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3])
+{
+    const int g = lane >> 4;
+    f32x4 h1[4], h2[4];
+    const float bxyz = sel4(g, px, py, pz, 0.0f), bn = sel4(g, nx, ny, nz, 0.0f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const float b = s < 4 ? sdfout[s] : (s == 4 ? bxyz : bn);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C1F + (t * 6 + s) * 64 + lane], b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+        h1[t] = acc;
+    }
+#pragma unroll
+    for (int to = 0; to < 4; ++to) {
+        f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C2F + (to * 16 + kk) * 64 + lane], h1[kk >> 2][kk & 3], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+        h2[to] = acc;
+    }
+    f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C3F + kk * 64 + lane], h2[kk >> 2][kk & 3], acc, 0, 0, 0);
+    rgb[0] = dv_sigmoid(acc[0]); rgb[1] = dv_sigmoid(acc[1]); rgb[2] = dv_sigmoid(acc[2]);
+}
+
+// ---- one 64-bin chunk of the per-bin scans of up_sample: row-local inclusive scan + cross-row carry ----
+// v: this lane's element (identity-padded); carry/first: state entering the chunk; returns the inclusive
+// tile-scan value and the value entering this lane's row (rc), updates carry/first.
+template <bool MUL>
+__device__ __forceinline__ float chunk_scan(float v, int lane, float &carry, bool &first, float &loc, float &row_in, bool &row_first)
+{
+    loc = row_scan<MUL>(v);
+    const float t0 = lane_bcast(loc, 15), t1 = lane_bcast(loc, 31), t2 = lane_bcast(loc, 47), t3 = lane_bcast(loc, 63);
+    const float c0 = carry; const bool f0 = first;
+    const float c1 = f0 ? t0 : (MUL ? c0 * t0 : c0 + t0);
+    const float c2 = MUL ? c1 * t1 : c1 + t1;
+    const float c3 = MUL ? c2 * t2 : c2 + t2;
+    const float c4 = MUL ? c3 * t3 : c3 + t3;
+    const int g = lane >> 4;
+    row_in = sel4(g, c0, c1, c2, c3);
+    row_first = f0 && g == 0;
+    carry = c4; first = false;
+    return row_first ? loc : (MUL ? row_in * loc : row_in + loc);
+}
+
+// =====================================================================================================
+__global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    float *zs = lds + OFF_WAVE + wave * WAVE_SLAB;      // zs[2][128]
+    float *sd = zs + 2 * MAXT;                          // sd[2][128]
+    float *cdf = sd + 2 * MAXT;                         // cdf[128]
+    float *znl = cdf + MAXT;                            // znew[16]
+    const rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.table), 0, a.table_bytes, 0x00020000);
+    const float bound = a.bound, two_bound = a.two_bound;
+    const int T0 = a.T0, nup = a.nup, T = T0 + 16 * nup;
+
+    for (int ray = blockIdx.x * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
+        const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
+        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+        // near_far_from_bound (cube)  instant_nsr.py:58-77
+        float near, far;
+        {
+            const float ex = dx + 1e-15f, ey = dy + 1e-15f, ez = dz + 1e-15f;
+            const float ax = (-bound - ox) / ex, bx = (bound - ox) / ex;
+            const float ay = (-bound - oy) / ey, by = (bound - oy) / ey;
+            const float az = (-bound - oz) / ez, bz = (bound - oz) / ez;
+            const float lx = ax < bx ? ax : bx, hx = ax > bx ? ax : bx;
+            const float ly = ay < by ? ay : by, hy = ay > by ? ay : by;
+            const float lz = az < bz ? az : bz, hz = az > bz ? az : bz;
+            near = lx; if (ly > near) near = ly; if (lz > near) near = lz;
+            far = hx; if (hy < far) far = hy; if (hz < far) far = hz;
+            if (near < 0.05f) near = 0.05f;
+        }
+        const float span = far - near;
+        const float sample_dist = span / (float)T0;
+        int cur = 0, cnt = T0;
+
+        // ---- coarse samples :155-180 -------------------------------------------------------------
+        for (int c = 0; c < T0 / 16; ++c) {
+            const int i = 16 * c + n;
+            float zi = near + span * lds[OFF_LIN + i];
+            if (a.perturb) zi = zi + (a.noise[(size_t)ray * T0 + i] - 0.5f) * sample_dist;
+            if (nup > 0) {
+                const float px = clampf(ox + dx * zi, -bound, bound), py = clampf(oy + dy * zi, -bound, bound),
+                            pz = clampf(oz + dz * zi, -bound, bound);
+                const f32x4 o2 = sdf_tile(lds, table, lane, px, py, pz, bound, two_bound);
+                if (g == 0) sd[i] = o2[0];
+            }
+            if (g == 0) zs[i] = zi;
+        }
+        wave_sync();
+
+        // ---- NeuS up-sampling :182-184, :410-475 -----------------------------------------------------
+        for (int it = 0; it < nup; ++it) {
+            const float *zc = zs + cur * MAXT, *sc = sd + cur * MAXT;
+            float *zn_ = zs + (cur ^ 1) * MAXT, *sn_ = sd + (cur ^ 1) * MAXT;
+            const int m = cnt - 1;
+            const float inv_s = (float)(64 << it);
+            float w[2];
+            float carry = 1.0f; bool first = true;
+            // pass 1: alpha, transmittance scan, weights (+1e-5)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int i = 64 * ch + lane;
+                float alpha = 0.0f, om = 1.0f;
+                if (i < m) {
+                    const float z0 = zc[i], z1 = zc[i + 1], s0 = sc[i], s1 = sc[i + 1];
+                    const float p0x = ox + dx * z0, p0y = oy + dy * z0, p0z = oz + dz * z0;
+                    const float p1x = ox + dx * z1, p1y = oy + dy * z1, p1z = oz + dz * z1;
+                    const float r0 = __builtin_sqrtf((p0x * p0x + p0y * p0y) + p0z * p0z);
+                    const float r1 = __builtin_sqrtf((p1x * p1x + p1y * p1y) + p1z * p1z);
+                    const bool inside = (r0 < 1.0f) | (r1 < 1.0f);
+                    const float mid = (s0 + s1) * 0.5f;
+                    const float dist = z1 - z0;
+                    const float cosv = (s1 - s0) / (dist + 1e-5f);
+                    float prev_cos = 0.0f;
+                    if (i > 0) { const float zm = zc[i - 1], sm = sc[i - 1]; prev_cos = (s0 - sm) / ((z0 - zm) + 1e-5f); }
+                    float cmin = prev_cos < cosv ? prev_cos : cosv;
+                    cmin = clampf(cmin, -1e3f, 0.0f) * (inside ? 1.0f : 0.0f);
+                    const float half = cmin * dist * 0.5f;
+                    const float pc = dv_sigmoid((mid - half) * inv_s), nc = dv_sigmoid((mid + half) * inv_s);
+                    alpha = (pc - nc + 1e-5f) / (pc + 1e-5f);
+                    om = 1.0f - alpha + 1e-7f;
+                }
+                float loc, row_in; bool row_first;
+                (void)chunk_scan<true>(om, lane, carry, first, loc, row_in, row_first);
+                // exclusive transmittance T_i = cp[i-1]: row-local inclusive value of lane n-1 times the row carry
+                const float sh = dpp_shr<1>(1.0f, loc);                 // local[n-1], identity in lane n==0
+                float Tex;
+                if (n == 0) Tex = row_first ? 1.0f : row_in;
+                else Tex = row_first ? sh : row_in * sh;
+                w[ch] = (i < m) ? alpha * Tex + 1e-5f : 0.0f;
+            }
+            // pass 2: total = last element of the inclusive add tile-scan of w
+            float total;
+            {
+                float c2 = 0.0f; bool f2 = true; float lc, ri; bool rf;
+                float last = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float incl = chunk_scan<false>(w[ch], lane, c2, f2, lc, ri, rf);
+                    const int il = m - 1 - 64 * ch;                    // lane holding element m-1 (wave-uniform)
+                    const float cand = __shfl(incl, il & 63);
+                    if (il >= 0 && il < 64) last = cand;
+                }
+                total = last;
+            }
+            // pass 3: pdf, cdf
+            {
+                float c3 = 0.0f; bool f3 = true; float lc, ri; bool rf;
+                if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const int i = 64 * ch + lane;
+                    const float pdf = (i < m) ? w[ch] / total : 0.0f;
+                    const float incl = chunk_scan<false>(pdf, lane, c3, f3, lc, ri, rf);
+                    if (i < m) cdf[i + 1] = incl;
+                }
+            }
+            wave_sync();
+            // sample_pdf(det=True): one new sample per n (replicated over the 4 groups)
+            float znew;
+            int ind;
+            {
+                const float u = lds[OFF_LIN + 64 + n];
+                int lo = 0, hi = cnt;
+                while (lo < hi) { const int md = (lo + hi) >> 1; if (cdf[md] <= u) lo = md + 1; else hi = md; }
+                ind = lo;
+                const int below = lo - 1 > 0 ? lo - 1 : 0;
+                const int above = lo < cnt - 1 ? lo : cnt - 1;
+                const float cb = cdf[below], ca = cdf[above];
+                float den = ca - cb;
+                if (den < 1e-5f) den = 1.0f;
+                const float t = (u - cb) / den;
+                const float zb = zc[below], za = zc[above];
+                znew = zb + t * (za - zb);
+            }
+            if (g == 0) {
+                znl[n] = znew;
+                if (a.out.ss_inds) a.out.ss_inds[((size_t)ray * nup + it) * 16 + n] = ind;
+            }
+            const bool last_it = (it + 1 == nup);
+            float sdf_new = 0.0f;
+            if (!last_it) {
+                const float px = clampf(ox + dx * znew, -bound, bound), py = clampf(oy + dy * znew, -bound, bound),
+                            pz = clampf(oz + dz * znew, -bound, bound);
+                const f32x4 o2 = sdf_tile(lds, table, lane, px, py, pz, bound, two_bound);
+                sdf_new = o2[0];
+            }
+            wave_sync();
+            // stable merge == torch.sort(cat([z, znew])) :466-473
+            int32_t *sidx = a.out.sort_index ? a.out.sort_index + ((size_t)ray * nup + it) * 128 : nullptr;
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int i = 64 * ch + lane;
+                if (i < cnt) {
+                    const float zi = zc[i];
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) c += (znl[j] < zi) ? 1 : 0;
+                    zn_[i + c] = zi; sn_[i + c] = sc[i];
+                    if (sidx) sidx[i + c] = i;
+                }
+                if (sidx && i >= cnt + 16) sidx[i] = -1;
+            }
+            if (g == 0) {
+                int lo = 0, hi = cnt;
+                while (lo < hi) { const int md = (lo + hi) >> 1; if (zc[md] <= znew) lo = md + 1; else hi = md; }
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { const float zj = znl[j]; c += ((zj < znew) || (zj == znew && j < n)) ? 1 : 0; }
+                zn_[lo + c] = znew; sn_[lo + c] = sdf_new;
+                if (sidx) sidx[lo + c] = cnt + n;
+            }
+            cnt += 16; cur ^= 1;
+            wave_sync();
+        }
+
+        // ---- render core :190-299 ---------------------------------------------------------------------
+        const float *zf = zs + cur * MAXT;
+        float cT = 1.0f;                                        // transmittance carry (cumprod)
+        float s_w = 0.0f, s_r = 0.0f, s_g = 0.0f, s_b = 0.0f, s_nx = 0.0f, s_ny = 0.0f, s_nz = 0.0f, s_d = 0.0f,
+              s_en = 0.0f, s_ed = 0.0f;
+        const float bxe = a.eps;
+        for (int c = 0; c < T / 16; ++c) {
+            const int i = 16 * c + n;
+            const float zi = zf[i];
+            const float delta = (i < T - 1) ? zf[i + 1] - zi : sample_dist;
+            const float zmid = (i < T - 1) ? zi + 0.5f * delta : zi;
+            const float px = clampf(ox + dx * zmid, -bound, bound), py = clampf(oy + dy * zmid, -bound, bound),
+                        pz = clampf(oz + dz * zmid, -bound, bound);
+            // centre + 6 finite-difference evaluations (:687-704) as ONE loop body (keeps a single copy of
+            // the gather/MLP code and its register footprint): e=0 centre, e=1..6 -> axis (e-1)>>1, sign (e-1)&1
+            f32x4 oc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            float gr[3] = { 0.0f, 0.0f, 0.0f };
+            float spos = 0.0f;
+#pragma unroll 1
+            for (int e = 0; e < 7; ++e) {
+                const int k = (e - 1) >> 1;
+                const float de = ((e - 1) & 1) ? -bxe : bxe;
+                const float qx_ = (e > 0 && k == 0) ? clampf(px + de, -bound, bound) : px;
+                const float qy_ = (e > 0 && k == 1) ? clampf(py + de, -bound, bound) : py;
+                const float qz_ = (e > 0 && k == 2) ? clampf(pz + de, -bound, bound) : pz;
+                const f32x4 o = sdf_tile(lds, table, lane, qx_, qy_, qz_, bound, two_bound);
+                if (e == 0) oc = o;
+                else if (e & 1) spos = o[0];
+                else {
+                    const float gk = 0.5f * (spos - o[0]) / bxe;
+                    if (k == 0) gr[0] = gk; else if (k == 1) gr[1] = gk; else gr[2] = gk;
+                }
+            }
+            // lanes g==0 hold the sdf-based values; broadcast the gradient to the other groups
+            const float gx = __shfl(gr[0], n), gy = __shfl(gr[1], n), gz = __shfl(gr[2], n);
+            const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+            const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
+            float rgb[3];
+            color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+            // NeuS alpha :219-248
+            const float sdf0 = oc[0];
+            const float tc = (dx * nx + dy * ny) + dz * nz;
+            const float a1 = dv_softplus100(-tc * 0.5f + 0.5f) * a.one_m_car;
+            const float a2 = dv_softplus100(-tc) * a.car;
+            const float iter_cos = -(a1 + a2);
+            const float half = iter_cos * delta * 0.5f;
+            const float pc = dv_sigmoid((sdf0 - half) * a.inv_s), nc = dv_sigmoid((sdf0 + half) * a.inv_s);
+            const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+            const float om = 1.0f - alpha + 1e-7f;
+            // transmittance: exclusive tile scan with carry  :250
+            const float loc = row_scan<true>(om);
+            const float sh = dpp_shr<1>(1.0f, loc);
+            float Tex;
+            if (n == 0) Tex = (c == 0) ? 1.0f : cT;
+            else Tex = (c == 0) ? sh : cT * sh;
+            const float tot = lane_bcast(loc, 15);
+            cT = (c == 0) ? tot : cT * tot;
+            const float wgt = alpha * Tex;
+            const float zn01 = clampf((zi - near) / span, 0.0f, 1.0f);
+            const float pn = __builtin_sqrtf((px * px + py * py) + pz * pz);
+            const float relax = pn < 1.2f ? 1.0f : 0.0f;
+            const float eerr = relax * ((gn - 1.0f) * (gn - 1.0f));
+            // reductions (lane 15 of row 0 holds the tile totals)
+#define AC_ACC(S, V) { const float t_ = lane_bcast(row_scan<false>(V), 15); S = (c == 0) ? t_ : S + t_; }
+            AC_ACC(s_w, wgt)
+            AC_ACC(s_r, rgb[0] * wgt) AC_ACC(s_nx, nx * wgt)
+            AC_ACC(s_g, rgb[1] * wgt) AC_ACC(s_ny, ny * wgt)
+            AC_ACC(s_b, rgb[2] * wgt) AC_ACC(s_nz, nz * wgt)
+            AC_ACC(s_d, wgt * zn01)
+            AC_ACC(s_en, eerr) AC_ACC(s_ed, relax)
+#undef AC_ACC
+            if (g == 0) {
+                const size_t si = (size_t)ray * T + i;
+                if (a.out.z_vals) a.out.z_vals[si] = zi;
+                if (a.out.weights) a.out.weights[si] = wgt;
+                if (a.out.alpha) a.out.alpha[si] = alpha;
+                if (a.out.sdf) a.out.sdf[si] = sdf0;
+                if (a.out.color) { a.out.color[3 * si] = rgb[0]; a.out.color[3 * si + 1] = rgb[1]; a.out.color[3 * si + 2] = rgb[2]; }
+                if (a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
+            }
+        }
+        if (lane == 0) {
+            const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
+            a.out.image[3 * ray] = s_r + (1.0f - s_w) * b0;
+            a.out.image[3 * ray + 1] = s_g + (1.0f - s_w) * b1;
+            a.out.image[3 * ray + 2] = s_b + (1.0f - s_w) * b2;
+            a.out.normal_map[3 * ray] = s_nx; a.out.normal_map[3 * ray + 1] = s_ny; a.out.normal_map[3 * ray + 2] = s_nz;
+            a.out.weights_sum[ray] = s_w;
+            a.out.depth[ray] = s_d;
+            a.out.eik[2 * ray] = s_en; a.out.eik[2 * ray + 1] = s_ed;
+        }
+        wave_sync();
+    }
+}
+
+// ---- stand-alone field queries (density(), extract_geometry(), unit tests) -------------------------------
+__global__ __launch_bounds__(BLOCK) void field_sdf_kernel(const RenderArgs a, const float *__restrict__ x, uint32_t B,
+                                                          float *__restrict__ out16)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.table), 0, a.table_bytes, 0x00020000);
+    const uint32_t ntiles = (B + 15) / 16;
+    for (uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + wave; tile < ntiles; tile += gridDim.x * WAVES_PER_BLOCK) {
+        const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
+        const float px = x[3 * bb], py = x[3 * bb + 1], pz = x[3 * bb + 2];
+        const f32x4 o = sdf_tile(lds, table, lane, px, py, pz, a.bound, a.two_bound);
+        if (b < B) *reinterpret_cast<f32x4 *>(out16 + (size_t)b * 16 + 4 * g) = o;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void field_color_kernel(const RenderArgs a, const float *__restrict__ x,
+                                                            const float *__restrict__ nrm, const float *__restrict__ sdfout,
+                                                            uint32_t B, float *__restrict__ rgb_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const uint32_t ntiles = (B + 15) / 16;
+    for (uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + wave; tile < ntiles; tile += gridDim.x * WAVES_PER_BLOCK) {
+        const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
+        const f32x4 so = *reinterpret_cast<const f32x4 *>(sdfout + (size_t)bb * 16 + 4 * g);
+        float rgb[3];
+        color_tile(lds, lane, x[3 * bb], x[3 * bb + 1], x[3 * bb + 2], nrm[3 * bb], nrm[3 * bb + 1], nrm[3 * bb + 2], so, rgb);
+        if (b < B && g == 0) { rgb_out[3 * b] = rgb[0]; rgb_out[3 * b + 1] = rgb[1]; rgb_out[3 * b + 2] = rgb[2]; }
+    }
+}
+
+// gradient_error: fixed-order reduction of per-ray partials (oracle: orc_eikonal_reduce)
+__global__ __launch_bounds__(1024) void eikonal_reduce_kernel(const float *__restrict__ eik, int n_rays, float *__restrict__ result)
+{
+    __shared__ float pn[1024], pd[1024];
+    const int t = threadIdx.x;
+    float a = 0.0f, b = 0.0f;
+    for (int r = t; r < n_rays; r += 1024) { a += eik[2 * r]; b += eik[2 * r + 1]; }
+    pn[t] = a; pd[t] = b;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (t < s) { pn[t] += pn[t + s]; pd[t] += pd[t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) result[0] = pn[0] / (pd[0] + 1e-5f);
+}
+
+int fill_args(RenderArgs &a, const ac_field *f, float bound)
+{
+    if (!f || !f->table || !f->W1 || !f->b1 || !f->W2 || !f->b2 || !f->Wc1 || !f->Wc2 || !f->Wc3) {
+        ac::set_error("ac_field: NULL parameter pointer"); return AC_ERR_BAD_ARG;
+    }
+    ac::LevelTable lt; ac::make_level_table(lt, 16, 3, f->S, f->H, f->offsets);
+    for (int l = 0; l < 16; ++l) {
+        a.lvl[l].scale = lt.scale[l]; a.lvl[l].stride1 = lt.stride1[l]; a.lvl[l].offset = lt.offset[l];
+        a.lvl[l].size = lt.size[l]; a.lvl[l].hashed = lt.hashed[l]; a.lvl[l].mask = lt.pow2mask[l];
+        a.lvl[l].pad0 = a.lvl[l].pad1 = 0;
+        if (lt.size[l] == 0) { ac::set_error("ac_field: level %d has zero size", l); return AC_ERR_BAD_ARG; }
+    }
+    a.table = f->table; a.table_bytes = (uint32_t)f->offsets[16] * 8u; a.W1 = f->W1; a.b1 = f->b1; a.W2 = f->W2; a.b2 = f->b2; a.Wc1 = f->Wc1; a.Wc2 = f->Wc2; a.Wc3 = f->Wc3;
+    a.bound = bound; a.two_bound = (float)(2.0 * (double)bound);
+    return AC_OK;
+}
+
+}  // namespace
+
+AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
+                          const float *bg, const float *noise, const float *lin_z, const float *lin_u,
+                          const ac_render_out *out, ac_stream_t stream)
+{
+    if (!op || !out) { ac::set_error("render_rays: NULL opts/out"); return AC_ERR_BAD_ARG; }
+    if (op->num_steps % 16 || op->upsample_steps % 16 || op->num_steps < 16 || op->num_steps > 64 ||
+        op->upsample_steps < 0 || op->num_steps + op->upsample_steps > MAXT) {
+        ac::set_error("render_rays: num_steps=%d upsample_steps=%d unsupported (multiples of 16, num_steps<=64, sum<=128)",
+                      op->num_steps, op->upsample_steps);
+        return AC_ERR_BAD_ARG;
+    }
+    if (op->n_rays <= 0) return AC_OK;
+    if (!rays_o || !rays_d || !lin_z || (op->upsample_steps && !lin_u) || (op->perturb && !noise) || !out->image ||
+        !out->weights_sum || !out->depth || !out->normal_map || !out->eik) {
+        ac::set_error("render_rays: NULL buffer"); return AC_ERR_BAD_ARG;
+    }
+    RenderArgs a{};
+    if (int rc = fill_args(a, field, op->bound)) return rc;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.bg = bg; a.noise = noise; a.lin_z = lin_z; a.lin_u = lin_u;
+    a.out = *out;
+    a.n_rays = op->n_rays; a.T0 = op->num_steps; a.nup = op->upsample_steps / 16;
+    a.inv_s = op->inv_s; a.car = op->cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
+    a.eps = op->fd_eps; a.perturb = op->perturb;
+    const int blocks = (op->n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    static bool attr_set = false;
+    const size_t lds_bytes = LDS_FLOATS * sizeof(float);
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(render_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(render_rays_kernel, dim3(blocks), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a);
+    return ac::check_launch("render_rays");
+}
+
+AC_API int ac_eikonal_reduce(const float *eik, int32_t n_rays, float *result, ac_stream_t stream)
+{
+    if (!result || n_rays < 0 || (!eik && n_rays > 0)) { ac::set_error("eikonal_reduce: bad argument"); return AC_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, eik, n_rays, result);
+    return ac::check_launch("eikonal_reduce");
+}
+
+AC_API int ac_field_sdf(const ac_field *field, const float *x, uint32_t B, float bound, float *out16, ac_stream_t stream)
+{
+    if (B == 0) return AC_OK;
+    if (!x || !out16) { ac::set_error("field_sdf: NULL buffer"); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = fill_args(a, field, bound)) return rc;
+    a.T0 = 0;
+    const size_t lds_bytes = OFF_WAVE * sizeof(float);
+    const uint32_t ntiles = (B + 15) / 16;
+    uint32_t blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(field_sdf_kernel, dim3(blocks), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a, x, B, out16);
+    return ac::check_launch("field_sdf");
+}
+
+AC_API int ac_field_color(const ac_field *field, const float *x, const float *n, const float *sdfout, uint32_t B, float *rgb,
+                          ac_stream_t stream)
+{
+    if (B == 0) return AC_OK;
+    if (!x || !n || !sdfout || !rgb) { ac::set_error("field_color: NULL buffer"); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = fill_args(a, field, 1.0f)) return rc;
+    a.T0 = 0;
+    const size_t lds_bytes = OFF_WAVE * sizeof(float);
+    const uint32_t ntiles = (B + 15) / 16;
+    uint32_t blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(field_color_kernel, dim3(blocks), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a, x, n, sdfout, B, rgb);
+    return ac::check_launch("field_color");
+}

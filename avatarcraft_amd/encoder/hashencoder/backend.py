@@ -1,0 +1,54 @@
+"""`_backend` of the hash encoder: same two functions, argument order and in-place convention as the
+reference's pybind module (encoder/hashencoder/src/bindings.cpp:6-7, hashencoder.cu:413-468), served
+by libavatarcraft_hip.so.  No JIT on import; raises RuntimeError when the library is absent."""
+import numpy as np
+import torch
+
+from ... import _lib as L
+
+
+def _floating(t, name):
+    if t.dtype != torch.float32:
+        # reference dispatches float/half/double; the MI355X path is fp32 (fp32 is the only dtype exercised)
+        raise RuntimeError(f"{name} must be a float32 tensor")
+
+
+class _Backend:
+    @staticmethod
+    def _offsets_host(offsets):
+        if offsets.dtype != torch.int32:
+            raise RuntimeError("offsets must be an int tensor")
+        cache = getattr(offsets, "_ac_host", None)
+        if cache is None:
+            cache = np.ascontiguousarray(offsets.detach().cpu().numpy(), dtype=np.int32)
+            try:
+                offsets._ac_host = cache
+            except Exception:
+                pass
+        return cache
+
+    @staticmethod
+    def hash_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L_, S, H, calc_grad_inputs, dy_dx):
+        L.require_cuda(inputs, embeddings, offsets, outputs, dy_dx)
+        for t, n in ((inputs, "inputs"), (embeddings, "embeddings"), (outputs, "outputs"), (dy_dx, "dy_dx")):
+            _floating(t, n)
+        oh = _Backend._offsets_host(offsets)
+        L.check(L.lib().ac_hash_encode_forward(inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(), oh.ctypes.data,
+                                               outputs.data_ptr(), B, D, C, L_, float(np.float32(S)), H, int(bool(calc_grad_inputs)),
+                                               dy_dx.data_ptr(), L.current_stream(inputs.device)), "hash_encode_forward")
+
+    @staticmethod
+    def hash_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L_, S, H, calc_grad_inputs, dy_dx,
+                             grad_inputs):
+        L.require_cuda(grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs)
+        for t, n in ((grad, "grad"), (inputs, "inputs"), (embeddings, "embeddings"), (grad_embeddings, "grad_embeddings")):
+            _floating(t, n)
+        oh = _Backend._offsets_host(offsets)
+        L.check(L.lib().ac_hash_encode_backward(grad.data_ptr(), inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(),
+                                                oh.ctypes.data, grad_embeddings.data_ptr(), B, D, C, L_, float(np.float32(S)), H,
+                                                int(bool(calc_grad_inputs)), dy_dx.data_ptr(), grad_inputs.data_ptr(),
+                                                L.current_stream(inputs.device)), "hash_encode_backward")
+
+
+_backend = _Backend()
+__all__ = ["_backend"]

@@ -1,0 +1,137 @@
+"""Python front end of the fused Instant-NSR renderer (ac_render_rays & friends).
+
+Host-side plumbing only: builds the ac_field / ac_render_opts / ac_render_out structs from torch
+CUDA tensors and enqueues the HIP kernels on torch's current stream.  The numerical work of
+NeRFRenderer.run (reference models/instant_nsr.py:133-299) is entirely inside
+libavatarcraft_hip.so; there is no eager fallback.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_F32 = torch.float32
+
+
+def _chk(t, name, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if t.dtype != _F32:
+        raise RuntimeError(f"{name} must be a float32 tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+class Field:
+    """Device-resident parameters of the default NeRFNetwork in the layout ac_field wants:
+    table [n_entries,2], offsets (17 host ints), S=log2(per_level_scale), H, and the EFFECTIVE
+    (weight-normed) MLP matrices W1[64,35] b1[64] W2[16,64] b2[16] Wc1[64,21] Wc2[64,64] Wc3[3,64]."""
+
+    def __init__(self, table, offsets, per_level_scale, base_resolution, W1, b1, W2, b2, Wc1, Wc2, Wc3):
+        offsets = [int(v) for v in offsets]
+        if len(offsets) != 17:
+            raise RuntimeError("the fused renderer supports the 16-level hash grid only")
+        self.t = dict(table=_chk(table, "table", (offsets[-1], 2)), W1=_chk(W1, "W1", (64, 35)), b1=_chk(b1, "b1", (64,)),
+                      W2=_chk(W2, "W2", (16, 64)), b2=_chk(b2, "b2", (16,)), Wc1=_chk(Wc1, "Wc1", (64, 21)),
+                      Wc2=_chk(Wc2, "Wc2", (64, 64)), Wc3=_chk(Wc3, "Wc3", (3, 64)))
+        import numpy as np
+        self.S = float(np.float32(np.log2(per_level_scale)))
+        self.H = int(base_resolution)
+        f = L.ac_field()
+        f.table = self.t["table"].data_ptr()
+        for i, v in enumerate(offsets):
+            f.offsets[i] = v
+        f.S = self.S
+        f.H = self.H
+        for k in ("W1", "b1", "W2", "b2", "Wc1", "Wc2", "Wc3"):
+            setattr(f, k, self.t[k].data_ptr())
+        self.c = f
+        self.device = table.device
+
+
+_LIN_CACHE = {}
+
+
+def linspace_tables(num_steps, device):
+    """lin_z = torch.linspace(0,1,num_steps), lin_u = torch.linspace(0.5/16, 1-0.5/16, 16), made on the
+    CPU exactly as the reference makes them (instant_nsr.py:155, :34) and cached on the device."""
+    key = (int(num_steps), str(device))
+    if key not in _LIN_CACHE:
+        lin_z = torch.linspace(0.0, 1.0, num_steps, dtype=_F32)
+        lin_u = torch.linspace(0. + 0.5 / 16, 1. - 0.5 / 16, steps=16, dtype=_F32)
+        _LIN_CACHE[key] = (lin_z.to(device), lin_u.to(device))
+    return _LIN_CACHE[key]
+
+
+def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg=None, noise=None,
+                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None):
+    """One launch of the fused renderer for N rays.  Returns a dict of CUDA tensors:
+    image[N,3] weights_sum[N] depth[N] normal_map[N,3] eik[N,2] gradient_error[] (+ z_vals, weights,
+    alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices)."""
+    rays_o = _chk(rays_o.reshape(-1, 3), "rays_o")
+    rays_d = _chk(rays_d.reshape(-1, 3), "rays_d")
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    T = num_steps + upsample_steps
+    nup = upsample_steps // 16
+    lin_z, lin_u = linspace_tables(num_steps, dev)
+    res = out if out is not None else {}
+
+    def buf(name, shape, dtype=_F32):
+        t = res.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            res[name] = t
+        return t
+    o = L.ac_render_out()
+    o.image = buf("image", (N, 3)).data_ptr()
+    o.weights_sum = buf("weights_sum", (N,)).data_ptr()
+    o.depth = buf("depth", (N,)).data_ptr()
+    o.normal_map = buf("normal_map", (N, 3)).data_ptr()
+    o.eik = buf("eik", (N, 2)).data_ptr()
+    if extras:
+        o.z_vals = buf("z_vals", (N, T)).data_ptr()
+        o.weights = buf("weights", (N, T)).data_ptr()
+        o.alpha = buf("alpha", (N, T)).data_ptr()
+        o.color = buf("color", (N, T, 3)).data_ptr()
+        o.sdf = buf("sdf", (N, T)).data_ptr()
+        o.gradient = buf("gradient", (N, T, 3)).data_ptr()
+    if debug_indices:
+        o.ss_inds = buf("ss_inds", (N, max(nup, 1), 16), torch.int32).data_ptr()
+        o.sort_index = buf("sort_index", (N, max(nup, 1), 128), torch.int32).data_ptr()
+    if bg is not None:
+        bg = _chk(bg.reshape(-1, 3), "bg_color", (N, 3))
+    if noise is not None:
+        noise = _chk(noise.reshape(N, num_steps), "noise")
+    import numpy as np
+    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), float(inv_s), float(cos_anneal_ratio),
+                          float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None))
+    st = L.current_stream(dev)
+    L.check(L.lib().ac_render_rays(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), L.ptr(noise),
+                                   lin_z.data_ptr(), lin_u.data_ptr(), C.byref(o), st), "render_rays")
+    ge = buf("gradient_error", ())
+    L.check(L.lib().ac_eikonal_reduce(res["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
+    return res
+
+
+def field_sdf(field, x, bound):
+    """forward_sdf (instant_nsr.py:627-642): x [B,3] -> [B,16] (sdf, 15 features)"""
+    x = _chk(x.reshape(-1, 3), "x")
+    out = torch.empty((x.shape[0], 16), dtype=_F32, device=x.device)
+    L.check(L.lib().ac_field_sdf(C.byref(field.c), x.data_ptr(), x.shape[0], float(bound), out.data_ptr(),
+                                 L.current_stream(x.device)), "field_sdf")
+    return out
+
+
+def field_color(field, x, n, sdfout):
+    """forward_color (instant_nsr.py:644-663), use_viewdirs=False: -> rgb [B,3]"""
+    x = _chk(x.reshape(-1, 3), "x"); n = _chk(n.reshape(-1, 3), "n"); sdfout = _chk(sdfout.reshape(-1, 16), "sdfout")
+    out = torch.empty((x.shape[0], 3), dtype=_F32, device=x.device)
+    L.check(L.lib().ac_field_color(C.byref(field.c), x.data_ptr(), n.data_ptr(), sdfout.data_ptr(), x.shape[0], out.data_ptr(),
+                                   L.current_stream(x.device)), "field_color")
+    return out

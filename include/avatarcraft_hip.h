@@ -1,0 +1,181 @@
+/*
+ * include/avatarcraft_hip.h -- C ABI of libavatarcraft_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary of the AvatarCraft hot path: every entry point replaces one
+ * function that the reference binds through pybind11 from its JIT-built CUDA extensions, with
+ * the same argument meaning and order, plus (a) an explicit stream and (b) an int status
+ * instead of a C++ exception (0 = ok; non-zero = bad arguments / launch failure, message in
+ * ac_last_error(); the Python wrappers raise RuntimeError exactly where the reference's
+ * TORCH_CHECK / std::runtime_error would).
+ *
+ * Conventions (same as the reference):
+ *   - the CALLER allocates every buffer; the library never allocates user-visible memory and
+ *     keeps no pointer after the call returns (small internal scratch is per-call);
+ *   - all pointers are DEVICE pointers unless the parameter is documented "host";
+ *   - all float data is fp32, all index data int32/uint32;
+ *   - kernels are enqueued on `stream` (a hipStream_t; NULL = the null stream) and the call
+ *     returns without synchronising.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   encoder/hashencoder/src/hashencoder.h:13-14   hash_encode_forward / hash_encode_backward
+ *   encoder/shencoder/src/shencoder.h:11,14       sh_encode_forward / sh_encode_backward
+ *   raymarching/src/raymarching.h:8-17            march_rays_train, composite_rays_train_forward/
+ *                                                 _backward, march_rays, composite_rays, compact_rays
+ *   models/instant_nsr.py:133-299,358-408         NeRFRenderer.run / render (the fused path:
+ *                                                 ac_render_rays; the reference has no native
+ *                                                 entry for it -- `run_cuda` is missing)
+ */
+#ifndef AVATARCRAFT_HIP_H
+#define AVATARCRAFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ac_stream_t; /* hipStream_t */
+
+#define AC_OK 0
+#define AC_ERR_BAD_ARG 1
+#define AC_ERR_LAUNCH 2
+#define AC_MAX_LEVELS 32
+
+/* library identification / diagnostics */
+int ac_version(void);                /* ABI version, currently 1 */
+const char *ac_last_error(void);     /* message of the last failing call on this thread */
+
+/* ---- hash-grid encoder -------------------------------------------------------------------
+ * replaces hash_encode_forward (encoder/hashencoder/src/hashencoder.cu:413-436)
+ *   inputs  [B,D] in [0,1]; embeddings [sum_l T_l, C]; offsets [L+1] int32 (device);
+ *   outputs [L,B,C] (level major); dy_dx [B, L*D*C] (only written if calc_grad_inputs).
+ *   D in {2,3}, C in {1,2,4,8}, L <= AC_MAX_LEVELS, else AC_ERR_BAD_ARG
+ *   ("GridEncoding: C must be 1, 2, 4, or 8." in the reference).
+ *   S = log2(per_level_scale) as float, H = base resolution.
+ *   offsets_host: the same L+1 offsets in HOST memory (the reference reads them on the device
+ *   only; the MI355X kernels take the level table as launch constants). */
+int ac_hash_encode_forward(const float *inputs, const float *embeddings, const int32_t *offsets,
+                           const int32_t *offsets_host, float *outputs, uint32_t B, uint32_t D, uint32_t C,
+                           uint32_t L, float S, uint32_t H, int calc_grad_inputs, float *dy_dx,
+                           ac_stream_t stream);
+
+/* replaces hash_encode_backward (hashencoder.cu:438-468): grad [L,B,C]; grad_embeddings is
+ * accumulated into (caller zero-fills, hashgrid.py:61); grad_inputs [B,D] written iff
+ * calc_grad_inputs. */
+int ac_hash_encode_backward(const float *grad, const float *inputs, const float *embeddings,
+                            const int32_t *offsets, const int32_t *offsets_host, float *grad_embeddings,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                            int calc_grad_inputs, const float *dy_dx, float *grad_inputs, ac_stream_t stream);
+
+/* debugging / parity: table entry index (before *C) of every trilinear corner, [L,B,2^D] uint32,
+ * 0xffffffff for out-of-range inputs */
+int ac_hash_corner_indices(const float *inputs, const int32_t *offsets_host, uint32_t *corner_idx, uint32_t B,
+                           uint32_t D, uint32_t L, float S, uint32_t H, ac_stream_t stream);
+
+/* host helper: the per-level (scale, resolution) table every kernel uses
+ * (hashencoder.cu:122-123), computed once on the host */
+void ac_hash_level_table(uint32_t L, float S, uint32_t H, float *scale_host, uint32_t *res_host);
+
+/* ---- spherical-harmonics encoder -----------------------------------------------------------
+ * replaces sh_encode_forward / sh_encode_backward (encoder/shencoder/src/shencoder.cu:403-441)
+ *   inputs [B,3]; outputs [B, C*C] (C = degree, 1..8); dy_dx [B, 3*C*C]. */
+int ac_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D, uint32_t C,
+                         int calc_grad_inputs, float *dy_dx, ac_stream_t stream);
+int ac_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D, uint32_t C,
+                          const float *dy_dx, float *grad_inputs, ac_stream_t stream);
+
+/* ---- raymarching operators (raymarching/src/raymarching.cu) ---------------------------------
+ * Same arguments as the reference wrappers.  Slot reservation is deterministic: packed samples
+ * are laid out in ray order (an exclusive prefix sum replaces the reference's atomicAdd), so
+ * rays[N,3] = (ray id, offset, n_steps) is reproducible.  counter[2] (device) is incremented by
+ * (total steps, N) as in the reference.  scratch: device int32 buffer of >= 2N+2 elements. */
+int ac_march_rays_train(const float *rays_o, const float *rays_d, const float *grid, float mean_density,
+                        int iter_density, float bound, uint32_t N, uint32_t H, uint32_t M, float *xyzs,
+                        float *dirs, float *deltas, int32_t *rays, int32_t *counter, uint32_t perturb,
+                        int32_t *scratch, ac_stream_t stream);
+int ac_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
+                                    const int32_t *rays, float bound, uint32_t M, uint32_t N,
+                                    float *weights_sum, float *image, ac_stream_t stream);
+int ac_composite_rays_train_backward(const float *grad_weights_sum, const float *grad, const float *sigmas,
+                                     const float *rgbs, const float *deltas, const int32_t *rays,
+                                     const float *weights_sum, const float *image, float bound, uint32_t M,
+                                     uint32_t N, float *grad_sigmas, float *grad_rgbs, ac_stream_t stream);
+int ac_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                  const float *rays_o, const float *rays_d, float bound, uint32_t H, const float *grid,
+                  float mean_density, const float *near, const float *far, float *xyzs, float *dirs,
+                  float *deltas, uint32_t perturb, ac_stream_t stream);
+int ac_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, float *rays_t,
+                      const float *sigmas, const float *rgbs, const float *normals, const float *deltas,
+                      float *weights_sum, float *depth, float *image, float *normal_map, ac_stream_t stream);
+/* order-preserving compaction; scratch: >= n_alive+2 int32 */
+int ac_compact_rays(uint32_t n_alive, int32_t *rays_alive, const int32_t *rays_alive_old, float *rays_t,
+                    const float *rays_t_old, int32_t *alive_counter, int32_t *scratch, ac_stream_t stream);
+
+/* ---- fused Instant-NSR renderer --------------------------------------------------------------
+ * One launch = NeRFRenderer.run for a batch of rays (models/instant_nsr.py:133-299,
+ * render_can=True): cube near/far, uniform(+jitter) z, 4x NeuS up-sampling (up_sample,
+ * sample_pdf, cat_z_vals), hash-grid SDF MLP, finite-difference normals, colour MLP, NeuS
+ * alpha, transmittance scan and compositing, eikonal partials.  Default model only:
+ * L=16, C=2, D=3 hash grid; SDF MLP 35-64-16; colour MLP 21-64-64-3. */
+typedef struct ac_field {
+    const float *table;       /* embeddings [offsets[16], 2]                           (device) */
+    int32_t offsets[17];      /* level offsets, entries                                (host values) */
+    float S;                  /* log2(per_level_scale)  (hashgrid.py:27)                         */
+    uint32_t H;               /* base resolution                                                  */
+    const float *W1, *b1;     /* effective sdf_net.0 weight [64,35] row-major, bias [64] (device) */
+    const float *W2, *b2;     /* effective sdf_net.1 weight [16,64], bias [16]                    */
+    const float *Wc1;         /* effective color_net.0 weight [64,21]                             */
+    const float *Wc2;         /* effective color_net.1 weight [64,64]                             */
+    const float *Wc3;         /* effective color_net.2 weight [3,64]                              */
+} ac_field;
+
+typedef struct ac_render_opts {
+    int32_t n_rays;
+    int32_t num_steps;        /* coarse samples per ray: 16,32,48 or 64                           */
+    int32_t upsample_steps;   /* multiple of 16, num_steps + upsample_steps <= 128                */
+    float bound;
+    float inv_s;              /* forward_variance() = exp(10*variance).clip(1e-6,1e6)             */
+    float cos_anneal_ratio;
+    float fd_eps;             /* 0.005 * (1 - normal_epsilon_ratio)                               */
+    int32_t perturb;          /* 1: z += (noise-0.5)*sample_dist (training && perturb_overwrite)  */
+} ac_render_opts;
+
+typedef struct ac_render_out {
+    float *image;             /* [N,3]  rgb incl. background blend                                */
+    float *weights_sum;       /* [N]                                                              */
+    float *depth;             /* [N]                                                              */
+    float *normal_map;        /* [N,3]                                                            */
+    float *eik;               /* [N,2]  per-ray (sum relax*(|g|-1)^2, sum relax)                  */
+    /* optional (NULL = not written); T = num_steps + upsample_steps */
+    float *z_vals;            /* [N,T]                                                            */
+    float *weights;           /* [N,T]                                                            */
+    float *alpha;             /* [N,T]                                                            */
+    float *color;             /* [N,T,3]                                                          */
+    float *sdf;               /* [N,T]                                                            */
+    float *gradient;          /* [N,T,3]                                                          */
+    int32_t *ss_inds;         /* [N, upsample_steps/16, 16]  searchsorted indices of sample_pdf   */
+    int32_t *sort_index;      /* [N, upsample_steps/16, 128] sort permutation of cat_z_vals, -1 pad */
+} ac_render_out;
+
+/* rays_o, rays_d [N,3]; bg [N,3] or NULL (= white, bg_color None -> 1); noise [N,num_steps] U[0,1)
+ * (read iff opts->perturb); lin_z [num_steps] = torch.linspace(0,1,num_steps) and lin_u [16] =
+ * torch.linspace(0.5/16, 1-0.5/16, 16) as DEVICE arrays made by the host (instant_nsr.py:155,:34). */
+int ac_render_rays(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d,
+                   const float *bg, const float *noise, const float *lin_z, const float *lin_u,
+                   const ac_render_out *out, ac_stream_t stream);
+
+/* gradient_error = sum(relax*err) / (sum(relax) + 1e-5) over the per-ray partials, fixed order
+ * (instant_nsr.py:270-272); result: 1 float (device) */
+int ac_eikonal_reduce(const float *eik, int32_t n_rays, float *result, ac_stream_t stream);
+
+/* SDF-only / field queries used by density(), extract_geometry() and the unit tests:
+ * out16 [B,16] = forward_sdf(x) (instant_nsr.py:627-642), x [B,3] in [-bound,bound] */
+int ac_field_sdf(const ac_field *field, const float *x, uint32_t B, float bound, float *out16, ac_stream_t stream);
+/* rgb [B,3] = forward_color(x, -, n, feat) (instant_nsr.py:644-663); sdfout [B,16] as returned above */
+int ac_field_color(const ac_field *field, const float *x, const float *n, const float *sdfout, uint32_t B,
+                   float *rgb, ac_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVATARCRAFT_HIP_H */

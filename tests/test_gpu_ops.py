@@ -1,0 +1,203 @@
+"""-m gpu: the stand-alone operators (hash encoder, SH encoder, raymarching) through the reference-shaped
+Python surface (-> C ABI -> HIP), against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import load_golden, make_table
+from tests.gpu_common import assert_bitwise
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+# ------------------------------------------------------------------ hash encoder
+@pytest.mark.parametrize("D,C,L,base,log2T,B", [(3, 2, 16, 16, 19, 5000), (3, 4, 8, 4, 12, 777), (2, 2, 6, 8, 10, 300),
+                                                (3, 1, 4, 16, 14, 129), (3, 8, 3, 4, 8, 64), (2, 1, 2, 2, 6, 1)])
+def test_hash_forward_backward(oracle, D, C, L, base, log2T, B):
+    from avatarcraft_amd.encoder.hashencoder.backend import _backend
+    O = oracle
+    desired = 2048 if L == 16 else None
+    offsets, pls = O.hash_offsets(D, L, C, 1.5, base, log2T, desired)
+    S = np.float32(np.log2(pls))
+    rs = np.random.RandomState(B)
+    grid = rs.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+    x = rs.uniform(0, 1, (B, D)).astype(np.float32)
+    x[0] = 1.0
+    if B > 4:
+        x[1] = 0.0; x[2, 0] = -0.1; x[3, -1] = 1.5        # out-of-range rows -> zeros
+    out_o, dd_o, ci_o = O.hash_encode_forward(x, grid, offsets, S, base, True, True)
+    xt, gt, ot = T(x), T(grid), T(offsets)
+    out = torch.empty(L, B, C, device=DEV); dd = torch.empty(B, L * D * C, device=DEV)
+    _backend.hash_encode_forward(xt, gt, ot, out, B, D, C, L, S, base, True, dd)
+    assert_bitwise(out, out_o, "hash outputs")
+    assert_bitwise(dd, dd_o, "hash dy_dx")
+    # corner indices: bit-exact
+    from avatarcraft_amd import _lib as Lb
+    ci = torch.empty(L, B, 1 << D, dtype=torch.int32, device=DEV)
+    Lb.check(Lb.lib().ac_hash_corner_indices(xt.data_ptr(), offsets.ctypes.data, ci.data_ptr(), B, D, L, float(S), base,
+                                             Lb.current_stream()))
+    assert np.array_equal(ci.cpu().numpy().view(np.uint32), ci_o)
+    # backward: atomics => order-free accumulation, compare with a tolerance
+    g = rs.normal(0, 1, (L, B, C)).astype(np.float32)
+    gg_o, gi_o = O.hash_encode_backward(g, x, grid, offsets, S, base, dd_o)
+    gg = torch.zeros_like(gt); gi = torch.zeros_like(xt)
+    _backend.hash_encode_backward(T(g), xt, gt, ot, gg, B, D, C, L, S, base, True, dd, gi)
+    np.testing.assert_allclose(gg.cpu().numpy(), gg_o, rtol=2e-5, atol=2e-5)
+    assert_bitwise(gi, gi_o, "hash grad_inputs")
+
+
+def test_hash_module_autograd_and_errors(oracle):
+    from avatarcraft_amd.encoder import get_encoder
+    enc, dim = get_encoder("hashgrid", dict(in_dim=3, hash_num_levels=8, hash_level_dim=2, hash_per_level_scale=2.0,
+                                            hash_base_resolution=4, hash_log2_hashmap_size=12, hash_desired_resolution=None))
+    enc = enc.to(DEV)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    x = torch.rand(1000, 3, device=DEV) * 2 - 1
+    y = enc(x, size=1.0)
+    assert y.shape == (1000, 16)
+    off = enc.offsets.cpu().numpy()
+    yo, _, _ = oracle.hash_encode_forward(((x.cpu().numpy() + np.float32(1.0)) / np.float32(2.0)), enc.embeddings.detach().cpu().numpy(),
+                                          off, np.float32(np.log2(2.0)), 4)
+    assert_bitwise(y, yo.transpose(1, 0, 2).reshape(1000, 16), "HashEncoder.forward")
+    y.sum().backward()
+    assert enc.embeddings.grad is not None and float(enc.embeddings.grad.abs().sum()) > 0
+    # empty and ragged batches
+    assert enc(torch.zeros(0, 3, device=DEV)).shape == (0, 16)
+    assert enc(torch.rand(7, 5, 3, device=DEV)).shape == (7, 5, 16)
+    from avatarcraft_amd.encoder.hashencoder.backend import _backend
+    with pytest.raises(RuntimeError):      # C = 3 is not a supported level_dim ("GridEncoding: C must be 1, 2, 4, or 8.")
+        _backend.hash_encode_forward(x, torch.zeros(100, 3, device=DEV), enc.offsets, torch.empty(8, 1000, 3, device=DEV), 1000, 3, 3, 8,
+                                     1.0, 4, False, torch.empty(1, device=DEV))
+    with pytest.raises(RuntimeError):      # CPU tensor
+        _backend.hash_encode_forward(x.cpu(), enc.embeddings, enc.offsets, y, 1000, 3, 2, 8, 1.0, 4, False, torch.empty(1, device=DEV))
+
+
+# ------------------------------------------------------------------ SH encoder
+@pytest.mark.parametrize("degree", [1, 2, 4, 6, 8])
+def test_sh_forward_backward(oracle, degree):
+    from avatarcraft_amd.encoder.shencoder.backend import _backend
+    rs = np.random.RandomState(degree)
+    x = rs.normal(0, 1, (513, 3)).astype(np.float32)
+    x[:256] /= np.linalg.norm(x[:256], axis=1, keepdims=True)     # unit directions and raw (non-unit) inputs
+    out_o, dd_o = oracle.sh_encode_forward(x, degree, True)
+    xt = T(x); out = torch.empty(513, degree ** 2, device=DEV); dd = torch.empty(513, 3 * degree ** 2, device=DEV)
+    _backend.sh_encode_forward(xt, out, 513, 3, degree, True, dd)
+    assert_bitwise(out, out_o, "sh outputs"); assert_bitwise(dd, dd_o, "sh dy_dx")
+    g = rs.normal(0, 1, (513, degree ** 2)).astype(np.float32)
+    gi_o = oracle.sh_encode_backward(g, x, degree, dd_o)
+    gi = torch.zeros_like(xt)
+    _backend.sh_encode_backward(T(g), xt, 513, 3, degree, dd, gi)
+    assert_bitwise(gi, gi_o, "sh grad_inputs")
+
+
+def test_sh_module(oracle):
+    from avatarcraft_amd.encoder import get_encoder
+    enc, dim = get_encoder("sphere_harmonics", dict(in_dim=3))
+    assert dim == 16
+    d = torch.randn(100, 3, device=DEV, requires_grad=True)
+    y = enc(d)
+    y.square().sum().backward()
+    # analytic Jacobian vs central differences of the oracle (fp64-ish check of dy_dx)
+    x = d.detach().cpu().numpy()
+    _, dd = oracle.sh_encode_forward(x, 4, True)
+    eps = 1e-3
+    for a in range(3):
+        xp, xm = x.copy(), x.copy(); xp[:, a] += eps; xm[:, a] -= eps
+        fd = (oracle.sh_encode_forward(xp, 4)[0].astype(np.float64) - oracle.sh_encode_forward(xm, 4)[0]) / (2 * eps)
+        assert np.abs(fd - dd.reshape(100, 3, 16)[:, a]).max() < 5e-2
+    with pytest.raises(AssertionError):
+        from avatarcraft_amd.encoder.shencoder import SHEncoder
+        SHEncoder(3, 9)
+
+
+# ------------------------------------------------------------------ raymarching
+def _sphere_grid(H=129, bound=1.6, r=0.5):
+    ax = np.linspace(-bound, bound, H, dtype=np.float32)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    return (100.0 * ((X ** 2 + Y ** 2 + Z ** 2) < r * r)).astype(np.float32)
+
+
+def test_march_rays_train_kat_and_oracle(oracle):
+    """SURVEY A.4 known answer + exact equality with the oracle (packed layout, ray triples, samples)."""
+    import avatarcraft_amd.raymarching as RM
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))["march_rays_train"]
+    r = load_golden("rays.npz"); o, d = r["kat64_o"], r["kat64_d"]
+    grid = _sphere_grid()
+    for perturb in (0, 1):
+        xo, do_, dlo, ro, co = oracle.march_rays_train(o, d, grid, float(grid.mean()), 1.6, perturb=perturb)
+        counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+        x, dd, dl, rays = RM.march_rays_train(T(o), T(d), 1.6, T(grid), float(grid.mean()), 0, counter, -1, bool(perturb), -1, True)
+        torch.cuda.synchronize()
+        assert counter.cpu().tolist() == co.tolist()
+        assert np.array_equal(rays.cpu().numpy(), ro)
+        m = int(co[0])
+        assert_bitwise(x[:m], xo[:m], "xyzs"); assert_bitwise(dd[:m], do_[:m], "dirs"); assert_bitwise(dl[:m], dlo[:m], "deltas")
+        if not perturb:
+            assert co.tolist() == kat["counter"]
+            assert int((ro[:, 2] > 0).sum()) == kat["rays_hit"] and int(ro[:, 2].max()) == kat["max_steps"]
+            assert ro[2080].tolist() == kat["centre_ray"]
+
+
+def test_composite_train_forward_backward(oracle):
+    import avatarcraft_amd.raymarching as RM
+    rs = np.random.RandomState(3)
+    N = 300
+    steps = rs.randint(0, 60, N).astype(np.int32); steps[5] = 0
+    offs = np.concatenate([[0], np.cumsum(steps)[:-1]]).astype(np.int32)
+    M = int(steps.sum()) + 1
+    perm = rs.permutation(N).astype(np.int32)
+    rays = np.stack([perm, offs, steps], 1).astype(np.int32)
+    sig = rs.uniform(0, 0.4, M).astype(np.float32); rgb = rs.uniform(0, 1, (M, 3)).astype(np.float32)
+    dl = rs.uniform(0.001, 0.01, M).astype(np.float32)
+    ws_o, img_o = oracle.composite_rays_train_forward(sig, rgb, dl, rays)
+    sg = T(sig).requires_grad_(True); rg = T(rgb).requires_grad_(True)
+    ws, img = RM.composite_rays_train(sg, rg, T(dl), T(rays), 1.6)
+    assert_bitwise(ws, ws_o, "weights_sum"); assert_bitwise(img, img_o, "image")
+    gws = rs.normal(0, 1, N).astype(np.float32); gimg = rs.normal(0, 1, (N, 3)).astype(np.float32)
+    (ws * T(gws)).sum().add((img * T(gimg)).sum()).backward()
+    gs_o, gc_o = oracle.composite_rays_train_backward(gws, gimg, sig, rgb, dl, rays, ws_o, img_o)
+    assert_bitwise(sg.grad, gs_o, "grad_sigmas"); assert_bitwise(rg.grad, gc_o, "grad_rgbs")
+    # KAT: alpha = 0.05 constant over 163 steps -> 1 - 0.95^163
+    s = np.full(164, 0.05, np.float32); c = np.full((164, 3), 0.5, np.float32)
+    w1, i1 = RM.composite_rays_train(T(s), T(c), T(s), T(np.array([[0, 0, 163]], np.int32)), 1.6)
+    assert abs(float(w1[0]) - 0.9997662) < 2e-6 and abs(float(i1[0, 0]) - 0.5 * 0.9997662) < 2e-6
+
+
+def test_inference_march_composite_compact(oracle):
+    import avatarcraft_amd.raymarching as RM
+    r = load_golden("rays.npz"); o, d = r["kat64_o"], r["kat64_d"]
+    grid = _sphere_grid()
+    N = o.shape[0]
+    rs = np.random.RandomState(9)
+    alive = rs.permutation(N)[:1500].astype(np.int32)
+    near = np.full(N, 0.05, np.float32); far = np.full(N, 3.0, np.float32)
+    t0 = np.full(1500, 0.6, np.float32)
+    for perturb in (0, 3):
+        xo, do_, dlo = oracle.march_rays(1500, 8, alive, t0, o, d, 1.6, grid, float(grid.mean()), near, far, perturb)
+        x, dd, dl = RM.march_rays(1500, 8, T(alive), T(t0), T(o), T(d), 1.6, T(grid), float(grid.mean()), T(near), T(far), -1, perturb)
+        assert_bitwise(x, xo, "xyzs"); assert_bitwise(dl, dlo, "deltas"); assert_bitwise(dd, do_, "dirs")
+    M = 1500 * 8
+    sig = rs.uniform(0, 0.7, M).astype(np.float32); rgb = rs.uniform(0, 1, (M, 3)).astype(np.float32)
+    nrm = rs.normal(0, 1, (M, 3)).astype(np.float32)
+    wo, dpo, imo, nmo = (np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32))
+    rt_o = t0.copy()
+    oracle.composite_rays(1500, 8, alive, rt_o, sig, rgb, nrm, dlo, wo, dpo, imo, nmo)
+    w, dp, im, nm, rt = (torch.zeros(N, device=DEV), torch.zeros(N, device=DEV), torch.zeros(N, 3, device=DEV),
+                         torch.zeros(N, 3, device=DEV), T(t0))
+    RM.composite_rays(1500, 8, T(alive), rt, T(sig), T(rgb), T(nrm), T(dlo), w, dp, im, nm)
+    for a, b, n in ((w, wo, "weights"), (dp, dpo, "depth"), (im, imo, "image"), (nm, nmo, "normal"), (rt, rt_o, "rays_t")):
+        assert_bitwise(a, b, n)
+    ra_o, rtt_o, cnt_o = oracle.compact_rays(1500, alive, rt_o)
+    ra = torch.zeros(1500, dtype=torch.int32, device=DEV); rtt = torch.zeros(1500, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    RM.compact_rays(1500, ra, T(alive), rtt, rt, cnt)
+    assert int(cnt[0]) == cnt_o and 0 < cnt_o < 1500
+    assert np.array_equal(ra.cpu().numpy()[:cnt_o], ra_o[:cnt_o]); assert_bitwise(rtt[:cnt_o], rtt_o[:cnt_o], "rays_t")

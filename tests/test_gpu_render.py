@@ -1,0 +1,148 @@
+"""-m gpu: the fused renderer (ac_render_rays through the C ABI) against the CPU oracle, bit for bit,
+and against the reference-generated goldens within tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import load_golden, make_rays
+from tests.gpu_common import device_field, oracle_field, assert_bitwise
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_KEYS = ["image", "weights_sum", "depth", "normal_map", "eik", "z_vals", "weights", "alpha", "color", "sdf", "gradient"]
+
+
+@pytest.fixture(scope="module")
+def env(oracle):
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    p = load_golden("nsr_params.npz")
+    f, table = device_field(p)
+    return dict(p=p, f=f, of=oracle_field(p, table), O=oracle)
+
+
+def _run_both(env, ro, rd, T0, up, bg=None, noise=None, car=1.0):
+    from avatarcraft_amd import nsr_ops
+    d = "cuda:0"
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(d)
+    g = nsr_ops.render_rays(env["f"], t(ro), t(rd), T0, up, 1.6, float(env["p"]["inv_s"]), bg=t(bg), noise=t(noise),
+                            cos_anneal_ratio=car, extras=True, debug_indices=True)
+    torch.cuda.synchronize()
+    r = env["O"].render_rays(env["of"], ro, rd, T0, up, 1.6, float(env["p"]["inv_s"]), bg=bg, noise=noise, cos_anneal_ratio=car)
+    return g, r
+
+
+def _compare_bitwise(g, r, up):
+    for k in FLOAT_KEYS:
+        assert_bitwise(g[k], r[k], k)
+    if up:
+        assert_bitwise(g["ss_inds"], r["ss_inds"], "ss_inds")
+        assert_bitwise(g["sort_index"], r["sort_index"], "sort_index")
+    assert_bitwise(g["gradient_error"].reshape(1), np.float32([r["gradient_error"]]), "gradient_error")
+
+
+@pytest.mark.parametrize("name", ["eval_64_64", "train_64_64", "eval_32_32", "eval_64_0"])
+def test_render_bitwise_vs_oracle_on_golden_inputs(env, name):
+    gd = load_golden(f"run_{name}.npz")
+    g, r = _run_both(env, gd["rays_o"], gd["rays_d"], int(gd["num_steps"]), int(gd["upsample_steps"]), gd["bg"], gd.get("noise"))
+    _compare_bitwise(g, r, int(gd["upsample_steps"]))
+
+
+@pytest.mark.parametrize("name", ["eval_64_64", "train_64_64", "eval_32_32", "eval_64_0"])
+def test_render_vs_reference_golden(env, name):
+    """GPU output against the reference's own run() output (tests/golden/make_golden.py)."""
+    gd = load_golden(f"run_{name}.npz")
+    g, _ = _run_both(env, gd["rays_o"], gd["rays_d"], int(gd["num_steps"]), int(gd["upsample_steps"]), gd["bg"], gd.get("noise"))
+    c = lambda k: g[k].cpu().numpy()
+    assert np.abs(c("image") - gd["image"]).max() <= 1e-3          # north-star tolerance: RGB within 1e-3 L_inf
+    assert np.abs(c("weights_sum") - gd["weights_sum"]).max() <= 1e-3
+    assert np.abs(c("depth") - gd["depth"]).max() <= 1e-3
+    assert np.abs(c("normal_map") - gd["normal_map"]).max() <= 2e-3
+    assert abs(float(g["gradient_error"]) - float(gd["gradient_error"])) <= 1e-4
+    up = int(gd["upsample_steps"]) // 16
+    if up:   # sample indices bit-exact on identical seeds
+        assert np.array_equal(c("ss_inds"), gd["ss_inds"])
+        assert np.array_equal(c("sort_index")[:, :up], gd["sort_index"][:, :up])
+        assert np.abs(c("z_vals") - gd["z_vals"]).max() <= 2e-3
+
+
+def test_render_bitwise_random_rays_4096(env):
+    """a full 4096-ray batch (64x64 view), eval and perturbed"""
+    ro, rd = make_rays(64, 64, dist=1.7, f=50.0)
+    rs = np.random.RandomState(11)
+    bg = rs.uniform(0, 1, (4096, 3)).astype(np.float32)
+    sel = rs.choice(4096, 192, replace=False)     # the oracle is ~15 ms/ray: check a random subset bit for bit
+    from avatarcraft_amd import nsr_ops
+    d = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(d)
+    noise = rs.uniform(0, 1, (4096, 64)).astype(np.float32)
+    for nz in (None, noise):
+        g = nsr_ops.render_rays(env["f"], t(ro), t(rd), 64, 64, 1.6, float(env["p"]["inv_s"]), bg=t(bg),
+                                noise=None if nz is None else t(nz), extras=True, debug_indices=True)
+        torch.cuda.synchronize()
+        r = env["O"].render_rays(env["of"], ro[sel], rd[sel], 64, 64, 1.6, float(env["p"]["inv_s"]), bg=bg[sel],
+                                 noise=None if nz is None else nz[sel])
+        for k in FLOAT_KEYS[:4] + FLOAT_KEYS[5:]:
+            assert_bitwise(g[k][torch.from_numpy(sel).to(d)], r[k], k)
+        assert_bitwise(g["ss_inds"][torch.from_numpy(sel).to(d)], r["ss_inds"], "ss_inds")
+        assert_bitwise(g["sort_index"][torch.from_numpy(sel).to(d)], r["sort_index"], "sort_index")
+
+
+def test_render_rough_field_and_anneal(oracle):
+    """amplitude-0.5 random table (|grad| ~ 5, worst-case conditioning) and cos_anneal_ratio != 1"""
+    p = load_golden("nsr_params.npz")
+    f, table = device_field(p, rough=True)
+    env = dict(p=p, f=f, of=oracle_field(p, table), O=oracle)
+    ro, rd = make_rays(8, 8, dist=1.5, f=5.0, jitter_seed=5)
+    g, r = _run_both(env, ro, rd, 48, 32, None, None, car=0.3)
+    _compare_bitwise(g, r, 32)
+
+
+def test_render_properties_full_size(env):
+    """size-independent properties at BASELINE size (256x256 = 16 batches of 4096 rays)"""
+    from avatarcraft_amd import nsr_ops
+    ro, rd = make_rays(256, 256, dist=1.7, f=200.0)
+    d = "cuda:0"
+    ro_t, rd_t = torch.from_numpy(ro).to(d), torch.from_numpy(rd).to(d)
+    outs = []
+    for i in range(0, 65536, 4096):
+        o = nsr_ops.render_rays(env["f"], ro_t[i:i + 4096], rd_t[i:i + 4096], 64, 64, 1.6, float(env["p"]["inv_s"]), extras=True)
+        outs.append({k: v.clone() for k, v in o.items()})
+    torch.cuda.synchronize()
+    z = torch.cat([o["z_vals"] for o in outs]); w = torch.cat([o["weights"] for o in outs]); a = torch.cat([o["alpha"] for o in outs])
+    ws = torch.cat([o["weights_sum"] for o in outs]); img = torch.cat([o["image"] for o in outs])
+    assert torch.isfinite(img).all() and torch.isfinite(z).all()
+    assert (z[:, 1:] >= z[:, :-1]).all()                                  # sortedness of the merged samples
+    assert (a >= 0).all() and (a <= 1).all() and (w >= 0).all()
+    assert (ws <= 1 + 1e-4).all() and (img >= -1e-6).all() and (img <= 1 + 1e-4).all()
+    # batching invariance: one 8192-ray launch == two 4096-ray launches, bit for bit
+    o2 = nsr_ops.render_rays(env["f"], ro_t[:8192], rd_t[:8192], 64, 64, 1.6, float(env["p"]["inv_s"]))
+    torch.cuda.synchronize()
+    assert torch.equal(o2["image"], torch.cat([outs[0]["image"], outs[1]["image"]]))
+
+
+def test_render_bad_arguments(env):
+    from avatarcraft_amd import nsr_ops
+    ro = torch.zeros(4, 3, device="cuda:0"); rd = torch.ones(4, 3, device="cuda:0")
+    with pytest.raises(RuntimeError):
+        nsr_ops.render_rays(env["f"], ro, rd, 60, 64, 1.6, 1.0)
+    with pytest.raises(RuntimeError):
+        nsr_ops.render_rays(env["f"], ro, rd, 64, 80, 1.6, 1.0)
+    with pytest.raises(RuntimeError):
+        nsr_ops.render_rays(env["f"], ro.cpu(), rd, 64, 64, 1.6, 1.0)
+    out = nsr_ops.render_rays(env["f"], ro[:0], rd[:0], 64, 64, 1.6, 1.0)   # empty batch is fine
+    assert out["image"].shape == (0, 3)
+
+
+def test_field_sdf_color_bitwise(env):
+    from avatarcraft_amd import nsr_ops
+    fp = load_golden("field_points.npz")
+    x = torch.from_numpy(fp["pts"]).to("cuda:0")
+    s = nsr_ops.field_sdf(env["f"], x, 1.6)
+    so = env["of"].sdf(fp["pts"], 1.6)
+    assert_bitwise(s, so, "forward_sdf")
+    assert np.abs(s.cpu().numpy() - fp["sdf"]).max() < 5e-6          # vs the reference's forward_sdf
+    n = torch.from_numpy(fp["normal"]).to("cuda:0")
+    c = nsr_ops.field_color(env["f"], x, n, s)
+    co = env["of"].color(fp["pts"], fp["normal"], so)
+    assert_bitwise(c, co, "forward_color")
+    assert np.abs(c.cpu().numpy() - fp["color"]).max() < 5e-6        # vs the reference's forward_color

@@ -124,7 +124,7 @@ def selfcheck():
     assert err < 1e-9, f"SH basis not orthonormal: {err}"
     return err
 
-def emit(path, guard):
+def emit(path, guard, qual="static const"):
     kinds = []  # 4 kinds: value, d/dx, d/dy, d/dz
     for axis in (None, 0, 1, 2):
         offs, mono = [0], []
@@ -139,11 +139,11 @@ def emit(path, guard):
                 " * 64 basis functions (degree 1..8); kind 0 = value, 1..3 = d/dx, d/dy, d/dz. */\n")
         f.write(f"#ifndef {guard}\n#define {guard}\n")
         for ki, (offs, mono) in enumerate(kinds):
-            f.write(f"static const unsigned short AC_SH_OFF{ki}[65] = {{{','.join(map(str, offs))}}};\n")
-            f.write(f"static const float AC_SH_COEF{ki}[{max(1,len(mono))}] = {{\n")
+            f.write(f"{qual} unsigned short AC_SH_OFF{ki}[65] = {{{','.join(map(str, offs))}}};\n")
+            f.write(f"{qual} float AC_SH_COEF{ki}[{max(1,len(mono))}] = {{\n")
             f.write(",\n".join("  " + ", ".join(f"{float(m[0]).hex()}f" for m in mono[i:i + 4]) for i in range(0, len(mono), 4)))
             f.write("\n};\n")
-            f.write(f"static const unsigned char AC_SH_EXP{ki}[{max(1,len(mono))}][3] = {{\n")
+            f.write(f"{qual} unsigned char AC_SH_EXP{ki}[{max(1,len(mono))}][3] = {{\n")
             f.write(",\n".join("  " + ", ".join("{%d,%d,%d}" % m[1:] for m in mono[i:i + 8]) for i in range(0, len(mono), 8)))
             f.write("\n};\n")
         f.write("#endif\n")
@@ -152,5 +152,5 @@ if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     print("orthonormality max err", selfcheck())
     emit(os.path.join(root, "oracle", "ac_sh_table.h"), "AC_SH_TABLE_ORACLE_H")
-    emit(os.path.join(root, "avatarcraft_amd", "csrc", "ac_sh_table.hpp"), "AC_SH_TABLE_HIP_HPP")
+    emit(os.path.join(root, "avatarcraft_amd", "csrc", "ac_sh_table.hpp"), "AC_SH_TABLE_HIP_HPP", "static __device__ const")
     print("written")
