@@ -69,7 +69,7 @@ def linspace_tables(num_steps, device):
 
 
 def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg=None, noise=None,
-                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None):
+                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None, events=None):
     """One launch of the fused renderer for N rays.  Returns a dict of CUDA tensors:
     image[N,3] weights_sum[N] depth[N] normal_map[N,3] eik[N,2] gradient_error[] (+ z_vals, weights,
     alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices)."""
@@ -112,8 +112,12 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), float(inv_s), float(cos_anneal_ratio),
                           float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None))
     st = L.current_stream(dev)
+    if events is not None:          # (start, end) torch.cuda.Event pair around the render kernel only (bench.py roofline)
+        events[0].record()
     L.check(L.lib().ac_render_rays(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), L.ptr(noise),
                                    lin_z.data_ptr(), lin_u.data_ptr(), C.byref(o), st), "render_rays")
+    if events is not None:
+        events[1].record()
     ge = buf("gradient_error", ())
     L.check(L.lib().ac_eikonal_reduce(res["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
     return res

@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the AvatarCraft hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): render_canonical.py 256x256, hash-grid Instant-NSR, 64+64 samples per
+ray, eval mode, white background, 16 batches of 4096 rays per image (render_utils.py:514-600).
+One STEP = one pass of the hot path (NeRFRenderer.run, here one ac_render_rays launch + the eikonal
+reduce) over one 4096-ray batch; step k renders batch k % 16 of the view.  Inputs (rays, 49 MB hash table,
+MLP weights) are resident in HBM before the timed region.  value = rays / s over all ranks (weak scaling:
+every rank renders its own view, no data-path collective -- rays are independent).
+
+Printed JSON (rank 0, one line) carries the contract fields plus
+  roofline     : dominant kernel (render_rays_kernel) against the HBM roofline with the ALGORITHMIC bytes of
+                 SURVEY 8(d): 1 032 192 gather bytes per ray (1008 hash evals x 1024 B) x 4096 rays per launch,
+                 divided by the mean launch duration measured with HIP events on the launch stream.
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm; OpenMP over rays) timed on this
+                 host on a bounded sample of the same workload.  A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+RAYS_PER_BATCH = 4096
+H = W = 256
+NUM_STEPS, UPSAMPLE_STEPS = 64, 64
+BYTES_PER_RAY = 1008 * 1024          # 1008 hash-grid evaluations x (16 levels x 8 corners x 2 ch x 4 B)
+FLOP_PER_RAY = 1008 * 6528 + 128 * 11264
+HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def make_inputs(device, rank):
+    from tests.common import load_golden, make_rays
+    from tests.gpu_common import device_field
+    p = load_golden("nsr_params.npz")
+    field, table = device_field(p, device=device)
+    # camera on the 360-degree path of render_canonical.py (dist 1.7, f = 0.78125*256 = 200), one view per rank
+    yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
+    ro, rd = make_rays(H, W, dist=1.7, f=200.0, yaw=yaw, pitch=0.0)
+    return p, field, table, ro, rd
+
+
+def cpu_baseline(p, table, ro, rd, budget_s=12.0):
+    """time the CPU oracle on a bounded, strided sample of the same rays"""
+    from oracle import oracle as O
+    from tests.gpu_common import oracle_field
+    of = oracle_field(p, table)
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    idx = np.arange(0, ro.shape[0], ro.shape[0] // 64)[:64]
+    t0 = time.time(); O.render_rays(of, ro[idx], rd[idx], NUM_STEPS, UPSAMPLE_STEPS, 1.6, float(p["inv_s"]), extras=False); dt = time.time() - t0
+    n = int(min(ro.shape[0], max(64, (budget_s / max(dt, 1e-3)) * 64)))
+    n = (n // 64) * 64
+    idx = np.arange(0, ro.shape[0], max(1, ro.shape[0] // n))[:n]
+    t0 = time.time(); O.render_rays(of, ro[idx], rd[idx], NUM_STEPS, UPSAMPLE_STEPS, 1.6, float(p["inv_s"]), extras=False); dt = time.time() - t0
+    return dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
+                sample=f"{n} rays (every {max(1, ro.shape[0] // n)}-th ray of the 256x256 view), 64+64 samples, {dt:.1f} s wall, OpenMP over rays")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); the hot path has no CPU fallback")
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from avatarcraft_amd import nsr_ops
+    p, field, table, ro, rd = make_inputs(dev, rank)
+    ro_t, rd_t = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    inv_s = float(p["inv_s"])
+    nb = (H * W) // RAYS_PER_BATCH
+    outs = [dict() for _ in range(nb)]           # output buffers allocated once (caller-owned, as in the reference)
+
+    def step(k, ev=None):
+        b = k % nb
+        sl = slice(b * RAYS_PER_BATCH, (b + 1) * RAYS_PER_BATCH)
+        nsr_ops.render_rays(field, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=outs[b], events=ev)
+
+    for k in range(a.warmup):
+        step(k)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(k, evs[k])
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
+
+    if rank == 0:
+        total_rays = world * a.steps * RAYS_PER_BATCH
+        achieved = BYTES_PER_RAY * RAYS_PER_BATCH / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("render_rays_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "rays/sec, 4096-ray batch, 256x256 render (64+64 samples/ray)", "value": total_rays / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "render_canonical 256x256, hash-grid Instant-NSR, 64+64 samples/ray, 16 x 4096-ray batches, eval, 1 view per rank",
+                       "rays_per_step": RAYS_PER_BATCH, "table_mb": round(table.nbytes / 1e6, 2), "parallelism": f"dp{world} (independent views, no collective)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "render_rays_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_RAY * RAYS_PER_BATCH,
+                         "mfma_f32_tflops": FLOP_PER_RAY * RAYS_PER_BATCH / (kern_ms * 1e-3) / 1e12, "mfma_f32_peak_tflops": 157.3},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(p, table, ro, rd)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
