@@ -1,0 +1,114 @@
+"""CPU: host-side logic and the C-ABI library (loads, exports every symbol of include/avatarcraft_hip.h;
+no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from avatarcraft_amd import build as hb, _lib
+    hb.build()
+    hdr = open(os.path.join(ROOT, "include", "avatarcraft_hip.h")).read()
+    declared = set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ac_field", "ac_render_opts", "ac_render_out"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.ac_version() == 1
+    # host helper needs no GPU: level table == oracle's == SURVEY Appendix B
+    scale = (ctypes.c_float * 16)(); res = (ctypes.c_uint32 * 16)()
+    S = float(np.float32(np.log2(1.381912879967776)))
+    lib.ac_hash_level_table(16, S, 16, ctypes.cast(scale, ctypes.c_void_p), ctypes.cast(res, ctypes.c_void_p))
+    from oracle import oracle as O
+    so, ro = O.hash_level_table(16, np.float32(S), 16)
+    assert list(scale) == so.tolist() and list(res) == ro.tolist() and scale[15] == 2047.0
+
+
+def test_struct_layout_matches_header():
+    from avatarcraft_amd import _lib
+    assert ctypes.sizeof(_lib.ac_render_opts) == 32
+    assert ctypes.sizeof(_lib.ac_render_out) == 13 * 8
+    assert _lib.ac_field.offsets.offset == 8 and _lib.ac_field.S.offset == 8 + 17 * 4 and _lib.ac_field.W1.offset == 88
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from avatarcraft_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_ops_reject_cpu_tensors():
+    from avatarcraft_amd import nsr_ops
+    from avatarcraft_amd.encoder.hashencoder.backend import _backend
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        nsr_ops._chk(torch.zeros(3, 3), "x")
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        _backend.hash_encode_forward(torch.zeros(1, 3), torch.zeros(4, 2), torch.zeros(2, dtype=torch.int32), torch.zeros(1, 1, 2),
+                                     1, 3, 2, 1, 1.0, 2, False, torch.zeros(1))
+
+
+def test_encoder_surface_matches_reference_facts():
+    """get_encoder / HashEncoder bookkeeping against facts recorded from the reference's Python (encoder_facts.npz)."""
+    from avatarcraft_amd.encoder import get_encoder
+    g = load_golden("encoder_facts.npz")
+    cfgs = {"default": dict(hash_num_levels=16, hash_level_dim=2, hash_per_level_scale=1.3819, hash_base_resolution=16,
+                            hash_log2_hashmap_size=19, hash_desired_resolution=2048),
+            "small": dict(hash_num_levels=8, hash_level_dim=4, hash_per_level_scale=2.0, hash_base_resolution=4,
+                          hash_log2_hashmap_size=12, hash_desired_resolution=None)}
+    for tag, cfg in cfgs.items():
+        enc, dim = get_encoder("hashgrid", dict(in_dim=3, **cfg))
+        assert np.array_equal(enc.offsets.numpy(), g[f"{tag}_offsets"]) and dim == int(g[f"{tag}_dim"])
+        assert float(enc.per_level_scale) == float(g[f"{tag}_pls"]) and int(enc.n_params) == int(g[f"{tag}_nparams"])
+        assert enc.embeddings.shape == (int(g[f"{tag}_offsets"][-1]), cfg["hash_level_dim"])
+        assert float(enc.embeddings.abs().max()) <= 1e-4
+    fe, fdim = get_encoder("frequency", dict(in_dim=3, freq_multires=6))
+    assert fdim == int(g["freq_dim"])
+    assert np.array_equal(fe(torch.from_numpy(g["freq_in"])).numpy(), g["freq_out"])
+    sh, shdim = get_encoder("sh", dict(in_dim=3))
+    assert shdim == 16
+    with pytest.raises(NotImplementedError):
+        get_encoder("tiled", {})
+
+
+def test_bench_refuses_to_run_without_gpu():
+    import subprocess, sys
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def test_dropin_registers_reference_module_names():
+    import sys
+    import avatarcraft_amd.dropin as d
+    names = d.install()
+    try:
+        import encoder, raymarching                      # noqa: F401  (the reference's top-level names)
+        from encoder import get_encoder
+        from encoder.hashencoder import HashEncoder
+        from encoder.shencoder import SHEncoder
+        from encoder.hashencoder.backend import _backend as hb
+        from raymarching.backend import _backend as rb
+        assert HashEncoder.__module__.startswith("avatarcraft_amd") and SHEncoder.__module__.startswith("avatarcraft_amd")
+        for fn in ("hash_encode_forward", "hash_encode_backward"):
+            assert hasattr(hb, fn)
+        for fn in ("march_rays_train", "composite_rays_train_forward", "composite_rays_train_backward", "march_rays",
+                   "composite_rays", "compact_rays"):
+            assert hasattr(rb, fn)
+        for fn in ("march_rays_train", "composite_rays_train", "march_rays", "composite_rays", "compact_rays"):
+            assert hasattr(raymarching, fn)
+        assert "encoder.freq_encoder" in names
+    finally:
+        d.uninstall()
+    assert "encoder" not in sys.modules
