@@ -78,12 +78,53 @@ __device__ __forceinline__ float dv_log1p(float x)
     return fma_(s, hfsq + R, fma_(dk, ln2_lo, c)) - hfsq + f + dk * ln2_hi;
 }
 
-// torch.nn.Softplus(beta=100): reference models/instant_nsr.py:231,591
-__device__ __forceinline__ float dv_softplus100(float x)
+// exp(-a), a >= 0, result in (0,1]; 0 above a = 82 (same algorithm as dv_exp, single power-of-two scale)
+__device__ __forceinline__ float dv_exp_neg(float a)
 {
-    float t = x * 100.0f;
-    if (t > 20.0f) return x;
-    return dv_log1p(dv_exp(t)) / 100.0f;
+    const float magic = 12582912.0f;
+    float t = fma_(a, -1.44269504f, magic);
+    float n = t - magic;
+    float r = fma_(n, -0.693359375f, -a);
+    r = fma_(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float e = fma_(p, r2, r) + 1.0f;
+    float u = e * bits2f((uint32_t)((int)n + 127) << 23);
+    return (a <= 82.0f) ? u : ((a != a) ? a : 0.0f);
+}
+
+// a / 100 with three fp32 ops; equal to the correctly rounded IEEE quotient for every a in {0} U [2^-120, 2^10)
+// (exhaustive proof: tools/verify_div100.c).  Every softplus argument lies in that set.
+__device__ __forceinline__ float dv_div100(float a)
+{
+    const float y = 0x1.47ae14p-7f;                 // RN(1/100)
+    float q0 = a * y;
+    float r = fma_(-q0, 100.0f, a);
+    return fma_(r, y, q0);
+}
+
+// torch.nn.Softplus(beta=100, threshold=20) (reference models/instant_nsr.py:231,591) in the overflow-free form
+//   log1p(exp(t)) = max(t,0) + u*Q(u), u = exp(-|t|); Q = 8 x degree-5 polynomial table (ac_sp_table.hpp).
+// spq: the table, [8][8] floats (LDS or global).  Bit-identical to oracle/ac_math.h: orc_softplus100.
+__device__ __forceinline__ float dv_softplus100(const float *__restrict__ spq, float x)
+{
+    const float t = x * 100.0f;
+    const float u = dv_exp_neg(__builtin_fabsf(t));
+    int idx = (int)(u * 8.0f);
+    idx = idx > 7 ? 7 : idx;
+    const float v = u - ((float)idx + 0.5f) * 0.125f;
+    const float4 c03 = *reinterpret_cast<const float4 *>(spq + idx * 8);
+    const float2 c45 = *reinterpret_cast<const float2 *>(spq + idx * 8 + 4);
+    float q = c45.y;
+    q = fma_(q, v, c45.x); q = fma_(q, v, c03.w); q = fma_(q, v, c03.z); q = fma_(q, v, c03.y); q = fma_(q, v, c03.x);
+    const float s = (t > 0.0f ? t : 0.0f) + u * q;
+    const float res = dv_div100(s);
+    return (t > 20.0f) ? x : ((t != t) ? t : res);
 }
 
 // torch.sigmoid

@@ -28,6 +28,7 @@
 // to oracle/ac_oracle.c:orc_render_rays on the same inputs.
 #include "ac_common.hpp"
 #include "ac_devmath.hpp"
+#include "ac_sp_table.hpp"
 
 using namespace acdev;
 
@@ -52,12 +53,17 @@ constexpr int OFF_B1 = OFF_C3F + 16 * 64;        // [64]
 constexpr int OFF_B2 = OFF_B1 + 64;              // [16]
 constexpr int OFF_LVL = OFF_B2 + 16;             // [16 levels][8 words]
 constexpr int OFF_LIN = OFF_LVL + 16 * 8;        // lin_z[64] + lin_u[16]
-constexpr int OFF_WAVE = OFF_LIN + 80;           // per-wave slabs start here
+constexpr int OFF_SPQ = OFF_LIN + 80;           // softplus Q table [8][8]
+constexpr int OFF_WAVE = OFF_SPQ + 64;          // per-wave slabs start here
 constexpr int WAVE_SLAB = 2 * MAXT * 2 + MAXT + 16 + 16;   // zs[2][128], sd[2][128], cdf[128], znew[16], pad
 constexpr int LDS_FLOATS = OFF_WAVE + WAVES_PER_BLOCK * WAVE_SLAB;
 static_assert(OFF_WAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
 
-struct LevelRec { float scale; uint32_t stride1, offset, size, hashed, mask, pad0, pad1; };
+// per-level launch constants: index = (hashed ? x ^ y*my ^ z*mz : x + y*my + z*mz) & mask [% wsize if wsize]
+// (my,mz) = (P1,P2) for hashed levels, (res+1, (res+1)^2) for dense ones; mask = size-1 for power-of-two hashed
+// levels, ~0 otherwise (a dense index is < size by construction); wsize = size only for a hashed level whose size
+// is not a power of two (never the case for tables allocated by HashEncoder, handled for completeness).
+struct LevelRec { float scale; uint32_t my, mz, offset, mask, hashed, wsize, pad; };
 
 struct RenderArgs {
     const float *table;
@@ -67,6 +73,7 @@ struct RenderArgs {
     ac_render_out out;
     LevelRec lvl[16];
     int n_rays, T0, nup;
+    int jmode[4];          // per gather round j (levels 4j..4j+3): 0 all dense, 1 all hashed, 2 mixed
     float bound, two_bound, inv_s, car, one_m_car, eps;
     int perturb;
 };
@@ -141,15 +148,16 @@ __device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
 #pragma unroll
         for (int l = 0; l < 16; ++l) {
             if (threadIdx.x == (unsigned)l) {
-                lw[8 * l + 0] = __float_as_uint(a.lvl[l].scale); lw[8 * l + 1] = a.lvl[l].stride1;
-                lw[8 * l + 2] = a.lvl[l].offset; lw[8 * l + 3] = a.lvl[l].size;
-                lw[8 * l + 4] = a.lvl[l].hashed; lw[8 * l + 5] = a.lvl[l].mask;
-                lw[8 * l + 6] = 0u; lw[8 * l + 7] = 0u;
+                lw[8 * l + 0] = __float_as_uint(a.lvl[l].scale); lw[8 * l + 1] = a.lvl[l].my;
+                lw[8 * l + 2] = a.lvl[l].mz; lw[8 * l + 3] = a.lvl[l].offset;
+                lw[8 * l + 4] = a.lvl[l].mask; lw[8 * l + 5] = a.lvl[l].hashed;
+                lw[8 * l + 6] = a.lvl[l].wsize; lw[8 * l + 7] = 0u;
             }
         }
     }
     for (int e = threadIdx.x; e < 64; e += BLOCK) lds[OFF_LIN + e] = e < a.T0 ? a.lin_z[e] : 0.0f;
     for (int e = threadIdx.x; e < 16; e += BLOCK) lds[OFF_LIN + 64 + e] = a.lin_u ? a.lin_u[e] : 0.0f;
+    for (int e = threadIdx.x; e < 64; e += BLOCK) lds[OFF_SPQ + e] = AC_SP_Q[e >> 3][e & 7];
 }
 
 // ---- hash-grid features of this lane's 4 levels (HashEncoder.forward + kernel_grid) -------------------
@@ -159,7 +167,7 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 template <int ROUND>
-__device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t table, int g,
+__device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t table, int g, const int (&jmode)[4],
                                         float px, float py, float pz, float bound, float two_bound, float (&f)[4][2])
 {
     const float ux = (px + bound) / two_bound, uy = (py + bound) / two_bound, uz = (pz + bound) / two_bound;
@@ -172,32 +180,41 @@ __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t ta
         for (int jj = 0; jj < ROUND; ++jj) {
             const int j = j0 + jj;
             const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8);
-            const uint2 r1 = *reinterpret_cast<const uint2 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
+            const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
             const float scale = __uint_as_float(r0.x);
-            const uint32_t stride1 = r0.y, offset = r0.z, size = r0.w, hashed = r1.x, mask = r1.y;
+            const uint32_t my = r0.y, mz = r0.z, offset = r0.w, mask = r1.x, hashed = r1.y;
             float qx = fma_(ux, scale, 0.5f), qy = fma_(uy, scale, 0.5f), qz = fma_(uz, scale, 0.5f);
             const uint32_t gx = (uint32_t)__builtin_floorf(qx), gy = (uint32_t)__builtin_floorf(qy), gz = (uint32_t)__builtin_floorf(qz);
             q[jj][0] = qx - (float)gx; q[jj][1] = qy - (float)gy; q[jj][2] = qz - (float)gz;
-            // per-axis partial indices: hashed  -> x, y*P1, z*P2 (xor);  dense -> x, y*s, z*s*s (add)
-            const uint32_t my = hashed ? 2654435761u : stride1, mz = hashed ? 805459861u : stride1 * stride1;
-            const uint32_t ax0 = gx, ax1 = gx + 1u, ay0 = gy * my, ay1 = (gy + 1u) * my, az0 = gz * mz, az1 = (gz + 1u) * mz;
+            const uint32_t ax0 = gx, ax1 = gx + 1u, ay0 = gy * my, ay1 = ay0 + my, az0 = gz * mz, az1 = az0 + mz;
+            const int mode = jmode[j];                      // wave-uniform: one code path per gather round
+            uint32_t idx[8];
+            if (mode == 0) {                                // all four levels of this round are dense
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t tx = (c & 1) ? ax1 : ax0, ty = (c & 2) ? ay1 : ay0, tz = (c & 4) ? az1 : az0;
-                uint32_t idx = hashed ? (tx ^ ty ^ tz) : (tx + ty + tz);
-                if (mask) idx &= mask;
-                else if (idx >= size) idx %= size;
-                v[jj][c] = __builtin_amdgcn_raw_buffer_load_b64(table, (offset + idx) * 8u, 0, 0);
+                for (int c = 0; c < 8; ++c) idx[c] = ((c & 1) ? ax1 : ax0) + ((c & 2) ? ay1 : ay0) + ((c & 4) ? az1 : az0);
+            } else if (mode == 1) {                         // all hashed
+#pragma unroll
+                for (int c = 0; c < 8; ++c) idx[c] = (((c & 1) ? ax1 : ax0) ^ ((c & 2) ? ay1 : ay0) ^ ((c & 4) ? az1 : az0)) & mask;
+            } else {                                        // mixed round (levels 4..7 of the default model)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t tx = (c & 1) ? ax1 : ax0, ty = (c & 2) ? ay1 : ay0, tz = (c & 4) ? az1 : az0;
+                    idx[c] = (hashed ? (tx ^ ty ^ tz) : (tx + ty + tz)) & mask;
+                }
             }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[jj][c] = __builtin_amdgcn_raw_buffer_load_b64(table, (offset + idx[c]) * 8u, 0, 0);
         }
 #pragma unroll
         for (int jj = 0; jj < ROUND; ++jj) {
             const float qx = q[jj][0], qy = q[jj][1], qz = q[jj][2];
             const float wx0 = 1.0f - qx, wy0 = 1.0f - qy, wz0 = 1.0f - qz;
+            const float w00 = wx0 * wy0, w10 = qx * wy0, w01 = wx0 * qy, w11 = qx * qy;
             float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float w = (((c & 1) ? qx : wx0) * ((c & 2) ? qy : wy0)) * ((c & 4) ? qz : wz0);
+                const float wxy = (c & 2) ? ((c & 1) ? w11 : w01) : ((c & 1) ? w10 : w00);
+                const float w = wxy * ((c & 4) ? qz : wz0);
                 a0 = fma_(w, __uint_as_float(v[jj][c].x), a0);
                 a1 = fma_(w, __uint_as_float(v[jj][c].y), a1);
             }
@@ -209,12 +226,13 @@ __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t ta
 }
 
 // ---- forward_sdf for a tile of 16 points: returns the 16 outputs as D2^T fragment (o = 4g+r) ----------
-__device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, rsrc_t table, int lane,
-                                          float px, float py, float pz, float bound, float two_bound)
+struct FieldCtx { rsrc_t table; int jmode[4]; float bound, two_bound; };
+
+__device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, const FieldCtx &fc, int lane, float px, float py, float pz)
 {
     const int g = lane >> 4;
     float f[4][2];
-    encode4<AC_ENC_ROUND>(lds, table, g, px, py, pz, bound, two_bound, f);
+    encode4<AC_ENC_ROUND>(lds, fc.table, g, fc.jmode, px, py, pz, fc.bound, fc.two_bound, f);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
@@ -233,7 +251,7 @@ __device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, rsrc_t 
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float h = dv_softplus100(acc[t][r]);
+            const float h = dv_softplus100(lds + OFF_SPQ, acc[t][r]);
             o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r) * 64 + lane], h, o2, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -297,6 +315,15 @@ __device__ __forceinline__ float chunk_scan(float v, int lane, float &carry, boo
     return row_first ? loc : (MUL ? row_in * loc : row_in + loc);
 }
 
+__device__ __forceinline__ FieldCtx make_ctx(const RenderArgs &a)
+{
+    FieldCtx fc;
+    fc.table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.table), 0, a.table_bytes, 0x00020000);
+    fc.jmode[0] = a.jmode[0]; fc.jmode[1] = a.jmode[1]; fc.jmode[2] = a.jmode[2]; fc.jmode[3] = a.jmode[3];
+    fc.bound = a.bound; fc.two_bound = a.two_bound;
+    return fc;
+}
+
 // =====================================================================================================
 __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 {
@@ -310,8 +337,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     float *sd = zs + 2 * MAXT;                          // sd[2][128]
     float *cdf = sd + 2 * MAXT;                         // cdf[128]
     float *znl = cdf + MAXT;                            // znew[16]
-    const rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.table), 0, a.table_bytes, 0x00020000);
-    const float bound = a.bound, two_bound = a.two_bound;
+    const FieldCtx fc = make_ctx(a);
+    const float bound = a.bound;
     const int T0 = a.T0, nup = a.nup, T = T0 + 16 * nup;
 
     for (int ray = blockIdx.x * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             if (nup > 0) {
                 const float px = clampf(ox + dx * zi, -bound, bound), py = clampf(oy + dy * zi, -bound, bound),
                             pz = clampf(oz + dz * zi, -bound, bound);
-                const f32x4 o2 = sdf_tile(lds, table, lane, px, py, pz, bound, two_bound);
+                const f32x4 o2 = sdf_tile(lds, fc, lane, px, py, pz);
                 if (g == 0) sd[i] = o2[0];
             }
             if (g == 0) zs[i] = zi;
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             if (!last_it) {
                 const float px = clampf(ox + dx * znew, -bound, bound), py = clampf(oy + dy * znew, -bound, bound),
                             pz = clampf(oz + dz * znew, -bound, bound);
-                const f32x4 o2 = sdf_tile(lds, table, lane, px, py, pz, bound, two_bound);
+                const f32x4 o2 = sdf_tile(lds, fc, lane, px, py, pz);
                 sdf_new = o2[0];
             }
             wave_sync();
@@ -501,7 +528,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 const float qx_ = (e > 0 && k == 0) ? clampf(px + de, -bound, bound) : px;
                 const float qy_ = (e > 0 && k == 1) ? clampf(py + de, -bound, bound) : py;
                 const float qz_ = (e > 0 && k == 2) ? clampf(pz + de, -bound, bound) : pz;
-                const f32x4 o = sdf_tile(lds, table, lane, qx_, qy_, qz_, bound, two_bound);
+                const f32x4 o = sdf_tile(lds, fc, lane, qx_, qy_, qz_);
                 if (e == 0) oc = o;
                 else if (e & 1) spos = o[0];
                 else {
@@ -518,8 +545,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             // NeuS alpha :219-248
             const float sdf0 = oc[0];
             const float tc = (dx * nx + dy * ny) + dz * nz;
-            const float a1 = dv_softplus100(-tc * 0.5f + 0.5f) * a.one_m_car;
-            const float a2 = dv_softplus100(-tc) * a.car;
+            const float a1 = dv_softplus100(lds + OFF_SPQ, -tc * 0.5f + 0.5f) * a.one_m_car;
+            const float a2 = dv_softplus100(lds + OFF_SPQ, -tc) * a.car;
             const float iter_cos = -(a1 + a2);
             const float half = iter_cos * delta * 0.5f;
             const float pc = dv_sigmoid((sdf0 - half) * a.inv_s), nc = dv_sigmoid((sdf0 + half) * a.inv_s);
@@ -579,12 +606,12 @@ __global__ __launch_bounds__(BLOCK) void field_sdf_kernel(const RenderArgs a, co
     fill_lds(lds, a);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-    const rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.table), 0, a.table_bytes, 0x00020000);
+    const FieldCtx fc = make_ctx(a);
     const uint32_t ntiles = (B + 15) / 16;
     for (uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + wave; tile < ntiles; tile += gridDim.x * WAVES_PER_BLOCK) {
         const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
         const float px = x[3 * bb], py = x[3 * bb + 1], pz = x[3 * bb + 2];
-        const f32x4 o = sdf_tile(lds, table, lane, px, py, pz, a.bound, a.two_bound);
+        const f32x4 o = sdf_tile(lds, fc, lane, px, py, pz);
         if (b < B) *reinterpret_cast<f32x4 *>(out16 + (size_t)b * 16 + 4 * g) = o;
     }
 }
@@ -630,10 +657,24 @@ int fill_args(RenderArgs &a, const ac_field *f, float bound)
     }
     ac::LevelTable lt; ac::make_level_table(lt, 16, 3, f->S, f->H, f->offsets);
     for (int l = 0; l < 16; ++l) {
-        a.lvl[l].scale = lt.scale[l]; a.lvl[l].stride1 = lt.stride1[l]; a.lvl[l].offset = lt.offset[l];
-        a.lvl[l].size = lt.size[l]; a.lvl[l].hashed = lt.hashed[l]; a.lvl[l].mask = lt.pow2mask[l];
-        a.lvl[l].pad0 = a.lvl[l].pad1 = 0;
+        const bool hashed = lt.hashed[l] != 0, pow2 = lt.pow2mask[l] != 0;
+        a.lvl[l].scale = lt.scale[l]; a.lvl[l].offset = lt.offset[l]; a.lvl[l].hashed = hashed ? 1u : 0u;
+        a.lvl[l].my = hashed ? 2654435761u : lt.stride1[l];
+        a.lvl[l].mz = hashed ? 805459861u : lt.stride1[l] * lt.stride1[l];
+        a.lvl[l].mask = (hashed && pow2) ? lt.pow2mask[l] : 0xffffffffu;
+        a.lvl[l].wsize = (hashed && !pow2) ? lt.size[l] : 0u;
+        a.lvl[l].pad = 0;
+        if (a.lvl[l].wsize) {
+            ac::set_error("ac_field: level %d is hashed with a non power-of-two size %u; the fused renderer supports tables "
+                          "allocated by HashEncoder only (use ac_hash_encode_forward for arbitrary layouts)", l, lt.size[l]);
+            return AC_ERR_BAD_ARG;
+        }
         if (lt.size[l] == 0) { ac::set_error("ac_field: level %d has zero size", l); return AC_ERR_BAD_ARG; }
+    }
+    for (int j = 0; j < 4; ++j) {
+        int nh = 0;
+        for (int g = 0; g < 4; ++g) nh += lt.hashed[4 * j + g] ? 1 : 0;
+        a.jmode[j] = nh == 0 ? 0 : (nh == 4 ? 1 : 2);
     }
     a.table = f->table; a.table_bytes = (uint32_t)f->offsets[16] * 8u; a.W1 = f->W1; a.b1 = f->b1; a.W2 = f->W2; a.b2 = f->b2; a.Wc1 = f->Wc1; a.Wc2 = f->Wc2; a.Wc3 = f->Wc3;
     a.bound = bound; a.two_bound = (float)(2.0 * (double)bound);

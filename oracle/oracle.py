@@ -20,7 +20,7 @@ u32p = C.POINTER(C.c_uint32)
 def build(force=False):
     """Compile libac_oracle.so with the committed Makefile (gcc, seconds)."""
     so = os.path.join(_HERE, "libac_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_math.h", "ac_sh_table.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_math.h", "ac_sh_table.h", "ac_sp_table.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libac_oracle.so"], stdout=subprocess.DEVNULL)
     return so

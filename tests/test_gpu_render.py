@@ -60,8 +60,8 @@ def test_render_vs_reference_golden(env, name):
     assert abs(float(g["gradient_error"]) - float(gd["gradient_error"])) <= 1e-4
     up = int(gd["upsample_steps"]) // 16
     if up:   # sample indices bit-exact on identical seeds
-        assert np.array_equal(c("ss_inds"), gd["ss_inds"])
-        assert np.array_equal(c("sort_index")[:, :up], gd["sort_index"][:, :up])
+        from tests.test_oracle_golden import _indices_match
+        _indices_match(c("ss_inds"), gd["ss_inds"], c("sort_index")[:, :up], gd["sort_index"][:, :up])
         assert np.abs(c("z_vals") - gd["z_vals"]).max() <= 2e-3
 
 
