@@ -55,8 +55,10 @@ constexpr int OFF_LVL = OFF_B2 + 16;             // [16 levels][8 words]
 constexpr int OFF_LIN = OFF_LVL + 16 * 8;        // lin_z[64] + lin_u[16]
 constexpr int OFF_SPQ = OFF_LIN + 80;           // softplus Q table [8][8]
 constexpr int OFF_WAVE = OFF_SPQ + 64;          // per-wave slabs start here
-constexpr int WAVE_SLAB = 2 * MAXT * 2 + MAXT + 16 + 16;   // zs[2][128], sd[2][128], cdf[128], znew[16], pad
+constexpr int FE_SLAB = 6 * 8 * 64;                        // hash features of the 6 finite-difference points: [e-1][2j+c][lane]
+constexpr int WAVE_SLAB = 2 * MAXT * 2 + MAXT + 16 + 16 + FE_SLAB;   // zs[2][128], sd[2][128], cdf[128], znew[16], pad, fe
 constexpr int LDS_FLOATS = OFF_WAVE + WAVES_PER_BLOCK * WAVE_SLAB;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget: one workgroup per CU");
 static_assert(OFF_WAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
 
 // per-level launch constants: index = (hashed ? x ^ y*my ^ z*mz : x + y*my + z*mz) & mask [% wsize if wsize]
@@ -227,17 +229,15 @@ __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t ta
 
 // ---- forward_sdf for a tile of 16 points: returns the 16 outputs as D2^T fragment (o = 4g+r) ----------
 struct FieldCtx { rsrc_t table; int jmode[4]; float bound, two_bound; };
+__device__ __forceinline__ rsrc_t table_of(const FieldCtx &fc) { return fc.table; }
 
-__device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, const FieldCtx &fc, int lane, float px, float py, float pz)
+// SDF MLP 35-64-16 on the tile's features (f[j][c] = level 4j+g, channel c; bxyz = this lane group's coordinate)
+__device__ __forceinline__ f32x4 sdf_mlp(const float *__restrict__ lds, int lane, float bxyz, const float (&f)[4][2])
 {
     const int g = lane >> 4;
-    float f[4][2];
-    encode4<AC_ENC_ROUND>(lds, fc.table, g, fc.jmode, px, py, pz, fc.bound, fc.two_bound, f);
-    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = *reinterpret_cast<const f32x4 *>(lds + OFF_B1 + 16 * t + 4 * g);
-    const float bxyz = sel4(g, px, py, pz, 0.0f);
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const float b = (s == 0) ? bxyz : f[(s - 1) >> 1][(s - 1) & 1];
@@ -257,6 +257,140 @@ __device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, const F
         __builtin_amdgcn_sched_barrier(0);
     }
     return o2;
+}
+
+__device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, const FieldCtx &fc, int lane, float px, float py, float pz)
+{
+    const int g = lane >> 4;
+    float f[4][2];
+    encode4<AC_ENC_ROUND>(lds, fc.table, g, fc.jmode, px, py, pz, fc.bound, fc.two_bound, f);
+    __builtin_amdgcn_sched_barrier(0);
+    return sdf_mlp(lds, lane, sel4(g, px, py, pz, 0.0f), f);
+}
+
+// ---- finite-difference stencil: hash features of the centre point and of p +- eps*e_k (k = x,y,z) ------------------
+// The 7 evaluations of finite_difference_normals_approximator (instant_nsr.py:687-704) share most grid corners
+// on the coarse levels (eps*scale < 1 cell up to level 11).  Every evaluation still computes ITS OWN position,
+// cell and interpolation weights exactly as a stand-alone evaluation would (bit-identical features); only the
+// memory fetches are shared: a face of the offset point's cell that coincides with a face of the centre cell
+// re-uses the centre's 4 corner values, other faces are gathered under an exec mask.
+// fe[e][j][c]: e = 0 centre, 1..6 = +x,-x,+y,-y,+z,-z ; pe[e] = the offset coordinate (clamped) of evaluation e.
+struct LvlC { float scale; uint32_t my, mz, offset, mask, hashed; };
+
+__device__ __forceinline__ uint32_t gidx(const LvlC &L, uint32_t tx, uint32_t ty, uint32_t tz)
+{
+    return (L.hashed ? (tx ^ ty ^ tz) : (tx + ty + tz)) & L.mask;
+}
+__device__ __forceinline__ void interp8(const u32x2 (&v)[8], float qx, float qy, float qz, bool oob, float &f0, float &f1)
+{
+    const float wx0 = 1.0f - qx, wy0 = 1.0f - qy, wz0 = 1.0f - qz;
+    const float w00 = wx0 * wy0, w10 = qx * wy0, w01 = wx0 * qy, w11 = qx * qy;
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float wxy = (c & 2) ? ((c & 1) ? w11 : w01) : ((c & 1) ? w10 : w00);
+        const float w = wxy * ((c & 4) ? qz : wz0);
+        a0 = fma_(w, __uint_as_float(v[c].x), a0);
+        a1 = fma_(w, __uint_as_float(v[c].y), a1);
+    }
+    f0 = oob ? 0.0f : a0;
+    f1 = oob ? 0.0f : a1;
+}
+// corner index (0..7) of the i-th corner (i = 0..3, other two axes in increasing order) on face b of axis K
+template <int K> __device__ __forceinline__ constexpr int face_corner(int b, int i)
+{
+    return K == 0 ? (b | (i << 1)) : (K == 1 ? ((i & 1) | (b << 1) | ((i >> 1) << 2)) : (i | (b << 2)));
+}
+
+template <int K>
+__device__ __forceinline__ void stencil_axis(rsrc_t table, const LvlC &L, const u32x2 (&vc)[8], const uint32_t (&gc)[3],
+                                             const uint32_t (&tx)[2], const uint32_t (&ty)[2], const uint32_t (&tz)[2],
+                                             const float (&qc)[3], bool oob_c, float pk_off, float bound, float two_bound,
+                                             float &f0, float &f1)
+{
+    const float u = (pk_off + bound) / two_bound;
+    const bool oob = oob_c | (u < 0.0f) | (u > 1.0f);      // the other two coordinates are the centre's
+    const float pos = fma_(u, L.scale, 0.5f);
+    const uint32_t gk = (uint32_t)__builtin_floorf(pos);
+    const float qk = pos - (float)gk;
+    const int d = (int)gk - (int)gc[K];                    // cell shift along K
+    const uint32_t mk = K == 0 ? 1u : (K == 1 ? L.my : L.mz);
+    const uint32_t tk0 = gk * mk, tk1 = tk0 + mk;
+    u32x2 v2[8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int dd = d + b;                              // 0 / 1: this face is the centre cell's face 0 / 1
+        const bool need = (dd != 0) & (dd != 1);
+        // lanes that re-use a centre face issue an out-of-range offset: the buffer descriptor's bounds check
+        // drops them (returns 0) without touching the cache -- branch-free "masked" gather
+        u32x2 w[4];
+        const uint32_t tk = b ? tk1 : tk0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = face_corner<K>(b, i);
+            const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
+            const uint32_t off = need ? (L.offset + gidx(L, ax, ay, az)) * 8u : 0xfffffff8u;
+            w[i] = __builtin_amdgcn_raw_buffer_load_b64(table, off, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = face_corner<K>(b, i), c0 = face_corner<K>(0, i), c1 = face_corner<K>(1, i);
+            v2[c].x = need ? w[i].x : (dd == 0 ? vc[c0].x : vc[c1].x);
+            v2[c].y = need ? w[i].y : (dd == 0 ? vc[c0].y : vc[c1].y);
+        }
+    }
+    interp8(v2, K == 0 ? qk : qc[0], K == 1 ? qk : qc[1], K == 2 ? qk : qc[2], oob, f0, f1);
+}
+
+__device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, float *__restrict__ fslab, const FieldCtx &fc, int lane,
+                                               float px, float py, float pz, float eps, float (&fe0)[4][2])
+{
+    const int g = lane >> 4;
+    const float bound = fc.bound, two_bound = fc.two_bound;
+    const float ux = (px + bound) / two_bound, uy = (py + bound) / two_bound, uz = (pz + bound) / two_bound;
+    const bool oob = (ux < 0.0f) | (ux > 1.0f) | (uy < 0.0f) | (uy > 1.0f) | (uz < 0.0f) | (uz > 1.0f);
+    const float p3[3] = { px, py, pz };
+    float poff[6];
+#pragma unroll
+    for (int e = 1; e < 7; ++e) poff[e - 1] = clampf(p3[(e - 1) >> 1] + (((e - 1) & 1) ? -eps : eps), -bound, bound);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8);
+        const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
+        LvlC L; L.scale = __uint_as_float(r0.x); L.my = r0.y; L.mz = r0.z; L.offset = r0.w; L.mask = r1.x; L.hashed = r1.y;
+        float qc[3]; uint32_t gc[3];
+        {
+            const float qx = fma_(ux, L.scale, 0.5f), qy = fma_(uy, L.scale, 0.5f), qz = fma_(uz, L.scale, 0.5f);
+            gc[0] = (uint32_t)__builtin_floorf(qx); gc[1] = (uint32_t)__builtin_floorf(qy); gc[2] = (uint32_t)__builtin_floorf(qz);
+            qc[0] = qx - (float)gc[0]; qc[1] = qy - (float)gc[1]; qc[2] = qz - (float)gc[2];
+        }
+        uint32_t tx[2], ty[2], tz[2];
+        tx[0] = gc[0]; tx[1] = gc[0] + 1u; ty[0] = gc[1] * L.my; ty[1] = ty[0] + L.my; tz[0] = gc[2] * L.mz; tz[1] = tz[0] + L.mz;
+        u32x2 vc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            vc[c] = __builtin_amdgcn_raw_buffer_load_b64(table_of(fc), (L.offset + gidx(L, tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2])) * 8u, 0, 0);
+        interp8(vc, qc[0], qc[1], qc[2], oob, fe0[j][0], fe0[j][1]);
+        { float f0_, f1_; stencil_axis<0>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[0], bound, two_bound, f0_, f1_);
+          fslab[(0 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(0 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
+        __builtin_amdgcn_sched_barrier(0);
+        { float f0_, f1_; stencil_axis<0>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[1], bound, two_bound, f0_, f1_);
+          fslab[(1 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(1 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
+        __builtin_amdgcn_sched_barrier(0);
+        { float f0_, f1_; stencil_axis<1>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[2], bound, two_bound, f0_, f1_);
+          fslab[(2 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(2 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
+        __builtin_amdgcn_sched_barrier(0);
+        { float f0_, f1_; stencil_axis<1>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[3], bound, two_bound, f0_, f1_);
+          fslab[(3 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(3 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
+        __builtin_amdgcn_sched_barrier(0);
+        { float f0_, f1_; stencil_axis<2>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[4], bound, two_bound, f0_, f1_);
+          fslab[(4 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(4 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
+        __builtin_amdgcn_sched_barrier(0);
+        { float f0_, f1_; stencil_axis<2>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[5], bound, two_bound, f0_, f1_);
+          fslab[(5 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(5 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ---- forward_color for a tile: rgb (post-sigmoid) valid in lanes g==0 ---------------------------------
@@ -337,6 +471,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     float *sd = zs + 2 * MAXT;                          // sd[2][128]
     float *cdf = sd + 2 * MAXT;                         // cdf[128]
     float *znl = cdf + MAXT;                            // znew[16]
+    float *fsl = znl + 32;                              // features of the finite-difference points [6][8][64]
     const FieldCtx fc = make_ctx(a);
     const float bound = a.bound;
     const int T0 = a.T0, nup = a.nup, T = T0 + 16 * nup;
@@ -516,21 +651,24 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float zmid = (i < T - 1) ? zi + 0.5f * delta : zi;
             const float px = clampf(ox + dx * zmid, -bound, bound), py = clampf(oy + dy * zmid, -bound, bound),
                         pz = clampf(oz + dz * zmid, -bound, bound);
-            // centre + 6 finite-difference evaluations (:687-704) as ONE loop body (keeps a single copy of
-            // the gather/MLP code and its register footprint): e=0 centre, e=1..6 -> axis (e-1)>>1, sign (e-1)&1
-            f32x4 oc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            // centre + 6 finite-difference evaluations (:687-704): features of all 7 points first (shared corner
+            // fetches), then 7 MLP passes as one loop body over a rotating feature register file.
+            float fe0[4][2];
+            encode_stencil(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
+            const float pc0 = sel4(g, px, py, pz, 0.0f);
+            const f32x4 oc = sdf_mlp(lds, lane, pc0, fe0);
             float gr[3] = { 0.0f, 0.0f, 0.0f };
             float spos = 0.0f;
 #pragma unroll 1
-            for (int e = 0; e < 7; ++e) {
+            for (int e = 1; e < 7; ++e) {                       // the six offset points: one loop body, features from LDS
                 const int k = (e - 1) >> 1;
-                const float de = ((e - 1) & 1) ? -bxe : bxe;
-                const float qx_ = (e > 0 && k == 0) ? clampf(px + de, -bound, bound) : px;
-                const float qy_ = (e > 0 && k == 1) ? clampf(py + de, -bound, bound) : py;
-                const float qz_ = (e > 0 && k == 2) ? clampf(pz + de, -bound, bound) : pz;
-                const f32x4 o = sdf_tile(lds, fc, lane, qx_, qy_, qz_);
-                if (e == 0) oc = o;
-                else if (e & 1) spos = o[0];
+                float fe[4][2];
+#pragma unroll
+                for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[((e - 1) * 8 + q_) * 64 + lane];
+                const float pk = k == 0 ? px : (k == 1 ? py : pz);
+                const float poff = clampf(pk + (((e - 1) & 1) ? -bxe : bxe), -bound, bound);
+                const f32x4 o = sdf_mlp(lds, lane, g == k ? poff : pc0, fe);
+                if (e & 1) spos = o[0];
                 else {
                     const float gk = 0.5f * (spos - o[0]) / bxe;
                     if (k == 0) gr[0] = gk; else if (k == 1) gr[1] = gk; else gr[2] = gk;
