@@ -127,6 +127,58 @@ __device__ __forceinline__ float dv_softplus100(const float *__restrict__ spq, f
     return (t > 20.0f) ? x : ((t != t) ? t : res);
 }
 
+// the same softplus on two independent values with packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are
+// IEEE-exact per half, so each half is bit-identical to dv_softplus100)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float a) { v2f r = { a, a }; return r; }
+
+__device__ __forceinline__ v2f dv_softplus100_x2(const float *__restrict__ spq, v2f x)
+{
+    const v2f t = x * splat2(100.0f);
+    v2f a; a.x = __builtin_fabsf(t.x); a.y = __builtin_fabsf(t.y);
+    const v2f magic = splat2(12582912.0f);
+    const v2f tt = pk_fma(a, splat2(-1.44269504f), magic);
+    const v2f n = tt - magic;
+    v2f r = pk_fma(n, splat2(-0.693359375f), -a);
+    r = pk_fma(n, splat2(2.12194440e-4f), r);
+    v2f p = splat2(1.9875691500e-4f);
+    p = pk_fma(p, r, splat2(1.3981999507e-3f));
+    p = pk_fma(p, r, splat2(8.3334519073e-3f));
+    p = pk_fma(p, r, splat2(4.1665795894e-2f));
+    p = pk_fma(p, r, splat2(1.6666665459e-1f));
+    p = pk_fma(p, r, splat2(5.0000001201e-1f));
+    const v2f r2 = r * r;
+    const v2f e = pk_fma(p, r2, r) + splat2(1.0f);
+    v2f sc; sc.x = bits2f((uint32_t)((int)n.x + 127) << 23); sc.y = bits2f((uint32_t)((int)n.y + 127) << 23);
+    v2f u = e * sc;
+    u.x = (a.x <= 82.0f) ? u.x : ((a.x != a.x) ? a.x : 0.0f);
+    u.y = (a.y <= 82.0f) ? u.y : ((a.y != a.y) ? a.y : 0.0f);
+    const v2f u8 = u * splat2(8.0f);
+    int i0 = (int)u8.x, i1 = (int)u8.y;
+    i0 = i0 > 7 ? 7 : i0; i1 = i1 > 7 ? 7 : i1;
+    v2f ctr; ctr.x = ((float)i0 + 0.5f) * 0.125f; ctr.y = ((float)i1 + 0.5f) * 0.125f;
+    const v2f v = u - ctr;
+    const float4 a03 = *reinterpret_cast<const float4 *>(spq + i0 * 8), b03 = *reinterpret_cast<const float4 *>(spq + i1 * 8);
+    const float2 a45 = *reinterpret_cast<const float2 *>(spq + i0 * 8 + 4), b45 = *reinterpret_cast<const float2 *>(spq + i1 * 8 + 4);
+    v2f q = { a45.y, b45.y };
+    { v2f c = { a45.x, b45.x }; q = pk_fma(q, v, c); }
+    { v2f c = { a03.w, b03.w }; q = pk_fma(q, v, c); }
+    { v2f c = { a03.z, b03.z }; q = pk_fma(q, v, c); }
+    { v2f c = { a03.y, b03.y }; q = pk_fma(q, v, c); }
+    { v2f c = { a03.x, b03.x }; q = pk_fma(q, v, c); }
+    v2f tp; tp.x = t.x > 0.0f ? t.x : 0.0f; tp.y = t.y > 0.0f ? t.y : 0.0f;
+    const v2f sgm = tp + u * q;
+    const v2f y = splat2(0x1.47ae14p-7f);
+    const v2f q0 = sgm * y;
+    const v2f rr = pk_fma(-q0, splat2(100.0f), sgm);
+    const v2f res = pk_fma(rr, y, q0);
+    v2f o;
+    o.x = (t.x > 20.0f) ? x.x : ((t.x != t.x) ? t.x : res.x);
+    o.y = (t.y > 20.0f) ? x.y : ((t.y != t.y) ? t.y : res.y);
+    return o;
+}
+
 // torch.sigmoid
 __device__ __forceinline__ float dv_sigmoid(float x) { return 1.0f / (1.0f + dv_exp(-x)); }
 

@@ -33,6 +33,15 @@
 using namespace acdev;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef AC_ABL_MFMA     // timing ablation: replace every MFMA by one VALU fma per accumulator register
+static __device__ __forceinline__ f32x4 abl_mfma(float a, float b, f32x4 c) { c[0] = __builtin_fmaf(a, b, c[0]); return c; }
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, C, X, Y, Z) abl_mfma(A, B, C)
+#endif
+#ifdef AC_ABL_GATHER   // timing ablation: every gather reads table entry 0 (perfectly cached, fully coalesced)
+#define AC_GOFF(X) ((X) & 0u)
+#else
+#define AC_GOFF(X) (X)
+#endif
 
 namespace {
 
@@ -65,6 +74,14 @@ static_assert(OFF_WAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
 // (my,mz) = (P1,P2) for hashed levels, (res+1, (res+1)^2) for dense ones; mask = size-1 for power-of-two hashed
 // levels, ~0 otherwise (a dense index is < size by construction); wsize = size only for a hashed level whose size
 // is not a power of two (never the case for tables allocated by HashEncoder, handled for completeness).
+#ifdef AC_PROFILE
+#define AC_T0() unsigned long long t_prof_ = __builtin_amdgcn_s_memtime()
+#define AC_TICK(SLOT) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); prof_acc[SLOT] += t2_ - t_prof_; t_prof_ = t2_; }
+#else
+#define AC_T0()
+#define AC_TICK(SLOT)
+#endif
+
 struct LevelRec { float scale; uint32_t my, mz, offset, mask, hashed, wsize, pad; };
 
 struct RenderArgs {
@@ -76,8 +93,10 @@ struct RenderArgs {
     LevelRec lvl[16];
     int n_rays, T0, nup;
     int jmode[4];          // per gather round j (levels 4j..4j+3): 0 all dense, 1 all hashed, 2 mixed
+    int jfine[4];          // per round: 1 if the FD offset eps can span >= 1 cell on any of its levels
     float bound, two_bound, inv_s, car, one_m_car, eps;
     int perturb;
+    unsigned long long *prof;   // AC_PROFILE builds only: [n_waves][8] cycle counters per phase
 };
 
 // ---- wave-level helpers -----------------------------------------------------------------------------
@@ -205,7 +224,7 @@ __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t ta
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[jj][c] = __builtin_amdgcn_raw_buffer_load_b64(table, (offset + idx[c]) * 8u, 0, 0);
+            for (int c = 0; c < 8; ++c) v[jj][c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((offset + idx[c]) * 8u), 0, 0);
         }
 #pragma unroll
         for (int jj = 0; jj < ROUND; ++jj) {
@@ -228,35 +247,56 @@ __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t ta
 }
 
 // ---- forward_sdf for a tile of 16 points: returns the 16 outputs as D2^T fragment (o = 4g+r) ----------
-struct FieldCtx { rsrc_t table; int jmode[4]; float bound, two_bound; };
+struct FieldCtx { rsrc_t table; int jmode[4]; int jfine[4]; float bound, two_bound; };
 __device__ __forceinline__ rsrc_t table_of(const FieldCtx &fc) { return fc.table; }
 
-// SDF MLP 35-64-16 on the tile's features (f[j][c] = level 4j+g, channel c; bxyz = this lane group's coordinate)
-__device__ __forceinline__ f32x4 sdf_mlp(const float *__restrict__ lds, int lane, float bxyz, const float (&f)[4][2])
+// SDF MLP 35-64-16 on the tile's features (f[j][c] = level 4j+g, channel c; bxyz = this lane group's coordinate),
+// split into layer 1 (36 MFMA) and softplus + layer 2 (16 x ~40 VALU + 16 MFMA) so that the caller can overlap
+// layer 1 of the NEXT evaluation (matrix pipe) with the softplus of the current one (vector pipe).
+struct Acc4 { f32x4 a[4]; };
+
+__device__ __forceinline__ Acc4 sdf_l1(const float *__restrict__ lds, int lane, float bxyz, const float (&f)[4][2])
 {
     const int g = lane >> 4;
-    f32x4 acc[4];
+    Acc4 acc;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = *reinterpret_cast<const f32x4 *>(lds + OFF_B1 + 16 * t + 4 * g);
+    for (int t = 0; t < 4; ++t) acc.a[t] = *reinterpret_cast<const f32x4 *>(lds + OFF_B1 + 16 * t + 4 * g);
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const float b = (s == 0) ? bxyz : f[(s - 1) >> 1][(s - 1) & 1];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W1F + (t * 9 + s) * 64 + lane], b, acc[t], 0, 0, 0);
+            acc.a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W1F + (t * 9 + s) * 64 + lane], b, acc.a[t], 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    return acc;
+}
+
+__device__ __forceinline__ f32x4 sdf_l2(const float *__restrict__ lds, int lane, const Acc4 &acc)
+{
+    const int g = lane >> 4;
     f32x4 o2 = *reinterpret_cast<const f32x4 *>(lds + OFF_B2 + 4 * g);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float h = dv_softplus100(lds + OFF_SPQ, acc[t][r]);
-            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r) * 64 + lane], h, o2, 0, 0, 0);
+        for (int r = 0; r < 4; r += 2) {
+            v2f xin = { acc.a[t][r], acc.a[t][r + 1] };
+#ifdef AC_ABL_SOFTPLUS
+            const v2f h = xin * splat2(0.5f);
+#else
+            const v2f h = dv_softplus100_x2(lds + OFF_SPQ, xin);
+#endif
+            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r) * 64 + lane], h.x, o2, 0, 0, 0);
+            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r + 1) * 64 + lane], h.y, o2, 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     return o2;
+}
+
+__device__ __forceinline__ f32x4 sdf_mlp(const float *__restrict__ lds, int lane, float bxyz, const float (&f)[4][2])
+{
+    const Acc4 acc = sdf_l1(lds, lane, bxyz, f);
+    __builtin_amdgcn_sched_barrier(0);
+    return sdf_l2(lds, lane, acc);
 }
 
 __device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, const FieldCtx &fc, int lane, float px, float py, float pz)
@@ -302,59 +342,88 @@ template <int K> __device__ __forceinline__ constexpr int face_corner(int b, int
     return K == 0 ? (b | (i << 1)) : (K == 1 ? ((i & 1) | (b << 1) | ((i >> 1) << 2)) : (i | (b << 2)));
 }
 
-template <int K>
-__device__ __forceinline__ void stencil_axis(rsrc_t table, const LvlC &L, const u32x2 (&vc)[8], const uint32_t (&gc)[3],
-                                             const uint32_t (&tx)[2], const uint32_t (&ty)[2], const uint32_t (&tz)[2],
-                                             const float (&qc)[3], bool oob_c, float pk_off, float bound, float two_bound,
-                                             float &f0, float &f1)
+// ---- coarse level (eps*scale < 1 cell): an offset point lies in the centre cell or in the adjacent one, so it needs at
+// most ONE face the centre does not have (coordinate g+2 for +eps, g-1 for -eps).  All 8 + 6*4 gathers of the level
+// are issued as one batch (lanes that need nothing send an out-of-range offset: dropped by the descriptor's bounds
+// check), then the 7 interpolations run from registers: one memory round trip per level instead of seven.
+template <int K, int SIGN>   // SIGN 0: +eps, 1: -eps
+struct AxisGeo { float qk; bool need, oob; };
+
+template <int K, int SIGN>
+__device__ __forceinline__ AxisGeo<K, SIGN> coarse_issue(rsrc_t table, const LvlC &L, const uint32_t (&gc)[3], const uint32_t (&tx)[2],
+                                                       const uint32_t (&ty)[2], const uint32_t (&tz)[2], bool oob_c, float u,
+                                                       u32x2 (&w)[4])
 {
-    const float u = (pk_off + bound) / two_bound;
-    const bool oob = oob_c | (u < 0.0f) | (u > 1.0f);      // the other two coordinates are the centre's
+    AxisGeo<K, SIGN> a;
+    a.oob = oob_c | (u < 0.0f) | (u > 1.0f);
     const float pos = fma_(u, L.scale, 0.5f);
     const uint32_t gk = (uint32_t)__builtin_floorf(pos);
-    const float qk = pos - (float)gk;
-    const int d = (int)gk - (int)gc[K];                    // cell shift along K
+    a.qk = pos - (float)gk;
+    a.need = gk != gc[K];                                   // shifted by exactly one cell (host guarantees |shift| <= 1)
     const uint32_t mk = K == 0 ? 1u : (K == 1 ? L.my : L.mz);
-    const uint32_t tk0 = gk * mk, tk1 = tk0 + mk;
+    const uint32_t base = K == 0 ? tx[0] : (K == 1 ? ty[0] : tz[0]);
+    const uint32_t tk = SIGN == 0 ? base + 2u * mk : base - mk;   // coordinate g+2 / g-1 along K
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = face_corner<K>(0, i);
+        const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
+        const uint32_t off = a.need ? (L.offset + gidx(L, ax, ay, az)) * 8u : 0xfffffff8u;
+        w[i] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF(off), 0, 0);
+    }
+    return a;
+}
+
+template <int K, int SIGN>
+__device__ __forceinline__ void coarse_finish(const AxisGeo<K, SIGN> &a, const u32x2 (&vc)[8], const u32x2 (&w)[4], const float (&qc)[3],
+                                              float &f0, float &f1)
+{
+    constexpr int NEWBIT = SIGN == 0 ? 1 : 0;               // +eps: the new face is face 1 of the shifted cell
     u32x2 v2[8];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int dd = d + b;                              // 0 / 1: this face is the centre cell's face 0 / 1
-        const bool need = (dd != 0) & (dd != 1);
-        // lanes that re-use a centre face issue an out-of-range offset: the buffer descriptor's bounds check
-        // drops them (returns 0) without touching the cache -- branch-free "masked" gather
-        u32x2 w[4];
-        const uint32_t tk = b ? tk1 : tk0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = face_corner<K>(b, i);
-            const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
-            const uint32_t off = need ? (L.offset + gidx(L, ax, ay, az)) * 8u : 0xfffffff8u;
-            w[i] = __builtin_amdgcn_raw_buffer_load_b64(table, off, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = face_corner<K>(b, i), c0 = face_corner<K>(0, i), c1 = face_corner<K>(1, i);
-            v2[c].x = need ? w[i].x : (dd == 0 ? vc[c0].x : vc[c1].x);
-            v2[c].y = need ? w[i].y : (dd == 0 ? vc[c0].y : vc[c1].y);
-        }
+    for (int c = 0; c < 8; ++c) {
+        const int bk = (c >> K) & 1;
+        const int i = K == 0 ? (c >> 1) : (K == 1 ? ((c & 1) | ((c >> 2) << 1)) : (c & 3));
+        if (bk == NEWBIT) { v2[c].x = a.need ? w[i].x : vc[c].x; v2[c].y = a.need ? w[i].y : vc[c].y; }
+        else { v2[c].x = a.need ? vc[c ^ (1 << K)].x : vc[c].x; v2[c].y = a.need ? vc[c ^ (1 << K)].y : vc[c].y; }
     }
-    interp8(v2, K == 0 ? qk : qc[0], K == 1 ? qk : qc[1], K == 2 ? qk : qc[2], oob, f0, f1);
+    interp8(v2, K == 0 ? a.qk : qc[0], K == 1 ? a.qk : qc[1], K == 2 ? a.qk : qc[2], a.oob, f0, f1);
 }
+
+// ---- fine level (eps spans one cell or more): every offset point gathers its own 8 corners ---------------------------
+template <int K>
+__device__ __forceinline__ void fine_issue(rsrc_t table, const LvlC &L, const uint32_t (&tx)[2], const uint32_t (&ty)[2],
+                                           const uint32_t (&tz)[2], bool oob_c, float u, u32x2 (&v)[8], float &qk, bool &oob)
+{
+    oob = oob_c | (u < 0.0f) | (u > 1.0f);
+    const float pos = fma_(u, L.scale, 0.5f);
+    const uint32_t gk = (uint32_t)__builtin_floorf(pos);
+    qk = pos - (float)gk;
+    const uint32_t mk = K == 0 ? 1u : (K == 1 ? L.my : L.mz);
+    const uint32_t t0 = gk * mk, t1 = t0 + mk;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t tk = ((c >> K) & 1) ? t1 : t0;
+        const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
+        v[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx(L, ax, ay, az)) * 8u), 0, 0);
+    }
+}
+
+#define AC_FSTORE(E, F0, F1) { fslab[((E - 1) * 8 + 2 * j) * 64 + lane] = F0; fslab[((E - 1) * 8 + 2 * j + 1) * 64 + lane] = F1; }
 
 __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, float *__restrict__ fslab, const FieldCtx &fc, int lane,
                                                float px, float py, float pz, float eps, float (&fe0)[4][2])
 {
     const int g = lane >> 4;
+    const rsrc_t table = fc.table;
     const float bound = fc.bound, two_bound = fc.two_bound;
     const float ux = (px + bound) / two_bound, uy = (py + bound) / two_bound, uz = (pz + bound) / two_bound;
     const bool oob = (ux < 0.0f) | (ux > 1.0f) | (uy < 0.0f) | (uy > 1.0f) | (uz < 0.0f) | (uz > 1.0f);
-    const float p3[3] = { px, py, pz };
-    float poff[6];
-#pragma unroll
-    for (int e = 1; e < 7; ++e) poff[e - 1] = clampf(p3[(e - 1) >> 1] + (((e - 1) & 1) ? -eps : eps), -bound, bound);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    // normalised coordinate of the six offset points (one division each, hoisted out of the level loop)
+    const float xp = (clampf(px + eps, -bound, bound) + bound) / two_bound, xm = (clampf(px + (-eps), -bound, bound) + bound) / two_bound;
+    const float yp = (clampf(py + eps, -bound, bound) + bound) / two_bound, ym = (clampf(py + (-eps), -bound, bound) + bound) / two_bound;
+    const float zp = (clampf(pz + eps, -bound, bound) + bound) / two_bound, zm = (clampf(pz + (-eps), -bound, bound) + bound) / two_bound;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {                           // one copy of each code path; results go to LDS / a rotating fe0
         const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8);
         const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
         LvlC L; L.scale = __uint_as_float(r0.x); L.my = r0.y; L.mz = r0.z; L.offset = r0.w; L.mask = r1.x; L.hashed = r1.y;
@@ -369,29 +438,54 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
         u32x2 vc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            vc[c] = __builtin_amdgcn_raw_buffer_load_b64(table_of(fc), (L.offset + gidx(L, tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2])) * 8u, 0, 0);
-        interp8(vc, qc[0], qc[1], qc[2], oob, fe0[j][0], fe0[j][1]);
-        { float f0_, f1_; stencil_axis<0>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[0], bound, two_bound, f0_, f1_);
-          fslab[(0 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(0 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
-        __builtin_amdgcn_sched_barrier(0);
-        { float f0_, f1_; stencil_axis<0>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[1], bound, two_bound, f0_, f1_);
-          fslab[(1 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(1 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
-        __builtin_amdgcn_sched_barrier(0);
-        { float f0_, f1_; stencil_axis<1>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[2], bound, two_bound, f0_, f1_);
-          fslab[(2 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(2 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
-        __builtin_amdgcn_sched_barrier(0);
-        { float f0_, f1_; stencil_axis<1>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[3], bound, two_bound, f0_, f1_);
-          fslab[(3 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(3 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
-        __builtin_amdgcn_sched_barrier(0);
-        { float f0_, f1_; stencil_axis<2>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[4], bound, two_bound, f0_, f1_);
-          fslab[(4 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(4 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
-        __builtin_amdgcn_sched_barrier(0);
-        { float f0_, f1_; stencil_axis<2>(table_of(fc), L, vc, gc, tx, ty, tz, qc, oob, poff[5], bound, two_bound, f0_, f1_);
-          fslab[(5 * 8 + 2 * j) * 64 + lane] = f0_; fslab[(5 * 8 + 2 * j + 1) * 64 + lane] = f1_; }
-        __builtin_amdgcn_sched_barrier(0);
+            vc[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx(L, tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2])) * 8u), 0, 0);
+        float c0, c1;
+        if (!fc.jfine[j]) {
+            u32x2 w0[4], w1[4], w2[4], w3[4], w4[4], w5[4];
+            const auto a0 = coarse_issue<0, 0>(table, L, gc, tx, ty, tz, oob, xp, w0);
+            const auto a1 = coarse_issue<0, 1>(table, L, gc, tx, ty, tz, oob, xm, w1);
+            const auto a2 = coarse_issue<1, 0>(table, L, gc, tx, ty, tz, oob, yp, w2);
+            const auto a3 = coarse_issue<1, 1>(table, L, gc, tx, ty, tz, oob, ym, w3);
+            const auto a4 = coarse_issue<2, 0>(table, L, gc, tx, ty, tz, oob, zp, w4);
+            const auto a5 = coarse_issue<2, 1>(table, L, gc, tx, ty, tz, oob, zm, w5);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+            float f0, f1;
+            coarse_finish<0, 0>(a0, vc, w0, qc, f0, f1); AC_FSTORE(1, f0, f1)
+            coarse_finish<0, 1>(a1, vc, w1, qc, f0, f1); AC_FSTORE(2, f0, f1)
+            coarse_finish<1, 0>(a2, vc, w2, qc, f0, f1); AC_FSTORE(3, f0, f1)
+            coarse_finish<1, 1>(a3, vc, w3, qc, f0, f1); AC_FSTORE(4, f0, f1)
+            coarse_finish<2, 0>(a4, vc, w4, qc, f0, f1); AC_FSTORE(5, f0, f1)
+            coarse_finish<2, 1>(a5, vc, w5, qc, f0, f1); AC_FSTORE(6, f0, f1)
+        } else {
+            u32x2 va[8], vb[8];
+            float qa, qb, f0, f1; bool oa, ob;
+            fine_issue<0>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
+            fine_issue<0>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+            interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
+            interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
+            __builtin_amdgcn_sched_barrier(0);
+            fine_issue<1>(table, L, tx, ty, tz, oob, yp, va, qa, oa);
+            fine_issue<1>(table, L, tx, ty, tz, oob, ym, vb, qb, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(va, qc[0], qa, qc[2], oa, f0, f1); AC_FSTORE(3, f0, f1)
+            interp8(vb, qc[0], qb, qc[2], ob, f0, f1); AC_FSTORE(4, f0, f1)
+            __builtin_amdgcn_sched_barrier(0);
+            fine_issue<2>(table, L, tx, ty, tz, oob, zp, va, qa, oa);
+            fine_issue<2>(table, L, tx, ty, tz, oob, zm, vb, qb, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(va, qc[0], qc[1], qa, oa, f0, f1); AC_FSTORE(5, f0, f1)
+            interp8(vb, qc[0], qc[1], qb, ob, f0, f1); AC_FSTORE(6, f0, f1)
+        }
+        // rotate the centre features into place: after the 4th iteration fe0[j] holds level 4j+g
+        fe0[0][0] = fe0[1][0]; fe0[0][1] = fe0[1][1]; fe0[1][0] = fe0[2][0]; fe0[1][1] = fe0[2][1];
+        fe0[2][0] = fe0[3][0]; fe0[2][1] = fe0[3][1]; fe0[3][0] = c0; fe0[3][1] = c1;
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+#undef AC_FSTORE
 
 // ---- forward_color for a tile: rgb (post-sigmoid) valid in lanes g==0 ---------------------------------
 __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int lane, float px, float py, float pz,
@@ -454,6 +548,7 @@ __device__ __forceinline__ FieldCtx make_ctx(const RenderArgs &a)
     FieldCtx fc;
     fc.table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.table), 0, a.table_bytes, 0x00020000);
     fc.jmode[0] = a.jmode[0]; fc.jmode[1] = a.jmode[1]; fc.jmode[2] = a.jmode[2]; fc.jmode[3] = a.jmode[3];
+    fc.jfine[0] = a.jfine[0]; fc.jfine[1] = a.jfine[1]; fc.jfine[2] = a.jfine[2]; fc.jfine[3] = a.jfine[3];
     fc.bound = a.bound; fc.two_bound = a.two_bound;
     return fc;
 }
@@ -476,7 +571,11 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     const float bound = a.bound;
     const int T0 = a.T0, nup = a.nup, T = T0 + 16 * nup;
 
+#ifdef AC_PROFILE
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int ray = blockIdx.x * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
+        AC_T0();
         const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
         const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
         // near_far_from_bound (cube)  instant_nsr.py:58-77
@@ -511,6 +610,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             if (g == 0) zs[i] = zi;
         }
         wave_sync();
+        AC_TICK(0)
 
         // ---- NeuS up-sampling :182-184, :410-475 -----------------------------------------------------
         for (int it = 0; it < nup; ++it) {
@@ -601,6 +701,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 znl[n] = znew;
                 if (a.out.ss_inds) a.out.ss_inds[((size_t)ray * nup + it) * 16 + n] = ind;
             }
+            AC_TICK(1)
             const bool last_it = (it + 1 == nup);
             float sdf_new = 0.0f;
             if (!last_it) {
@@ -610,6 +711,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 sdf_new = o2[0];
             }
             wave_sync();
+            AC_TICK(2)
             // stable merge == torch.sort(cat([z, znew])) :466-473
             int32_t *sidx = a.out.sort_index ? a.out.sort_index + ((size_t)ray * nup + it) * 128 : nullptr;
 #pragma unroll
@@ -636,6 +738,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             cnt += 16; cur ^= 1;
             wave_sync();
+            AC_TICK(1)
         }
 
         // ---- render core :190-299 ---------------------------------------------------------------------
@@ -653,33 +756,45 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                         pz = clampf(oz + dz * zmid, -bound, bound);
             // centre + 6 finite-difference evaluations (:687-704): features of all 7 points first (shared corner
             // fetches), then 7 MLP passes as one loop body over a rotating feature register file.
+            AC_TICK(7)
             float fe0[4][2];
             encode_stencil(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
+            AC_TICK(3)
             const float pc0 = sel4(g, px, py, pz, 0.0f);
-            const f32x4 oc = sdf_mlp(lds, lane, pc0, fe0);
+            // 7 MLP passes, software-pipelined: layer 1 of evaluation e+1 (MFMA) is issued next to the softplus +
+            // layer 2 of evaluation e (VALU), so the matrix and vector pipes of the SIMD overlap inside one wave.
+            f32x4 oc = { 0.0f, 0.0f, 0.0f, 0.0f };
             float gr[3] = { 0.0f, 0.0f, 0.0f };
             float spos = 0.0f;
+            Acc4 acc = sdf_l1(lds, lane, pc0, fe0);
 #pragma unroll 1
-            for (int e = 1; e < 7; ++e) {                       // the six offset points: one loop body, features from LDS
-                const int k = (e - 1) >> 1;
+            for (int e = 0; e < 7; ++e) {
+                const int en = e < 6 ? e + 1 : 6;                  // next evaluation (the last iteration recomputes #6: discarded)
+                const int kn = (en - 1) >> 1;
                 float fe[4][2];
 #pragma unroll
-                for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[((e - 1) * 8 + q_) * 64 + lane];
-                const float pk = k == 0 ? px : (k == 1 ? py : pz);
-                const float poff = clampf(pk + (((e - 1) & 1) ? -bxe : bxe), -bound, bound);
-                const f32x4 o = sdf_mlp(lds, lane, g == k ? poff : pc0, fe);
-                if (e & 1) spos = o[0];
+                for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[((en - 1) * 8 + q_) * 64 + lane];
+                const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
+                const float poff = clampf(pk + (((en - 1) & 1) ? -bxe : bxe), -bound, bound);
+                const Acc4 accn = sdf_l1(lds, lane, g == kn ? poff : pc0, fe);
+                const f32x4 o = sdf_l2(lds, lane, acc);
+                acc = accn;
+                const int k = (e - 1) >> 1;
+                if (e == 0) oc = o;
+                else if (e & 1) spos = o[0];
                 else {
                     const float gk = 0.5f * (spos - o[0]) / bxe;
                     if (k == 0) gr[0] = gk; else if (k == 1) gr[1] = gk; else gr[2] = gk;
                 }
             }
+            AC_TICK(4)
             // lanes g==0 hold the sdf-based values; broadcast the gradient to the other groups
             const float gx = __shfl(gr[0], n), gy = __shfl(gr[1], n), gz = __shfl(gr[2], n);
             const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
             const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
             float rgb[3];
             color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+            AC_TICK(5)
             // NeuS alpha :219-248
             const float sdf0 = oc[0];
             const float tc = (dx * nx + dy * ny) + dz * nz;
@@ -712,6 +827,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             AC_ACC(s_d, wgt * zn01)
             AC_ACC(s_en, eerr) AC_ACC(s_ed, relax)
 #undef AC_ACC
+            AC_TICK(6)
             if (g == 0) {
                 const size_t si = (size_t)ray * T + i;
                 if (a.out.z_vals) a.out.z_vals[si] = zi;
@@ -734,6 +850,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         }
         wave_sync();
     }
+#ifdef AC_PROFILE
+    if (a.prof && lane == 0) { const int w_ = blockIdx.x * WAVES_PER_BLOCK + wave; for (int i = 0; i < 8; ++i) a.prof[w_ * 8 + i] = prof_acc[i]; }
+#endif
 }
 
 // ---- stand-alone field queries (density(), extract_geometry(), unit tests) -------------------------------
@@ -821,6 +940,11 @@ int fill_args(RenderArgs &a, const ac_field *f, float bound)
 
 }  // namespace
 
+#ifdef AC_PROFILE
+static unsigned long long *g_prof = nullptr;
+AC_API void ac_debug_set_prof(unsigned long long *p) { g_prof = p; }
+#endif
+
 AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
                           const float *bg, const float *noise, const float *lin_z, const float *lin_u,
                           const ac_render_out *out, ac_stream_t stream)
@@ -844,6 +968,16 @@ AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const
     a.n_rays = op->n_rays; a.T0 = op->num_steps; a.nup = op->upsample_steps / 16;
     a.inv_s = op->inv_s; a.car = op->cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
     a.eps = op->fd_eps; a.perturb = op->perturb;
+#ifdef AC_PROFILE
+    a.prof = g_prof;
+#endif
+    for (int j = 0; j < 4; ++j) {           // finite-difference reach in cells, per gather round (see encode_stencil)
+        a.jfine[j] = 0;
+        for (int g = 0; g < 4; ++g) {
+            const double cells = (double)op->fd_eps / (double)a.two_bound * (double)a.lvl[4 * j + g].scale;
+            if (!(cells * 1.001 + 1e-3 < 1.0)) a.jfine[j] = 1;
+        }
+    }
     const int blocks = (op->n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     static bool attr_set = false;
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);

@@ -1,0 +1,32 @@
+"""Per-phase cycle breakdown of render_rays_kernel (s_memtime instrumentation, -DAC_PROFILE build).
+    python tools/phase_profile.py        (on the GPU box; builds a separate instrumented library)"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+csrc = os.path.join(ROOT, "avatarcraft_amd", "csrc")
+out = os.path.join(ROOT, "gpurun_out", "libac_prof.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip")]
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                       "-DAC_PROFILE", "-Wno-unused-result", "-o", out] + srcs)
+from avatarcraft_amd import _lib
+_lib.LIB_PATH = out
+_lib._SIGS["ac_debug_set_prof"] = ([ctypes.c_void_p], None)
+from avatarcraft_amd import nsr_ops
+from tests.common import load_golden, make_rays
+from tests.gpu_common import device_field
+p = load_golden("nsr_params.npz"); f, _ = device_field(p)
+ro, rd = make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)
+ro, rd = torch.from_numpy(ro[:4096].copy()).cuda(), torch.from_numpy(rd[:4096].copy()).cuda()
+prof = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+_lib.lib().ac_debug_set_prof(prof.data_ptr())
+for _ in range(3):
+    prof.zero_(); nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, float(p["inv_s"])); torch.cuda.synchronize()
+pr = prof.cpu().numpy().reshape(4096, 8).astype(np.float64)
+names = ["coarse(64 sdf evals)", "upsample math+merge", "upsample sdf eval", "final: stencil gather+interp", "final: 7x sdf mlp", "final: colour mlp",
+         "final: alpha+composite", "final: tile setup"]
+tot = pr.sum(1).mean()
+print("s_memtime ticks per ray (100 MHz const clock): total %.0f" % tot)
+for n, v in zip(names, pr.mean(0)):
+    print("  %-32s %9.0f  %5.1f%%" % (n, v, 100 * v / tot))
