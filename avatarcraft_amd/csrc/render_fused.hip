@@ -45,7 +45,10 @@ static __device__ __forceinline__ f32x4 abl_mfma(float a, float b, f32x4 c) { c[
 
 namespace {
 
-constexpr int WAVES_PER_BLOCK = 8;
+#ifndef AC_WPB
+#define AC_WPB 8
+#endif
+constexpr int WAVES_PER_BLOCK = AC_WPB;
 constexpr int BLOCK = WAVES_PER_BLOCK * 64;
 constexpr int MAXT = 128;
 #ifndef AC_ENC_ROUND
@@ -574,7 +577,16 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 #ifdef AC_PROFILE
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (int ray = blockIdx.x * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
+#ifdef AC_STAGGER      // experiment: de-phase the two waves that share a SIMD (waves w and w+4 of the workgroup)
+    if (wave >= 4) { for (int i_ = 0; i_ < AC_STAGGER; ++i_) __builtin_amdgcn_s_sleep(127); }
+#endif
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule; speed only): give every XCD a contiguous
+    // slab of rays so that neighbouring pixels share one L2 instead of eight
+    int bid = blockIdx.x;
+#ifndef AC_NO_XCD_REMAP
+    if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+    for (int ray = bid * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
         AC_T0();
         const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
         const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
@@ -743,6 +755,10 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 
         // ---- render core :190-299 ---------------------------------------------------------------------
         const float *zf = zs + cur * MAXT;
+#ifdef AC_PINGPONG     // experiment: waves 4..7 run the gather/MLP phases one phase behind waves 0..3 (same SIMDs)
+        __builtin_amdgcn_s_barrier();
+        if (wave >= 4) __builtin_amdgcn_s_barrier();
+#endif
         float cT = 1.0f;                                        // transmittance carry (cumprod)
         float s_w = 0.0f, s_r = 0.0f, s_g = 0.0f, s_b = 0.0f, s_nx = 0.0f, s_ny = 0.0f, s_nz = 0.0f, s_d = 0.0f,
               s_en = 0.0f, s_ed = 0.0f;
@@ -759,6 +775,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             AC_TICK(7)
             float fe0[4][2];
             encode_stencil(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
+#ifdef AC_PINGPONG
+            __builtin_amdgcn_s_barrier();
+#endif
             AC_TICK(3)
             const float pc0 = sel4(g, px, py, pz, 0.0f);
             // 7 MLP passes, software-pipelined: layer 1 of evaluation e+1 (MFMA) is issued next to the softplus +
@@ -827,6 +846,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             AC_ACC(s_d, wgt * zn01)
             AC_ACC(s_en, eerr) AC_ACC(s_ed, relax)
 #undef AC_ACC
+#ifdef AC_PINGPONG
+            __builtin_amdgcn_s_barrier();
+#endif
             AC_TICK(6)
             if (g == 0) {
                 const size_t si = (size_t)ray * T + i;
@@ -838,6 +860,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 if (a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
             }
         }
+#ifdef AC_PINGPONG
+        if (wave < 4) __builtin_amdgcn_s_barrier();
+#endif
         if (lane == 0) {
             const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
             a.out.image[3 * ray] = s_r + (1.0f - s_w) * b0;
