@@ -1,0 +1,287 @@
+"""Instant-NSR model + NeuS renderer behind the reference's model API (models/instant_nsr.py:90-726).
+
+`NeRFNetwork()` has the reference's constructor, parameter names (state_dict keys: encoder.embeddings,
+encoder.offsets, sdf_net.{0,1}.{bias,weight_g,weight_v}, color_net.{0,1,2}.{weight_g,weight_v},
+deviation_net.variance -- SURVEY section 5) and `.render(...)` signature / result keys, so the reference's drivers
+and checkpoints (bare_smpl.pth.tar) work unchanged.
+
+Where the work happens:
+  * no-grad rendering (render_canonical, render_val, the sampling stage of every training render) is ONE launch of
+    the fused HIP kernel (nsr_ops.render_rays == NeRFRenderer.run :133-299);
+  * rendering with gradients (stylize / reconstruct) takes the sample positions from the fused kernel (the reference
+    computes them under no_grad, :176-184) and evaluates the differentiable "render core" (:190-299) with autograd
+    over the HIP hash encoder; a fused backward kernel is the next step.
+  * render_can=False (SMPL inverse warp, :166-172,198-203) is not built yet and raises NotImplementedError.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nsr_ops
+from .encoder import get_encoder
+
+DEFAULT_GEO_THRESH = 0.05     # utils/constant.py:17
+
+
+def near_far_from_bound(rays_o, rays_d, bound, type='cube'):
+    """models/instant_nsr.py:58-77 (host-side helper kept for API parity; the fused kernel has its own copy)."""
+    radius = rays_o.norm(dim=-1, keepdim=True)
+    if type == 'sphere':
+        return radius - bound, radius + bound
+    tmin = (-bound - rays_o) / (rays_d + 1e-15)
+    tmax = (bound - rays_o) / (rays_d + 1e-15)
+    near = torch.where(tmin < tmax, tmin, tmax).max(dim=-1, keepdim=True)[0]
+    far = torch.where(tmin > tmax, tmin, tmax).min(dim=-1, keepdim=True)[0]
+    return torch.clamp(near, min=0.05), far
+
+
+class SingleVarianceNetwork(nn.Module):
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter('variance', nn.Parameter(torch.tensor(init_val)))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, cuda_ray=False, curvature_loss=False):
+        super().__init__()
+        self.cuda_ray = cuda_ray
+        self.curvature_loss = curvature_loss
+        if cuda_ray:   # extra state of the occupancy-grid marcher (instant_nsr.py:100-110)
+            self.register_buffer('density_grid', torch.zeros([128 + 1] * 3))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.register_buffer('step_counter', torch.zeros(64, 2, dtype=torch.int32))
+            self.mean_count = 0
+            self.local_step = 0
+
+    # ------------------------------------------------------------------ fused field handle
+    def _field(self):
+        """ac_field view of the current parameters (effective = weight-normed matrices)."""
+        wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0).detach().contiguous()
+        enc = self.encoder
+        return nsr_ops.Field(enc.embeddings.detach(), enc.offsets.tolist(), enc.per_level_scale, enc.base_resolution,
+                             wn(self.sdf_net[0]), self.sdf_net[0].bias.detach().contiguous(), wn(self.sdf_net[1]),
+                             self.sdf_net[1].bias.detach().contiguous(), wn(self.color_net[0]), wn(self.color_net[1]), wn(self.color_net[2]))
+
+    def _fused_supported(self):
+        enc = getattr(self, "encoder", None)
+        return (not self.use_viewdirs and self.include_input and self.num_layers == 2 and self.hidden_dim == 64 and self.geo_feat_dim == 15
+                and self.num_layers_color == 3 and self.hidden_dim_color == 64 and hasattr(enc, "embeddings")
+                and enc.num_levels == 16 and enc.level_dim == 2 and enc.input_dim == 3 and not self.curvature_loss)
+
+    # ------------------------------------------------------------------ run == reference :133-299
+    def run(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0,
+            render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True):
+        if not render_can:
+            raise NotImplementedError("render_can=False (SMPL inverse warp) is not built yet in avatarcraft_amd")
+        if not self._fused_supported():
+            raise NotImplementedError("the fused MI355X renderer supports the default NeRFNetwork configuration only")
+        B, N = rays_o.shape[:2]
+        device = rays_o.device
+        ro = rays_o.reshape(-1, 3).float().contiguous()
+        rd = rays_d.reshape(-1, 3).float().contiguous()
+        inv_s_t = self.forward_variance()
+        noise = None
+        if self.training and perturb_overwrite:                  # :161-162
+            noise = torch.rand((N, num_steps), device=device)
+        bg = None
+        if bg_color is not None:                                 # tensor [N,3] / [3] / scalar; None -> 1 (white), :291-294
+            bg = torch.as_tensor(bg_color, dtype=torch.float32, device=device)
+            bg = bg.reshape(-1, 3) if bg.numel() >= 3 else bg.reshape(1, 1).expand(1, 3)
+            bg = bg.expand(N, 3).contiguous() if bg.shape[0] == 1 else bg.contiguous()
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        field = self._field()
+        out = nsr_ops.render_rays(field, ro, rd, num_steps, upsample_steps, bound, float(inv_s_t.detach().reshape(-1)[0]), bg=bg, noise=noise,
+                                  cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, extras=True)
+        if not needs_grad:
+            return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
+                    out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])
+        return self._render_core_autograd(ro, rd, out["z_vals"], num_steps, upsample_steps, bound, bg,
+                                          cos_anneal_ratio, normal_epsilon_ratio, B, N)
+
+    def _render_core_autograd(self, rays_o, rays_d, z_vals, num_steps0, upsample_steps, bound, bg_color, cos_anneal_ratio,
+                              normal_epsilon_ratio, B, N):
+        """The differentiable part of run() (reference :190-299) on the sample positions delivered by the fused kernel."""
+        near, far = near_far_from_bound(rays_o, rays_d, bound, type='cube')
+        sample_dist = (far - near) / num_steps0
+        T = num_steps0 + upsample_steps
+        deltas = z_vals[:, 1:] - z_vals[:, :-1]
+        deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[:, :1])], dim=-1)
+        z_mid = torch.cat([z_vals[:, :-1] + 0.5 * deltas[:, :-1], z_vals[:, -1:]], dim=-1)
+        pts = (rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_mid.unsqueeze(-1)).clamp(-bound, bound).float()
+        dirs = rays_d.unsqueeze(-2).expand_as(pts)
+        flat = pts.reshape(-1, 3)
+        sdf_out = self.forward_sdf(flat, bound)
+        sdf, feat = sdf_out[:, :1], sdf_out[:, 1:]
+        gradient = self.gradient(flat, bound, 0.005 * (1.0 - normal_epsilon_ratio)).squeeze()
+        normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
+        color = self.forward_color(flat, dirs.reshape(-1, 3), normal.reshape(-1, 3), feat, bound)
+        inv_s = self.forward_variance().expand(N * T, 1)
+        true_cos = (dirs.reshape(-1, 3) * normal).sum(-1, keepdim=True)
+        act = nn.Softplus(beta=100)
+        iter_cos = -(act(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + act(-true_cos) * cos_anneal_ratio)
+        half = iter_cos * deltas.reshape(-1, 1) * 0.5
+        prev_cdf = torch.sigmoid((sdf - half) * inv_s)
+        next_cdf = torch.sigmoid((sdf + half) * inv_s)
+        alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).reshape(N, T).clip(0.0, 1.0)
+        weights = alpha * torch.cumprod(torch.cat([torch.ones([N, 1], device=alpha.device), 1. - alpha + 1e-7], -1), -1)[:, :-1]
+        weights_sum = weights.sum(dim=-1, keepdim=True)
+        color = color.reshape(N, T, 3)
+        image = (color * weights[:, :, None]).sum(dim=1)
+        normal_map = torch.sum(normal.reshape(N, T, 3) * weights[:, :, None], dim=1)
+        depth = torch.sum(weights * ((z_vals - near) / (far - near)).clamp(0, 1), dim=-1)
+        pts_norm = torch.linalg.norm(flat, ord=2, dim=-1, keepdim=True).reshape(N, T)
+        relax = (pts_norm < 1.2).float().detach()
+        gerr = (torch.linalg.norm(gradient.reshape(N, T, 3), ord=2, dim=-1) - 1.0) ** 2
+        gradient_error = (relax * gerr).sum() / (relax.sum() + 1e-5)
+        assert (gradient == gradient).all(), 'Nan or Inf found!'
+        if bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum) * bg_color
+        return depth.reshape(B, N), weights, weights_sum, image.reshape(B, N, 3), normal_map, gradient_error, 0.0, color, alpha, z_vals
+
+    # ------------------------------------------------------------------ render == reference :358-408
+    def render(self, rays_o, rays_d, num_steps, bound, upsample_steps, staged=False, max_ray_batch=4096, bg_color=None,
+               cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0, render_can=True, verts=None, faces=None, Ts=None, perturb: bool = False,
+               use_mesh_guide: bool = True, **kwargs):
+        B, N = rays_o.shape[:2]
+        device = rays_o.device
+        if staged and not self.cuda_ray:
+            depth = torch.empty((B, N), device=device); image = torch.empty((B, N, 3), device=device)
+            normal = torch.empty((B, N, 3), device=device)
+            weights = weight_sum = pts_color = pts_alpha = z_vals = None
+            gradient_error = curvature_error = 0.0
+            for b in range(B):
+                head = 0
+                while head < N:
+                    tail = min(head + max_ray_batch, N)
+                    r = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], num_steps, bound, upsample_steps, bg_color,
+                                 cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio)
+                    depth[b:b + 1, head:tail] = r[0].detach(); image[b:b + 1, head:tail] = r[3].detach()
+                    normal[b, head:tail] = r[4].detach()
+                    head += max_ray_batch
+        else:
+            (depth, weights, weight_sum, image, normal, gradient_error, curvature_error, pts_color, pts_alpha, z_vals) = self.run(
+                rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio, normal_epsilon_ratio, render_can=render_can,
+                verts=verts, faces=faces, Ts=Ts, perturb_overwrite=perturb, use_mesh_guide=use_mesh_guide)
+        return {'depth': depth, 'weights': weights, 'weight_sum': weight_sum, 'rgb': image, 'normal': normal,
+                'gradient_error': gradient_error, 'curvature_error': curvature_error, 'pts_color': pts_color, 'pts_alpha': pts_alpha,
+                'z_vals': z_vals}
+
+
+class NeRFNetwork(NeRFRenderer):
+    """models/instant_nsr.py:478-718; the construction order (and therefore the RNG stream) follows the reference,
+    so torch.manual_seed(s); NeRFNetwork() yields the same initial parameters."""
+
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, hidden_dim_color=64, bound=1.0, geometric_init=True, weight_norm=True, cuda_ray=False,
+                 include_input=True, curvature_loss=False, use_viewdirs=False):
+        super().__init__(cuda_ray, curvature_loss)
+        self.num_layers, self.hidden_dim, self.geo_feat_dim, self.include_input = num_layers, hidden_dim, geo_feat_dim, include_input
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.use_viewdirs = use_viewdirs
+        pos_cfg = {"in_dim": 3, "freq_multires": 6, "hash_num_levels": 16, "hash_level_dim": 2, "hash_base_resolution": 16,
+                   "hash_per_level_scale": 1.3819, "hash_log2_hashmap_size": 19, "hash_desired_resolution": 2048}
+        dir_cfg = {"in_dim": 3, "freq_multires": 4}
+        self.encoder, self.in_dim = get_encoder(encoding, pos_cfg)
+        sdf_net = []
+        for l in range(num_layers):
+            in_dim = (self.in_dim + 3 if include_input else self.in_dim) if l == 0 else hidden_dim
+            out_dim = 1 + geo_feat_dim if l == num_layers - 1 else hidden_dim
+            lin = nn.Linear(in_dim, out_dim)
+            if geometric_init:
+                if l == num_layers - 1:
+                    torch.nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(in_dim), std=0.0001)
+                    torch.nn.init.constant_(lin.bias, 0)
+                elif l == 0 and include_input:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    torch.nn.init.constant_(lin.weight[:, 3:], 0.0)
+                else:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight[:, :], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            if weight_norm:
+                lin = nn.utils.weight_norm(lin)
+            sdf_net.append(lin)
+        self.sdf_net = nn.ModuleList(sdf_net)
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.encoder_dir = None
+        if use_viewdirs:
+            self.encoder_dir, self.in_dim_color = get_encoder(encoding_dir, dir_cfg)
+            self.in_dim_color = self.in_dim_color + geo_feat_dim + 6
+        else:
+            self.in_dim_color = geo_feat_dim + 6
+        color_net = []
+        for l in range(num_layers_color):
+            lin = nn.Linear(self.in_dim_color if l == 0 else hidden_dim, 3 if l == num_layers_color - 1 else hidden_dim, bias=False)
+            if weight_norm:
+                lin = nn.utils.weight_norm(lin)
+            color_net.append(lin)
+        self.color_net = nn.ModuleList(color_net)
+        self.deviation_net = SingleVarianceNetwork(0.3)
+        self.activation = nn.Softplus(beta=100)
+
+    # ---- differentiable field (autograd path: HIP hash encoder + torch MLP), reference :627-704
+    def forward_sdf(self, x, bound):
+        h = self.encoder(x, bound)
+        if self.include_input:
+            h = torch.cat([x, h], dim=-1)
+        for l in range(self.num_layers):
+            h = self.sdf_net[l](h)
+            if l != self.num_layers - 1:
+                h = self.activation(h)
+        return h
+
+    def forward_color(self, x, d, n, geo_feat, bound):
+        if self.use_viewdirs:
+            h = torch.cat([x, self.encoder_dir(d), n, geo_feat], dim=-1)
+        else:
+            h = torch.cat([x, n, geo_feat], dim=-1)
+        for l in range(self.num_layers_color):
+            h = self.color_net[l](h)
+            if l != self.num_layers_color - 1:
+                h = F.relu(h, inplace=True)
+        return torch.sigmoid(h)
+
+    def forward_variance(self):
+        return self.deviation_net(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6)
+
+    def density(self, x, bound):
+        """sdf only (reference :669-681); no-grad queries go through the fused field kernel"""
+        if not torch.is_grad_enabled() and x.is_cuda and self._fused_supported():
+            return nsr_ops.field_sdf(self._field(), x.reshape(-1, 3).float().contiguous(), bound)[:, 0].reshape(x.shape[:-1])
+        return self.forward_sdf(x, bound)[..., 0]
+
+    def gradient(self, x, bound, epsilon=0.0005):
+        return self.finite_difference_normals_approximator(x, bound, epsilon)
+
+    def finite_difference_normals_approximator(self, x, bound, epsilon=0.0005):
+        outs = []
+        for k in range(3):
+            e = torch.zeros(1, 3, device=x.device); e[0, k] = epsilon
+            pos = self.forward_sdf((x + e).clamp(-bound, bound), bound)[:, :1]
+            neg = self.forward_sdf((x - e).clamp(-bound, bound), bound)[:, :1]
+            outs.append(0.5 * (pos - neg) / epsilon)
+        return torch.cat(outs, dim=-1)
+
+    def extract_geometry(self, bound: float, resolution: int, threshold: int = 0.0, device=None):
+        """marching cubes on the SDF grid (reference :706-764); PyMCubes is an optional dependency"""
+        import mcubes
+        N = 256
+        xs = torch.linspace(-bound, bound, resolution).split(N)
+        u = np.zeros([resolution] * 3, dtype=np.float32)
+        with torch.no_grad():
+            for xi, x in enumerate(xs):
+                for yi, y in enumerate(xs):
+                    for zi, z in enumerate(xs):
+                        xx, yy, zz = torch.meshgrid(x, y, z, indexing="ij")
+                        pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1).to(self.encoder.embeddings.device)
+                        val = self.density(pts, bound).reshape(len(x), len(y), len(z))
+                        u[xi * N: xi * N + len(x), yi * N: yi * N + len(y), zi * N: zi * N + len(z)] = val.cpu().numpy()
+        vertices, triangles = mcubes.marching_cubes(-1.0 * u, threshold)
+        vertices = vertices / (resolution - 1.0) * (2 * bound) - bound
+        return vertices, triangles

@@ -1,0 +1,102 @@
+"""One SDS stylisation step (and its data-parallel form): counterpart of Trainer.train's inner loop,
+stylize.py:95-199, for one view:
+
+    (A) render_val : no-grad full-view render of net_style (train mode => jittered samples)      stylize.py:115 -> :298
+    (B) guidance   : image -> d(loss)/d(image); Stable-Diffusion SDS in the reference              :128-130
+    (C) per 4096-ray patch: render net_style with grad; backward(image_grad); backward(w_eik * eikonal);
+        render frozen net_gt; backward(1e5 * smooth_l1(clamp(opacity_pred), clamp(opacity_gt)))  :143-196
+    (D) optimizer.step()  (Adam lr 5e-3 on all parameters of net_style)                            :199, :355-363
+
+The SD UNet is an opaque `guidance(rgb[1,3,h,w]) -> grad[1,3,h,w]` callable (it stays PyTorch-ROCm; `diffusers` is not
+available offline, so `SyntheticGuidance` -- clamp(N(0,1), -1, 1), the statistics of the clamped SDS gradient
+(models/diffusion.py:139-146) -- stands in for measurement and tests).
+
+Data parallel (BASELINE config 5): one view per rank, parameters replicated, ONE all-reduce (sum,
+then / world) of the flat fp32 gradient (12 248 902 elements = 49 MB) before the optimizer step.
+"""
+import torch
+import torch.nn.functional as F
+
+from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG
+
+
+class SyntheticGuidance:
+    """Stand-in for StableDiffusion.mannual_backward: a clamped Gaussian image gradient from a per-call seeded stream."""
+
+    def __init__(self, seed=42):
+        self.gen = None
+        self.seed = seed
+
+    def __call__(self, rgb):
+        if self.gen is None:
+            self.gen = torch.Generator(device=rgb.device); self.gen.manual_seed(self.seed)
+        return torch.randn(rgb.shape, generator=self.gen, device=rgb.device, dtype=rgb.dtype).clamp_(-1.0, 1.0)
+
+
+def flat_grad_view(params):
+    """Allocate ONE contiguous fp32 buffer and point every p.grad into it (so that the all-reduce is a single
+    collective over 49 MB instead of 15 small ones).  Returns the flat buffer."""
+    params = [p for p in params if p.requires_grad]
+    n = sum(p.numel() for p in params)
+    flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    return flat
+
+
+def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_size=4096, w_eikonal=0.01, use_opacity=True,
+             bkg_key=WHITE_BKG, flat_grad=None, process_group=None, num_steps=64, upsample_steps=64):
+    """rays_o, rays_d: [h*w, 3] of the (sub-sampled) training view; hw = (h, w).  Returns a dict of scalars."""
+    h, w = hw
+    n_rays = h * w
+    # (A) render_val: net_style stays in train mode (stylize.py never calls eval()), no grad
+    rgb_val, _ = render_instantnsr_naive(net_style, rays_o, rays_d, rays_per_batch=batch_size, requires_grad=False, bkg_key=bkg_key,
+                                         render_can=True, perturb=True, num_steps=num_steps, upsample_steps=upsample_steps, bound=NSR_BOUND)
+    img = rgb_val.reshape(h, w, 3).permute(2, 0, 1).unsqueeze(0)             # "(h w) c -> 1 c h w"
+    # (B) gradient of the guidance loss w.r.t. the whole image
+    grad_img = guidance(img.detach())
+    grad_rays = grad_img.squeeze(0).permute(1, 2, 0).reshape(n_rays, 3).detach()
+    # (C) patch-wise backward
+    if flat_grad is not None:
+        flat_grad.zero_()
+    else:
+        optimizer.zero_grad()
+    bs = min(batch_size, n_rays)
+    eik_vals, opa_vals = [], []
+    for i in range(0, n_rays, bs):
+        ro, rd = rays_o[i:i + bs], rays_d[i:i + bs]
+        rgb, eik, extra = render_instantnsr_naive(net_style, ro, rd, requires_grad=True, bkg_key=bkg_key, rays_per_batch=bs, perturb=1.0,
+                                                  return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
+                                                  upsample_steps=upsample_steps)
+        opacity_pred = extra["weight_sum"]
+        rgb.backward(gradient=grad_rays[i:i + bs], retain_graph=True)
+        if w_eikonal > 0.0:
+            eik_loss = eik * w_eikonal
+            eik_vals.append(eik_loss.detach())
+            eik_loss.backward(retain_graph=True)
+        with torch.no_grad():       # frozen reference avatar: its graph is never used (the reference detaches it, :187)
+            _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
+                                                     return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps)
+        opacity_loss = F.smooth_l1_loss(opacity_pred.clamp(0.0, 1.0), extra_gt["weight_sum"].clamp(0.0, 1.0).detach()) * 1e5
+        opa_vals.append(opacity_loss.detach())
+        if use_opacity:
+            opacity_loss.backward(retain_graph=False)
+    # data parallel: one collective over the flat gradient
+    if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        world = torch.distributed.get_world_size(process_group)
+        if world > 1:
+            if flat_grad is None:
+                raise RuntimeError("data-parallel sds_step needs flat_grad = flat_grad_view(net_style.parameters())")
+            torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
+            flat_grad.div_(world)
+    # (D)
+    optimizer.step()
+    return {"eikonal": torch.stack(eik_vals).mean() if eik_vals else torch.zeros(()), "opacity": torch.stack(opa_vals).mean()}
+
+
+def shard_views(n_views, rank, world):
+    """view indices handled by `rank` in one epoch: round-robin, every rank the same count (drop the remainder)"""
+    per = n_views // world
+    return [rank + world * k for k in range(per)]

@@ -67,12 +67,54 @@ def cpu_baseline(p, table, ro, rd, budget_s=12.0):
                 sample=f"{n} rays (every {max(1, ro.shape[0] // n)}-th ray of the 256x256 view), 64+64 samples, {dt:.1f} s wall, OpenMP over rays")
 
 
+def time_sds_step(dev, p, table, rank, world, dist, steps):
+    """secondary metric: ms per 4096-ray SDS step (stylize.py coarse stage: 64x64 sub-sampled view of a 256x256 camera,
+    3 renders + 3 backward passes per patch, Adam, all-reduce of the 49 MB flat gradient when world > 1).  Synthetic guidance
+    (the SD UNet is out of scope); differentiable render core currently on autograd over the HIP hash encoder."""
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view
+    from tests.common import make_rays
+
+    def make_net(train):
+        torch.manual_seed(0)
+        net = NeRFNetwork()
+        sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
+        sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
+        net.load_state_dict(sd)
+        return net.to(dev).train(train)
+    net, net_gt = make_net(True), make_net(False)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    flat = flat_grad_view(net.parameters())
+    guidance = SyntheticGuidance(42 + rank)
+    yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
+    ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=yaw, pitch=0.0)
+    ro = torch.from_numpy(ro.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy()).to(dev)      # stride-4 sub-sampling -> 64x64
+    rd = torch.from_numpy(rd.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy()).to(dev)
+    sds_step(net, net_gt, ro, rd, (64, 64), opt, guidance, batch_size=4096, flat_grad=flat)        # warm-up
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sds_step(net, net_gt, ro, rd, (64, 64), opt, guidance, batch_size=4096, flat_grad=flat)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    return {"ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad + 1 frozen",
+            "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)", "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if world > 1 else 0,
+            "core": "fused HIP sampling + autograd render core over the HIP hash encoder (fused backward kernel: next round)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sds-steps", type=int, default=3, help="also time this many 4096-ray SDS steps (secondary metric); 0 = skip")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,6 +165,10 @@ def main():
         dt = float(tt.item())
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
 
+    sds = None
+    if a.sds_steps > 0:
+        sds = time_sds_step(dev, p, table, rank, world, dist, a.sds_steps)
+
     if rank == 0:
         total_rays = world * a.steps * RAYS_PER_BATCH
         achieved = BYTES_PER_RAY * RAYS_PER_BATCH / (kern_ms * 1e-3) / 1e9
@@ -144,6 +190,8 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_RAY * RAYS_PER_BATCH,
                          "mfma_f32_tflops": FLOP_PER_RAY * RAYS_PER_BATCH / (kern_ms * 1e-3) / 1e12, "mfma_f32_peak_tflops": 157.3},
         }
+        if sds is not None:
+            res["sds_step"] = sds
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, table, ro, rd)
         print(json.dumps(res))

@@ -182,6 +182,32 @@ def main():
         print(name, "weights_sum min/mean/max", c["weights_sum"].min(), c["weights_sum"].mean(), c["weights_sum"].max(),
               "eik", c["gradient_error"])
 
+    # gradients of one training render: rgb.backward(image_grad) + (0.01 * eikonal).backward(),
+    # stylize.py:163-169, on the reference's own autograd graph (hash backward served by the oracle)
+    net.train(True)
+    net.zero_grad()
+    torch.manual_seed(42)
+    noise_g = torch.rand(ro2.shape[0], 64).numpy().copy()
+    torch.manual_seed(42)
+    outg = net.render(torch.from_numpy(ro2)[None], torch.from_numpy(rd2)[None], num_steps=64, bound=1.6, upsample_steps=64, staged=False,
+                      bg_color=torch.from_numpy(bg2), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=True)
+    img_grad = np.clip(np.random.RandomState(5).normal(0, 1, (ro2.shape[0], 3)), -1, 1).astype(np.float32)
+    outg["rgb"][0].backward(gradient=torch.from_numpy(img_grad), retain_graph=True)
+    (outg["gradient_error"] * 0.01).backward()
+    gg = dict(rays_o=ro2, rays_d=rd2, bg=bg2, noise=noise_g, img_grad=img_grad, rgb=outg["rgb"][0].detach().numpy(),
+              z_vals=outg["z_vals"].detach().numpy())
+    for k, prm in net.named_parameters():
+        if k != "encoder.embeddings":
+            gg["grad." + k] = prm.grad.numpy().copy()
+    ge = net.encoder.embeddings.grad.numpy()
+    nz = np.flatnonzero(np.abs(ge).sum(1))
+    pick = nz[np.random.RandomState(6).choice(len(nz), 4096, replace=False)]
+    gg["emb_idx"] = pick.astype(np.int64); gg["emb_grad"] = ge[pick].copy()
+    gg["emb_nnz"] = np.int64(len(nz)); gg["emb_l2"] = np.float64(np.sqrt((ge.astype(np.float64) ** 2).sum())); gg["emb_sum"] = np.float64(ge.astype(np.float64).sum())
+    np.savez_compressed(os.path.join(HERE, "train_grad.npz"), **gg)
+    print("train_grad: emb nnz", len(nz), "l2", gg["emb_l2"], "variance grad", gg["grad.deviation_net.variance"])
+    net.zero_grad()
+
     # forward_sdf / forward_color / gradient point-wise goldens (instant_nsr.py:627-704)
     pts = rs.uniform(-1.6, 1.6, size=(257, 3)).astype(np.float32)
     pts[0] = [1.6, -1.6, 1.6]; pts[1] = [0, 0, 0]

@@ -1,0 +1,110 @@
+"""-m gpu: the host mirror of the reference's model API (NeRFNetwork.render, render_instantnsr_naive, the SDS step)
+against goldens recorded from the reference's Python."""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import load_golden, make_table, make_rays
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def golden_net(train=False):
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    p = load_golden("nsr_params.npz")
+    torch.manual_seed(0)
+    net = NeRFNetwork()
+    sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
+    sd["encoder.embeddings"] = torch.from_numpy(make_table(int(p["offsets"][-1]), seed=int(p["table_seed"]), offsets=p["offsets"],
+                                                           level_amp=p["level_amp"]))
+    sd["encoder.offsets"] = torch.from_numpy(p["offsets"])
+    net.load_state_dict(sd, strict=True)           # same keys as the reference's checkpoints
+    return net.to(DEV).train(train), p
+
+
+@pytest.mark.parametrize("name", ["eval_64_64", "eval_32_32", "eval_64_0"])
+def test_render_matches_reference_render(name):
+    net, p = golden_net()
+    g = load_golden(f"run_{name}.npz")
+    with torch.no_grad():
+        out = net.render(torch.from_numpy(g["rays_o"]).to(DEV)[None], torch.from_numpy(g["rays_d"]).to(DEV)[None],
+                         num_steps=int(g["num_steps"]), bound=1.6, upsample_steps=int(g["upsample_steps"]), staged=False,
+                         bg_color=torch.from_numpy(g["bg"]).to(DEV), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=False)
+    N, T = g["rays_o"].shape[0], int(g["num_steps"]) + int(g["upsample_steps"])
+    assert set(out) == {"depth", "weights", "weight_sum", "rgb", "normal", "gradient_error", "curvature_error", "pts_color", "pts_alpha", "z_vals"}
+    assert out["rgb"].shape == (1, N, 3) and out["depth"].shape == (1, N) and out["weight_sum"].shape == (N, 1)
+    assert out["weights"].shape == (N, T) and out["pts_color"].shape == (N, T, 3) and out["normal"].shape == (N, 3)
+    c = lambda t: t.detach().cpu().numpy()
+    assert np.abs(c(out["rgb"])[0] - g["image"]).max() <= 1e-3
+    assert np.abs(c(out["weight_sum"])[:, 0] - g["weights_sum"]).max() <= 1e-3
+    assert np.abs(c(out["depth"])[0] - g["depth"]).max() <= 1e-3
+    assert abs(float(out["gradient_error"]) - float(g["gradient_error"])) <= 1e-4
+
+
+def test_render_instantnsr_naive_batches_and_shapes():
+    from avatarcraft_amd.render_utils import render_instantnsr_naive, WHITE_BKG, BLACK_BKG
+    net, p = golden_net()
+    ro, rd = make_rays(16, 16, dist=1.7, f=12.5)
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    rgb, eik, extra = render_instantnsr_naive(net, ro_t, rd_t, rays_per_batch=100, bkg_key=WHITE_BKG, render_can=True, perturb=False, return_raw=True)
+    assert rgb.shape == (256, 3) and extra["depth"].shape == (256, 1) and extra["weight_sum"].shape == (256, 1) and extra["normal"].shape == (256, 3)
+    # ragged batching (100,100,56) == one batch, bit for bit (rays are independent)
+    rgb1, eik1, _ = render_instantnsr_naive(net, ro_t, rd_t, rays_per_batch=6400, bkg_key=WHITE_BKG, render_can=True, perturb=False, return_raw=True)
+    assert torch.equal(rgb, rgb1)
+    rgbk, _ = render_instantnsr_naive(net, ro_t, rd_t, rays_per_batch=256, bkg_key=BLACK_BKG, render_can=True, perturb=False)
+    ws = extra["weight_sum"]
+    assert torch.allclose(rgb - rgbk, (1 - ws).expand(-1, 3), atol=1e-6)          # image = colour + (1 - w) * bg
+    with pytest.raises(NotImplementedError):
+        render_instantnsr_naive(net, ro_t, rd_t, render_can=False)
+
+
+def test_training_gradients_match_reference_autograd():
+    """stylize.py:163-169: rgb.backward(image_grad) then (0.01*eikonal).backward() -- parameter gradients against the
+    reference's own autograd (tests/golden/train_grad.npz)."""
+    from avatarcraft_amd import nsr_ops
+    net, p = golden_net(train=True)
+    g = load_golden("train_grad.npz")
+    ro, rd = torch.from_numpy(g["rays_o"]).to(DEV), torch.from_numpy(g["rays_d"]).to(DEV)
+    # feed the recorded jitter so that the sample positions are the reference's (torch.rand streams differ across devices)
+    orig_rand = torch.rand
+    torch.rand = lambda *a, **k: torch.from_numpy(g["noise"]).to(DEV)
+    try:
+        out = net.render(ro[None], rd[None], num_steps=64, bound=1.6, upsample_steps=64, staged=False, bg_color=torch.from_numpy(g["bg"]).to(DEV),
+                         cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=True)
+    finally:
+        torch.rand = orig_rand
+    assert np.abs(out["rgb"][0].detach().cpu().numpy() - g["rgb"]).max() <= 1e-3
+    out["rgb"][0].backward(gradient=torch.from_numpy(g["img_grad"]).to(DEV), retain_graph=True)
+    (out["gradient_error"] * 0.01).backward()
+    for k, prm in net.named_parameters():
+        if k == "encoder.embeddings":
+            continue
+        ref = g["grad." + k]
+        got = prm.grad.detach().cpu().numpy()
+        scale = np.abs(ref).max() + 1e-12
+        assert np.abs(got - ref).max() <= 2e-2 * scale, (k, np.abs(got - ref).max(), scale)
+    ge = net.encoder.embeddings.grad
+    l2 = float(torch.sqrt((ge.double() ** 2).sum()))
+    assert abs(l2 - float(g["emb_l2"])) <= 2e-2 * float(g["emb_l2"])
+    sub = ge[torch.from_numpy(g["emb_idx"]).to(DEV)].cpu().numpy()
+    assert np.abs(sub - g["emb_grad"]).max() <= 3e-2 * np.abs(g["emb_grad"]).max()
+    nnz = int((ge.abs().sum(1) > 0).sum())
+    assert abs(nnz - int(g["emb_nnz"])) <= 0.01 * int(g["emb_nnz"])
+
+
+def test_sds_step_updates_parameters_and_is_finite():
+    from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view
+    net, p = golden_net(train=True)
+    net_gt, _ = golden_net(train=False)          # frozen copy of the initial avatar (stylize.py:328-338 loads the ckpt twice)
+    ro, rd = make_rays(32, 32, dist=1.8, f=25.0)
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    flat = flat_grad_view(net.parameters())
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    stats = sds_step(net, net_gt, ro_t, rd_t, (32, 32), opt, SyntheticGuidance(42), batch_size=512, flat_grad=flat)
+    assert torch.isfinite(flat).all() and float(flat.abs().sum()) > 0
+    assert torch.isfinite(stats["eikonal"]) and torch.isfinite(stats["opacity"])
+    changed = [k for k, v in net.named_parameters() if not torch.equal(v.detach(), before[k])]
+    assert "encoder.embeddings" in changed and "sdf_net.0.weight_v" in changed and "color_net.2.weight_v" in changed
+    assert flat.numel() == 12248902
