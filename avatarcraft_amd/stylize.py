@@ -71,18 +71,22 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                                                   return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
                                                   upsample_steps=upsample_steps)
         opacity_pred = extra["weight_sum"]
-        rgb.backward(gradient=grad_rays[i:i + bs], retain_graph=True)
+        # The reference back-propagates the three terms one after the other through the same retained graph
+        # (stylize.py:163,169,193).  Gradients are linear in the loss, so ONE backward pass of their sum gives the same
+        # parameter gradients with a third of the hash-table scatter traffic.
+        total = (rgb * grad_rays[i:i + bs]).sum()
         if w_eikonal > 0.0:
             eik_loss = eik * w_eikonal
             eik_vals.append(eik_loss.detach())
-            eik_loss.backward(retain_graph=True)
+            total = total + eik_loss
         with torch.no_grad():       # frozen reference avatar: its graph is never used (the reference detaches it, :187)
             _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
                                                      return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps)
         opacity_loss = F.smooth_l1_loss(opacity_pred.clamp(0.0, 1.0), extra_gt["weight_sum"].clamp(0.0, 1.0).detach()) * 1e5
         opa_vals.append(opacity_loss.detach())
         if use_opacity:
-            opacity_loss.backward(retain_graph=False)
+            total = total + opacity_loss
+        total.backward()
     # data parallel: one collective over the flat gradient
     if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
         world = torch.distributed.get_world_size(process_group)
