@@ -54,6 +54,8 @@ _SIGS = {
     "ac_eikonal_reduce": ([vp, i32, vp, vp], C.c_int),
     "ac_field_sdf": ([C.POINTER(ac_field), vp, u32, f32, vp, vp], C.c_int),
     "ac_field_color": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),
+    "ac_mesh_near_far": ([vp, vp, vp, u32, u32, f32, vp, vp, vp], C.c_int),
+    "ac_warp_samples": ([vp, vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp, vp, vp, vp, vp], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
 

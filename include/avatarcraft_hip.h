@@ -175,6 +175,23 @@ int ac_field_sdf(const ac_field *field, const float *x, uint32_t B, float bound,
 int ac_field_color(const ac_field *field, const float *x, const float *n, const float *sdfout, uint32_t B,
                    float *rgb, ac_stream_t stream);
 
+/* ---- SMPL-guided animation path (render_warp.py, NeRFRenderer.run with render_can=False) ---------------------
+ * replaces geometry_guided_near_far_torch (utils/ray_utils.py:277-294): per ray, over V vertex spheres of radius
+ * geo_threshold; near/far [N], +inf / -inf where the ray misses every sphere (the caller substitutes the cube bounds,
+ * models/instant_nsr.py:152-153). */
+int ac_mesh_near_far(const float *rays_o, const float *rays_d, const float *verts, uint32_t N, uint32_t V, float geo_threshold,
+                     float *near, float *far, ac_stream_t stream);
+
+/* replaces warp_samples_to_canonical (utils/ray_utils.py:62-90; CPU libigl + numpy in the reference): for every sample
+ * pts[P,3] (fp32): exact closest point on the triangle mesh (verts[V,3] fp32, faces[F,3] int32), mask = dist^2 < threshold
+ * (the reference compares the SQUARED distance with DEFAULT_GEO_THRESH), barycentric blend of the per-vertex transforms
+ * T[V',4,4] (fp64, V' >= max vertex index + 1), 4x4 inverse and application, all in fp64.
+ * Outputs: can_pts [P,3] fp64 and/or can_pts_f32 [P,3] (at least one non-NULL); optional closest [P,3] fp64, dist2 [P] fp64,
+ * face_id [P]; mask [P] uint8. */
+int ac_warp_samples(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V, uint32_t F,
+                    double threshold, double *can_pts, float *can_pts_f32, double *closest, double *dist2, int32_t *face_id,
+                    uint8_t *mask, ac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -333,3 +333,114 @@ ORC_API int orc_compact_rays(uint32_t n_alive, int32_t *rays_alive, const int32_
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* SMPL-guided warp (utils/ray_utils.py:62-90, 277-308)                 */
+/* ------------------------------------------------------------------ */
+/* geometry_guided_near_far_torch (ray_utils.py:277-294): per ray, over V vertex-spheres of radius r */
+ORC_API int orc_mesh_near_far(const float *rays_o, const float *rays_d, const float *verts, uint32_t N, uint32_t V,
+                              float geo_threshold, float *near, float *far)
+{
+    const float r2 = (float)((double)geo_threshold * (double)geo_threshold);   /* geo_threshold**2 is a python float */
+    #pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const float *o = rays_o + 3 * n, *d = rays_d + 3 * n;
+        float nr = INFINITY, fr = -INFINITY;
+        for (uint32_t v = 0; v < V; v++) {
+            const float x = verts[3 * v] - o[0], y = verts[3 * v + 1] - o[1], z = verts[3 * v + 2] - o[2];
+            const float z0 = (x * d[0] + y * d[1]) + z * d[2];
+            const float nrm = sqrtf((x * x + y * y) + z * z);
+            const float dz = sqrtf(r2 - (nrm * nrm - z0 * z0));
+            const float a = z0 - dz, b = z0 + dz;
+            if (a == a && a < nr) nr = a;          /* NaN -> +inf / -inf */
+            if (b == b && b > fr) fr = b;
+        }
+        near[n] = nr; far[n] = fr;
+    }
+    return 0;
+}
+
+/* closest point on triangle (a,b,c) to p, all double: Ericson, Real-Time Collision Detection 5.1.5 */
+static void closest_pt_tri(const double p[3], const double a[3], const double b[3], const double c[3], double out[3])
+{
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+    #define DOT(u, v) ((u)[0] * (v)[0] + (u)[1] * (v)[1] + (u)[2] * (v)[2])
+    const double d1 = DOT(ab, ap), d2 = DOT(ac, ap);
+    if (d1 <= 0.0 && d2 <= 0.0) { for (int i = 0; i < 3; i++) out[i] = a[i]; return; }
+    for (int i = 0; i < 3; i++) bp[i] = p[i] - b[i];
+    const double d3 = DOT(ab, bp), d4 = DOT(ac, bp);
+    if (d3 >= 0.0 && d4 <= d3) { for (int i = 0; i < 3; i++) out[i] = b[i]; return; }
+    const double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) { const double v = d1 / (d1 - d3); for (int i = 0; i < 3; i++) out[i] = a[i] + v * ab[i]; return; }
+    for (int i = 0; i < 3; i++) cp[i] = p[i] - c[i];
+    const double d5 = DOT(ab, cp), d6 = DOT(ac, cp);
+    if (d6 >= 0.0 && d5 <= d6) { for (int i = 0; i < 3; i++) out[i] = c[i]; return; }
+    const double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { const double w = d2 / (d2 - d6); for (int i = 0; i < 3; i++) out[i] = a[i] + w * ac[i]; return; }
+    const double va = d3 * d6 - d5 * d4;
+    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+        const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int i = 0; i < 3; i++) out[i] = b[i] + w * (c[i] - b[i]);
+        return;
+    }
+    const double denom = 1.0 / (va + vb + vc), v = vb * denom, w = vc * denom;
+    for (int i = 0; i < 3; i++) out[i] = a[i] + ab[i] * v + ac[i] * w;
+}
+
+/* 4x4 inverse, Gauss-Jordan with partial pivoting (np.linalg.inv restated) */
+static int inv4(const double m[16], double out[16])
+{
+    double a[4][8];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { a[i][j] = m[4 * i + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; col++) {
+        int piv = col; double best = fabs(a[col][col]);
+        for (int r = col + 1; r < 4; r++) if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+        if (best == 0.0) return 1;
+        if (piv != col) for (int j = 0; j < 8; j++) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+        const double ip = 1.0 / a[col][col];
+        for (int j = 0; j < 8; j++) a[col][j] *= ip;
+        for (int r = 0; r < 4; r++) if (r != col) { const double f = a[r][col]; if (f != 0.0) for (int j = 0; j < 8; j++) a[r][j] -= f * a[col][j]; }
+    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out[4 * i + j] = a[i][4 + j];
+    return 0;
+}
+
+/* warp_samples_to_canonical (ray_utils.py:62-90): closest point on the mesh (brute force over all faces, double;
+ * the reference uses libigl's AABB tree -- same mathematical result), mask = dist^2 < threshold,
+ * barycentric blend of the three per-vertex 4x4 (double), inverse, apply.  Ties between faces: lowest face id.
+ * Outputs: can_pts [P,3] double, closest [P,3] double, dist2 [P] double, face_id [P], mask [P] uint8. */
+ORC_API int orc_warp_samples(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t F,
+                             double threshold, double *can_pts, double *closest, double *dist2, int32_t *face_id, uint8_t *mask)
+{
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)P; i++) {
+        const double p[3] = { pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] };
+        double best = INFINITY, bc[3] = {0, 0, 0}; int bf = 0;
+        for (uint32_t f = 0; f < F; f++) {
+            double a[3], b[3], c[3], q[3];
+            for (int k = 0; k < 3; k++) { a[k] = verts[3 * faces[3 * f] + k]; b[k] = verts[3 * faces[3 * f + 1] + k]; c[k] = verts[3 * faces[3 * f + 2] + k]; }
+            closest_pt_tri(p, a, b, c, q);
+            const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2], d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best) { best = d2; bf = (int)f; bc[0] = q[0]; bc[1] = q[1]; bc[2] = q[2]; }
+        }
+        /* igl.barycentric_coordinates_tri(closest, a, b, c) */
+        double a[3], b[3], c[3], v0[3], v1[3], v2[3];
+        const int32_t *fv = faces + 3 * bf;
+        for (int k = 0; k < 3; k++) { a[k] = verts[3 * fv[0] + k]; b[k] = verts[3 * fv[1] + k]; c[k] = verts[3 * fv[2] + k];
+                                      v0[k] = b[k] - a[k]; v1[k] = c[k] - a[k]; v2[k] = bc[k] - a[k]; }
+        const double d00 = DOT(v0, v0), d01 = DOT(v0, v1), d11 = DOT(v1, v1), d20 = DOT(v2, v0), d21 = DOT(v2, v1);
+        const double den = d00 * d11 - d01 * d01;
+        const double bv = (d11 * d20 - d01 * d21) / den, bw = (d00 * d21 - d01 * d20) / den, bu = 1.0 - bv - bw;
+        double M[16], Mi[16];
+        for (int e = 0; e < 16; e++) M[e] = T[16 * (size_t)fv[0] + e] * bu + T[16 * (size_t)fv[1] + e] * bv + T[16 * (size_t)fv[2] + e] * bw;
+        inv4(M, Mi);
+        for (int r = 0; r < 3; r++) can_pts[3 * i + r] = Mi[4 * r] * p[0] + Mi[4 * r + 1] * p[1] + Mi[4 * r + 2] * p[2] + Mi[4 * r + 3];
+        if (closest) for (int k = 0; k < 3; k++) closest[3 * i + k] = bc[k];
+        if (dist2) dist2[i] = best;
+        if (face_id) face_id[i] = bf;
+        mask[i] = best < threshold ? 1 : 0;
+    }
+    return 0;
+    #undef DOT
+}

@@ -299,3 +299,26 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
         raise RuntimeError("render_rays: unsupported num_steps/upsample_steps")
     res["gradient_error"] = float(lib().orc_eikonal_reduce(_p(res["eik"]), C.c_int32(N)))
     return res
+
+
+# ------------------------------------------------------------------ SMPL-guided warp
+def mesh_near_far(rays_o, rays_d, verts, geo_threshold=0.05):
+    rays_o = _f(rays_o).reshape(-1, 3); rays_d = _f(rays_d).reshape(-1, 3); verts = _f(verts).reshape(-1, 3)
+    N = rays_o.shape[0]
+    near = np.empty(N, np.float32); far = np.empty(N, np.float32)
+    lib().orc_mesh_near_far(_p(rays_o), _p(rays_d), _p(verts), C.c_uint32(N), C.c_uint32(verts.shape[0]), C.c_float(geo_threshold), _p(near), _p(far))
+    return near, far
+
+
+def warp_samples(pts, verts, faces, T, threshold=0.05):
+    """warp_samples_to_canonical (utils/ray_utils.py:62-90): returns can_pts f64, closest f64, dist2 f64, face_id, mask"""
+    pts = _f(pts).reshape(-1, 3); verts = _f(verts).reshape(-1, 3)
+    faces = np.ascontiguousarray(faces[:, :3], np.int32); T = np.ascontiguousarray(T, np.float64)
+    P = pts.shape[0]
+    can = np.empty((P, 3), np.float64); clo = np.empty((P, 3), np.float64); d2 = np.empty(P, np.float64)
+    fid = np.empty(P, np.int32); mask = np.empty(P, np.uint8)
+    dp = C.POINTER(C.c_double)
+    lib().orc_warp_samples(_p(pts), _p(verts), _p(faces, i32p), T.ctypes.data_as(dp), C.c_uint32(P), C.c_uint32(faces.shape[0]),
+                           C.c_double(threshold), can.ctypes.data_as(dp), clo.ctypes.data_as(dp), d2.ctypes.data_as(dp), _p(fid, i32p),
+                           mask.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return can, clo, d2, fid, mask.astype(bool)

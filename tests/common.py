@@ -63,3 +63,38 @@ def oracle_field_from_golden(params=None):
     table = make_table(int(p["offsets"][-1]), seed=int(p["table_seed"]), offsets=p["offsets"], level_amp=p["level_amp"])
     return O.Field(table, p["offsets"], p["W1"], p["b1"], p["W2"], p["b2"], p["Wc1"], p["Wc2"], p["Wc3"],
                    float(p["per_level_scale"]))
+
+
+def make_body(n_lat=40, n_lon=80, seed=3):
+    """Synthetic SMPL-like body for the warp tests: a closed capsule mesh (UV sphere stretched along y, scaled to the
+    avatar's size), per-vertex rigid-ish 4x4 transforms (float64, smooth in space, like blended LBS matrices).
+    Returns verts[V,3] f32, faces[F,3] i32, Ts[V,4,4] f64."""
+    th = np.linspace(0, np.pi, n_lat + 2)[1:-1]
+    ph = np.linspace(0, 2 * np.pi, n_lon, endpoint=False)
+    v = [[0, 1, 0]]
+    for t in th:
+        for p_ in ph:
+            v.append([np.sin(t) * np.cos(p_), np.cos(t), np.sin(t) * np.sin(p_)])
+    v.append([0, -1, 0])
+    v = np.array(v) * np.array([0.28, 0.85, 0.2])
+    f = []
+    for j in range(n_lon):
+        f.append([0, 1 + (j + 1) % n_lon, 1 + j])
+    for i in range(n_lat - 1):
+        for j in range(n_lon):
+            a = 1 + i * n_lon + j; b = 1 + i * n_lon + (j + 1) % n_lon; c = a + n_lon; d = b + n_lon
+            f.append([a, b, d]); f.append([a, d, c])
+    last = len(v) - 1
+    for j in range(n_lon):
+        a = 1 + (n_lat - 1) * n_lon + j; b = 1 + (n_lat - 1) * n_lon + (j + 1) % n_lon
+        f.append([a, b, last])
+    verts = v.astype(np.float32)
+    faces = np.array(f, dtype=np.int32)
+    rs = np.random.RandomState(seed)
+    # smooth transform field: rotation about z by an angle that varies with height + small translation, scaled by 1/0.9
+    ang = 0.35 * np.sin(2.0 * verts[:, 1].astype(np.float64)) + 0.05 * rs.normal(size=verts.shape[0])
+    Ts = np.tile(np.eye(4)[None], (verts.shape[0], 1, 1))
+    Ts[:, 0, 0] = np.cos(ang); Ts[:, 0, 1] = -np.sin(ang); Ts[:, 1, 0] = np.sin(ang); Ts[:, 1, 1] = np.cos(ang)
+    Ts[:, :3, 3] = 0.03 * rs.normal(size=(verts.shape[0], 3))
+    Ts = Ts @ (np.eye(4) / 0.9)
+    return verts, faces, Ts

@@ -294,5 +294,41 @@ def make_ray_goldens():
     print("rays: centre d", out["kat64_d"][2080], "corner", out["kat64_d"][0], "o", out["kat64_o"][0])
 
 
+def make_warp_goldens():
+    """SMPL-guided warp rows (a2, a13): geometry_guided_near_far_{torch,np} are pure torch/numpy in the reference;
+    warp_samples_to_canonical calls libigl (absent here) for the closest point and the barycentric coordinates: those two
+    calls are served by a stand-in (closest point from the oracle, the textbook barycentric formula), everything else in
+    the function (mask on the SQUARED distance, blend of the per-vertex 4x4, np.linalg.inv, apply, can_dirs) is the
+    reference's own numpy code.  Hence: closest-point parity is pinned against the definition only."""
+    import utils.ray_utils as RY
+    from tests.common import make_body
+    verts, faces, Ts = make_body()
+    igl = sys.modules["igl"]
+
+    def point_mesh_squared_distance(P, V, F):
+        can, clo, d2, fid, mask = O.warp_samples(P, V, F, np.tile(np.eye(4)[None], (V.shape[0], 1, 1)))
+        return d2, fid, clo
+
+    def barycentric_coordinates_tri(p, a, b, c):
+        p, a, b, c = (np.asarray(t, np.float64) for t in (p, a, b, c))       # libigl's double-precision path
+        v0, v1, v2 = b - a, c - a, p - a
+        d00 = (v0 * v0).sum(1); d01 = (v0 * v1).sum(1); d11 = (v1 * v1).sum(1); d20 = (v2 * v0).sum(1); d21 = (v2 * v1).sum(1)
+        den = d00 * d11 - d01 * d01
+        v = (d11 * d20 - d01 * d21) / den; w = (d00 * d21 - d01 * d20) / den
+        return np.stack([1 - v - w, v, w], 1)
+    igl.point_mesh_squared_distance = point_mesh_squared_distance
+    igl.barycentric_coordinates_tri = barycentric_coordinates_tri
+    ro, rd = make_rays(12, 12, dist=1.8, f=9.0, jitter_seed=11)
+    near_t, far_t = RY.geometry_guided_near_far_torch(torch.from_numpy(ro), torch.from_numpy(rd), verts, 0.05)
+    near_n, far_n = RY.geometry_guided_near_far_np(ro, rd, verts, 0.05)
+    z = np.linspace(0.9, 2.7, 24, dtype=np.float32)
+    pts = (ro[:, None, :] + rd[:, None, :] * z[None, :, None]).astype(np.float32)
+    can, can_dirs, closest, mask = RY.warp_samples_to_canonical(pts, verts, np.concatenate([faces, faces], 1), Ts, 0.05)
+    np.savez_compressed(os.path.join(HERE, "warp.npz"), rays_o=ro, rays_d=rd, near_t=near_t.numpy(), far_t=far_t.numpy(), near_n=near_n, far_n=far_n,
+                        pts=pts, can_pts=can, can_dirs=can_dirs, closest=closest, mask=mask)
+    print("warp: rays hitting the body", int(np.isfinite(near_t.numpy()).sum()), "of", ro.shape[0], "mask frac", float(mask.mean()))
+
+
 if __name__ == "__main__":
     make_ray_goldens()
+    make_warp_goldens()

@@ -201,3 +201,33 @@ def test_inference_march_composite_compact(oracle):
     RM.compact_rays(1500, ra, T(alive), rtt, rt, cnt)
     assert int(cnt[0]) == cnt_o and 0 < cnt_o < 1500
     assert np.array_equal(ra.cpu().numpy()[:cnt_o], ra_o[:cnt_o]); assert_bitwise(rtt[:cnt_o], rtt_o[:cnt_o], "rays_t")
+
+
+# ------------------------------------------------------------------ SMPL-guided warp (rows a2, a13)
+def test_mesh_near_far_and_warp(oracle):
+    from avatarcraft_amd import ray_utils as RY
+    from tests.common import make_body, make_rays
+    g = load_golden("warp.npz")
+    verts, faces, Ts = make_body()
+    # goldens (reference code)
+    near, far = RY.geometry_guided_near_far(T(g["rays_o"]), T(g["rays_d"]), verts, 0.05)
+    fin = np.isfinite(g["near_t"])
+    assert np.array_equal(np.isfinite(near.cpu().numpy()), fin)
+    assert np.abs(near.cpu().numpy()[fin] - g["near_t"][fin]).max() < 5e-5
+    can, dirs, clo, mask = RY.warp_samples_to_canonical(g["pts"], verts, np.concatenate([faces, faces], 1), Ts, 0.05)   # numpy in -> numpy out
+    assert isinstance(can, np.ndarray) and can.dtype == np.float64
+    assert np.array_equal(mask, g["mask"]) and np.abs(can - g["can_pts"]).max() < 1e-12
+    assert np.abs(dirs - g["can_dirs"]).max() < 1e-9 and np.abs(clo - g["closest"]).max() < 1e-12
+    # bitwise vs the oracle on a larger problem, torch in -> torch out
+    ro, rd = make_rays(48, 48, dist=1.8, f=40.0, jitter_seed=2)
+    n_o, f_o = oracle.mesh_near_far(ro, rd, verts, 0.05)
+    n_g, f_g = RY.geometry_guided_near_far(T(ro), T(rd), T(verts), 0.05)
+    assert_bitwise(n_g, n_o, "mesh near"); assert_bitwise(f_g, f_o, "mesh far")
+    z = np.linspace(0.8, 2.8, 32, dtype=np.float32)
+    pts = (ro[:, None, :] + rd[:, None, :] * z[None, :, None]).astype(np.float32)
+    can_o, clo_o, d2_o, fid_o, m_o = oracle.warp_samples(pts.reshape(-1, 3), verts, faces, Ts, 0.05)
+    can_g, _, clo_g, m_g = RY.warp_samples_to_canonical(T(pts), T(verts), T(faces), T(Ts), 0.05)
+    assert can_g.is_cuda and can_g.dtype == torch.float64
+    assert np.array_equal(can_g.cpu().numpy().reshape(-1, 3).view(np.uint64), can_o.view(np.uint64))
+    assert np.array_equal(clo_g.cpu().numpy().reshape(-1, 3).view(np.uint64), clo_o.view(np.uint64))
+    assert np.array_equal(m_g.cpu().numpy(), m_o)

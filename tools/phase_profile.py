@@ -7,7 +7,7 @@ import numpy as np, torch
 csrc = os.path.join(ROOT, "avatarcraft_amd", "csrc")
 out = os.path.join(ROOT, "gpurun_out", "libac_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip")]
+srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "warp.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                        "-DAC_PROFILE", "-Wno-unused-result", "-o", out] + srcs)
 from avatarcraft_amd import _lib
