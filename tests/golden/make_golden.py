@@ -332,3 +332,28 @@ def make_warp_goldens():
 if __name__ == "__main__":
     make_ray_goldens()
     make_warp_goldens()
+
+
+# ---------------------------------------------------------------- SMPL skinning goldens
+def make_smpl_goldens():
+    """models.smpl.lbs is a free function (models/smpl.py:351): called with synthetic buffers of the SMPL layout (the licensed
+    pickle is not available), for T (return_T, concat_joints) and for the posed vertices / joints."""
+    import torch
+    import models.smpl as RS
+    from avatarcraft_amd.smpl import BodyModel
+    bm = BodyModel.synthetic(seed=3, n_verts=600)
+    g = np.random.default_rng(11)
+    pose = (g.standard_normal((1, 72)) * 0.4).astype(np.float32)
+    pose[0, 3:6] = 0.0                                     # one exactly-zero rotation: exercises the 1e-8 epsilon
+    betas = g.standard_normal((1, 10)).astype(np.float32)
+    args = (bm.v_template, bm.shapedirs, bm.posedirs, bm.J_regressor, bm.parents, bm.lbs_weights)
+    T, v, dv = RS.lbs(torch.from_numpy(betas), torch.from_numpy(pose), *args, return_T=True, concat_joints=True)
+    verts, joints = RS.lbs(torch.from_numpy(betas), torch.from_numpy(pose), *args)
+    R = RS.batch_rodrigues(torch.from_numpy(pose).view(-1, 3))
+    np.savez_compressed(os.path.join(HERE, "smpl.npz"), pose=pose, betas=betas, T=T.numpy(), v=v.numpy(), dv=dv.numpy(), verts=verts.numpy(),
+                        joints=joints.numpy(), R=R.numpy())
+    print("smpl: T", tuple(T.shape), "verts", tuple(verts.shape))
+
+
+if __name__ == "__main__":
+    make_smpl_goldens()
