@@ -35,6 +35,11 @@ class ac_render_out(C.Structure):
                 ("sort_index", vp)]
 
 
+class ac_warp_mesh(C.Structure):
+    _fields_ = [("verts", vp), ("faces", vp), ("T", vp), ("V", u32), ("F", u32), ("threshold", C.c_double), ("geo_threshold", f32),
+                ("use_mesh_guide", i32)]
+
+
 _SIGS = {
     "ac_version": ([], C.c_int),
     "ac_last_error": ([], C.c_char_p),
@@ -55,6 +60,9 @@ _SIGS = {
     "ac_field_sdf": ([C.POINTER(ac_field), vp, u32, f32, vp, vp], C.c_int),
     "ac_field_color": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),
     "ac_mesh_near_far": ([vp, vp, vp, u32, u32, f32, vp, vp, vp], C.c_int),
+    "ac_render_rays_warped_scratch": ([i32, i32, C.POINTER(C.c_size_t)], C.c_size_t),
+    "ac_render_rays_warped": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_warp_mesh), vp, C.c_size_t,
+                               C.POINTER(ac_render_out), vp], C.c_int),
     "ac_warp_samples": ([vp, vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp, vp, vp, vp, vp], C.c_int),
 }
 EXPORTS = tuple(_SIGS)

@@ -100,7 +100,35 @@ struct RenderArgs {
     float bound, two_bound, inv_s, car, one_m_car, eps;
     int perturb;
     unsigned long long *prof;   // AC_PROFILE builds only: [n_waves][8] cycle counters per phase
+    // posed-space rendering (render_can=False) only: see ac_render_rays_warped
+    const float *near_m, *far_m;   // [N] mesh-guided range (+-inf where the ray misses the body) or NULL
+    const float *ext_pts;          // MODE_UPSAMPLE: warped coarse points [N,T0,3]; MODE_FINAL: warped mid points [N,T,3]
+    const uint8_t *mask;           // MODE_FINAL: [N,T] alpha mask
+    float *zbuf;                   // [N,T] final z values: written by MODE_UPSAMPLE, read by MODE_FINAL
+    float *mid_pts;                // MODE_UPSAMPLE: posed-space mid points [N,T,3]
 };
+
+// render_rays_kernel<MODE>: MODE_FULL is the fused canonical-space renderer.  With the SMPL inverse warp between the phases
+// (a global closest-point search per sample: csrc/warp.hip) the same code is instantiated as its two halves:
+// MODE_UPSAMPLE = coarse sdf at externally warped points + the NeuS up-sampling, writes z and the posed-space mid points;
+// MODE_FINAL = render core at externally warped mid points, alpha multiplied by the mask.
+enum { MODE_FULL = 0, MODE_UPSAMPLE = 2, MODE_FINAL = 3 };
+
+// near_far_from_bound (cube)  instant_nsr.py:58-77
+__device__ __forceinline__ void cube_near_far(float ox, float oy, float oz, float dx, float dy, float dz, float bound, float &near, float &far)
+{
+    const float ex = dx + 1e-15f, ey = dy + 1e-15f, ez = dz + 1e-15f;
+    const float ax = (-bound - ox) / ex, bx = (bound - ox) / ex;
+    const float ay = (-bound - oy) / ey, by = (bound - oy) / ey;
+    const float az = (-bound - oz) / ez, bz = (bound - oz) / ez;
+    const float lx = ax < bx ? ax : bx, hx = ax > bx ? ax : bx;
+    const float ly = ay < by ? ay : by, hy = ay > by ? ay : by;
+    const float lz = az < bz ? az : bz, hz = az > bz ? az : bz;
+    near = lx; if (ly > near) near = ly; if (lz > near) near = lz;
+    far = hx; if (hy < far) far = hy; if (hz < far) far = hz;
+    if (near < 0.05f) near = 0.05f;
+}
+__device__ __forceinline__ bool is_inf(float v) { return __builtin_fabsf(v) == __builtin_inff(); }
 
 // ---- wave-level helpers -----------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync()
@@ -557,6 +585,7 @@ __device__ __forceinline__ FieldCtx make_ctx(const RenderArgs &a)
 }
 
 // =====================================================================================================
+template <int MODE>
 __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -590,42 +619,47 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         AC_T0();
         const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
         const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-        // near_far_from_bound (cube)  instant_nsr.py:58-77
         float near, far;
-        {
-            const float ex = dx + 1e-15f, ey = dy + 1e-15f, ez = dz + 1e-15f;
-            const float ax = (-bound - ox) / ex, bx = (bound - ox) / ex;
-            const float ay = (-bound - oy) / ey, by = (bound - oy) / ey;
-            const float az = (-bound - oz) / ez, bz = (bound - oz) / ez;
-            const float lx = ax < bx ? ax : bx, hx = ax > bx ? ax : bx;
-            const float ly = ay < by ? ay : by, hy = ay > by ? ay : by;
-            const float lz = az < bz ? az : bz, hz = az > bz ? az : bz;
-            near = lx; if (ly > near) near = ly; if (lz > near) near = lz;
-            far = hx; if (hy < far) far = hy; if (hz < far) far = hz;
-            if (near < 0.05f) near = 0.05f;
+        cube_near_far(ox, oy, oz, dx, dy, dz, bound, near, far);
+        if constexpr (MODE != MODE_FULL) {                       // :148-153 mesh-guided range where the ray passes the body
+            if (a.near_m) {
+                const float nm = a.near_m[ray], fm = a.far_m[ray];
+                if (!is_inf(nm)) near = nm;
+                if (!is_inf(fm)) far = fm;
+            }
         }
         const float span = far - near;
         const float sample_dist = span / (float)T0;
         int cur = 0, cnt = T0;
 
         // ---- coarse samples :155-180 -------------------------------------------------------------
-        for (int c = 0; c < T0 / 16; ++c) {
-            const int i = 16 * c + n;
-            float zi = near + span * lds[OFF_LIN + i];
-            if (a.perturb) zi = zi + (a.noise[(size_t)ray * T0 + i] - 0.5f) * sample_dist;
-            if (nup > 0) {
-                const float px = clampf(ox + dx * zi, -bound, bound), py = clampf(oy + dy * zi, -bound, bound),
-                            pz = clampf(oz + dz * zi, -bound, bound);
-                const f32x4 o2 = sdf_tile(lds, fc, lane, px, py, pz);
-                if (g == 0) sd[i] = o2[0];
+        if constexpr (MODE == MODE_FINAL) {
+            for (int i = lane; i < T; i += 64) zs[i] = a.zbuf[(size_t)ray * T + i];
+        } else {
+            for (int c = 0; c < T0 / 16; ++c) {
+                const int i = 16 * c + n;
+                float zi = near + span * lds[OFF_LIN + i];
+                if (a.perturb) zi = zi + (a.noise[(size_t)ray * T0 + i] - 0.5f) * sample_dist;
+                if (nup > 0) {
+                    float px, py, pz;
+                    if constexpr (MODE == MODE_UPSAMPLE) {
+                        const float *e = a.ext_pts + ((size_t)ray * T0 + i) * 3;
+                        px = clampf(e[0], -bound, bound); py = clampf(e[1], -bound, bound); pz = clampf(e[2], -bound, bound);
+                    } else {
+                        px = clampf(ox + dx * zi, -bound, bound); py = clampf(oy + dy * zi, -bound, bound);
+                        pz = clampf(oz + dz * zi, -bound, bound);
+                    }
+                    const f32x4 o2 = sdf_tile(lds, fc, lane, px, py, pz);
+                    if (g == 0) sd[i] = o2[0];
+                }
+                if (g == 0) zs[i] = zi;
             }
-            if (g == 0) zs[i] = zi;
         }
         wave_sync();
         AC_TICK(0)
 
         // ---- NeuS up-sampling :182-184, :410-475 -----------------------------------------------------
-        for (int it = 0; it < nup; ++it) {
+        for (int it = 0; it < (MODE == MODE_FINAL ? 0 : nup); ++it) {
             const float *zc = zs + cur * MAXT, *sc = sd + cur * MAXT;
             float *zn_ = zs + (cur ^ 1) * MAXT, *sn_ = sd + (cur ^ 1) * MAXT;
             const int m = cnt - 1;
@@ -755,6 +789,18 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 
         // ---- render core :190-299 ---------------------------------------------------------------------
         const float *zf = zs + cur * MAXT;
+        if constexpr (MODE == MODE_UPSAMPLE) {                 // hand z and the posed-space mid points to the warp
+            for (int i = lane; i < T; i += 64) {
+                const float zi = zf[i];
+                const float delta = (i < T - 1) ? zf[i + 1] - zi : sample_dist;
+                const float zmid = (i < T - 1) ? zi + 0.5f * delta : zi;
+                const size_t si = (size_t)ray * T + i;
+                a.zbuf[si] = zi;
+                a.mid_pts[3 * si] = ox + dx * zmid; a.mid_pts[3 * si + 1] = oy + dy * zmid; a.mid_pts[3 * si + 2] = oz + dz * zmid;
+            }
+            wave_sync();
+            continue;
+        }
 #ifdef AC_PINGPONG     // experiment: waves 4..7 run the gather/MLP phases one phase behind waves 0..3 (same SIMDs)
         __builtin_amdgcn_s_barrier();
         if (wave >= 4) __builtin_amdgcn_s_barrier();
@@ -768,8 +814,14 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float zi = zf[i];
             const float delta = (i < T - 1) ? zf[i + 1] - zi : sample_dist;
             const float zmid = (i < T - 1) ? zi + 0.5f * delta : zi;
-            const float px = clampf(ox + dx * zmid, -bound, bound), py = clampf(oy + dy * zmid, -bound, bound),
-                        pz = clampf(oz + dz * zmid, -bound, bound);
+            float px, py, pz;
+            if constexpr (MODE == MODE_FINAL) {
+                const float *e = a.ext_pts + ((size_t)ray * T + i) * 3;
+                px = clampf(e[0], -bound, bound); py = clampf(e[1], -bound, bound); pz = clampf(e[2], -bound, bound);
+            } else {
+                px = clampf(ox + dx * zmid, -bound, bound); py = clampf(oy + dy * zmid, -bound, bound);
+                pz = clampf(oz + dz * zmid, -bound, bound);
+            }
             // centre + 6 finite-difference evaluations (:687-704): features of all 7 points first (shared corner
             // fetches), then 7 MLP passes as one loop body over a rotating feature register file.
             AC_TICK(7)
@@ -822,7 +874,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float iter_cos = -(a1 + a2);
             const float half = iter_cos * delta * 0.5f;
             const float pc = dv_sigmoid((sdf0 - half) * a.inv_s), nc = dv_sigmoid((sdf0 + half) * a.inv_s);
-            const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+            float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+            if constexpr (MODE == MODE_FINAL) alpha = alpha * (a.mask[(size_t)ray * T + i] ? 1.0f : 0.0f);      // :246-249
             const float om = 1.0f - alpha + 1e-7f;
             // transmittance: exclusive tile scan with carry  :250
             const float loc = row_scan<true>(om);
@@ -970,32 +1023,57 @@ static unsigned long long *g_prof = nullptr;
 AC_API void ac_debug_set_prof(unsigned long long *p) { g_prof = p; }
 #endif
 
-AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
-                          const float *bg, const float *noise, const float *lin_z, const float *lin_u,
-                          const ac_render_out *out, ac_stream_t stream)
+// posed-space coarse samples: pts[n, i] = o + d * z_i (unclamped, fp32), the input of the first warp  (:155-165)
+__global__ __launch_bounds__(256) void coarse_pts_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                         const float *__restrict__ near_m, const float *__restrict__ far_m,
+                                                         const float *__restrict__ lin_z, const float *__restrict__ noise, int n_rays, int T0,
+                                                         float bound, int perturb, float *__restrict__ pts)
 {
-    if (!op || !out) { ac::set_error("render_rays: NULL opts/out"); return AC_ERR_BAD_ARG; }
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rays * T0) return;
+    const int ray = idx / T0, i = idx - ray * T0;
+    const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
+    const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
+    float near, far;
+    cube_near_far(ox, oy, oz, dx, dy, dz, bound, near, far);
+    if (near_m) {
+        const float nm = near_m[ray], fm = far_m[ray];
+        if (!is_inf(nm)) near = nm;
+        if (!is_inf(fm)) far = fm;
+    }
+    const float span = far - near;
+    const float sample_dist = span / (float)T0;
+    float zi = near + span * lin_z[i];
+    if (perturb) zi = zi + (noise[idx] - 0.5f) * sample_dist;
+    pts[3 * (size_t)idx] = ox + dx * zi; pts[3 * (size_t)idx + 1] = oy + dy * zi; pts[3 * (size_t)idx + 2] = oz + dz * zi;
+}
+
+static int check_render_args(const char *who, const ac_render_opts *op, const float *rays_o, const float *rays_d, const float *noise,
+                             const float *lin_z, const float *lin_u, const ac_render_out *out)
+{
     if (op->num_steps % 16 || op->upsample_steps % 16 || op->num_steps < 16 || op->num_steps > 64 ||
         op->upsample_steps < 0 || op->num_steps + op->upsample_steps > MAXT) {
-        ac::set_error("render_rays: num_steps=%d upsample_steps=%d unsupported (multiples of 16, num_steps<=64, sum<=128)",
+        ac::set_error("%s: num_steps=%d upsample_steps=%d unsupported (multiples of 16, num_steps<=64, sum<=128)", who,
                       op->num_steps, op->upsample_steps);
         return AC_ERR_BAD_ARG;
     }
     if (op->n_rays <= 0) return AC_OK;
     if (!rays_o || !rays_d || !lin_z || (op->upsample_steps && !lin_u) || (op->perturb && !noise) || !out->image ||
         !out->weights_sum || !out->depth || !out->normal_map || !out->eik) {
-        ac::set_error("render_rays: NULL buffer"); return AC_ERR_BAD_ARG;
+        ac::set_error("%s: NULL buffer", who); return AC_ERR_BAD_ARG;
     }
-    RenderArgs a{};
+    return AC_OK;
+}
+
+static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
+                            const float *bg, const float *noise, const float *lin_z, const float *lin_u, const ac_render_out *out)
+{
     if (int rc = fill_args(a, field, op->bound)) return rc;
     a.rays_o = rays_o; a.rays_d = rays_d; a.bg = bg; a.noise = noise; a.lin_z = lin_z; a.lin_u = lin_u;
     a.out = *out;
     a.n_rays = op->n_rays; a.T0 = op->num_steps; a.nup = op->upsample_steps / 16;
     a.inv_s = op->inv_s; a.car = op->cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
     a.eps = op->fd_eps; a.perturb = op->perturb;
-#ifdef AC_PROFILE
-    a.prof = g_prof;
-#endif
     for (int j = 0; j < 4; ++j) {           // finite-difference reach in cells, per gather round (see encode_stencil)
         a.jfine[j] = 0;
         for (int g = 0; g < 4; ++g) {
@@ -1003,15 +1081,94 @@ AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const
             if (!(cells * 1.001 + 1e-3 < 1.0)) a.jfine[j] = 1;
         }
     }
-    const int blocks = (op->n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    return AC_OK;
+}
+
+template <int MODE>
+static void launch_render(const RenderArgs &a, hipStream_t stream)
+{
+    const int blocks = (a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     static bool attr_set = false;
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(render_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(render_rays_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL(render_rays_kernel, dim3(blocks), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(render_rays_kernel<MODE>, dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
+}
+
+AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
+                          const float *bg, const float *noise, const float *lin_z, const float *lin_u,
+                          const ac_render_out *out, ac_stream_t stream)
+{
+    if (!op || !out) { ac::set_error("render_rays: NULL opts/out"); return AC_ERR_BAD_ARG; }
+    if (int rc = check_render_args("render_rays", op, rays_o, rays_d, noise, lin_z, lin_u, out)) return rc;
+    if (op->n_rays <= 0) return AC_OK;
+    RenderArgs a{};
+    if (int rc = fill_render_args(a, field, op, rays_o, rays_d, bg, noise, lin_z, lin_u, out)) return rc;
+#ifdef AC_PROFILE
+    a.prof = g_prof;
+#endif
+    launch_render<MODE_FULL>(a, (hipStream_t)stream);
     return ac::check_launch("render_rays");
+}
+
+// scratch layout of ac_render_rays_warped (byte offsets, 256-byte aligned): near_m, far_m [N] f32; pts, can [N,T,3] f32;
+// mask [N,T] u8; zbuf [N,T] f32
+AC_API size_t ac_render_rays_warped_scratch(int32_t n_rays, int32_t T, size_t offs[6])
+{
+    const size_t N = n_rays > 0 ? (size_t)n_rays : 0, NT = N * (size_t)(T > 0 ? T : 0);
+    const size_t sz[6] = { N * 4, N * 4, NT * 12, NT * 12, NT, NT * 4 };
+    size_t o = 0;
+    for (int i = 0; i < 6; ++i) { if (offs) offs[i] = o; o += (sz[i] + 255) & ~(size_t)255; }
+    return o;
+}
+
+AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
+                                 const float *bg, const float *noise, const float *lin_z, const float *lin_u,
+                                 const ac_warp_mesh *mesh, void *scratch, size_t scratch_bytes, const ac_render_out *out,
+                                 ac_stream_t stream)
+{
+    if (!op || !out || !mesh) { ac::set_error("render_rays_warped: NULL opts/out/mesh"); return AC_ERR_BAD_ARG; }
+    if (int rc = check_render_args("render_rays_warped", op, rays_o, rays_d, noise, lin_z, lin_u, out)) return rc;
+    if (op->n_rays <= 0) return AC_OK;
+    if (!mesh->verts || !mesh->faces || !mesh->T || mesh->V == 0 || mesh->F == 0) {
+        ac::set_error("render_rays_warped: NULL mesh buffer or empty mesh"); return AC_ERR_BAD_ARG;
+    }
+    const int N = op->n_rays, T0 = op->num_steps, T = T0 + op->upsample_steps;
+    size_t offs[6];
+    const size_t need = ac_render_rays_warped_scratch(N, T, offs);
+    if (!scratch || scratch_bytes < need) {
+        ac::set_error("render_rays_warped: scratch of %zu bytes needed, %zu given", need, scratch_bytes); return AC_ERR_BAD_ARG;
+    }
+    char *sc = static_cast<char *>(scratch);
+    float *near_m = reinterpret_cast<float *>(sc + offs[0]), *far_m = reinterpret_cast<float *>(sc + offs[1]);
+    float *pts = reinterpret_cast<float *>(sc + offs[2]), *can = reinterpret_cast<float *>(sc + offs[3]);
+    uint8_t *mask = reinterpret_cast<uint8_t *>(sc + offs[4]);
+    float *zbuf = reinterpret_cast<float *>(sc + offs[5]);
+    hipStream_t st = (hipStream_t)stream;
+    RenderArgs a{};
+    if (int rc = fill_render_args(a, field, op, rays_o, rays_d, bg, noise, lin_z, lin_u, out)) return rc;
+    if (mesh->use_mesh_guide) {
+        if (int rc = ac_mesh_near_far(rays_o, rays_d, mesh->verts, (uint32_t)N, mesh->V, mesh->geo_threshold, near_m, far_m, stream)) return rc;
+        a.near_m = near_m; a.far_m = far_m;
+    }
+    a.zbuf = zbuf; a.mid_pts = pts;
+    if (op->upsample_steps > 0) {                                 // coarse samples -> canonical space (:166-172)
+        hipLaunchKernelGGL(coarse_pts_kernel, dim3((N * T0 + 255) / 256), dim3(256), 0, st, rays_o, rays_d, a.near_m, a.far_m, lin_z, noise, N, T0,
+                           op->bound, op->perturb, pts);
+        if (int rc = ac::check_launch("render_rays_warped (coarse points)")) return rc;
+        if (int rc = ac_warp_samples(pts, mesh->verts, mesh->faces, mesh->T, (uint32_t)(N * T0), mesh->V, mesh->F, mesh->threshold, nullptr, can,
+                                     nullptr, nullptr, nullptr, mask, stream)) return rc;
+    }
+    a.ext_pts = can;
+    launch_render<MODE_UPSAMPLE>(a, st);                          // coarse sdf, up-sampling, mid points (posed space)
+    if (int rc = ac::check_launch("render_rays_warped (up-sampling)")) return rc;
+    if (int rc = ac_warp_samples(pts, mesh->verts, mesh->faces, mesh->T, (uint32_t)(N * T), mesh->V, mesh->F, mesh->threshold, nullptr, can,
+                                 nullptr, nullptr, nullptr, mask, stream)) return rc;     // :198-203
+    a.mask = mask;
+    launch_render<MODE_FINAL>(a, st);
+    return ac::check_launch("render_rays_warped");
 }
 
 AC_API int ac_eikonal_reduce(const float *eik, int32_t n_rays, float *result, ac_stream_t stream)

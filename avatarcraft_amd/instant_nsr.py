@@ -11,7 +11,7 @@ Where the work happens:
   * rendering with gradients (stylize / reconstruct) takes the sample positions from the fused kernel (the reference
     computes them under no_grad, :176-184) and evaluates the differentiable "render core" (:190-299) with autograd
     over the HIP hash encoder; a fused backward kernel is the next step.
-  * render_can=False (SMPL inverse warp, :166-172,198-203) is not built yet and raises NotImplementedError.
+  * render_can=False (SMPL inverse warp, :166-172,198-203): no-grad only (render_warp.py), ac_render_rays_warped.
 """
 import numpy as np
 import torch
@@ -76,8 +76,9 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ run == reference :133-299
     def run(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0,
             render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True):
-        if not render_can:
-            raise NotImplementedError("render_can=False (SMPL inverse warp) is not built yet in avatarcraft_amd")
+        if render_can and verts is not None and use_mesh_guide:
+            raise NotImplementedError("mesh-guided near/far is built for posed-space rendering (render_can=False) only; pass "
+                                      "use_mesh_guide=False or verts=None for a canonical-space render")
         if not self._fused_supported():
             raise NotImplementedError("the fused MI355X renderer supports the default NeRFNetwork configuration only")
         B, N = rays_o.shape[:2]
@@ -95,8 +96,16 @@ class NeRFRenderer(nn.Module):
             bg = bg.expand(N, 3).contiguous() if bg.shape[0] == 1 else bg.contiguous()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         field = self._field()
+        warp = None
+        if not render_can:                                       # SMPL inverse warp :166-172,198-203 (inference path of render_warp.py)
+            if needs_grad:
+                raise NotImplementedError("posed-space rendering (render_can=False) is an inference path: call it under torch.no_grad()")
+            if verts is None or faces is None or Ts is None:
+                raise RuntimeError("render_can=False needs verts, faces and Ts")
+            warp = verts if isinstance(verts, nsr_ops.WarpMesh) else nsr_ops.WarpMesh(verts, faces, Ts, device, DEFAULT_GEO_THRESH,
+                                                                                      DEFAULT_GEO_THRESH, use_mesh_guide)
         out = nsr_ops.render_rays(field, ro, rd, num_steps, upsample_steps, bound, float(inv_s_t.detach().reshape(-1)[0]), bg=bg, noise=noise,
-                                  cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, extras=True)
+                                  cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp)
         if not needs_grad:
             return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
                     out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])

@@ -69,10 +69,11 @@ def linspace_tables(num_steps, device):
 
 
 def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg=None, noise=None,
-                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None, events=None):
+                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None, events=None, warp=None):
     """One launch of the fused renderer for N rays.  Returns a dict of CUDA tensors:
     image[N,3] weights_sum[N] depth[N] normal_map[N,3] eik[N,2] gradient_error[] (+ z_vals, weights,
-    alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices)."""
+    alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices).
+    warp = WarpMesh(...) renders in posed space (run(render_can=False)): + can_mid[N,T,3], mask[N,T] views of the scratch."""
     rays_o = _chk(rays_o.reshape(-1, 3), "rays_o")
     rays_d = _chk(rays_d.reshape(-1, 3), "rays_d")
     N = rays_o.shape[0]
@@ -114,13 +115,42 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     st = L.current_stream(dev)
     if events is not None:          # (start, end) torch.cuda.Event pair around the render kernel only (bench.py roofline)
         events[0].record()
-    L.check(L.lib().ac_render_rays(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), L.ptr(noise),
-                                   lin_z.data_ptr(), lin_u.data_ptr(), C.byref(o), st), "render_rays")
+    if warp is None:
+        L.check(L.lib().ac_render_rays(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), L.ptr(noise),
+                                       lin_z.data_ptr(), lin_u.data_ptr(), C.byref(o), st), "render_rays")
+    else:
+        offs = (C.c_size_t * 6)()
+        nbytes = L.lib().ac_render_rays_warped_scratch(N, T, offs)
+        scratch = buf("_warp_scratch", (max(int(nbytes), 1),), torch.uint8)
+        L.check(L.lib().ac_render_rays_warped(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), L.ptr(noise),
+                                              lin_z.data_ptr(), lin_u.data_ptr(), C.byref(warp.c), scratch.data_ptr(), int(nbytes), C.byref(o), st),
+                "render_rays_warped")
+        res["can_mid"] = scratch[offs[3]:offs[3] + N * T * 12].view(_F32).view(N, T, 3)
+        res["mask"] = scratch[offs[4]:offs[4] + N * T].view(N, T)
     if events is not None:
         events[1].record()
     ge = buf("gradient_error", ())
     L.check(L.lib().ac_eikonal_reduce(res["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
     return res
+
+
+class WarpMesh:
+    """the posed SMPL mesh of one frame + its per-vertex rest->scene transforms, on the device (ac_warp_mesh)"""
+
+    def __init__(self, verts, faces, Ts, device, threshold=0.05, geo_threshold=0.05, use_mesh_guide=True):
+        import numpy as np
+
+        def dev(a, dtype):
+            if not isinstance(a, torch.Tensor):
+                a = torch.from_numpy(np.ascontiguousarray(a))
+            return a.to(device=device, dtype=dtype).contiguous()
+        self.verts = dev(verts, _F32).reshape(-1, 3)
+        self.faces = dev(faces, torch.int32)[:, :3].contiguous()
+        self.T = dev(Ts, torch.float64).reshape(-1, 4, 4)
+        if int(self.faces.max()) >= self.T.shape[0] or self.T.shape[0] < self.verts.shape[0]:
+            raise RuntimeError("WarpMesh: Ts must hold one 4x4 per vertex")
+        self.c = L.ac_warp_mesh(self.verts.data_ptr(), self.faces.data_ptr(), self.T.data_ptr(), self.verts.shape[0], self.faces.shape[0],
+                                float(threshold), float(geo_threshold), int(bool(use_mesh_guide)))
 
 
 def field_sdf(field, x, bound):

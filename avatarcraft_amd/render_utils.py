@@ -8,6 +8,8 @@ import random
 import numpy as np
 import torch
 
+from . import nsr_ops
+
 WHITE_BKG, BLACK_BKG, NOISE_BKG, CHESSBOARD_BKG = 0, 1, 2, 3        # utils/constant.py:27-30
 CANONICAL_ZOOM_FACTOR = 1000 / 1280                                  # utils/constant.py:9
 NSR_BOUND = 1.6                                                      # utils/constant.py:21
@@ -59,6 +61,8 @@ def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_g
     total = rays_o.shape[0]
     rgbs, depths, wsums, normals = [], [], [], []
     total_eikonal = 0.0
+    if not render_can and verts is not None and not isinstance(verts, nsr_ops.WarpMesh):
+        verts = nsr_ops.WarpMesh(verts, faces, Ts, device)       # upload the frame's mesh once, not once per ray batch
     with torch.set_grad_enabled(requires_grad):
         for i in range(0, total, rays_per_batch):
             ro, rd = rays_o[i:i + rays_per_batch], rays_d[i:i + rays_per_batch]

@@ -192,6 +192,32 @@ int ac_warp_samples(const float *pts, const float *verts, const int32_t *faces, 
                     double threshold, double *can_pts, float *can_pts_f32, double *closest, double *dist2, int32_t *face_id,
                     uint8_t *mask, ac_stream_t stream);
 
+/* ---- posed-space rendering: NeRFRenderer.run(render_can=False, verts, faces, Ts, use_mesh_guide)
+ * models/instant_nsr.py:147-172 (mesh-guided near/far, warp of the coarse samples), :198-203 (warp of the mid points),
+ * :246-249 (alpha mask).  The reference moves the samples to the CPU for libigl twice per batch; here the whole sequence
+ * (near/far -> coarse points -> warp -> coarse sdf + up-sampling -> warp -> render core) is enqueued on `stream`.
+ * As in the reference, the up-sampling queries the field at the UNwarped new samples (cat_z_vals, :464-469). */
+typedef struct ac_warp_mesh {
+    const float *verts;        /* [V,3]  posed SMPL vertices of the frame */
+    const int32_t *faces;      /* [F,3] */
+    const double *T;           /* [V',4,4] rest->scene transform per vertex (V' >= V; render_warp.py passes V+24) */
+    uint32_t V, F;
+    double threshold;          /* mask: squared distance < threshold   (DEFAULT_GEO_THRESH = 0.05) */
+    float geo_threshold;       /* radius of the vertex spheres of the near/far guide (DEFAULT_GEO_THRESH) */
+    int32_t use_mesh_guide;
+} ac_warp_mesh;
+
+/* bytes of device scratch ac_render_rays_warped needs for n_rays rays of T = num_steps + upsample_steps samples; if offs is not
+ * NULL it receives the byte offsets of {near_m[N] f32, far_m[N] f32, posed pts[N,T,3] f32, canonical pts[N,T,3] f32,
+ * mask[N,T] u8, z[N,T] f32} (valid after the call; exposed for tests). */
+size_t ac_render_rays_warped_scratch(int32_t n_rays, int32_t T, size_t offs[6]);
+
+/* same arguments and outputs as ac_render_rays, plus the mesh and the scratch buffer */
+int ac_render_rays_warped(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d,
+                          const float *bg, const float *noise, const float *lin_z, const float *lin_u,
+                          const ac_warp_mesh *mesh, void *scratch, size_t scratch_bytes, const ac_render_out *out,
+                          ac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

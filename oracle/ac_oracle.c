@@ -519,9 +519,33 @@ static void orc_merge(const float *z, int n, const float *znew, int *pos_old, in
     }
 }
 
+/* posed-space rendering (run(render_can=False), instant_nsr.py:147-172,198-203,246-249): the SMPL mesh of the frame, its
+ * per-vertex rest->scene transforms, and the two thresholds (both DEFAULT_GEO_THRESH = 0.05 in the reference) */
+typedef struct {
+    const float *verts; const int32_t *faces; const double *T; uint32_t V, F;
+    double threshold; float geo_threshold; int32_t use_mesh_guide;
+    float *can_mid; uint8_t *mask;      /* optional exports: warped+clamped mid points [N,T,3], alpha mask [N,T] */
+} orc_warp_ctx;
+ORC_API int orc_mesh_near_far(const float *rays_o, const float *rays_d, const float *verts, uint32_t N, uint32_t V,
+                              float geo_threshold, float *near, float *far);
+ORC_API int orc_warp_samples(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t F,
+                             double threshold, double *can_pts, double *closest, double *dist2, int32_t *face_id, uint8_t *mask);
+
+/* pts[n,3] (posed space, fp32) -> canonical, fp64 -> clamp(-bound, bound) -> fp32  (:166-174) */
+static void warp_clamp(const orc_warp_ctx *wc, const float *pts, int n, float bound, float *can, uint8_t *mask)
+{
+    double cd[ORC_MAXT * 3];
+    orc_warp_samples(pts, wc->verts, wc->faces, wc->T, (uint32_t)n, wc->F, wc->threshold, cd, NULL, NULL, NULL, mask);
+    for (int i = 0; i < 3 * n; i++) {
+        double v = cd[i];
+        v = v < -(double)bound ? -(double)bound : (v > (double)bound ? (double)bound : v);
+        can[i] = (float)v;
+    }
+}
+
 static void render_one_ray(const orc_field *f, const orc_render_opts *op, const float *o, const float *d,
                            const float *bg, const float *noise, const float *lin_z, const float *lin_u,
-                           int r, const orc_render_out *out)
+                           int r, const orc_render_out *out, const orc_warp_ctx *wc)
 {
     const float bound = op->bound;
     const int T0 = op->num_steps, nup = op->upsample_steps / 16, T = T0 + 16 * nup;
@@ -535,6 +559,12 @@ static void render_one_ray(const orc_field *f, const orc_render_opts *op, const 
         if (k == 0 || hi < far) far = hi;
     }
     if (near < 0.05f) near = 0.05f;
+    if (wc && wc->use_mesh_guide) {                  /* :148-153: mesh-guided range where the ray passes the body */
+        float nm, fm;
+        orc_mesh_near_far(o, d, wc->verts, 1, wc->V, wc->geo_threshold, &nm, &fm);
+        if (!isinf(nm)) near = nm;
+        if (!isinf(fm)) far = fm;
+    }
     const float span = far - near;
     const float sample_dist = span / (float)T0;      /* instant_nsr.py:160 */
     float z[ORC_MAXT], sdf[ORC_MAXT];
@@ -545,9 +575,14 @@ static void render_one_ray(const orc_field *f, const orc_render_opts *op, const 
     }
     int n = T0;
     if (nup > 0) {
+        float cpts[ORC_MAXT * 3]; uint8_t cmask[ORC_MAXT];
+        if (wc) {
+            for (int i = 0; i < T0; i++) for (int k = 0; k < 3; k++) cpts[3 * i + k] = o[k] + d[k] * z[i];
+            warp_clamp(wc, cpts, T0, bound, cpts, cmask);
+        }
         for (int i = 0; i < T0; i++) {               /* :165,173-180 */
             float p[3], s16[16];
-            for (int k = 0; k < 3; k++) p[k] = clampf(o[k] + d[k] * z[i], -bound, bound);
+            for (int k = 0; k < 3; k++) p[k] = wc ? cpts[3 * i + k] : clampf(o[k] + d[k] * z[i], -bound, bound);
             field_sdf(f, p, bound, s16);
             sdf[i] = s16[0];
         }
@@ -586,11 +621,22 @@ static void render_one_ray(const orc_field *f, const orc_render_opts *op, const 
     float col[ORC_MAXT][3], nrm[ORC_MAXT][3], zn[ORC_MAXT], eerr[ORC_MAXT], erelax[ORC_MAXT];
     const float car = op->cos_anneal_ratio, one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
     const float eps = op->fd_eps;
+    float mpts[ORC_MAXT * 3]; uint8_t mmask[ORC_MAXT];
+    if (wc) {                                           /* :198-203 (the up-sampled z were placed with UNwarped sdf queries) */
+        for (int i = 0; i < T; i++) {
+            float delta = (i < T - 1) ? z[i + 1] - z[i] : sample_dist;
+            float zmid = (i < T - 1) ? z[i] + 0.5f * delta : z[i];
+            for (int k = 0; k < 3; k++) mpts[3 * i + k] = o[k] + d[k] * zmid;
+        }
+        warp_clamp(wc, mpts, T, bound, mpts, mmask);
+        if (wc->can_mid) memcpy(wc->can_mid + (size_t)r * T * 3, mpts, (size_t)T * 3 * sizeof(float));
+        if (wc->mask) memcpy(wc->mask + (size_t)r * T, mmask, (size_t)T);
+    }
     for (int i = 0; i < T; i++) {
         float delta = (i < T - 1) ? z[i + 1] - z[i] : sample_dist;
         float zmid = (i < T - 1) ? z[i] + 0.5f * delta : z[i];
         float p[3], s16[16], g[3];
-        for (int k = 0; k < 3; k++) p[k] = clampf(o[k] + d[k] * zmid, -bound, bound);
+        for (int k = 0; k < 3; k++) p[k] = wc ? mpts[3 * i + k] : clampf(o[k] + d[k] * zmid, -bound, bound);
         field_sdf(f, p, bound, s16);
         for (int k = 0; k < 3; k++) {               /* FD normals :687-704 */
             float q[3] = { p[0], p[1], p[2] }, sp[16], sn[16];
@@ -612,6 +658,7 @@ static void render_one_ray(const orc_field *f, const orc_render_opts *op, const 
         float en = s16[0] + half, ep = s16[0] - half;                   /* :236-237 */
         float pc = orc_sigmoid(ep * op->inv_s), nc = orc_sigmoid(en * op->inv_s);
         alpha[i] = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f); /* :243 */
+        if (wc) alpha[i] = alpha[i] * (mmask[i] ? 1.0f : 0.0f);          /* :246-249 */
         om[i] = 1.0f - alpha[i] + 1e-7f;
         for (int k = 0; k < 3; k++) nrm[i][k] = nn[k];
         zn[i] = clampf((z[i] - near) / span, 0.0f, 1.0f);               /* :262 */
@@ -665,7 +712,21 @@ ORC_API int orc_render_rays(const orc_field *f, const orc_render_opts *op, const
     #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t r = 0; r < (int64_t)op->n_rays; r++)
         render_one_ray(f, op, rays_o + 3 * r, rays_d + 3 * r, bg ? bg + 3 * r : NULL,
-                       noise ? noise + (size_t)r * op->num_steps : NULL, lin_z, lin_u, (int)r, out);
+                       noise ? noise + (size_t)r * op->num_steps : NULL, lin_z, lin_u, (int)r, out, NULL);
+    return 0;
+}
+
+/* NeRFRenderer.run(render_can=False, verts, faces, Ts, use_mesh_guide) */
+ORC_API int orc_render_rays_warped(const orc_field *f, const orc_render_opts *op, const float *rays_o,
+                                   const float *rays_d, const float *bg, const float *noise,
+                                   const float *lin_z, const float *lin_u, const orc_warp_ctx *wc, const orc_render_out *out)
+{
+    if (op->num_steps % 16 || op->upsample_steps % 16 || op->num_steps < 16 || op->num_steps > 64 ||
+        op->num_steps + op->upsample_steps > ORC_MAXT || !wc) return 1;
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t r = 0; r < (int64_t)op->n_rays; r++)
+        render_one_ray(f, op, rays_o + 3 * r, rays_d + 3 * r, bg ? bg + 3 * r : NULL,
+                       noise ? noise + (size_t)r * op->num_steps : NULL, lin_z, lin_u, (int)r, out, wc);
     return 0;
 }
 

@@ -271,9 +271,16 @@ def linspace_tables(num_steps):
     return lin_z, lin_u
 
 
+class _WarpCtx(C.Structure):
+    _fields_ = [("verts", f32p), ("faces", i32p), ("T", C.POINTER(C.c_double)), ("V", C.c_uint32), ("F", C.c_uint32),
+                ("threshold", C.c_double), ("geo_threshold", C.c_float), ("use_mesh_guide", C.c_int32),
+                ("can_mid", f32p), ("mask", C.POINTER(C.c_uint8))]
+
+
 def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=None, bg=None, noise=None,
-                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=True):
-    """NeRFRenderer.run (models/instant_nsr.py:133-299), render_can=True.  Returns a dict."""
+                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=True, warp=None):
+    """NeRFRenderer.run (models/instant_nsr.py:133-299).  render_can=True unless warp = dict(verts, faces, Ts[, threshold,
+    use_mesh_guide]) is given (render_can=False: SMPL-guided inverse warp of the samples).  Returns a dict."""
     rays_o = _f(rays_o).reshape(-1, 3); rays_d = _f(rays_d).reshape(-1, 3)
     N = rays_o.shape[0]
     T = num_steps + upsample_steps
@@ -293,8 +300,20 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
         setattr(o, k, _p(v, i32p if v.dtype == np.int32 else f32p))
     bgc = _f(bg).reshape(-1, 3) if bg is not None else None
     nz = _f(noise).reshape(N, num_steps) if noise is not None else None
-    rc = lib().orc_render_rays(C.byref(field.c), C.byref(op), _p(rays_o), _p(rays_d), _p(bgc), _p(nz), _p(lin_z), _p(lin_u),
-                               C.byref(o))
+    if warp is None:
+        rc = lib().orc_render_rays(C.byref(field.c), C.byref(op), _p(rays_o), _p(rays_d), _p(bgc), _p(nz), _p(lin_z), _p(lin_u),
+                                   C.byref(o))
+    else:
+        verts = _f(warp["verts"]).reshape(-1, 3)
+        faces = np.ascontiguousarray(np.asarray(warp["faces"])[:, :3], np.int32)
+        Ts = np.ascontiguousarray(warp["Ts"], np.float64)
+        thr = warp.get("threshold", 0.05)
+        res["can_mid"] = np.empty((N, T, 3), np.float32); res["mask"] = np.empty((N, T), np.uint8)
+        wc = _WarpCtx(_p(verts), _p(faces, i32p), Ts.ctypes.data_as(C.POINTER(C.c_double)), verts.shape[0], faces.shape[0], float(thr),
+                      float(thr), int(bool(warp.get("use_mesh_guide", True))), _p(res["can_mid"]),
+                      res["mask"].ctypes.data_as(C.POINTER(C.c_uint8)))
+        rc = lib().orc_render_rays_warped(C.byref(field.c), C.byref(op), _p(rays_o), _p(rays_d), _p(bgc), _p(nz), _p(lin_z), _p(lin_u),
+                                          C.byref(wc), C.byref(o))
     if rc:
         raise RuntimeError("render_rays: unsupported num_steps/upsample_steps")
     res["gradient_error"] = float(lib().orc_eikonal_reduce(_p(res["eik"]), C.c_int32(N)))

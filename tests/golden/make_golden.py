@@ -303,6 +303,12 @@ def make_warp_goldens():
     import utils.ray_utils as RY
     from tests.common import make_body
     verts, faces, Ts = make_body()
+    install_igl_standin()
+    ro, rd = make_rays(12, 12, dist=1.8, f=9.0, jitter_seed=11)
+    return _make_warp_goldens_body(RY, verts, faces, Ts, ro, rd)
+
+
+def install_igl_standin():
     igl = sys.modules["igl"]
 
     def point_mesh_squared_distance(P, V, F):
@@ -318,7 +324,9 @@ def make_warp_goldens():
         return np.stack([1 - v - w, v, w], 1)
     igl.point_mesh_squared_distance = point_mesh_squared_distance
     igl.barycentric_coordinates_tri = barycentric_coordinates_tri
-    ro, rd = make_rays(12, 12, dist=1.8, f=9.0, jitter_seed=11)
+
+
+def _make_warp_goldens_body(RY, verts, faces, Ts, ro, rd):
     near_t, far_t = RY.geometry_guided_near_far_torch(torch.from_numpy(ro), torch.from_numpy(rd), verts, 0.05)
     near_n, far_n = RY.geometry_guided_near_far_np(ro, rd, verts, 0.05)
     z = np.linspace(0.9, 2.7, 24, dtype=np.float32)
@@ -355,5 +363,29 @@ def make_smpl_goldens():
     print("smpl: T", tuple(T.shape), "verts", tuple(verts.shape))
 
 
+def make_warp_render_golden():
+    """run(render_can=False, verts, faces, Ts) (models/instant_nsr.py:147-172,198-203,246-249) at render_warp.py's sampling
+    (32 + 32), eval mode, with the same libigl stand-in as make_warp_goldens."""
+    from tests.common import make_body
+    install_igl_standin()
+    verts, faces, Ts = make_body()
+    net = build_reference_net()
+    net.eval()
+    ro, rd = make_rays(16, 16, dist=1.8, f=14.0, jitter_seed=5)
+    bg = np.ones((ro.shape[0], 3), np.float32)
+    res = {}
+    for tag, guide in (("guide", True), ("noguide", False)):
+        with torch.no_grad():
+            out = net.render(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], num_steps=32, bound=1.6, upsample_steps=32, staged=False,
+                             bg_color=torch.from_numpy(bg), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=False, verts=verts,
+                             faces=faces, Ts=Ts, perturb=False, use_mesh_guide=guide)
+        res.update({f"{tag}_image": out["rgb"][0].numpy(), f"{tag}_weights_sum": out["weight_sum"][:, 0].numpy(), f"{tag}_depth": out["depth"][0].numpy(),
+                    f"{tag}_normal_map": out["normal"].numpy(), f"{tag}_weights": out["weights"].numpy(), f"{tag}_alpha": out["pts_alpha"].numpy(),
+                    f"{tag}_z_vals": out["z_vals"].numpy(), f"{tag}_gradient_error": np.float32(out["gradient_error"].item())})
+        print("warp render", tag, "mean opacity", float(out["weight_sum"].mean()), "rays with opacity > 0.5:", int((out["weight_sum"] > 0.5).sum()))
+    np.savez_compressed(os.path.join(HERE, "warp_render.npz"), rays_o=ro, rays_d=rd, bg=bg, **res)
+
+
 if __name__ == "__main__":
     make_smpl_goldens()
+    make_warp_render_golden()

@@ -55,8 +55,8 @@ def test_render_instantnsr_naive_batches_and_shapes():
     rgbk, _ = render_instantnsr_naive(net, ro_t, rd_t, rays_per_batch=256, bkg_key=BLACK_BKG, render_can=True, perturb=False)
     ws = extra["weight_sum"]
     assert torch.allclose(rgb - rgbk, (1 - ws).expand(-1, 3), atol=1e-6)          # image = colour + (1 - w) * bg
-    with pytest.raises(NotImplementedError):
-        render_instantnsr_naive(net, ro_t, rd_t, render_can=False)
+    with pytest.raises(RuntimeError, match="needs verts"):
+        render_instantnsr_naive(net, ro_t, rd_t, render_can=False)       # the reference's default: posed space, needs the frame's mesh
 
 
 def test_training_gradients_match_reference_autograd():
@@ -108,3 +108,27 @@ def test_sds_step_updates_parameters_and_is_finite():
     changed = [k for k, v in net.named_parameters() if not torch.equal(v.detach(), before[k])]
     assert "encoder.embeddings" in changed and "sdf_net.0.weight_v" in changed and "color_net.2.weight_v" in changed
     assert flat.numel() == 12248902
+
+
+def test_posed_render_matches_reference_render():
+    """NeRFNetwork.render(render_can=False, verts, faces, Ts) == the reference's (render_warp.py:96-106 call shape)"""
+    from tests.common import make_body
+    from tests.test_oracle_golden import check_warp_render_vs_golden
+    from avatarcraft_amd.render_utils import render_instantnsr_naive
+    net, p = golden_net()
+    net.eval()
+    g = load_golden("warp_render.npz")
+    verts, faces, Ts = make_body()
+    ro, rd = torch.from_numpy(g["rays_o"]).to(DEV), torch.from_numpy(g["rays_d"]).to(DEV)
+    with torch.no_grad():
+        out = net.render(ro[None], rd[None], num_steps=32, bound=1.6, upsample_steps=32, staged=False, bg_color=torch.from_numpy(g["bg"]).to(DEV),
+                         cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=False, verts=verts, faces=faces, Ts=Ts, perturb=False)
+    m = {"image": out["rgb"][0], "weights_sum": out["weight_sum"][:, 0], "depth": out["depth"][0], "normal_map": out["normal"], "weights": out["weights"],
+         "alpha": out["pts_alpha"], "z_vals": out["z_vals"], "gradient_error": out["gradient_error"]}
+    check_warp_render_vs_golden(lambda k: m[k].detach().cpu().numpy(), g, "guide")
+    # through the harness the animate driver uses
+    rgb, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=100, requires_grad=False, render_can=False, perturb=False, verts=verts, faces=faces,
+                                     Ts=Ts, num_steps=32, upsample_steps=32, bound=1.6)
+    assert rgb.shape == (256, 3) and np.abs(rgb.cpu().numpy()[1:] - g["guide_image"][1:]).max() <= 1e-3
+    with pytest.raises(NotImplementedError):
+        net.render(ro[None], rd[None], num_steps=32, bound=1.6, upsample_steps=32, render_can=False, verts=verts, faces=faces, Ts=Ts)   # grad mode

@@ -146,3 +146,61 @@ def test_field_sdf_color_bitwise(env):
     co = env["of"].color(fp["pts"], fp["normal"], so)
     assert_bitwise(c, co, "forward_color")
     assert np.abs(c.cpu().numpy() - fp["color"]).max() < 5e-6        # vs the reference's forward_color
+
+
+# ------------------------------------------------------------------ posed-space rendering (render_can=False)
+def _warp_both(env, ro, rd, T0, up, guide, noise=None, body=None):
+    from avatarcraft_amd import nsr_ops
+    from tests.common import make_body
+    verts, faces, Ts = body if body is not None else make_body()
+    d = "cuda:0"
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(d)
+    wm = nsr_ops.WarpMesh(verts, faces, Ts, d, use_mesh_guide=guide)
+    g = nsr_ops.render_rays(env["f"], t(ro), t(rd), T0, up, 1.6, float(env["p"]["inv_s"]), noise=t(noise), extras=True, debug_indices=True, warp=wm)
+    torch.cuda.synchronize()
+    r = env["O"].render_rays(env["of"], ro, rd, T0, up, 1.6, float(env["p"]["inv_s"]), noise=noise,
+                             warp=dict(verts=verts, faces=faces, Ts=Ts, use_mesh_guide=guide))
+    return g, r
+
+
+@pytest.mark.parametrize("T0,up,guide,perturb", [(32, 32, True, False), (32, 32, False, True), (64, 64, True, True), (16, 0, True, False)])
+def test_warped_render_bitwise_vs_oracle(env, T0, up, guide, perturb):
+    ro, rd = make_rays(20, 20, dist=1.8, f=17.0, jitter_seed=9)
+    noise = np.random.RandomState(3).rand(ro.shape[0], T0).astype(np.float32) if perturb else None
+    g, r = _warp_both(env, ro, rd, T0, up, guide, noise)
+    _compare_bitwise(g, r, up)
+    assert_bitwise(g["can_mid"].clamp(-1.6, 1.6), r["can_mid"], "can_mid")     # the scratch holds the points before the clamp to the bound
+    assert np.array_equal(g["mask"].cpu().numpy(), r["mask"])
+    assert 0.02 < r["mask"].mean() < 0.7 and r["weights_sum"].max() > 0.5
+
+
+@pytest.mark.parametrize("tag,guide", [("guide", True), ("noguide", False)])
+def test_warped_render_vs_reference_golden(env, tag, guide):
+    from tests.test_oracle_golden import check_warp_render_vs_golden
+    gd = load_golden("warp_render.npz")
+    g, _ = _warp_both(env, gd["rays_o"], gd["rays_d"], 32, 32, guide)
+    check_warp_render_vs_golden(lambda k: g[k].cpu().numpy(), gd, tag)
+
+
+def test_warped_render_bad_arguments(env):
+    from avatarcraft_amd import nsr_ops, _lib as L
+    import ctypes as C
+    from tests.common import make_body
+    verts, faces, Ts = make_body()
+    with pytest.raises(RuntimeError, match="one 4x4 per vertex"):
+        nsr_ops.WarpMesh(verts, faces, Ts[:10], "cuda:0")
+    wm = nsr_ops.WarpMesh(verts, faces, Ts, "cuda:0")
+    ro, rd = make_rays(4, 4)
+    t = lambda a: torch.from_numpy(a).to("cuda:0")
+    with pytest.raises(RuntimeError, match="unsupported"):
+        nsr_ops.render_rays(env["f"], t(ro), t(rd), 24, 32, 1.6, 1.0, warp=wm)
+    # scratch too small is refused
+    op = L.ac_render_opts(16, 32, 32, 1.6, 1.0, 1.0, 0.005, 0)
+    o = L.ac_render_out()
+    for k in ("image", "weights_sum", "depth", "normal_map", "eik"):
+        setattr(o, k, torch.empty(64, device="cuda:0").data_ptr())
+    lz, lu = nsr_ops.linspace_tables(32, torch.device("cuda:0"))
+    sc = torch.empty(1024, dtype=torch.uint8, device="cuda:0")
+    rc = L.lib().ac_render_rays_warped(C.byref(env["f"].c), C.byref(op), t(ro).data_ptr(), t(rd).data_ptr(), None, None, lz.data_ptr(), lu.data_ptr(),
+                                       C.byref(wm.c), sc.data_ptr(), 1024, C.byref(o), None)
+    assert rc != 0 and b"scratch" in L.lib().ac_last_error()
