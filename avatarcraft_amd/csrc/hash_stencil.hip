@@ -1,0 +1,260 @@
+// avatarcraft_amd/csrc/hash_stencil.hip -- the hash-grid encoder on the 7-point finite-difference stencil (training path).
+//
+// One SDF query of the render core is 7 encoder calls in the reference: the sample x (forward_sdf, models/instant_nsr.py:627-642)
+// and x +- eps e_k clamped to the bound (finite_difference_normals_approximator, :687-704), each through
+// HashEncoder.forward / _hash_encode.backward (encoder/hashencoder/hashgrid.py:11-73,126-142).  This operator evaluates the seven
+// points of every sample in one launch and, in the backward, combines their table gradients in registers before touching HBM:
+// on the levels where eps spans less than one cell all seven points lie in the same or a neighbouring cell, so their
+// 7 x 8 corners collapse onto at most 32 distinct table entries (normally 8) -> 7x fewer atomics on exactly the coarse levels
+// where the float atomics of the one-point-at-a-time backward serialise (profiles/r01_v3_sds_kernel_stats.txt).
+//
+// Point order p = 0..6: x, +x, -x, +y, -y, +z, -z.  Layouts: x [B,3] fp32 world space (already clamped to the bound, as the
+// render core passes it); features / their gradient [7, L, B, 2] (level-major like the reference's [L,B,C] kernel output).
+// Arithmetic per point is the one of hash_fwd_kernel (fma(x, scale, 0.5), floor, trilinear weights as products in d order);
+// the normalisation to [0,1] is (clamp(x +- eps) + bound) / (2 bound) with a true division, like the fused renderer.
+#include "ac_common.hpp"
+#include "ac_devmath.hpp"
+
+using namespace acdev;
+
+namespace {
+
+struct LevelC { float scale; uint32_t stride1, size, hashed, mask; };
+
+__device__ __forceinline__ uint32_t gindex(const LevelC &L, uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t index;
+    if (L.hashed) index = x ^ (y * 2654435761u) ^ (z * 805459861u);
+    else index = x + (y + z * L.stride1) * L.stride1;
+    if (L.mask) index &= L.mask;
+    else if (index >= L.size) index %= L.size;
+    return index;
+}
+
+struct Loc { uint32_t pg; float fr; bool oob; };
+
+// world coordinate -> cell + fraction on one axis
+__device__ __forceinline__ Loc locate(float xw, float bound, float two_bound, float scale)
+{
+    const float u = (xw + bound) / two_bound;
+    Loc r;
+    r.oob = (u < 0.0f) | (u > 1.0f);
+    const float p = fma_(u, scale, 0.5f);
+    const float fl = __builtin_floorf(p);
+    r.pg = (uint32_t)fl;
+    r.fr = p - (float)r.pg;
+    return r;
+}
+
+__device__ __forceinline__ LevelC level_of(const ac::LevelTable &lt, uint32_t level)
+{
+    LevelC L;
+    L.scale = lt.scale[level]; L.stride1 = lt.stride1[level]; L.size = lt.size[level]; L.hashed = lt.hashed[level]; L.mask = lt.pow2mask[level];
+    return L;
+}
+
+__device__ __forceinline__ float offset_coord(float xc, int sign, float eps, float bound)
+{
+    return clampf(xc + (sign ? -eps : eps), -bound, bound);
+}
+
+// ---- forward: out[p][level][b][0..1] ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hash_stencil_fwd_kernel(const float *__restrict__ x, const float *__restrict__ grid,
+                                                               float *__restrict__ out, uint32_t B, ac::LevelTable lt, float eps,
+                                                               float bound, float two_bound)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y, Lc = lt.L;
+    const LevelC L = level_of(lt, level);
+    const float2 *g = reinterpret_cast<const float2 *>(grid) + lt.offset[level];
+    const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
+    Loc c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = locate(xc[d], bound, two_bound, L.scale);
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        Loc q[3] = { c[0], c[1], c[2] };
+        if (p > 0) { const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale); }
+        float a0 = 0.0f, a1 = 0.0f;
+        if (!(q[0].oob | q[1].oob | q[2].oob)) {
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; ++idx) {
+                float w = 1.0f; uint32_t pl[3];
+#pragma unroll
+                for (uint32_t d = 0; d < 3; ++d) {
+                    if ((idx & (1u << d)) == 0) { w *= 1.0f - q[d].fr; pl[d] = q[d].pg; }
+                    else { w *= q[d].fr; pl[d] = q[d].pg + 1u; }
+                }
+                const float2 f = g[gindex(L, pl[0], pl[1], pl[2])];
+                a0 = fma_(w, f.x, a0); a1 = fma_(w, f.y, a1);
+            }
+        }
+        reinterpret_cast<float2 *>(out)[((size_t)p * Lc + level) * B + b] = make_float2(a0, a1);
+    }
+}
+
+// ---- backward ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void scatter8(float2 *__restrict__ gg, const LevelC &L, const Loc (&q)[3], float g0, float g1)
+{
+    if (q[0].oob | q[1].oob | q[2].oob) return;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; ++idx) {
+        float w = 1.0f; uint32_t pl[3];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) {
+            if ((idx & (1u << d)) == 0) { w *= 1.0f - q[d].fr; pl[d] = q[d].pg; }
+            else { w *= q[d].fr; pl[d] = q[d].pg + 1u; }
+        }
+        float *t = reinterpret_cast<float *>(gg + gindex(L, pl[0], pl[1], pl[2]));
+        unsafeAtomicAdd(t, w * g0); unsafeAtomicAdd(t + 1, w * g1);
+    }
+}
+
+// fine_mask bit l: eps can reach a non-neighbouring cell on level l -> the seven points scatter independently
+__global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ x,
+                                                               float *__restrict__ grad_grid, uint32_t B, ac::LevelTable lt, float eps,
+                                                               float bound, float two_bound, uint32_t fine_mask)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y, Lc = lt.L;
+    const LevelC L = level_of(lt, level);
+    float2 *gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
+    const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
+    float2 gp[7];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
+    Loc c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = locate(xc[d], bound, two_bound, L.scale);
+
+    if ((fine_mask >> level) & 1u) {
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            Loc q[3] = { c[0], c[1], c[2] };
+            if (p > 0) { const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale); }
+            scatter8(gg, L, q, gp[p].x, gp[p].y);
+        }
+        return;
+    }
+    if (c[0].oob | c[1].oob | c[2].oob) {        // caller passed a point outside the bound: no combining, plain path
+#pragma unroll
+        for (int p = 1; p < 7; ++p) {
+            Loc q[3] = { c[0], c[1], c[2] };
+            const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale);
+            scatter8(gg, L, q, gp[p].x, gp[p].y);
+        }
+        return;
+    }
+    // combine: base[idx] = the 8 corners of the centre cell; ext[k][side][jm] = the 4 corners one plane below (side 0) / above
+    // (side 1) the centre cell along axis k (jm = corner bits of the two other axes, in axis order)
+    float bs0[8], bs1[8], ex0[3][2][4], ex1[3][2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { bs0[i] = 0.0f; bs1[i] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ex0[k][s][j] = 0.0f; ex1[k][s][j] = 0.0f; }
+    const float wd[3][2] = { { 1.0f - c[0].fr, c[0].fr }, { 1.0f - c[1].fr, c[1].fr }, { 1.0f - c[2].fr, c[2].fr } };
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; ++idx) {
+        float w = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) w *= wd[d][(idx >> d) & 1u];
+        bs0[idx] = w * gp[0].x; bs1[idx] = w * gp[0].y;
+    }
+#pragma unroll
+    for (int p = 1; p < 7; ++p) {
+        const int k = (p - 1) >> 1;
+        const Loc q = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale);
+        if (q.oob) continue;
+        const int delta = (int)q.pg - (int)c[k].pg;                 // -1, 0, +1 on a coarse level
+        const float wk[2] = { 1.0f - q.fr, q.fr };
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; ++idx) {
+            // same product order as the forward: d = 0, 1, 2
+            float w = 1.0f;
+#pragma unroll
+            for (uint32_t d = 0; d < 3; ++d) w *= ((int)d == k) ? wk[(idx >> d) & 1u] : wd[d][(idx >> d) & 1u];
+            const float v0 = w * gp[p].x, v1 = w * gp[p].y;
+            const int t = delta + (int)((idx >> k) & 1u);           // plane along axis k relative to the centre cell: -1..2
+            // jm: bits of the two other axes
+            const uint32_t lo = (k == 0) ? ((idx >> 1) & 1u) : (idx & 1u);
+            const uint32_t hi = (k == 2) ? ((idx >> 1) & 1u) : ((idx >> 2) & 1u);
+            const uint32_t jm = lo | (hi << 1);
+            const uint32_t i0 = idx & ~(1u << k), i1 = idx | (1u << k);
+            ex0[k][0][jm] += (t == -1) ? v0 : 0.0f; ex1[k][0][jm] += (t == -1) ? v1 : 0.0f;
+            bs0[i0] += (t == 0) ? v0 : 0.0f;        bs1[i0] += (t == 0) ? v1 : 0.0f;
+            bs0[i1] += (t == 1) ? v0 : 0.0f;        bs1[i1] += (t == 1) ? v1 : 0.0f;
+            ex0[k][1][jm] += (t == 2) ? v0 : 0.0f;  ex1[k][1][jm] += (t == 2) ? v1 : 0.0f;
+        }
+    }
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; ++idx) {
+        if (bs0[idx] != 0.0f || bs1[idx] != 0.0f) {
+            float *t = reinterpret_cast<float *>(gg + gindex(L, c[0].pg + (idx & 1u), c[1].pg + ((idx >> 1) & 1u), c[2].pg + ((idx >> 2) & 1u)));
+            unsafeAtomicAdd(t, bs0[idx]); unsafeAtomicAdd(t + 1, bs1[idx]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (uint32_t jm = 0; jm < 4; ++jm) {
+                if (ex0[k][s][jm] != 0.0f || ex1[k][s][jm] != 0.0f) {
+                    uint32_t pl[3];
+                    const uint32_t lo = jm & 1u, hi = jm >> 1;
+                    pl[0] = c[0].pg + (k == 0 ? 0u : lo);
+                    pl[1] = c[1].pg + (k == 1 ? 0u : (k == 0 ? lo : hi));
+                    pl[2] = c[2].pg + (k == 2 ? 0u : hi);
+                    pl[k] = s ? c[k].pg + 2u : c[k].pg - 1u;
+                    float *t = reinterpret_cast<float *>(gg + gindex(L, pl[0], pl[1], pl[2]));
+                    unsafeAtomicAdd(t, ex0[k][s][jm]); unsafeAtomicAdd(t + 1, ex1[k][s][jm]);
+                }
+            }
+}
+
+int check(const char *who, uint32_t C, uint32_t L, const int32_t *offsets_host, float eps, float bound)
+{
+    if (C != 2) { ac::set_error("%s: level_dim must be 2, got %u", who, C); return AC_ERR_BAD_ARG; }
+    if (L == 0 || L > AC_MAX_LEVELS) { ac::set_error("%s: L=%u out of range (1..%d)", who, L, AC_MAX_LEVELS); return AC_ERR_BAD_ARG; }
+    if (!offsets_host) { ac::set_error("%s: offsets_host is NULL", who); return AC_ERR_BAD_ARG; }
+    if (!(eps > 0.0f) || !(bound > 0.0f)) { ac::set_error("%s: eps and bound must be positive", who); return AC_ERR_BAD_ARG; }
+    return AC_OK;
+}
+
+}  // namespace
+
+AC_API int ac_hash_stencil_forward(const float *x, const float *embeddings, const int32_t *offsets_host, float *outputs, uint32_t B,
+                                   uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream)
+{
+    if (int rc = check("hash_stencil_forward", C, L, offsets_host, eps, bound)) return rc;
+    if (B == 0) return AC_OK;
+    if (!x || !embeddings || !outputs) { ac::set_error("hash_stencil_forward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
+    hipLaunchKernelGGL(hash_stencil_fwd_kernel, dim3((B + 255) / 256, L), dim3(256), 0, (hipStream_t)stream, x, embeddings, outputs, B, lt, eps,
+                       bound, (float)(2.0 * (double)bound));
+    return ac::check_launch("hash_stencil_forward");
+}
+
+AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                                    uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream)
+{
+    if (int rc = check("hash_stencil_backward", C, L, offsets_host, eps, bound)) return rc;
+    if (B == 0) return AC_OK;
+    if (!grad || !x || !grad_embeddings) { ac::set_error("hash_stencil_backward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
+    const float two_bound = (float)(2.0 * (double)bound);
+    uint32_t fine_mask = 0;
+    for (uint32_t l = 0; l < L; ++l) {           // same rule as the fused renderer's jfine (render_fused.hip)
+        const double cells = (double)eps / (double)two_bound * (double)lt.scale[l];
+        if (!(cells * 1.001 + 1e-3 < 1.0)) fine_mask |= 1u << l;
+    }
+    hipLaunchKernelGGL(hash_stencil_bwd_kernel, dim3((B + 255) / 256, L), dim3(256), 0, (hipStream_t)stream, grad, x, grad_embeddings, B, lt, eps,
+                       bound, two_bound, fine_mask);
+    return ac::check_launch("hash_stencil_backward");
+}

@@ -50,5 +50,23 @@ class _Backend:
                                                 L.current_stream(inputs.device)), "hash_encode_backward")
 
 
+    # ---- the 7-point finite-difference stencil in one launch (csrc/hash_stencil.hip); not part of the reference's pybind surface
+    @staticmethod
+    def hash_stencil_forward(x, embeddings, offsets, outputs, B, C, L_, S, H, eps, bound):
+        L.require_cuda(x, embeddings, offsets, outputs)
+        oh = _Backend._offsets_host(offsets)
+        L.check(L.lib().ac_hash_stencil_forward(x.data_ptr(), embeddings.data_ptr(), oh.ctypes.data, outputs.data_ptr(), B, C, L_,
+                                                float(np.float32(S)), H, float(eps), float(bound), L.current_stream(x.device)),
+                "hash_stencil_forward")
+
+    @staticmethod
+    def hash_stencil_backward(grad, x, offsets, grad_embeddings, B, C, L_, S, H, eps, bound):
+        L.require_cuda(grad, x, offsets, grad_embeddings)
+        oh = _Backend._offsets_host(offsets)
+        L.check(L.lib().ac_hash_stencil_backward(grad.data_ptr(), x.data_ptr(), oh.ctypes.data, grad_embeddings.data_ptr(), B, C, L_,
+                                                 float(np.float32(S)), H, float(eps), float(bound), L.current_stream(x.device)),
+                "hash_stencil_backward")
+
+
 _backend = _Backend()
 __all__ = ["_backend"]

@@ -55,6 +55,37 @@ class _hash_encode(Function):
 hash_encode = _hash_encode.apply
 
 
+class _hash_encode_stencil(Function):
+    """features of x and of clamp(x +- eps e_k, -bound, bound), k = x,y,z: [7, B, L*C] in ONE launch each way (the reference makes
+    7 HashEncoder calls per SDF query of the render core, models/instant_nsr.py:627-642,687-704).  x: [B,3] world space, no grad."""
+
+    @staticmethod
+    def forward(ctx, x, embeddings, offsets, per_level_scale, base_resolution, eps, bound):
+        x = x.contiguous()
+        embeddings = embeddings.contiguous()
+        B = x.shape[0]
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = np.log2(per_level_scale)
+        out = torch.empty(7, L, B, C, device=x.device, dtype=x.dtype)
+        _backend.hash_stencil_forward(x, embeddings, offsets, out, B, C, L, S, base_resolution, eps, bound)
+        ctx.save_for_backward(x, embeddings, offsets)
+        ctx.cfg = (B, C, L, S, base_resolution, eps, bound)
+        return out.permute(0, 2, 1, 3).reshape(7, B, L * C)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, embeddings, offsets = ctx.saved_tensors
+        B, C, L, S, H, eps, bound = ctx.cfg
+        grad = grad.view(7, B, L, C).permute(0, 2, 1, 3).contiguous()
+        grad_embeddings = torch.zeros_like(embeddings)
+        _backend.hash_stencil_backward(grad, x, offsets, grad_embeddings, B, C, L, S, H, eps, bound)
+        return None, grad_embeddings, None, None, None, None, None
+
+
+hash_encode_stencil = _hash_encode_stencil.apply
+
+
 class HashEncoder(nn.Module):
     def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
                  desired_resolution=None):
@@ -95,3 +126,10 @@ class HashEncoder(nn.Module):
         inputs = inputs.view(-1, self.input_dim)
         outputs = hash_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad)
         return outputs.view(prefix_shape + [self.output_dim])
+
+    def forward_stencil(self, x, size, eps):
+        """x [B,3] in [-size,size] -> [7, B, L*C]: the encodings of x, x+eps e_x, x-eps e_x, ... (offsets clamped to the bound)"""
+        if self.input_dim != 3 or self.level_dim != 2:
+            raise RuntimeError("forward_stencil: input_dim 3 and level_dim 2 only")
+        return hash_encode_stencil(x.reshape(-1, 3), self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, float(eps),
+                                   float(size))

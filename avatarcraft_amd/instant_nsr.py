@@ -124,9 +124,13 @@ class NeRFRenderer(nn.Module):
         pts = (rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_mid.unsqueeze(-1)).clamp(-bound, bound).float()
         dirs = rays_d.unsqueeze(-2).expand_as(pts)
         flat = pts.reshape(-1, 3)
-        sdf_out = self.forward_sdf(flat, bound)
+        fd_eps = 0.005 * (1.0 - normal_epsilon_ratio)
+        if fd_eps > 0.0 and hasattr(self.encoder, "forward_stencil"):
+            sdf_out, gradient = self.forward_sdf_stencil(flat, bound, fd_eps)      # 1 encoder launch + 1 MLP pass for the 7 points
+        else:
+            sdf_out = self.forward_sdf(flat, bound)
+            gradient = self.gradient(flat, bound, fd_eps).squeeze()
         sdf, feat = sdf_out[:, :1], sdf_out[:, 1:]
-        gradient = self.gradient(flat, bound, 0.005 * (1.0 - normal_epsilon_ratio)).squeeze()
         normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
         color = self.forward_color(flat, dirs.reshape(-1, 3), normal.reshape(-1, 3), feat, bound)
         inv_s = self.forward_variance().expand(N * T, 1)
@@ -244,6 +248,25 @@ class NeRFNetwork(NeRFRenderer):
             if l != self.num_layers - 1:
                 h = self.activation(h)
         return h
+
+    def forward_sdf_stencil(self, x, bound, epsilon):
+        """forward_sdf(x) (:627-642) and finite_difference_normals_approximator(x) (:687-704) together: the seven hash encodings
+        come from one stencil launch (encoder.forward_stencil) and the SDF MLP runs once over the 7B points.
+        Returns (sdf_out [B,16], gradient [B,3])."""
+        B = x.shape[0]
+        h7 = self.encoder.forward_stencil(x, bound, epsilon)                       # [7,B,32]: x, +x, -x, +y, -y, +z, -z
+        pts = x.unsqueeze(0).repeat(7, 1, 1)
+        for k in range(3):
+            pts[1 + 2 * k, :, k] = (x[:, k] + epsilon).clamp(-bound, bound)
+            pts[2 + 2 * k, :, k] = (x[:, k] - epsilon).clamp(-bound, bound)
+        h = torch.cat([pts, h7], dim=-1).reshape(7 * B, -1) if self.include_input else h7.reshape(7 * B, -1)
+        for l in range(self.num_layers):
+            h = self.sdf_net[l](h)
+            if l != self.num_layers - 1:
+                h = self.activation(h)
+        h = h.view(7, B, -1)
+        gradient = (0.5 * (h[1::2, :, 0] - h[2::2, :, 0]) / epsilon).t()
+        return h[0], gradient
 
     def forward_color(self, x, d, n, geo_feat, bound):
         if self.use_viewdirs:

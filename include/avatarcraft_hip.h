@@ -192,6 +192,18 @@ int ac_warp_samples(const float *pts, const float *verts, const int32_t *faces, 
                     double threshold, double *can_pts, float *can_pts_f32, double *closest, double *dist2, int32_t *face_id,
                     uint8_t *mask, ac_stream_t stream);
 
+/* ---- hash-grid encoder on the 7-point finite-difference stencil (training path)
+ * One SDF query of the render core is 7 HashEncoder calls in the reference: forward_sdf at x (models/instant_nsr.py:627-642) and at
+ * clamp(x +- eps e_k) (finite_difference_normals_approximator, :687-704), each through encoder/hashencoder/hashgrid.py:11-73.
+ * These two entry points evaluate / back-propagate the seven points of every sample in one launch; the backward combines the
+ * table gradients of the seven points in registers before its atomics (same sums as 7 x ac_hash_encode_backward).
+ * x [B,3] world space, clamped to [-bound, bound]; point order x, +x, -x, +y, -y, +z, -z; outputs / grad [7, L, B, C], C = 2, D = 3;
+ * grad_embeddings is accumulated into (zero it first). */
+int ac_hash_stencil_forward(const float *x, const float *embeddings, const int32_t *offsets_host, float *outputs, uint32_t B,
+                            uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream);
+int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                             uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream);
+
 /* ---- posed-space rendering: NeRFRenderer.run(render_can=False, verts, faces, Ts, use_mesh_guide)
  * models/instant_nsr.py:147-172 (mesh-guided near/far, warp of the coarse samples), :198-203 (warp of the mid points),
  * :246-249 (alpha mask).  The reference moves the samples to the CPU for libigl twice per batch; here the whole sequence
