@@ -19,6 +19,12 @@ using namespace acdev;
 
 namespace {
 
+#ifdef AC_ABL_NOATOMIC      // timing ablation (tools/ablate_stencil.sh): keep the address math, drop the atomic itself
+#define AC_ATOMIC_ADD(P, V) { if ((V) == 123456.789f) *(P) = (V); }
+#else
+#define AC_ATOMIC_ADD(P, V) unsafeAtomicAdd((P), (V))
+#endif
+
 struct LevelC { float scale; uint32_t stride1, size, hashed, mask; };
 
 __device__ __forceinline__ uint32_t gindex(const LevelC &L, uint32_t x, uint32_t y, uint32_t z)
@@ -95,19 +101,56 @@ __global__ __launch_bounds__(256) void hash_stencil_fwd_kernel(const float *__re
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void scatter8(float2 *__restrict__ gg, const LevelC &L, const Loc (&q)[3], float g0, float g1)
+// A wave holds 64 consecutive samples of one ray (B index = ray * T + sample, sorted by depth), and the importance sampling packs
+// most of them into a few cells: neighbouring lanes that sit in the same cell address the same table entries.  Their
+// contributions are summed inside the wave first (segmented inclusive scan over runs of equal cell, 6 shuffle steps) and only
+// the last lane of each run issues the atomics.
+template <int N>
+__device__ __forceinline__ bool run_reduce(float (&v)[N], bool head, int lane)
 {
-    if (q[0].oob | q[1].oob | q[2].oob) return;
+#ifdef AC_ABL_NORUN         // timing ablation: every lane is its own run
+    return true;
+#endif
+    int f = head ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int tf = __shfl_up(f, d);
+        const bool take = (lane >= d) && !f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { const float t = __shfl_up(v[i], d); v[i] += take ? t : 0.0f; }
+        if (lane >= d) f |= tf;
+    }
+    const int next_head = __shfl_down(head ? 1 : 0, 1);
+    return lane == 63 || next_head != 0;
+}
+
+__device__ __forceinline__ bool run_head(const Loc (&q)[3], bool ok, int lane)
+{
+    const uint32_t p0 = __shfl_up(q[0].pg, 1), p1 = __shfl_up(q[1].pg, 1), p2 = __shfl_up(q[2].pg, 1);
+    const int pok = __shfl_up(ok ? 1 : 0, 1);
+    return lane == 0 || p0 != q[0].pg || p1 != q[1].pg || p2 != q[2].pg || pok != (ok ? 1 : 0);    // runs are homogeneous in `ok`
+}
+
+// one point's 8 corners, combined over the run of lanes in the same cell
+__device__ __forceinline__ void scatter8_runs(float2 *__restrict__ gg, const LevelC &L, const Loc (&q)[3], float g0, float g1, int lane)
+{
+    const bool ok = !(q[0].oob | q[1].oob | q[2].oob);
+    float v[16];
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; ++idx) {
-        float w = 1.0f; uint32_t pl[3];
+        float w = 1.0f;
 #pragma unroll
-        for (uint32_t d = 0; d < 3; ++d) {
-            if ((idx & (1u << d)) == 0) { w *= 1.0f - q[d].fr; pl[d] = q[d].pg; }
-            else { w *= q[d].fr; pl[d] = q[d].pg + 1u; }
+        for (uint32_t d = 0; d < 3; ++d) w *= ((idx >> d) & 1u) ? q[d].fr : 1.0f - q[d].fr;
+        v[2 * idx] = ok ? w * g0 : 0.0f; v[2 * idx + 1] = ok ? w * g1 : 0.0f;
+    }
+    const bool tail = run_reduce<16>(v, run_head(q, ok, lane), lane);
+    if (!tail || !ok) return;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; ++idx) {
+        if (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f) {
+            float *t = reinterpret_cast<float *>(gg + gindex(L, q[0].pg + (idx & 1u), q[1].pg + ((idx >> 1) & 1u), q[2].pg + ((idx >> 2) & 1u)));
+            AC_ATOMIC_ADD(t, v[2 * idx]); AC_ATOMIC_ADD(t + 1, v[2 * idx + 1]);
         }
-        float *t = reinterpret_cast<float *>(gg + gindex(L, pl[0], pl[1], pl[2]));
-        unsafeAtomicAdd(t, w * g0); unsafeAtomicAdd(t + 1, w * g1);
     }
 }
 
@@ -116,87 +159,79 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
                                                                float *__restrict__ grad_grid, uint32_t B, ac::LevelTable lt, float eps,
                                                                float bound, float two_bound, uint32_t fine_mask)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = b0 < B;
+    const uint32_t b = valid ? b0 : B - 1;
+    const int lane = threadIdx.x & 63;
     const uint32_t level = blockIdx.y, Lc = lt.L;
     const LevelC L = level_of(lt, level);
     float2 *gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
     const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
     float2 gp[7];
 #pragma unroll
-    for (int p = 0; p < 7; ++p) gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
+    for (int p = 0; p < 7; ++p) {
+        gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
+        if (!valid) gp[p] = make_float2(0.0f, 0.0f);
+    }
     Loc c[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) c[d] = locate(xc[d], bound, two_bound, L.scale);
+    const bool cen_ok = !(c[0].oob | c[1].oob | c[2].oob);
 
-    if ((fine_mask >> level) & 1u) {
+    if (((fine_mask >> level) & 1u) || !__all(cen_ok)) {     // wave-uniform: every lane takes the same path (shuffles inside)
 #pragma unroll
         for (int p = 0; p < 7; ++p) {
             Loc q[3] = { c[0], c[1], c[2] };
             if (p > 0) { const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale); }
-            scatter8(gg, L, q, gp[p].x, gp[p].y);
+            scatter8_runs(gg, L, q, gp[p].x, gp[p].y, lane);
         }
         return;
     }
-    if (c[0].oob | c[1].oob | c[2].oob) {        // caller passed a point outside the bound: no combining, plain path
+    // combine the seven points: v[2*idx+c] = the 8 corners of the centre cell; v[16 + ((k*2+side)*4+jm)*2 + c] = the 4 corners one
+    // plane below (side 0) / above (side 1) the centre cell along axis k (jm = corner bits of the two other axes, in axis order)
+    float v[64];
 #pragma unroll
-        for (int p = 1; p < 7; ++p) {
-            Loc q[3] = { c[0], c[1], c[2] };
-            const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale);
-            scatter8(gg, L, q, gp[p].x, gp[p].y);
-        }
-        return;
-    }
-    // combine: base[idx] = the 8 corners of the centre cell; ext[k][side][jm] = the 4 corners one plane below (side 0) / above
-    // (side 1) the centre cell along axis k (jm = corner bits of the two other axes, in axis order)
-    float bs0[8], bs1[8], ex0[3][2][4], ex1[3][2][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { bs0[i] = 0.0f; bs1[i] = 0.0f; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { ex0[k][s][j] = 0.0f; ex1[k][s][j] = 0.0f; }
+    for (int i = 0; i < 64; ++i) v[i] = 0.0f;
     const float wd[3][2] = { { 1.0f - c[0].fr, c[0].fr }, { 1.0f - c[1].fr, c[1].fr }, { 1.0f - c[2].fr, c[2].fr } };
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; ++idx) {
         float w = 1.0f;
 #pragma unroll
         for (uint32_t d = 0; d < 3; ++d) w *= wd[d][(idx >> d) & 1u];
-        bs0[idx] = w * gp[0].x; bs1[idx] = w * gp[0].y;
+        v[2 * idx] = w * gp[0].x; v[2 * idx + 1] = w * gp[0].y;
     }
 #pragma unroll
     for (int p = 1; p < 7; ++p) {
         const int k = (p - 1) >> 1;
         const Loc q = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale);
-        if (q.oob) continue;
+        const float live = q.oob ? 0.0f : 1.0f;
         const int delta = (int)q.pg - (int)c[k].pg;                 // -1, 0, +1 on a coarse level
         const float wk[2] = { 1.0f - q.fr, q.fr };
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; ++idx) {
-            // same product order as the forward: d = 0, 1, 2
-            float w = 1.0f;
+            float w = live;
 #pragma unroll
             for (uint32_t d = 0; d < 3; ++d) w *= ((int)d == k) ? wk[(idx >> d) & 1u] : wd[d][(idx >> d) & 1u];
             const float v0 = w * gp[p].x, v1 = w * gp[p].y;
             const int t = delta + (int)((idx >> k) & 1u);           // plane along axis k relative to the centre cell: -1..2
-            // jm: bits of the two other axes
             const uint32_t lo = (k == 0) ? ((idx >> 1) & 1u) : (idx & 1u);
             const uint32_t hi = (k == 2) ? ((idx >> 1) & 1u) : ((idx >> 2) & 1u);
             const uint32_t jm = lo | (hi << 1);
             const uint32_t i0 = idx & ~(1u << k), i1 = idx | (1u << k);
-            ex0[k][0][jm] += (t == -1) ? v0 : 0.0f; ex1[k][0][jm] += (t == -1) ? v1 : 0.0f;
-            bs0[i0] += (t == 0) ? v0 : 0.0f;        bs1[i0] += (t == 0) ? v1 : 0.0f;
-            bs0[i1] += (t == 1) ? v0 : 0.0f;        bs1[i1] += (t == 1) ? v1 : 0.0f;
-            ex0[k][1][jm] += (t == 2) ? v0 : 0.0f;  ex1[k][1][jm] += (t == 2) ? v1 : 0.0f;
+            const uint32_t e0 = 16 + ((k * 2 + 0) * 4 + jm) * 2, e1 = 16 + ((k * 2 + 1) * 4 + jm) * 2;
+            v[e0] += (t == -1) ? v0 : 0.0f;     v[e0 + 1] += (t == -1) ? v1 : 0.0f;
+            v[2 * i0] += (t == 0) ? v0 : 0.0f;  v[2 * i0 + 1] += (t == 0) ? v1 : 0.0f;
+            v[2 * i1] += (t == 1) ? v0 : 0.0f;  v[2 * i1 + 1] += (t == 1) ? v1 : 0.0f;
+            v[e1] += (t == 2) ? v0 : 0.0f;      v[e1 + 1] += (t == 2) ? v1 : 0.0f;
         }
     }
+    const bool tail = run_reduce<64>(v, run_head(c, true, lane), lane);
+    if (!tail) return;
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; ++idx) {
-        if (bs0[idx] != 0.0f || bs1[idx] != 0.0f) {
+        if (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f) {
             float *t = reinterpret_cast<float *>(gg + gindex(L, c[0].pg + (idx & 1u), c[1].pg + ((idx >> 1) & 1u), c[2].pg + ((idx >> 2) & 1u)));
-            unsafeAtomicAdd(t, bs0[idx]); unsafeAtomicAdd(t + 1, bs1[idx]);
+            AC_ATOMIC_ADD(t, v[2 * idx]); AC_ATOMIC_ADD(t + 1, v[2 * idx + 1]);
         }
     }
 #pragma unroll
@@ -205,7 +240,8 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (uint32_t jm = 0; jm < 4; ++jm) {
-                if (ex0[k][s][jm] != 0.0f || ex1[k][s][jm] != 0.0f) {
+                const uint32_t e = 16 + ((k * 2 + s) * 4 + jm) * 2;
+                if (v[e] != 0.0f || v[e + 1] != 0.0f) {
                     uint32_t pl[3];
                     const uint32_t lo = jm & 1u, hi = jm >> 1;
                     pl[0] = c[0].pg + (k == 0 ? 0u : lo);
@@ -213,7 +249,7 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
                     pl[2] = c[2].pg + (k == 2 ? 0u : hi);
                     pl[k] = s ? c[k].pg + 2u : c[k].pg - 1u;
                     float *t = reinterpret_cast<float *>(gg + gindex(L, pl[0], pl[1], pl[2]));
-                    unsafeAtomicAdd(t, ex0[k][s][jm]); unsafeAtomicAdd(t + 1, ex1[k][s][jm]);
+                    AC_ATOMIC_ADD(t, v[e]); AC_ATOMIC_ADD(t + 1, v[e + 1]);
                 }
             }
 }
