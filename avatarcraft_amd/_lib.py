@@ -37,7 +37,7 @@ class ac_render_out(C.Structure):
 
 class ac_warp_mesh(C.Structure):
     _fields_ = [("verts", vp), ("faces", vp), ("T", vp), ("V", u32), ("F", u32), ("threshold", C.c_double), ("geo_threshold", f32),
-                ("use_mesh_guide", i32)]
+                ("use_mesh_guide", i32), ("accel", vp)]
 
 
 _SIGS = {
@@ -60,6 +60,9 @@ _SIGS = {
     "ac_field_sdf": ([C.POINTER(ac_field), vp, u32, f32, vp, vp], C.c_int),
     "ac_field_color": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),
     "ac_mesh_near_far": ([vp, vp, vp, u32, u32, f32, vp, vp, vp], C.c_int),
+    "ac_warp_accel_bytes": ([u32], C.c_size_t),
+    "ac_warp_accel_build": ([vp, vp, u32, u32, vp, C.c_size_t, vp], C.c_int),
+    "ac_warp_samples_accel": ([vp, vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_hash_stencil_forward": ([vp, vp, vp, vp, u32, u32, u32, f32, u32, f32, f32, vp], C.c_int),
     "ac_hash_stencil_backward": ([vp, vp, vp, vp, u32, u32, u32, f32, u32, f32, f32, vp], C.c_int),
     "ac_render_rays_warped_scratch": ([i32, i32, C.POINTER(C.c_size_t)], C.c_size_t),

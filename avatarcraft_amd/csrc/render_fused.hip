@@ -1124,6 +1124,14 @@ AC_API size_t ac_render_rays_warped_scratch(int32_t n_rays, int32_t T, size_t of
     return o;
 }
 
+static int warp_any(const ac_warp_mesh *m, const float *pts, uint32_t P, float *can, uint8_t *mask, ac_stream_t stream)
+{
+    if (m->accel)
+        return ac_warp_samples_accel(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, m->accel, nullptr, can, nullptr, nullptr, nullptr,
+                                     mask, stream);
+    return ac_warp_samples(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, nullptr, can, nullptr, nullptr, nullptr, mask, stream);
+}
+
 AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
                                  const float *bg, const float *noise, const float *lin_z, const float *lin_u,
                                  const ac_warp_mesh *mesh, void *scratch, size_t scratch_bytes, const ac_render_out *out,
@@ -1158,14 +1166,12 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
         hipLaunchKernelGGL(coarse_pts_kernel, dim3((N * T0 + 255) / 256), dim3(256), 0, st, rays_o, rays_d, a.near_m, a.far_m, lin_z, noise, N, T0,
                            op->bound, op->perturb, pts);
         if (int rc = ac::check_launch("render_rays_warped (coarse points)")) return rc;
-        if (int rc = ac_warp_samples(pts, mesh->verts, mesh->faces, mesh->T, (uint32_t)(N * T0), mesh->V, mesh->F, mesh->threshold, nullptr, can,
-                                     nullptr, nullptr, nullptr, mask, stream)) return rc;
+        if (int rc = warp_any(mesh, pts, (uint32_t)(N * T0), can, mask, stream)) return rc;
     }
     a.ext_pts = can;
     launch_render<MODE_UPSAMPLE>(a, st);                          // coarse sdf, up-sampling, mid points (posed space)
     if (int rc = ac::check_launch("render_rays_warped (up-sampling)")) return rc;
-    if (int rc = ac_warp_samples(pts, mesh->verts, mesh->faces, mesh->T, (uint32_t)(N * T), mesh->V, mesh->F, mesh->threshold, nullptr, can,
-                                 nullptr, nullptr, nullptr, mask, stream)) return rc;     // :198-203
+    if (int rc = warp_any(mesh, pts, (uint32_t)(N * T), can, mask, stream)) return rc;     // :198-203
     a.mask = mask;
     launch_render<MODE_FINAL>(a, st);
     return ac::check_launch("render_rays_warped");

@@ -131,6 +131,39 @@ __device__ __forceinline__ bool inv4(const double (&m)[16], double (&out)[16])
     return true;
 }
 
+// barycentric coordinates of the closest point, blend of the three per-vertex 4x4, inverse, application  (ray_utils.py:77-88)
+__device__ __forceinline__ void finish_sample(uint32_t i, const double (&p)[3], const double (&bc)[3], double best, int bf,
+                                              const float *__restrict__ verts, const int32_t *__restrict__ faces, const double *__restrict__ T,
+                                              double threshold, double *__restrict__ can_pts, float *__restrict__ can_pts_f32,
+                                              double *__restrict__ closest, double *__restrict__ dist2, int32_t *__restrict__ face_id,
+                                              uint8_t *__restrict__ mask)
+{
+    const int32_t f0v = faces[3 * (size_t)bf], f1v = faces[3 * (size_t)bf + 1], f2v = faces[3 * (size_t)bf + 2];
+    double a[3], b[3], c[3], v0[3], v1[3], v2[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        a[k] = (double)verts[3 * (size_t)f0v + k]; b[k] = (double)verts[3 * (size_t)f1v + k]; c[k] = (double)verts[3 * (size_t)f2v + k];
+        v0[k] = b[k] - a[k]; v1[k] = c[k] - a[k]; v2[k] = bc[k] - a[k];
+    }
+    const double d00 = DOT3(v0, v0), d01 = DOT3(v0, v1), d11 = DOT3(v1, v1), d20 = DOT3(v2, v0), d21 = DOT3(v2, v1);
+    const double den = d00 * d11 - d01 * d01;
+    const double bv = (d11 * d20 - d01 * d21) / den, bw = (d00 * d21 - d01 * d20) / den, bu = 1.0 - bv - bw;
+    double M[16], Mi[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) M[e] = T[16 * (size_t)f0v + e] * bu + T[16 * (size_t)f1v + e] * bv + T[16 * (size_t)f2v + e] * bw;
+    inv4(M, Mi);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double v = Mi[4 * r] * p[0] + Mi[4 * r + 1] * p[1] + Mi[4 * r + 2] * p[2] + Mi[4 * r + 3];
+        if (can_pts) can_pts[3 * (size_t)i + r] = v;
+        if (can_pts_f32) can_pts_f32[3 * (size_t)i + r] = (float)v;
+    }
+    if (closest) { closest[3 * (size_t)i] = bc[0]; closest[3 * (size_t)i + 1] = bc[1]; closest[3 * (size_t)i + 2] = bc[2]; }
+    if (dist2) dist2[i] = best;
+    if (face_id) face_id[i] = bf;
+    mask[i] = best < threshold ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
                                                            const int32_t *__restrict__ faces, const double *__restrict__ T, uint32_t P,
                                                            uint32_t F, double threshold, double *__restrict__ can_pts,
@@ -164,30 +197,263 @@ __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restri
         }
     }
     if (!live) return;
-    const int32_t f0v = faces[3 * (size_t)bf], f1v = faces[3 * (size_t)bf + 1], f2v = faces[3 * (size_t)bf + 2];
-    double a[3], b[3], c[3], v0[3], v1[3], v2[3];
+    finish_sample(i, p, bc, best, bf, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
+}
+
+// ---- exact closest-face search with culling ---------------------------------------------------------------------------------
+// Per frame (ac_warp_accel_build): faces sorted along a Morton curve of their centroids (one workgroup, bitonic sort of
+// 16384 64-bit keys in 128 KB of LDS), cut into tiles of 32 faces with an axis-aligned box and one representative vertex.
+// Per sample (warp_samples_accel_kernel): one WAVE searches for one sample at a time -- lane = tile in the bounding pass
+// (boxes live in registers for the whole kernel), lane = face in the exact pass, so the lanes never diverge:
+//   1. ub = min over tiles of |p - representative vertex|^2          (a point of the mesh: upper bound of the answer)
+//   2. tiles with box distance^2 <= ub (1 + 1e-9) are the candidates (the box distance is a lower bound for every face inside)
+//   3. the faces of two candidate tiles at a time go through the same fp64 Ericson routine as the brute-force kernel; each lane
+//      keeps its own best (d2, face id), one wave reduction per sample, ties -> lowest face id (order independent).
+// A wave owns 64 consecutive samples: the search runs sample by sample, the result of sample j parks in lane j, and the
+// barycentric blend / 4x4 inverse epilogue runs lane-parallel for the 64 samples.  Bit-identical to warp_samples_kernel.
+constexpr int TILE_F = 32;          // faces per tile
+constexpr int MAX_TILES = 512;      // 8 bounding-pass iterations of 64 lanes
+constexpr uint32_t MAX_ACCEL_FACES = MAX_TILES * TILE_F;     // 16384
+
+struct AccelView {                   // pointers into the caller's accel buffer
+    uint32_t *hdr;                   // [0] = number of tiles, [1] = F
+    uint32_t *sorted;                // [16384] face ids along the curve
+    float *tri;                      // [MAX_TILES*32][9]
+    int32_t *oid;                    // [MAX_TILES*32] original face id of each slot
+    float *box;                      // [9][MAX_TILES]: min xyz, max xyz, representative vertex xyz
+};
+__host__ __device__ inline size_t accel_offsets(size_t (&o)[5])
+{
+    size_t off = 0;
+    const size_t sz[5] = { 64, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)9 * MAX_TILES * 4 };
+    for (int i = 0; i < 5; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
+    return off;
+}
+__host__ __device__ inline AccelView accel_view(void *base)
+{
+    size_t o[5]; accel_offsets(o);
+    char *b = static_cast<char *>(base);
+    AccelView v;
+    v.hdr = reinterpret_cast<uint32_t *>(b + o[0]); v.sorted = reinterpret_cast<uint32_t *>(b + o[1]);
+    v.tri = reinterpret_cast<float *>(b + o[2]); v.oid = reinterpret_cast<int32_t *>(b + o[3]); v.box = reinterpret_cast<float *>(b + o[4]);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v)      // 10 bits -> every third bit
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// one workgroup of 1024 threads: centroid bounds, Morton keys, bitonic sort (key << 32 | face id) in LDS
+__global__ __launch_bounds__(1024) void accel_sort_kernel(const float *__restrict__ verts, const int32_t *__restrict__ faces, uint32_t F,
+                                                          uint32_t *__restrict__ sorted)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];       // [16384]
+    __shared__ float red[6][1024];
+    const uint32_t t = threadIdx.x;
+    float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+    for (uint32_t f = t; f < F; f += 1024) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        a[k] = (double)verts[3 * (size_t)f0v + k]; b[k] = (double)verts[3 * (size_t)f1v + k]; c[k] = (double)verts[3 * (size_t)f2v + k];
-        v0[k] = b[k] - a[k]; v1[k] = c[k] - a[k]; v2[k] = bc[k] - a[k];
+        for (int k = 0; k < 3; ++k) {
+            const float c = (verts[3 * (size_t)faces[3 * f] + k] + verts[3 * (size_t)faces[3 * f + 1] + k]) + verts[3 * (size_t)faces[3 * f + 2] + k];
+            lo[k] = c < lo[k] ? c : lo[k]; hi[k] = c > hi[k] ? c : hi[k];
+        }
     }
-    const double d00 = DOT3(v0, v0), d01 = DOT3(v0, v1), d11 = DOT3(v1, v1), d20 = DOT3(v2, v0), d21 = DOT3(v2, v1);
-    const double den = d00 * d11 - d01 * d01;
-    const double bv = (d11 * d20 - d01 * d21) / den, bw = (d00 * d21 - d01 * d20) / den, bu = 1.0 - bv - bw;
-    double M[16], Mi[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) M[e] = T[16 * (size_t)f0v + e] * bu + T[16 * (size_t)f1v + e] * bv + T[16 * (size_t)f2v + e] * bw;
-    inv4(M, Mi);
+    for (int k = 0; k < 3; ++k) { red[k][t] = lo[k]; red[3 + k][t] = hi[k]; }
+    __syncthreads();
+    for (uint32_t s = 512; s > 0; s >>= 1) {
+        if (t < s) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const double v = Mi[4 * r] * p[0] + Mi[4 * r + 1] * p[1] + Mi[4 * r + 2] * p[2] + Mi[4 * r + 3];
-        if (can_pts) can_pts[3 * (size_t)i + r] = v;
-        if (can_pts_f32) can_pts_f32[3 * (size_t)i + r] = (float)v;
+            for (int k = 0; k < 3; ++k) {
+                red[k][t] = red[k][t + s] < red[k][t] ? red[k][t + s] : red[k][t];
+                red[3 + k][t] = red[3 + k][t + s] > red[3 + k][t] ? red[3 + k][t + s] : red[3 + k][t];
+            }
+        }
+        __syncthreads();
     }
-    if (closest) { closest[3 * (size_t)i] = bc[0]; closest[3 * (size_t)i + 1] = bc[1]; closest[3 * (size_t)i + 2] = bc[2]; }
-    if (dist2) dist2[i] = best;
-    if (face_id) face_id[i] = bf;
-    mask[i] = best < threshold ? 1 : 0;
+    float org[3], inv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { org[k] = red[k][0]; const float ext = red[3 + k][0] - red[k][0]; inv[k] = ext > 0.0f ? 1023.0f / ext : 0.0f; }
+    for (uint32_t f = t; f < MAX_ACCEL_FACES; f += 1024) {
+        unsigned long long key = ~0ull;
+        if (f < F) {
+            uint32_t q[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float c = (verts[3 * (size_t)faces[3 * f] + k] + verts[3 * (size_t)faces[3 * f + 1] + k]) + verts[3 * (size_t)faces[3 * f + 2] + k];
+                float g = (c - org[k]) * inv[k];
+                g = g < 0.0f ? 0.0f : (g > 1023.0f ? 1023.0f : g);
+                q[k] = (uint32_t)g;
+            }
+            const uint32_t m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+            key = ((unsigned long long)m << 32) | f;
+        }
+        keys[f] = key;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= MAX_ACCEL_FACES; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < MAX_ACCEL_FACES; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = keys[i], b = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t f = t; f < MAX_ACCEL_FACES; f += 1024) sorted[f] = (uint32_t)(keys[f] & 0xffffffffull);
+}
+
+// identity order (meshes the sort kernel does not cover are not accelerated at all; kept for tests of the tile builder)
+__global__ __launch_bounds__(256) void accel_tiles_kernel(const float *__restrict__ verts, const int32_t *__restrict__ faces, uint32_t F,
+                                                          AccelView av)
+{
+    __shared__ float sb[256][9];
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;            // 8 tiles per block
+    const uint32_t nt = (F + TILE_F - 1) / TILE_F;
+    const uint32_t src = slot < F ? slot : F - 1;                     // the tail of the last tile repeats the last face
+    const uint32_t f = av.sorted[src];
+    float v[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[3 * c + k] = verts[3 * (size_t)faces[3 * f + c] + k];
+    if (slot < nt * TILE_F) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) av.tri[(size_t)slot * 9 + e] = v[e];
+        av.oid[slot] = (int32_t)f;
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) sb[threadIdx.x][e] = v[e];
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const uint32_t tile = blockIdx.x * 8 + threadIdx.x;
+        if (tile < MAX_TILES) {
+            float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+            float rep[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() };
+            if (tile < nt) {
+                for (int j = 0; j < TILE_F; ++j)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float x = sb[threadIdx.x * TILE_F + j][3 * c + k];
+                            lo[k] = x < lo[k] ? x : lo[k]; hi[k] = x > hi[k] ? x : hi[k];
+                        }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rep[k] = sb[threadIdx.x * TILE_F][k];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { av.box[k * MAX_TILES + tile] = lo[k]; av.box[(3 + k) * MAX_TILES + tile] = hi[k]; av.box[(6 + k) * MAX_TILES + tile] = rep[k]; }
+        }
+    }
+    if (slot == 0) { av.hdr[0] = nt; av.hdr[1] = F; }
+}
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(v, d); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
+                                                                 const int32_t *__restrict__ faces, const double *__restrict__ T, uint32_t P,
+                                                                 double threshold, AccelView av, double *__restrict__ can_pts,
+                                                                 float *__restrict__ can_pts_f32, double *__restrict__ closest,
+                                                                 double *__restrict__ dist2, int32_t *__restrict__ face_id,
+                                                                 uint8_t *__restrict__ mask)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nt = av.hdr[0];
+    const uint32_t nit = (nt + 63) >> 6;
+    // this lane's tiles (tile = 64 * it + lane): box and representative vertex, resident in registers
+    float bx[8][9];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) bx[it][e] = av.box[e * MAX_TILES + it * 64 + lane];
+    const uint32_t i = wave * 64 + lane;
+    const bool live = i < P;
+    const uint32_t ii = live ? i : P - 1;
+    const double p[3] = { (double)pts[3 * (size_t)ii], (double)pts[3 * (size_t)ii + 1], (double)pts[3 * (size_t)ii + 2] };
+    double rbest = __builtin_inf(), rbc[3] = { 0.0, 0.0, 0.0 };
+    int rbf = 0;
+    const uint32_t npts = (P - wave * 64 < 64u) ? P - wave * 64 : 64u;            // wave-uniform
+    for (uint32_t j = 0; j < npts; ++j) {
+        const double q[3] = { __shfl(p[0], (int)j), __shfl(p[1], (int)j), __shfl(p[2], (int)j) };
+        // 1. upper bound from the representative vertices
+        double ub = __builtin_inf();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const double ex = q[0] - (double)bx[it][6], ey = q[1] - (double)bx[it][7], ez = q[2] - (double)bx[it][8];
+            const double u = ex * ex + ey * ey + ez * ez;
+            ub = u < ub ? u : ub;                    // padding tiles hold +inf
+        }
+        ub = wave_min_f64(ub);
+        const double lim = ub * (1.0 + 1e-9);
+        // 2./3. candidates, two tiles per step
+        double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
+        int bid = 0x7fffffff;
+#pragma unroll 1
+        for (uint32_t it = 0; it < nit; ++it) {
+            float b9[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                float v = bx[0][e];
+#pragma unroll
+                for (int u2 = 1; u2 < 8; ++u2) v = (it == (uint32_t)u2) ? bx[u2][e] : v;
+                b9[e] = v;
+            }
+            double lb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double lo = (double)b9[k] - q[k], hi = q[k] - (double)b9[3 + k];
+                double d = lo > hi ? lo : hi;
+                d = d > 0.0 ? d : 0.0;
+                lb += d * d;
+            }
+            unsigned long long cand = __ballot(lb <= lim);         // NaN/inf boxes of padding tiles never qualify
+            while (cand) {
+                const int t0 = __builtin_ctzll(cand); cand &= cand - 1;
+                int t1 = -1;
+                if (cand) { t1 = __builtin_ctzll(cand); cand &= cand - 1; }
+                const int tl = lane < 32 ? t0 : t1;
+                if (tl >= 0) {
+                    const uint32_t slot = (it * 64 + (uint32_t)tl) * TILE_F + (uint32_t)(lane & 31);
+                    const float *tp = av.tri + (size_t)slot * 9;
+                    const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
+                                 c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
+                    double cq[3];
+                    closest_pt_tri(q, a, b, c, cq);
+                    const double ex = q[0] - cq[0], ey = q[1] - cq[1], ez = q[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
+                    const int id = av.oid[slot];
+                    if (d2 < best || (d2 == best && id < bid)) { best = d2; bid = id; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2]; }
+                }
+            }
+        }
+        const double wbest = wave_min_f64(best);
+        const int wid = wave_min_i32(best == wbest ? bid : 0x7fffffff);
+        const unsigned long long win = __ballot(best == wbest && bid == wid);
+        const int wl = __builtin_ctzll(win);
+        const double w0 = __shfl(bc[0], wl), w1 = __shfl(bc[1], wl), w2 = __shfl(bc[2], wl);
+        if (lane == (int)j) { rbest = wbest; rbf = wid; rbc[0] = w0; rbc[1] = w1; rbc[2] = w2; }
+    }
+    if (!live) return;
+    finish_sample(i, p, rbc, rbest, rbf, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
 }
 
 }  // namespace
@@ -212,4 +478,43 @@ AC_API int ac_warp_samples(const float *pts, const float *verts, const int32_t *
     hipLaunchKernelGGL(warp_samples_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts, verts, faces, T, P, F, threshold,
                        can_pts, can_pts_f32, closest, dist2, face_id, mask);
     return ac::check_launch("warp_samples");
+}
+
+AC_API size_t ac_warp_accel_bytes(uint32_t F)
+{
+    if (F == 0 || F > MAX_ACCEL_FACES) return 0;
+    size_t o[5];
+    return accel_offsets(o);
+}
+
+AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_t V, uint32_t F, void *accel, size_t accel_bytes,
+                               ac_stream_t stream)
+{
+    (void)V;
+    const size_t need = ac_warp_accel_bytes(F);
+    if (need == 0) { ac::set_error("warp_accel_build: %u faces not supported (1..%u); use ac_warp_samples", F, MAX_ACCEL_FACES); return AC_ERR_BAD_ARG; }
+    if (!verts || !faces || !accel || accel_bytes < need) { ac::set_error("warp_accel_build: NULL buffer or accel buffer smaller than %zu bytes", need); return AC_ERR_BAD_ARG; }
+    const AccelView av = accel_view(accel);
+    static bool attr_set = false;
+    const size_t lds = (size_t)MAX_ACCEL_FACES * 8;
+    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(accel_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(accel_sort_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, verts, faces, F, av.sorted);
+    hipLaunchKernelGGL(accel_tiles_kernel, dim3(MAX_TILES / 8), dim3(256), 0, (hipStream_t)stream, verts, faces, F, av);
+    return ac::check_launch("warp_accel_build");
+}
+
+AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V,
+                                 uint32_t F, double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest,
+                                 double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream)
+{
+    (void)V;
+    if (P == 0) return AC_OK;
+    if (!pts || !verts || !faces || !T || !mask || !accel || F == 0 || F > MAX_ACCEL_FACES || (!can_pts && !can_pts_f32)) {
+        ac::set_error("warp_samples_accel: NULL buffer, empty mesh or more than %u faces", MAX_ACCEL_FACES); return AC_ERR_BAD_ARG;
+    }
+    const AccelView av = accel_view(const_cast<void *>(accel));
+    const uint32_t waves = (P + 63) / 64;
+    hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av,
+                       can_pts, can_pts_f32, closest, dist2, face_id, mask);
+    return ac::check_launch("warp_samples_accel");
 }

@@ -137,7 +137,7 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
 class WarpMesh:
     """the posed SMPL mesh of one frame + its per-vertex rest->scene transforms, on the device (ac_warp_mesh)"""
 
-    def __init__(self, verts, faces, Ts, device, threshold=0.05, geo_threshold=0.05, use_mesh_guide=True):
+    def __init__(self, verts, faces, Ts, device, threshold=0.05, geo_threshold=0.05, use_mesh_guide=True, accel=True):
         import numpy as np
 
         def dev(a, dtype):
@@ -149,8 +149,15 @@ class WarpMesh:
         self.T = dev(Ts, torch.float64).reshape(-1, 4, 4)
         if int(self.faces.max()) >= self.T.shape[0] or self.T.shape[0] < self.verts.shape[0]:
             raise RuntimeError("WarpMesh: Ts must hold one 4x4 per vertex")
+        # exact-culling acceleration structure for the closest-face search (rebuilt per frame: the posed mesh changes)
+        self.accel = None
+        nbytes = int(L.lib().ac_warp_accel_bytes(self.faces.shape[0])) if accel else 0
+        if nbytes:
+            self.accel = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            L.check(L.lib().ac_warp_accel_build(self.verts.data_ptr(), self.faces.data_ptr(), self.verts.shape[0], self.faces.shape[0],
+                                                self.accel.data_ptr(), nbytes, L.current_stream(torch.device(device))), "warp_accel_build")
         self.c = L.ac_warp_mesh(self.verts.data_ptr(), self.faces.data_ptr(), self.T.data_ptr(), self.verts.shape[0], self.faces.shape[0],
-                                float(threshold), float(geo_threshold), int(bool(use_mesh_guide)))
+                                float(threshold), float(geo_threshold), int(bool(use_mesh_guide)), L.ptr(self.accel))
 
 
 def field_sdf(field, x, bound):

@@ -24,7 +24,7 @@ def to_homogeneous(pts):
     return np.concatenate([pts, np.ones_like(pts[..., 0:1])], axis=-1)
 
 
-def warp_samples_to_canonical(pts, verts, faces, T, threshold=0.2, device=None, return_torch=None):
+def warp_samples_to_canonical(pts, verts, faces, T, threshold=0.2, device=None, return_torch=None, accel=True):
     """pts [num_rays, num_samples, 3]; verts [V,3]; faces [F,>=3] (first three columns); T [V',4,4] (fp64).
     Returns (can_pts [R,S,3] fp64, can_dirs [R,S,3], closest [R,S,3], mask [R*S] bool) -- numpy if pts is numpy."""
     assert len(pts.shape) == 3, 'pts should have shape [num_rays, num_samples, 3]'
@@ -40,9 +40,17 @@ def warp_samples_to_canonical(pts, verts, faces, T, threshold=0.2, device=None, 
     can = torch.empty((P, 3), dtype=torch.float64, device=device)
     clo = torch.empty((P, 3), dtype=torch.float64, device=device)
     mask = torch.empty(P, dtype=torch.uint8, device=device)
-    L.check(L.lib().ac_warp_samples(p.data_ptr(), v.data_ptr(), f.data_ptr(), Tm.data_ptr(), P, v.shape[0], f.shape[0], float(threshold),
-                                    can.data_ptr(), None, clo.data_ptr(), None, None, mask.data_ptr(), L.current_stream(device)),
-            "warp_samples_to_canonical")
+    st = L.current_stream(device)
+    nbytes = int(L.lib().ac_warp_accel_bytes(f.shape[0])) if accel else 0
+    if nbytes:                                    # exact culling (same results bit for bit); brute force for meshes it does not cover
+        acc = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        L.check(L.lib().ac_warp_accel_build(v.data_ptr(), f.data_ptr(), v.shape[0], f.shape[0], acc.data_ptr(), nbytes, st), "warp_accel_build")
+        L.check(L.lib().ac_warp_samples_accel(p.data_ptr(), v.data_ptr(), f.data_ptr(), Tm.data_ptr(), P, v.shape[0], f.shape[0], float(threshold),
+                                              acc.data_ptr(), can.data_ptr(), None, clo.data_ptr(), None, None, mask.data_ptr(), st),
+                "warp_samples_to_canonical")
+    else:
+        L.check(L.lib().ac_warp_samples(p.data_ptr(), v.data_ptr(), f.data_ptr(), Tm.data_ptr(), P, v.shape[0], f.shape[0], float(threshold),
+                                        can.data_ptr(), None, clo.data_ptr(), None, None, mask.data_ptr(), st), "warp_samples_to_canonical")
     can = can.reshape(R, S, 3)
     closest = clo.reshape(R, S, 3)
     dirs = can[:, 1:] - can[:, :-1]

@@ -192,6 +192,17 @@ int ac_warp_samples(const float *pts, const float *verts, const int32_t *faces, 
                     double threshold, double *can_pts, float *can_pts_f32, double *closest, double *dist2, int32_t *face_id,
                     uint8_t *mask, ac_stream_t stream);
 
+/* Accelerated form of ac_warp_samples: identical outputs bit for bit (same fp64 point-triangle arithmetic, ties -> lowest face id).
+ * ac_warp_accel_build (once per frame / mesh) sorts the faces along a space-filling curve and cuts them into tiles of 32 with
+ * bounding boxes; ac_warp_samples_accel then tests only the tiles whose box can contain the closest face (exact culling).
+ * F <= 16384 (SMPL: 13776); ac_warp_accel_bytes returns 0 for meshes outside that range. */
+size_t ac_warp_accel_bytes(uint32_t F);
+int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_t V, uint32_t F, void *accel, size_t accel_bytes,
+                        ac_stream_t stream);
+int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V, uint32_t F,
+                          double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest, double *dist2,
+                          int32_t *face_id, uint8_t *mask, ac_stream_t stream);
+
 /* ---- hash-grid encoder on the 7-point finite-difference stencil (training path)
  * One SDF query of the render core is 7 HashEncoder calls in the reference: forward_sdf at x (models/instant_nsr.py:627-642) and at
  * clamp(x +- eps e_k) (finite_difference_normals_approximator, :687-704), each through encoder/hashencoder/hashgrid.py:11-73.
@@ -217,6 +228,7 @@ typedef struct ac_warp_mesh {
     double threshold;          /* mask: squared distance < threshold   (DEFAULT_GEO_THRESH = 0.05) */
     float geo_threshold;       /* radius of the vertex spheres of the near/far guide (DEFAULT_GEO_THRESH) */
     int32_t use_mesh_guide;
+    const void *accel;         /* ac_warp_accel_build output for (verts, faces), or NULL = brute-force search */
 } ac_warp_mesh;
 
 /* bytes of device scratch ac_render_rays_warped needs for n_rays rays of T = num_steps + upsample_steps samples; if offs is not

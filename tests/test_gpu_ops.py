@@ -282,3 +282,44 @@ def test_hash_stencil_forward_backward(oracle):
     (s0.sum() + (g0 ** 2).sum()).backward()
     gb = net.encoder.embeddings.grad
     assert (ga - gb).abs().max() <= 2e-3 * gb.abs().max()
+
+
+@pytest.mark.parametrize("nlat,nlon", [(40, 80), (83, 83), (3, 5)])
+def test_warp_accel_equals_brute_force(oracle, nlat, nlon):
+    """the culled closest-face search returns exactly what the exhaustive one returns (all outputs bit for bit), also with
+    shuffled face order, on points near, inside and far from the body"""
+    from avatarcraft_amd import _lib as Lb
+    from tests.common import make_body
+    verts, faces, Ts = make_body(n_lat=nlat, n_lon=nlon)
+    rs = np.random.RandomState(7)
+    faces = faces[rs.permutation(faces.shape[0])]                    # the order along the Morton curve must not matter
+    P = 5000
+    pts = np.concatenate([rs.uniform(-1.6, 1.6, size=(P // 2, 3)),
+                          verts[rs.randint(0, verts.shape[0], P - P // 2)] + rs.normal(0, 0.03, size=(P - P // 2, 3))]).astype(np.float32)
+    pts[:7] = verts[:7]                                              # exactly on vertices: many equally close faces
+    pts[7] = 0.0                                                     # the centre: medial axis
+    tp, tv, tf, tT = T(pts), T(verts), torch.from_numpy(faces).to(DEV), torch.from_numpy(Ts).to(DEV)
+    F, V = faces.shape[0], verts.shape[0]
+    st = None
+    def outs():
+        return dict(can=torch.empty(P, 3, dtype=torch.float64, device=DEV), canf=torch.empty(P, 3, device=DEV),
+                    clo=torch.empty(P, 3, dtype=torch.float64, device=DEV), d2=torch.empty(P, dtype=torch.float64, device=DEV),
+                    fid=torch.empty(P, dtype=torch.int32, device=DEV), mask=torch.empty(P, dtype=torch.uint8, device=DEV))
+    a, b = outs(), outs()
+    Lb.check(Lb.lib().ac_warp_samples(tp.data_ptr(), tv.data_ptr(), tf.data_ptr(), tT.data_ptr(), P, V, F, 0.05, a["can"].data_ptr(), a["canf"].data_ptr(),
+                                      a["clo"].data_ptr(), a["d2"].data_ptr(), a["fid"].data_ptr(), a["mask"].data_ptr(), st))
+    nbytes = Lb.lib().ac_warp_accel_bytes(F)
+    assert nbytes > 0 and Lb.lib().ac_warp_accel_bytes(16385) == 0 and Lb.lib().ac_warp_accel_bytes(0) == 0
+    acc = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    Lb.check(Lb.lib().ac_warp_accel_build(tv.data_ptr(), tf.data_ptr(), V, F, acc.data_ptr(), nbytes, st))
+    Lb.check(Lb.lib().ac_warp_samples_accel(tp.data_ptr(), tv.data_ptr(), tf.data_ptr(), tT.data_ptr(), P, V, F, 0.05, acc.data_ptr(), b["can"].data_ptr(),
+                                            b["canf"].data_ptr(), b["clo"].data_ptr(), b["d2"].data_ptr(), b["fid"].data_ptr(), b["mask"].data_ptr(), st))
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # and the oracle agrees with both
+    can_o, clo_o, d2_o, fid_o, m_o = oracle.warp_samples(pts[:600], verts, faces, Ts, 0.05)
+    assert np.array_equal(b["fid"][:600].cpu().numpy(), fid_o) and np.array_equal(b["d2"][:600].cpu().numpy().view(np.uint64), d2_o.view(np.uint64))
+    assert np.array_equal(b["can"][:600].cpu().numpy().view(np.uint64), can_o.view(np.uint64))
+    # too small a buffer / too many faces are refused
+    assert Lb.lib().ac_warp_accel_build(tv.data_ptr(), tf.data_ptr(), V, F, acc.data_ptr(), 100, st) != 0

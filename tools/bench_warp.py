@@ -21,6 +21,8 @@ print("near/far %d rays x %d verts: %.3f ms" % (ro.shape[0], verts.shape[0], tim
 for S in (32, 64):
     z = torch.linspace(0.8, 2.8, S, device=dev)
     pts = (tro[:, None, :] + trd[:, None, :] * z[None, :, None]).contiguous()
-    t = timeit(lambda: RY.warp_samples_to_canonical(pts, tv, tf, tT, 0.05))
     P = pts.shape[0] * S
-    print("warp %d pts x %d faces: %.2f ms  (%.1f G point-face tests/s)" % (P, faces.shape[0], t, P * faces.shape[0] / t / 1e6))
+    t = timeit(lambda: RY.warp_samples_to_canonical(pts, tv, tf, tT, 0.05, accel=False))
+    print("warp brute force %d pts x %d faces: %.2f ms  (%.1f G point-face tests/s)" % (P, faces.shape[0], t, P * faces.shape[0] / t / 1e6))
+    t = timeit(lambda: RY.warp_samples_to_canonical(pts, tv, tf, tT, 0.05, accel=True))
+    print("warp culled (incl. per-call build) %d pts: %.2f ms  (%.1f M samples/s)" % (P, t, P / t / 1e3))
