@@ -105,7 +105,38 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     return {"ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad + 1 frozen",
             "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)", "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if world > 1 else 0,
-            "core": "fused HIP sampling + autograd render core over the HIP hash encoder (fused backward kernel: next round)"}
+            "core": "fused HIP sampling + autograd render core: 7-point stencil hash operator (register + in-wave gradient combining), torch fp32 MLP"}
+
+
+def time_posed_frame(dev, p, table, frames):
+    """secondary metric: ms per 256x256 frame of render_warp.py (BASELINE config 4): posed-space rendering, 32+32 samples per ray,
+    8192-ray batches like the reference driver, SMPL-sized synthetic body (6 891 vertices / 13 778 faces, per-vertex 4x4), mesh uploaded
+    and its culling structure rebuilt once per frame.  The reference does the two warps of every batch on the CPU (libigl)."""
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    from avatarcraft_amd.render_utils import render_instantnsr_naive
+    from tests.common import make_rays, make_body
+    torch.manual_seed(0)
+    net = NeRFNetwork()
+    sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
+    sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    verts, faces, Ts = make_body(n_lat=83, n_lon=83)
+    ro, rd = make_rays(256, 256, dist=1.8, f=443.405 / 2, yaw=0.3, pitch=-0.1)
+    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+
+    def frame():
+        rgb, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=8192, requires_grad=False, render_can=False, perturb=False, verts=verts, faces=faces,
+                                         Ts=Ts, num_steps=32, upsample_steps=32, bound=1.6)
+        return rgb
+    frame(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        rgb = frame()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    return {"ms_per_frame": dt * 1e3, "rays_per_s": 65536 / dt, "frames": frames, "samples_per_ray": "32+32", "mesh": "synthetic 6891 verts / 13778 faces",
+            "covered": float((rgb < 0.999).any(dim=1).float().mean())}
 
 
 def main():
@@ -115,6 +146,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sds-steps", type=int, default=3, help="also time this many 4096-ray SDS steps (secondary metric); 0 = skip")
+    ap.add_argument("--posed-frames", type=int, default=2, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,6 +224,8 @@ def main():
         }
         if sds is not None:
             res["sds_step"] = sds
+        if world == 1 and a.posed_frames > 0:
+            res["posed_frame"] = time_posed_frame(dev, p, table, a.posed_frames)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, table, ro, rd)
         print(json.dumps(res))
