@@ -244,10 +244,8 @@ if __name__ == "__main__":
 
 
 # ---------------------------------------------------------------- ray generation goldens
-def make_ray_goldens():
-    """Rays from the reference's own camera code: default_360_path -> pose2cap -> shot_rays
-    (utils/render_utils.py:137-154,323-337,363-376; utils/ray_utils.py:25-37), and
-    SMPLDataset.gen_rays_pose's formula is exercised in a separate golden."""
+def _prepare_render_utils():
+    """stubs the third-party modules utils/render_utils.py imports at module level (none is used by the functions called here)"""
     import numpy
     for name in ("pytorch3d", "pytorch3d.structures", "pytorch3d.renderer", "open3d", "cv2", "torchvision", "torchvision.transforms",
                  "imageio", "lpips", "prompt_toolkit"):
@@ -271,6 +269,13 @@ def make_ray_goldens():
                 k.pop("copy"); return numpy.asarray(*a, **k)
             return numpy.array(*a, **k)
     T.numpy = _NP()
+
+
+def make_ray_goldens():
+    """Rays from the reference's own camera code: default_360_path -> pose2cap -> shot_rays
+    (utils/render_utils.py:137-154,323-337,363-376; utils/ray_utils.py:25-37), and
+    SMPLDataset.gen_rays_pose's formula is exercised in a separate golden."""
+    _prepare_render_utils()
     try:
         import utils.render_utils as RU
     except Exception as e:   # pragma: no cover
@@ -389,3 +394,40 @@ def make_warp_render_golden():
 if __name__ == "__main__":
     make_smpl_goldens()
     make_warp_render_golden()
+
+
+# ---------------------------------------------------------------- config-1 plumbing goldens
+def make_vanilla_golden():
+    """get_freq_embedder(10 / 4) -> NeRF(8x256, use_viewdirs) -> ray_to_samples(16) -> raw2outputs on the 64x64 pose-0 rays of kat/rays
+    (o = (0,0,1.44), f = 50), near 1, far 4, torch.manual_seed(0) default init, CPU."""
+    import torch
+    import models.nerf as RN
+    import utils.ray_utils as RY
+    _prepare_render_utils()
+    import utils.render_utils as RU
+    from encoder.freq_encoder import get_freq_embedder
+    pe, pdim = get_freq_embedder(10)
+    de, ddim = get_freq_embedder(4)
+    torch.manual_seed(0)
+    net = RN.NeRF(depth=8, width=256, input_ch=pdim, input_ch_views=ddim, use_viewdirs=True)
+    g = np.load(os.path.join(HERE, "rays.npz"))
+    ro, rd = torch.from_numpy(g["kat64_o"]), torch.from_numpy(g["kat64_d"])
+    R = ro.shape[0]
+    batch = dict(origin=ro, direction=rd, near=torch.full((R, 1), 1.0), far=torch.full((R, 1), 4.0))
+    with torch.no_grad():
+        pts, dirs, z = RY.ray_to_samples(batch, 16)
+        raw = net(pe(pts.reshape(-1, 3)), de(dirs.reshape(-1, 3))).reshape(R, 16, 4)
+        rgb, disp, acc, w, depth = RU.raw2outputs(raw, z, dirs[:, 0, :], white_bkg=True)
+        torch.manual_seed(3)
+        _, _, zp = RY.ray_to_samples(batch, 16, perturb=1.0)
+        net2 = RN.NeRF(depth=4, width=32, input_ch=pdim, output_ch=4, skips=[1], scale=0.5, scale_type='tanh')
+        raw2 = net2(pe(pts.reshape(-1, 3)[:64]))
+    sd2 = {k: v.numpy() for k, v in net2.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "vanilla.npz"), rgb=rgb.numpy(), disp=disp.numpy(), acc=acc.numpy(), weights=w.numpy(), depth=depth.numpy(),
+                        z=z.numpy(), z_perturbed=zp.numpy(), raw_sub=raw[::64].numpy(), raw2=raw2.numpy(), n_params=np.int64(sum(p.numel() for p in net.parameters())),
+                        **{"net2." + k: v for k, v in sd2.items()})
+    print("vanilla: rgb mean", float(rgb.mean()), "acc mean", float(acc.mean()), "params", sum(p.numel() for p in net.parameters()))
+
+
+if __name__ == "__main__":
+    make_vanilla_golden()

@@ -156,3 +156,40 @@ def test_calc_local_trans_properties():
     assert n2 == 4 and np.isfinite(Ts2[3]).all() and np.abs(wv2[0] - wv2[3]).max() > 1e-4
     with pytest.raises(NotImplementedError):
         SM.calc_local_trans(bm, render_type="other")
+
+
+# ------------------------------------------------------------------ config-1 plumbing (row a19)
+def test_vanilla_nerf_plumbing_matches_reference():
+    """BASELINE config 1: 64x64 rays, 16 samples, PE(10)/PE(4), NeRF 8x256 with view directions, white background -- against the
+    reference's own models/nerf.py + ray_to_samples + raw2outputs (tests/golden/vanilla.npz), CPU like the reference"""
+    import torch
+    from avatarcraft_amd import nerf as NF
+    from avatarcraft_amd.encoder import get_encoder
+    g, r = load_golden("vanilla.npz"), load_golden("rays.npz")
+    pe, pdim = get_encoder("frequency", dict(in_dim=3, freq_multires=10))
+    de, ddim = get_encoder("frequency", dict(in_dim=3, freq_multires=4))
+    assert (pdim, ddim) == (63, 27)
+    torch.manual_seed(0)
+    net = NF.NeRF(depth=8, width=256, input_ch=pdim, input_ch_views=ddim, use_viewdirs=True)        # same RNG stream as the reference's ctor
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    ro, rd = torch.from_numpy(r["kat64_o"]), torch.from_numpy(r["kat64_d"])
+    with torch.no_grad():
+        rgb, disp, acc, w, depth = NF.render_rays_vanilla(net, pe, de, ro, rd, 1.0, 4.0, 16)
+    assert rgb.shape == (4096, 3) and w.shape == (4096, 16)
+    for name, val in (("rgb", rgb), ("disp", disp), ("acc", acc), ("weights", w), ("depth", depth)):
+        v, ref = val.numpy(), g[name]
+        assert np.array_equal(np.isnan(v), np.isnan(ref)), name            # disp = 1/max(1e-10, depth/acc) is NaN where acc == 0 (0/0), as in the reference
+        ok = ~np.isnan(ref)
+        assert np.abs(v[ok] - ref[ok]).max() <= 2e-6 * max(1.0, np.abs(ref[ok]).max()), name
+    batch = dict(origin=ro, direction=rd, near=torch.full((4096, 1), 1.0), far=torch.full((4096, 1), 4.0))
+    pts, dirs, z = NF.ray_to_samples(batch, 16)
+    assert np.array_equal(z.numpy(), g["z"]) and pts.shape == (4096, 16, 3) and dirs.shape == (4096, 16, 3)
+    torch.manual_seed(3)
+    _, _, zp = NF.ray_to_samples(batch, 16, perturb=1.0)
+    assert np.array_equal(zp.numpy(), g["z_perturbed"])                                                # same draw order and clipping
+    # the no-viewdirs / skip / tanh-scale variant with the reference's weights loaded by name
+    net2 = NF.NeRF(depth=4, width=32, input_ch=pdim, output_ch=4, skips=[1], scale=0.5, scale_type='tanh')
+    net2.load_state_dict({k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("net2.")}, strict=True)
+    with torch.no_grad():
+        raw2 = net2(pe(pts.reshape(-1, 3)[:64]))
+    assert np.abs(raw2.numpy() - g["raw2"]).max() <= 1e-6
