@@ -199,7 +199,10 @@ def main():
 
     sds = None
     if a.sds_steps > 0:
-        sds = time_sds_step(dev, p, table, rank, world, dist, a.sds_steps)
+        try:                                   # secondary metric: never let it take the headline line down with it
+            sds = time_sds_step(dev, p, table, rank, world, dist, a.sds_steps)
+        except Exception as e:                 # noqa: BLE001
+            sds = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         total_rays = world * a.steps * RAYS_PER_BATCH
@@ -225,7 +228,10 @@ def main():
         if sds is not None:
             res["sds_step"] = sds
         if world == 1 and a.posed_frames > 0:
-            res["posed_frame"] = time_posed_frame(dev, p, table, a.posed_frames)
+            try:
+                res["posed_frame"] = time_posed_frame(dev, p, table, a.posed_frames)
+            except Exception as e:             # noqa: BLE001
+                res["posed_frame"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, table, ro, rd)
         print(json.dumps(res))
