@@ -78,53 +78,23 @@ __device__ __forceinline__ float dv_log1p(float x)
     return fma_(s, hfsq + R, fma_(dk, ln2_lo, c)) - hfsq + f + dk * ln2_hi;
 }
 
-// exp(-a), a >= 0, result in (0,1]; 0 above a = 82 (same algorithm as dv_exp, single power-of-two scale)
-__device__ __forceinline__ float dv_exp_neg(float a)
-{
-    const float magic = 12582912.0f;
-    float t = fma_(a, -1.44269504f, magic);
-    float n = t - magic;
-    float r = fma_(n, -0.693359375f, -a);
-    r = fma_(n, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = fma_(p, r, 1.3981999507e-3f);
-    p = fma_(p, r, 8.3334519073e-3f);
-    p = fma_(p, r, 4.1665795894e-2f);
-    p = fma_(p, r, 1.6666665459e-1f);
-    p = fma_(p, r, 5.0000001201e-1f);
-    float r2 = r * r;
-    float e = fma_(p, r2, r) + 1.0f;
-    float u = e * bits2f((uint32_t)((int)n + 127) << 23);
-    return (a <= 82.0f) ? u : ((a != a) ? a : 0.0f);
-}
-
-// a / 100 with three fp32 ops; equal to the correctly rounded IEEE quotient for every a in {0} U [2^-120, 2^10)
-// (exhaustive proof: tools/verify_div100.c).  Every softplus argument lies in that set.
-__device__ __forceinline__ float dv_div100(float a)
-{
-    const float y = 0x1.47ae14p-7f;                 // RN(1/100)
-    float q0 = a * y;
-    float r = fma_(-q0, 100.0f, a);
-    return fma_(r, y, q0);
-}
-
-// torch.nn.Softplus(beta=100, threshold=20) (reference models/instant_nsr.py:231,591) in the overflow-free form
-//   log1p(exp(t)) = max(t,0) + u*Q(u), u = exp(-|t|); Q = 8 x degree-5 polynomial table (ac_sp_table.hpp).
-// spq: the table, [8][8] floats (LDS or global).  Bit-identical to oracle/ac_math.h: orc_softplus100.
-__device__ __forceinline__ float dv_softplus100(const float *__restrict__ spq, float x)
+// torch.nn.Softplus(beta=100, threshold=20) (reference models/instant_nsr.py:231,591):
+//   softplus_100(x) = max(x, 0) + G(|100 x|),  G(a) = log1p(exp(-a)) / 100 from a 64-piece degree-5 table on [0, 32]
+//   (ac_sp_table.hpp; tools/gen_softplus_table.py) -- no exponential, no division.
+// spg: the table, [64][8] floats (LDS or global).  Bit-identical to oracle/ac_math.h: orc_softplus100.
+__device__ __forceinline__ float dv_softplus100(const float *__restrict__ spg, float x)
 {
     const float t = x * 100.0f;
-    const float u = dv_exp_neg(__builtin_fabsf(t));
-    int idx = (int)(u * 8.0f);
-    idx = idx > 7 ? 7 : idx;
-    const float v = u - ((float)idx + 0.5f) * 0.125f;
-    const float4 c03 = *reinterpret_cast<const float4 *>(spq + idx * 8);
-    const float2 c45 = *reinterpret_cast<const float2 *>(spq + idx * 8 + 4);
+    const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
+    int idx = (int)(am * 2.0f);
+    idx = idx > 63 ? 63 : idx;
+    const float v = fma_(-0.5f, (float)idx, am);
+    const float4 c03 = *reinterpret_cast<const float4 *>(spg + idx * 8);
+    const float2 c45 = *reinterpret_cast<const float2 *>(spg + idx * 8 + 4);
     float q = c45.y;
     q = fma_(q, v, c45.x); q = fma_(q, v, c03.w); q = fma_(q, v, c03.z); q = fma_(q, v, c03.y); q = fma_(q, v, c03.x);
-    const float s = (t > 0.0f ? t : 0.0f) + u * q;
-    const float res = dv_div100(s);
-    return (t > 20.0f) ? x : ((t != t) ? t : res);
+    const float r = (x > 0.0f ? x : 0.0f) + q;
+    return (t != t) ? t : r;
 }
 
 // the same softplus on two independent values with packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are
@@ -133,49 +103,28 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat2(float a) { v2f r = { a, a }; return r; }
 
-__device__ __forceinline__ v2f dv_softplus100_x2(const float *__restrict__ spq, v2f x)
+__device__ __forceinline__ v2f dv_softplus100_x2(const float *__restrict__ spg, v2f x)
 {
     const v2f t = x * splat2(100.0f);
-    v2f a; a.x = __builtin_fabsf(t.x); a.y = __builtin_fabsf(t.y);
-    const v2f magic = splat2(12582912.0f);
-    const v2f tt = pk_fma(a, splat2(-1.44269504f), magic);
-    const v2f n = tt - magic;
-    v2f r = pk_fma(n, splat2(-0.693359375f), -a);
-    r = pk_fma(n, splat2(2.12194440e-4f), r);
-    v2f p = splat2(1.9875691500e-4f);
-    p = pk_fma(p, r, splat2(1.3981999507e-3f));
-    p = pk_fma(p, r, splat2(8.3334519073e-3f));
-    p = pk_fma(p, r, splat2(4.1665795894e-2f));
-    p = pk_fma(p, r, splat2(1.6666665459e-1f));
-    p = pk_fma(p, r, splat2(5.0000001201e-1f));
-    const v2f r2 = r * r;
-    const v2f e = pk_fma(p, r2, r) + splat2(1.0f);
-    v2f sc; sc.x = bits2f((uint32_t)((int)n.x + 127) << 23); sc.y = bits2f((uint32_t)((int)n.y + 127) << 23);
-    v2f u = e * sc;
-    u.x = (a.x <= 82.0f) ? u.x : ((a.x != a.x) ? a.x : 0.0f);
-    u.y = (a.y <= 82.0f) ? u.y : ((a.y != a.y) ? a.y : 0.0f);
-    const v2f u8 = u * splat2(8.0f);
-    int i0 = (int)u8.x, i1 = (int)u8.y;
-    i0 = i0 > 7 ? 7 : i0; i1 = i1 > 7 ? 7 : i1;
-    v2f ctr; ctr.x = ((float)i0 + 0.5f) * 0.125f; ctr.y = ((float)i1 + 0.5f) * 0.125f;
-    const v2f v = u - ctr;
-    const float4 a03 = *reinterpret_cast<const float4 *>(spq + i0 * 8), b03 = *reinterpret_cast<const float4 *>(spq + i1 * 8);
-    const float2 a45 = *reinterpret_cast<const float2 *>(spq + i0 * 8 + 4), b45 = *reinterpret_cast<const float2 *>(spq + i1 * 8 + 4);
+    v2f am; am.x = __builtin_fminf(__builtin_fabsf(t.x), 32.0f); am.y = __builtin_fminf(__builtin_fabsf(t.y), 32.0f);
+    const v2f a2 = am * splat2(2.0f);
+    int i0 = (int)a2.x, i1 = (int)a2.y;
+    i0 = i0 > 63 ? 63 : i0; i1 = i1 > 63 ? 63 : i1;
+    v2f fi; fi.x = (float)i0; fi.y = (float)i1;
+    const v2f v = pk_fma(splat2(-0.5f), fi, am);
+    const float4 a03 = *reinterpret_cast<const float4 *>(spg + i0 * 8), b03 = *reinterpret_cast<const float4 *>(spg + i1 * 8);
+    const float2 a45 = *reinterpret_cast<const float2 *>(spg + i0 * 8 + 4), b45 = *reinterpret_cast<const float2 *>(spg + i1 * 8 + 4);
     v2f q = { a45.y, b45.y };
     { v2f c = { a45.x, b45.x }; q = pk_fma(q, v, c); }
     { v2f c = { a03.w, b03.w }; q = pk_fma(q, v, c); }
     { v2f c = { a03.z, b03.z }; q = pk_fma(q, v, c); }
     { v2f c = { a03.y, b03.y }; q = pk_fma(q, v, c); }
     { v2f c = { a03.x, b03.x }; q = pk_fma(q, v, c); }
-    v2f tp; tp.x = t.x > 0.0f ? t.x : 0.0f; tp.y = t.y > 0.0f ? t.y : 0.0f;
-    const v2f sgm = tp + u * q;
-    const v2f y = splat2(0x1.47ae14p-7f);
-    const v2f q0 = sgm * y;
-    const v2f rr = pk_fma(-q0, splat2(100.0f), sgm);
-    const v2f res = pk_fma(rr, y, q0);
+    v2f m; m.x = x.x > 0.0f ? x.x : 0.0f; m.y = x.y > 0.0f ? x.y : 0.0f;
+    const v2f r = m + q;
     v2f o;
-    o.x = (t.x > 20.0f) ? x.x : ((t.x != t.x) ? t.x : res.x);
-    o.y = (t.y > 20.0f) ? x.y : ((t.y != t.y) ? t.y : res.y);
+    o.x = (t.x != t.x) ? t.x : r.x;
+    o.y = (t.y != t.y) ? t.y : r.y;
     return o;
 }
 

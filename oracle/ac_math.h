@@ -87,46 +87,24 @@ static inline float orc_log1pf(float x)
     return fmaf(s, hfsq + R, fmaf(dk, ln2_lo, c)) - hfsq + f + dk * ln2_hi;
 }
 
-/* exp(-a) for a >= 0 (result in (0,1]); flushes to 0 above a = 82 (exp(-82) = 2.4e-36) */
-static inline float orc_exp_neg(float a)
-{
-    if (!(a <= 82.0f)) return (a != a) ? a : 0.0f;
-    float t = fmaf(a, -1.44269504f, 12582912.0f);
-    float n = t - 12582912.0f;                          /* n = rint(-a/ln2) <= 0 */
-    float r = fmaf(n, -0.693359375f, -a);
-    r = fmaf(n, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = fmaf(p, r, 1.3981999507e-3f);
-    p = fmaf(p, r, 8.3334519073e-3f);
-    p = fmaf(p, r, 4.1665795894e-2f);
-    p = fmaf(p, r, 1.6666665459e-1f);
-    p = fmaf(p, r, 5.0000001201e-1f);
-    float r2 = r * r;
-    float e = fmaf(p, r2, r) + 1.0f;
-    return e * orc_bits2f((uint32_t)((int)n + 127) << 23);
-}
-
-/* torch.nn.Softplus(beta=100, threshold=20): x if x*beta > 20 else log1p(exp(x*beta))/beta
- * (models/instant_nsr.py:231,591), evaluated in the overflow-free form
- *     log1p(exp(t)) = max(t,0) + log1p(u),  u = exp(-|t|) in (0,1],  log1p(u) = u*Q(u)
- * with Q a table of degree-5 polynomials (ac_sp_table.h, tools/gen_softplus_table.py; <= 1.3e-7 relative).
- * The final /beta is a true division (the HIP kernel uses an fma sequence proven equal for every
- * reachable argument, tools/verify_div100.c). */
+/* torch.nn.Softplus(beta=100, threshold=20) (reference models/instant_nsr.py:231,591):
+ *     softplus_100(x) = log1p(exp(100 x)) / 100 = max(x, 0) + G(|100 x|),   G(a) = log1p(exp(-a)) / 100
+ * G comes from a 64-piece degree-5 table on [0, 32] (ac_sp_table.h, tools/gen_softplus_table.py; max abs error 4.8e-10, i.e. one
+ * fp32 ulp of G(0)): one multiply, one table lookup, five fma, one add -- no exponential and no division.  For 100 x > 20
+ * (torch's linear branch) G < 2.1e-11 is below half an ulp of x, so x is returned exactly, as by torch. */
 #include "ac_sp_table.h"
 static inline float orc_softplus100(float x)
 {
     float t = x * 100.0f;
-    if (t > 20.0f) return x;
     if (t != t) return t;
-    float u = orc_exp_neg(fabsf(t));
-    int idx = (int)(u * 8.0f);
-    if (idx > 7) idx = 7;
-    float v = u - ((float)idx + 0.5f) * 0.125f;
-    const float *c = AC_SP_Q[idx];
+    float am = fminf(fabsf(t), 32.0f);
+    int idx = (int)(am * 2.0f);
+    if (idx > 63) idx = 63;
+    float v = fmaf(-0.5f, (float)idx, am);
+    const float *c = AC_SP_G[idx];
     float q = c[5];
     q = fmaf(q, v, c[4]); q = fmaf(q, v, c[3]); q = fmaf(q, v, c[2]); q = fmaf(q, v, c[1]); q = fmaf(q, v, c[0]);
-    float s = (t > 0.0f ? t : 0.0f) + u * q;
-    return s / 100.0f;
+    return (x > 0.0f ? x : 0.0f) + q;
 }
 
 /* torch.sigmoid: 1 / (1 + exp(-x)) */
