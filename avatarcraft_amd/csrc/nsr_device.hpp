@@ -1,0 +1,598 @@
+// avatarcraft_amd/csrc/nsr_device.hpp -- device-side building blocks of the Instant-NSR field on gfx950, shared by the fused
+// renderer (render_fused.hip) and the fused training operators (sdf_train.hip): LDS layout, MFMA-ordered weight fragments,
+// hash-grid gathers (single point and 7-point finite-difference stencil), SDF / colour MLP tiles, DPP scans.
+// Everything lives in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+#include "ac_common.hpp"
+#include "ac_devmath.hpp"
+#include "ac_sp_table.hpp"
+
+using namespace acdev;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef AC_ABL_MFMA     // timing ablation: replace every MFMA by one VALU fma per accumulator register
+static __device__ __forceinline__ f32x4 abl_mfma(float a, float b, f32x4 c) { c[0] = __builtin_fmaf(a, b, c[0]); return c; }
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, C, X, Y, Z) abl_mfma(A, B, C)
+#endif
+#ifdef AC_ABL_GATHER   // timing ablation: every gather reads table entry 0 (perfectly cached, fully coalesced)
+#define AC_GOFF(X) ((X) & 0u)
+#else
+#define AC_GOFF(X) (X)
+#endif
+
+namespace {
+
+#ifndef AC_WPB
+#define AC_WPB 8
+#endif
+constexpr int WAVES_PER_BLOCK = AC_WPB;
+constexpr int BLOCK = WAVES_PER_BLOCK * 64;
+constexpr int MAXT = 128;
+#ifndef AC_ENC_ROUND
+#define AC_ENC_ROUND 2      // hash levels gathered per round per lane (registers vs loads in flight)
+#endif
+
+// ---- LDS layout (floats) -------------------------------------------------------------------------
+constexpr int OFF_W1F = 0;                       // [4 tiles][9 ksteps][64]
+constexpr int OFF_W2F = OFF_W1F + 4 * 9 * 64;    // [16 ksteps][64]
+constexpr int OFF_C1F = OFF_W2F + 16 * 64;       // [4][6][64]
+constexpr int OFF_C2F = OFF_C1F + 4 * 6 * 64;    // [4][16][64]
+constexpr int OFF_C3F = OFF_C2F + 4 * 16 * 64;   // [16][64]
+constexpr int OFF_B1 = OFF_C3F + 16 * 64;        // [64]
+constexpr int OFF_B2 = OFF_B1 + 64;              // [16]
+constexpr int OFF_LVL = OFF_B2 + 16;             // [16 levels][8 words]
+constexpr int OFF_LIN = OFF_LVL + 16 * 8;        // lin_z[64] + lin_u[16]
+constexpr int OFF_SPQ = OFF_LIN + 80;           // softplus G table [64][8]
+constexpr int OFF_WAVE = OFF_SPQ + 512;         // per-wave slabs start here
+constexpr int FE_SLAB = 6 * 8 * 64;                        // hash features of the 6 finite-difference points: [e-1][2j+c][lane]
+constexpr int WAVE_SLAB = 2 * MAXT * 2 + MAXT + 16 + 16 + FE_SLAB;   // zs[2][128], sd[2][128], cdf[128], znew[16], pad, fe
+constexpr int LDS_FLOATS = OFF_WAVE + WAVES_PER_BLOCK * WAVE_SLAB;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget: one workgroup per CU");
+static_assert(OFF_WAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
+
+// per-level launch constants: index = (hashed ? x ^ y*my ^ z*mz : x + y*my + z*mz) & mask [% wsize if wsize]
+// (my,mz) = (P1,P2) for hashed levels, (res+1, (res+1)^2) for dense ones; mask = size-1 for power-of-two hashed
+// levels, ~0 otherwise (a dense index is < size by construction); wsize = size only for a hashed level whose size
+// is not a power of two (never the case for tables allocated by HashEncoder, handled for completeness).
+#ifdef AC_PROFILE
+#define AC_T0() unsigned long long t_prof_ = __builtin_amdgcn_s_memtime()
+#define AC_TICK(SLOT) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); prof_acc[SLOT] += t2_ - t_prof_; t_prof_ = t2_; }
+#else
+#define AC_T0()
+#define AC_TICK(SLOT)
+#endif
+
+struct LevelRec { float scale; uint32_t my, mz, offset, mask, hashed, wsize, pad; };
+
+struct RenderArgs {
+    const float *table;
+    uint32_t table_bytes;
+    const float *W1, *b1, *W2, *b2, *Wc1, *Wc2, *Wc3;
+    const float *rays_o, *rays_d, *bg, *noise, *lin_z, *lin_u;
+    ac_render_out out;
+    LevelRec lvl[16];
+    int n_rays, T0, nup;
+    int jmode[4];          // per gather round j (levels 4j..4j+3): 0 all dense, 1 all hashed, 2 mixed
+    int jfine[4];          // per round: 1 if the FD offset eps can span >= 1 cell on any of its levels
+    float bound, two_bound, inv_s, car, one_m_car, eps;
+    int perturb;
+    unsigned long long *prof;   // AC_PROFILE builds only: [n_waves][8] cycle counters per phase
+    // posed-space rendering (render_can=False) only: see ac_render_rays_warped
+    const float *near_m, *far_m;   // [N] mesh-guided range (+-inf where the ray misses the body) or NULL
+    const float *ext_pts;          // MODE_UPSAMPLE: warped coarse points [N,T0,3]; MODE_FINAL: warped mid points [N,T,3]
+    const uint8_t *mask;           // MODE_FINAL: [N,T] alpha mask
+    float *zbuf;                   // [N,T] final z values: written by MODE_UPSAMPLE, read by MODE_FINAL
+    float *mid_pts;                // MODE_UPSAMPLE: posed-space mid points [N,T,3]
+};
+
+// render_rays_kernel<MODE>: MODE_FULL is the fused canonical-space renderer.  With the SMPL inverse warp between the phases
+// (a global closest-point search per sample: csrc/warp.hip) the same code is instantiated as its two halves:
+// MODE_UPSAMPLE = coarse sdf at externally warped points + the NeuS up-sampling, writes z and the posed-space mid points;
+// MODE_FINAL = render core at externally warped mid points, alpha multiplied by the mask.
+enum { MODE_FULL = 0, MODE_UPSAMPLE = 2, MODE_FINAL = 3 };
+
+// near_far_from_bound (cube)  instant_nsr.py:58-77
+__device__ __forceinline__ void cube_near_far(float ox, float oy, float oz, float dx, float dy, float dz, float bound, float &near, float &far)
+{
+    const float ex = dx + 1e-15f, ey = dy + 1e-15f, ez = dz + 1e-15f;
+    const float ax = (-bound - ox) / ex, bx = (bound - ox) / ex;
+    const float ay = (-bound - oy) / ey, by = (bound - oy) / ey;
+    const float az = (-bound - oz) / ez, bz = (bound - oz) / ez;
+    const float lx = ax < bx ? ax : bx, hx = ax > bx ? ax : bx;
+    const float ly = ay < by ? ay : by, hy = ay > by ? ay : by;
+    const float lz = az < bz ? az : bz, hz = az > bz ? az : bz;
+    near = lx; if (ly > near) near = ly; if (lz > near) near = lz;
+    far = hx; if (hy < far) far = hy; if (hz < far) far = hz;
+    if (near < 0.05f) near = 0.05f;
+}
+__device__ __forceinline__ bool is_inf(float v) { return __builtin_fabsf(v) == __builtin_inff(); }
+
+// ---- wave-level helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int OFF> __device__ __forceinline__ float dpp_shr(float ident, float v)
+{
+    // lanes n >= OFF of every 16-lane row receive v[n-OFF]; the others keep `ident`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v),
+                                                                  0x110 + OFF, 0xf, 0xf, false));
+}
+// Kogge-Stone inclusive scan inside every 16-lane row
+template <bool MUL> __device__ __forceinline__ float row_scan(float v)
+{
+    const float id = MUL ? 1.0f : 0.0f;
+    float s;
+    s = dpp_shr<1>(id, v); v = MUL ? s * v : s + v;
+    s = dpp_shr<2>(id, v); v = MUL ? s * v : s + v;
+    s = dpp_shr<4>(id, v); v = MUL ? s * v : s + v;
+    s = dpp_shr<8>(id, v); v = MUL ? s * v : s + v;
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float sel4(int g, float a, float b, float c, float d)
+{
+    return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
+}
+
+// ---- workgroup prologue: weights -> MFMA A-fragment order in LDS -------------------------------------
+__device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
+{
+    for (int e = threadIdx.x; e < 4 * 9 * 64; e += blockDim.x) {          // sdf_net.0 [64,35]
+        int l = e & 63, fs = e >> 6, t = fs / 9, s = fs % 9;
+        int u = 16 * t + (l & 15), g = l >> 4;
+        int col = (s == 0) ? (g < 3 ? g : -1) : 3 + 2 * (4 * ((s - 1) >> 1) + g) + ((s - 1) & 1);
+        lds[OFF_W1F + e] = col < 0 ? 0.0f : a.W1[u * 35 + col];
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {             // sdf_net.1 [16,64]
+        int l = e & 63, kk = e >> 6, t = kk >> 2, r = kk & 3;
+        lds[OFF_W2F + e] = a.W2[(l & 15) * 64 + 16 * t + 4 * (l >> 4) + r];
+    }
+    for (int e = threadIdx.x; e < 4 * 6 * 64; e += blockDim.x) {          // color_net.0 [64,21] = [x(3), n(3), feat(15)]
+        int l = e & 63, fs = e >> 6, t = fs / 6, s = fs % 6;
+        int u = 16 * t + (l & 15), g = l >> 4;
+        float v;
+        if (s < 4) { int o = 4 * g + s; v = (o == 0) ? 0.0f : a.Wc1[u * 21 + 6 + (o - 1)]; }
+        else if (s == 4) v = g < 3 ? a.Wc1[u * 21 + g] : 0.0f;
+        else v = g < 3 ? a.Wc1[u * 21 + 3 + g] : 0.0f;
+        lds[OFF_C1F + e] = v;
+    }
+    for (int e = threadIdx.x; e < 4 * 16 * 64; e += blockDim.x) {         // color_net.1 [64,64]
+        int l = e & 63, fs = e >> 6, to = fs >> 4, kk = fs & 15, t = kk >> 2, r = kk & 3;
+        lds[OFF_C2F + e] = a.Wc2[(16 * to + (l & 15)) * 64 + 16 * t + 4 * (l >> 4) + r];
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {             // color_net.2 [3,64]
+        int l = e & 63, kk = e >> 6, t = kk >> 2, r = kk & 3, o = l & 15;
+        lds[OFF_C3F + e] = o < 3 ? a.Wc3[o * 64 + 16 * t + 4 * (l >> 4) + r] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) lds[OFF_B1 + e] = a.b1[e];
+    for (int e = threadIdx.x; e < 16; e += blockDim.x) lds[OFF_B2 + e] = a.b2[e];
+    {   // level records: static kernarg indexing only (a dynamic index would copy the struct to scratch)
+        uint32_t *lw = reinterpret_cast<uint32_t *>(lds) + OFF_LVL;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            if (threadIdx.x == (unsigned)l) {
+                lw[8 * l + 0] = __float_as_uint(a.lvl[l].scale); lw[8 * l + 1] = a.lvl[l].my;
+                lw[8 * l + 2] = a.lvl[l].mz; lw[8 * l + 3] = a.lvl[l].offset;
+                lw[8 * l + 4] = a.lvl[l].mask; lw[8 * l + 5] = a.lvl[l].hashed;
+                lw[8 * l + 6] = a.lvl[l].wsize; lw[8 * l + 7] = 0u;
+            }
+        }
+    }
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) lds[OFF_LIN + e] = e < a.T0 ? a.lin_z[e] : 0.0f;
+    for (int e = threadIdx.x; e < 16; e += blockDim.x) lds[OFF_LIN + 64 + e] = a.lin_u ? a.lin_u[e] : 0.0f;
+    for (int e = threadIdx.x; e < 512; e += blockDim.x) lds[OFF_SPQ + e] = AC_SP_G[e >> 3][e & 7];
+}
+
+// ---- hash-grid features of this lane's 4 levels (HashEncoder.forward + kernel_grid) -------------------
+// p: world position (clamped to +-bound); returns f[j][c] for level 4j+g.  The gathers go through a
+// buffer descriptor (32-bit byte offsets, hardware bounds check) and are issued ROUND levels at a time.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int ROUND>
+__device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t table, int g, const int (&jmode)[4],
+                                        float px, float py, float pz, float bound, float two_bound, float (&f)[4][2])
+{
+    const float ux = (px + bound) / two_bound, uy = (py + bound) / two_bound, uz = (pz + bound) / two_bound;
+    const bool oob = (ux < 0.0f) | (ux > 1.0f) | (uy < 0.0f) | (uy > 1.0f) | (uz < 0.0f) | (uz > 1.0f);
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0 += ROUND) {
+        float q[ROUND][3];
+        u32x2 v[ROUND][8];
+#pragma unroll
+        for (int jj = 0; jj < ROUND; ++jj) {
+            const int j = j0 + jj;
+            const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8);
+            const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
+            const float scale = __uint_as_float(r0.x);
+            const uint32_t my = r0.y, mz = r0.z, offset = r0.w, mask = r1.x, hashed = r1.y;
+            float qx = fma_(ux, scale, 0.5f), qy = fma_(uy, scale, 0.5f), qz = fma_(uz, scale, 0.5f);
+            const uint32_t gx = (uint32_t)__builtin_floorf(qx), gy = (uint32_t)__builtin_floorf(qy), gz = (uint32_t)__builtin_floorf(qz);
+            q[jj][0] = qx - (float)gx; q[jj][1] = qy - (float)gy; q[jj][2] = qz - (float)gz;
+            const uint32_t ax0 = gx, ax1 = gx + 1u, ay0 = gy * my, ay1 = ay0 + my, az0 = gz * mz, az1 = az0 + mz;
+            const int mode = jmode[j];                      // wave-uniform: one code path per gather round
+            uint32_t idx[8];
+            if (mode == 0) {                                // all four levels of this round are dense
+#pragma unroll
+                for (int c = 0; c < 8; ++c) idx[c] = ((c & 1) ? ax1 : ax0) + ((c & 2) ? ay1 : ay0) + ((c & 4) ? az1 : az0);
+            } else if (mode == 1) {                         // all hashed
+#pragma unroll
+                for (int c = 0; c < 8; ++c) idx[c] = (((c & 1) ? ax1 : ax0) ^ ((c & 2) ? ay1 : ay0) ^ ((c & 4) ? az1 : az0)) & mask;
+            } else {                                        // mixed round (levels 4..7 of the default model)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t tx = (c & 1) ? ax1 : ax0, ty = (c & 2) ? ay1 : ay0, tz = (c & 4) ? az1 : az0;
+                    idx[c] = (hashed ? (tx ^ ty ^ tz) : (tx + ty + tz)) & mask;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[jj][c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((offset + idx[c]) * 8u), 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < ROUND; ++jj) {
+            const float qx = q[jj][0], qy = q[jj][1], qz = q[jj][2];
+            const float wx0 = 1.0f - qx, wy0 = 1.0f - qy, wz0 = 1.0f - qz;
+            const float w00 = wx0 * wy0, w10 = qx * wy0, w01 = wx0 * qy, w11 = qx * qy;
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wxy = (c & 2) ? ((c & 1) ? w11 : w01) : ((c & 1) ? w10 : w00);
+                const float w = wxy * ((c & 4) ? qz : wz0);
+                a0 = fma_(w, __uint_as_float(v[jj][c].x), a0);
+                a1 = fma_(w, __uint_as_float(v[jj][c].y), a1);
+            }
+            f[j0 + jj][0] = oob ? 0.0f : a0;
+            f[j0 + jj][1] = oob ? 0.0f : a1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- forward_sdf for a tile of 16 points: returns the 16 outputs as D2^T fragment (o = 4g+r) ----------
+struct FieldCtx { rsrc_t table; int jmode[4]; int jfine[4]; float bound, two_bound; };
+__device__ __forceinline__ rsrc_t table_of(const FieldCtx &fc) { return fc.table; }
+
+// SDF MLP 35-64-16 on the tile's features (f[j][c] = level 4j+g, channel c; bxyz = this lane group's coordinate),
+// split into layer 1 (36 MFMA) and softplus + layer 2 (16 x ~40 VALU + 16 MFMA) so that the caller can overlap
+// layer 1 of the NEXT evaluation (matrix pipe) with the softplus of the current one (vector pipe).
+struct Acc4 { f32x4 a[4]; };
+
+__device__ __forceinline__ Acc4 sdf_l1(const float *__restrict__ lds, int lane, float bxyz, const float (&f)[4][2])
+{
+    const int g = lane >> 4;
+    Acc4 acc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc.a[t] = *reinterpret_cast<const f32x4 *>(lds + OFF_B1 + 16 * t + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const float b = (s == 0) ? bxyz : f[(s - 1) >> 1][(s - 1) & 1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc.a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W1F + (t * 9 + s) * 64 + lane], b, acc.a[t], 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ f32x4 sdf_l2(const float *__restrict__ lds, int lane, const Acc4 &acc)
+{
+    const int g = lane >> 4;
+    f32x4 o2 = *reinterpret_cast<const f32x4 *>(lds + OFF_B2 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            v2f xin = { acc.a[t][r], acc.a[t][r + 1] };
+#ifdef AC_ABL_SOFTPLUS
+            const v2f h = xin * splat2(0.5f);
+#else
+            const v2f h = dv_softplus100_x2(lds + OFF_SPQ, xin);
+#endif
+            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r) * 64 + lane], h.x, o2, 0, 0, 0);
+            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r + 1) * 64 + lane], h.y, o2, 0, 0, 0);
+        }
+    }
+    return o2;
+}
+
+__device__ __forceinline__ f32x4 sdf_mlp(const float *__restrict__ lds, int lane, float bxyz, const float (&f)[4][2])
+{
+    const Acc4 acc = sdf_l1(lds, lane, bxyz, f);
+    __builtin_amdgcn_sched_barrier(0);
+    return sdf_l2(lds, lane, acc);
+}
+
+__device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, const FieldCtx &fc, int lane, float px, float py, float pz)
+{
+    const int g = lane >> 4;
+    float f[4][2];
+    encode4<AC_ENC_ROUND>(lds, fc.table, g, fc.jmode, px, py, pz, fc.bound, fc.two_bound, f);
+    __builtin_amdgcn_sched_barrier(0);
+    return sdf_mlp(lds, lane, sel4(g, px, py, pz, 0.0f), f);
+}
+
+// ---- finite-difference stencil: hash features of the centre point and of p +- eps*e_k (k = x,y,z) ------------------
+// The 7 evaluations of finite_difference_normals_approximator (instant_nsr.py:687-704) share most grid corners
+// on the coarse levels (eps*scale < 1 cell up to level 11).  Every evaluation still computes ITS OWN position,
+// cell and interpolation weights exactly as a stand-alone evaluation would (bit-identical features); only the
+// memory fetches are shared: a face of the offset point's cell that coincides with a face of the centre cell
+// re-uses the centre's 4 corner values, other faces are gathered under an exec mask.
+// fe[e][j][c]: e = 0 centre, 1..6 = +x,-x,+y,-y,+z,-z ; pe[e] = the offset coordinate (clamped) of evaluation e.
+struct LvlC { float scale; uint32_t my, mz, offset, mask, hashed; };
+
+__device__ __forceinline__ uint32_t gidx(const LvlC &L, uint32_t tx, uint32_t ty, uint32_t tz)
+{
+    return (L.hashed ? (tx ^ ty ^ tz) : (tx + ty + tz)) & L.mask;
+}
+__device__ __forceinline__ void interp8(const u32x2 (&v)[8], float qx, float qy, float qz, bool oob, float &f0, float &f1)
+{
+    const float wx0 = 1.0f - qx, wy0 = 1.0f - qy, wz0 = 1.0f - qz;
+    const float w00 = wx0 * wy0, w10 = qx * wy0, w01 = wx0 * qy, w11 = qx * qy;
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float wxy = (c & 2) ? ((c & 1) ? w11 : w01) : ((c & 1) ? w10 : w00);
+        const float w = wxy * ((c & 4) ? qz : wz0);
+        a0 = fma_(w, __uint_as_float(v[c].x), a0);
+        a1 = fma_(w, __uint_as_float(v[c].y), a1);
+    }
+    f0 = oob ? 0.0f : a0;
+    f1 = oob ? 0.0f : a1;
+}
+// corner index (0..7) of the i-th corner (i = 0..3, other two axes in increasing order) on face b of axis K
+template <int K> __device__ __forceinline__ constexpr int face_corner(int b, int i)
+{
+    return K == 0 ? (b | (i << 1)) : (K == 1 ? ((i & 1) | (b << 1) | ((i >> 1) << 2)) : (i | (b << 2)));
+}
+
+// ---- coarse level (eps*scale < 1 cell): an offset point lies in the centre cell or in the adjacent one, so it needs at
+// most ONE face the centre does not have (coordinate g+2 for +eps, g-1 for -eps).  All 8 + 6*4 gathers of the level
+// are issued as one batch (lanes that need nothing send an out-of-range offset: dropped by the descriptor's bounds
+// check), then the 7 interpolations run from registers: one memory round trip per level instead of seven.
+template <int K, int SIGN>   // SIGN 0: +eps, 1: -eps
+struct AxisGeo { float qk; bool need, oob; };
+
+template <int K, int SIGN>
+__device__ __forceinline__ AxisGeo<K, SIGN> coarse_issue(rsrc_t table, const LvlC &L, const uint32_t (&gc)[3], const uint32_t (&tx)[2],
+                                                       const uint32_t (&ty)[2], const uint32_t (&tz)[2], bool oob_c, float u,
+                                                       u32x2 (&w)[4])
+{
+    AxisGeo<K, SIGN> a;
+    a.oob = oob_c | (u < 0.0f) | (u > 1.0f);
+    const float pos = fma_(u, L.scale, 0.5f);
+    const uint32_t gk = (uint32_t)__builtin_floorf(pos);
+    a.qk = pos - (float)gk;
+    a.need = gk != gc[K];                                   // shifted by exactly one cell (host guarantees |shift| <= 1)
+    const uint32_t mk = K == 0 ? 1u : (K == 1 ? L.my : L.mz);
+    const uint32_t base = K == 0 ? tx[0] : (K == 1 ? ty[0] : tz[0]);
+    const uint32_t tk = SIGN == 0 ? base + 2u * mk : base - mk;   // coordinate g+2 / g-1 along K
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = face_corner<K>(0, i);
+        const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
+        const uint32_t off = a.need ? (L.offset + gidx(L, ax, ay, az)) * 8u : 0xfffffff8u;
+        w[i] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF(off), 0, 0);
+    }
+    return a;
+}
+
+template <int K, int SIGN>
+__device__ __forceinline__ void coarse_finish(const AxisGeo<K, SIGN> &a, const u32x2 (&vc)[8], const u32x2 (&w)[4], const float (&qc)[3],
+                                              float &f0, float &f1)
+{
+    constexpr int NEWBIT = SIGN == 0 ? 1 : 0;               // +eps: the new face is face 1 of the shifted cell
+    u32x2 v2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int bk = (c >> K) & 1;
+        const int i = K == 0 ? (c >> 1) : (K == 1 ? ((c & 1) | ((c >> 2) << 1)) : (c & 3));
+        if (bk == NEWBIT) { v2[c].x = a.need ? w[i].x : vc[c].x; v2[c].y = a.need ? w[i].y : vc[c].y; }
+        else { v2[c].x = a.need ? vc[c ^ (1 << K)].x : vc[c].x; v2[c].y = a.need ? vc[c ^ (1 << K)].y : vc[c].y; }
+    }
+    interp8(v2, K == 0 ? a.qk : qc[0], K == 1 ? a.qk : qc[1], K == 2 ? a.qk : qc[2], a.oob, f0, f1);
+}
+
+// ---- fine level (eps spans one cell or more): every offset point gathers its own 8 corners ---------------------------
+template <int K>
+__device__ __forceinline__ void fine_issue(rsrc_t table, const LvlC &L, const uint32_t (&tx)[2], const uint32_t (&ty)[2],
+                                           const uint32_t (&tz)[2], bool oob_c, float u, u32x2 (&v)[8], float &qk, bool &oob)
+{
+    oob = oob_c | (u < 0.0f) | (u > 1.0f);
+    const float pos = fma_(u, L.scale, 0.5f);
+    const uint32_t gk = (uint32_t)__builtin_floorf(pos);
+    qk = pos - (float)gk;
+    const uint32_t mk = K == 0 ? 1u : (K == 1 ? L.my : L.mz);
+    const uint32_t t0 = gk * mk, t1 = t0 + mk;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t tk = ((c >> K) & 1) ? t1 : t0;
+        const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
+        v[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx(L, ax, ay, az)) * 8u), 0, 0);
+    }
+}
+
+#define AC_FSTORE(E, F0, F1) { fslab[((E - 1) * 8 + 2 * j) * 64 + lane] = F0; fslab[((E - 1) * 8 + 2 * j + 1) * 64 + lane] = F1; }
+
+__device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, float *__restrict__ fslab, const FieldCtx &fc, int lane,
+                                               float px, float py, float pz, float eps, float (&fe0)[4][2])
+{
+    const int g = lane >> 4;
+    const rsrc_t table = fc.table;
+    const float bound = fc.bound, two_bound = fc.two_bound;
+    const float ux = (px + bound) / two_bound, uy = (py + bound) / two_bound, uz = (pz + bound) / two_bound;
+    const bool oob = (ux < 0.0f) | (ux > 1.0f) | (uy < 0.0f) | (uy > 1.0f) | (uz < 0.0f) | (uz > 1.0f);
+    // normalised coordinate of the six offset points (one division each, hoisted out of the level loop)
+    const float xp = (clampf(px + eps, -bound, bound) + bound) / two_bound, xm = (clampf(px + (-eps), -bound, bound) + bound) / two_bound;
+    const float yp = (clampf(py + eps, -bound, bound) + bound) / two_bound, ym = (clampf(py + (-eps), -bound, bound) + bound) / two_bound;
+    const float zp = (clampf(pz + eps, -bound, bound) + bound) / two_bound, zm = (clampf(pz + (-eps), -bound, bound) + bound) / two_bound;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {                           // one copy of each code path; results go to LDS / a rotating fe0
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8);
+        const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
+        LvlC L; L.scale = __uint_as_float(r0.x); L.my = r0.y; L.mz = r0.z; L.offset = r0.w; L.mask = r1.x; L.hashed = r1.y;
+        float qc[3]; uint32_t gc[3];
+        {
+            const float qx = fma_(ux, L.scale, 0.5f), qy = fma_(uy, L.scale, 0.5f), qz = fma_(uz, L.scale, 0.5f);
+            gc[0] = (uint32_t)__builtin_floorf(qx); gc[1] = (uint32_t)__builtin_floorf(qy); gc[2] = (uint32_t)__builtin_floorf(qz);
+            qc[0] = qx - (float)gc[0]; qc[1] = qy - (float)gc[1]; qc[2] = qz - (float)gc[2];
+        }
+        uint32_t tx[2], ty[2], tz[2];
+        tx[0] = gc[0]; tx[1] = gc[0] + 1u; ty[0] = gc[1] * L.my; ty[1] = ty[0] + L.my; tz[0] = gc[2] * L.mz; tz[1] = tz[0] + L.mz;
+        u32x2 vc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            vc[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx(L, tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2])) * 8u), 0, 0);
+        float c0, c1;
+        if (!fc.jfine[j]) {
+            u32x2 w0[4], w1[4], w2[4], w3[4], w4[4], w5[4];
+            const auto a0 = coarse_issue<0, 0>(table, L, gc, tx, ty, tz, oob, xp, w0);
+            const auto a1 = coarse_issue<0, 1>(table, L, gc, tx, ty, tz, oob, xm, w1);
+            const auto a2 = coarse_issue<1, 0>(table, L, gc, tx, ty, tz, oob, yp, w2);
+            const auto a3 = coarse_issue<1, 1>(table, L, gc, tx, ty, tz, oob, ym, w3);
+            const auto a4 = coarse_issue<2, 0>(table, L, gc, tx, ty, tz, oob, zp, w4);
+            const auto a5 = coarse_issue<2, 1>(table, L, gc, tx, ty, tz, oob, zm, w5);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+            float f0, f1;
+            coarse_finish<0, 0>(a0, vc, w0, qc, f0, f1); AC_FSTORE(1, f0, f1)
+            coarse_finish<0, 1>(a1, vc, w1, qc, f0, f1); AC_FSTORE(2, f0, f1)
+            coarse_finish<1, 0>(a2, vc, w2, qc, f0, f1); AC_FSTORE(3, f0, f1)
+            coarse_finish<1, 1>(a3, vc, w3, qc, f0, f1); AC_FSTORE(4, f0, f1)
+            coarse_finish<2, 0>(a4, vc, w4, qc, f0, f1); AC_FSTORE(5, f0, f1)
+            coarse_finish<2, 1>(a5, vc, w5, qc, f0, f1); AC_FSTORE(6, f0, f1)
+        } else {
+            u32x2 va[8], vb[8];
+            float qa, qb, f0, f1; bool oa, ob;
+            fine_issue<0>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
+            fine_issue<0>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+            interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
+            interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
+            __builtin_amdgcn_sched_barrier(0);
+            fine_issue<1>(table, L, tx, ty, tz, oob, yp, va, qa, oa);
+            fine_issue<1>(table, L, tx, ty, tz, oob, ym, vb, qb, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(va, qc[0], qa, qc[2], oa, f0, f1); AC_FSTORE(3, f0, f1)
+            interp8(vb, qc[0], qb, qc[2], ob, f0, f1); AC_FSTORE(4, f0, f1)
+            __builtin_amdgcn_sched_barrier(0);
+            fine_issue<2>(table, L, tx, ty, tz, oob, zp, va, qa, oa);
+            fine_issue<2>(table, L, tx, ty, tz, oob, zm, vb, qb, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(va, qc[0], qc[1], qa, oa, f0, f1); AC_FSTORE(5, f0, f1)
+            interp8(vb, qc[0], qc[1], qb, ob, f0, f1); AC_FSTORE(6, f0, f1)
+        }
+        // rotate the centre features into place: after the 4th iteration fe0[j] holds level 4j+g
+        fe0[0][0] = fe0[1][0]; fe0[0][1] = fe0[1][1]; fe0[1][0] = fe0[2][0]; fe0[1][1] = fe0[2][1];
+        fe0[2][0] = fe0[3][0]; fe0[2][1] = fe0[3][1]; fe0[3][0] = c0; fe0[3][1] = c1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+#undef AC_FSTORE
+
+// ---- forward_color for a tile: rgb (post-sigmoid) valid in lanes g==0 ---------------------------------
+__device__ __forceinline__ void color_tile(const float *__restrict__ lds, int lane, float px, float py, float pz,
+                                           float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3])
+{
+    const int g = lane >> 4;
+    f32x4 h1[4], h2[4];
+    const float bxyz = sel4(g, px, py, pz, 0.0f), bn = sel4(g, nx, ny, nz, 0.0f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const float b = s < 4 ? sdfout[s] : (s == 4 ? bxyz : bn);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C1F + (t * 6 + s) * 64 + lane], b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+        h1[t] = acc;
+    }
+#pragma unroll
+    for (int to = 0; to < 4; ++to) {
+        f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C2F + (to * 16 + kk) * 64 + lane], h1[kk >> 2][kk & 3], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+        h2[to] = acc;
+    }
+    f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C3F + kk * 64 + lane], h2[kk >> 2][kk & 3], acc, 0, 0, 0);
+    rgb[0] = dv_sigmoid(acc[0]); rgb[1] = dv_sigmoid(acc[1]); rgb[2] = dv_sigmoid(acc[2]);
+}
+
+// ---- one 64-bin chunk of the per-bin scans of up_sample: row-local inclusive scan + cross-row carry ----
+// v: this lane's element (identity-padded); carry/first: state entering the chunk; returns the inclusive
+// tile-scan value and the value entering this lane's row (rc), updates carry/first.
+template <bool MUL>
+__device__ __forceinline__ float chunk_scan(float v, int lane, float &carry, bool &first, float &loc, float &row_in, bool &row_first)
+{
+    loc = row_scan<MUL>(v);
+    const float t0 = lane_bcast(loc, 15), t1 = lane_bcast(loc, 31), t2 = lane_bcast(loc, 47), t3 = lane_bcast(loc, 63);
+    const float c0 = carry; const bool f0 = first;
+    const float c1 = f0 ? t0 : (MUL ? c0 * t0 : c0 + t0);
+    const float c2 = MUL ? c1 * t1 : c1 + t1;
+    const float c3 = MUL ? c2 * t2 : c2 + t2;
+    const float c4 = MUL ? c3 * t3 : c3 + t3;
+    const int g = lane >> 4;
+    row_in = sel4(g, c0, c1, c2, c3);
+    row_first = f0 && g == 0;
+    carry = c4; first = false;
+    return row_first ? loc : (MUL ? row_in * loc : row_in + loc);
+}
+
+__device__ __forceinline__ FieldCtx make_ctx(const RenderArgs &a)
+{
+    FieldCtx fc;
+    fc.table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.table), 0, a.table_bytes, 0x00020000);
+    fc.jmode[0] = a.jmode[0]; fc.jmode[1] = a.jmode[1]; fc.jmode[2] = a.jmode[2]; fc.jmode[3] = a.jmode[3];
+    fc.jfine[0] = a.jfine[0]; fc.jfine[1] = a.jfine[1]; fc.jfine[2] = a.jfine[2]; fc.jfine[3] = a.jfine[3];
+    fc.bound = a.bound; fc.two_bound = a.two_bound;
+    return fc;
+}
+
+// =====================================================================================================
+
+int fill_args(RenderArgs &a, const ac_field *f, float bound)
+{
+    if (!f || !f->table || !f->W1 || !f->b1 || !f->W2 || !f->b2 || !f->Wc1 || !f->Wc2 || !f->Wc3) {
+        ac::set_error("ac_field: NULL parameter pointer"); return AC_ERR_BAD_ARG;
+    }
+    ac::LevelTable lt; ac::make_level_table(lt, 16, 3, f->S, f->H, f->offsets);
+    for (int l = 0; l < 16; ++l) {
+        const bool hashed = lt.hashed[l] != 0, pow2 = lt.pow2mask[l] != 0;
+        a.lvl[l].scale = lt.scale[l]; a.lvl[l].offset = lt.offset[l]; a.lvl[l].hashed = hashed ? 1u : 0u;
+        a.lvl[l].my = hashed ? 2654435761u : lt.stride1[l];
+        a.lvl[l].mz = hashed ? 805459861u : lt.stride1[l] * lt.stride1[l];
+        a.lvl[l].mask = (hashed && pow2) ? lt.pow2mask[l] : 0xffffffffu;
+        a.lvl[l].wsize = (hashed && !pow2) ? lt.size[l] : 0u;
+        a.lvl[l].pad = 0;
+        if (a.lvl[l].wsize) {
+            ac::set_error("ac_field: level %d is hashed with a non power-of-two size %u; the fused renderer supports tables "
+                          "allocated by HashEncoder only (use ac_hash_encode_forward for arbitrary layouts)", l, lt.size[l]);
+            return AC_ERR_BAD_ARG;
+        }
+        if (lt.size[l] == 0) { ac::set_error("ac_field: level %d has zero size", l); return AC_ERR_BAD_ARG; }
+    }
+    for (int j = 0; j < 4; ++j) {
+        int nh = 0;
+        for (int g = 0; g < 4; ++g) nh += lt.hashed[4 * j + g] ? 1 : 0;
+        a.jmode[j] = nh == 0 ? 0 : (nh == 4 ? 1 : 2);
+    }
+    a.table = f->table; a.table_bytes = (uint32_t)f->offsets[16] * 8u; a.W1 = f->W1; a.b1 = f->b1; a.W2 = f->W2; a.b2 = f->b2; a.Wc1 = f->Wc1; a.Wc2 = f->Wc2; a.Wc3 = f->Wc3;
+    a.bound = bound; a.two_bound = (float)(2.0 * (double)bound);
+    return AC_OK;
+}
+
+
+}  // namespace

@@ -1,0 +1,350 @@
+// avatarcraft_amd/csrc/sdf_train.hip -- fused SDF query of the differentiable render core (training path), forward and backward.
+//
+// One SDF query of the render core (reference models/instant_nsr.py:205-215) is forward_sdf at x (:627-642: hash encoder ->
+// cat[x, h] -> WN-Linear 35->64 -> Softplus(100) -> WN-Linear 64->16) plus finite_difference_normals_approximator at
+// clamp(x +- eps e_k) (:687-704): 7 encoder + MLP evaluations, ~40 PyTorch kernels forward and ~90 backward, every
+// intermediate ([7B,35], [7B,64] x 2, [7B,16]) round-tripping HBM.  Here:
+//   sdf_stencil_fwd_kernel : x -> sdf_out[B,16], gradient[B,3]     (the renderer's own stencil gather + MFMA MLP tiles,
+//                                                                    bit-identical to the fused renderer and the oracle)
+//   sdf_stencil_bwd_kernel : (x, d sdf_out, d gradient) -> d features [7,16,B,2] (consumed by hash_stencil_bwd_kernel, which
+//                            owns the atomic-bound table scatter) and per-wave partial sums of dW1, db1, dW2, db2.
+// The backward recomputes the forward per tile of 16 samples (gathers are L2/MALL hits, MFMA is cheap) instead of storing
+// activations, and runs every product on the matrix pipe, tile layout lane = (sample n = lane & 15, group g = lane >> 4):
+//   ga   = W2^T d2         16 MFMA   B operand = d2 in the register layout the forward produced it in (o = 4g + s)
+//   d1   = ga * softplus'  (derivative of the SAME table polynomial the forward evaluates)
+//   dinp = W1^T d1         32 MFMA   row order chosen so that every lane receives the gradient of ITS OWN 8 features
+//   dW2 += d2 a^T          16 MFMA   } K = the 16 samples of the tile: operands transposed through a per-wave LDS slab,
+//   dW1 += d1 inp^T        48 MFMA   } accumulators live in registers for the whole kernel (a column of ones gives db1)
+// Weight-gradient partials are written per wave (no atomics) and summed by sdf_partials_reduce_kernel (deterministic).
+#include "nsr_device.hpp"
+
+namespace {
+
+constexpr int TW = 4;                              // waves per workgroup
+constexpr int TBLOCK = TW * 64;
+constexpr int TLD = 17;                            // padded leading dimension of the transpose slabs
+constexpr int OFF_W2T = OFF_WAVE;                  // [4 tiles][4 ksteps][64]   A fragments of W2^T
+constexpr int OFF_W1T = OFF_W2T + 16 * 64;         // [2 tiles][16 ksteps][64]  A fragments of W1^T (feature rows)
+constexpr int OFF_TW = OFF_W1T + 32 * 64;          // per-wave slabs
+constexpr int TS_T2 = FE_SLAB;                     // d2  [16][TLD]
+constexpr int TS_TA = TS_T2 + 16 * TLD;            // a   [64][TLD]
+constexpr int TS_TD = TS_TA + 64 * TLD;            // d1  [64][TLD]
+constexpr int TS_TI = TS_TD + 64 * TLD;            // inp [48][TLD]  rows 0..34 inputs, 35 = 1 (bias column), 36..47 = 0
+constexpr int TRAIN_SLAB = ((TS_TI + 48 * TLD + 3) / 4) * 4;
+constexpr int FWD_LDS_FLOATS = OFF_WAVE + TW * FE_SLAB;
+constexpr int BWD_LDS_FLOATS = OFF_TW + TW * TRAIN_SLAB;
+static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+constexpr int NPART = 64 * 36 + 16 * 64 + 16;      // dW1 [64][36] (column 35 = db1), dW2 [16][64], db2 [16]
+
+// softplus_100 and its derivative from the same table row: d/dx [max(x,0) + G(|100 x|)] = [x > 0] + sign(x) 100 G'(|100 x|)
+__device__ __forceinline__ void softplus100_vg(const float *__restrict__ spg, float x, float &val, float &der)
+{
+    const float t = x * 100.0f;
+    const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
+    int idx = (int)(am * 2.0f);
+    idx = idx > 63 ? 63 : idx;
+    const float v = fma_(-0.5f, (float)idx, am);
+    const float4 c03 = *reinterpret_cast<const float4 *>(spg + idx * 8);
+    const float2 c45 = *reinterpret_cast<const float2 *>(spg + idx * 8 + 4);
+    float q = c45.y;
+    q = fma_(q, v, c45.x); q = fma_(q, v, c03.w); q = fma_(q, v, c03.z); q = fma_(q, v, c03.y); q = fma_(q, v, c03.x);
+    float dq = 5.0f * c45.y;
+    dq = fma_(dq, v, 4.0f * c45.x); dq = fma_(dq, v, 3.0f * c03.w); dq = fma_(dq, v, 2.0f * c03.z); dq = fma_(dq, v, c03.y);
+    const bool pos = x > 0.0f;
+    val = (pos ? x : 0.0f) + q;
+    der = (pos ? 1.0f : 0.0f) + (pos ? 100.0f : -100.0f) * dq;
+}
+
+// the 7 evaluations of one tile: centre outputs (o = 4g + r) and the finite-difference gradient (valid in the lanes g == 0)
+__device__ __forceinline__ void fd_forward(const float *__restrict__ lds, const float *__restrict__ fsl, int lane, float px, float py, float pz,
+                                           float eps, float bound, const float (&fe0)[4][2], f32x4 &oc, float (&gr)[3])
+{
+    const int g = lane >> 4;
+    const float pc0 = sel4(g, px, py, pz, 0.0f);
+    oc = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    gr[0] = gr[1] = gr[2] = 0.0f;
+    float spos = 0.0f;
+    Acc4 acc = sdf_l1(lds, lane, pc0, fe0);
+#pragma unroll 1
+    for (int e = 0; e < 7; ++e) {
+        const int en = e < 6 ? e + 1 : 6;
+        const int kn = (en - 1) >> 1;
+        float fe[4][2];
+#pragma unroll
+        for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[((en - 1) * 8 + q_) * 64 + lane];
+        const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
+        const float poff = clampf(pk + (((en - 1) & 1) ? -eps : eps), -bound, bound);
+        const Acc4 accn = sdf_l1(lds, lane, g == kn ? poff : pc0, fe);
+        const f32x4 o = sdf_l2(lds, lane, acc);
+        acc = accn;
+        const int k = (e - 1) >> 1;
+        if (e == 0) oc = o;
+        else if (e & 1) spos = o[0];
+        else {
+            const float gk = 0.5f * (spos - o[0]) / eps;
+            if (k == 0) gr[0] = gk; else if (k == 1) gr[1] = gk; else gr[2] = gk;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TBLOCK) void sdf_stencil_fwd_kernel(const RenderArgs a, const float *__restrict__ x, uint32_t B, float eps,
+                                                                 float *__restrict__ out16, float *__restrict__ grad)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
+    const FieldCtx fc = make_ctx(a);
+    const uint32_t ntiles = (B + 15) / 16;
+    for (uint32_t tile = blockIdx.x * TW + wave; tile < ntiles; tile += gridDim.x * TW) {
+        const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
+        const float px = x[3 * (size_t)bb], py = x[3 * (size_t)bb + 1], pz = x[3 * (size_t)bb + 2];
+        float fe0[4][2];
+        encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
+        f32x4 oc; float gr[3];
+        fd_forward(lds, fsl, lane, px, py, pz, eps, a.bound, fe0, oc, gr);
+        if (b < B) {
+            *reinterpret_cast<f32x4 *>(out16 + (size_t)b * 16 + 4 * g) = oc;
+            if (g == 0) { grad[3 * (size_t)b] = gr[0]; grad[3 * (size_t)b + 1] = gr[1]; grad[3 * (size_t)b + 2] = gr[2]; }
+        }
+        wave_sync();
+    }
+}
+
+// extra weight fragments of the backward: W2^T (ga = W2^T d2) and the feature rows of W1^T (dinp = W1^T d1)
+__device__ __forceinline__ void fill_lds_bwd(float *lds, const RenderArgs &a)
+{
+    for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {       // fragment (t, s): lane (m, kk) = W2[o = 4 kk + s][unit = 16 t + m]
+        const int l = e & 63, fs = e >> 6, t = fs >> 2, s = fs & 3, m = l & 15, kk = l >> 4;
+        lds[OFF_W2T + e] = a.W2[(4 * kk + s) * 64 + 16 * t + m];
+    }
+    for (int e = threadIdx.x; e < 32 * 64; e += blockDim.x) {       // fragment (t', ks = 4t + r): lane (m, kk) = W1[unit = 16t + 4kk + r][col(t', m)]
+        const int l = e & 63, fs = e >> 6, tp = fs >> 4, ks = fs & 15, t = ks >> 2, r = ks & 3, m = l & 15, kk = l >> 4;
+        const int s1 = 4 * tp + (m & 3);                            // feature slot 2j + c of lane group m >> 2
+        const int col = 3 + 2 * (4 * (s1 >> 1) + (m >> 2)) + (s1 & 1);
+        lds[OFF_W1T + e] = a.W1[(16 * t + 4 * kk + r) * 35 + col];
+    }
+}
+
+__global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ g_out,
+                                                                 const float *__restrict__ g_grad, uint32_t B, float eps,
+                                                                 float *__restrict__ gfeat, float *__restrict__ partials)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    fill_lds_bwd(lds, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    float *slab = lds + OFF_TW + wave * TRAIN_SLAB;
+    float *fsl = slab, *T2 = slab + TS_T2, *TA = slab + TS_TA, *TD = slab + TS_TD, *TI = slab + TS_TI;
+    for (int e = lane; e < 48 * TLD; e += 64) TI[e] = (e >= 35 * TLD && e < 36 * TLD) ? 1.0f : 0.0f;       // bias column, zero padding rows
+    __syncthreads();
+    const FieldCtx fc = make_ctx(a);
+    const float bound = a.bound;
+    f32x4 gW1[4][3], gW2[4];
+    float gb2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        gW2[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gW1[t][c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    }
+    const uint32_t ntiles = (B + 15) / 16;
+    const float hs = 0.5f / eps;
+    for (uint32_t tile = blockIdx.x * TW + wave; tile < ntiles; tile += gridDim.x * TW) {
+        const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
+        const bool live = b < B;
+        const float px = x[3 * (size_t)bb], py = x[3 * (size_t)bb + 1], pz = x[3 * (size_t)bb + 2];
+        f32x4 go = *reinterpret_cast<const f32x4 *>(g_out + (size_t)bb * 16 + 4 * g);
+        float gg[3] = { g_grad[3 * (size_t)bb], g_grad[3 * (size_t)bb + 1], g_grad[3 * (size_t)bb + 2] };
+        if (!live) { go = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; gg[0] = gg[1] = gg[2] = 0.0f; }
+        float fe0[4][2];
+        encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
+        const float pc0 = sel4(g, px, py, pz, 0.0f);
+#pragma unroll 1
+        for (int e = 0; e < 7; ++e) {
+            const int k = e > 0 ? (e - 1) >> 1 : 3;
+            float fe[4][2];
+            if (e == 0) {
+#pragma unroll
+                for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fe0[q_ >> 1][q_ & 1];
+            } else {
+#pragma unroll
+                for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[((e - 1) * 8 + q_) * 64 + lane];
+            }
+            const float pk = k == 0 ? px : (k == 1 ? py : pz);
+            const float poff = clampf(pk + (((e - 1) & 1) ? -eps : eps), -bound, bound);
+            const float bx = (e > 0 && g == k) ? poff : pc0;
+            // upstream gradient of this evaluation's 16 outputs, in the forward's register layout (o = 4g + r)
+            f32x4 d2;
+            if (e == 0) d2 = go;
+            else {
+                const float gk = k == 0 ? gg[0] : (k == 1 ? gg[1] : gg[2]);
+                const float s = ((e - 1) & 1) ? -(gk * hs) : gk * hs;          // d gradient_k / d sdf(x +- eps e_k) = +-0.5 / eps
+                d2 = f32x4{ g == 0 ? s : 0.0f, 0.0f, 0.0f, 0.0f };
+            }
+            // recompute layer 1, softplus and its derivative
+            const Acc4 h1 = sdf_l1(lds, lane, bx, fe);
+            Acc4 av, dv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { float v_, d_; softplus100_vg(lds + OFF_SPQ, h1.a[t][r], v_, d_); av.a[t][r] = v_; dv.a[t][r] = d_; }
+            // ga = W2^T d2, d1 = ga * softplus'
+            Acc4 d1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 ga = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                for (int s = 0; s < 4; ++s) ga = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2T + (t * 4 + s) * 64 + lane], d2[s], ga, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d1.a[t][r] = ga[r] * dv.a[t][r];
+            }
+            // dinp = W1^T d1: this lane's own features (j = 2t' + (r >> 1), c = r & 1)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                f32x4 gi = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        gi = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W1T + (tp * 16 + 4 * t + r) * 64 + lane], d1.a[t][r], gi, 0, 0, 0);
+                if (live) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int j = 2 * tp + m;
+                        *reinterpret_cast<float2 *>(gfeat + (((size_t)e * 16 + 4 * j + g) * B + b) * 2) = make_float2(gi[2 * m], gi[2 * m + 1]);
+                    }
+                }
+            }
+            // transposes for the weight gradients (K = the 16 samples of the tile)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T2[(4 * g + r) * TLD + n] = d2[r];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    TA[(16 * t + 4 * g + r) * TLD + n] = av.a[t][r];
+                    TD[(16 * t + 4 * g + r) * TLD + n] = d1.a[t][r];
+                }
+            if (g < 3) TI[g * TLD + n] = bx;
+#pragma unroll
+            for (int s1 = 0; s1 < 8; ++s1) TI[(3 + 2 * (4 * (s1 >> 1) + g) + (s1 & 1)) * TLD + n] = fe[s1 >> 1][s1 & 1];
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float a2 = T2[n * TLD + 4 * s + g];                     // A: d2[o = lane & 15][sample 4s + kk]
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    gW2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, TA[(16 * c + n) * TLD + 4 * s + g], gW2[c], 0, 0, 0);
+                float bi[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) bi[c] = TI[(16 * c + n) * TLD + 4 * s + g];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float a1 = TD[(16 * t + n) * TLD + 4 * s + g];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gW1[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bi[c], gW1[t][c], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gb2[r] += d2[r];
+            wave_sync();
+        }
+    }
+    // per-wave partial sums: dW1 [64][36] | dW2 [16][64] | db2 [16]
+    float *part = partials + (size_t)(blockIdx.x * TW + wave) * NPART;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int unit = 16 * t + 4 * g + r, kcol = 16 * c + n;
+                if (kcol < 36) part[unit * 36 + kcol] = gW1[t][c][r];
+            }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[64 * 36 + (4 * g + r) * 64 + 16 * c + n] = gW2[c][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float tot = row_scan<false>(gb2[r]);                   // inclusive scan over the 16 samples of the row: lane n == 15 holds the total
+        if (n == 15) part[64 * 36 + 16 * 64 + 4 * g + r] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void sdf_partials_reduce_kernel(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)NPART) return;
+    float s = 0.0f;
+    for (uint32_t w = 0; w < nwaves; ++w) s += partials[(size_t)w * NPART + i];
+    out[i] = s;
+}
+
+uint32_t train_grid(uint32_t B)
+{
+    const uint32_t ntiles = (B + 15) / 16;
+    uint32_t blocks = (ntiles + TW - 1) / TW;
+    if (blocks > 512) blocks = 512;                    // persistent: 2 workgroups' worth of tiles in flight per CU at most
+    return blocks ? blocks : 1;
+}
+
+int prep_args(RenderArgs &a, const ac_field *field, float bound, float eps)
+{
+    if (int rc = fill_args(a, field, bound)) return rc;
+    a.eps = eps;
+    for (int j = 0; j < 4; ++j) {
+        a.jfine[j] = 0;
+        for (int g = 0; g < 4; ++g) {
+            const double cells = (double)eps / (double)a.two_bound * (double)a.lvl[4 * j + g].scale;
+            if (!(cells * 1.001 + 1e-3 < 1.0)) a.jfine[j] = 1;
+        }
+    }
+    return AC_OK;
+}
+
+}  // namespace
+
+AC_API int ac_sdf_stencil_forward(const ac_field *field, const float *x, uint32_t B, float bound, float eps, float *out16, float *grad,
+                                  ac_stream_t stream)
+{
+    if (B == 0) return AC_OK;
+    if (!x || !out16 || !grad || !(eps > 0.0f)) { ac::set_error("sdf_stencil_forward: NULL buffer or eps <= 0"); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = prep_args(a, field, bound, eps)) return rc;
+    const size_t lds_bytes = FWD_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_stencil_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    uint32_t blocks = ((B + 15) / 16 + TW - 1) / TW;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sdf_stencil_fwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, B, eps, out16, grad);
+    return ac::check_launch("sdf_stencil_forward");
+}
+
+AC_API size_t ac_sdf_stencil_backward_scratch(uint32_t B)
+{
+    return (size_t)train_grid(B) * TW * NPART * sizeof(float);
+}
+
+AC_API int ac_sdf_stencil_backward(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
+                                   float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream)
+{
+    if (!gparams) { ac::set_error("sdf_stencil_backward: NULL gparams"); return AC_ERR_BAD_ARG; }
+    if (B == 0) { hipMemsetAsync(gparams, 0, NPART * sizeof(float), (hipStream_t)stream); return AC_OK; }
+    if (!x || !g_out16 || !g_grad || !gfeat || !scratch || !(eps > 0.0f)) { ac::set_error("sdf_stencil_backward: NULL buffer or eps <= 0"); return AC_ERR_BAD_ARG; }
+    const size_t need = ac_sdf_stencil_backward_scratch(B);
+    if (scratch_bytes < need) { ac::set_error("sdf_stencil_backward: scratch of %zu bytes needed, %zu given", need, scratch_bytes); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = prep_args(a, field, bound, eps)) return rc;
+    const size_t lds_bytes = BWD_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_stencil_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    const uint32_t blocks = train_grid(B);
+    hipLaunchKernelGGL(sdf_stencil_bwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
+                       static_cast<float *>(scratch));
+    hipLaunchKernelGGL(sdf_partials_reduce_kernel, dim3((NPART + 255) / 256), dim3(256), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
+                       blocks * TW, gparams);
+    return ac::check_launch("sdf_stencil_backward");
+}

@@ -67,6 +67,14 @@ class NeRFRenderer(nn.Module):
                              wn(self.sdf_net[0]), self.sdf_net[0].bias.detach().contiguous(), wn(self.sdf_net[1]),
                              self.sdf_net[1].bias.detach().contiguous(), wn(self.color_net[0]), wn(self.color_net[1]), wn(self.color_net[2]))
 
+    fused_training = True      # render core's SDF query through the fused forward/backward operator (False: torch MLP over the stencil encoder)
+
+    def _offsets_host(self):
+        oh = getattr(self, "_offsets_cache", None)
+        if oh is None:
+            oh = self._offsets_cache = self.encoder.offsets.tolist()
+        return oh
+
     def _fused_supported(self):
         enc = getattr(self, "encoder", None)
         return (not self.use_viewdirs and self.include_input and self.num_layers == 2 and self.hidden_dim == 64 and self.geo_feat_dim == 15
@@ -253,6 +261,11 @@ class NeRFNetwork(NeRFRenderer):
         """forward_sdf(x) (:627-642) and finite_difference_normals_approximator(x) (:687-704) together: the seven hash encodings
         come from one stencil launch (encoder.forward_stencil) and the SDF MLP runs once over the 7B points.
         Returns (sdf_out [B,16], gradient [B,3])."""
+        if self.fused_training and self._fused_supported() and x.is_cuda:           # one kernel forward, two backward (csrc/sdf_train.hip)
+            l0, l1, enc = self.sdf_net[0], self.sdf_net[1], self.encoder
+            return nsr_ops.sdf_stencil(x, enc.embeddings, torch._weight_norm(l0.weight_v, l0.weight_g, 0), l0.bias,
+                                       torch._weight_norm(l1.weight_v, l1.weight_g, 0), l1.bias, self._offsets_host(), enc.per_level_scale,
+                                       enc.base_resolution, bound, epsilon)
         B = x.shape[0]
         h7 = self.encoder.forward_stencil(x, bound, epsilon)                       # [7,B,32]: x, +x, -x, +y, -y, +z, -z
         pts = x.unsqueeze(0).repeat(7, 1, 1)

@@ -160,6 +160,60 @@ class WarpMesh:
                                 float(threshold), float(geo_threshold), int(bool(use_mesh_guide)), L.ptr(self.accel))
 
 
+class _SdfStencil(torch.autograd.Function):
+    """forward_sdf(x) + finite_difference_normals_approximator(x) of the render core as one fused op with a fused backward
+    (csrc/sdf_train.hip).  Inputs: x [B,3] (no grad), the hash table, the EFFECTIVE sdf_net matrices (weight norm stays in torch)."""
+
+    @staticmethod
+    def forward(ctx, x, table, W1, b1, W2, b2, cfg):
+        offsets, pls, H, bound, eps = cfg
+        x = x.contiguous()
+        dev = x.device
+        dummy = lambda *shape: torch.zeros(shape, dtype=_F32, device=dev)
+        field = Field(table.detach().contiguous(), offsets, pls, H, W1.detach().contiguous(), b1.detach().contiguous(), W2.detach().contiguous(),
+                      b2.detach().contiguous(), dummy(64, 21), dummy(64, 64), dummy(3, 64))
+        B = x.shape[0]
+        out16 = torch.empty((B, 16), dtype=_F32, device=dev)
+        grad = torch.empty((B, 3), dtype=_F32, device=dev)
+        L.check(L.lib().ac_sdf_stencil_forward(C.byref(field.c), x.data_ptr(), B, float(bound), float(eps), out16.data_ptr(), grad.data_ptr(),
+                                               L.current_stream(dev)), "sdf_stencil_forward")
+        ctx.save_for_backward(x, table, W1, b1, W2, b2)
+        ctx.cfg = cfg
+        return out16, grad
+
+    @staticmethod
+    def backward(ctx, g_out, g_grad):
+        import numpy as np
+        x, table, W1, b1, W2, b2 = ctx.saved_tensors
+        offsets, pls, H, bound, eps = ctx.cfg
+        dev = x.device
+        dummy = lambda *shape: torch.zeros(shape, dtype=_F32, device=dev)
+        field = Field(table.detach().contiguous(), offsets, pls, H, W1.detach().contiguous(), b1.detach().contiguous(), W2.detach().contiguous(),
+                      b2.detach().contiguous(), dummy(64, 21), dummy(64, 64), dummy(3, 64))
+        B = x.shape[0]
+        g_out = g_out.contiguous().float(); g_grad = g_grad.contiguous().float()
+        gfeat = torch.empty((7, 16, B, 2), dtype=_F32, device=dev)
+        gparams = torch.empty(64 * 36 + 16 * 64 + 16, dtype=_F32, device=dev)
+        nbytes = int(L.lib().ac_sdf_stencil_backward_scratch(B))
+        scratch = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        st = L.current_stream(dev)
+        L.check(L.lib().ac_sdf_stencil_backward(C.byref(field.c), x.data_ptr(), g_out.data_ptr(), g_grad.data_ptr(), B, float(bound), float(eps),
+                                                gfeat.data_ptr(), gparams.data_ptr(), scratch.data_ptr(), nbytes, st), "sdf_stencil_backward")
+        g_table = torch.zeros_like(table)
+        oh = np.asarray(offsets, dtype=np.int32)
+        L.check(L.lib().ac_hash_stencil_backward(gfeat.data_ptr(), x.data_ptr(), oh.ctypes.data, g_table.data_ptr(), B, 2, 16, field.S, H, float(eps),
+                                                 float(bound), st), "hash_stencil_backward")
+        gW1b = gparams[:64 * 36].view(64, 36)
+        return (None, g_table, gW1b[:, :35].contiguous(), gW1b[:, 35].contiguous(), gparams[64 * 36:64 * 36 + 1024].view(16, 64),
+                gparams[64 * 36 + 1024:], None)
+
+
+def sdf_stencil(x, table, W1, b1, W2, b2, offsets, per_level_scale, base_resolution, bound, eps):
+    """-> (sdf_out [B,16], gradient [B,3]); differentiable w.r.t. table, W1, b1, W2, b2"""
+    cfg = ([int(v) for v in offsets], per_level_scale, int(base_resolution), float(bound), float(eps))
+    return _SdfStencil.apply(x, table, W1, b1, W2, b2, cfg)
+
+
 def field_sdf(field, x, bound):
     """forward_sdf (instant_nsr.py:627-642): x [B,3] -> [B,16] (sdf, 15 features)"""
     x = _chk(x.reshape(-1, 3), "x")

@@ -215,6 +215,21 @@ int ac_hash_stencil_forward(const float *x, const float *embeddings, const int32
 int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
                              uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream);
 
+/* ---- fused SDF query of the differentiable render core (training path): forward_sdf(x) (models/instant_nsr.py:627-642) and
+ * finite_difference_normals_approximator(x) (:687-704), i.e. 7 hash-encoder + MLP evaluations per sample, in one kernel each way.
+ * forward : x [B,3] (clamped to the bound) -> out16 [B,16] = forward_sdf(x), grad [B,3] = the finite-difference gradient (eps > 0);
+ *           bit-identical to the values ac_render_rays computes internally.
+ * backward: (x, g_out16 [B,16], g_grad [B,3]) -> gfeat [7,16,B,2]: the gradient w.r.t. the hash features of the 7 stencil points in
+ *           the layout ac_hash_stencil_backward consumes (the table scatter stays there), and gparams [3344] =
+ *           dW1 [64][36] (column 35 = db1, columns 0..34 = the 35 input columns of sdf_net.0) | dW2 [16][64] | db2 [16]
+ *           w.r.t. the EFFECTIVE (weight-normed) matrices of `field`.  The forward is recomputed per tile; no activations are stored.
+ *           scratch: ac_sdf_stencil_backward_scratch(B) bytes (per-wave partial sums, reduced deterministically). */
+int ac_sdf_stencil_forward(const ac_field *field, const float *x, uint32_t B, float bound, float eps, float *out16, float *grad,
+                           ac_stream_t stream);
+size_t ac_sdf_stencil_backward_scratch(uint32_t B);
+int ac_sdf_stencil_backward(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
+                            float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream);
+
 /* ---- posed-space rendering: NeRFRenderer.run(render_can=False, verts, faces, Ts, use_mesh_guide)
  * models/instant_nsr.py:147-172 (mesh-guided near/far, warp of the coarse samples), :198-203 (warp of the mid points),
  * :246-249 (alpha mask).  The reference moves the samples to the CPU for libigl twice per batch; here the whole sequence

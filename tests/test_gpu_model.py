@@ -132,3 +132,37 @@ def test_posed_render_matches_reference_render():
     assert rgb.shape == (256, 3) and np.abs(rgb.cpu().numpy()[1:] - g["guide_image"][1:]).max() <= 1e-3
     with pytest.raises(NotImplementedError):
         net.render(ro[None], rd[None], num_steps=32, bound=1.6, upsample_steps=32, render_can=False, verts=verts, faces=faces, Ts=Ts)   # grad mode
+
+
+def test_fused_sdf_query_matches_autograd_formulation():
+    """sdf_stencil (csrc/sdf_train.hip) against the torch formulation (stencil encoder + nn.Linear/Softplus autograd): values and the
+    gradients w.r.t. the hash table and every sdf_net parameter, for a loss that uses all 16 outputs and the finite-difference normals"""
+    net, _ = golden_net(train=True)
+    rs = np.random.RandomState(4)
+    pts = rs.uniform(-1.3, 1.3, size=(5000, 3)).astype(np.float32)
+    pts[:50] = np.sign(pts[:50]) * 1.6                                   # on the bound: clamped offsets
+    x = torch.from_numpy(pts).to(DEV)
+    w16 = torch.from_numpy(rs.normal(size=(1, 16)).astype(np.float32)).to(DEV)
+    w3 = torch.from_numpy(rs.normal(size=(5000, 3)).astype(np.float32)).to(DEV)
+
+    def run(fused):
+        net.fused_training = fused
+        net.zero_grad()
+        s, g = net.forward_sdf_stencil(x, 1.6, 0.005)
+        loss = (s * w16).sum() + (g * w3).sum() * 0.01 + ((g.norm(dim=-1) - 1) ** 2).mean()
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        return s.detach(), g.detach(), grads
+    s1, g1, G1 = run(True)
+    s0, g0, G0 = run(False)
+    assert torch.allclose(s1, s0, atol=3e-6, rtol=1e-5) and torch.allclose(g1, g0, atol=3e-3, rtol=1e-3)
+    assert set(G1) == set(G0) and "encoder.embeddings" in G1 and "sdf_net.0.weight_v" in G1 and "sdf_net.1.bias" in G1
+    for k in G0:
+        scale = G0[k].abs().max().item()
+        assert scale > 0, k
+        err = (G1[k] - G0[k]).abs().max().item()
+        assert err <= 2e-3 * scale, (k, err, scale)
+    # bit-identical to the stand-alone field query (== oracle) for the value part
+    from avatarcraft_amd import nsr_ops
+    f = net._field()
+    assert torch.equal(s1, nsr_ops.field_sdf(f, x, 1.6))
