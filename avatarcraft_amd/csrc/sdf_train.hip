@@ -274,13 +274,23 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
     }
 }
 
-__global__ __launch_bounds__(256) void sdf_partials_reduce_kernel(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ out)
+// out[i] = sum over waves of partials[w][i]: 64 outputs x 16 wave slices per workgroup, fixed summation order (deterministic)
+__global__ __launch_bounds__(1024) void sdf_partials_reduce_kernel(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint32_t)NPART) return;
+    __shared__ float red[16][64];
+    const uint32_t o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64 + o;
     float s = 0.0f;
-    for (uint32_t w = 0; w < nwaves; ++w) s += partials[(size_t)w * NPART + i];
-    out[i] = s;
+    if (i < (uint32_t)NPART)
+        for (uint32_t w = sl; w < nwaves; w += 16) s += partials[(size_t)w * NPART + i];
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < (uint32_t)NPART) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][o];
+        out[i] = t;
+    }
 }
 
 uint32_t train_grid(uint32_t B)
@@ -344,7 +354,7 @@ AC_API int ac_sdf_stencil_backward(const ac_field *field, const float *x, const 
     const uint32_t blocks = train_grid(B);
     hipLaunchKernelGGL(sdf_stencil_bwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
                        static_cast<float *>(scratch));
-    hipLaunchKernelGGL(sdf_partials_reduce_kernel, dim3((NPART + 255) / 256), dim3(256), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
+    hipLaunchKernelGGL(sdf_partials_reduce_kernel, dim3((NPART + 63) / 64), dim3(1024), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
                        blocks * TW, gparams);
     return ac::check_launch("sdf_stencil_backward");
 }
