@@ -157,7 +157,8 @@ __device__ __forceinline__ void scatter8_runs(float2 *__restrict__ gg, const Lev
 // fine_mask bit l: eps can reach a non-neighbouring cell on level l -> the seven points scatter independently
 __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ x,
                                                                float *__restrict__ grad_grid, uint32_t B, ac::LevelTable lt, float eps,
-                                                               float bound, float two_bound, uint32_t fine_mask)
+                                                               float bound, float two_bound, uint32_t fine_mask, float *__restrict__ priv,
+                                                               uint32_t n_priv, uint32_t priv_entries, uint32_t n_copies)
 {
     const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = b0 < B;
@@ -165,7 +166,10 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
     const int lane = threadIdx.x & 63;
     const uint32_t level = blockIdx.y, Lc = lt.L;
     const LevelC L = level_of(lt, level);
-    float2 *gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
+    // the small dense levels take bursts of same-address atomics from neighbouring rays: spread them over n_copies private
+    // copies (one per workgroup, round robin), summed into the table by priv_reduce_kernel
+    float2 *gg = (level < n_priv) ? reinterpret_cast<float2 *>(priv) + (size_t)(blockIdx.x % n_copies) * priv_entries + lt.offset[level]
+                                  : reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
     const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
     float2 gp[7];
 #pragma unroll
@@ -254,6 +258,16 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
             }
 }
 
+__global__ __launch_bounds__(256) void priv_reduce_kernel(const float *__restrict__ priv, uint32_t n_floats, uint32_t n_copies,
+                                                          float *__restrict__ grad_grid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats) return;
+    float s = 0.0f;
+    for (uint32_t c = 0; c < n_copies; ++c) s += priv[(size_t)c * n_floats + i];
+    if (s != 0.0f) grad_grid[i] += s;
+}
+
 int check(const char *who, uint32_t C, uint32_t L, const int32_t *offsets_host, float eps, float bound)
 {
     if (C != 2) { ac::set_error("%s: level_dim must be 2, got %u", who, C); return AC_ERR_BAD_ARG; }
@@ -277,8 +291,25 @@ AC_API int ac_hash_stencil_forward(const float *x, const float *embeddings, cons
     return ac::check_launch("hash_stencil_forward");
 }
 
+// entries of the leading dense levels that are worth privatising (none if the caller gives no scratch)
+static uint32_t priv_levels(const ac::LevelTable &lt, uint32_t L, uint32_t &entries)
+{
+    uint32_t n = 0; entries = 0;
+    while (n < L && !lt.hashed[n] && lt.size[n] <= (1u << 18) && lt.offset[n] == entries) { entries += lt.size[n]; ++n; }
+    return n;
+}
+
+AC_API size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_copies)
+{
+    if (!offsets_host || L == 0 || L > AC_MAX_LEVELS) return 0;
+    ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
+    uint32_t entries; priv_levels(lt, L, entries);
+    return (size_t)entries * 8 * n_copies;
+}
+
 AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
-                                    uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream)
+                                    uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
+                                    ac_stream_t stream)
 {
     if (int rc = check("hash_stencil_backward", C, L, offsets_host, eps, bound)) return rc;
     if (B == 0) return AC_OK;
@@ -290,7 +321,18 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
         const double cells = (double)eps / (double)two_bound * (double)lt.scale[l];
         if (!(cells * 1.001 + 1e-3 < 1.0)) fine_mask |= 1u << l;
     }
+    uint32_t entries = 0, n_priv = 0, n_copies = 1;
+    if (scratch) {
+        n_priv = priv_levels(lt, L, entries);
+        n_copies = entries ? (uint32_t)(scratch_bytes / ((size_t)entries * 8)) : 0;
+        if (n_copies > 64) n_copies = 64;
+        if (n_copies < 2) { n_priv = 0; n_copies = 1; }
+        else hipMemsetAsync(scratch, 0, (size_t)entries * 8 * n_copies, (hipStream_t)stream);
+    }
     hipLaunchKernelGGL(hash_stencil_bwd_kernel, dim3((B + 255) / 256, L), dim3(256), 0, (hipStream_t)stream, grad, x, grad_embeddings, B, lt, eps,
-                       bound, two_bound, fine_mask);
+                       bound, two_bound, fine_mask, static_cast<float *>(scratch), n_priv, entries, n_copies);
+    if (n_priv)
+        hipLaunchKernelGGL(priv_reduce_kernel, dim3((entries * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
+                           entries * 2, n_copies, grad_embeddings);
     return ac::check_launch("hash_stencil_backward");
 }

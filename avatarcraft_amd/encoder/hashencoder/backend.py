@@ -13,6 +13,19 @@ def _floating(t, name):
         raise RuntimeError(f"{name} must be a float32 tensor")
 
 
+PRIVATE_COPIES = 16         # private copies of the small dense levels in the stencil backward (same-address atomic bursts)
+_SCRATCH = {}
+
+
+def stencil_scratch(offsets_host, L_, S, H, device):
+    """(tensor, nbytes): device scratch for ac_hash_stencil_backward, cached per (device, layout); (None, 0) if not needed"""
+    key = (str(device), int(offsets_host[-1]), L_, S, H)
+    if key not in _SCRATCH:
+        nbytes = int(L.lib().ac_hash_stencil_backward_scratch(offsets_host.ctypes.data, L_, S, H, PRIVATE_COPIES))
+        _SCRATCH[key] = (torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None, nbytes)
+    return _SCRATCH[key]
+
+
 class _Backend:
     @staticmethod
     def _offsets_host(offsets):
@@ -63,9 +76,10 @@ class _Backend:
     def hash_stencil_backward(grad, x, offsets, grad_embeddings, B, C, L_, S, H, eps, bound):
         L.require_cuda(grad, x, offsets, grad_embeddings)
         oh = _Backend._offsets_host(offsets)
+        scratch, nbytes = stencil_scratch(oh, L_, float(np.float32(S)), H, x.device)
         L.check(L.lib().ac_hash_stencil_backward(grad.data_ptr(), x.data_ptr(), oh.ctypes.data, grad_embeddings.data_ptr(), B, C, L_,
-                                                 float(np.float32(S)), H, float(eps), float(bound), L.current_stream(x.device)),
-                "hash_stencil_backward")
+                                                 float(np.float32(S)), H, float(eps), float(bound), L.ptr(scratch), nbytes,
+                                                 L.current_stream(x.device)), "hash_stencil_backward")
 
 
 _backend = _Backend()

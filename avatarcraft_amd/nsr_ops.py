@@ -201,8 +201,10 @@ class _SdfStencil(torch.autograd.Function):
                                                 gfeat.data_ptr(), gparams.data_ptr(), scratch.data_ptr(), nbytes, st), "sdf_stencil_backward")
         g_table = torch.zeros_like(table)
         oh = np.asarray(offsets, dtype=np.int32)
+        from .encoder.hashencoder.backend import stencil_scratch
+        hs, hbytes = stencil_scratch(oh, 16, field.S, H, dev)
         L.check(L.lib().ac_hash_stencil_backward(gfeat.data_ptr(), x.data_ptr(), oh.ctypes.data, g_table.data_ptr(), B, 2, 16, field.S, H, float(eps),
-                                                 float(bound), st), "hash_stencil_backward")
+                                                 float(bound), L.ptr(hs), hbytes, st), "hash_stencil_backward")
         gW1b = gparams[:64 * 36].view(64, 36)
         return (None, g_table, gW1b[:, :35].contiguous(), gW1b[:, 35].contiguous(), gparams[64 * 36:64 * 36 + 1024].view(16, 64),
                 gparams[64 * 36 + 1024:], None)

@@ -209,11 +209,16 @@ int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *f
  * These two entry points evaluate / back-propagate the seven points of every sample in one launch; the backward combines the
  * table gradients of the seven points in registers before its atomics (same sums as 7 x ac_hash_encode_backward).
  * x [B,3] world space, clamped to [-bound, bound]; point order x, +x, -x, +y, -y, +z, -z; outputs / grad [7, L, B, C], C = 2, D = 3;
- * grad_embeddings is accumulated into (zero it first). */
+ * grad_embeddings is accumulated into (zero it first).
+ */
 int ac_hash_stencil_forward(const float *x, const float *embeddings, const int32_t *offsets_host, float *outputs, uint32_t B,
                             uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream);
+/* scratch (optional, NULL = none): ac_hash_stencil_backward_scratch(offsets_host, L, S, H, n_copies) bytes for n_copies >= 2 private
+ * copies of the small dense levels, which otherwise take bursts of same-address atomics from neighbouring rays. */
+size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_copies);
 int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
-                             uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream);
+                             uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
+                             ac_stream_t stream);
 
 /* ---- fused SDF query of the differentiable render core (training path): forward_sdf(x) (models/instant_nsr.py:627-642) and
  * finite_difference_normals_approximator(x) (:687-704), i.e. 7 hash-encoder + MLP evaluations per sample, in one kernel each way.

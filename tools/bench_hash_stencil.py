@@ -36,7 +36,9 @@ for l, sc in enumerate(scales):
     offs = np.array([0, size], np.int32)
     gg = torch.zeros(size, 2, device=dev)
     grad = torch.randn(7, 1, B, 2, device=dev)
-    tm = timeit(lambda: L.check(L.lib().ac_hash_stencil_backward(grad.data_ptr(), x.data_ptr(), offs.ctypes.data, gg.data_ptr(), B, 2, 1, 0.0, H, 0.005, 1.6, st)))
+    nb = int(L.lib().ac_hash_stencil_backward_scratch(offs.ctypes.data, 1, 0.0, H, int(os.environ.get('COPIES', 16))))
+    scr = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
+    tm = timeit(lambda: L.check(L.lib().ac_hash_stencil_backward(grad.data_ptr(), x.data_ptr(), offs.ctypes.data, gg.data_ptr(), B, 2, 1, 0.0, H, 0.005, 1.6, scr.data_ptr() if scr is not None else None, nb, st)))
     tot += tm
     print(f"level {l:2d} scale {sc:7.1f} size {size:7d} {'dense' if (H+1)**3 <= size else 'hash '}  {tm:7.3f} ms")
 print("sum", tot)
