@@ -2,7 +2,7 @@
 //
 // Replaces two CPU stages of the reference's animation path (render_warp.py -> NeRFRenderer.run with render_can=False):
 //   geometry_guided_near_far_torch (utils/ray_utils.py:277-294): O(N*V) with three [N,V,3] temporaries (0.68 GB each at
-//     N=8192) -> mesh_near_far_kernel: one lane per ray, the 6890 vertices streamed through LDS tiles, no temporaries;
+//     N=8192) -> mesh_near_far_kernel: lane = ray, 16 waves share 64 rays and split the vertices (LDS tiles), no temporaries;
 //   warp_samples_to_canonical (utils/ray_utils.py:62-90): libigl closest-point query + numpy fp64 4x4 inverse on the CPU
 //     with two PCIe round trips per ray batch (models/instant_nsr.py:166-172,198-203) -> warp_samples_kernel: one lane
 //     per sample, the triangle soup streamed through LDS tiles, exact closest point / barycentric blend / 4x4 inverse in
@@ -17,12 +17,17 @@ namespace {
 constexpr int VT = 1024;   // vertices per LDS tile (12 KB)
 constexpr int FT = 512;    // faces per LDS tile (9 floats each, 18 KB)
 
-__global__ __launch_bounds__(256) void mesh_near_far_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                            const float *__restrict__ verts, uint32_t N, uint32_t V, float r2,
-                                                            float *__restrict__ near, float *__restrict__ far)
+// one workgroup = 64 rays x 16 waves: every wave scans a 1/16 slice of each vertex tile for the same 64 rays (lane = ray), the
+// per-wave min / max meet in LDS.  min / max are exact and order independent: the result does not depend on the split.
+constexpr int NF_WAVES = 16;
+__global__ __launch_bounds__(NF_WAVES * 64) void mesh_near_far_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                      const float *__restrict__ verts, uint32_t N, uint32_t V, float r2,
+                                                                      float *__restrict__ near, float *__restrict__ far)
 {
     __shared__ float sv[VT * 3];
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float snr[NF_WAVES][64], sfr[NF_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * 64 + lane;
     const bool live = n < N;
     const uint32_t nn = live ? n : 0;
     const float ox = rays_o[3 * nn], oy = rays_o[3 * nn + 1], oz = rays_o[3 * nn + 2];
@@ -33,7 +38,7 @@ __global__ __launch_bounds__(256) void mesh_near_far_kernel(const float *__restr
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cnt * 3; i += blockDim.x) sv[i] = verts[(size_t)v0 * 3 + i];
         __syncthreads();
-        for (uint32_t v = 0; v < cnt; ++v) {
+        for (uint32_t v = wave; v < cnt; v += NF_WAVES) {
             const float x = sv[3 * v] - ox, y = sv[3 * v + 1] - oy, z = sv[3 * v + 2] - oz;
             const float z0 = (x * dx + y * dy) + z * dz_;
             const float nrm = __builtin_sqrtf((x * x + y * y) + z * z);
@@ -43,7 +48,13 @@ __global__ __launch_bounds__(256) void mesh_near_far_kernel(const float *__restr
             if (b == b && b > fr) fr = b;
         }
     }
-    if (live) { near[n] = nr; far[n] = fr; }
+    snr[wave][lane] = nr; sfr[wave][lane] = fr;
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int w = 1; w < NF_WAVES; ++w) { const float a = snr[w][lane], b = sfr[w][lane]; nr = a < nr ? a : nr; fr = b > fr ? b : fr; }
+        near[n] = nr; far[n] = fr;
+    }
 }
 
 #define DOT3(u, v) ((u)[0] * (v)[0] + (u)[1] * (v)[1] + (u)[2] * (v)[2])
@@ -395,45 +406,39 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
     const uint32_t npts = (P - wave * 64 < 64u) ? P - wave * 64 : 64u;            // wave-uniform
     for (uint32_t j = 0; j < npts; ++j) {
         const double q[3] = { __shfl(p[0], (int)j), __shfl(p[1], (int)j), __shfl(p[2], (int)j) };
-        // 1. upper bound from the representative vertices
-        double ub = __builtin_inf();
+        // 1. upper bound from the representative vertices, lower bound of every tile (kept in registers)
+        double ub = __builtin_inf(), lb[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const double ex = q[0] - (double)bx[it][6], ey = q[1] - (double)bx[it][7], ez = q[2] - (double)bx[it][8];
             const double u = ex * ex + ey * ey + ez * ez;
             ub = u < ub ? u : ub;                    // padding tiles hold +inf
+            double l = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double lo = (double)bx[it][k] - q[k], hi = q[k] - (double)bx[it][3 + k];
+                double d = lo > hi ? lo : hi;
+                d = d > 0.0 ? d : 0.0;
+                l += d * d;
+            }
+            lb[it] = l;                              // +inf for padding tiles
         }
         ub = wave_min_f64(ub);
         const double lim = ub * (1.0 + 1e-9);
         // 2./3. candidates, two tiles per step
         double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
         int bid = 0x7fffffff;
-#pragma unroll 1
-        for (uint32_t it = 0; it < nit; ++it) {
-            float b9[9];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) {
-                float v = bx[0][e];
-#pragma unroll
-                for (int u2 = 1; u2 < 8; ++u2) v = (it == (uint32_t)u2) ? bx[u2][e] : v;
-                b9[e] = v;
-            }
-            double lb = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double lo = (double)b9[k] - q[k], hi = q[k] - (double)b9[3 + k];
-                double d = lo > hi ? lo : hi;
-                d = d > 0.0 ? d : 0.0;
-                lb += d * d;
-            }
-            unsigned long long cand = __ballot(lb <= lim);         // NaN/inf boxes of padding tiles never qualify
+        for (int it = 0; it < 8; ++it) {
+            if ((uint32_t)it >= nit) break;                            // wave-uniform
+            unsigned long long cand = __ballot(lb[it] <= lim);
             while (cand) {
                 const int t0 = __builtin_ctzll(cand); cand &= cand - 1;
                 int t1 = -1;
                 if (cand) { t1 = __builtin_ctzll(cand); cand &= cand - 1; }
-                const int tl = lane < 32 ? t0 : t1;
-                if (tl >= 0) {
-                    const uint32_t slot = (it * 64 + (uint32_t)tl) * TILE_F + (uint32_t)(lane & 31);
+                const int tmine = lane < 32 ? t0 : t1;
+                if (tmine >= 0) {
+                    const uint32_t slot = ((uint32_t)it * 64 + (uint32_t)tmine) * TILE_F + (uint32_t)(lane & 31);
                     const float *tp = av.tri + (size_t)slot * 9;
                     const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
                                  c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
@@ -464,7 +469,7 @@ AC_API int ac_mesh_near_far(const float *rays_o, const float *rays_d, const floa
     if (N == 0) return AC_OK;
     if (!rays_o || !rays_d || !verts || !near || !far || V == 0) { ac::set_error("mesh_near_far: NULL buffer or empty mesh"); return AC_ERR_BAD_ARG; }
     const float r2 = (float)((double)geo_threshold * (double)geo_threshold);
-    hipLaunchKernelGGL(mesh_near_far_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, verts, N, V, r2, near, far);
+    hipLaunchKernelGGL(mesh_near_far_kernel, dim3((N + 63) / 64), dim3(NF_WAVES * 64), 0, (hipStream_t)stream, rays_o, rays_d, verts, N, V, r2, near, far);
     return ac::check_launch("mesh_near_far");
 }
 
