@@ -1,8 +1,8 @@
 # quick PMC profile of the bench (run through gpurun): tools/prof_quick.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$1; rm -rf $O; mkdir -p $O
-B="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python $R/bench.py --steps 32 --warmup 4 --no-cpu-baseline > $O/kt.log 2>&1
+B="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --sds-steps 0 --posed-frames 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python $R/bench.py --steps 32 --warmup 4 --no-cpu-baseline --sds-steps 0 --posed-frames 0 > $O/kt.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/sq -o p -- $B > $O/sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM --output-format csv -d $O/sq2 -o p -- $B > $O/sq2.log 2>&1
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/tc -o p -- $B > $O/tc.log 2>&1
