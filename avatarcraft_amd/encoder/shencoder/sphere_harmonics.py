@@ -1,60 +1,65 @@
-"""SHEncoder module: drop-in for encoder/shencoder/sphere_harmonics.py:11-83."""
+"""Real spherical-harmonics direction encoding (degree <= 8) on the MI355X: module-level counterpart of the reference's
+encoder/shencoder/sphere_harmonics.py:11-83 (same class name, constructor, attributes and call convention; the work is done by
+ac_sh_encode_forward / ac_sh_encode_backward, csrc/shencoder.hip)."""
 import torch
-import torch.nn as nn
-from torch.autograd import Function
-from torch.autograd.function import once_differentiable
+from torch import nn
 
 from .backend import _backend
 
+_MAX_DEGREE = 8
 
-class _sh_encoder(Function):
-    @staticmethod
-    def forward(ctx, inputs, degree, calc_grad_inputs=False):
-        inputs = inputs.contiguous()
-        B, input_dim = inputs.shape
-        output_dim = degree ** 2
-        outputs = torch.empty(B, output_dim, dtype=inputs.dtype, device=inputs.device)
-        if calc_grad_inputs:
-            dy_dx = torch.empty(B, input_dim * output_dim, dtype=inputs.dtype, device=inputs.device)
-        else:
-            dy_dx = torch.empty(1, dtype=inputs.dtype, device=inputs.device)
-        _backend.sh_encode_forward(inputs, outputs, B, input_dim, degree, calc_grad_inputs, dy_dx)
-        ctx.save_for_backward(inputs, dy_dx)
-        ctx.dims = [B, input_dim, degree]
-        ctx.calc_grad_inputs = calc_grad_inputs
-        return outputs
+
+def _new(like, *shape):
+    return torch.empty(shape, dtype=like.dtype, device=like.device)
+
+
+class SphericalHarmonicsFn(torch.autograd.Function):
+    """y[b, :] = the degree**2 real SH basis functions at direction x[b, :]; optionally keeps dy/dx for the backward"""
 
     @staticmethod
-    @once_differentiable
-    def backward(ctx, grad):
-        if not ctx.calc_grad_inputs:
+    def forward(ctx, directions, degree, want_input_grad):
+        x = directions.contiguous()
+        n, d = x.shape
+        n_out = degree * degree
+        y = _new(x, n, n_out)
+        jac = _new(x, n, d * n_out) if want_input_grad else _new(x, 1)
+        _backend.sh_encode_forward(x, y, n, d, degree, want_input_grad, jac)
+        ctx.want_input_grad = bool(want_input_grad)
+        if ctx.want_input_grad:
+            ctx.save_for_backward(x, jac)
+            ctx.shape = (n, d, degree)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        if not ctx.want_input_grad:
             return None, None, None
-        grad = grad.contiguous()
-        inputs, dy_dx = ctx.saved_tensors
-        B, input_dim, degree = ctx.dims
-        grad_inputs = torch.zeros_like(inputs)
-        _backend.sh_encode_backward(grad, inputs, B, input_dim, degree, dy_dx, grad_inputs)
-        return grad_inputs, None, None
+        x, jac = ctx.saved_tensors
+        n, d, degree = ctx.shape
+        dx = torch.zeros_like(x)
+        _backend.sh_encode_backward(dy.contiguous(), x, n, d, degree, jac, dx)
+        return dx, None, None
 
 
-sh_encode = _sh_encoder.apply
+def sh_encode(inputs, degree, calc_grad_inputs=False):
+    return SphericalHarmonicsFn.apply(inputs, degree, calc_grad_inputs)
 
 
 class SHEncoder(nn.Module):
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
-        self.input_dim = input_dim
-        self.degree = degree
-        self.output_dim = degree ** 2
-        assert self.input_dim == 3, "SH encoder only support input dim == 3"
-        assert self.degree > 0 and self.degree <= 8, "SH encoder only supports degree in [1, 8]"
+        assert input_dim == 3, "SH encoder only support input dim == 3"
+        assert 0 < degree <= _MAX_DEGREE, "SH encoder only supports degree in [1, 8]"
+        self.input_dim, self.degree, self.output_dim = input_dim, degree, degree * degree
+
+    def extra_repr(self):
+        return f"input_dim={self.input_dim} degree={self.degree}"
 
     def __repr__(self):
-        return f"SHEncoder: input_dim={self.input_dim} degree={self.degree}"
+        return f"SHEncoder: {self.extra_repr()}"
 
     def forward(self, inputs, size=1):
-        inputs = inputs / size
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.reshape(-1, self.input_dim)
-        outputs = sh_encode(inputs, self.degree, inputs.requires_grad)
-        return outputs.reshape(prefix_shape + [self.output_dim])
+        lead = inputs.shape[:-1]
+        flat = (inputs / size).reshape(-1, self.input_dim)
+        return sh_encode(flat, self.degree, flat.requires_grad).reshape(*lead, self.output_dim)
