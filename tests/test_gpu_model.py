@@ -166,3 +166,33 @@ def test_fused_sdf_query_matches_autograd_formulation():
     from avatarcraft_amd import nsr_ops
     f = net._field()
     assert torch.equal(s1, nsr_ops.field_sdf(f, x, 1.6))
+
+
+@pytest.mark.parametrize("B", [0, 1, 17, 1000])
+def test_fused_sdf_query_ragged_sizes(B):
+    """tile tails (B not a multiple of 16), a single sample and the empty batch"""
+    from avatarcraft_amd import nsr_ops
+    net, _ = golden_net(train=True)
+    rs = np.random.RandomState(B)
+    x = torch.from_numpy(rs.uniform(-1.5, 1.5, size=(B, 3)).astype(np.float32)).to(DEV)
+    net.fused_training = True
+    net.zero_grad()
+    s, g = net.forward_sdf_stencil(x, 1.6, 0.005)
+    assert s.shape == (B, 16) and g.shape == (B, 3)
+    (s.sum() + g.sum()).backward()
+    gt = net.encoder.embeddings.grad
+    assert gt is not None and torch.isfinite(gt).all()
+    if B == 0:
+        assert float(gt.abs().max()) == 0.0 and float(net.sdf_net[0].weight_v.grad.abs().max()) == 0.0
+        return
+    f = net._field()
+    assert torch.equal(s.detach(), nsr_ops.field_sdf(f, x, 1.6))
+    net.fused_training = False
+    g_fused = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad()
+    s0, g0 = net.forward_sdf_stencil(x, 1.6, 0.005)
+    (s0.sum() + g0.sum()).backward()
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            assert (g_fused[k] - p.grad).abs().max() <= 2e-3 * max(float(p.grad.abs().max()), 1e-12), k
+    net.fused_training = True

@@ -323,3 +323,19 @@ def test_warp_accel_equals_brute_force(oracle, nlat, nlon):
     assert np.array_equal(b["can"][:600].cpu().numpy().view(np.uint64), can_o.view(np.uint64))
     # too small a buffer / too many faces are refused
     assert Lb.lib().ac_warp_accel_build(tv.data_ptr(), tf.data_ptr(), V, F, acc.data_ptr(), 100, st) != 0
+
+
+@pytest.mark.parametrize("P", [1, 63, 65])
+def test_warp_tiny_point_sets(oracle, P):
+    from avatarcraft_amd import ray_utils as RY
+    from tests.common import make_body
+    verts, faces, Ts = make_body(n_lat=6, n_lon=9)
+    rs = np.random.RandomState(P)
+    pts = rs.uniform(-1, 1, size=(1, P, 3)).astype(np.float32)
+    can_o, clo_o, d2_o, fid_o, m_o = oracle.warp_samples(pts.reshape(-1, 3), verts, faces, Ts, 0.05)
+    for accel in (True, False):
+        can, dirs, clo, mask = RY.warp_samples_to_canonical(T(pts), T(verts), torch.from_numpy(faces).to(DEV), torch.from_numpy(Ts).to(DEV), 0.05, accel=accel)
+        assert np.array_equal(can.cpu().numpy().reshape(-1, 3).view(np.uint64), can_o.view(np.uint64))
+        assert np.array_equal(mask.cpu().numpy(), m_o)
+    empty = RY.warp_samples_to_canonical(torch.empty(0, 4, 3, device=DEV), T(verts), torch.from_numpy(faces).to(DEV), torch.from_numpy(Ts).to(DEV), 0.05)
+    assert empty[0].shape == (0, 4, 3)

@@ -204,3 +204,12 @@ def test_warped_render_bad_arguments(env):
     rc = L.lib().ac_render_rays_warped(C.byref(env["f"].c), C.byref(op), t(ro).data_ptr(), t(rd).data_ptr(), None, None, lz.data_ptr(), lu.data_ptr(),
                                        C.byref(wm.c), sc.data_ptr(), 1024, C.byref(o), None)
     assert rc != 0 and b"scratch" in L.lib().ac_last_error()
+
+
+@pytest.mark.parametrize("n", [1, 3, 13])
+def test_warped_render_small_batches(env, n):
+    """ray counts below one workgroup (8 rays) and not a multiple of it; a mesh the culling structure does not cover falls back"""
+    ro, rd = make_rays(8, 8, dist=1.8, f=6.0, jitter_seed=4)
+    sel = np.arange(n) * 4 + 9
+    g, r = _warp_both(env, ro[sel], rd[sel], 32, 32, True)
+    _compare_bitwise(g, r, 32)
