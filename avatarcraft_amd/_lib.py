@@ -56,6 +56,7 @@ _SIGS = {
     "ac_composite_rays": ([u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_compact_rays": ([u32, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_render_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_render_out), vp], C.c_int),
+    "ac_sample_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_eikonal_reduce": ([vp, i32, vp, vp], C.c_int),
     "ac_field_sdf": ([C.POINTER(ac_field), vp, u32, f32, vp, vp], C.c_int),
     "ac_field_color": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),

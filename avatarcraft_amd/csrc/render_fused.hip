@@ -87,7 +87,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 if (a.perturb) zi = zi + (a.noise[(size_t)ray * T0 + i] - 0.5f) * sample_dist;
                 if (nup > 0) {
                     float px, py, pz;
-                    if constexpr (MODE == MODE_UPSAMPLE) {
+                    if (MODE == MODE_UPSAMPLE && a.ext_pts) {       // posed space: the warped coarse points (NULL: canonical sampling only)
                         const float *e = a.ext_pts + ((size_t)ray * T0 + i) * 3;
                         px = clampf(e[0], -bound, bound); py = clampf(e[1], -bound, bound); pz = clampf(e[2], -bound, bound);
                     } else {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 const float zmid = (i < T - 1) ? zi + 0.5f * delta : zi;
                 const size_t si = (size_t)ray * T + i;
                 a.zbuf[si] = zi;
-                a.mid_pts[3 * si] = ox + dx * zmid; a.mid_pts[3 * si + 1] = oy + dy * zmid; a.mid_pts[3 * si + 2] = oz + dz * zmid;
+                if (a.mid_pts) { a.mid_pts[3 * si] = ox + dx * zmid; a.mid_pts[3 * si + 1] = oy + dy * zmid; a.mid_pts[3 * si + 2] = oz + dz * zmid; }
             }
             wave_sync();
             continue;
@@ -525,6 +525,25 @@ AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const
 #endif
     launch_render<MODE_FULL>(a, (hipStream_t)stream);
     return ac::check_launch("render_rays");
+}
+
+// the sampling stage alone (coarse z, coarse sdf, NeuS up-sampling): what the reference computes under no_grad before the
+// differentiable render core (instant_nsr.py:155-184)
+AC_API int ac_sample_rays(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d, const float *noise,
+                          const float *lin_z, const float *lin_u, float *z_vals, ac_stream_t stream)
+{
+    if (!op || !z_vals) { ac::set_error("sample_rays: NULL opts/z_vals"); return AC_ERR_BAD_ARG; }
+    ac_render_out dummy{};
+    float sink = 0.0f;                       // check_render_args wants the mandatory outputs non-NULL; this mode never writes them
+    dummy.image = dummy.weights_sum = dummy.depth = dummy.normal_map = dummy.eik = &sink;
+    if (int rc = check_render_args("sample_rays", op, rays_o, rays_d, noise, lin_z, lin_u, &dummy)) return rc;
+    if (op->n_rays <= 0) return AC_OK;
+    RenderArgs a{};
+    if (int rc = fill_render_args(a, field, op, rays_o, rays_d, nullptr, noise, lin_z, lin_u, &dummy)) return rc;
+    a.out = ac_render_out{};
+    a.zbuf = z_vals;
+    launch_render<MODE_UPSAMPLE>(a, (hipStream_t)stream);
+    return ac::check_launch("sample_rays");
 }
 
 // scratch layout of ac_render_rays_warped (byte offsets, 256-byte aligned): near_m, far_m [N] f32; pts, can [N,T,3] f32;

@@ -112,13 +112,13 @@ class NeRFRenderer(nn.Module):
                 raise RuntimeError("render_can=False needs verts, faces and Ts")
             warp = verts if isinstance(verts, nsr_ops.WarpMesh) else nsr_ops.WarpMesh(verts, faces, Ts, device, DEFAULT_GEO_THRESH,
                                                                                       DEFAULT_GEO_THRESH, use_mesh_guide)
+        if needs_grad:                                           # only the sample positions come from the no-grad stage (:176-184)
+            z_vals = nsr_ops.sample_rays(field, ro, rd, num_steps, upsample_steps, bound, noise=noise)
+            return self._render_core_autograd(ro, rd, z_vals, num_steps, upsample_steps, bound, bg, cos_anneal_ratio, normal_epsilon_ratio, B, N)
         out = nsr_ops.render_rays(field, ro, rd, num_steps, upsample_steps, bound, float(inv_s_t.detach().reshape(-1)[0]), bg=bg, noise=noise,
                                   cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp)
-        if not needs_grad:
-            return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
-                    out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])
-        return self._render_core_autograd(ro, rd, out["z_vals"], num_steps, upsample_steps, bound, bg,
-                                          cos_anneal_ratio, normal_epsilon_ratio, B, N)
+        return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
+                out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])
 
     def _render_core_autograd(self, rays_o, rays_d, z_vals, num_steps0, upsample_steps, bound, bg_color, cos_anneal_ratio,
                               normal_epsilon_ratio, B, N):

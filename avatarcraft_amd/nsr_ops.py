@@ -134,6 +134,21 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     return res
 
 
+def sample_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, noise=None):
+    """the no-grad sampling stage of run() only -> z_vals [N, num_steps + upsample_steps] (identical to render_rays' z_vals)"""
+    rays_o = _chk(rays_o.reshape(-1, 3), "rays_o")
+    rays_d = _chk(rays_d.reshape(-1, 3), "rays_d")
+    N, dev = rays_o.shape[0], rays_o.device
+    lin_z, lin_u = linspace_tables(num_steps, dev)
+    if noise is not None:
+        noise = _chk(noise.reshape(N, num_steps), "noise")
+    z = torch.empty((N, num_steps + upsample_steps), dtype=_F32, device=dev)
+    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), 1.0, 1.0, 0.005, int(noise is not None))
+    L.check(L.lib().ac_sample_rays(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(noise), lin_z.data_ptr(),
+                                   lin_u.data_ptr(), z.data_ptr(), L.current_stream(dev)), "sample_rays")
+    return z
+
+
 class WarpMesh:
     """the posed SMPL mesh of one frame + its per-vertex rest->scene transforms, on the device (ac_warp_mesh)"""
 

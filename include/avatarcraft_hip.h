@@ -220,6 +220,12 @@ int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *o
                              uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
                              ac_stream_t stream);
 
+/* The sampling stage of run() alone: coarse z (+ jitter), coarse SDF, 4x NeuS up-sampling -> z_vals [N, num_steps + upsample_steps]
+ * (models/instant_nsr.py:155-184; the reference runs it under no_grad before the differentiable render core).  Same z as
+ * ac_render_rays bit for bit, at a fraction of its cost. */
+int ac_sample_rays(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d, const float *noise,
+                   const float *lin_z, const float *lin_u, float *z_vals, ac_stream_t stream);
+
 /* ---- fused SDF query of the differentiable render core (training path): forward_sdf(x) (models/instant_nsr.py:627-642) and
  * finite_difference_normals_approximator(x) (:687-704), i.e. 7 hash-encoder + MLP evaluations per sample, in one kernel each way.
  * forward : x [B,3] (clamped to the bound) -> out16 [B,16] = forward_sdf(x), grad [B,3] = the finite-difference gradient (eps > 0);
