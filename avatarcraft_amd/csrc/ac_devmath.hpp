@@ -79,52 +79,30 @@ __device__ __forceinline__ float dv_log1p(float x)
 }
 
 // torch.nn.Softplus(beta=100, threshold=20) (reference models/instant_nsr.py:231,591):
-//   softplus_100(x) = max(x, 0) + G(|100 x|),  G(a) = log1p(exp(-a)) / 100 from a 64-piece degree-5 table on [0, 32]
-//   (ac_sp_table.hpp; tools/gen_softplus_table.py) -- no exponential, no division.
-// spg: the table, [64][8] floats (LDS or global).  Bit-identical to oracle/ac_math.h: orc_softplus100.
+//   softplus_100(x) = max(x, 0) + G(|100 x|),  G(a) = log1p(exp(-a)) / 100 from a 128-piece cubic table on [0, 32]
+//   (ac_sp_table.hpp; tools/gen_softplus_table.py) -- no exponential, no division: 14 VALU + one ds_read_b128.
+// spg: the table, [128][4] floats (LDS or global).  Bit-identical to oracle/ac_math.h: orc_softplus100.
 __device__ __forceinline__ float dv_softplus100(const float *__restrict__ spg, float x)
 {
     const float t = x * 100.0f;
     const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
-    int idx = (int)(am * 2.0f);
-    idx = idx > 63 ? 63 : idx;
-    const float v = fma_(-0.5f, (float)idx, am);
-    const float4 c03 = *reinterpret_cast<const float4 *>(spg + idx * 8);
-    const float2 c45 = *reinterpret_cast<const float2 *>(spg + idx * 8 + 4);
-    float q = c45.y;
-    q = fma_(q, v, c45.x); q = fma_(q, v, c03.w); q = fma_(q, v, c03.z); q = fma_(q, v, c03.y); q = fma_(q, v, c03.x);
-    const float r = (x > 0.0f ? x : 0.0f) + q;
-    return (t != t) ? t : r;
+    int idx = (int)(am * 4.0f);
+    idx = idx > 127 ? 127 : idx;
+    const float v = fma_(-0.25f, (float)idx, am);
+    const float4 c = *reinterpret_cast<const float4 *>(spg + idx * 4);
+    float q = c.w;
+    q = fma_(q, v, c.z); q = fma_(q, v, c.y); q = fma_(q, v, c.x);
+    return fma_(x, 0.0f, (x > 0.0f ? x : 0.0f) + q);          // x * 0: NaN / inf propagate, finite x adds an exact zero
 }
 
-// the same softplus on two independent values with packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are
-// IEEE-exact per half, so each half is bit-identical to dv_softplus100)
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat2(float a) { v2f r = { a, a }; return r; }
 
+// two independent values (kept for the call sites that hold accumulator pairs; evaluated as two scalar chains: the table rows of
+// the two halves differ, so packed fma would need register shuffles that cost more than they save)
 __device__ __forceinline__ v2f dv_softplus100_x2(const float *__restrict__ spg, v2f x)
 {
-    const v2f t = x * splat2(100.0f);
-    v2f am; am.x = __builtin_fminf(__builtin_fabsf(t.x), 32.0f); am.y = __builtin_fminf(__builtin_fabsf(t.y), 32.0f);
-    const v2f a2 = am * splat2(2.0f);
-    int i0 = (int)a2.x, i1 = (int)a2.y;
-    i0 = i0 > 63 ? 63 : i0; i1 = i1 > 63 ? 63 : i1;
-    v2f fi; fi.x = (float)i0; fi.y = (float)i1;
-    const v2f v = pk_fma(splat2(-0.5f), fi, am);
-    const float4 a03 = *reinterpret_cast<const float4 *>(spg + i0 * 8), b03 = *reinterpret_cast<const float4 *>(spg + i1 * 8);
-    const float2 a45 = *reinterpret_cast<const float2 *>(spg + i0 * 8 + 4), b45 = *reinterpret_cast<const float2 *>(spg + i1 * 8 + 4);
-    v2f q = { a45.y, b45.y };
-    { v2f c = { a45.x, b45.x }; q = pk_fma(q, v, c); }
-    { v2f c = { a03.w, b03.w }; q = pk_fma(q, v, c); }
-    { v2f c = { a03.z, b03.z }; q = pk_fma(q, v, c); }
-    { v2f c = { a03.y, b03.y }; q = pk_fma(q, v, c); }
-    { v2f c = { a03.x, b03.x }; q = pk_fma(q, v, c); }
-    v2f m; m.x = x.x > 0.0f ? x.x : 0.0f; m.y = x.y > 0.0f ? x.y : 0.0f;
-    const v2f r = m + q;
-    v2f o;
-    o.x = (t.x != t.x) ? t.x : r.x;
-    o.y = (t.y != t.y) ? t.y : r.y;
+    v2f o; o.x = dv_softplus100(spg, x.x); o.y = dv_softplus100(spg, x.y);
     return o;
 }
 

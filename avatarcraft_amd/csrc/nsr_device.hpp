@@ -42,7 +42,7 @@ constexpr int OFF_B1 = OFF_C3F + 16 * 64;        // [64]
 constexpr int OFF_B2 = OFF_B1 + 64;              // [16]
 constexpr int OFF_LVL = OFF_B2 + 16;             // [16 levels][8 words]
 constexpr int OFF_LIN = OFF_LVL + 16 * 8;        // lin_z[64] + lin_u[16]
-constexpr int OFF_SPQ = OFF_LIN + 80;           // softplus G table [64][8]
+constexpr int OFF_SPQ = OFF_LIN + 80;           // softplus G table [128][4]
 constexpr int OFF_WAVE = OFF_SPQ + 512;         // per-wave slabs start here
 constexpr int FE_SLAB = 6 * 8 * 64;                        // hash features of the 6 finite-difference points: [e-1][2j+c][lane]
 constexpr int WAVE_SLAB = 2 * MAXT * 2 + MAXT + 16 + 16 + FE_SLAB;   // zs[2][128], sd[2][128], cdf[128], znew[16], pad, fe
@@ -186,7 +186,7 @@ __device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
     }
     for (int e = threadIdx.x; e < 64; e += blockDim.x) lds[OFF_LIN + e] = e < a.T0 ? a.lin_z[e] : 0.0f;
     for (int e = threadIdx.x; e < 16; e += blockDim.x) lds[OFF_LIN + 64 + e] = a.lin_u ? a.lin_u[e] : 0.0f;
-    for (int e = threadIdx.x; e < 512; e += blockDim.x) lds[OFF_SPQ + e] = AC_SP_G[e >> 3][e & 7];
+    for (int e = threadIdx.x; e < 512; e += blockDim.x) lds[OFF_SPQ + e] = AC_SP_G[e >> 2][e & 3];
 }
 
 // ---- hash-grid features of this lane's 4 levels (HashEncoder.forward + kernel_grid) -------------------

@@ -41,15 +41,14 @@ __device__ __forceinline__ void softplus100_vg(const float *__restrict__ spg, fl
 {
     const float t = x * 100.0f;
     const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
-    int idx = (int)(am * 2.0f);
-    idx = idx > 63 ? 63 : idx;
-    const float v = fma_(-0.5f, (float)idx, am);
-    const float4 c03 = *reinterpret_cast<const float4 *>(spg + idx * 8);
-    const float2 c45 = *reinterpret_cast<const float2 *>(spg + idx * 8 + 4);
-    float q = c45.y;
-    q = fma_(q, v, c45.x); q = fma_(q, v, c03.w); q = fma_(q, v, c03.z); q = fma_(q, v, c03.y); q = fma_(q, v, c03.x);
-    float dq = 5.0f * c45.y;
-    dq = fma_(dq, v, 4.0f * c45.x); dq = fma_(dq, v, 3.0f * c03.w); dq = fma_(dq, v, 2.0f * c03.z); dq = fma_(dq, v, c03.y);
+    int idx = (int)(am * 4.0f);
+    idx = idx > 127 ? 127 : idx;
+    const float v = fma_(-0.25f, (float)idx, am);
+    const float4 c = *reinterpret_cast<const float4 *>(spg + idx * 4);
+    float q = c.w;
+    q = fma_(q, v, c.z); q = fma_(q, v, c.y); q = fma_(q, v, c.x);
+    float dq = 3.0f * c.w;
+    dq = fma_(dq, v, 2.0f * c.z); dq = fma_(dq, v, c.y);
     const bool pos = x > 0.0f;
     val = (pos ? x : 0.0f) + q;
     der = (pos ? 1.0f : 0.0f) + (pos ? 100.0f : -100.0f) * dq;

@@ -89,22 +89,21 @@ static inline float orc_log1pf(float x)
 
 /* torch.nn.Softplus(beta=100, threshold=20) (reference models/instant_nsr.py:231,591):
  *     softplus_100(x) = log1p(exp(100 x)) / 100 = max(x, 0) + G(|100 x|),   G(a) = log1p(exp(-a)) / 100
- * G comes from a 64-piece degree-5 table on [0, 32] (ac_sp_table.h, tools/gen_softplus_table.py; max abs error 4.8e-10, i.e. one
- * fp32 ulp of G(0)): one multiply, one table lookup, five fma, one add -- no exponential and no division.  For 100 x > 20
- * (torch's linear branch) G < 2.1e-11 is below half an ulp of x, so x is returned exactly, as by torch. */
+ * G comes from a 128-piece cubic table on [0, 32] (ac_sp_table.h, tools/gen_softplus_table.py; max abs error 1.9e-9): one
+ * multiply, one 16-byte table lookup, three fma, one add -- no exponential and no division.  For 100 x > 20 (torch's linear branch)
+ * G < 2.1e-11 is below half an ulp of x, so x is returned exactly, as by torch.  NaN / inf inputs give NaN (x * 0). */
 #include "ac_sp_table.h"
 static inline float orc_softplus100(float x)
 {
     float t = x * 100.0f;
-    if (t != t) return t;
     float am = fminf(fabsf(t), 32.0f);
-    int idx = (int)(am * 2.0f);
-    if (idx > 63) idx = 63;
-    float v = fmaf(-0.5f, (float)idx, am);
+    int idx = (int)(am * 4.0f);
+    if (idx > 127) idx = 127;
+    float v = fmaf(-0.25f, (float)idx, am);
     const float *c = AC_SP_G[idx];
-    float q = c[5];
-    q = fmaf(q, v, c[4]); q = fmaf(q, v, c[3]); q = fmaf(q, v, c[2]); q = fmaf(q, v, c[1]); q = fmaf(q, v, c[0]);
-    return (x > 0.0f ? x : 0.0f) + q;
+    float q = c[3];
+    q = fmaf(q, v, c[2]); q = fmaf(q, v, c[1]); q = fmaf(q, v, c[0]);
+    return fmaf(x, 0.0f, (x > 0.0f ? x : 0.0f) + q);
 }
 
 /* torch.sigmoid: 1 / (1 + exp(-x)) */
