@@ -213,11 +213,12 @@ __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restri
 
 // ---- exact closest-face search with culling ---------------------------------------------------------------------------------
 // Per frame (ac_warp_accel_build): faces sorted along a Morton curve of their centroids (one workgroup, bitonic sort of
-// 16384 64-bit keys in 128 KB of LDS), cut into tiles of 32 faces with an axis-aligned box and one representative vertex.
+// 16384 64-bit keys in 128 KB of LDS), cut into tiles of 32 faces with an oriented box (axis 0 = mean normal) and one
+// representative vertex.
 // Per sample (warp_samples_accel_kernel): one WAVE searches for one sample at a time -- lane = tile in the bounding pass
-// (boxes live in registers for the whole kernel), lane = face in the exact pass, so the lanes never diverge:
+// (bounds of all tiles in LDS), lane = face in the exact pass, so the lanes never diverge:
 //   1. ub = min over tiles of |p - representative vertex|^2          (a point of the mesh: upper bound of the answer)
-//   2. tiles with box distance^2 <= ub (1 + 1e-9) are the candidates (the box distance is a lower bound for every face inside)
+//   2. tiles whose oriented-box distance^2 <= bound (1 + 1e-9) are the candidates (a lower bound for every face inside)
 //   3. the faces of two candidate tiles at a time go through the same fp64 Ericson routine as the brute-force kernel; each lane
 //      keeps its own best (d2, face id), one wave reduction per sample, ties -> lowest face id (order independent).
 // A wave owns 64 consecutive samples: the search runs sample by sample, the result of sample j parks in lane j, and the
@@ -225,18 +226,19 @@ __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restri
 constexpr int TILE_F = 32;          // faces per tile
 constexpr int MAX_TILES = 512;      // 8 bounding-pass iterations of 64 lanes
 constexpr uint32_t MAX_ACCEL_FACES = MAX_TILES * TILE_F;     // 16384
+constexpr int NB = 18;              // floats of bounds per tile
 
 struct AccelView {                   // pointers into the caller's accel buffer
     uint32_t *hdr;                   // [0] = number of tiles, [1] = F
     uint32_t *sorted;                // [16384] face ids along the curve
     float *tri;                      // [MAX_TILES*32][9]
     int32_t *oid;                    // [MAX_TILES*32] original face id of each slot
-    float *box;                      // [9][MAX_TILES]: min xyz, max xyz, representative vertex xyz
+    float *box;                      // [NB][MAX_TILES]: oriented box: axes u0 (mean normal), u1, u2 (9), lo (3), hi (3); representative vertex (3)
 };
 __host__ __device__ inline size_t accel_offsets(size_t (&o)[5])
 {
     size_t off = 0;
-    const size_t sz[5] = { 64, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)9 * MAX_TILES * 4 };
+    const size_t sz[5] = { 64, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)NB * MAX_TILES * 4 };
     for (int i = 0; i < 5; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
     return off;
 }
@@ -346,22 +348,58 @@ __global__ __launch_bounds__(256) void accel_tiles_kernel(const float *__restric
     if (threadIdx.x < 8) {
         const uint32_t tile = blockIdx.x * 8 + threadIdx.x;
         if (tile < MAX_TILES) {
+            // oriented box of the tile: axis 0 = area-weighted mean normal of its faces, axes 1, 2 = a tangent basis; a surface patch
+            // is thin along its normal, so this box is tight where an axis-aligned one is loose (by the patch size) -- and the
+            // looseness of the lower bound is what decides how many tiles a sample has to test
+            float ax[3][3] = { { 1.0f, 0.0f, 0.0f }, { 0.0f, 1.0f, 0.0f }, { 0.0f, 0.0f, 1.0f } };
             float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
             float rep[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() };
             if (tile < nt) {
+                float nrm[3] = { 0.0f, 0.0f, 0.0f };
+                for (int j = 0; j < TILE_F; ++j) {
+                    const float *t = sb[threadIdx.x * TILE_F + j];
+                    const float e0[3] = { t[3] - t[0], t[4] - t[1], t[5] - t[2] }, e1[3] = { t[6] - t[0], t[7] - t[1], t[8] - t[2] };
+                    nrm[0] += e0[1] * e1[2] - e0[2] * e1[1]; nrm[1] += e0[2] * e1[0] - e0[0] * e1[2]; nrm[2] += e0[0] * e1[1] - e0[1] * e1[0];
+                }
+                const float len = __builtin_sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+                if (len > 0.0f) {
+                    const float n0 = nrm[0] / len, n1 = nrm[1] / len, n2 = nrm[2] / len;
+                    // tangent: the coordinate axis least aligned with n, made orthogonal to it
+                    const float a0 = __builtin_fabsf(n0), a1 = __builtin_fabsf(n1), a2 = __builtin_fabsf(n2);
+                    float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f;
+                    if (a0 <= a1 && a0 <= a2) h0 = 1.0f; else if (a1 <= a2) h1 = 1.0f; else h2 = 1.0f;
+                    const float dp = h0 * n0 + h1 * n1 + h2 * n2;
+                    float t0 = h0 - dp * n0, t1 = h1 - dp * n1, t2 = h2 - dp * n2;
+                    const float tl = __builtin_sqrtf(t0 * t0 + t1 * t1 + t2 * t2);
+                    t0 /= tl; t1 /= tl; t2 /= tl;
+                    ax[0][0] = n0; ax[0][1] = n1; ax[0][2] = n2;
+                    ax[1][0] = t0; ax[1][1] = t1; ax[1][2] = t2;
+                    ax[2][0] = n1 * t2 - n2 * t1; ax[2][1] = n2 * t0 - n0 * t2; ax[2][2] = n0 * t1 - n1 * t0;
+                }
                 for (int j = 0; j < TILE_F; ++j)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
+                    for (int c = 0; c < 3; ++c) {
+                        const float *t = sb[threadIdx.x * TILE_F + j] + 3 * c;
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
-                            const float x = sb[threadIdx.x * TILE_F + j][3 * c + k];
-                            lo[k] = x < lo[k] ? x : lo[k]; hi[k] = x > hi[k] ? x : hi[k];
+                            const float d = ax[k][0] * t[0] + ax[k][1] * t[1] + ax[k][2] * t[2];
+                            lo[k] = d < lo[k] ? d : lo[k]; hi[k] = d > hi[k] ? d : hi[k];
                         }
+                    }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {                        // fp32 dot products and axes: stay conservative
+                    const float pad = 1e-5f * (1.0f + __builtin_fabsf(lo[k]) + __builtin_fabsf(hi[k]));
+                    lo[k] -= pad; hi[k] += pad;
+                }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) rep[k] = sb[threadIdx.x * TILE_F][k];
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { av.box[k * MAX_TILES + tile] = lo[k]; av.box[(3 + k) * MAX_TILES + tile] = hi[k]; av.box[(6 + k) * MAX_TILES + tile] = rep[k]; }
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) av.box[(3 * k + c) * MAX_TILES + tile] = ax[k][c];
+                av.box[(9 + k) * MAX_TILES + tile] = lo[k]; av.box[(12 + k) * MAX_TILES + tile] = hi[k]; av.box[(15 + k) * MAX_TILES + tile] = rep[k];
+            }
         }
     }
     if (slot == 0) { av.hdr[0] = nt; av.hdr[1] = F; }
@@ -391,12 +429,10 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nt = av.hdr[0];
     const uint32_t nit = (nt + 63) >> 6;
-    // this lane's tiles (tile = 64 * it + lane): box and representative vertex, resident in registers
-    float bx[8][9];
-#pragma unroll
-    for (int it = 0; it < 8; ++it)
-#pragma unroll
-        for (int e = 0; e < 9; ++e) bx[it][e] = av.box[e * MAX_TILES + it * 64 + lane];
+    // bounds of all tiles in LDS (28 KB), lane = tile in the bounding pass
+    __shared__ float sbox[NB][MAX_TILES];
+    for (int e = threadIdx.x; e < NB * MAX_TILES; e += blockDim.x) (&sbox[0][0])[e] = av.box[e];
+    __syncthreads();
     const uint32_t i = wave * 64 + lane;
     const bool live = i < P;
     const uint32_t ii = live ? i : P - 1;
@@ -407,31 +443,65 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
     for (uint32_t j = 0; j < npts; ++j) {
         const double q[3] = { __shfl(p[0], (int)j), __shfl(p[1], (int)j), __shfl(p[2], (int)j) };
         // 1. upper bound from the representative vertices, lower bound of every tile (kept in registers)
-        double ub = __builtin_inf(), lb[8];
+        double ubl = __builtin_inf(), lb[8];
+        int tbest = 0;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const double ex = q[0] - (double)bx[it][6], ey = q[1] - (double)bx[it][7], ez = q[2] - (double)bx[it][8];
+            lb[it] = __builtin_inf();
+            if ((uint32_t)it >= nit) continue;                         // wave-uniform
+            const int tl = it * 64 + lane;
+            const double ex = q[0] - (double)sbox[15][tl], ey = q[1] - (double)sbox[16][tl], ez = q[2] - (double)sbox[17][tl];
             const double u = ex * ex + ey * ey + ez * ez;
-            ub = u < ub ? u : ub;                    // padding tiles hold +inf
+            if (u < ubl) { ubl = u; tbest = tl; }                      // padding tiles hold +inf
             double l = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double lo = (double)bx[it][k] - q[k], hi = q[k] - (double)bx[it][3 + k];
+                const double sk = q[0] * (double)sbox[3 * k][tl] + q[1] * (double)sbox[3 * k + 1][tl] + q[2] * (double)sbox[3 * k + 2][tl];
+                const double lo = (double)sbox[9 + k][tl] - sk, hi = sk - (double)sbox[12 + k][tl];
                 double d = lo > hi ? lo : hi;
                 d = d > 0.0 ? d : 0.0;
                 l += d * d;
             }
-            lb[it] = l;                              // +inf for padding tiles
+            lb[it] = l * (1.0 - 1e-5);                                 // axes orthonormal up to fp32 rounding; +inf for padding tiles
         }
-        ub = wave_min_f64(ub);
-        const double lim = ub * (1.0 + 1e-9);
-        // 2./3. candidates, two tiles per step
+        const double ub = wave_min_f64(ubl);
+        // seed: the faces of the tile with the nearest representative vertex (lanes 0..31) and of the tile with the smallest lower
+        // bound (lanes 32..63) are tested first; their exact distances replace the vertex distance as the bound
+        double lmin = lb[0];
+        int tlow = lane;
+#pragma unroll
+        for (int it = 1; it < 8; ++it) if (lb[it] < lmin) { lmin = lb[it]; tlow = it * 64 + lane; }
+        const double lminw = wave_min_f64(lmin);
+        const int tA = __shfl(tbest, __builtin_ctzll(__ballot(ubl == ub)));
+        const int tB = __shfl(tlow, __builtin_ctzll(__ballot(lmin == lminw)));
         double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
         int bid = 0x7fffffff;
+        {
+            const int tmine = lane < 32 ? tA : tB;
+            const uint32_t slot = (uint32_t)tmine * TILE_F + (uint32_t)(lane & 31);
+            const float *tp = av.tri + (size_t)slot * 9;
+            const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
+                         c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
+            double cq[3];
+            closest_pt_tri(q, a, b, c, cq);
+            const double ex = q[0] - cq[0], ey = q[1] - cq[1], ez = q[2] - cq[2];
+            best = ex * ex + ey * ey + ez * ez; bid = av.oid[slot]; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2];
+        }
+        const double seed = wave_min_f64(best);
+        const double lim = (seed < ub ? seed : ub) * (1.0 + 1e-9);
+        // 2./3. remaining candidates, two tiles per step
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             if ((uint32_t)it >= nit) break;                            // wave-uniform
             unsigned long long cand = __ballot(lb[it] <= lim);
+            if (it == (tA >> 6)) cand &= ~(1ull << (tA & 63));         // the seed tiles are done
+            if (it == (tB >> 6)) cand &= ~(1ull << (tB & 63));
+#ifdef AC_ABL_NOCAND
+            cand = 0;
+#endif
+#ifdef AC_COUNT_CAND
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 4), (unsigned long long)__builtin_popcountll(cand));
+#endif
             while (cand) {
                 const int t0 = __builtin_ctzll(cand); cand &= cand - 1;
                 int t1 = -1;

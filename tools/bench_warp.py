@@ -2,6 +2,8 @@
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
+from avatarcraft_amd import _lib as L
+if os.environ.get('AC_LIB_PATH'): L.LIB_PATH = os.environ['AC_LIB_PATH']
 from avatarcraft_amd import ray_utils as RY
 from tests.common import make_body, make_rays
 dev = "cuda:0"
@@ -26,3 +28,19 @@ for S in (32, 64):
     print("warp brute force %d pts x %d faces: %.2f ms  (%.1f G point-face tests/s)" % (P, faces.shape[0], t, P * faces.shape[0] / t / 1e6))
     t = timeit(lambda: RY.warp_samples_to_canonical(pts, tv, tf, tT, 0.05, accel=True))
     print("warp culled (incl. per-call build) %d pts: %.2f ms  (%.1f M samples/s)" % (P, t, P / t / 1e3))
+
+if os.environ.get("COUNT"):
+    # -DAC_COUNT_CAND build: candidate tiles per sample, near the body vs the whole frustum
+    nb = int(L.lib().ac_warp_accel_bytes(faces.shape[0]))
+    for name, zz in (("whole ray 0.8..2.8", torch.linspace(0.8, 2.8, 64, device=dev)), ("near the body 1.5..2.1", torch.linspace(1.5, 2.1, 64, device=dev))):
+        pts = (tro[:, None, :] + trd[:, None, :] * zz[None, :, None]).contiguous().reshape(-1, 3)
+        acc = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        st = L.current_stream(torch.device(dev))
+        L.check(L.lib().ac_warp_accel_build(tv.data_ptr(), tf.data_ptr(), tv.shape[0], tf.shape[0], acc.data_ptr(), nb, st))
+        P = pts.shape[0]
+        can = torch.empty(P, 3, device=dev); mask = torch.empty(P, dtype=torch.uint8, device=dev)
+        L.check(L.lib().ac_warp_samples_accel(pts.data_ptr(), tv.data_ptr(), tf.data_ptr(), tT.data_ptr(), P, tv.shape[0], tf.shape[0], 0.05, acc.data_ptr(), None,
+                                              can.data_ptr(), None, None, None, mask.data_ptr(), st))
+        torch.cuda.synchronize()
+        cnt = int(acc[16:24].view(torch.int64)[0])
+        print("candidate tiles per sample, %s: %.2f  (mask fraction %.3f)" % (name, cnt / P, float(mask.float().mean())))
