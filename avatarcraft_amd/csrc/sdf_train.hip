@@ -292,6 +292,231 @@ __global__ __launch_bounds__(1024) void sdf_partials_reduce_kernel(const float *
     }
 }
 
+// ======================================================================================================================
+// colour MLP of the render core (forward_color, models/instant_nsr.py:644-663, use_viewdirs = False):
+//   rgb = sigmoid(Wc3 relu(Wc2 relu(Wc1 [x(3), normal(3), feat(15)])))            (no biases, weight-normed matrices)
+// forward = the renderer's colour tile; backward recomputes it and runs all six products on the matrix pipe:
+//   dh2 = Wc3^T do3 (4 MFMA), dh1 = Wc2^T dh2 (64), dinp = Wc1^T dh1 (32; lane (n, g) receives d sdf_out[4g..4g+3] and d normal_g:
+//   exactly the layouts sdf_stencil_bwd_kernel and the caller read), dWc3 += do3 h2^T (16), dWc2 += dh2 h1^T (64),
+//   dWc1 += dh1 inp^T (32) with K = the 16 samples of the tile through LDS transposes.
+constexpr int OFF_C3T = OFF_WAVE;                  // [4 tiles][64]              A fragments of Wc3^T
+constexpr int OFF_C2T = OFF_C3T + 4 * 64;          // [4 tiles][16 ksteps][64]   Wc2^T
+constexpr int OFF_C1T = OFF_C2T + 64 * 64;         // [2 tiles][16 ksteps][64]   Wc1^T (rows: sdf_out[16] | normal, coordinate)
+constexpr int OFF_CW = OFF_C1T + 32 * 64;          // per-wave slabs
+constexpr int CS_H1 = 0, CS_H2 = 64 * TLD, CS_D1 = 128 * TLD, CS_D2 = 192 * TLD, CS_O3 = 256 * TLD, CS_IN = 272 * TLD;
+constexpr int COLOR_SLAB = ((CS_IN + 32 * TLD + 3) / 4) * 4;
+constexpr int CBWD_LDS_FLOATS = OFF_CW + TW * COLOR_SLAB;
+static_assert(CBWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+constexpr int NPART_C = 64 * 32 + 64 * 64 + 16 * 64;     // dWc1 [64][32] (columns 0..20 = x, n, feat) | dWc2 [64][64] | dWc3 [16][64] (rows 0..2)
+
+__global__ __launch_bounds__(TBLOCK) void color_fwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ nrm,
+                                                           const float *__restrict__ sdf16, uint32_t B, float *__restrict__ rgb_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const uint32_t ntiles = (B + 15) / 16;
+    for (uint32_t tile = blockIdx.x * TW + wave; tile < ntiles; tile += gridDim.x * TW) {
+        const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
+        const f32x4 so = *reinterpret_cast<const f32x4 *>(sdf16 + (size_t)bb * 16 + 4 * g);
+        float rgb[3];
+        color_tile(lds, lane, x[3 * (size_t)bb], x[3 * (size_t)bb + 1], x[3 * (size_t)bb + 2], nrm[3 * (size_t)bb], nrm[3 * (size_t)bb + 1],
+                   nrm[3 * (size_t)bb + 2], so, rgb);
+        if (b < B && g == 0) { rgb_out[3 * (size_t)b] = rgb[0]; rgb_out[3 * (size_t)b + 1] = rgb[1]; rgb_out[3 * (size_t)b + 2] = rgb[2]; }
+    }
+}
+
+__device__ __forceinline__ void fill_lds_color_bwd(float *lds, const RenderArgs &a)
+{
+    for (int e = threadIdx.x; e < 4 * 64; e += blockDim.x) {        // fragment to: lane (m, kk) = Wc3[o = kk][unit = 16 to + m]
+        const int l = e & 63, to = e >> 6, m = l & 15, kk = l >> 4;
+        lds[OFF_C3T + e] = kk < 3 ? a.Wc3[kk * 64 + 16 * to + m] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {       // fragment (t, ks = 4 to + r): lane (m, kk) = Wc2[i = 16 to + 4 kk + r][j = 16 t + m]
+        const int l = e & 63, fs = e >> 6, t = fs >> 4, ks = fs & 15, to = ks >> 2, r = ks & 3, m = l & 15, kk = l >> 4;
+        lds[OFF_C2T + e] = a.Wc2[(16 * to + 4 * kk + r) * 64 + 16 * t + m];
+    }
+    for (int e = threadIdx.x; e < 32 * 64; e += blockDim.x) {       // fragment (tp, ks = 4 t + r): lane (m, kk) = Wc1[u = 16 t + 4 kk + r][col(tp, m)]
+        const int l = e & 63, fs = e >> 6, tp = fs >> 4, ks = fs & 15, t = ks >> 2, r = ks & 3, m = l & 15, kk = l >> 4;
+        int col = -1;
+        if (tp == 0) col = m == 0 ? -1 : 6 + (m - 1);                // row m = sdf_out[m]: feat m-1 (the sdf itself is not an input)
+        else if ((m & 3) == 0 && (m >> 2) < 3) col = 3 + (m >> 2);   // row 4 g: normal component g
+        lds[OFF_C1T + e] = col < 0 ? 0.0f : a.Wc1[(16 * t + 4 * kk + r) * 21 + col];
+    }
+}
+
+__global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ nrm,
+                                                           const float *__restrict__ sdf16, const float *__restrict__ g_rgb, uint32_t B,
+                                                           float *__restrict__ g_nrm, float *__restrict__ g_sdf16, float *__restrict__ partials)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    fill_lds_color_bwd(lds, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    float *slab = lds + OFF_CW + wave * COLOR_SLAB;
+    float *TH1 = slab + CS_H1, *TH2 = slab + CS_H2, *TD1 = slab + CS_D1, *TD2 = slab + CS_D2, *TO3 = slab + CS_O3, *TIN = slab + CS_IN;
+    for (int e = lane; e < 16 * TLD; e += 64) TO3[e] = 0.0f;          // rows 3..15 stay zero
+    for (int e = lane; e < 32 * TLD; e += 64) TIN[e] = 0.0f;          // rows 21..31 stay zero
+    __syncthreads();
+    f32x4 gW1[4][2], gW2[4][4], gW3[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        gW3[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int c = 0; c < 2; ++c) gW1[t][c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gW2[t][c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    }
+    const uint32_t ntiles = (B + 15) / 16;
+    for (uint32_t tile = blockIdx.x * TW + wave; tile < ntiles; tile += gridDim.x * TW) {
+        const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
+        const bool live = b < B;
+        const float px = x[3 * (size_t)bb], py = x[3 * (size_t)bb + 1], pz = x[3 * (size_t)bb + 2];
+        const float nx = nrm[3 * (size_t)bb], ny = nrm[3 * (size_t)bb + 1], nz = nrm[3 * (size_t)bb + 2];
+        const f32x4 so = *reinterpret_cast<const f32x4 *>(sdf16 + (size_t)bb * 16 + 4 * g);
+        const float bxyz = sel4(g, px, py, pz, 0.0f), bn = sel4(g, nx, ny, nz, 0.0f);
+        // forward recompute (same instruction sequence as color_tile), activations kept
+        f32x4 h1[4], h2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const float bv = s < 4 ? so[s] : (s == 4 ? bxyz : bn);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C1F + (t * 6 + s) * 64 + lane], bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+            h1[t] = acc;
+        }
+#pragma unroll
+        for (int to = 0; to < 4; ++to) {
+            f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C2F + (to * 16 + kk) * 64 + lane], h1[kk >> 2][kk & 3], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+            h2[to] = acc;
+        }
+        f32x4 o3 = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            o3 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C3F + kk * 64 + lane], h2[kk >> 2][kk & 3], o3, 0, 0, 0);
+        // d o3 = d rgb * rgb (1 - rgb), held by the lanes g == 0 (o = r); broadcast to lane group kk = o as the B operand of Wc3^T
+        float d3[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float rgb = dv_sigmoid(o3[o]);
+            const float up = (live && g == 0) ? g_rgb[3 * (size_t)bb + o] : 0.0f;
+            d3[o] = up * (rgb * (1.0f - rgb));
+        }
+        const float s0 = __shfl(d3[0], n), s1 = __shfl(d3[1], n), s2 = __shfl(d3[2], n);
+        const float b3 = g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : 0.0f));
+        // dh2 = Wc3^T d3 (.) [h2 > 0]; dh1 = Wc2^T dh2 (.) [h1 > 0]
+        f32x4 dh2[4], dh1[4];
+#pragma unroll
+        for (int to = 0; to < 4; ++to) {
+            f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C3T + to * 64 + lane], b3, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = h2[to][r] > 0.0f ? acc[r] : 0.0f;
+            dh2[to] = acc;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C2T + (t * 16 + ks) * 64 + lane], dh2[ks >> 2][ks & 3], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = h1[t][r] > 0.0f ? acc[r] : 0.0f;
+            dh1[t] = acc;
+        }
+        // dinp = Wc1^T dh1: tile 0 -> d sdf_out[4g + r], tile 1 reg 0 -> d normal_g
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C1T + (tp * 16 + ks) * 64 + lane], dh1[ks >> 2][ks & 3], acc, 0, 0, 0);
+            if (live) {
+                if (tp == 0) *reinterpret_cast<f32x4 *>(g_sdf16 + (size_t)b * 16 + 4 * g) = acc;
+                else if (g < 3) g_nrm[3 * (size_t)b + g] = acc[0];
+            }
+        }
+        // weight gradients (K = the tile's 16 samples)
+        if (g == 0) { TO3[0 * TLD + n] = d3[0]; TO3[1 * TLD + n] = d3[1]; TO3[2 * TLD + n] = d3[2]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = (16 * t + 4 * g + r) * TLD + n;
+                TH1[u] = h1[t][r]; TH2[u] = h2[t][r]; TD1[u] = dh1[t][r]; TD2[u] = dh2[t][r];
+            }
+        // inputs in the column order of Wc1: x (0..2), normal (3..5), feat (6..20) = sdf_out[1..15]
+        if (g < 3) { TIN[g * TLD + n] = bxyz; TIN[(3 + g) * TLD + n] = bn; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { const int o = 4 * g + s; if (o > 0) TIN[(6 + o - 1) * TLD + n] = so[s]; }
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a3 = TO3[n * TLD + 4 * s + g];
+            float bh2[4], bh1[4], bin[2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { bh2[c] = TH2[(16 * c + n) * TLD + 4 * s + g]; bh1[c] = TH1[(16 * c + n) * TLD + 4 * s + g]; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bin[c] = TIN[(16 * c + n) * TLD + 4 * s + g];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gW3[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bh2[c], gW3[c], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float a2 = TD2[(16 * t + n) * TLD + 4 * s + g], a1 = TD1[(16 * t + n) * TLD + 4 * s + g];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gW2[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bh1[c], gW2[t][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) gW1[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bin[c], gW1[t][c], 0, 0, 0);
+            }
+        }
+        wave_sync();
+    }
+    float *part = partials + (size_t)(blockIdx.x * TW + wave) * NPART_C;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * g + r;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) part[row * 32 + 16 * c + n] = gW1[t][c][r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[64 * 32 + row * 64 + 16 * c + n] = gW2[t][c][r];
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[64 * 32 + 64 * 64 + (4 * g + r) * 64 + 16 * c + n] = gW3[c][r];
+}
+
+// generic: out[i] = sum over waves of partials[w][i], i < n_out
+__global__ __launch_bounds__(1024) void partials_reduce_kernel(const float *__restrict__ partials, uint32_t nwaves, uint32_t n_out, float *__restrict__ out)
+{
+    __shared__ float red[16][64];
+    const uint32_t o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64 + o;
+    float s = 0.0f;
+    if (i < n_out)
+        for (uint32_t w = sl; w < nwaves; w += 16) s += partials[(size_t)w * n_out + i];
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < n_out) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][o];
+        out[i] = t;
+    }
+}
+
 uint32_t train_grid(uint32_t B)
 {
     const uint32_t ntiles = (B + 15) / 16;
@@ -311,6 +536,16 @@ int prep_args(RenderArgs &a, const ac_field *field, float bound, float eps)
             if (!(cells * 1.001 + 1e-3 < 1.0)) a.jfine[j] = 1;
         }
     }
+    return AC_OK;
+}
+
+// the colour kernels use the weight fragments only: no hash-level validation (the table of `field` is never touched)
+int prep_color_args(RenderArgs &a, const ac_field *f)
+{
+    if (!f || !f->W1 || !f->b1 || !f->W2 || !f->b2 || !f->Wc1 || !f->Wc2 || !f->Wc3) { ac::set_error("ac_field: NULL parameter pointer"); return AC_ERR_BAD_ARG; }
+    a.table = f->table; a.table_bytes = 0;
+    a.W1 = f->W1; a.b1 = f->b1; a.W2 = f->W2; a.b2 = f->b2; a.Wc1 = f->Wc1; a.Wc2 = f->Wc2; a.Wc3 = f->Wc3;
+    a.bound = 1.0f; a.two_bound = 2.0f;
     return AC_OK;
 }
 
@@ -356,4 +591,43 @@ AC_API int ac_sdf_stencil_backward(const ac_field *field, const float *x, const 
     hipLaunchKernelGGL(sdf_partials_reduce_kernel, dim3((NPART + 63) / 64), dim3(1024), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
                        blocks * TW, gparams);
     return ac::check_launch("sdf_stencil_backward");
+}
+
+AC_API int ac_color_forward(const ac_field *field, const float *x, const float *normal, const float *sdf16, uint32_t B, float *rgb, ac_stream_t stream)
+{
+    if (B == 0) return AC_OK;
+    if (!x || !normal || !sdf16 || !rgb) { ac::set_error("color_forward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = prep_color_args(a, field)) return rc;
+    const size_t lds_bytes = OFF_WAVE * sizeof(float);
+    uint32_t blocks = ((B + 15) / 16 + TW - 1) / TW;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(color_fwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, normal, sdf16, B, rgb);
+    return ac::check_launch("color_forward");
+}
+
+AC_API size_t ac_color_backward_scratch(uint32_t B)
+{
+    return (size_t)train_grid(B) * TW * NPART_C * sizeof(float);
+}
+
+AC_API int ac_color_backward(const ac_field *field, const float *x, const float *normal, const float *sdf16, const float *g_rgb, uint32_t B,
+                             float *g_normal, float *g_sdf16, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream)
+{
+    if (!gparams) { ac::set_error("color_backward: NULL gparams"); return AC_ERR_BAD_ARG; }
+    if (B == 0) { hipMemsetAsync(gparams, 0, NPART_C * sizeof(float), (hipStream_t)stream); return AC_OK; }
+    if (!x || !normal || !sdf16 || !g_rgb || !g_normal || !g_sdf16 || !scratch) { ac::set_error("color_backward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    const size_t need = ac_color_backward_scratch(B);
+    if (scratch_bytes < need) { ac::set_error("color_backward: scratch of %zu bytes needed, %zu given", need, scratch_bytes); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = prep_color_args(a, field)) return rc;
+    const size_t lds_bytes = CBWD_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(color_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    const uint32_t blocks = train_grid(B);
+    hipLaunchKernelGGL(color_bwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, normal, sdf16, g_rgb, B, g_normal, g_sdf16,
+                       static_cast<float *>(scratch));
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((NPART_C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
+                       blocks * TW, (uint32_t)NPART_C, gparams);
+    return ac::check_launch("color_backward");
 }

@@ -140,7 +140,10 @@ class NeRFRenderer(nn.Module):
             gradient = self.gradient(flat, bound, fd_eps).squeeze()
         sdf, feat = sdf_out[:, :1], sdf_out[:, 1:]
         normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
-        color = self.forward_color(flat, dirs.reshape(-1, 3), normal.reshape(-1, 3), feat, bound)
+        if self.fused_training and self._fused_supported() and flat.is_cuda:
+            color = self.forward_color_fused(flat, normal.reshape(-1, 3), sdf_out)
+        else:
+            color = self.forward_color(flat, dirs.reshape(-1, 3), normal.reshape(-1, 3), feat, bound)
         inv_s = self.forward_variance().expand(N * T, 1)
         true_cos = (dirs.reshape(-1, 3) * normal).sum(-1, keepdim=True)
         act = nn.Softplus(beta=100)
@@ -280,6 +283,11 @@ class NeRFNetwork(NeRFRenderer):
         h = h.view(7, B, -1)
         gradient = (0.5 * (h[1::2, :, 0] - h[2::2, :, 0]) / epsilon).t()
         return h[0], gradient
+
+    def forward_color_fused(self, x, n, sdf_out):
+        """forward_color on the outputs of forward_sdf (sdf_out [B,16] = [sdf, feat]) as one fused op with a fused backward"""
+        wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0)
+        return nsr_ops.color_mlp(x, n, sdf_out, wn(self.color_net[0]), wn(self.color_net[1]), wn(self.color_net[2]))
 
     def forward_color(self, x, d, n, geo_feat, bound):
         if self.use_viewdirs:

@@ -225,6 +225,49 @@ class _SdfStencil(torch.autograd.Function):
                 gparams[64 * 36 + 1024:], None)
 
 
+class _ColorMlp(torch.autograd.Function):
+    """forward_color of the render core (use_viewdirs = False) as a fused op with a fused backward (csrc/sdf_train.hip).
+    Inputs: x [B,3] (no grad), normal [B,3], sdf_out [B,16] (column 0 unused), the EFFECTIVE colour matrices."""
+
+    @staticmethod
+    def _field(dev, Wc1, Wc2, Wc3):
+        z = lambda *shape: torch.zeros(shape, dtype=_F32, device=dev)
+        offs = list(range(0, 17))                  # a dummy 16-level layout of one entry per level: the colour kernels never touch the table
+        return Field(z(16, 2), offs, 2.0, 16, z(64, 35), z(64), z(16, 64), z(16), Wc1.detach().contiguous(), Wc2.detach().contiguous(),
+                     Wc3.detach().contiguous())
+
+    @staticmethod
+    def forward(ctx, x, normal, sdf_out, Wc1, Wc2, Wc3):
+        x, normal, sdf_out = x.contiguous(), normal.contiguous(), sdf_out.contiguous()
+        B, dev = x.shape[0], x.device
+        field = _ColorMlp._field(dev, Wc1, Wc2, Wc3)
+        rgb = torch.empty((B, 3), dtype=_F32, device=dev)
+        L.check(L.lib().ac_color_forward(C.byref(field.c), x.data_ptr(), normal.data_ptr(), sdf_out.data_ptr(), B, rgb.data_ptr(), L.current_stream(dev)),
+                "color_forward")
+        ctx.save_for_backward(x, normal, sdf_out, Wc1, Wc2, Wc3)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        x, normal, sdf_out, Wc1, Wc2, Wc3 = ctx.saved_tensors
+        B, dev = x.shape[0], x.device
+        field = _ColorMlp._field(dev, Wc1, Wc2, Wc3)
+        g_rgb = g_rgb.contiguous().float()
+        g_n = torch.empty((B, 3), dtype=_F32, device=dev)
+        g_s = torch.empty((B, 16), dtype=_F32, device=dev)
+        gp = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)
+        nbytes = int(L.lib().ac_color_backward_scratch(B))
+        scratch = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        L.check(L.lib().ac_color_backward(C.byref(field.c), x.data_ptr(), normal.data_ptr(), sdf_out.data_ptr(), g_rgb.data_ptr(), B, g_n.data_ptr(),
+                                          g_s.data_ptr(), gp.data_ptr(), scratch.data_ptr(), nbytes, L.current_stream(dev)), "color_backward")
+        return (None, g_n, g_s, gp[:2048].view(64, 32)[:, :21].contiguous(), gp[2048:6144].view(64, 64), gp[6144:].view(16, 64)[:3].contiguous())
+
+
+def color_mlp(x, normal, sdf_out, Wc1, Wc2, Wc3):
+    """-> rgb [B,3]; differentiable w.r.t. normal, sdf_out[:, 1:], Wc1, Wc2, Wc3"""
+    return _ColorMlp.apply(x, normal, sdf_out, Wc1, Wc2, Wc3)
+
+
 def sdf_stencil(x, table, W1, b1, W2, b2, offsets, per_level_scale, base_resolution, bound, eps):
     """-> (sdf_out [B,16], gradient [B,3]); differentiable w.r.t. table, W1, b1, W2, b2"""
     cfg = ([int(v) for v in offsets], per_level_scale, int(base_resolution), float(bound), float(eps))

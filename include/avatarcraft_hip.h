@@ -241,6 +241,17 @@ size_t ac_sdf_stencil_backward_scratch(uint32_t B);
 int ac_sdf_stencil_backward(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
                             float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
+/* ---- colour MLP of the render core (training path): forward_color (models/instant_nsr.py:644-663, use_viewdirs = False)
+ * rgb = sigmoid(Wc3 relu(Wc2 relu(Wc1 [x, normal, feat]))) with feat = sdf16[:, 1:16].
+ * forward : same values as ac_field_color / ac_render_rays.   backward: recomputes the forward per tile of 16 samples and returns
+ * g_normal [B,3], g_sdf16 [B,16] (column 0 = 0: the sdf itself is not an input of the colour net) and
+ * gparams [7168] = dWc1 [64][32] (columns 0..20 = x(3), normal(3), feat(15)) | dWc2 [64][64] | dWc3 [16][64] (rows 0..2)
+ * w.r.t. the EFFECTIVE matrices of `field`.  scratch: ac_color_backward_scratch(B) bytes. */
+int ac_color_forward(const ac_field *field, const float *x, const float *normal, const float *sdf16, uint32_t B, float *rgb, ac_stream_t stream);
+size_t ac_color_backward_scratch(uint32_t B);
+int ac_color_backward(const ac_field *field, const float *x, const float *normal, const float *sdf16, const float *g_rgb, uint32_t B,
+                      float *g_normal, float *g_sdf16, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream);
+
 /* ---- posed-space rendering: NeRFRenderer.run(render_can=False, verts, faces, Ts, use_mesh_guide)
  * models/instant_nsr.py:147-172 (mesh-guided near/far, warp of the coarse samples), :198-203 (warp of the mid points),
  * :246-249 (alpha mask).  The reference moves the samples to the CPU for libigl twice per batch; here the whole sequence

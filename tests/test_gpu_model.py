@@ -196,3 +196,34 @@ def test_fused_sdf_query_ragged_sizes(B):
         if p.grad is not None:
             assert (g_fused[k] - p.grad).abs().max() <= 2e-3 * max(float(p.grad.abs().max()), 1e-12), k
     net.fused_training = True
+
+
+@pytest.mark.parametrize("B", [0, 5, 4099])
+def test_fused_color_mlp_matches_autograd(B):
+    """color_mlp (csrc/sdf_train.hip) against forward_color with torch autograd: rgb, d normal, d feat and the three weight gradients"""
+    from avatarcraft_amd import nsr_ops
+    net, _ = golden_net(train=True)
+    rs = np.random.RandomState(B + 1)
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).to(DEV)
+    x = t(rs.uniform(-1.5, 1.5, size=(B, 3)))
+    nrm = t(rs.normal(size=(B, 3))).requires_grad_(True)
+    so = t(rs.normal(size=(B, 16)) * 0.3).requires_grad_(True)
+    up = t(rs.normal(size=(B, 3)))
+
+    def run(fused):
+        net.zero_grad(); nrm.grad = None; so.grad = None
+        rgb = net.forward_color_fused(x, nrm, so) if fused else net.forward_color(x, None, nrm, so[:, 1:], 1.6)
+        (rgb * up).sum().backward()
+        return rgb.detach(), nrm.grad.clone(), so.grad.clone(), {k: p.grad.clone() for k, p in net.color_net.named_parameters()}
+    r1, n1, s1, G1 = run(True)
+    r0, n0, s0, G0 = run(False)
+    assert r1.shape == (B, 3)
+    if B == 0:
+        assert all(float(v.abs().max()) == 0.0 for v in G1.values())
+        return
+    assert torch.allclose(r1, r0, atol=2e-6) and torch.allclose(n1, n0, atol=1e-5, rtol=1e-4) and torch.allclose(s1, s0, atol=1e-5, rtol=1e-4)
+    assert float(s1[:, 0].abs().max()) == 0.0
+    for k in G0:
+        assert (G1[k] - G0[k]).abs().max() <= 1e-3 * G0[k].abs().max(), k
+    f = net._field()
+    assert torch.equal(r1, nsr_ops.field_color(f, x, nrm.detach(), so.detach()))            # == the renderer's / the oracle's colour
