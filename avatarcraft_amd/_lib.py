@@ -65,7 +65,7 @@ _SIGS = {
     "ac_warp_accel_build": ([vp, vp, u32, u32, vp, C.c_size_t, vp], C.c_int),
     "ac_warp_samples_accel": ([vp, vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_hash_stencil_forward": ([vp, vp, vp, vp, u32, u32, u32, f32, u32, f32, f32, vp], C.c_int),
-    "ac_hash_stencil_backward_scratch": ([vp, u32, f32, u32, u32], C.c_size_t),
+    "ac_hash_stencil_backward_scratch": ([vp, u32, f32, u32, u32, u32], C.c_size_t),
     "ac_hash_stencil_backward": ([vp, vp, vp, vp, u32, u32, u32, f32, u32, f32, f32, vp, C.c_size_t, vp], C.c_int),
     "ac_sdf_stencil_forward": ([C.POINTER(ac_field), vp, u32, f32, f32, vp, vp, vp], C.c_int),
     "ac_sdf_stencil_backward_scratch": ([u32], C.c_size_t),

@@ -25,6 +25,12 @@ namespace {
 #define AC_ATOMIC_ADD(P, V) unsafeAtomicAdd((P), (V))
 #endif
 
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct LevelC { float scale; uint32_t stride1, size, hashed, mask; };
 
 __device__ __forceinline__ uint32_t gindex(const LevelC &L, uint32_t x, uint32_t y, uint32_t z)
@@ -131,8 +137,82 @@ __device__ __forceinline__ bool run_head(const Loc (&q)[3], bool ok, int lane)
     return lane == 0 || p0 != q[0].pg || p1 != q[1].pg || p2 != q[2].pg || pok != (ok ? 1 : 0);    // runs are homogeneous in `ok`
 }
 
+// ---- where the combined gradients go -------------------------------------------------------------------------------------------
+// DirectSink: two hardware float atomics per table entry (the device does ~20.9 G of those per second, whatever the scope, table
+// size or address spread: tools/atomics_bench.hip) -- used for the small dense levels (with private copies).
+// BinSink: the hashed levels.  A record (entry, v0, v1) is appended to a per-wave LDS buffer; a flush bins the buffer by
+// destination bucket (64 buckets of 8192 entries per level), reserves the slots of every bucket with ONE global atomic per
+// (flush, bucket) and streams the records into per-bucket queues in HBM; bucket_accumulate_kernel then gives every bucket to
+// one workgroup that sums its queue in LDS (ds_add_f32, ~1000x the global atomic rate) and adds the 64 KB slice to the table
+// without atomics.  Global atomics per record: 2 -> ~1/30.
+struct DirectSink {
+    float2 *gg;
+    __device__ __forceinline__ void add(bool pred, uint32_t index, float v0, float v1) const
+    {
+        if (pred) { float *t = reinterpret_cast<float *>(gg + index); AC_ATOMIC_ADD(t, v0); AC_ATOMIC_ADD(t + 1, v1); }
+    }
+};
+
+constexpr int NBUCKET = 64;
+constexpr int RCAP = 2560;                 // records per wave buffer: a flush leaves <= 512, one sample group adds <= 2048
+struct Rec { uint32_t idx; float v0, v1; };
+
+struct BinSink {
+    uint32_t *ridx; float *rv0, *rv1;      // this wave's LDS record buffer [RCAP]
+    uint32_t *hist, *base;                 // this wave's LDS [NBUCKET] each (hist zero between flushes)
+    uint32_t cnt;                          // wave-uniform
+    uint32_t shift;                        // bucket = index >> shift
+    uint32_t *qcount;                      // global [NBUCKET] of this level
+    Rec *queue;                            // global [NBUCKET][cap] of this level
+    uint32_t cap;
+    float2 *gg;                            // overflow path: direct atomics
+    int lane;
+    __device__ __forceinline__ void add(bool pred, uint32_t index, float v0, float v1)
+    {
+        const unsigned long long m = __ballot(pred);
+        if (pred) {
+            const uint32_t pos = cnt + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            ridx[pos] = index; rv0[pos] = v0; rv1[pos] = v1;
+        }
+        cnt += (uint32_t)__builtin_popcountll(m);
+    }
+    __device__ __forceinline__ void flush()
+    {
+        wave_sync_lds();
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const uint32_t idx = ridx[i];
+            const uint32_t rank = atomicAdd(&hist[idx >> shift], 1u);
+            ridx[i] = idx | (rank << 19);
+        }
+        wave_sync_lds();
+        {
+            const uint32_t c = hist[lane];
+            base[lane] = c ? atomicAdd(&qcount[lane], c) : 0u;
+            hist[lane] = 0u;
+        }
+        wave_sync_lds();
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const uint32_t packed = ridx[i], idx = packed & 0x7ffffu, bucket = idx >> shift;
+            const uint32_t slot = base[bucket] + (packed >> 19);
+            const float v0 = rv0[i], v1 = rv1[i];
+            if (slot < cap) {
+                Rec r; r.idx = idx & ((1u << shift) - 1u); r.v0 = v0; r.v1 = v1;
+                queue[(size_t)bucket * cap + slot] = r;
+            } else {                        // queue full (never with the default sizing): fall back to atomics
+                float *t = reinterpret_cast<float *>(gg + idx); AC_ATOMIC_ADD(t, v0); AC_ATOMIC_ADD(t + 1, v1);
+            }
+        }
+        wave_sync_lds();
+        cnt = 0;
+    }
+};
+
+__device__ __forceinline__ void sink_reserve(DirectSink &, uint32_t) {}
+__device__ __forceinline__ void sink_reserve(BinSink &s, uint32_t room) { if (s.cnt + room > (uint32_t)RCAP) s.flush(); }
+
 // one point's 8 corners, combined over the run of lanes in the same cell
-__device__ __forceinline__ void scatter8_runs(float2 *__restrict__ gg, const LevelC &L, const Loc (&q)[3], float g0, float g1, int lane)
+template <class Sink>
+__device__ __forceinline__ void scatter8_runs(Sink &sink, const LevelC &L, const Loc (&q)[3], float g0, float g1, int lane)
 {
     const bool ok = !(q[0].oob | q[1].oob | q[2].oob);
     float v[16];
@@ -143,51 +223,31 @@ __device__ __forceinline__ void scatter8_runs(float2 *__restrict__ gg, const Lev
         for (uint32_t d = 0; d < 3; ++d) w *= ((idx >> d) & 1u) ? q[d].fr : 1.0f - q[d].fr;
         v[2 * idx] = ok ? w * g0 : 0.0f; v[2 * idx + 1] = ok ? w * g1 : 0.0f;
     }
-    const bool tail = run_reduce<16>(v, run_head(q, ok, lane), lane);
-    if (!tail || !ok) return;
+    const bool tail = run_reduce<16>(v, run_head(q, ok, lane), lane) && ok;
 #pragma unroll
-    for (uint32_t idx = 0; idx < 8; ++idx) {
-        if (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f) {
-            float *t = reinterpret_cast<float *>(gg + gindex(L, q[0].pg + (idx & 1u), q[1].pg + ((idx >> 1) & 1u), q[2].pg + ((idx >> 2) & 1u)));
-            AC_ATOMIC_ADD(t, v[2 * idx]); AC_ATOMIC_ADD(t + 1, v[2 * idx + 1]);
-        }
-    }
+    for (uint32_t idx = 0; idx < 8; ++idx)
+        sink.add(tail && (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f),
+                 gindex(L, q[0].pg + (idx & 1u), q[1].pg + ((idx >> 1) & 1u), q[2].pg + ((idx >> 2) & 1u)), v[2 * idx], v[2 * idx + 1]);
 }
 
-// fine_mask bit l: eps can reach a non-neighbouring cell on level l -> the seven points scatter independently
-__global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ x,
-                                                               float *__restrict__ grad_grid, uint32_t B, ac::LevelTable lt, float eps,
-                                                               float bound, float two_bound, uint32_t fine_mask, float *__restrict__ priv,
-                                                               uint32_t n_priv, uint32_t priv_entries, uint32_t n_copies)
+// the seven stencil points of one sample per lane (64 consecutive samples per wave) on one level.
+// fine: eps can reach a non-neighbouring cell on this level -> the seven points scatter independently
+template <class Sink>
+__device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, bool fine, const float (&xc)[3], const float2 (&gp)[7], float eps,
+                                                float bound, float two_bound, int lane, uint32_t fine_room)
 {
-    const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = b0 < B;
-    const uint32_t b = valid ? b0 : B - 1;
-    const int lane = threadIdx.x & 63;
-    const uint32_t level = blockIdx.y, Lc = lt.L;
-    const LevelC L = level_of(lt, level);
-    // the small dense levels take bursts of same-address atomics from neighbouring rays: spread them over n_copies private
-    // copies (one per workgroup, round robin), summed into the table by priv_reduce_kernel
-    float2 *gg = (level < n_priv) ? reinterpret_cast<float2 *>(priv) + (size_t)(blockIdx.x % n_copies) * priv_entries + lt.offset[level]
-                                  : reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
-    const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
-    float2 gp[7];
-#pragma unroll
-    for (int p = 0; p < 7; ++p) {
-        gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
-        if (!valid) gp[p] = make_float2(0.0f, 0.0f);
-    }
     Loc c[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) c[d] = locate(xc[d], bound, two_bound, L.scale);
     const bool cen_ok = !(c[0].oob | c[1].oob | c[2].oob);
 
-    if (((fine_mask >> level) & 1u) || !__all(cen_ok)) {     // wave-uniform: every lane takes the same path (shuffles inside)
+    if (fine || !__all(cen_ok)) {                        // wave-uniform: every lane takes the same path (shuffles inside)
 #pragma unroll
         for (int p = 0; p < 7; ++p) {
             Loc q[3] = { c[0], c[1], c[2] };
             if (p > 0) { const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale); }
-            scatter8_runs(gg, L, q, gp[p].x, gp[p].y, lane);
+            sink_reserve(sink, fine_room);
+            scatter8_runs(sink, L, q, gp[p].x, gp[p].y, lane);
         }
         return;
     }
@@ -230,14 +290,10 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
         }
     }
     const bool tail = run_reduce<64>(v, run_head(c, true, lane), lane);
-    if (!tail) return;
 #pragma unroll
-    for (uint32_t idx = 0; idx < 8; ++idx) {
-        if (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f) {
-            float *t = reinterpret_cast<float *>(gg + gindex(L, c[0].pg + (idx & 1u), c[1].pg + ((idx >> 1) & 1u), c[2].pg + ((idx >> 2) & 1u)));
-            AC_ATOMIC_ADD(t, v[2 * idx]); AC_ATOMIC_ADD(t + 1, v[2 * idx + 1]);
-        }
-    }
+    for (uint32_t idx = 0; idx < 8; ++idx)
+        sink.add(tail && (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f),
+                 gindex(L, c[0].pg + (idx & 1u), c[1].pg + ((idx >> 1) & 1u), c[2].pg + ((idx >> 2) & 1u)), v[2 * idx], v[2 * idx + 1]);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -245,17 +301,109 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
 #pragma unroll
             for (uint32_t jm = 0; jm < 4; ++jm) {
                 const uint32_t e = 16 + ((k * 2 + s) * 4 + jm) * 2;
-                if (v[e] != 0.0f || v[e + 1] != 0.0f) {
-                    uint32_t pl[3];
-                    const uint32_t lo = jm & 1u, hi = jm >> 1;
-                    pl[0] = c[0].pg + (k == 0 ? 0u : lo);
-                    pl[1] = c[1].pg + (k == 1 ? 0u : (k == 0 ? lo : hi));
-                    pl[2] = c[2].pg + (k == 2 ? 0u : hi);
-                    pl[k] = s ? c[k].pg + 2u : c[k].pg - 1u;
-                    float *t = reinterpret_cast<float *>(gg + gindex(L, pl[0], pl[1], pl[2]));
-                    AC_ATOMIC_ADD(t, v[e]); AC_ATOMIC_ADD(t + 1, v[e + 1]);
-                }
+                uint32_t pl[3];
+                const uint32_t lo = jm & 1u, hi = jm >> 1;
+                pl[0] = c[0].pg + (k == 0 ? 0u : lo);
+                pl[1] = c[1].pg + (k == 1 ? 0u : (k == 0 ? lo : hi));
+                pl[2] = c[2].pg + (k == 2 ? 0u : hi);
+                pl[k] = s ? c[k].pg + 2u : c[k].pg - 1u;
+                sink.add(tail && (v[e] != 0.0f || v[e + 1] != 0.0f), gindex(L, pl[0], pl[1], pl[2]), v[e], v[e + 1]);
             }
+}
+
+// direct atomics: one sample per thread, level = blockIdx.y in [0, n_levels)
+__global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ x,
+                                                               float *__restrict__ grad_grid, uint32_t B, ac::LevelTable lt, float eps,
+                                                               float bound, float two_bound, uint32_t fine_mask, float *__restrict__ priv,
+                                                               uint32_t n_priv, uint32_t priv_entries, uint32_t n_copies, uint32_t direct_mask)
+{
+    const uint32_t level = blockIdx.y, Lc = lt.L;
+    if (!((direct_mask >> level) & 1u)) return;          // this level goes through the binned path
+    const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = b0 < B;
+    const uint32_t b = valid ? b0 : B - 1;
+    const int lane = threadIdx.x & 63;
+    const LevelC L = level_of(lt, level);
+    // the small dense levels take bursts of same-address atomics from neighbouring rays: spread them over n_copies private
+    // copies (one per workgroup, round robin), summed into the table by priv_reduce_kernel
+    DirectSink sink;
+    sink.gg = (level < n_priv) ? reinterpret_cast<float2 *>(priv) + (size_t)(blockIdx.x % n_copies) * priv_entries + lt.offset[level]
+                               : reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
+    const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
+    float2 gp[7];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
+        if (!valid) gp[p] = make_float2(0.0f, 0.0f);
+    }
+    stencil_scatter(sink, L, ((fine_mask >> level) & 1u) != 0, xc, gp, eps, bound, two_bound, lane, 0u);
+}
+
+// binned path: blockIdx.y indexes the binned levels; every wave walks over groups of 64 samples and flushes its record buffer
+// when the next batch might not fit
+__global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const float *__restrict__ grad, const float *__restrict__ x,
+                                                                      float *__restrict__ grad_grid, uint32_t B, ac::LevelTable lt, float eps,
+                                                                      float bound, float two_bound, uint32_t fine_mask, uint32_t binned_mask,
+                                                                      uint32_t *__restrict__ qcount, Rec *__restrict__ queues, uint32_t cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // the blockIdx.y-th set bit of binned_mask
+    uint32_t level = 0, seen = 0;
+    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
+    const uint32_t Lc = lt.L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LevelC L = level_of(lt, level);
+    uint32_t *wbase = smem + wave * (3 * RCAP + 2 * NBUCKET);
+    BinSink sink;
+    sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
+    sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
+    sink.cnt = 0; sink.lane = lane;
+    sink.shift = 31u - (uint32_t)__builtin_clz(lt.size[level]) - 6u;         // size is a power of two here: size / 64 entries per bucket
+    sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
+    sink.queue = queues + (size_t)blockIdx.y * NBUCKET * cap;
+    sink.cap = cap;
+    sink.gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
+    sink.hist[lane] = 0u;
+    const bool fine = ((fine_mask >> level) & 1u) != 0;
+    const uint32_t ngroups = (B + 63) / 64;
+    for (uint32_t grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+        const uint32_t b0 = grp * 64 + lane;
+        const bool valid = b0 < B;
+        const uint32_t b = valid ? b0 : B - 1;
+        const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
+        float2 gp[7];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
+            if (!valid) gp[p] = make_float2(0.0f, 0.0f);
+        }
+        sink_reserve(sink, 2048u);                       // the combined path emits <= 32 slots per lane in one go
+        stencil_scatter(sink, L, fine, xc, gp, eps, bound, two_bound, lane, 512u);
+    }
+    sink.flush();
+}
+
+// one workgroup per (bucket, binned level): sum the bucket's queue in LDS, then add the slice to the table (no atomics: the
+// workgroup owns these entries, and every producer of records has finished -- kernel boundary)
+__global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restrict__ grad_grid, ac::LevelTable lt, uint32_t binned_mask,
+                                                                 const uint32_t *__restrict__ qcount, const Rec *__restrict__ queues, uint32_t cap)
+{
+    extern __shared__ __attribute__((aligned(16))) float acc[];            // [entries per bucket][2]
+    uint32_t level = 0, seen = 0;
+    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
+    const uint32_t per = lt.size[level] / NBUCKET, bucket = blockIdx.x;
+    for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) acc[e] = 0.0f;
+    __syncthreads();
+    uint32_t n = qcount[(size_t)blockIdx.y * NBUCKET + bucket];
+    n = n < cap ? n : cap;
+    const Rec *q = queues + ((size_t)blockIdx.y * NBUCKET + bucket) * cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const Rec r = q[i];
+        atomicAdd(&acc[2 * r.idx], r.v0); atomicAdd(&acc[2 * r.idx + 1], r.v1);
+    }
+    __syncthreads();
+    float *dst = grad_grid + ((size_t)lt.offset[level] + (size_t)bucket * per) * 2;
+    for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) { const float v = acc[e]; if (v != 0.0f) dst[e] += v; }
 }
 
 __global__ __launch_bounds__(256) void priv_reduce_kernel(const float *__restrict__ priv, uint32_t n_floats, uint32_t n_copies,
@@ -299,12 +447,37 @@ static uint32_t priv_levels(const ac::LevelTable &lt, uint32_t L, uint32_t &entr
     return n;
 }
 
-AC_API size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_copies)
+// levels that go through the binned path: hashed, power-of-two size between 2^16 and 2^19 (64 buckets of <= 8192 entries = 64 KB of LDS)
+static uint32_t binned_levels(const ac::LevelTable &lt, uint32_t L)
+{
+    uint32_t m = 0;
+    for (uint32_t l = 0; l < L; ++l)
+        if (lt.hashed[l] && lt.pow2mask[l] && lt.size[l] >= (1u << 16) && lt.size[l] <= (1u << 19)) m |= 1u << l;
+    return m;
+}
+static uint32_t queue_cap(uint32_t B) { return (uint32_t)(((uint64_t)B * 56u * 3u / 2u) / NBUCKET) + 4096u; }   // 1.5 x the fine-level average
+
+struct StencilScratch { size_t priv_off, qcount_off, queue_off, total; uint32_t entries, n_priv, binned_mask, n_binned, cap; };
+static StencilScratch stencil_layout(const ac::LevelTable &lt, uint32_t L, uint32_t n_copies, uint32_t B)
+{
+    StencilScratch sc{};
+    sc.n_priv = n_copies >= 2 ? priv_levels(lt, L, sc.entries) : 0;
+    size_t off = 0;
+    sc.priv_off = off; off += ((size_t)sc.entries * 8 * (sc.n_priv ? n_copies : 0) + 255) & ~(size_t)255;
+    sc.binned_mask = B ? binned_levels(lt, L) : 0;
+    sc.n_binned = (uint32_t)__builtin_popcount(sc.binned_mask);
+    sc.cap = queue_cap(B);
+    sc.qcount_off = off; off += ((size_t)sc.n_binned * NBUCKET * 4 + 255) & ~(size_t)255;
+    sc.queue_off = off; off += (size_t)sc.n_binned * NBUCKET * sc.cap * sizeof(Rec);
+    sc.total = off;
+    return sc;
+}
+
+AC_API size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_copies, uint32_t B)
 {
     if (!offsets_host || L == 0 || L > AC_MAX_LEVELS) return 0;
     ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
-    uint32_t entries; priv_levels(lt, L, entries);
-    return (size_t)entries * 8 * n_copies;
+    return stencil_layout(lt, L, n_copies, B).total;
 }
 
 AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
@@ -316,23 +489,49 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
     if (!grad || !x || !grad_embeddings) { ac::set_error("hash_stencil_backward: NULL buffer"); return AC_ERR_BAD_ARG; }
     ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
     const float two_bound = (float)(2.0 * (double)bound);
+    hipStream_t st = (hipStream_t)stream;
     uint32_t fine_mask = 0;
     for (uint32_t l = 0; l < L; ++l) {           // same rule as the fused renderer's jfine (render_fused.hip)
         const double cells = (double)eps / (double)two_bound * (double)lt.scale[l];
         if (!(cells * 1.001 + 1e-3 < 1.0)) fine_mask |= 1u << l;
     }
-    uint32_t entries = 0, n_priv = 0, n_copies = 1;
+    // scratch: the layout for the largest copy count (<= 64) that fits; without scratch everything goes through direct atomics
+    StencilScratch sc{};
+    uint32_t n_copies = 1;
     if (scratch) {
-        n_priv = priv_levels(lt, L, entries);
-        n_copies = entries ? (uint32_t)(scratch_bytes / ((size_t)entries * 8)) : 0;
-        if (n_copies > 64) n_copies = 64;
-        if (n_copies < 2) { n_priv = 0; n_copies = 1; }
-        else hipMemsetAsync(scratch, 0, (size_t)entries * 8 * n_copies, (hipStream_t)stream);
+        for (uint32_t k = 64; k >= 1; k >>= 1) {
+            sc = stencil_layout(lt, L, k, B);
+            if (sc.total <= scratch_bytes) { n_copies = k; break; }
+            if (k == 1) { sc = StencilScratch{}; }
+        }
     }
-    hipLaunchKernelGGL(hash_stencil_bwd_kernel, dim3((B + 255) / 256, L), dim3(256), 0, (hipStream_t)stream, grad, x, grad_embeddings, B, lt, eps,
-                       bound, two_bound, fine_mask, static_cast<float *>(scratch), n_priv, entries, n_copies);
-    if (n_priv)
-        hipLaunchKernelGGL(priv_reduce_kernel, dim3((entries * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
-                           entries * 2, n_copies, grad_embeddings);
+    char *sb = static_cast<char *>(scratch);
+    float *priv = sc.n_priv ? reinterpret_cast<float *>(sb + sc.priv_off) : nullptr;
+    if (sc.n_priv) hipMemsetAsync(priv, 0, (size_t)sc.entries * 8 * n_copies, st);
+    uint32_t *qcount = sc.n_binned ? reinterpret_cast<uint32_t *>(sb + sc.qcount_off) : nullptr;
+    Rec *queues = sc.n_binned ? reinterpret_cast<Rec *>(sb + sc.queue_off) : nullptr;
+    const uint32_t all = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+    const uint32_t direct_mask = all & ~sc.binned_mask;
+    if (direct_mask)
+        hipLaunchKernelGGL(hash_stencil_bwd_kernel, dim3((B + 255) / 256, L), dim3(256), 0, st, grad, x, grad_embeddings, B, lt, eps, bound, two_bound,
+                           fine_mask, priv, sc.n_priv, sc.entries, n_copies, direct_mask);
+    if (sc.n_binned) {
+        hipMemsetAsync(qcount, 0, (size_t)sc.n_binned * NBUCKET * 4, st);
+        static bool attr_set = false;
+        const size_t lds1 = (size_t)4 * (3 * RCAP + 2 * NBUCKET) * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 8;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(hash_stencil_bwd_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            attr_set = true;
+        }
+        uint32_t gx = ((B + 63) / 64 + 3) / 4;
+        if (gx > 256) gx = 256;                          // persistent waves: full record buffers per flush
+        hipLaunchKernelGGL(hash_stencil_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, x, grad_embeddings, B, lt, eps, bound,
+                           two_bound, fine_mask, sc.binned_mask, qcount, queues, sc.cap);
+        hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount,
+                           queues, sc.cap);
+    }
+    if (sc.n_priv)
+        hipLaunchKernelGGL(priv_reduce_kernel, dim3((sc.entries * 2 + 255) / 256), dim3(256), 0, st, priv, sc.entries * 2, n_copies, grad_embeddings);
     return ac::check_launch("hash_stencil_backward");
 }

@@ -17,11 +17,17 @@ PRIVATE_COPIES = 16         # private copies of the small dense levels in the st
 _SCRATCH = {}
 
 
-def stencil_scratch(offsets_host, L_, S, H, device):
-    """(tensor, nbytes): device scratch for ac_hash_stencil_backward, cached per (device, layout); (None, 0) if not needed"""
-    key = (str(device), int(offsets_host[-1]), L_, S, H)
+BINNED_SCATTER = True       # hashed levels through the binned two-pass scatter (needs ~8 KB of device scratch per sample)
+
+
+def stencil_scratch(offsets_host, L_, S, H, device, B=0):
+    """(tensor, nbytes): device scratch for ac_hash_stencil_backward, cached per (device, layout, batch size); (None, 0) if not needed"""
+    B = int(B) if BINNED_SCATTER else 0
+    key = (str(device), int(offsets_host[-1]), L_, S, H, B)
     if key not in _SCRATCH:
-        nbytes = int(L.lib().ac_hash_stencil_backward_scratch(offsets_host.ctypes.data, L_, S, H, PRIVATE_COPIES))
+        for k in [k for k in _SCRATCH if k[:5] == key[:5]]:          # one batch size at a time per layout: free the previous queues
+            del _SCRATCH[k]
+        nbytes = int(L.lib().ac_hash_stencil_backward_scratch(offsets_host.ctypes.data, L_, S, H, PRIVATE_COPIES, B))
         _SCRATCH[key] = (torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None, nbytes)
     return _SCRATCH[key]
 
@@ -76,7 +82,7 @@ class _Backend:
     def hash_stencil_backward(grad, x, offsets, grad_embeddings, B, C, L_, S, H, eps, bound):
         L.require_cuda(grad, x, offsets, grad_embeddings)
         oh = _Backend._offsets_host(offsets)
-        scratch, nbytes = stencil_scratch(oh, L_, float(np.float32(S)), H, x.device)
+        scratch, nbytes = stencil_scratch(oh, L_, float(np.float32(S)), H, x.device, B)
         L.check(L.lib().ac_hash_stencil_backward(grad.data_ptr(), x.data_ptr(), oh.ctypes.data, grad_embeddings.data_ptr(), B, C, L_,
                                                  float(np.float32(S)), H, float(eps), float(bound), L.ptr(scratch), nbytes,
                                                  L.current_stream(x.device)), "hash_stencil_backward")

@@ -217,7 +217,7 @@ class _SdfStencil(torch.autograd.Function):
         g_table = torch.zeros_like(table)
         oh = np.asarray(offsets, dtype=np.int32)
         from .encoder.hashencoder.backend import stencil_scratch
-        hs, hbytes = stencil_scratch(oh, 16, field.S, H, dev)
+        hs, hbytes = stencil_scratch(oh, 16, field.S, H, dev, B)
         L.check(L.lib().ac_hash_stencil_backward(gfeat.data_ptr(), x.data_ptr(), oh.ctypes.data, g_table.data_ptr(), B, 2, 16, field.S, H, float(eps),
                                                  float(bound), L.ptr(hs), hbytes, st), "hash_stencil_backward")
         gW1b = gparams[:64 * 36].view(64, 36)

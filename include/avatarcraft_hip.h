@@ -213,9 +213,12 @@ int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *f
  */
 int ac_hash_stencil_forward(const float *x, const float *embeddings, const int32_t *offsets_host, float *outputs, uint32_t B,
                             uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream);
-/* scratch (optional, NULL = none): ac_hash_stencil_backward_scratch(offsets_host, L, S, H, n_copies) bytes for n_copies >= 2 private
- * copies of the small dense levels, which otherwise take bursts of same-address atomics from neighbouring rays. */
-size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_copies);
+/* scratch (optional, NULL = none = every level through hardware float atomics):
+ * ac_hash_stencil_backward_scratch(offsets_host, L, S, H, n_copies, B) bytes hold (a) n_copies >= 2 private copies of the small dense
+ * levels, which otherwise take bursts of same-address atomics from neighbouring rays, and (b) for B > 0 the per-bucket record queues of
+ * the hashed levels (binned two-pass scatter: records are queued by destination bucket with one global atomic per flush and bucket,
+ * then every bucket is summed in LDS by one workgroup and added to the table without atomics); ~4 GB for B = 524288. */
+size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_copies, uint32_t B);
 int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
                              uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
                              ac_stream_t stream);

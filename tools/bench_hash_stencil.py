@@ -36,7 +36,7 @@ for l, sc in enumerate(scales):
     offs = np.array([0, size], np.int32)
     gg = torch.zeros(size, 2, device=dev)
     grad = torch.randn(7, 1, B, 2, device=dev)
-    nb = int(L.lib().ac_hash_stencil_backward_scratch(offs.ctypes.data, 1, 0.0, H, int(os.environ.get('COPIES', 16))))
+    nb = int(L.lib().ac_hash_stencil_backward_scratch(offs.ctypes.data, 1, 0.0, H, int(os.environ.get('COPIES', 16)), B if os.environ.get('BINNED', '1') == '1' else 0))
     scr = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
     tm = timeit(lambda: L.check(L.lib().ac_hash_stencil_backward(grad.data_ptr(), x.data_ptr(), offs.ctypes.data, gg.data_ptr(), B, 2, 1, 0.0, H, 0.005, 1.6, scr.data_ptr() if scr is not None else None, nb, st)))
     tot += tm
