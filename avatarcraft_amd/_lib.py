@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavatarcraft_hip.so")
+LIB_PATH = os.environ.get("AC_LIB_PATH") or os.path.join(_HERE, "libavatarcraft_hip.so")      # AC_LIB_PATH: ablation builds (tools/)
 
 _lib = None
 

@@ -154,14 +154,14 @@ struct DirectSink {
 };
 
 constexpr int NBUCKET = 64;
-constexpr int RCAP = 2560;                 // records per wave buffer: a flush leaves <= 512, one sample group adds <= 2048
+constexpr int RCAP = 1536;                 // records per wave buffer: every emission step adds <= 512 (8 slots x 64 lanes) after a reserve(512)
 struct Rec { uint32_t idx; float v0, v1; };
 
 struct BinSink {
     uint32_t *ridx; float *rv0, *rv1;      // this wave's LDS record buffer [RCAP]
     uint32_t *hist, *base;                 // this wave's LDS [NBUCKET] each (hist zero between flushes)
     uint32_t cnt;                          // wave-uniform
-    uint32_t shift;                        // bucket = index >> shift
+    uint32_t per;                          // entries per bucket: bucket = index / per
     uint32_t *qcount;                      // global [NBUCKET] of this level
     Rec *queue;                            // global [NBUCKET][cap] of this level
     uint32_t cap;
@@ -181,7 +181,7 @@ struct BinSink {
         wave_sync_lds();
         for (uint32_t i = lane; i < cnt; i += 64) {
             const uint32_t idx = ridx[i];
-            const uint32_t rank = atomicAdd(&hist[idx >> shift], 1u);
+            const uint32_t rank = atomicAdd(&hist[idx / per], 1u);
             ridx[i] = idx | (rank << 19);
         }
         wave_sync_lds();
@@ -192,11 +192,11 @@ struct BinSink {
         }
         wave_sync_lds();
         for (uint32_t i = lane; i < cnt; i += 64) {
-            const uint32_t packed = ridx[i], idx = packed & 0x7ffffu, bucket = idx >> shift;
+            const uint32_t packed = ridx[i], idx = packed & 0x7ffffu, bucket = idx / per;
             const uint32_t slot = base[bucket] + (packed >> 19);
             const float v0 = rv0[i], v1 = rv1[i];
             if (slot < cap) {
-                Rec r; r.idx = idx & ((1u << shift) - 1u); r.v0 = v0; r.v1 = v1;
+                Rec r; r.idx = idx - bucket * per; r.v0 = v0; r.v1 = v1;
                 queue[(size_t)bucket * cap + slot] = r;
             } else {                        // queue full (never with the default sizing): fall back to atomics
                 float *t = reinterpret_cast<float *>(gg + idx); AC_ATOMIC_ADD(t, v0); AC_ATOMIC_ADD(t + 1, v1);
@@ -290,12 +290,14 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
         }
     }
     const bool tail = run_reduce<64>(v, run_head(c, true, lane), lane);
+    sink_reserve(sink, fine_room);
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; ++idx)
         sink.add(tail && (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f),
                  gindex(L, c[0].pg + (idx & 1u), c[1].pg + ((idx >> 1) & 1u), c[2].pg + ((idx >> 2) & 1u)), v[2 * idx], v[2 * idx + 1]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k) {
+        sink_reserve(sink, fine_room);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -309,6 +311,7 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
                 pl[k] = s ? c[k].pg + 2u : c[k].pg - 1u;
                 sink.add(tail && (v[e] != 0.0f || v[e + 1] != 0.0f), gindex(L, pl[0], pl[1], pl[2]), v[e], v[e + 1]);
             }
+    }
 }
 
 // direct atomics: one sample per thread, level = blockIdx.y in [0, n_levels)
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
     sink.cnt = 0; sink.lane = lane;
-    sink.shift = 31u - (uint32_t)__builtin_clz(lt.size[level]) - 6u;         // size is a power of two here: size / 64 entries per bucket
+    sink.per = (lt.size[level] + NBUCKET - 1) / NBUCKET;
     sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
     sink.queue = queues + (size_t)blockIdx.y * NBUCKET * cap;
     sink.cap = cap;
@@ -377,7 +380,6 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
             gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
             if (!valid) gp[p] = make_float2(0.0f, 0.0f);
         }
-        sink_reserve(sink, 2048u);                       // the combined path emits <= 32 slots per lane in one go
         stencil_scatter(sink, L, fine, xc, gp, eps, bound, two_bound, lane, 512u);
     }
     sink.flush();
@@ -391,19 +393,30 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
     extern __shared__ __attribute__((aligned(16))) float acc[];            // [entries per bucket][2]
     uint32_t level = 0, seen = 0;
     for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
-    const uint32_t per = lt.size[level] / NBUCKET, bucket = blockIdx.x;
+    const uint32_t per = (lt.size[level] + NBUCKET - 1) / NBUCKET, bucket = blockIdx.x;
+    const uint32_t first = bucket * per;
+    const uint32_t mine = first >= lt.size[level] ? 0u : (lt.size[level] - first < per ? lt.size[level] - first : per);     // the last bucket may be short
     for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) acc[e] = 0.0f;
     __syncthreads();
     uint32_t n = qcount[(size_t)blockIdx.y * NBUCKET + bucket];
     n = n < cap ? n : cap;
     const Rec *q = queues + ((size_t)blockIdx.y * NBUCKET + bucket) * cap;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const Rec r = q[i];
-        atomicAdd(&acc[2 * r.idx], r.v0); atomicAdd(&acc[2 * r.idx + 1], r.v1);
+    constexpr int U = 8;                                 // records in flight per thread (the loop is latency bound otherwise)
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += blockDim.x * U) {
+        Rec r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * blockDim.x; r[u] = q[i < n ? i : i0]; if (i >= n) { r[u].v0 = 0.0f; r[u].v1 = 0.0f; } }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#ifdef AC_ABL_NOLDSATOMIC
+            if (r[u].v0 != 0.0f || r[u].v1 != 0.0f) { acc[2 * r[u].idx] = r[u].v0; acc[2 * r[u].idx + 1] = r[u].v1; }
+#else
+            if (r[u].v0 != 0.0f || r[u].v1 != 0.0f) { atomicAdd(&acc[2 * r[u].idx], r[u].v0); atomicAdd(&acc[2 * r[u].idx + 1], r[u].v1); }
+#endif
     }
     __syncthreads();
-    float *dst = grad_grid + ((size_t)lt.offset[level] + (size_t)bucket * per) * 2;
-    for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) { const float v = acc[e]; if (v != 0.0f) dst[e] += v; }
+    float *dst = grad_grid + ((size_t)lt.offset[level] + (size_t)first) * 2;
+    for (uint32_t e = threadIdx.x; e < mine * 2; e += blockDim.x) { const float v = acc[e]; if (v != 0.0f) dst[e] += v; }
 }
 
 __global__ __launch_bounds__(256) void priv_reduce_kernel(const float *__restrict__ priv, uint32_t n_floats, uint32_t n_copies,
@@ -447,12 +460,12 @@ static uint32_t priv_levels(const ac::LevelTable &lt, uint32_t L, uint32_t &entr
     return n;
 }
 
-// levels that go through the binned path: hashed, power-of-two size between 2^16 and 2^19 (64 buckets of <= 8192 entries = 64 KB of LDS)
+// levels that go through the binned path: 64 buckets of <= 8192 entries (64 KB of LDS), i.e. every level of up to 2^19 entries
 static uint32_t binned_levels(const ac::LevelTable &lt, uint32_t L)
 {
     uint32_t m = 0;
     for (uint32_t l = 0; l < L; ++l)
-        if (lt.hashed[l] && lt.pow2mask[l] && lt.size[l] >= (1u << 16) && lt.size[l] <= (1u << 19)) m |= 1u << l;
+        if (lt.size[l] >= (uint32_t)NBUCKET && lt.size[l] <= (1u << 19)) m |= 1u << l;
     return m;
 }
 static uint32_t queue_cap(uint32_t B) { return (uint32_t)(((uint64_t)B * 56u * 3u / 2u) / NBUCKET) + 4096u; }   // 1.5 x the fine-level average
@@ -461,7 +474,7 @@ struct StencilScratch { size_t priv_off, qcount_off, queue_off, total; uint32_t 
 static StencilScratch stencil_layout(const ac::LevelTable &lt, uint32_t L, uint32_t n_copies, uint32_t B)
 {
     StencilScratch sc{};
-    sc.n_priv = n_copies >= 2 ? priv_levels(lt, L, sc.entries) : 0;
+    sc.n_priv = (n_copies >= 2 && B == 0) ? priv_levels(lt, L, sc.entries) : 0;       // with queues (B > 0) every level is binned
     size_t off = 0;
     sc.priv_off = off; off += ((size_t)sc.entries * 8 * (sc.n_priv ? n_copies : 0) + 255) & ~(size_t)255;
     sc.binned_mask = B ? binned_levels(lt, L) : 0;

@@ -339,3 +339,45 @@ def test_warp_tiny_point_sets(oracle, P):
         assert np.array_equal(mask.cpu().numpy(), m_o)
     empty = RY.warp_samples_to_canonical(torch.empty(0, 4, 3, device=DEV), T(verts), torch.from_numpy(faces).to(DEV), torch.from_numpy(Ts).to(DEV), 0.05)
     assert empty[0].shape == (0, 4, 3)
+
+
+def test_hash_stencil_backward_paths_agree():
+    """the three scatter paths of ac_hash_stencil_backward give the same table gradient (up to summation order):
+    no scratch (hardware float atomics), private copies of the dense levels only, binned two-pass scatter"""
+    from avatarcraft_amd import _lib as Lb
+    from avatarcraft_amd.encoder.hashencoder.hashgrid import HashEncoder
+    enc = HashEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048).to(DEV)
+    rs = np.random.RandomState(8)
+    B = 70000                                                   # > 64 * RCAP / 56: several flushes per wave, partial last group
+    z = np.sort(rs.uniform(0.2, 3.0, size=(B // 100, 100)), axis=1)   # depth-sorted samples along rays: long same-cell runs
+    o = rs.uniform(-0.3, 0.3, size=(B // 100, 1, 3)); d = rs.normal(size=(B // 100, 1, 3)); d /= np.linalg.norm(d, axis=2, keepdims=True)
+    x = torch.from_numpy(np.clip(o - d * 1.5 + d * z[:, :, None], -1.6, 1.6).reshape(-1, 3).astype(np.float32)).to(DEV)
+    g = torch.from_numpy(rs.normal(size=(7, 16, B, 2)).astype(np.float32)).to(DEV)
+    g[:, :, ::3] = 0.0                                          # exact zeros are skipped
+    oh = enc.offsets.cpu().numpy().astype(np.int32)
+    S = float(np.float32(np.log2(enc.per_level_scale)))
+    outs = []
+    for copies, nb in ((0, 0), (16, 0), (16, B)):
+        gt = torch.zeros_like(enc.embeddings)
+        nbytes = int(Lb.lib().ac_hash_stencil_backward_scratch(oh.ctypes.data, 16, S, 16, copies, nb)) if copies else 0
+        sc = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=DEV)
+        Lb.check(Lb.lib().ac_hash_stencil_backward(g.data_ptr(), x.data_ptr(), oh.ctypes.data, gt.data_ptr(), B, 2, 16, S, 16, 0.005, 1.6,
+                                                   sc.data_ptr() if nbytes else None, nbytes, None))
+        torch.cuda.synchronize()
+        outs.append(gt)
+    scale = float(outs[0].abs().max())
+    assert scale > 0
+    for k in (1, 2):
+        assert float((outs[k] - outs[0]).abs().max()) <= 2e-5 * scale, k
+    # adversarial distribution: two alternating points -> no runs, all records of a level land in a handful of buckets, whose queues
+    # overflow into the atomic path; the sums must not change
+    x2 = x.clone(); x2[0::2] = torch.tensor([0.31, -0.42, 0.77], device=DEV); x2[1::2] = torch.tensor([-1.01, 0.63, -0.2], device=DEV)
+    res = []
+    for nb in (0, B):
+        gt = torch.zeros_like(enc.embeddings)
+        nbytes = int(Lb.lib().ac_hash_stencil_backward_scratch(oh.ctypes.data, 16, S, 16, 16, nb))
+        sc = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=DEV)
+        Lb.check(Lb.lib().ac_hash_stencil_backward(g.data_ptr(), x2.data_ptr(), oh.ctypes.data, gt.data_ptr(), B, 2, 16, S, 16, 0.005, 1.6, sc.data_ptr(), nbytes, None))
+        torch.cuda.synchronize()
+        res.append(gt)
+    assert float((res[1] - res[0]).abs().max()) <= 1e-4 * float(res[0].abs().max())
