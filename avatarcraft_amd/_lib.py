@@ -73,6 +73,8 @@ _SIGS = {
     "ac_color_forward": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),
     "ac_color_backward_scratch": ([u32], C.c_size_t),
     "ac_color_backward": ([C.POINTER(ac_field), vp, vp, vp, vp, u32, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+    "ac_composite_forward": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp], C.c_int),
+    "ac_composite_backward": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_render_rays_warped_scratch": ([i32, i32, C.POINTER(C.c_size_t)], C.c_size_t),
     "ac_render_rays_warped": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_warp_mesh), vp, C.c_size_t,
                                C.POINTER(ac_render_out), vp], C.c_int),

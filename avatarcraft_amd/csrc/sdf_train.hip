@@ -498,6 +498,171 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
         for (int r = 0; r < 4; ++r) part[64 * 32 + 64 * 64 + (4 * g + r) * 64 + 16 * c + n] = gW3[c][r];
 }
 
+// ======================================================================================================================
+// NeuS alpha + compositing of the render core (models/instant_nsr.py:219-263,290-299) for training: one wave per ray, the
+// forward is the renderer's own arithmetic (16-sample tile scans with sequential carry), the backward recomputes it.
+//   forward : (z, sdf, normal, colour, ray) -> image, weights_sum, depth, normal_map, weights, alpha
+//   backward: (d image, d weights_sum, d depth, d normal_map) -> d sdf, d normal, d colour, per-ray partial of d inv_s
+struct CompArgs {
+    const float *rays_o, *rays_d, *z, *sdf, *nrm, *col, *bg;
+    int n_rays, T0, T;
+    float bound, inv_s, car, one_m_car;
+};
+
+struct CompSample { float alpha, om, u, pc, nc, half, delta, tc, zn; };
+
+__device__ __forceinline__ CompSample comp_sample(const float *__restrict__ spg, const CompArgs &a, const float *__restrict__ zr, int i, float sdf0,
+                                                  float nx, float ny, float nz, float dx, float dy, float dz, float near, float span, float sample_dist)
+{
+    CompSample s;
+    const float zi = zr[i];
+    s.delta = (i < a.T - 1) ? zr[i + 1] - zi : sample_dist;
+    s.tc = (dx * nx + dy * ny) + dz * nz;
+    const float a1 = dv_softplus100(spg, -s.tc * 0.5f + 0.5f) * a.one_m_car;
+    const float a2 = dv_softplus100(spg, -s.tc) * a.car;
+    const float iter_cos = -(a1 + a2);
+    s.half = iter_cos * s.delta * 0.5f;
+    s.pc = dv_sigmoid((sdf0 - s.half) * a.inv_s); s.nc = dv_sigmoid((sdf0 + s.half) * a.inv_s);
+    s.u = (s.pc - s.nc + 1e-5f) / (s.pc + 1e-5f);
+    s.alpha = clampf(s.u, 0.0f, 1.0f);
+    s.om = 1.0f - s.alpha + 1e-7f;
+    s.zn = clampf((zi - near) / span, 0.0f, 1.0f);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const CompArgs a, float *__restrict__ image, float *__restrict__ wsum,
+                                                            float *__restrict__ depth, float *__restrict__ nmap, float *__restrict__ weights,
+                                                            float *__restrict__ alpha_out)
+{
+    __shared__ float spg[512];
+    __shared__ float zsh[4][128];
+    for (int e = threadIdx.x; e < 512; e += blockDim.x) spg[e] = AC_SP_G[e >> 2][e & 3];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15;
+    float *zr = zsh[wave];
+    for (int ray = blockIdx.x * 4 + wave; ray < a.n_rays; ray += gridDim.x * 4) {
+        const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
+        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+        float near, far;
+        cube_near_far(ox, oy, oz, dx, dy, dz, a.bound, near, far);
+        const float span = far - near, sample_dist = span / (float)a.T0;
+        for (int i = lane; i < a.T; i += 64) zr[i] = a.z[(size_t)ray * a.T + i];
+        wave_sync();
+        float cT = 1.0f, s_w = 0.0f, s_r = 0.0f, s_g = 0.0f, s_b = 0.0f, s_nx = 0.0f, s_ny = 0.0f, s_nz = 0.0f, s_d = 0.0f;
+        for (int c = 0; c < a.T / 16; ++c) {
+            const int i = 16 * c + n;
+            const size_t si = (size_t)ray * a.T + i;
+            const float nx = a.nrm[3 * si], ny = a.nrm[3 * si + 1], nz = a.nrm[3 * si + 2];
+            const CompSample s = comp_sample(spg, a, zr, i, a.sdf[si], nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            const float loc = row_scan<true>(s.om);
+            const float sh = dpp_shr<1>(1.0f, loc);
+            float Tex;
+            if (n == 0) Tex = (c == 0) ? 1.0f : cT;
+            else Tex = (c == 0) ? sh : cT * sh;
+            const float tot = lane_bcast(loc, 15);
+            cT = (c == 0) ? tot : cT * tot;
+            const float wgt = s.alpha * Tex;
+            const float r = a.col[3 * si], g = a.col[3 * si + 1], b = a.col[3 * si + 2];
+#define AC_ACC(S, V) { const float t_ = lane_bcast(row_scan<false>(V), 15); S = (c == 0) ? t_ : S + t_; }
+            AC_ACC(s_w, wgt)
+            AC_ACC(s_r, r * wgt) AC_ACC(s_nx, nx * wgt)
+            AC_ACC(s_g, g * wgt) AC_ACC(s_ny, ny * wgt)
+            AC_ACC(s_b, b * wgt) AC_ACC(s_nz, nz * wgt)
+            AC_ACC(s_d, wgt * s.zn)
+#undef AC_ACC
+            if (lane < 16) { weights[si] = wgt; alpha_out[si] = s.alpha; }
+        }
+        if (lane == 0) {
+            const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
+            image[3 * ray] = s_r + (1.0f - s_w) * b0; image[3 * ray + 1] = s_g + (1.0f - s_w) * b1; image[3 * ray + 2] = s_b + (1.0f - s_w) * b2;
+            nmap[3 * ray] = s_nx; nmap[3 * ray + 1] = s_ny; nmap[3 * ray + 2] = s_nz;
+            wsum[ray] = s_w; depth[ray] = s_d;
+        }
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a, const float *__restrict__ g_image, const float *__restrict__ g_wsum,
+                                                            const float *__restrict__ g_depth, const float *__restrict__ g_nmap,
+                                                            float *__restrict__ g_sdf, float *__restrict__ g_nrm, float *__restrict__ g_col,
+                                                            float *__restrict__ g_invs_ray)
+{
+    __shared__ float spg[512];
+    __shared__ float zsh[4][128], tex[4][128], wq[4][128], psum[4][128];
+    for (int e = threadIdx.x; e < 512; e += blockDim.x) spg[e] = AC_SP_G[e >> 2][e & 3];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15;
+    float *zr = zsh[wave];
+    for (int ray = blockIdx.x * 4 + wave; ray < a.n_rays; ray += gridDim.x * 4) {
+        const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
+        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+        float near, far;
+        cube_near_far(ox, oy, oz, dx, dy, dz, a.bound, near, far);
+        const float span = far - near, sample_dist = span / (float)a.T0;
+        for (int i = lane; i < a.T; i += 64) zr[i] = a.z[(size_t)ray * a.T + i];
+        wave_sync();
+        const float gi0 = g_image[3 * ray], gi1 = g_image[3 * ray + 1], gi2 = g_image[3 * ray + 2];
+        const float gws = g_wsum[ray], gdp = g_depth[ray];
+        const float gn0 = g_nmap[3 * ray], gn1 = g_nmap[3 * ray + 1], gn2 = g_nmap[3 * ray + 2];
+        const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
+        // pass A: transmittance, weights, d loss / d w_i, prefix sums of dw_i w_i
+        float cT = 1.0f, run = 0.0f;
+        for (int c = 0; c < a.T / 16; ++c) {
+            const int i = 16 * c + n;
+            const size_t si = (size_t)ray * a.T + i;
+            const float nx = a.nrm[3 * si], ny = a.nrm[3 * si + 1], nz = a.nrm[3 * si + 2];
+            const CompSample s = comp_sample(spg, a, zr, i, a.sdf[si], nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            const float loc = row_scan<true>(s.om);
+            const float sh = dpp_shr<1>(1.0f, loc);
+            float Tex;
+            if (n == 0) Tex = (c == 0) ? 1.0f : cT;
+            else Tex = (c == 0) ? sh : cT * sh;
+            const float tot = lane_bcast(loc, 15);
+            cT = (c == 0) ? tot : cT * tot;
+            const float wgt = s.alpha * Tex;
+            const float r = a.col[3 * si], g = a.col[3 * si + 1], b = a.col[3 * si + 2];
+            const float dw = ((gi0 * (r - b0) + gi1 * (g - b1)) + gi2 * (b - b2)) + gws + gdp * s.zn + ((gn0 * nx + gn1 * ny) + gn2 * nz);
+            const float incl = row_scan<false>(dw * wgt) + run;
+            run = lane_bcast(incl, 15);
+            if (lane < 16) { tex[wave][i] = Tex; wq[wave][i] = dw; psum[wave][i] = incl; }
+        }
+        const float total = run;
+        wave_sync();
+        // pass B: every lane one sample (two chunks of 64)
+        float ds_acc = 0.0f;
+        for (int i = lane; i < a.T; i += 64) {
+            const size_t si = (size_t)ray * a.T + i;
+            const float nx = a.nrm[3 * si], ny = a.nrm[3 * si + 1], nz = a.nrm[3 * si + 2];
+            const float sdf0 = a.sdf[si];
+            const CompSample s = comp_sample(spg, a, zr, i, sdf0, nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            const float Tex = tex[wave][i], dw = wq[wave][i];
+            const float wgt = s.alpha * Tex;
+            const float suffix = total - psum[wave][i];                         // sum over j > i of dw_j w_j
+            const float dalpha = dw * Tex - suffix / s.om;
+            const float du = (s.u >= 0.0f && s.u <= 1.0f) ? dalpha : 0.0f;      // torch.clip passes the gradient on the closed interval
+            const float den = s.pc + 1e-5f;
+            const float dpc = du * s.nc / (den * den), dnc = -du / den;
+            const float dap = dpc * s.pc * (1.0f - s.pc), dan = dnc * s.nc * (1.0f - s.nc);
+            const float dsdf = (dap + dan) * a.inv_s;
+            const float dhalf = (dan - dap) * a.inv_s;
+            ds_acc += dap * (sdf0 - s.half) + dan * (sdf0 + s.half);
+            const float dic = dhalf * s.delta * 0.5f;
+            float v1, d1, v2, d2;
+            softplus100_vg(spg, -s.tc * 0.5f + 0.5f, v1, d1);
+            softplus100_vg(spg, -s.tc, v2, d2);
+            const float dtc = dic * (0.5f * d1 * a.one_m_car + d2 * a.car);
+            g_sdf[si] = dsdf;
+            g_nrm[3 * si] = dtc * dx + wgt * gn0; g_nrm[3 * si + 1] = dtc * dy + wgt * gn1; g_nrm[3 * si + 2] = dtc * dz + wgt * gn2;
+            g_col[3 * si] = wgt * gi0; g_col[3 * si + 1] = wgt * gi1; g_col[3 * si + 2] = wgt * gi2;
+        }
+        // per-ray partial of d inv_s: wave reduction
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ds_acc += __shfl_xor(ds_acc, d);
+        if (lane == 0) g_invs_ray[ray] = ds_acc;
+        wave_sync();
+    }
+}
+
 // generic: out[i] = sum over waves of partials[w][i], i < n_out
 __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float *__restrict__ partials, uint32_t nwaves, uint32_t n_out, float *__restrict__ out)
 {
@@ -630,4 +795,44 @@ AC_API int ac_color_backward(const ac_field *field, const float *x, const float 
     hipLaunchKernelGGL(partials_reduce_kernel, dim3((NPART_C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
                        blocks * TW, (uint32_t)NPART_C, gparams);
     return ac::check_launch("color_backward");
+}
+
+static int comp_args(CompArgs &a, const char *who, const float *rays_o, const float *rays_d, const float *z, const float *sdf, const float *nrm,
+                     const float *col, const float *bg, int32_t n_rays, int32_t T0, int32_t T, float bound, float inv_s, float car)
+{
+    if (!rays_o || !rays_d || !z || !sdf || !nrm || !col) { ac::set_error("%s: NULL buffer", who); return AC_ERR_BAD_ARG; }
+    if (T0 <= 0 || T % 16 || T < T0 || T > 128) { ac::set_error("%s: T0=%d T=%d unsupported (T a multiple of 16, <= 128)", who, T0, T); return AC_ERR_BAD_ARG; }
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.sdf = sdf; a.nrm = nrm; a.col = col; a.bg = bg;
+    a.n_rays = n_rays; a.T0 = T0; a.T = T; a.bound = bound; a.inv_s = inv_s; a.car = car; a.one_m_car = (float)(1.0 - (double)car);
+    return AC_OK;
+}
+
+AC_API int ac_composite_forward(const float *rays_o, const float *rays_d, const float *z_vals, const float *sdf, const float *normal, const float *color,
+                                const float *bg, int32_t n_rays, int32_t num_steps, int32_t T, float bound, float inv_s, float cos_anneal_ratio,
+                                float *image, float *weights_sum, float *depth, float *normal_map, float *weights, float *alpha, ac_stream_t stream)
+{
+    if (n_rays <= 0) return AC_OK;
+    CompArgs a{};
+    if (int rc = comp_args(a, "composite_forward", rays_o, rays_d, z_vals, sdf, normal, color, bg, n_rays, num_steps, T, bound, inv_s, cos_anneal_ratio)) return rc;
+    if (!image || !weights_sum || !depth || !normal_map || !weights || !alpha) { ac::set_error("composite_forward: NULL output"); return AC_ERR_BAD_ARG; }
+    int blocks = (n_rays + 3) / 4; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, image, weights_sum, depth, normal_map, weights, alpha);
+    return ac::check_launch("composite_forward");
+}
+
+AC_API int ac_composite_backward(const float *rays_o, const float *rays_d, const float *z_vals, const float *sdf, const float *normal, const float *color,
+                                 const float *bg, int32_t n_rays, int32_t num_steps, int32_t T, float bound, float inv_s, float cos_anneal_ratio,
+                                 const float *g_image, const float *g_weights_sum, const float *g_depth, const float *g_normal_map,
+                                 float *g_sdf, float *g_normal, float *g_color, float *g_inv_s_per_ray, ac_stream_t stream)
+{
+    if (n_rays <= 0) return AC_OK;
+    CompArgs a{};
+    if (int rc = comp_args(a, "composite_backward", rays_o, rays_d, z_vals, sdf, normal, color, bg, n_rays, num_steps, T, bound, inv_s, cos_anneal_ratio)) return rc;
+    if (!g_image || !g_weights_sum || !g_depth || !g_normal_map || !g_sdf || !g_normal || !g_color || !g_inv_s_per_ray) {
+        ac::set_error("composite_backward: NULL buffer"); return AC_ERR_BAD_ARG;
+    }
+    int blocks = (n_rays + 3) / 4; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, g_image, g_weights_sum, g_depth, g_normal_map, g_sdf,
+                       g_normal, g_color, g_inv_s_per_ray);
+    return ac::check_launch("composite_backward");
 }

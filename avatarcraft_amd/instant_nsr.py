@@ -144,6 +144,23 @@ class NeRFRenderer(nn.Module):
             color = self.forward_color_fused(flat, normal.reshape(-1, 3), sdf_out)
         else:
             color = self.forward_color(flat, dirs.reshape(-1, 3), normal.reshape(-1, 3), feat, bound)
+        pts_norm = torch.linalg.norm(flat, ord=2, dim=-1, keepdim=True).reshape(N, T)
+        relax = (pts_norm < 1.2).float().detach()
+        gerr = (torch.linalg.norm(gradient.reshape(N, T, 3), ord=2, dim=-1) - 1.0) ** 2
+        gradient_error = (relax * gerr).sum() / (relax.sum() + 1e-5)
+        assert (gradient == gradient).all(), 'Nan or Inf found!'
+        if self.fused_training and self._fused_supported() and flat.is_cuda and T % 16 == 0 and T <= 128:
+            # NeuS alpha + compositing as one fused op each way (same arithmetic as the inference renderer)
+            bg = None
+            if bg_color is not None:
+                bg = torch.as_tensor(bg_color, dtype=torch.float32, device=flat.device)
+                bg = bg.reshape(-1, 3) if bg.numel() >= 3 else bg.reshape(1, 1).expand(1, 3)
+                bg = (bg.expand(N, 3) if bg.shape[0] == 1 else bg).contiguous()
+            image, wsum, depth, normal_map, weights, alpha = nsr_ops.composite(
+                z_vals, sdf.reshape(N, T), normal.reshape(N, T, 3), color.reshape(N, T, 3), self.forward_variance(), rays_o, rays_d, bg, num_steps0,
+                bound, cos_anneal_ratio)
+            return (depth.reshape(B, N), weights, wsum[:, None], image.reshape(B, N, 3), normal_map, gradient_error, 0.0, color.reshape(N, T, 3), alpha,
+                    z_vals)
         inv_s = self.forward_variance().expand(N * T, 1)
         true_cos = (dirs.reshape(-1, 3) * normal).sum(-1, keepdim=True)
         act = nn.Softplus(beta=100)
@@ -158,11 +175,6 @@ class NeRFRenderer(nn.Module):
         image = (color * weights[:, :, None]).sum(dim=1)
         normal_map = torch.sum(normal.reshape(N, T, 3) * weights[:, :, None], dim=1)
         depth = torch.sum(weights * ((z_vals - near) / (far - near)).clamp(0, 1), dim=-1)
-        pts_norm = torch.linalg.norm(flat, ord=2, dim=-1, keepdim=True).reshape(N, T)
-        relax = (pts_norm < 1.2).float().detach()
-        gerr = (torch.linalg.norm(gradient.reshape(N, T, 3), ord=2, dim=-1) - 1.0) ** 2
-        gradient_error = (relax * gerr).sum() / (relax.sum() + 1e-5)
-        assert (gradient == gradient).all(), 'Nan or Inf found!'
         if bg_color is None:
             bg_color = 1
         image = image + (1 - weights_sum) * bg_color

@@ -268,6 +268,48 @@ def color_mlp(x, normal, sdf_out, Wc1, Wc2, Wc3):
     return _ColorMlp.apply(x, normal, sdf_out, Wc1, Wc2, Wc3)
 
 
+class _Composite(torch.autograd.Function):
+    """NeuS alpha + compositing of the render core as one fused op each way (csrc/sdf_train.hip)"""
+
+    @staticmethod
+    def forward(ctx, z_vals, sdf, normal, color, inv_s, rays_o, rays_d, bg, num_steps, bound, car):
+        N, T = z_vals.shape
+        dev = z_vals.device
+        z_vals, sdf, normal, color = z_vals.contiguous(), sdf.contiguous(), normal.contiguous(), color.contiguous()
+        f = lambda *s: torch.empty(s, dtype=_F32, device=dev)
+        image, wsum, depth, nmap, weights, alpha = f(N, 3), f(N), f(N), f(N, 3), f(N, T), f(N, T)
+        s = float(inv_s.detach().reshape(-1)[0])
+        L.check(L.lib().ac_composite_forward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), sdf.data_ptr(), normal.data_ptr(), color.data_ptr(),
+                                             L.ptr(bg), N, int(num_steps), T, float(bound), s, float(car), image.data_ptr(), wsum.data_ptr(),
+                                             depth.data_ptr(), nmap.data_ptr(), weights.data_ptr(), alpha.data_ptr(), L.current_stream(dev)),
+                "composite_forward")
+        ctx.save_for_backward(z_vals, sdf, normal, color, inv_s, rays_o, rays_d, bg if bg is not None else torch.empty(0, device=dev))
+        ctx.cfg = (int(num_steps), float(bound), float(car), s, bg is not None)
+        ctx.mark_non_differentiable(weights, alpha)
+        return image, wsum, depth, nmap, weights, alpha
+
+    @staticmethod
+    def backward(ctx, g_image, g_wsum, g_depth, g_nmap, _gw, _ga):
+        z_vals, sdf, normal, color, inv_s, rays_o, rays_d, bg = ctx.saved_tensors
+        num_steps, bound, car, s, has_bg = ctx.cfg
+        N, T = z_vals.shape
+        dev = z_vals.device
+        c = lambda g, *shape: (g.contiguous().float() if g is not None else torch.zeros(shape, dtype=_F32, device=dev))
+        g_image, g_wsum, g_depth, g_nmap = c(g_image, N, 3), c(g_wsum, N), c(g_depth, N), c(g_nmap, N, 3)
+        f = lambda *sh: torch.empty(sh, dtype=_F32, device=dev)
+        g_sdf, g_nrm, g_col, g_s = f(N, T), f(N, T, 3), f(N, T, 3), f(N)
+        L.check(L.lib().ac_composite_backward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), sdf.data_ptr(), normal.data_ptr(), color.data_ptr(),
+                                              bg.data_ptr() if has_bg else None, N, num_steps, T, bound, s, car, g_image.data_ptr(), g_wsum.data_ptr(),
+                                              g_depth.data_ptr(), g_nmap.data_ptr(), g_sdf.data_ptr(), g_nrm.data_ptr(), g_col.data_ptr(), g_s.data_ptr(),
+                                              L.current_stream(dev)), "composite_backward")
+        return None, g_sdf, g_nrm, g_col, g_s.sum().reshape(inv_s.shape), None, None, None, None, None, None
+
+
+def composite(z_vals, sdf, normal, color, inv_s, rays_o, rays_d, bg, num_steps, bound, cos_anneal_ratio):
+    """-> image [N,3], weights_sum [N], depth [N], normal_map [N,3], weights [N,T], alpha [N,T]; differentiable w.r.t. sdf, normal, color, inv_s"""
+    return _Composite.apply(z_vals, sdf, normal, color, inv_s, rays_o, rays_d, bg, num_steps, bound, cos_anneal_ratio)
+
+
 def sdf_stencil(x, table, W1, b1, W2, b2, offsets, per_level_scale, base_resolution, bound, eps):
     """-> (sdf_out [B,16], gradient [B,3]); differentiable w.r.t. table, W1, b1, W2, b2"""
     cfg = ([int(v) for v in offsets], per_level_scale, int(base_resolution), float(bound), float(eps))

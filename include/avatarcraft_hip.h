@@ -255,6 +255,20 @@ size_t ac_color_backward_scratch(uint32_t B);
 int ac_color_backward(const ac_field *field, const float *x, const float *normal, const float *sdf16, const float *g_rgb, uint32_t B,
                       float *g_normal, float *g_sdf16, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
+/* ---- NeuS alpha + compositing of the render core (training path): models/instant_nsr.py:219-263,290-299 for rays in canonical space.
+ * Inputs per sample: z_vals, sdf, normal (= gradient / (1e-5 + |gradient|)), colour, [N,T] / [N,T,3]; per ray: origin, direction
+ * (near/far of the cube and sample_dist = (far - near) / num_steps are recomputed), optional background [N,3] (NULL = white).
+ * forward : image [N,3], weights_sum [N], depth [N], normal_map [N,3], weights [N,T], alpha [N,T] -- the arithmetic of ac_render_rays.
+ * backward: (d image, d weights_sum, d depth, d normal_map) -> d sdf [N,T], d normal [N,T,3], d colour [N,T,3] and the per-ray partial
+ *           sums of d inv_s [N] (the caller adds them up).  T = num_steps + upsample_steps, a multiple of 16, <= 128. */
+int ac_composite_forward(const float *rays_o, const float *rays_d, const float *z_vals, const float *sdf, const float *normal, const float *color,
+                         const float *bg, int32_t n_rays, int32_t num_steps, int32_t T, float bound, float inv_s, float cos_anneal_ratio,
+                         float *image, float *weights_sum, float *depth, float *normal_map, float *weights, float *alpha, ac_stream_t stream);
+int ac_composite_backward(const float *rays_o, const float *rays_d, const float *z_vals, const float *sdf, const float *normal, const float *color,
+                          const float *bg, int32_t n_rays, int32_t num_steps, int32_t T, float bound, float inv_s, float cos_anneal_ratio,
+                          const float *g_image, const float *g_weights_sum, const float *g_depth, const float *g_normal_map,
+                          float *g_sdf, float *g_normal, float *g_color, float *g_inv_s_per_ray, ac_stream_t stream);
+
 /* ---- posed-space rendering: NeRFRenderer.run(render_can=False, verts, faces, Ts, use_mesh_guide)
  * models/instant_nsr.py:147-172 (mesh-guided near/far, warp of the coarse samples), :198-203 (warp of the mid points),
  * :246-249 (alpha mask).  The reference moves the samples to the CPU for libigl twice per batch; here the whole sequence

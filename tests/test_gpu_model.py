@@ -227,3 +227,39 @@ def test_fused_color_mlp_matches_autograd(B):
         assert (G1[k] - G0[k]).abs().max() <= 1e-3 * G0[k].abs().max(), k
     f = net._field()
     assert torch.equal(r1, nsr_ops.field_color(f, x, nrm.detach(), so.detach()))            # == the renderer's / the oracle's colour
+
+
+def test_fused_composite_matches_autograd_formulation():
+    """composite (csrc/sdf_train.hip) against the torch formulation of alpha + compositing: all outputs, and the gradients of a loss
+    that uses image, weights_sum, depth and normal_map w.r.t. every parameter (incl. the variance); then the whole training render
+    with everything fused against everything in torch"""
+    net, _ = golden_net(train=True)
+    ro, rd = make_rays(24, 24, dist=1.7, f=16.0, jitter_seed=2)
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    N = ro.shape[0]
+    rs = np.random.RandomState(0)
+    wi = torch.from_numpy(rs.normal(size=(1, N, 3)).astype(np.float32)).to(DEV)
+    wn = torch.from_numpy(rs.normal(size=(N, 3)).astype(np.float32)).to(DEV)
+    bg = torch.from_numpy(rs.uniform(size=(N, 3)).astype(np.float32)).to(DEV)
+
+    def run(fused):
+        net.fused_training = fused
+        net.zero_grad()
+        torch.manual_seed(5)
+        out = net.render(ro_t[None], rd_t[None], num_steps=32, bound=1.6, upsample_steps=32, staged=False, bg_color=bg, cos_anneal_ratio=0.7,
+                         normal_epsilon_ratio=0.0, render_can=True, perturb=True)
+        loss = (out["rgb"] * wi).sum() + 3.0 * out["weight_sum"].clamp(0, 1).sum() + out["depth"].sum() + (out["normal"] * wn).sum() + 0.01 * out["gradient_error"]
+        loss.backward()
+        return {k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    o1, G1 = run(True)
+    o0, G0 = run(False)
+    for k in ("rgb", "weight_sum", "depth", "normal", "weights", "pts_alpha", "z_vals"):
+        assert torch.allclose(o1[k], o0[k], atol=2e-4, rtol=1e-3), k
+    assert "deviation_net.variance" in G1 and set(G1) == set(G0)
+    for k in G0:
+        scale = float(G0[k].abs().max())
+        # the two colour-MLP evaluations differ in the last ulp (MFMA chain vs hipBLASLt), which flips a few ReLU gates: discrete
+        # differences of up to ~1 % in single entries of the colour weights; everything upstream of smooth functions agrees to ~1e-4
+        tol = 2e-2 if k.startswith("color_net") else 5e-3
+        assert float((G1[k] - G0[k]).abs().max()) <= tol * scale + 1e-9, (k, float((G1[k] - G0[k]).abs().max()), scale)
+    net.fused_training = True
