@@ -105,7 +105,7 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     return {"ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad + 1 frozen",
             "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)", "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if world > 1 else 0,
-            "core": "HIP sampling launch + fused SDF query / colour MLP operators (MFMA forward + backward with recomputation), binned two-pass table scatter; torch autograd only for alpha / compositing"}
+            "core": "HIP sampling launch + fused SDF query / colour MLP / compositing operators (MFMA forward + backward with recomputation), binned two-pass table scatter; torch: weight norm, losses, Adam"}
 
 
 def time_posed_frame(dev, p, table, frames):
