@@ -120,8 +120,13 @@ class CameraPose:
         return self.camera_to_world[:3, 3]
 
 
-def pose_spherical(theta, phi, radius):
-    """render_utils.py:57-76 without the training-time noise"""
+def pose_spherical(theta, phi, radius, add_noise=False, noise_scale=1.0):
+    """render_utils.py:57-76; add_noise: the training-time camera jitter (closer by U(0, 0.2), elevation U(-15, 15) deg, azimuth
+    N(0, 1) deg, all times noise_scale), drawn from numpy's global stream in the reference's order"""
+    if add_noise:
+        radius += np.random.uniform(-0.2, 0) * noise_scale
+        phi += np.random.uniform(-15, 15) * noise_scale
+        theta += np.random.normal(0, 1) * noise_scale
     c2w = _trans_t(radius)
     c2w = _rot_phi(phi / 180. * np.pi) @ c2w
     c2w = _rot_theta(theta / 180. * np.pi) @ c2w
@@ -144,16 +149,46 @@ def _rotation_matrix(angle, direction):
     return R
 
 
-def default_360_path(center, up, dist, res=40, rad=360):
-    """camera ring around `center` (render_utils.py:137-154)"""
+def describe_view(angles, body_part: str = "body"):
+    """text prefix per view for the prompt augmentation (render_utils.py:80-90; the camera ring starts behind the avatar)"""
+    out = []
+    for a in angles:
+        where = "front" if (-180 <= a <= -150 or 150 <= a <= 180) else ("back" if -30 <= a <= 30 else "side")
+        out.append(f"{where} view of the {body_part} of the")
+    return out
+
+
+def _ring_frame(center, up):
     up = np.asarray(up, dtype=np.float64); up2 = np.array([0, 0, 1.0])
     axis = np.cross(up, up2)
     angle = np.arccos(np.clip(np.dot(up, up2) / (np.linalg.norm(up) * np.linalg.norm(up2)), -1, 1))
-    rot = _rotation_matrix(-angle, axis)
     trans = np.eye(4); trans[:3, 3] = np.asarray(center, dtype=np.float64)
+    return trans @ _rotation_matrix(-angle, axis)
+
+
+def default_360_path(center, up, dist, res=40, rad=360, add_noise=False):
+    """camera ring around `center` (render_utils.py:137-154) -> (poses, angles)"""
+    frame = _ring_frame(center, up)
     angles = np.linspace(-rad / 2, rad / 2, res + 1)[:-1]
-    poses = [pose_spherical(a, 0, dist) for a in angles]
-    return [CameraPose(trans @ rot @ p.camera_to_world) for p in poses], angles
+    poses = [pose_spherical(a, 0, dist, add_noise, noise_scale=1.0) for a in angles]
+    return [CameraPose(frame @ p.camera_to_world) for p in poses], angles
+
+
+def style_360_path(center, up, dist, res=40, rad=360, add_noise=False, noise_scale=1.0, style_head=False, head_offset=0.0, body_part: str = "body",
+                   head_rate=0.0, head_dist=0.5):
+    """training views (render_utils.py:157-208): front and back sectors only (res//4 in [-180,-120], res//4 in [120,180], res//2 in
+    [-60,60]) and, with style_head, int(res * head_rate) close-ups of the head (always jittered) -> (poses, descriptions)"""
+    frame = _ring_frame(center, up)
+    angles = np.concatenate([np.linspace(-180, -120, res // 4), np.linspace(120, 180, res // 4), np.linspace(-60, 60, res // 2)])
+    poses = [CameraPose(frame @ pose_spherical(a, 0, dist, add_noise, noise_scale).camera_to_world) for a in angles]
+    desc = describe_view(angles, body_part)
+    if style_head and head_rate > 0.0:
+        n = int(res * head_rate)
+        hframe = _ring_frame(np.asarray(center, dtype=np.float64) + np.asarray(up, dtype=np.float64) * head_offset, up)
+        hangles = np.concatenate([np.linspace(-180, -120, n // 2), np.linspace(120, 180, n // 2)])
+        poses = poses + [CameraPose(hframe @ pose_spherical(a, 0, head_dist, True, 1.0).camera_to_world) for a in hangles]
+        desc = desc + describe_view(hangles, "face")
+    return poses, desc
 
 
 class PinholeCapture:

@@ -27,7 +27,7 @@ class SyntheticGuidance:
         self.gen = None
         self.seed = seed
 
-    def __call__(self, rgb):
+    def __call__(self, rgb, text=None):
         if self.gen is None:
             self.gen = torch.Generator(device=rgb.device); self.gen.manual_seed(self.seed)
         return torch.randn(rgb.shape, generator=self.gen, device=rgb.device, dtype=rgb.dtype).clamp_(-1.0, 1.0)
@@ -98,6 +98,63 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
     # (D)
     optimizer.step()
     return {"eikonal": torch.stack(eik_vals).mean() if eik_vals else torch.zeros(()), "opacity": torch.stack(opa_vals).mean()}
+
+
+def stylize_epochs(net_style, net_gt, optimizer, guidance, hw=(256, 256), n_cap=100, coarse_epochs=1, fine_epochs=0, subsample_scale=4,
+                   center=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), camera_dist=2.0 * 0.9, augment_cam=False, stylize_head=False, coarse_head=0.0,
+                   fine_head=0.0, head_offset=0.47 * 0.9, head_dist=0.5 * 0.9, augment_bkg=False, white_bkg=True, augment_text=False, tgt_text="",
+                   batch_size=4096, w_eikonal=0.01, use_opacity=True, seed=42, device="cuda", flat_grad=None, on_step=None):
+    """The outer loop of Trainer.train (stylize.py:46-215): per epoch a ring of training views (default_360_path, or style_360_path with
+    camera jitter / head close-ups), visited in random order; per view the stride-sub-sampled rays of a 256x256 pinhole camera, a random
+    background when augment_bkg, the view description prepended to the prompt when augment_text, and one sds_step.  The fine stage halves
+    the stride (subsample_scale // 2, at least 1).  Under torch.distributed every rank draws the same poses and permutation (same seed)
+    and takes the views rank, rank + world, ...; the gradients meet in sds_step's single all-reduce.
+    guidance(rgb[1,3,h,w], text=...) -> d loss / d rgb.  on_step(global_step, epoch, stats) is called after every optimizer step.
+    Returns the number of optimizer steps taken by this rank."""
+    import random
+    import numpy as np
+    from .render_utils import (default_360_path, style_360_path, describe_view, pose2cap, cap2rays, sparse_ray_sampling, BLACK_BKG, NOISE_BKG)
+    H, W = hw
+    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+    np.random.seed(seed); random.seed(seed)
+    gen = torch.Generator(); gen.manual_seed(seed)
+    center, up = np.asarray(center, dtype=np.float64), np.asarray(up, dtype=np.float64)
+    step = 0
+    for epoch in range(coarse_epochs + fine_epochs):
+        coarse = epoch < coarse_epochs
+        head_rate = coarse_head if coarse else fine_head
+        if augment_cam or stylize_head:
+            poses, desc = style_360_path(center, up, camera_dist, n_cap, add_noise=augment_cam, noise_scale=2.0 if augment_cam else 1.0,
+                                         style_head=stylize_head, head_offset=head_offset, head_rate=head_rate, head_dist=head_dist)
+        else:
+            poses, angles = default_360_path(center, up, camera_dist, n_cap, add_noise=False)
+            desc = describe_view(angles)
+        perm = torch.randperm(len(poses), generator=gen).tolist()
+        stride = subsample_scale if coarse else max(1, subsample_scale // 2)
+        assert stride in (1, 2, 4, 8, 16), 'subsample scale must be 1, 2, 4, 8, or 16'
+        for k in shard_views(len(perm), rank, world):
+            i = perm[k]
+            bkg_key = random.randint(WHITE_BKG, NOISE_BKG) if augment_bkg else (WHITE_BKG if white_bkg else BLACK_BKG)
+            text = f"{desc[i]} {tgt_text}" if augment_text else tgt_text
+            ro, rd = cap2rays(pose2cap([H, W], poses[i]), device=device)
+            ro, rd = sparse_ray_sampling(ro.reshape(H, W, 3), rd.reshape(H, W, 3), stride)
+            h, w = ro.shape[0], ro.shape[1]
+            g = (lambda rgb, _t=text: guidance(rgb, text=_t)) if _accepts_text(guidance) else guidance
+            stats = sds_step(net_style, net_gt, ro.reshape(-1, 3).float().contiguous(), rd.reshape(-1, 3).float().contiguous(), (h, w), optimizer, g,
+                             batch_size=batch_size, w_eikonal=w_eikonal, use_opacity=use_opacity, bkg_key=bkg_key, flat_grad=flat_grad)
+            if on_step is not None:
+                on_step(step, epoch, stats)
+            step += 1
+    return step
+
+
+def _accepts_text(guidance):
+    import inspect
+    try:
+        return "text" in inspect.signature(guidance).parameters
+    except (TypeError, ValueError):
+        return False
 
 
 def shard_views(n_views, rank, world):

@@ -431,3 +431,27 @@ def make_vanilla_golden():
 
 if __name__ == "__main__":
     make_vanilla_golden()
+
+
+# ---------------------------------------------------------------- training-view goldens (the stylize outer loop)
+def make_path_goldens():
+    """style_360_path / describe_view / the jittered pose_spherical of utils/render_utils.py:57-90,157-208 under a fixed numpy seed"""
+    import numpy
+    _prepare_render_utils()
+    import utils.render_utils as RU
+    out = {}
+    c, up = np.array([0.0, 0.1, 0.0]), np.array([0.0, 1.0, 0.0])
+    poses, desc = RU.style_360_path(c, up, 1.8, 20)
+    out["plain_c2w"] = np.stack([p.camera_to_world for p in poses]); out["plain_desc"] = np.array(desc)
+    numpy.random.seed(7)
+    poses, desc = RU.style_360_path(c, up, 1.8, 20, add_noise=True, noise_scale=2.0, style_head=True, head_offset=0.423, head_rate=0.4, head_dist=0.45)
+    out["noisy_c2w"] = np.stack([p.camera_to_world for p in poses]); out["noisy_desc"] = np.array(desc)
+    numpy.random.seed(9)
+    poses, _ = RU.default_360_path(c, up, 1.8, 8, add_noise=True)
+    out["ring_noisy_c2w"] = np.stack([p.camera_to_world for p in poses])
+    np.savez_compressed(os.path.join(HERE, "paths.npz"), **out)
+    print("paths:", out["plain_c2w"].shape, out["noisy_c2w"].shape, out["noisy_desc"][:2], out["noisy_desc"][-1])
+
+
+if __name__ == "__main__":
+    make_path_goldens()

@@ -193,3 +193,21 @@ def test_vanilla_nerf_plumbing_matches_reference():
     with torch.no_grad():
         raw2 = net2(pe(pts.reshape(-1, 3)[:64]))
     assert np.abs(raw2.numpy() - g["raw2"]).max() <= 1e-6
+
+
+# ------------------------------------------------------------------ training views of the stylize outer loop
+def test_style_paths_match_reference():
+    """style_360_path (front / back sectors, head close-ups), describe_view and the camera jitter of pose_spherical against the
+    reference under the same numpy seed (tests/golden/paths.npz)"""
+    from avatarcraft_amd import render_utils as RU
+    g = load_golden("paths.npz")
+    c, up = np.array([0.0, 0.1, 0.0]), np.array([0.0, 1.0, 0.0])
+    poses, desc = RU.style_360_path(c, up, 1.8, 20)
+    assert np.abs(np.stack([p.camera_to_world for p in poses]) - g["plain_c2w"]).max() < 1e-6 and list(desc) == list(g["plain_desc"])
+    np.random.seed(7)
+    poses, desc = RU.style_360_path(c, up, 1.8, 20, add_noise=True, noise_scale=2.0, style_head=True, head_offset=0.423, head_rate=0.4, head_dist=0.45)
+    assert len(poses) == 20 + 8 and list(desc) == list(g["noisy_desc"]) and desc[-1].startswith("front view of the face")
+    assert np.abs(np.stack([p.camera_to_world for p in poses]) - g["noisy_c2w"]).max() < 1e-6
+    np.random.seed(9)
+    poses, _ = RU.default_360_path(c, up, 1.8, 8, add_noise=True)
+    assert np.abs(np.stack([p.camera_to_world for p in poses]) - g["ring_noisy_c2w"]).max() < 1e-6
