@@ -163,6 +163,7 @@ struct BinSink {
     uint32_t cnt;                          // wave-uniform
     uint32_t per;                          // entries per bucket: bucket = index / per
     uint32_t *qcount;                      // global [NBUCKET] of this level
+    uint32_t *vmax;                        // global: bits of max |v| over this level's records (positive floats order like uints)
     Rec *queue;                            // global [NBUCKET][cap] of this level
     uint32_t cap;
     float2 *gg;                            // overflow path: direct atomics
@@ -179,6 +180,14 @@ struct BinSink {
     __device__ __forceinline__ void flush()
     {
         wave_sync_lds();
+        uint32_t mx = 0;
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const uint32_t a0 = __float_as_uint(rv0[i]) & 0x7fffffffu, a1 = __float_as_uint(rv1[i]) & 0x7fffffffu;
+            mx = mx > a0 ? mx : a0; mx = mx > a1 ? mx : a1;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d); mx = mx > o ? mx : o; }
+        if (lane == 0 && mx) atomicMax(vmax, mx);
         for (uint32_t i = lane; i < cnt; i += 64) {
             const uint32_t idx = ridx[i];
             const uint32_t rank = atomicAdd(&hist[idx / per], 1u);
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
     sink.cnt = 0; sink.lane = lane;
     sink.per = (lt.size[level] + NBUCKET - 1) / NBUCKET;
     sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
+    sink.vmax = qcount + (size_t)gridDim.y * NBUCKET + blockIdx.y;
     sink.queue = queues + (size_t)blockIdx.y * NBUCKET * cap;
     sink.cap = cap;
     sink.gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
@@ -386,37 +396,52 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
 }
 
 // one workgroup per (bucket, binned level): sum the bucket's queue in LDS, then add the slice to the table (no atomics: the
-// workgroup owns these entries, and every producer of records has finished -- kernel boundary)
+// workgroup owns these entries, and every producer of records has finished -- kernel boundary).
+// LDS float atomics (ds_add_f32) run at 0.33 lane-operations per clock and CU on gfx950, integer ones (ds_add_u32 / ds_add_u64) at
+// > 3 (tools/lds_atomics_bench.hip), so the sums are taken in 64-bit fixed point: v * 2^k with 2^k chosen from the level's largest
+// |v| (collected by the queue fill) and the length n of this queue, |v| 2^k < 2^(62 - ceil(log2(n + 1))), so that no entry can
+// overflow.  Contributions keep >= 24 significant bits down to 2^-18 of the level's maximum and vanish below 2^-42 of it; in
+// exchange the result does not depend on the order of the records (deterministic), which float atomics never gave.
 __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restrict__ grad_grid, ac::LevelTable lt, uint32_t binned_mask,
                                                                  const uint32_t *__restrict__ qcount, const Rec *__restrict__ queues, uint32_t cap)
 {
-    extern __shared__ __attribute__((aligned(16))) float acc[];            // [entries per bucket][2]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];        // [entries per bucket][2]
     uint32_t level = 0, seen = 0;
     for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
     const uint32_t per = (lt.size[level] + NBUCKET - 1) / NBUCKET, bucket = blockIdx.x;
     const uint32_t first = bucket * per;
     const uint32_t mine = first >= lt.size[level] ? 0u : (lt.size[level] - first < per ? lt.size[level] - first : per);     // the last bucket may be short
-    for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) acc[e] = 0.0f;
-    __syncthreads();
     uint32_t n = qcount[(size_t)blockIdx.y * NBUCKET + bucket];
     n = n < cap ? n : cap;
+    const uint32_t mbits = qcount[(size_t)gridDim.y * NBUCKET + blockIdx.y];
+    if (n == 0 || mbits == 0 || mine == 0) return;                                   // wave-uniform: nothing queued for this bucket
+    for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) acc[e] = 0ull;
+    __syncthreads();
+    const int emax = (int)(mbits >> 23) - 126;                                       // |v| < 2^emax for every record of the level
+    const int head = 32 - __builtin_clz(n);                                          // ceil(log2(n + 1))
+    const int k = 62 - head - emax;
     const Rec *q = queues + ((size_t)blockIdx.y * NBUCKET + bucket) * cap;
-    constexpr int U = 8;                                 // records in flight per thread (the loop is latency bound otherwise)
+    constexpr int U = 4;
     for (uint32_t i0 = threadIdx.x; i0 < n; i0 += blockDim.x * U) {
         Rec r[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * blockDim.x; r[u] = q[i < n ? i : i0]; if (i >= n) { r[u].v0 = 0.0f; r[u].v1 = 0.0f; } }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
 #ifdef AC_ABL_NOLDSATOMIC
-            if (r[u].v0 != 0.0f || r[u].v1 != 0.0f) { acc[2 * r[u].idx] = r[u].v0; acc[2 * r[u].idx + 1] = r[u].v1; }
+            if (r[u].v0 != 0.0f || r[u].v1 != 0.0f) { acc[2 * r[u].idx] = 1ull; acc[2 * r[u].idx + 1] = 1ull; }
 #else
-            if (r[u].v0 != 0.0f || r[u].v1 != 0.0f) { atomicAdd(&acc[2 * r[u].idx], r[u].v0); atomicAdd(&acc[2 * r[u].idx + 1], r[u].v1); }
+            if (r[u].v0 != 0.0f) atomicAdd(&acc[2 * r[u].idx], (unsigned long long)__double2ll_rn(ldexp((double)r[u].v0, k)));
+            if (r[u].v1 != 0.0f) atomicAdd(&acc[2 * r[u].idx + 1], (unsigned long long)__double2ll_rn(ldexp((double)r[u].v1, k)));
 #endif
+        }
     }
     __syncthreads();
     float *dst = grad_grid + ((size_t)lt.offset[level] + (size_t)first) * 2;
-    for (uint32_t e = threadIdx.x; e < mine * 2; e += blockDim.x) { const float v = acc[e]; if (v != 0.0f) dst[e] += v; }
+    for (uint32_t e = threadIdx.x; e < mine * 2; e += blockDim.x) {
+        const long long v = (long long)acc[e];
+        if (v != 0) dst[e] += (float)ldexp((double)v, -k);
+    }
 }
 
 __global__ __launch_bounds__(256) void priv_reduce_kernel(const float *__restrict__ priv, uint32_t n_floats, uint32_t n_copies,
@@ -480,7 +505,7 @@ static StencilScratch stencil_layout(const ac::LevelTable &lt, uint32_t L, uint3
     sc.binned_mask = B ? binned_levels(lt, L) : 0;
     sc.n_binned = (uint32_t)__builtin_popcount(sc.binned_mask);
     sc.cap = queue_cap(B);
-    sc.qcount_off = off; off += ((size_t)sc.n_binned * NBUCKET * 4 + 255) & ~(size_t)255;
+    sc.qcount_off = off; off += ((size_t)sc.n_binned * (NBUCKET + 1) * 4 + 255) & ~(size_t)255;       // slot counters + the level's max |v|
     sc.queue_off = off; off += (size_t)sc.n_binned * NBUCKET * sc.cap * sizeof(Rec);
     sc.total = off;
     return sc;
@@ -529,9 +554,9 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
         hipLaunchKernelGGL(hash_stencil_bwd_kernel, dim3((B + 255) / 256, L), dim3(256), 0, st, grad, x, grad_embeddings, B, lt, eps, bound, two_bound,
                            fine_mask, priv, sc.n_priv, sc.entries, n_copies, direct_mask);
     if (sc.n_binned) {
-        hipMemsetAsync(qcount, 0, (size_t)sc.n_binned * NBUCKET * 4, st);
+        hipMemsetAsync(qcount, 0, (size_t)sc.n_binned * (NBUCKET + 1) * 4, st);
         static bool attr_set = false;
-        const size_t lds1 = (size_t)4 * (3 * RCAP + 2 * NBUCKET) * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 8;
+        const size_t lds1 = (size_t)4 * (3 * RCAP + 2 * NBUCKET) * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 16;
         if (!attr_set) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(hash_stencil_bwd_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
             hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
