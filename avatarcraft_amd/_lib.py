@@ -46,6 +46,8 @@ _SIGS = {
     "ac_hash_level_table": ([u32, f32, u32, vp, vp], None),
     "ac_hash_encode_forward": ([vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp], C.c_int),
     "ac_hash_encode_backward": ([vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp, vp], C.c_int),
+    "ac_hash_encode_backward_scratch": ([vp, u32, u32, u32, f32, u32, u32], C.c_size_t),
+    "ac_hash_encode_backward_ws": ([vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp, vp, C.c_size_t, vp], C.c_int),
     "ac_hash_corner_indices": ([vp, vp, vp, u32, u32, u32, f32, u32, vp], C.c_int),
     "ac_sh_encode_forward": ([vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
     "ac_sh_encode_backward": ([vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),

@@ -395,6 +395,51 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
     sink.flush();
 }
 
+// the reference's one-point backward (kernel_grid_backward, hashencoder.cu:223-308; D = 3, C = 2) through the binned scatter:
+// inputs [B,3] in [0,1], grad [L,B,2]; one sample per lane, runs of lanes in the same cell are combined like in the stencil path
+__global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                              float *__restrict__ grad_grid, uint32_t B, ac::LevelTable lt, uint32_t binned_mask,
+                                                              uint32_t *__restrict__ qcount, Rec *__restrict__ queues, uint32_t cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t level = 0, seen = 0;
+    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LevelC L = level_of(lt, level);
+    uint32_t *wbase = smem + wave * (3 * RCAP + 2 * NBUCKET);
+    BinSink sink;
+    sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
+    sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
+    sink.cnt = 0; sink.lane = lane;
+    sink.per = (lt.size[level] + NBUCKET - 1) / NBUCKET;
+    sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
+    sink.vmax = qcount + (size_t)gridDim.y * NBUCKET + blockIdx.y;
+    sink.queue = queues + (size_t)blockIdx.y * NBUCKET * cap;
+    sink.cap = cap;
+    sink.gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
+    sink.hist[lane] = 0u;
+    const uint32_t ngroups = (B + 63) / 64;
+    for (uint32_t grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+        const uint32_t b0 = grp * 64 + lane;
+        const bool valid = b0 < B;
+        const uint32_t b = valid ? b0 : B - 1;
+        Loc q[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float u = inputs[(size_t)b * 3 + d];
+            q[d].oob = (u < 0.0f) | (u > 1.0f);
+            const float p = fma_(u, L.scale, 0.5f);
+            q[d].pg = (uint32_t)__builtin_floorf(p);
+            q[d].fr = p - (float)q[d].pg;
+        }
+        float2 g = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
+        if (!valid) g = make_float2(0.0f, 0.0f);
+        sink_reserve(sink, 512u);
+        scatter8_runs(sink, L, q, g.x, g.y, lane);
+    }
+    sink.flush();
+}
+
 // one workgroup per (bucket, binned level): sum the bucket's queue in LDS, then add the slice to the table (no atomics: the
 // workgroup owns these entries, and every producer of records has finished -- kernel boundary).
 // LDS float atomics (ds_add_f32) run at 0.33 lane-operations per clock and CU on gfx950, integer ones (ds_add_u32 / ds_add_u64) at
@@ -493,10 +538,10 @@ static uint32_t binned_levels(const ac::LevelTable &lt, uint32_t L)
         if (lt.size[l] >= (uint32_t)NBUCKET && lt.size[l] <= (1u << 19)) m |= 1u << l;
     return m;
 }
-static uint32_t queue_cap(uint32_t B) { return (uint32_t)(((uint64_t)B * 56u * 3u / 2u) / NBUCKET) + 4096u; }   // 1.5 x the fine-level average
+static uint32_t queue_cap(uint32_t B, uint32_t per_sample = 56u) { return (uint32_t)(((uint64_t)B * per_sample * 3u / 2u) / NBUCKET) + 4096u; }   // 1.5 x the average
 
 struct StencilScratch { size_t priv_off, qcount_off, queue_off, total; uint32_t entries, n_priv, binned_mask, n_binned, cap; };
-static StencilScratch stencil_layout(const ac::LevelTable &lt, uint32_t L, uint32_t n_copies, uint32_t B)
+static StencilScratch stencil_layout(const ac::LevelTable &lt, uint32_t L, uint32_t n_copies, uint32_t B, uint32_t per_sample = 56u)
 {
     StencilScratch sc{};
     sc.n_priv = (n_copies >= 2 && B == 0) ? priv_levels(lt, L, sc.entries) : 0;       // with queues (B > 0) every level is binned
@@ -504,7 +549,7 @@ static StencilScratch stencil_layout(const ac::LevelTable &lt, uint32_t L, uint3
     sc.priv_off = off; off += ((size_t)sc.entries * 8 * (sc.n_priv ? n_copies : 0) + 255) & ~(size_t)255;
     sc.binned_mask = B ? binned_levels(lt, L) : 0;
     sc.n_binned = (uint32_t)__builtin_popcount(sc.binned_mask);
-    sc.cap = queue_cap(B);
+    sc.cap = queue_cap(B, per_sample);
     sc.qcount_off = off; off += ((size_t)sc.n_binned * (NBUCKET + 1) * 4 + 255) & ~(size_t)255;       // slot counters + the level's max |v|
     sc.queue_off = off; off += (size_t)sc.n_binned * NBUCKET * sc.cap * sizeof(Rec);
     sc.total = off;
@@ -572,4 +617,47 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
     if (sc.n_priv)
         hipLaunchKernelGGL(priv_reduce_kernel, dim3((sc.entries * 2 + 255) / 256), dim3(256), 0, st, priv, sc.entries * 2, n_copies, grad_embeddings);
     return ac::check_launch("hash_stencil_backward");
+}
+
+// ---- the reference's operator (ac_hash_encode_backward) with caller scratch: binned scatter when D = 3, C = 2 and every level fits
+AC_API size_t ac_hash_encode_backward_scratch(const int32_t *offsets_host, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t B)
+{
+    if (!offsets_host || D != 3 || C != 2 || L == 0 || L > AC_MAX_LEVELS || B == 0) return 0;
+    ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
+    const uint32_t all = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+    if (binned_levels(lt, L) != all) return 0;
+    return stencil_layout(lt, L, 0, B, 8u).total;
+}
+
+AC_API int ac_hash_encode_backward_ws(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets,
+                                      const int32_t *offsets_host, float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                      uint32_t H, int calc_grad_inputs, const float *dy_dx, float *grad_inputs, void *scratch, size_t scratch_bytes,
+                                      ac_stream_t stream)
+{
+    const size_t need = ac_hash_encode_backward_scratch(offsets_host, D, C, L, S, H, B);
+    if (!scratch || need == 0 || scratch_bytes < need || calc_grad_inputs)         // not coverable: the direct-atomic operator
+        return ac_hash_encode_backward(grad, inputs, embeddings, offsets, offsets_host, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx,
+                                       grad_inputs, stream);
+    if (!grad || !inputs || !grad_embeddings) { ac::set_error("hash_encode_backward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
+    const StencilScratch sc = stencil_layout(lt, L, 0, B, 8u);
+    hipStream_t st = (hipStream_t)stream;
+    char *sb = static_cast<char *>(scratch);
+    uint32_t *qcount = reinterpret_cast<uint32_t *>(sb + sc.qcount_off);
+    Rec *queues = reinterpret_cast<Rec *>(sb + sc.queue_off);
+    hipMemsetAsync(qcount, 0, (size_t)sc.n_binned * (NBUCKET + 1) * 4, st);
+    static bool attr_set = false;
+    const size_t lds1 = (size_t)4 * (3 * RCAP + 2 * NBUCKET) * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 16;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(hash_bwd_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        attr_set = true;
+    }
+    uint32_t gx = ((B + 63) / 64 + 3) / 4;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(hash_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, inputs, grad_embeddings, B, lt, sc.binned_mask, qcount,
+                       queues, sc.cap);
+    hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount, queues,
+                       sc.cap);
+    return ac::check_launch("hash_encode_backward");
 }

@@ -63,10 +63,18 @@ class _Backend:
         for t, n in ((grad, "grad"), (inputs, "inputs"), (embeddings, "embeddings"), (grad_embeddings, "grad_embeddings")):
             _floating(t, n)
         oh = _Backend._offsets_host(offsets)
-        L.check(L.lib().ac_hash_encode_backward(grad.data_ptr(), inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(),
-                                                oh.ctypes.data, grad_embeddings.data_ptr(), B, D, C, L_, float(np.float32(S)), H,
-                                                int(bool(calc_grad_inputs)), dy_dx.data_ptr(), grad_inputs.data_ptr(),
-                                                L.current_stream(inputs.device)), "hash_encode_backward")
+        Sf = float(np.float32(S))
+        key = ("enc", str(inputs.device), int(oh[-1]), D, C, L_, Sf, H, int(B))
+        if BINNED_SCATTER and not calc_grad_inputs and key not in _SCRATCH:
+            for k in [k for k in _SCRATCH if k[:8] == key[:8]]:
+                del _SCRATCH[k]
+            nbytes = int(L.lib().ac_hash_encode_backward_scratch(oh.ctypes.data, D, C, L_, Sf, H, B))
+            _SCRATCH[key] = (torch.empty(nbytes, dtype=torch.uint8, device=inputs.device) if nbytes else None, nbytes)
+        scratch, nbytes = _SCRATCH.get(key, (None, 0)) if BINNED_SCATTER and not calc_grad_inputs else (None, 0)
+        L.check(L.lib().ac_hash_encode_backward_ws(grad.data_ptr(), inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(),
+                                                   oh.ctypes.data, grad_embeddings.data_ptr(), B, D, C, L_, Sf, H,
+                                                   int(bool(calc_grad_inputs)), dy_dx.data_ptr(), grad_inputs.data_ptr(), L.ptr(scratch), nbytes,
+                                                   L.current_stream(inputs.device)), "hash_encode_backward")
 
 
     # ---- the 7-point finite-difference stencil in one launch (csrc/hash_stencil.hip); not part of the reference's pybind surface

@@ -203,6 +203,16 @@ int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *f
                           double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest, double *dist2,
                           int32_t *face_id, uint8_t *mask, ac_stream_t stream);
 
+/* ac_hash_encode_backward with caller scratch: for D = 3, C = 2 and levels of at most 2^19 entries (the default model) the table
+ * gradient goes through the binned two-pass scatter (see ac_hash_stencil_backward) instead of one float atomic per corner and
+ * channel; any other configuration, a NULL / too small scratch or calc_grad_inputs falls back to ac_hash_encode_backward.
+ * ac_hash_encode_backward_scratch returns the bytes needed (0 = not coverable). */
+size_t ac_hash_encode_backward_scratch(const int32_t *offsets_host, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t B);
+int ac_hash_encode_backward_ws(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets,
+                               const int32_t *offsets_host, float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                               uint32_t H, int calc_grad_inputs, const float *dy_dx, float *grad_inputs, void *scratch, size_t scratch_bytes,
+                               ac_stream_t stream);
+
 /* ---- hash-grid encoder on the 7-point finite-difference stencil (training path)
  * One SDF query of the render core is 7 HashEncoder calls in the reference: forward_sdf at x (models/instant_nsr.py:627-642) and at
  * clamp(x +- eps e_k) (finite_difference_normals_approximator, :687-704), each through encoder/hashencoder/hashgrid.py:11-73.

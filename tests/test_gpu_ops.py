@@ -381,3 +381,35 @@ def test_hash_stencil_backward_paths_agree():
         torch.cuda.synchronize()
         res.append(gt)
     assert float((res[1] - res[0]).abs().max()) <= 1e-4 * float(res[0].abs().max())
+
+
+def test_hash_backward_binned_equals_direct(oracle):
+    """the reference operator's backward through the binned scatter (ac_hash_encode_backward_ws) against the direct float atomics and
+    the oracle, default 16-level grid"""
+    from avatarcraft_amd import _lib as Lb
+    O = oracle
+    offs, pls = O.hash_offsets(desired_resolution=2048)
+    S = float(np.float32(np.log2(pls)))
+    rs = np.random.RandomState(12)
+    B = 50001
+    x = rs.uniform(0, 1, size=(B, 3)).astype(np.float32)
+    x[:100] = np.round(x[:100] * 15) / 15                       # on coarse cell borders
+    g = rs.normal(size=(16, B, 2)).astype(np.float32)
+    xt, gt_ = T(x), T(g)
+    emb = torch.zeros(int(offs[-1]), 2, device=DEV)
+    ot = torch.from_numpy(offs).to(DEV)
+    dummy = torch.zeros(1, device=DEV)
+    res = []
+    for use_ws in (False, True):
+        gg = torch.zeros_like(emb)
+        nbytes = int(Lb.lib().ac_hash_encode_backward_scratch(offs.ctypes.data, 3, 2, 16, S, 16, B)) if use_ws else 0
+        assert (nbytes > 0) == use_ws
+        sc = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=DEV)
+        Lb.check(Lb.lib().ac_hash_encode_backward_ws(gt_.data_ptr(), xt.data_ptr(), emb.data_ptr(), ot.data_ptr(), offs.ctypes.data, gg.data_ptr(), B, 3, 2, 16,
+                                                     S, 16, 0, dummy.data_ptr(), dummy.data_ptr(), sc.data_ptr() if use_ws else None, nbytes, None))
+        torch.cuda.synchronize()
+        res.append(gg.cpu().numpy())
+    gg_o, _ = O.hash_encode_backward(g, x, np.zeros((int(offs[-1]), 2), np.float32), offs, S, 16, None)
+    scale = np.abs(gg_o).max()
+    assert np.abs(res[0] - gg_o).max() <= 2e-5 * scale and np.abs(res[1] - gg_o).max() <= 2e-5 * scale
+    assert Lb.lib().ac_hash_encode_backward_scratch(offs.ctypes.data, 3, 4, 16, S, 16, B) == 0          # C = 4: direct path only

@@ -39,3 +39,25 @@ grad = torch.randn(16, B, 2, device=dev); dummy = torch.zeros(1, device=dev)
 print("16-level call", timeit(lambda: _backend.hash_encode_backward(grad, x, emb, offsets, gg, B, 3, 2, 16, float(np.log2(pls)), 16, False, dummy, dummy)), "ms")
 out = torch.empty(16, B, 2, device=dev)
 print("16-level forward", timeit(lambda: _backend.hash_encode_forward(x, emb, offsets, out, B, 3, 2, 16, float(np.log2(pls)), 16, False, dummy)), "ms")
+
+# the same 16-level call through the binned scatter
+from avatarcraft_amd import _lib as L
+nb = int(L.lib().ac_hash_encode_backward_scratch(offs.ctypes.data, 3, 2, 16, float(np.float32(np.log2(pls))), 16, B))
+sc = torch.empty(nb, dtype=torch.uint8, device=dev)
+st = L.current_stream(torch.device(dev))
+print("16-level call, binned", timeit(lambda: L.check(L.lib().ac_hash_encode_backward_ws(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), offsets.data_ptr(), offs.ctypes.data,
+      gg.data_ptr(), B, 3, 2, 16, float(np.float32(np.log2(pls))), 16, 0, dummy.data_ptr(), dummy.data_ptr(), sc.data_ptr(), nb, st))), "ms")
+
+# and on the real sample distribution of a training batch (importance-sampled mid points of the fused renderer)
+from avatarcraft_amd import nsr_ops
+from tests.common import load_golden
+from tests.gpu_common import device_field
+pp = load_golden("nsr_params.npz"); f, _ = device_field(pp)
+t = lambda a: torch.from_numpy(a).to(dev)
+z = nsr_ops.sample_rays(f, t(ro), t(rd), 64, 64, 1.6)
+d = z[:, 1:] - z[:, :-1]; zm = torch.cat([z[:, :-1] + 0.5 * d, z[:, -1:]], 1)
+xr = (((t(ro)[:, None, :] + t(rd)[:, None, :] * zm[:, :, None]).clamp(-1.6, 1.6).reshape(-1, 3) + 1.6) / 3.2).contiguous()
+print("real distribution: direct", timeit(lambda: L.check(L.lib().ac_hash_encode_backward_ws(grad.data_ptr(), xr.data_ptr(), emb.data_ptr(), offsets.data_ptr(), offs.ctypes.data,
+      gg.data_ptr(), B, 3, 2, 16, float(np.float32(np.log2(pls))), 16, 0, dummy.data_ptr(), dummy.data_ptr(), None, 0, st))), "ms;  binned",
+      timeit(lambda: L.check(L.lib().ac_hash_encode_backward_ws(grad.data_ptr(), xr.data_ptr(), emb.data_ptr(), offsets.data_ptr(), offs.ctypes.data,
+      gg.data_ptr(), B, 3, 2, 16, float(np.float32(np.log2(pls))), 16, 0, dummy.data_ptr(), dummy.data_ptr(), sc.data_ptr(), nb, st))), "ms")
