@@ -232,7 +232,11 @@ __device__ __forceinline__ void scatter8_runs(Sink &sink, const LevelC &L, const
         for (uint32_t d = 0; d < 3; ++d) w *= ((idx >> d) & 1u) ? q[d].fr : 1.0f - q[d].fr;
         v[2 * idx] = ok ? w * g0 : 0.0f; v[2 * idx + 1] = ok ? w * g1 : 0.0f;
     }
+#ifdef AC_FINE_NORUN        // experiment: no run combining on the per-point path (few same-cell neighbours on the fine levels)
+    const bool tail = ok;
+#else
     const bool tail = run_reduce<16>(v, run_head(q, ok, lane), lane) && ok;
+#endif
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; ++idx)
         sink.add(tail && (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f),

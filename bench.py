@@ -156,13 +156,18 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()        # one rank per GPU; more ranks than GPUs only in the gloo smoke test below
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("AC_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" lets the N > 1 path be exercised on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from avatarcraft_amd import nsr_ops
     p, field, table, ro, rd = make_inputs(dev, rank)
