@@ -263,3 +263,15 @@ def test_fused_composite_matches_autograd_formulation():
         tol = 2e-2 if k.startswith("color_net") else 5e-3
         assert float((G1[k] - G0[k]).abs().max()) <= tol * scale + 1e-9, (k, float((G1[k] - G0[k]).abs().max()), scale)
     net.fused_training = True
+
+
+def test_cap2rays_on_device_equals_host():
+    """ray generation on the GPU (the per-view host cost of the stylize loop otherwise) against the numpy path, which the goldens pin"""
+    from avatarcraft_amd import render_utils as RU
+    poses, _ = RU.style_360_path(np.array([0.0, 0.05, 0.0]), np.array([0.0, 1.0, 0.0]), 1.8, 8)
+    for pose in (poses[0], poses[5]):
+        cap = RU.pose2cap([96, 128], pose)
+        o_h, d_h = RU.cap2rays(cap, device="cpu")
+        o_g, d_g = RU.cap2rays(cap, device=DEV)
+        assert o_g.shape == (96 * 128, 3) and o_g.is_cuda
+        assert torch.equal(o_g.cpu(), o_h) and float((d_g.cpu() - d_h).abs().max()) <= 1.2e-7
