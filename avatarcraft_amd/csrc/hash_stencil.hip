@@ -3,10 +3,12 @@
 // One SDF query of the render core is 7 encoder calls in the reference: the sample x (forward_sdf, models/instant_nsr.py:627-642)
 // and x +- eps e_k clamped to the bound (finite_difference_normals_approximator, :687-704), each through
 // HashEncoder.forward / _hash_encode.backward (encoder/hashencoder/hashgrid.py:11-73,126-142).  This operator evaluates the seven
-// points of every sample in one launch and, in the backward, combines their table gradients in registers before touching HBM:
-// on the levels where eps spans less than one cell all seven points lie in the same or a neighbouring cell, so their
-// 7 x 8 corners collapse onto at most 32 distinct table entries (normally 8) -> 7x fewer atomics on exactly the coarse levels
-// where the float atomics of the one-point-at-a-time backward serialise (profiles/r01_v3_sds_kernel_stats.txt).
+// points of every sample in one launch.  The backward (the table-gradient scatter, profiles/r01_sds.txt) removes work in three
+// steps: (1) on the levels where eps spans less than one cell all seven points lie in the same or a neighbouring cell, so their
+// 7 x 8 corners collapse onto at most 32 distinct table entries (normally 8) in registers; (2) runs of lanes in the same cell
+// (a wave holds 64 depth-sorted samples of a ray) are summed with a segmented shuffle scan; (3) the surviving records do not
+// touch the table with atomics: they are queued per destination bucket and summed per bucket in LDS (BinSink below).  The same
+// scatter serves the reference's one-point operator (hash_bwd_binned_kernel).
 //
 // Point order p = 0..6: x, +x, -x, +y, -y, +z, -z.  Layouts: x [B,3] fp32 world space (already clamped to the bound, as the
 // render core passes it); features / their gradient [7, L, B, 2] (level-major like the reference's [L,B,C] kernel output).

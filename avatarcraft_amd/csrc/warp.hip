@@ -8,8 +8,8 @@
 //     per sample, the triangle soup streamed through LDS tiles, exact closest point / barycentric blend / 4x4 inverse in
 //     fp64 on the device (fp64 vector rate of MI355X: 78 TFLOP/s).
 // Arithmetic order follows oracle/ac_oracle_ops.c (orc_mesh_near_far, orc_warp_samples) operation for operation
-// (-ffp-contract=off), so results are bit-identical to the CPU oracle.  Brute force over the faces in round 1; a
-// uniform-grid broad phase is the planned next step.
+// (-ffp-contract=off), so results are bit-identical to the CPU oracle.  warp_samples_kernel is the exhaustive search;
+// warp_samples_accel_kernel (further down) returns the same bits from an exact culled search, one wave per sample.
 #include "ac_common.hpp"
 
 namespace {
