@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restri
 
 // ---- exact closest-face search with culling ---------------------------------------------------------------------------------
 // Per frame (ac_warp_accel_build): faces sorted along a Morton curve of their centroids (one workgroup, bitonic sort of
-// 16384 64-bit keys in 128 KB of LDS), cut into tiles of 32 faces with an oriented box (axis 0 = mean normal) and one
+// 16384 64-bit keys in 128 KB of LDS), cut into tiles of TILE_F faces with an oriented box (axis 0 = mean normal) and one
 // representative vertex.
 // Per sample (warp_samples_accel_kernel): one WAVE searches for one sample at a time -- lane = tile in the bounding pass
 // (bounds of all tiles in LDS), lane = face in the exact pass, so the lanes never diverge:
@@ -223,16 +223,22 @@ __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restri
 //      keeps its own best (d2, face id), one wave reduction per sample, ties -> lowest face id (order independent).
 // A wave owns 64 consecutive samples: the search runs sample by sample, the result of sample j parks in lane j, and the
 // barycentric blend / 4x4 inverse epilogue runs lane-parallel for the 64 samples.  Bit-identical to warp_samples_kernel.
-constexpr int TILE_F = 32;          // faces per tile
-constexpr int MAX_TILES = 512;      // 8 bounding-pass iterations of 64 lanes
+#ifndef AC_TILE_F
+#define AC_TILE_F 32
+#endif
+constexpr int TILE_F = AC_TILE_F;   // faces per tile; 16 was tried: twice the boxes to bound costs more than the smaller candidates save (6.0 vs 4.3 ms / 1 M samples)
+constexpr int MAX_TILES = 16384 / TILE_F;
+constexpr int NIT = MAX_TILES / 64; // bounding-pass iterations of 64 lanes
+constexpr int GROUPS = 64 / TILE_F; // tiles tested per exact step
+constexpr int TPB = 256 / TILE_F;   // tiles per block of the tile builder
 constexpr uint32_t MAX_ACCEL_FACES = MAX_TILES * TILE_F;     // 16384
 constexpr int NB = 18;              // floats of bounds per tile
 
 struct AccelView {                   // pointers into the caller's accel buffer
     uint32_t *hdr;                   // [0] = number of tiles, [1] = F
     uint32_t *sorted;                // [16384] face ids along the curve
-    float *tri;                      // [MAX_TILES*32][9]
-    int32_t *oid;                    // [MAX_TILES*32] original face id of each slot
+    float *tri;                      // [MAX_ACCEL_FACES][9]
+    int32_t *oid;                    // [MAX_ACCEL_FACES] original face id of each slot
     float *box;                      // [NB][MAX_TILES]: oriented box: axes u0 (mean normal), u1, u2 (9), lo (3), hi (3); representative vertex (3)
 };
 __host__ __device__ inline size_t accel_offsets(size_t (&o)[5])
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) void accel_tiles_kernel(const float *__restric
                                                           AccelView av)
 {
     __shared__ float sb[256][9];
-    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;            // 8 tiles per block
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;            // TPB tiles per block
     const uint32_t nt = (F + TILE_F - 1) / TILE_F;
     const uint32_t src = slot < F ? slot : F - 1;                     // the tail of the last tile repeats the last face
     const uint32_t f = av.sorted[src];
@@ -345,8 +351,8 @@ __global__ __launch_bounds__(256) void accel_tiles_kernel(const float *__restric
 #pragma unroll
     for (int e = 0; e < 9; ++e) sb[threadIdx.x][e] = v[e];
     __syncthreads();
-    if (threadIdx.x < 8) {
-        const uint32_t tile = blockIdx.x * 8 + threadIdx.x;
+    if (threadIdx.x < TPB) {
+        const uint32_t tile = blockIdx.x * TPB + threadIdx.x;
         if (tile < MAX_TILES) {
             // oriented box of the tile: axis 0 = area-weighted mean normal of its faces, axes 1, 2 = a tangent basis; a surface patch
             // is thin along its normal, so this box is tight where an axis-aligned one is loose (by the patch size) -- and the
@@ -430,8 +436,9 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
     const uint32_t nt = av.hdr[0];
     const uint32_t nit = (nt + 63) >> 6;
     // bounds of all tiles in LDS (28 KB), lane = tile in the bounding pass
-    __shared__ float sbox[NB][MAX_TILES];
-    for (int e = threadIdx.x; e < NB * MAX_TILES; e += blockDim.x) (&sbox[0][0])[e] = av.box[e];
+    extern __shared__ __attribute__((aligned(16))) float sbox_raw[];
+    float (*sbox)[MAX_TILES] = reinterpret_cast<float (*)[MAX_TILES]>(sbox_raw);
+    for (int e = threadIdx.x; e < NB * MAX_TILES; e += blockDim.x) sbox_raw[e] = av.box[e];
     __syncthreads();
     const uint32_t i = wave * 64 + lane;
     const bool live = i < P;
@@ -443,10 +450,10 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
     for (uint32_t j = 0; j < npts; ++j) {
         const double q[3] = { __shfl(p[0], (int)j), __shfl(p[1], (int)j), __shfl(p[2], (int)j) };
         // 1. upper bound from the representative vertices, lower bound of every tile (kept in registers)
-        double ubl = __builtin_inf(), lb[8];
+        double ubl = __builtin_inf(), lb[NIT];
         int tbest = 0;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             lb[it] = __builtin_inf();
             if ((uint32_t)it >= nit) continue;                         // wave-uniform
             const int tl = it * 64 + lane;
@@ -470,15 +477,15 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
         double lmin = lb[0];
         int tlow = lane;
 #pragma unroll
-        for (int it = 1; it < 8; ++it) if (lb[it] < lmin) { lmin = lb[it]; tlow = it * 64 + lane; }
+        for (int it = 1; it < NIT; ++it) if (lb[it] < lmin) { lmin = lb[it]; tlow = it * 64 + lane; }
         const double lminw = wave_min_f64(lmin);
         const int tA = __shfl(tbest, __builtin_ctzll(__ballot(ubl == ub)));
         const int tB = __shfl(tlow, __builtin_ctzll(__ballot(lmin == lminw)));
         double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
         int bid = 0x7fffffff;
-        {
-            const int tmine = lane < 32 ? tA : tB;
-            const uint32_t slot = (uint32_t)tmine * TILE_F + (uint32_t)(lane & 31);
+        if (lane < 2 * TILE_F) {
+            const int tmine = lane < TILE_F ? tA : tB;
+            const uint32_t slot = (uint32_t)tmine * TILE_F + (uint32_t)(lane & (TILE_F - 1));
             const float *tp = av.tri + (size_t)slot * 9;
             const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
                          c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
         const double lim = (seed < ub ? seed : ub) * (1.0 + 1e-9);
         // 2./3. remaining candidates, two tiles per step
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             if ((uint32_t)it >= nit) break;                            // wave-uniform
             unsigned long long cand = __ballot(lb[it] <= lim);
             if (it == (tA >> 6)) cand &= ~(1ull << (tA & 63));         // the seed tiles are done
@@ -503,12 +510,15 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 4), (unsigned long long)__builtin_popcountll(cand));
 #endif
             while (cand) {
-                const int t0 = __builtin_ctzll(cand); cand &= cand - 1;
-                int t1 = -1;
-                if (cand) { t1 = __builtin_ctzll(cand); cand &= cand - 1; }
-                const int tmine = lane < 32 ? t0 : t1;
+                int tmine = -1;
+#pragma unroll
+                for (int gi = 0; gi < GROUPS; ++gi) {                  // the next GROUPS candidate tiles, one per group of TILE_F lanes
+                    int t = -1;
+                    if (cand) { t = __builtin_ctzll(cand); cand &= cand - 1; }
+                    if (lane / TILE_F == gi) tmine = t;
+                }
                 if (tmine >= 0) {
-                    const uint32_t slot = ((uint32_t)it * 64 + (uint32_t)tmine) * TILE_F + (uint32_t)(lane & 31);
+                    const uint32_t slot = ((uint32_t)it * 64 + (uint32_t)tmine) * TILE_F + (uint32_t)(lane & (TILE_F - 1));
                     const float *tp = av.tri + (size_t)slot * 9;
                     const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
                                  c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
@@ -574,7 +584,7 @@ AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_
     const size_t lds = (size_t)MAX_ACCEL_FACES * 8;
     if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(accel_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     hipLaunchKernelGGL(accel_sort_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, verts, faces, F, av.sorted);
-    hipLaunchKernelGGL(accel_tiles_kernel, dim3(MAX_TILES / 8), dim3(256), 0, (hipStream_t)stream, verts, faces, F, av);
+    hipLaunchKernelGGL(accel_tiles_kernel, dim3(MAX_TILES / TPB), dim3(256), 0, (hipStream_t)stream, verts, faces, F, av);
     return ac::check_launch("warp_accel_build");
 }
 
@@ -589,7 +599,10 @@ AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int
     }
     const AccelView av = accel_view(const_cast<void *>(accel));
     const uint32_t waves = (P + 63) / 64;
-    hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av,
+    const size_t lds = (size_t)NB * MAX_TILES * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(warp_samples_accel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + 3) / 4), dim3(256), lds, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av,
                        can_pts, can_pts_f32, closest, dist2, face_id, mask);
     return ac::check_launch("warp_samples_accel");
 }
