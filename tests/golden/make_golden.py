@@ -455,3 +455,29 @@ def make_path_goldens():
 
 if __name__ == "__main__":
     make_path_goldens()
+
+
+def make_dataset_ray_golden():
+    """SMPLDataset.gen_rays_pose (utils/SMPLDataset.py:86-103) without the dataset files: the method only reads W, H, K, device"""
+    for name in ("imageio", "scipy.ndimage"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                _stub(name)
+    _prepare_render_utils()
+    import utils.SMPLDataset as SD
+    ds = object.__new__(SD.SMPLDataset)
+    ds.W = ds.H = 512; ds.device = torch.device("cpu")
+    focal = .5 * 512 / np.tan(.5 * (np.pi / 3))
+    ds.K = torch.from_numpy(np.array([[focal, 0, 256.0], [0, focal, 256.0], [0, 0, 1]])).cpu()
+    rs = np.random.RandomState(2)
+    A = rs.normal(size=(3, 3)); Q, _ = np.linalg.qr(A)
+    pose = np.eye(4, dtype=np.float32); pose[:3, :3] = Q; pose[:3, 3] = [0.3, -0.2, 2.1]
+    o, v = ds.gen_rays_pose(torch.from_numpy(pose), 8)
+    np.savez_compressed(os.path.join(HERE, "dataset_rays.npz"), pose=pose, rays_o=o.numpy(), rays_d=v.numpy())
+    print("dataset rays", tuple(v.shape))
+
+
+if __name__ == "__main__":
+    make_dataset_ray_golden()

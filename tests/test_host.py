@@ -211,3 +211,11 @@ def test_style_paths_match_reference():
     np.random.seed(9)
     poses, _ = RU.default_360_path(c, up, 1.8, 8, add_noise=True)
     assert np.abs(np.stack([p.camera_to_world for p in poses]) - g["ring_noisy_c2w"]).max() < 1e-6
+
+
+def test_dataset_camera_rays_match_reference():
+    """gen_rays_pose (the camera of render_warp.py) against utils/SMPLDataset.py:86-103 (tests/golden/dataset_rays.npz)"""
+    from avatarcraft_amd.drivers import gen_rays_pose
+    g = load_golden("dataset_rays.npz")
+    o, v = gen_rays_pose(g["pose"], 8, device="cpu")
+    assert o.shape == (64, 64, 3) and np.array_equal(o.numpy(), g["rays_o"]) and np.abs(v.numpy() - g["rays_d"]).max() <= 1e-7
