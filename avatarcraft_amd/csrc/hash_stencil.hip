@@ -113,6 +113,40 @@ __global__ __launch_bounds__(256) void hash_stencil_fwd_kernel(const float *__re
 // most of them into a few cells: neighbouring lanes that sit in the same cell address the same table entries.  Their
 // contributions are summed inside the wave first (segmented inclusive scan over runs of equal cell, 6 shuffle steps) and only
 // the last lane of each run issues the atomics.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_f(float v)
+{
+    // lanes without a valid source (first lanes of a row for row_shr, rows outside ROW_MASK for row_bcast) receive 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf); }
+
+// one step of the segmented scan: every lane that has not met the head of its run yet (f == 0) adds the value CTRL points at.
+// v += dpp(v) * m with m in {0, 1} is ONE v_fmac_f32_dpp per value (the compiler's DPP combiner does not fold a DPP move into
+// v_fmac, hence the inline assembly).  The s_nop covers the "VALU write -> DPP read" (2) and "VALU writes EXEC -> DPP" (5) wait states for the first value of a step
+// (the hazard recogniser does not look into inline assembly); within a step and between steps N - 1 >= 15 instructions lie
+// between the write of a register and its DPP read.
+#define AC_FMAC_DPP(MODS) asm volatile("v_fmac_f32_dpp %0, %0, %1 " MODS : "+v"(v[i]) : "v"(m))
+template <int N, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void run_step(float (&v)[N], int &f)
+{
+    const float m = f ? 0.0f : 1.0f;
+    asm volatile("s_nop 4");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if constexpr (CTRL == 0x111) AC_FMAC_DPP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+        else if constexpr (CTRL == 0x112) AC_FMAC_DPP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+        else if constexpr (CTRL == 0x114) AC_FMAC_DPP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+        else if constexpr (CTRL == 0x118) AC_FMAC_DPP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+        else if constexpr (CTRL == 0x142) AC_FMAC_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+        else AC_FMAC_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    }
+    f |= dpp_i<CTRL, ROW_MASK>(f);
+}
+#undef AC_FMAC_DPP
+
+// segmented inclusive sums over runs of lanes (head = first lane of a run): DPP only, no LDS traffic -- Kogge-Stone inside every
+// 16-lane row (row_shr 1, 2, 4, 8), then the open tail of the previous row(s) is carried over with row_bcast15 / row_bcast31.
+// Returns true in the last lane of every run (the one that holds the run's total).
 template <int N>
 __device__ __forceinline__ bool run_reduce(float (&v)[N], bool head, int lane)
 {
@@ -120,6 +154,7 @@ __device__ __forceinline__ bool run_reduce(float (&v)[N], bool head, int lane)
     return true;
 #endif
     int f = head ? 1 : 0;
+#ifdef AC_RUN_SHUFFLE       // the first implementation: 6 Kogge-Stone steps over the whole wave with ds_bpermute
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int tf = __shfl_up(f, d);
@@ -128,6 +163,14 @@ __device__ __forceinline__ bool run_reduce(float (&v)[N], bool head, int lane)
         for (int i = 0; i < N; ++i) { const float t = __shfl_up(v[i], d); v[i] += take ? t : 0.0f; }
         if (lane >= d) f |= tf;
     }
+#else
+    run_step<N, 0x111, 0xf>(v, f);
+    run_step<N, 0x112, 0xf>(v, f);
+    run_step<N, 0x114, 0xf>(v, f);
+    run_step<N, 0x118, 0xf>(v, f);
+    run_step<N, 0x142, 0xa>(v, f);          // row_bcast15: rows 1 and 3 take lane 15 of rows 0 and 2
+    run_step<N, 0x143, 0xc>(v, f);          // row_bcast31: rows 2 and 3 take lane 31
+#endif
     const int next_head = __shfl_down(head ? 1 : 0, 1);
     return lane == 63 || next_head != 0;
 }

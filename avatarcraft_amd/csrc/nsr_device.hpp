@@ -28,6 +28,9 @@ namespace {
 constexpr int WAVES_PER_BLOCK = AC_WPB;
 constexpr int BLOCK = WAVES_PER_BLOCK * 64;
 constexpr int MAXT = 128;
+#ifndef AC_FINE_BATCH
+#define AC_FINE_BATCH 3     // fine stencil levels: offset-point pairs gathered per memory round trip (1: x | y | z, 2: x+y | z, 3: all six: 221 VGPRs, -2 % time)
+#endif
 #ifndef AC_ENC_ROUND
 #define AC_ENC_ROUND 2      // hash levels gathered per round per lane (registers vs loads in flight)
 #endif
@@ -76,7 +79,7 @@ struct RenderArgs {
     int jfine[4];          // per round: 1 if the FD offset eps can span >= 1 cell on any of its levels
     float bound, two_bound, inv_s, car, one_m_car, eps;
     int perturb;
-    unsigned long long *prof;   // AC_PROFILE builds only: [n_waves][8] cycle counters per phase
+    unsigned long long *prof;   // AC_PROFILE builds only: [n_waves][10]: 8 per-phase s_memtime counters, whole-wave s_memtime and s_memrealtime (100 MHz)
     // posed-space rendering (render_can=False) only: see ac_render_rays_warped
     const float *near_m, *far_m;   // [N] mesh-guided range (+-inf where the ray misses the body) or NULL
     const float *ext_pts;          // MODE_UPSAMPLE: warped coarse points [N,T0,3]; MODE_FINAL: warped mid points [N,T,3]
@@ -466,6 +469,44 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
             coarse_finish<2, 0>(a4, vc, w4, qc, f0, f1); AC_FSTORE(5, f0, f1)
             coarse_finish<2, 1>(a5, vc, w5, qc, f0, f1); AC_FSTORE(6, f0, f1)
         } else {
+#if AC_FINE_BATCH == 3     // all 48 gathers of the six offset points in flight at once: one memory round trip instead of three
+            u32x2 va[8], vb[8], vc2[8], vd[8], ve[8], vf[8];
+            float qa, qb, qc2, qd, qe, qf, f0, f1; bool oa, ob, oc2, od, oe, of;
+            fine_issue<0>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
+            fine_issue<0>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
+            fine_issue<1>(table, L, tx, ty, tz, oob, yp, vc2, qc2, oc2);
+            fine_issue<1>(table, L, tx, ty, tz, oob, ym, vd, qd, od);
+            fine_issue<2>(table, L, tx, ty, tz, oob, zp, ve, qe, oe);
+            fine_issue<2>(table, L, tx, ty, tz, oob, zm, vf, qf, of);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+            interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
+            interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
+            interp8(vc2, qc[0], qc2, qc[2], oc2, f0, f1); AC_FSTORE(3, f0, f1)
+            interp8(vd, qc[0], qd, qc[2], od, f0, f1); AC_FSTORE(4, f0, f1)
+            interp8(ve, qc[0], qc[1], qe, oe, f0, f1); AC_FSTORE(5, f0, f1)
+            interp8(vf, qc[0], qc[1], qf, of, f0, f1); AC_FSTORE(6, f0, f1)
+#elif AC_FINE_BATCH == 2   // x and y offsets in one round trip, z offsets in a second one
+            u32x2 va[8], vb[8], vc2[8], vd[8];
+            float qa, qb, qc2, qd, f0, f1; bool oa, ob, oc2, od;
+            fine_issue<0>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
+            fine_issue<0>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
+            fine_issue<1>(table, L, tx, ty, tz, oob, yp, vc2, qc2, oc2);
+            fine_issue<1>(table, L, tx, ty, tz, oob, ym, vd, qd, od);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+            interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
+            interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
+            __builtin_amdgcn_sched_barrier(0);
+            fine_issue<2>(table, L, tx, ty, tz, oob, zp, va, qa, oa);
+            fine_issue<2>(table, L, tx, ty, tz, oob, zm, vb, qb, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(vc2, qc[0], qc2, qc[2], oc2, f0, f1); AC_FSTORE(3, f0, f1)
+            interp8(vd, qc[0], qd, qc[2], od, f0, f1); AC_FSTORE(4, f0, f1)
+            __builtin_amdgcn_sched_barrier(0);
+            interp8(va, qc[0], qc[1], qa, oa, f0, f1); AC_FSTORE(5, f0, f1)
+            interp8(vb, qc[0], qc[1], qb, ob, f0, f1); AC_FSTORE(6, f0, f1)
+#else
             u32x2 va[8], vb[8];
             float qa, qb, f0, f1; bool oa, ob;
             fine_issue<0>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
@@ -486,6 +527,7 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
             __builtin_amdgcn_sched_barrier(0);
             interp8(va, qc[0], qc[1], qa, oa, f0, f1); AC_FSTORE(5, f0, f1)
             interp8(vb, qc[0], qc[1], qb, ob, f0, f1); AC_FSTORE(6, f0, f1)
+#endif
         }
         // rotate the centre features into place: after the 4th iteration fe0[j] holds level 4j+g
         fe0[0][0] = fe0[1][0]; fe0[0][1] = fe0[1][1]; fe0[1][0] = fe0[2][0]; fe0[1][1] = fe0[2][1];

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 
 #ifdef AC_PROFILE
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #ifdef AC_STAGGER      // experiment: de-phase the two waves that share a SIMD (waves w and w+4 of the workgroup)
     if (wave >= 4) { for (int i_ = 0; i_ < AC_STAGGER; ++i_) __builtin_amdgcn_s_sleep(127); }
@@ -374,7 +375,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         wave_sync();
     }
 #ifdef AC_PROFILE
-    if (a.prof && lane == 0) { const int w_ = blockIdx.x * WAVES_PER_BLOCK + wave; for (int i = 0; i < 8; ++i) a.prof[w_ * 8 + i] = prof_acc[i]; }
+    if (a.prof && lane == 0) { const int w_ = blockIdx.x * WAVES_PER_BLOCK + wave; for (int i = 0; i < 8; ++i) a.prof[w_ * 10 + i] = prof_acc[i];
+        a.prof[w_ * 10 + 8] = __builtin_amdgcn_s_memtime() - prof_t0; a.prof[w_ * 10 + 9] = __builtin_amdgcn_s_memrealtime() - prof_r0; }   // shader clock vs 100 MHz
 #endif
 }
 

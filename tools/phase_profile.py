@@ -7,7 +7,7 @@ import numpy as np, torch
 csrc = os.path.join(ROOT, "avatarcraft_amd", "csrc")
 out = os.path.join(ROOT, "gpurun_out", "libac_prof.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "warp.hip")]
+srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "hash_stencil.hip", "sdf_train.hip", "warp.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                        "-DAC_PROFILE", "-Wno-unused-result", "-o", out] + srcs)
 from avatarcraft_amd import _lib
@@ -19,14 +19,17 @@ from tests.gpu_common import device_field
 p = load_golden("nsr_params.npz"); f, _ = device_field(p)
 ro, rd = make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)
 ro, rd = torch.from_numpy(ro[:4096].copy()).cuda(), torch.from_numpy(rd[:4096].copy()).cuda()
-prof = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+prof = torch.zeros(4096 * 10, dtype=torch.int64, device="cuda")
 _lib.lib().ac_debug_set_prof(prof.data_ptr())
 for _ in range(3):
     prof.zero_(); nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, float(p["inv_s"])); torch.cuda.synchronize()
-pr = prof.cpu().numpy().reshape(4096, 8).astype(np.float64)
+pa = prof.cpu().numpy().reshape(4096, 10).astype(np.float64)
+pr = pa[:, :8]
 names = ["coarse(64 sdf evals)", "upsample math+merge", "upsample sdf eval", "final: stencil gather+interp", "final: 7x sdf mlp", "final: colour mlp",
          "final: alpha+composite", "final: tile setup"]
 tot = pr.sum(1).mean()
-print("s_memtime ticks per ray (100 MHz const clock): total %.0f" % tot)
+print("s_memtime ticks per ray: total %.0f" % tot)
+print("whole wave: %.0f s_memtime ticks in %.0f s_memrealtime ticks (100 MHz) = %.1f us  ->  s_memtime runs at %.3f GHz"
+      % (pa[:, 8].mean(), pa[:, 9].mean(), pa[:, 9].mean() / 100.0, pa[:, 8].mean() / pa[:, 9].mean() * 0.1))
 for n, v in zip(names, pr.mean(0)):
     print("  %-32s %9.0f  %5.1f%%" % (n, v, 100 * v / tot))
