@@ -21,6 +21,9 @@ using namespace acdev;
 
 namespace {
 
+#ifndef AC_ABL_FLUSH
+#define AC_ABL_FLUSH 0
+#endif
 #ifdef AC_ABL_NOATOMIC      // timing ablation (tools/ablate_stencil.sh): keep the address math, drop the atomic itself
 #define AC_ATOMIC_ADD(P, V) { if ((V) == 123456.789f) *(P) = (V); }
 #else
@@ -32,6 +35,10 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+
+#ifdef AC_PROFILE_FILL
+__device__ unsigned long long g_fill_prof[AC_MAX_LEVELS * 6];      // [level][combine, records, reservation, write-out, whole wave, flushes] s_memtime ticks summed over waves
+#endif
 
 struct LevelC { float scale; uint32_t stride1, size, hashed, mask; };
 
@@ -192,52 +199,82 @@ __device__ __forceinline__ bool run_head(const Loc (&q)[3], bool ok, int lane)
 // without atomics.  Global atomics per record: 2 -> ~1/30.
 struct DirectSink {
     float2 *gg;
-    __device__ __forceinline__ void add(bool pred, uint32_t index, float v0, float v1) const
+    __device__ __forceinline__ void tick(int) const {}
+    // eight table entries at once: pred[k] says whether this lane contributes (v[2k], v[2k+1]) to entry index_of(k)
+    template <class F> __device__ __forceinline__ void add8(const bool (&pred)[8], F index_of, const float (&v)[16]) const
     {
-        if (pred) { float *t = reinterpret_cast<float *>(gg + index); AC_ATOMIC_ADD(t, v0); AC_ATOMIC_ADD(t + 1, v1); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (pred[k]) { float *t = reinterpret_cast<float *>(gg + index_of(k)); AC_ATOMIC_ADD(t, v[2 * k]); AC_ATOMIC_ADD(t + 1, v[2 * k + 1]); }
     }
 };
 
 constexpr int NBUCKET = 64;
-constexpr int RCAP = 1536;                 // records per wave buffer: every emission step adds <= 512 (8 slots x 64 lanes) after a reserve(512)
+#ifndef AC_RCAP
+#define AC_RCAP 1536
+#endif
+constexpr int RCAP = AC_RCAP;              // records per wave buffer; add8 reserves room for 8 x 64 records
 struct Rec { uint32_t idx; float v0, v1; };
 
 struct BinSink {
-    uint32_t *ridx; float *rv0, *rv1;      // this wave's LDS record buffer [RCAP]
+    uint32_t *ridx; float *rv0, *rv1;      // this wave's LDS record buffer [RCAP]; ridx = entry | rank inside its bucket << 19
     uint32_t *hist, *base;                 // this wave's LDS [NBUCKET] each (hist zero between flushes)
     uint32_t cnt;                          // wave-uniform
-    uint32_t per;                          // entries per bucket: bucket = index / per
+    uint32_t sh;                           // bucket = index >> sh (2^sh entries per bucket, <= NBUCKET buckets per level)
+    uint32_t mx;                           // per lane: bits of the largest |v| recorded since the last flush
     uint32_t *qcount;                      // global [NBUCKET] of this level
     uint32_t *vmax;                        // global: bits of max |v| over this level's records (positive floats order like uints)
     Rec *queue;                            // global [NBUCKET][cap] of this level
     uint32_t cap;
     float2 *gg;                            // overflow path: direct atomics
     int lane;
-    __device__ __forceinline__ void add(bool pred, uint32_t index, float v0, float v1)
+#ifdef AC_PROFILE_FILL                     // s_memtime per phase: 0 stencil combine + run scan, 1 records -> LDS, 2 flush: slot reservation, 3 flush: write-out
+    unsigned long long ft, facc[4], nflush;
+    __device__ __forceinline__ void tick(int slot) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); facc[slot] += t2 - ft; ft = t2; }
+#else
+    __device__ __forceinline__ void tick(int) {}
+#endif
+    // the bucket histogram and the running max |v| are taken while the record is still in registers: the flush is then ONE pass over
+    // the buffer (three passes over LDS cost 1.2 of the kernel's 1.85 ms, profiles/r01_sds.txt)
+    // eight table entries at once (after reserving room for 8 x 64 records): the bucket ranks of all eight are requested first
+    // (LDS atomics with return), then the records are written -- one LDS round trip per eight slots instead of eight
+    template <class F> __device__ __forceinline__ void add8(const bool (&pred)[8], F index_of, const float (&v)[16])
     {
-        const unsigned long long m = __ballot(pred);
-        if (pred) {
-            const uint32_t pos = cnt + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-            ridx[pos] = index; rv0[pos] = v0; rv1[pos] = v1;
+        if (cnt + 512u > (uint32_t)RCAP) flush();
+        unsigned long long m[8];
+        uint32_t index[8], rank[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            m[k] = __ballot(pred[k]);
+            index[k] = 0u; rank[k] = 0u;
+            if (m[k] != 0ull && pred[k]) {                                         // wave-uniform skip: most neighbour slots of a coarse level are empty
+                index[k] = index_of(k);
+                rank[k] = atomicAdd(&hist[index[k] >> sh], 1u);
+            }
         }
-        cnt += (uint32_t)__builtin_popcountll(m);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (m[k] == 0ull) continue;
+            if (pred[k]) {
+                const uint32_t pos = cnt + (uint32_t)__builtin_popcountll(m[k] & ((1ull << lane) - 1ull));
+                ridx[pos] = index[k] | (rank[k] << 19); rv0[pos] = v[2 * k]; rv1[pos] = v[2 * k + 1];
+                const uint32_t a0 = __float_as_uint(v[2 * k]) & 0x7fffffffu, a1 = __float_as_uint(v[2 * k + 1]) & 0x7fffffffu;
+                mx = mx > a0 ? mx : a0; mx = mx > a1 ? mx : a1;
+            }
+            cnt += (uint32_t)__builtin_popcountll(m[k]);
+        }
     }
     __device__ __forceinline__ void flush()
     {
-        wave_sync_lds();
-        uint32_t mx = 0;
-        for (uint32_t i = lane; i < cnt; i += 64) {
-            const uint32_t a0 = __float_as_uint(rv0[i]) & 0x7fffffffu, a1 = __float_as_uint(rv1[i]) & 0x7fffffffu;
-            mx = mx > a0 ? mx : a0; mx = mx > a1 ? mx : a1;
-        }
+#if AC_ABL_FLUSH == 1       // timing ablation: drop the records
+        cnt = 0; return;
+#endif
+        tick(1);
+        uint32_t wmx = mx;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d); mx = mx > o ? mx : o; }
-        if (lane == 0 && mx) atomicMax(vmax, mx);
-        for (uint32_t i = lane; i < cnt; i += 64) {
-            const uint32_t idx = ridx[i];
-            const uint32_t rank = atomicAdd(&hist[idx / per], 1u);
-            ridx[i] = idx | (rank << 19);
-        }
+        for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)wmx, d); wmx = wmx > o ? wmx : o; }
+        if (lane == 0 && wmx) atomicMax(vmax, wmx);
+        mx = 0u;
         wave_sync_lds();
         {
             const uint32_t c = hist[lane];
@@ -245,24 +282,51 @@ struct BinSink {
             hist[lane] = 0u;
         }
         wave_sync_lds();
-        for (uint32_t i = lane; i < cnt; i += 64) {
-            const uint32_t packed = ridx[i], idx = packed & 0x7ffffu, bucket = idx / per;
-            const uint32_t slot = base[bucket] + (packed >> 19);
-            const float v0 = rv0[i], v1 = rv1[i];
-            if (slot < cap) {
-                Rec r; r.idx = idx - bucket * per; r.v0 = v0; r.v1 = v1;
-                queue[(size_t)bucket * cap + slot] = r;
-            } else {                        // queue full (never with the default sizing): fall back to atomics
-                float *t = reinterpret_cast<float *>(gg + idx); AC_ATOMIC_ADD(t, v0); AC_ATOMIC_ADD(t + 1, v1);
+        tick(2);
+        // write-out, WU records per lane and trip: the LDS reads of a trip are issued together (one LDS latency per trip, not per record)
+        constexpr uint32_t WU = 4;
+        for (uint32_t i0 = lane; i0 < cnt; i0 += 64 * WU) {
+            uint32_t packed[WU]; float v0[WU], v1[WU]; uint32_t bs[WU];
+#pragma unroll
+            for (uint32_t u = 0; u < WU; ++u) {
+                const uint32_t i = i0 + 64 * u, ic = i < cnt ? i : i0;
+                packed[u] = ridx[ic]; v0[u] = rv0[ic]; v1[u] = rv1[ic];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < WU; ++u) bs[u] = base[(packed[u] & 0x7ffffu) >> sh];
+#pragma unroll
+            for (uint32_t u = 0; u < WU; ++u) {
+                if (i0 + 64 * u >= cnt) continue;
+                const uint32_t idx = packed[u] & 0x7ffffu, bucket = idx >> sh;
+                const uint32_t slot = bs[u] + (packed[u] >> 19);
+                if (slot < cap) {
+                    Rec r; r.idx = idx - (bucket << sh); r.v0 = v0[u]; r.v1 = v1[u];
+#if AC_ABL_FLUSH == 2       // timing ablation: bin the records but do not write them
+                    if (v0[u] == 123456.789f)
+#endif
+                    queue[(size_t)bucket * cap + slot] = r;
+                } else {                    // queue full (never with the default sizing): fall back to atomics
+                    float *t = reinterpret_cast<float *>(gg + idx); AC_ATOMIC_ADD(t, v0[u]); AC_ATOMIC_ADD(t + 1, v1[u]);
+                }
             }
         }
         wave_sync_lds();
         cnt = 0;
+        tick(3);
+#ifdef AC_PROFILE_FILL
+        ++nflush;
+#endif
     }
 };
 
-__device__ __forceinline__ void sink_reserve(DirectSink &, uint32_t) {}
-__device__ __forceinline__ void sink_reserve(BinSink &s, uint32_t room) { if (s.cnt + room > (uint32_t)RCAP) s.flush(); }
+// entries per bucket = 2^bucket_shift: the smallest power of two that covers the level with NBUCKET buckets
+__host__ __device__ __forceinline__ uint32_t bucket_shift(uint32_t size)
+{
+    uint32_t sh = 0;
+    while (((size + (1u << sh) - 1u) >> sh) > (uint32_t)NBUCKET) ++sh;
+    return sh;
+}
+
 
 // one point's 8 corners, combined over the run of lanes in the same cell
 template <class Sink>
@@ -282,17 +346,19 @@ __device__ __forceinline__ void scatter8_runs(Sink &sink, const LevelC &L, const
 #else
     const bool tail = run_reduce<16>(v, run_head(q, ok, lane), lane) && ok;
 #endif
+    sink.tick(0);
+    bool pred[8];
 #pragma unroll
-    for (uint32_t idx = 0; idx < 8; ++idx)
-        sink.add(tail && (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f),
-                 gindex(L, q[0].pg + (idx & 1u), q[1].pg + ((idx >> 1) & 1u), q[2].pg + ((idx >> 2) & 1u)), v[2 * idx], v[2 * idx + 1]);
+    for (int k = 0; k < 8; ++k) pred[k] = tail && (v[2 * k] != 0.0f || v[2 * k + 1] != 0.0f);
+    sink.add8(pred, [&](int k) { return gindex(L, q[0].pg + ((uint32_t)k & 1u), q[1].pg + (((uint32_t)k >> 1) & 1u), q[2].pg + (((uint32_t)k >> 2) & 1u)); }, v);
+    sink.tick(1);
 }
 
 // the seven stencil points of one sample per lane (64 consecutive samples per wave) on one level.
 // fine: eps can reach a non-neighbouring cell on this level -> the seven points scatter independently
 template <class Sink>
 __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, bool fine, const float (&xc)[3], const float2 (&gp)[7], float eps,
-                                                float bound, float two_bound, int lane, uint32_t fine_room)
+                                                float bound, float two_bound, int lane)
 {
     Loc c[3];
 #pragma unroll
@@ -304,7 +370,6 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
         for (int p = 0; p < 7; ++p) {
             Loc q[3] = { c[0], c[1], c[2] };
             if (p > 0) { const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale); }
-            sink_reserve(sink, fine_room);
             scatter8_runs(sink, L, q, gp[p].x, gp[p].y, lane);
         }
         return;
@@ -348,28 +413,32 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
         }
     }
     const bool tail = run_reduce<64>(v, run_head(c, true, lane), lane);
-    sink_reserve(sink, fine_room);
+    sink.tick(0);
+    {
+        bool pred[8]; float vv[16];
 #pragma unroll
-    for (uint32_t idx = 0; idx < 8; ++idx)
-        sink.add(tail && (v[2 * idx] != 0.0f || v[2 * idx + 1] != 0.0f),
-                 gindex(L, c[0].pg + (idx & 1u), c[1].pg + ((idx >> 1) & 1u), c[2].pg + ((idx >> 2) & 1u)), v[2 * idx], v[2 * idx + 1]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        sink_reserve(sink, fine_room);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (uint32_t jm = 0; jm < 4; ++jm) {
-                const uint32_t e = 16 + ((k * 2 + s) * 4 + jm) * 2;
-                uint32_t pl[3];
-                const uint32_t lo = jm & 1u, hi = jm >> 1;
-                pl[0] = c[0].pg + (k == 0 ? 0u : lo);
-                pl[1] = c[1].pg + (k == 1 ? 0u : (k == 0 ? lo : hi));
-                pl[2] = c[2].pg + (k == 2 ? 0u : hi);
-                pl[k] = s ? c[k].pg + 2u : c[k].pg - 1u;
-                sink.add(tail && (v[e] != 0.0f || v[e + 1] != 0.0f), gindex(L, pl[0], pl[1], pl[2]), v[e], v[e + 1]);
-            }
+        for (int k = 0; k < 8; ++k) { vv[2 * k] = v[2 * k]; vv[2 * k + 1] = v[2 * k + 1]; pred[k] = tail && (v[2 * k] != 0.0f || v[2 * k + 1] != 0.0f); }
+        sink.add8(pred, [&](int k) { return gindex(L, c[0].pg + ((uint32_t)k & 1u), c[1].pg + (((uint32_t)k >> 1) & 1u), c[2].pg + (((uint32_t)k >> 2) & 1u)); }, vv);
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                            // the two planes next to the centre cell along axis k: slot n = side * 4 + jm
+        bool pred[8]; float vv[16];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const uint32_t e = 16 + (k * 8 + n) * 2;
+            vv[2 * n] = v[e]; vv[2 * n + 1] = v[e + 1]; pred[n] = tail && (v[e] != 0.0f || v[e + 1] != 0.0f);
+        }
+        sink.add8(pred, [&](int n) {
+            const uint32_t jm = (uint32_t)n & 3u, lo = jm & 1u, hi = jm >> 1;
+            uint32_t pl[3];
+            pl[0] = c[0].pg + (k == 0 ? 0u : lo);
+            pl[1] = c[1].pg + (k == 1 ? 0u : (k == 0 ? lo : hi));
+            pl[2] = c[2].pg + (k == 2 ? 0u : hi);
+            pl[k] = (n >> 2) ? c[k].pg + 2u : c[k].pg - 1u;
+            return gindex(L, pl[0], pl[1], pl[2]);
+        }, vv);
+    }
+    sink.tick(1);
 }
 
 // direct atomics: one sample per thread, level = blockIdx.y in [0, n_levels)
@@ -397,7 +466,7 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
         gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
         if (!valid) gp[p] = make_float2(0.0f, 0.0f);
     }
-    stencil_scatter(sink, L, ((fine_mask >> level) & 1u) != 0, xc, gp, eps, bound, two_bound, lane, 0u);
+    stencil_scatter(sink, L, ((fine_mask >> level) & 1u) != 0, xc, gp, eps, bound, two_bound, lane);
 }
 
 // binned path: blockIdx.y indexes the binned levels; every wave walks over groups of 64 samples and flushes its record buffer
@@ -419,13 +488,17 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
     sink.cnt = 0; sink.lane = lane;
-    sink.per = (lt.size[level] + NBUCKET - 1) / NBUCKET;
+    sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
     sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
     sink.vmax = qcount + (size_t)gridDim.y * NBUCKET + blockIdx.y;
     sink.queue = queues + (size_t)blockIdx.y * NBUCKET * cap;
     sink.cap = cap;
     sink.gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
     sink.hist[lane] = 0u;
+#ifdef AC_PROFILE_FILL
+    sink.facc[0] = sink.facc[1] = sink.facc[2] = sink.facc[3] = 0ull; sink.nflush = 0ull; sink.ft = __builtin_amdgcn_s_memtime();
+    const unsigned long long prof_t0 = sink.ft;
+#endif
     const bool fine = ((fine_mask >> level) & 1u) != 0;
     const uint32_t ngroups = (B + 63) / 64;
     for (uint32_t grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
@@ -439,9 +512,16 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
             gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
             if (!valid) gp[p] = make_float2(0.0f, 0.0f);
         }
-        stencil_scatter(sink, L, fine, xc, gp, eps, bound, two_bound, lane, 512u);
+        stencil_scatter(sink, L, fine, xc, gp, eps, bound, two_bound, lane);
     }
     sink.flush();
+#ifdef AC_PROFILE_FILL
+    if (lane == 0) {
+        unsigned long long *o = g_fill_prof + (size_t)level * 6;
+        atomicAdd(o, sink.facc[0]); atomicAdd(o + 1, sink.facc[1]); atomicAdd(o + 2, sink.facc[2]); atomicAdd(o + 3, sink.facc[3]);
+        atomicAdd(o + 4, __builtin_amdgcn_s_memtime() - prof_t0); atomicAdd(o + 5, sink.nflush);
+    }
+#endif
 }
 
 // the reference's one-point backward (kernel_grid_backward, hashencoder.cu:223-308; D = 3, C = 2) through the binned scatter:
@@ -460,7 +540,7 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
     sink.cnt = 0; sink.lane = lane;
-    sink.per = (lt.size[level] + NBUCKET - 1) / NBUCKET;
+    sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
     sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
     sink.vmax = qcount + (size_t)gridDim.y * NBUCKET + blockIdx.y;
     sink.queue = queues + (size_t)blockIdx.y * NBUCKET * cap;
@@ -483,7 +563,6 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
         }
         float2 g = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
         if (!valid) g = make_float2(0.0f, 0.0f);
-        sink_reserve(sink, 512u);
         scatter8_runs(sink, L, q, g.x, g.y, lane);
     }
     sink.flush();
@@ -502,7 +581,7 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];        // [entries per bucket][2]
     uint32_t level = 0, seen = 0;
     for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
-    const uint32_t per = (lt.size[level] + NBUCKET - 1) / NBUCKET, bucket = blockIdx.x;
+    const uint32_t per = 1u << bucket_shift(lt.size[level]), bucket = blockIdx.x;
     const uint32_t first = bucket * per;
     const uint32_t mine = first >= lt.size[level] ? 0u : (lt.size[level] - first < per ? lt.size[level] - first : per);     // the last bucket may be short
     uint32_t n = qcount[(size_t)blockIdx.y * NBUCKET + bucket];
@@ -667,6 +746,15 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
         hipLaunchKernelGGL(priv_reduce_kernel, dim3((sc.entries * 2 + 255) / 256), dim3(256), 0, st, priv, sc.entries * 2, n_copies, grad_embeddings);
     return ac::check_launch("hash_stencil_backward");
 }
+
+#ifdef AC_PROFILE_FILL
+AC_API void ac_debug_fill_prof(unsigned long long *out, int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_prof), sizeof(unsigned long long) * AC_MAX_LEVELS * 6);
+    if (reset) { static unsigned long long z[AC_MAX_LEVELS * 6] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fill_prof), z, sizeof(z)); }
+}
+#endif
 
 // ---- the reference's operator (ac_hash_encode_backward) with caller scratch: binned scatter when D = 3, C = 2 and every level fits
 AC_API size_t ac_hash_encode_backward_scratch(const int32_t *offsets_host, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t B)
