@@ -233,6 +233,8 @@ constexpr int GROUPS = 64 / TILE_F; // tiles tested per exact step
 constexpr int TPB = 256 / TILE_F;   // tiles per block of the tile builder
 constexpr uint32_t MAX_ACCEL_FACES = MAX_TILES * TILE_F;     // 16384
 constexpr int NB = 18;              // floats of bounds per tile
+constexpr int STEPS = 4;            // trips of the face loop handle STEPS x GROUPS tiles
+constexpr uint32_t RING = 512;      // per-wave ring of faces that passed the disc test: < 64 left over + STEPS x 64 new ones per trip
 
 struct AccelView {                   // pointers into the caller's accel buffer
     uint32_t *hdr;                   // [0] = number of tiles, [1] = F
@@ -240,21 +242,24 @@ struct AccelView {                   // pointers into the caller's accel buffer
     float *tri;                      // [MAX_ACCEL_FACES][9]
     int32_t *oid;                    // [MAX_ACCEL_FACES] original face id of each slot
     float *box;                      // [NB][MAX_TILES]: oriented box: axes u0 (mean normal), u1, u2 (9), lo (3), hi (3); representative vertex (3)
+    float4 *sph;                     // [MAX_ACCEL_FACES][2] bounding disc of each slot's face: (centre, padded radius), (unit normal or 0, -)
 };
-__host__ __device__ inline size_t accel_offsets(size_t (&o)[5])
+__host__ __device__ inline size_t accel_offsets(size_t (&o)[6])
 {
     size_t off = 0;
-    const size_t sz[5] = { 64, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)NB * MAX_TILES * 4 };
-    for (int i = 0; i < 5; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
+    const size_t sz[6] = { 64, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)NB * MAX_TILES * 4,
+                           (size_t)MAX_ACCEL_FACES * 32 };
+    for (int i = 0; i < 6; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
     return off;
 }
 __host__ __device__ inline AccelView accel_view(void *base)
 {
-    size_t o[5]; accel_offsets(o);
+    size_t o[6]; accel_offsets(o);
     char *b = static_cast<char *>(base);
     AccelView v;
     v.hdr = reinterpret_cast<uint32_t *>(b + o[0]); v.sorted = reinterpret_cast<uint32_t *>(b + o[1]);
     v.tri = reinterpret_cast<float *>(b + o[2]); v.oid = reinterpret_cast<int32_t *>(b + o[3]); v.box = reinterpret_cast<float *>(b + o[4]);
+    v.sph = reinterpret_cast<float4 *>(b + o[5]);
     return v;
 }
 
@@ -347,6 +352,29 @@ __global__ __launch_bounds__(256) void accel_tiles_kernel(const float *__restric
 #pragma unroll
         for (int e = 0; e < 9; ++e) av.tri[(size_t)slot * 9 + e] = v[e];
         av.oid[slot] = (int32_t)f;
+        // bounding disc: the face lies in the disc (centre c = centroid, radius r = largest vertex distance from the STORED c) of its
+        // own plane, so dist(q, face)^2 >= pd^2 + max(0, rho - r)^2 with pd = n.(q - c) and rho^2 = |q - c|^2 - pd^2.  Built in fp64
+        // from the fp32 vertices and rounded to fp32; the search pads for that rounding.  A (nearly) degenerate face gets n = 0:
+        // the bound then falls back to the bounding sphere.
+        const double A[3] = { (double)v[0], (double)v[1], (double)v[2] }, Bv[3] = { (double)v[3], (double)v[4], (double)v[5] },
+                     Cv[3] = { (double)v[6], (double)v[7], (double)v[8] };
+        float cf[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cf[k] = (float)((A[k] + Bv[k] + Cv[k]) / 3.0);
+        double r2 = 0.0;
+#pragma unroll
+        for (int cnr = 0; cnr < 3; ++cnr) {
+            const double ex = (double)v[3 * cnr] - (double)cf[0], ey = (double)v[3 * cnr + 1] - (double)cf[1], ez = (double)v[3 * cnr + 2] - (double)cf[2];
+            const double d = ex * ex + ey * ey + ez * ez;
+            r2 = d > r2 ? d : r2;
+        }
+        const double e0[3] = { Bv[0] - A[0], Bv[1] - A[1], Bv[2] - A[2] }, e1[3] = { Cv[0] - A[0], Cv[1] - A[1], Cv[2] - A[2] };
+        const double nx = e0[1] * e1[2] - e0[2] * e1[1], ny = e0[2] * e1[0] - e0[0] * e1[2], nz = e0[0] * e1[1] - e0[1] * e1[0];
+        const double nl = __builtin_sqrt(nx * nx + ny * ny + nz * nz);
+        const double l0 = __builtin_sqrt(DOT3(e0, e0)), l1 = __builtin_sqrt(DOT3(e1, e1));
+        const bool flat = nl > 1e-6 * l0 * l1 && nl > 0.0;           // sin(angle at A) > 1e-6: the normal of a sliver is not trustworthy
+        av.sph[2 * (size_t)slot] = make_float4(cf[0], cf[1], cf[2], (float)(__builtin_sqrt(r2) * (1.0 + 1e-6) + 1e-7));
+        av.sph[2 * (size_t)slot + 1] = flat ? make_float4((float)(nx / nl), (float)(ny / nl), (float)(nz / nl), 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 #pragma unroll
     for (int e = 0; e < 9; ++e) sb[threadIdx.x][e] = v[e];
@@ -411,18 +439,46 @@ __global__ __launch_bounds__(256) void accel_tiles_kernel(const float *__restric
     if (slot == 0) { av.hdr[0] = nt; av.hdr[1] = F; }
 }
 
-__device__ __forceinline__ double wave_min_f64(double v)
+__device__ __forceinline__ void wave_sync_lds()
 {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(v, d); v = o < v ? o : v; }
-    return v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// wave-wide minima without LDS traffic: inclusive min scan inside every 16-lane row (DPP row_shr 1, 2, 4, 8), the rows are joined with
+// row_bcast15 / row_bcast31, the total sits in lane 63 and is broadcast through an SGPR.  Lanes without a DPP source keep their own value.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_keep(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false); }
+#define AC_WAVE_MIN_STEPS(STEP) STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#define STEP(C, M) { const float o = __builtin_bit_cast(float, dpp_keep<C, M>(__builtin_bit_cast(int, v))); v = o < v ? o : v; }
+    AC_WAVE_MIN_STEPS(STEP)
+#undef STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; }
-    return v;
+#define STEP(C, M) { const int o = dpp_keep<C, M>(v); v = o < v ? o : v; }
+    AC_WAVE_MIN_STEPS(STEP)
+#undef STEP
+    return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ double lane_f64(double v, int l)        // l wave-uniform
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#define STEP(C, M) { const unsigned long long b = __builtin_bit_cast(unsigned long long, v); \
+                     const unsigned lo = (unsigned)dpp_keep<C, M>((int)(unsigned)b), hi = (unsigned)dpp_keep<C, M>((int)(unsigned)(b >> 32)); \
+                     const double o = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); v = o < v ? o : v; }
+    AC_WAVE_MIN_STEPS(STEP)
+#undef STEP
+    return lane_f64(v, 63);
+}
+#undef AC_WAVE_MIN_STEPS
+__device__ __forceinline__ float lane_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
                                                                  const int32_t *__restrict__ faces, const double *__restrict__ T, uint32_t P,
@@ -438,49 +494,55 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
     // bounds of all tiles in LDS (28 KB), lane = tile in the bounding pass
     extern __shared__ __attribute__((aligned(16))) float sbox_raw[];
     float (*sbox)[MAX_TILES] = reinterpret_cast<float (*)[MAX_TILES]>(sbox_raw);
+    uint16_t *ring = reinterpret_cast<uint16_t *>(sbox_raw + NB * MAX_TILES) + (threadIdx.x >> 6) * (RING + MAX_TILES);   // this wave's candidate faces (slots)
+    uint16_t *tlist = ring + RING;                                                                                        // ... and candidate tiles
     for (int e = threadIdx.x; e < NB * MAX_TILES; e += blockDim.x) sbox_raw[e] = av.box[e];
     __syncthreads();
     const uint32_t i = wave * 64 + lane;
     const bool live = i < P;
     const uint32_t ii = live ? i : P - 1;
-    const double p[3] = { (double)pts[3 * (size_t)ii], (double)pts[3 * (size_t)ii + 1], (double)pts[3 * (size_t)ii + 2] };
+    const float pf[3] = { pts[3 * (size_t)ii], pts[3 * (size_t)ii + 1], pts[3 * (size_t)ii + 2] };
+    const double p[3] = { (double)pf[0], (double)pf[1], (double)pf[2] };
     double rbest = __builtin_inf(), rbc[3] = { 0.0, 0.0, 0.0 };
     int rbf = 0;
     const uint32_t npts = (P - wave * 64 < 64u) ? P - wave * 64 : 64u;            // wave-uniform
     for (uint32_t j = 0; j < npts; ++j) {
-        const double q[3] = { __shfl(p[0], (int)j), __shfl(p[1], (int)j), __shfl(p[2], (int)j) };
-        // 1. upper bound from the representative vertices, lower bound of every tile (kept in registers)
-        double ubl = __builtin_inf(), lb[NIT];
+        const float qf[3] = { lane_f32(pf[0], (int)j), lane_f32(pf[1], (int)j), lane_f32(pf[2], (int)j) };
+        const double q[3] = { (double)qf[0], (double)qf[1], (double)qf[2] };
+        // 1. upper bound from the representative vertices, lower bound of every tile (kept in registers).  Both are bounds, not results:
+        // fp32 with every rounding padded to the safe side (the vector fp32 rate is twice the fp64 rate, and the boxes are fp32)
+        const float padq = 4e-7f * ((__builtin_fabsf(qf[0]) + __builtin_fabsf(qf[1])) + __builtin_fabsf(qf[2]));      // >= the error of q . axis
+        float ubl = __builtin_inff(), lb[NIT];
         int tbest = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            lb[it] = __builtin_inf();
+            lb[it] = __builtin_inff();
             if ((uint32_t)it >= nit) continue;                         // wave-uniform
             const int tl = it * 64 + lane;
-            const double ex = q[0] - (double)sbox[15][tl], ey = q[1] - (double)sbox[16][tl], ez = q[2] - (double)sbox[17][tl];
-            const double u = ex * ex + ey * ey + ez * ez;
+            const float ex = qf[0] - sbox[15][tl], ey = qf[1] - sbox[16][tl], ez = qf[2] - sbox[17][tl];
+            const float u = (ex * ex + ey * ey + ez * ez) * (1.0f + 1e-6f);      // >= |q - representative vertex|^2
             if (u < ubl) { ubl = u; tbest = tl; }                      // padding tiles hold +inf
-            double l = 0.0;
+            float l = 0.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double sk = q[0] * (double)sbox[3 * k][tl] + q[1] * (double)sbox[3 * k + 1][tl] + q[2] * (double)sbox[3 * k + 2][tl];
-                const double lo = (double)sbox[9 + k][tl] - sk, hi = sk - (double)sbox[12 + k][tl];
-                double d = lo > hi ? lo : hi;
-                d = d > 0.0 ? d : 0.0;
+                const float sk = qf[0] * sbox[3 * k][tl] + qf[1] * sbox[3 * k + 1][tl] + qf[2] * sbox[3 * k + 2][tl];
+                const float lo = sbox[9 + k][tl] - sk, hi = sk - sbox[12 + k][tl];
+                float d = (lo > hi ? lo : hi) - padq;                  // the box itself is padded by its builder
+                d = d > 0.0f ? d : 0.0f;
                 l += d * d;
             }
-            lb[it] = l * (1.0 - 1e-5);                                 // axes orthonormal up to fp32 rounding; +inf for padding tiles
+            lb[it] = l * (1.0f - 1e-5f);                               // axes orthonormal up to fp32 rounding; +inf for padding tiles
         }
-        const double ub = wave_min_f64(ubl);
+        const float ub = wave_min_f32(ubl);
         // seed: the faces of the tile with the nearest representative vertex (lanes 0..31) and of the tile with the smallest lower
         // bound (lanes 32..63) are tested first; their exact distances replace the vertex distance as the bound
-        double lmin = lb[0];
+        float lmin = lb[0];
         int tlow = lane;
 #pragma unroll
         for (int it = 1; it < NIT; ++it) if (lb[it] < lmin) { lmin = lb[it]; tlow = it * 64 + lane; }
-        const double lminw = wave_min_f64(lmin);
-        const int tA = __shfl(tbest, __builtin_ctzll(__ballot(ubl == ub)));
-        const int tB = __shfl(tlow, __builtin_ctzll(__ballot(lmin == lminw)));
+        const float lminw = wave_min_f32(lmin);
+        const int tA = __builtin_amdgcn_readlane(tbest, __builtin_ctzll(__ballot(ubl == ub)));
+        const int tB = __builtin_amdgcn_readlane(tlow, __builtin_ctzll(__ballot(lmin == lminw)));
         double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
         int bid = 0x7fffffff;
         if (lane < 2 * TILE_F) {
@@ -495,46 +557,85 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
             best = ex * ex + ey * ey + ez * ez; bid = av.oid[slot]; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2];
         }
         const double seed = wave_min_f64(best);
-        const double lim = (seed < ub ? seed : ub) * (1.0 + 1e-9);
-        // 2./3. remaining candidates, two tiles per step
+        const double lim0 = (seed < (double)ub ? seed : (double)ub) * (1.0 + 1e-9);
+        // 2. the candidate tiles (box distance^2 <= bound) are listed in LDS
+        double lim = lim0;
+        uint32_t ntl = 0;                                              // wave-uniform
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if ((uint32_t)it >= nit) break;                            // wave-uniform
-            unsigned long long cand = __ballot(lb[it] <= lim);
+            unsigned long long cand = __ballot((double)lb[it] <= lim);
             if (it == (tA >> 6)) cand &= ~(1ull << (tA & 63));         // the seed tiles are done
             if (it == (tB >> 6)) cand &= ~(1ull << (tB & 63));
 #ifdef AC_ABL_NOCAND
             cand = 0;
 #endif
-#ifdef AC_COUNT_CAND
-            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 4), (unsigned long long)__builtin_popcountll(cand));
-#endif
-            while (cand) {
-                int tmine = -1;
-#pragma unroll
-                for (int gi = 0; gi < GROUPS; ++gi) {                  // the next GROUPS candidate tiles, one per group of TILE_F lanes
-                    int t = -1;
-                    if (cand) { t = __builtin_ctzll(cand); cand &= cand - 1; }
-                    if (lane / TILE_F == gi) tmine = t;
-                }
-                if (tmine >= 0) {
-                    const uint32_t slot = ((uint32_t)it * 64 + (uint32_t)tmine) * TILE_F + (uint32_t)(lane & (TILE_F - 1));
-                    const float *tp = av.tri + (size_t)slot * 9;
-                    const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
-                                 c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
-                    double cq[3];
-                    closest_pt_tri(q, a, b, c, cq);
-                    const double ex = q[0] - cq[0], ey = q[1] - cq[1], ez = q[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
-                    const int id = av.oid[slot];
-                    if (d2 < best || (d2 == best && id < bid)) { best = d2; bid = id; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2]; }
-                }
-            }
+            if ((cand >> lane) & 1ull) tlist[ntl + (uint32_t)__builtin_popcountll(cand & ((1ull << lane) - 1ull))] = (uint16_t)(it * 64 + lane);
+            ntl += (uint32_t)__builtin_popcountll(cand);
         }
+#ifdef AC_COUNT_CAND
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 4), (unsigned long long)ntl);
+#endif
+        wave_sync_lds();
+        // 3. their faces, STEPS x 2 tiles per trip (the loads of a trip are in flight together): every face is first tested against its
+        // bounding disc (a lower bound of its distance); the survivors are compacted into a ring in LDS and go through the fp64
+        // Ericson routine 64 at a time
+        uint32_t head = 0, tail = 0;                                   // wave-uniform ring positions
+        auto exact_batch = [&](uint32_t n) {
+            wave_sync_lds();
+            if ((uint32_t)lane < n) {
+                const uint32_t slot = ring[(head + (uint32_t)lane) & (RING - 1)];
+                const float *tp = av.tri + (size_t)slot * 9;
+                const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
+                             c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
+                double cq[3];
+                closest_pt_tri(q, a, b, c, cq);
+                const double ex = q[0] - cq[0], ey = q[1] - cq[1], ez = q[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
+                const int id = av.oid[slot];
+                if (d2 < best || (d2 == best && id < bid)) { best = d2; bid = id; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2]; }
+            }
+            head += n;
+            const double nb = wave_min_f64(best) * (1.0 + 1e-9);       // a better bound prunes the faces still to come
+            if (nb < lim) lim = nb;
+            wave_sync_lds();
+        };
+        for (uint32_t t0 = 0; t0 < ntl; t0 += GROUPS * STEPS) {
+            uint32_t slot[STEPS]; bool have[STEPS];
+            float4 sp[STEPS], sn[STEPS];
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) {
+                const uint32_t ti = t0 + (uint32_t)(GROUPS * u + lane / TILE_F);
+                have[u] = ti < ntl;
+                slot[u] = (uint32_t)tlist[have[u] ? ti : t0] * TILE_F + (uint32_t)(lane & (TILE_F - 1));
+                sp[u] = av.sph[2 * (size_t)slot[u]]; sn[u] = av.sph[2 * (size_t)slot[u] + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) {
+                // lower bound of the face's distance from its bounding disc (accel_tiles_kernel); every rounding is padded towards "pass"
+                const double ex = q[0] - (double)sp[u].x, ey = q[1] - (double)sp[u].y, ez = q[2] - (double)sp[u].z;
+                const double e2 = ex * ex + ey * ey + ez * ez;
+                const double apd = __builtin_fabs(ex * (double)sn[u].x + ey * (double)sn[u].y + ez * (double)sn[u].z);
+                const double err = 1e-6 * (__builtin_fabs(ex) + __builtin_fabs(ey) + __builtin_fabs(ez)) + 1e-6;      // fp32 normal and centre
+                const double pdl = apd > err ? apd - err : 0.0, pdh = apd + err;
+                const double rem = lim - pdl * pdl;                               // what is left for the in-plane distance
+                const double rho2 = e2 * (1.0 - 1e-12) - pdh * pdh;              // <= (in-plane distance of q from c)^2
+                const double rr = (double)sp[u].w + (double)(__builtin_sqrtf((float)rem) * 1.000001f) + 1e-12;
+                const bool pass = have[u] && rem >= 0.0 && rho2 <= rr * rr;
+                const unsigned long long pm = __ballot(pass);
+#ifdef AC_COUNT_CAND
+                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 6), (unsigned long long)__builtin_popcountll(pm));
+#endif
+                if (pass) ring[(tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))) & (RING - 1)] = (uint16_t)slot[u];
+                tail += (uint32_t)__builtin_popcountll(pm);
+            }
+            while (tail - head >= 64u) exact_batch(64u);
+        }
+        if (tail != head) exact_batch(tail - head);
         const double wbest = wave_min_f64(best);
         const int wid = wave_min_i32(best == wbest ? bid : 0x7fffffff);
         const unsigned long long win = __ballot(best == wbest && bid == wid);
         const int wl = __builtin_ctzll(win);
-        const double w0 = __shfl(bc[0], wl), w1 = __shfl(bc[1], wl), w2 = __shfl(bc[2], wl);
+        const double w0 = lane_f64(bc[0], wl), w1 = lane_f64(bc[1], wl), w2 = lane_f64(bc[2], wl);
         if (lane == (int)j) { rbest = wbest; rbf = wid; rbc[0] = w0; rbc[1] = w1; rbc[2] = w2; }
     }
     if (!live) return;
@@ -568,7 +669,7 @@ AC_API int ac_warp_samples(const float *pts, const float *verts, const int32_t *
 AC_API size_t ac_warp_accel_bytes(uint32_t F)
 {
     if (F == 0 || F > MAX_ACCEL_FACES) return 0;
-    size_t o[5];
+    size_t o[6];
     return accel_offsets(o);
 }
 
@@ -599,7 +700,7 @@ AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int
     }
     const AccelView av = accel_view(const_cast<void *>(accel));
     const uint32_t waves = (P + 63) / 64;
-    const size_t lds = (size_t)NB * MAX_TILES * sizeof(float);
+    const size_t lds = (size_t)NB * MAX_TILES * sizeof(float) + 4 * (RING + MAX_TILES) * sizeof(uint16_t);
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(warp_samples_accel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + 3) / 4), dim3(256), lds, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av,

@@ -42,5 +42,5 @@ if os.environ.get("COUNT"):
         L.check(L.lib().ac_warp_samples_accel(pts.data_ptr(), tv.data_ptr(), tf.data_ptr(), tT.data_ptr(), P, tv.shape[0], tf.shape[0], 0.05, acc.data_ptr(), None,
                                               can.data_ptr(), None, None, None, mask.data_ptr(), st))
         torch.cuda.synchronize()
-        cnt = int(acc[16:24].view(torch.int64)[0])
-        print("candidate tiles per sample, %s: %.2f  (mask fraction %.3f)" % (name, cnt / P, float(mask.float().mean())))
+        cnt = int(acc[16:24].view(torch.int64)[0]); cf = int(acc[24:32].view(torch.int64)[0])
+        print("candidate tiles per sample, %s: %.2f, faces through the sphere test: %.1f  (mask fraction %.3f)" % (name, cnt / P, cf / P, float(mask.float().mean())))
