@@ -233,7 +233,13 @@ constexpr int GROUPS = 64 / TILE_F; // tiles tested per exact step
 constexpr int TPB = 256 / TILE_F;   // tiles per block of the tile builder
 constexpr uint32_t MAX_ACCEL_FACES = MAX_TILES * TILE_F;     // 16384
 constexpr int NB = 18;              // floats of bounds per tile
-constexpr int STEPS = 4;            // trips of the face loop handle STEPS x GROUPS tiles
+#ifndef AC_WARP_WAVES
+#define AC_WARP_WAVES 4                // waves per SIMD the search kernel is compiled for (<= 128 VGPRs; 29.5 instead of 31.6 ms per posed frame)
+#endif
+#ifndef AC_WARP_STEPS
+#define AC_WARP_STEPS 4
+#endif
+constexpr int STEPS = AC_WARP_STEPS;            // trips of the face loop handle STEPS x GROUPS tiles
 constexpr uint32_t RING = 512;      // per-wave ring of faces that passed the disc test: < 64 left over + STEPS x 64 new ones per trip
 
 struct AccelView {                   // pointers into the caller's accel buffer
@@ -480,7 +486,7 @@ __device__ __forceinline__ double wave_min_f64(double v)
 #undef AC_WAVE_MIN_STEPS
 __device__ __forceinline__ float lane_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
-__global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
+__global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
                                                                  const int32_t *__restrict__ faces, const double *__restrict__ T, uint32_t P,
                                                                  double threshold, AccelView av, double *__restrict__ can_pts,
                                                                  float *__restrict__ can_pts_f32, double *__restrict__ closest,
@@ -493,10 +499,11 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
     const uint32_t nit = (nt + 63) >> 6;
     // bounds of all tiles in LDS (28 KB), lane = tile in the bounding pass
     extern __shared__ __attribute__((aligned(16))) float sbox_raw[];
-    float (*sbox)[MAX_TILES] = reinterpret_cast<float (*)[MAX_TILES]>(sbox_raw);
-    uint16_t *ring = reinterpret_cast<uint16_t *>(sbox_raw + NB * MAX_TILES) + (threadIdx.x >> 6) * (RING + MAX_TILES);   // this wave's candidate faces (slots)
-    uint16_t *tlist = ring + RING;                                                                                        // ... and candidate tiles
-    for (int e = threadIdx.x; e < NB * MAX_TILES; e += blockDim.x) sbox_raw[e] = av.box[e];
+    const uint32_t ntp = nit * 64;                                     // tiles rounded up to whole bounding-pass iterations: the LDS row length
+    uint16_t *ring = reinterpret_cast<uint16_t *>(sbox_raw + NB * ntp) + (threadIdx.x >> 6) * (RING + ntp);   // this wave's candidate faces (slots)
+    uint16_t *tlist = ring + RING;                                                                            // ... and candidate tiles
+    for (uint32_t e = threadIdx.x; e < NB * ntp; e += blockDim.x) sbox_raw[e] = av.box[(e / ntp) * MAX_TILES + e % ntp];
+#define SBOX(ROW, TL) sbox_raw[(ROW) * ntp + (TL)]
     __syncthreads();
     const uint32_t i = wave * 64 + lane;
     const bool live = i < P;
@@ -519,14 +526,14 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
             lb[it] = __builtin_inff();
             if ((uint32_t)it >= nit) continue;                         // wave-uniform
             const int tl = it * 64 + lane;
-            const float ex = qf[0] - sbox[15][tl], ey = qf[1] - sbox[16][tl], ez = qf[2] - sbox[17][tl];
+            const float ex = qf[0] - SBOX(15, tl), ey = qf[1] - SBOX(16, tl), ez = qf[2] - SBOX(17, tl);
             const float u = (ex * ex + ey * ey + ez * ez) * (1.0f + 1e-6f);      // >= |q - representative vertex|^2
             if (u < ubl) { ubl = u; tbest = tl; }                      // padding tiles hold +inf
             float l = 0.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float sk = qf[0] * sbox[3 * k][tl] + qf[1] * sbox[3 * k + 1][tl] + qf[2] * sbox[3 * k + 2][tl];
-                const float lo = sbox[9 + k][tl] - sk, hi = sk - sbox[12 + k][tl];
+                const float sk = qf[0] * SBOX(3 * k, tl) + qf[1] * SBOX(3 * k + 1, tl) + qf[2] * SBOX(3 * k + 2, tl);
+                const float lo = SBOX(9 + k, tl) - sk, hi = sk - SBOX(12 + k, tl);
                 float d = (lo > hi ? lo : hi) - padq;                  // the box itself is padded by its builder
                 d = d > 0.0f ? d : 0.0f;
                 l += d * d;
@@ -638,6 +645,7 @@ __global__ __launch_bounds__(256) void warp_samples_accel_kernel(const float *__
         const double w0 = lane_f64(bc[0], wl), w1 = lane_f64(bc[1], wl), w2 = lane_f64(bc[2], wl);
         if (lane == (int)j) { rbest = wbest; rbf = wid; rbc[0] = w0; rbc[1] = w1; rbc[2] = w2; }
     }
+#undef SBOX
     if (!live) return;
     finish_sample(i, p, rbc, rbest, rbf, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
 }
@@ -700,9 +708,13 @@ AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int
     }
     const AccelView av = accel_view(const_cast<void *>(accel));
     const uint32_t waves = (P + 63) / 64;
-    const size_t lds = (size_t)NB * MAX_TILES * sizeof(float) + 4 * (RING + MAX_TILES) * sizeof(uint16_t);
+    const size_t ntp = (((size_t)F + TILE_F - 1) / TILE_F + 63) / 64 * 64;        // as in the kernel: tiles rounded up to 64
+    const size_t lds = (size_t)NB * ntp * sizeof(float) + 4 * (RING + ntp) * sizeof(uint16_t);
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(warp_samples_accel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (!attr_set) {                 // the limit for the largest mesh the search supports; a launch asks for what its mesh needs
+        const size_t lds_max = (size_t)NB * MAX_TILES * sizeof(float) + 4 * (RING + MAX_TILES) * sizeof(uint16_t);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(warp_samples_accel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_set = true;
+    }
     hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + 3) / 4), dim3(256), lds, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av,
                        can_pts, can_pts_f32, closest, dist2, face_id, mask);
     return ac::check_launch("warp_samples_accel");
