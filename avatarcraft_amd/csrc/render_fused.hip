@@ -52,9 +52,6 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef AC_STAGGER      // experiment: de-phase the two waves that share a SIMD (waves w and w+4 of the workgroup)
-    if (wave >= 4) { for (int i_ = 0; i_ < AC_STAGGER; ++i_) __builtin_amdgcn_s_sleep(127); }
-#endif
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule; speed only): give every XCD a contiguous
     // slab of rays so that neighbouring pixels share one L2 instead of eight
     int bid = blockIdx.x;
@@ -247,10 +244,6 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             wave_sync();
             continue;
         }
-#ifdef AC_PINGPONG     // experiment: waves 4..7 run the gather/MLP phases one phase behind waves 0..3 (same SIMDs)
-        __builtin_amdgcn_s_barrier();
-        if (wave >= 4) __builtin_amdgcn_s_barrier();
-#endif
         float cT = 1.0f;                                        // transmittance carry (cumprod)
         float s_w = 0.0f, s_r = 0.0f, s_g = 0.0f, s_b = 0.0f, s_nx = 0.0f, s_ny = 0.0f, s_nz = 0.0f, s_d = 0.0f,
               s_en = 0.0f, s_ed = 0.0f;
@@ -273,9 +266,6 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             AC_TICK(7)
             float fe0[4][2];
             encode_stencil(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
-#ifdef AC_PINGPONG
-            __builtin_amdgcn_s_barrier();
-#endif
             AC_TICK(3)
             const float pc0 = sel4(g, px, py, pz, 0.0f);
             // 7 MLP passes, software-pipelined: layer 1 of evaluation e+1 (MFMA) is issued next to the softplus +
@@ -345,9 +335,6 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             AC_ACC(s_d, wgt * zn01)
             AC_ACC(s_en, eerr) AC_ACC(s_ed, relax)
 #undef AC_ACC
-#ifdef AC_PINGPONG
-            __builtin_amdgcn_s_barrier();
-#endif
             AC_TICK(6)
             if (g == 0) {
                 const size_t si = (size_t)ray * T + i;
@@ -359,9 +346,6 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 if (a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
             }
         }
-#ifdef AC_PINGPONG
-        if (wave < 4) __builtin_amdgcn_s_barrier();
-#endif
         if (lane == 0) {
             const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
             a.out.image[3 * ray] = s_r + (1.0f - s_w) * b0;

@@ -5,13 +5,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 csrc = os.path.join(ROOT, "avatarcraft_amd", "csrc")
-srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "warp.hip")]
+srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "hash_stencil.hip", "sdf_train.hip", "warp.hip")]
 from tests.common import load_golden, make_rays
 p = load_golden("nsr_params.npz")
 ro, rd = make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)
 variants = {"xcd_remap": [], "no_remap": ["-DAC_NO_XCD_REMAP"]} if "--xcd" in sys.argv else {"cg_wpb8": ["-DAC_ABL_GATHER"], "cg_wpb4": ["-DAC_ABL_GATHER", "-DAC_WPB=4"], "cg_wpb2": ["-DAC_ABL_GATHER", "-DAC_WPB=2"],
-            "nosp_nomfma_wpb8": ["-DAC_ABL_SOFTPLUS", "-DAC_ABL_MFMA"], "nosp_nomfma_wpb4": ["-DAC_ABL_SOFTPLUS", "-DAC_ABL_MFMA", "-DAC_WPB=4"], "nosp_nomfma_wpb2": ["-DAC_ABL_SOFTPLUS", "-DAC_ABL_MFMA", "-DAC_WPB=2"]} if "--wpb2" in sys.argv else {"baseline": [], "wpb4": ["-DAC_WPB=4"], "wpb2": ["-DAC_WPB=2"]} if "--wpb" in sys.argv else {"baseline": [], "pingpong": ["-DAC_PINGPONG"]} if "--pingpong" in sys.argv else {"baseline": [], "stagger4": ["-DAC_STAGGER=4"], "stagger8": ["-DAC_STAGGER=8"], "stagger16": ["-DAC_STAGGER=16"], "stagger32": ["-DAC_STAGGER=32"],
-            } if "--stagger" in sys.argv else {"baseline": [], "no_softplus": ["-DAC_ABL_SOFTPLUS"], "no_mfma": ["-DAC_ABL_MFMA"], "cached_gather": ["-DAC_ABL_GATHER"],
+            "nosp_nomfma_wpb8": ["-DAC_ABL_SOFTPLUS", "-DAC_ABL_MFMA"], "nosp_nomfma_wpb4": ["-DAC_ABL_SOFTPLUS", "-DAC_ABL_MFMA", "-DAC_WPB=4"], "nosp_nomfma_wpb2": ["-DAC_ABL_SOFTPLUS", "-DAC_ABL_MFMA", "-DAC_WPB=2"]} if "--wpb2" in sys.argv else {"baseline": [], "wpb4": ["-DAC_WPB=4"], "wpb2": ["-DAC_WPB=2"]} if "--wpb" in sys.argv else {"baseline": [], "no_softplus": ["-DAC_ABL_SOFTPLUS"], "no_mfma": ["-DAC_ABL_MFMA"], "cached_gather": ["-DAC_ABL_GATHER"],
             "no_softplus+no_mfma": ["-DAC_ABL_SOFTPLUS", "-DAC_ABL_MFMA"], "all_three": ["-DAC_ABL_SOFTPLUS", "-DAC_ABL_MFMA", "-DAC_ABL_GATHER"]}
 procs = {}
 for name, fl in variants.items():
