@@ -552,7 +552,11 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
         const int tB = __builtin_amdgcn_readlane(tlow, __builtin_ctzll(__ballot(lmin == lminw)));
         double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
         int bid = 0x7fffffff;
+#ifdef AC_ABL_NOSEED        // timing ablation: no exact seed test
+        if (lane > 1000) {
+#else
         if (lane < 2 * TILE_F) {
+#endif
             const int tmine = lane < TILE_F ? tA : tB;
             const uint32_t slot = (uint32_t)tmine * TILE_F + (uint32_t)(lane & (TILE_F - 1));
             const float *tp = av.tri + (size_t)slot * 9;
@@ -588,9 +592,14 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
         // bounding disc (a lower bound of its distance); the survivors are compacted into a ring in LDS and go through the fp64
         // Ericson routine 64 at a time
         uint32_t head = 0, tail = 0;                                   // wave-uniform ring positions
+        float limf = (float)lim * 1.000001f;                           // >= lim
         auto exact_batch = [&](uint32_t n) {
             wave_sync_lds();
+#ifdef AC_ABL_NOBATCH       // timing ablation: survivors of the disc test are dropped
+            if ((uint32_t)lane > 1000u) {
+#else
             if ((uint32_t)lane < n) {
+#endif
                 const uint32_t slot = ring[(head + (uint32_t)lane) & (RING - 1)];
                 const float *tp = av.tri + (size_t)slot * 9;
                 const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
             }
             head += n;
             const double nb = wave_min_f64(best) * (1.0 + 1e-9);       // a better bound prunes the faces still to come
-            if (nb < lim) lim = nb;
+            if (nb < lim) { lim = nb; limf = (float)nb * 1.000001f; }
             wave_sync_lds();
         };
         for (uint32_t t0 = 0; t0 < ntl; t0 += GROUPS * STEPS) {
@@ -618,16 +627,18 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
             }
 #pragma unroll
             for (int u = 0; u < STEPS; ++u) {
-                // lower bound of the face's distance from its bounding disc (accel_tiles_kernel); every rounding is padded towards "pass"
-                const double ex = q[0] - (double)sp[u].x, ey = q[1] - (double)sp[u].y, ez = q[2] - (double)sp[u].z;
-                const double e2 = ex * ex + ey * ey + ez * ez;
-                const double apd = __builtin_fabs(ex * (double)sn[u].x + ey * (double)sn[u].y + ez * (double)sn[u].z);
-                const double err = 1e-6 * (__builtin_fabs(ex) + __builtin_fabs(ey) + __builtin_fabs(ez)) + 1e-6;      // fp32 normal and centre
-                const double pdl = apd > err ? apd - err : 0.0, pdh = apd + err;
-                const double rem = lim - pdl * pdl;                               // what is left for the in-plane distance
-                const double rho2 = e2 * (1.0 - 1e-12) - pdh * pdh;              // <= (in-plane distance of q from c)^2
-                const double rr = (double)sp[u].w + (double)(__builtin_sqrtf((float)rem) * 1.000001f) + 1e-12;
-                const bool pass = have[u] && rem >= 0.0 && rho2 <= rr * rr;
+                // lower bound of the face's distance from its bounding disc (accel_tiles_kernel), in fp32: q, the disc and the normal are
+                // fp32 data, and every rounding below is padded towards "pass" (a face that passes wrongly only costs an exact test)
+                const float ex = qf[0] - sp[u].x, ey = qf[1] - sp[u].y, ez = qf[2] - sp[u].z;
+                const float e1 = (__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez);
+                const float e2 = (ex * ex + ey * ey) + ez * ez;
+                const float apd = __builtin_fabsf((ex * sn[u].x + ey * sn[u].y) + ez * sn[u].z);
+                const float err = 1e-6f * e1 + 1e-6f;                              // rounding of the dot product, of the stored normal and centre
+                const float pdl = apd > err ? apd - err : 0.0f, pdh = apd + err;   // plane distance of q: lower / upper bound
+                const float rem = (limf - pdl * pdl) + 1e-6f * (limf + pdl * pdl); // >= what the bound leaves for the in-plane distance^2
+                const float rho2 = (e2 - pdh * pdh) - 2e-6f * (e2 + pdh * pdh);    // <= (in-plane distance of q from the disc centre)^2
+                const float rr = (sp[u].w + __builtin_sqrtf(rem > 0.0f ? rem : 0.0f) * 1.000001f) + 1e-12f;
+                const bool pass = have[u] && rem >= 0.0f && rho2 <= rr * rr * 1.000001f;
                 const unsigned long long pm = __ballot(pass);
 #ifdef AC_COUNT_CAND
                 if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 6), (unsigned long long)__builtin_popcountll(pm));
