@@ -564,8 +564,10 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
                          c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
             double cq[3];
             closest_pt_tri(q, a, b, c, cq);
-            const double ex = q[0] - cq[0], ey = q[1] - cq[1], ez = q[2] - cq[2];
-            best = ex * ex + ey * ey + ez * ez; bid = av.oid[slot]; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2];
+            const double ex = q[0] - cq[0], ey = q[1] - cq[1], ez = q[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
+            // same acceptance rule as everywhere else: a degenerate face (two equal corners: 0 / 0 in the edge regions) yields NaN and is
+            // never accepted -- an unconditional assignment would poison this lane's running minimum for the rest of the sample
+            if (d2 < best) { best = d2; bid = av.oid[slot]; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2]; }
         }
         const double seed = wave_min_f64(best);
         const double lim0 = (seed < (double)ub ? seed : (double)ub) * (1.0 + 1e-9);

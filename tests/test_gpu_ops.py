@@ -325,6 +325,54 @@ def test_warp_accel_equals_brute_force(oracle, nlat, nlon):
     assert Lb.lib().ac_warp_accel_build(tv.data_ptr(), tf.data_ptr(), V, F, acc.data_ptr(), 100, st) != 0
 
 
+def test_warp_accel_degenerate_faces_and_far_points():
+    """the conservative fp32 bounds of the culled search (boxes, per-face bounding discs) must not lose the closest face when the
+    mesh holds zero-area and sliver triangles, and for query points far outside the mesh: culled == exhaustive, bit for bit"""
+    from avatarcraft_amd import _lib as Lb
+    from tests.common import make_body
+    verts, faces, Ts = make_body(n_lat=20, n_lon=30)
+    rs = np.random.RandomState(11)
+    V0 = verts.shape[0]
+    extra_v, extra_f = [], []
+    for k in range(40):
+        i, j = rs.randint(0, V0, 2)
+        a, b = verts[i], verts[j]
+        t = rs.uniform(0.2, 0.8)
+        mid = (a + t * (b - a) + rs.normal(0, 1e-7 if k % 2 else 1e-4, 3)).astype(np.float32)      # (nearly) on the segment a-b: a sliver
+        extra_v.append(mid)
+        extra_f.append([i, j, V0 + k])
+    for k in range(10):
+        i, j = rs.randint(0, V0, 2)
+        extra_f.append([i, i, j])                                    # zero area: two equal corners
+        extra_f.append([i, i, i])                                    # a point
+    verts2 = np.concatenate([verts, np.stack(extra_v)]).astype(np.float32)
+    faces2 = np.concatenate([faces, np.asarray(extra_f, dtype=faces.dtype)])
+    faces2 = faces2[rs.permutation(faces2.shape[0])]
+    Ts2 = np.concatenate([Ts, Ts[rs.randint(0, Ts.shape[0], len(extra_v))]])
+    P = 4096
+    pts = np.concatenate([rs.uniform(-1.6, 1.6, size=(P // 4, 3)), rs.uniform(-40.0, 40.0, size=(P // 4, 3)),
+                          verts2[rs.randint(0, verts2.shape[0], P // 2)] + rs.normal(0, 0.02, size=(P // 2, 3))]).astype(np.float32)
+    tp, tv, tf, tT = T(pts), T(verts2), torch.from_numpy(faces2).to(DEV), torch.from_numpy(Ts2).to(DEV)
+    F, V = faces2.shape[0], verts2.shape[0]
+    def outs():
+        return dict(can=torch.empty(P, 3, dtype=torch.float64, device=DEV), clo=torch.empty(P, 3, dtype=torch.float64, device=DEV),
+                    d2=torch.empty(P, dtype=torch.float64, device=DEV), fid=torch.empty(P, dtype=torch.int32, device=DEV),
+                    mask=torch.empty(P, dtype=torch.uint8, device=DEV))
+    a, b = outs(), outs()
+    Lb.check(Lb.lib().ac_warp_samples(tp.data_ptr(), tv.data_ptr(), tf.data_ptr(), tT.data_ptr(), P, V, F, 0.05, a["can"].data_ptr(), None,
+                                      a["clo"].data_ptr(), a["d2"].data_ptr(), a["fid"].data_ptr(), a["mask"].data_ptr(), None))
+    nbytes = Lb.lib().ac_warp_accel_bytes(F)
+    acc = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    Lb.check(Lb.lib().ac_warp_accel_build(tv.data_ptr(), tf.data_ptr(), V, F, acc.data_ptr(), nbytes, None))
+    Lb.check(Lb.lib().ac_warp_samples_accel(tp.data_ptr(), tv.data_ptr(), tf.data_ptr(), tT.data_ptr(), P, V, F, 0.05, acc.data_ptr(), b["can"].data_ptr(),
+                                            None, b["clo"].data_ptr(), b["d2"].data_ptr(), b["fid"].data_ptr(), b["mask"].data_ptr(), None))
+    torch.cuda.synchronize()
+    for k in ("fid", "d2", "clo", "mask"):
+        assert torch.equal(a[k], b[k]), k
+    fin = torch.isfinite(a["can"]).all(1)                            # a degenerate winner can make the blend singular: same non-finite pattern
+    assert torch.equal(fin, torch.isfinite(b["can"]).all(1)) and torch.equal(a["can"][fin], b["can"][fin])
+
+
 @pytest.mark.parametrize("P", [1, 63, 65])
 def test_warp_tiny_point_sets(oracle, P):
     from avatarcraft_amd import ray_utils as RY
