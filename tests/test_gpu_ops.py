@@ -431,6 +431,35 @@ def test_hash_stencil_backward_paths_agree():
     assert float((res[1] - res[0]).abs().max()) <= 1e-4 * float(res[0].abs().max())
 
 
+@pytest.mark.parametrize("L,base,log2T,pls,binned", [(4, 4, 12, 2.0, True), (8, 16, 15, 1.5, True), (6, 5, 14, 1.7, True), (3, 2, 10, 2.0, False)])
+def test_hash_backward_binned_other_grids(oracle, L, base, log2T, pls, binned):
+    """binned scatter on grids other than the default one (bucket size = a power of two that covers each level with <= 64 buckets;
+    a level of fewer than 64 entries is not binned: the operator falls back to the direct atomics)"""
+    from avatarcraft_amd import _lib as Lb
+    O = oracle
+    offs, _ = O.hash_offsets(num_levels=L, per_level_scale=pls, base_resolution=base, log2_hashmap_size=log2T)
+    S = float(np.float32(np.log2(pls)))
+    rs = np.random.RandomState(5)
+    B = 20011
+    x = rs.uniform(0, 1, size=(B, 3)).astype(np.float32)
+    x[:64] = rs.uniform(0.4, 0.41, size=(64, 3))                 # a cluster: long runs of lanes in one cell
+    g = rs.normal(size=(L, B, 2)).astype(np.float32)
+    xt, gt_ = T(x), T(g)
+    n = int(offs[-1])
+    emb = torch.zeros(n, 2, device=DEV)
+    ot = torch.from_numpy(offs).to(DEV)
+    dummy = torch.zeros(1, device=DEV)
+    nbytes = int(Lb.lib().ac_hash_encode_backward_scratch(offs.ctypes.data, 3, 2, L, S, base, B))
+    assert (nbytes > 0) == binned
+    sc = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=DEV)
+    gg = torch.zeros_like(emb)
+    Lb.check(Lb.lib().ac_hash_encode_backward_ws(gt_.data_ptr(), xt.data_ptr(), emb.data_ptr(), ot.data_ptr(), offs.ctypes.data, gg.data_ptr(), B, 3, 2, L,
+                                                 S, base, 0, dummy.data_ptr(), dummy.data_ptr(), sc.data_ptr(), nbytes, None))
+    torch.cuda.synchronize()
+    gg_o, _ = O.hash_encode_backward(g, x, np.zeros((n, 2), np.float32), offs, S, base, None)
+    assert np.abs(gg.cpu().numpy() - gg_o).max() <= 2e-5 * np.abs(gg_o).max()
+
+
 def test_hash_backward_binned_equals_direct(oracle):
     """the reference operator's backward through the binned scatter (ac_hash_encode_backward_ws) against the direct float atomics and
     the oracle, default 16-level grid"""
