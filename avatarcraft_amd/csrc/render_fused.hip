@@ -201,7 +201,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             wave_sync();
             AC_TICK(2)
-            // stable merge == torch.sort(cat([z, znew])) :466-473
+            // stable merge == torch.sort(cat([z, znew])) :466-473.  The old z are sorted except in the first iteration of a ray whose slab
+            // test gave far < near (it misses the cube: its coarse z run from near DOWN to far): there the old elements are ranked too
+            const bool old_sorted = !(it == 0 && span < 0.0f);         // wave-uniform
             int32_t *sidx = a.out.sort_index ? a.out.sort_index + ((size_t)ray * nup + it) * 128 : nullptr;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
@@ -211,14 +213,23 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                     int c = 0;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) c += (znl[j] < zi) ? 1 : 0;
-                    zn_[i + c] = zi; sn_[i + c] = sc[i];
-                    if (sidx) sidx[i + c] = i;
+                    int before = i;
+                    if (!old_sorted) {
+                        before = 0;
+                        for (int k = 0; k < cnt; ++k) { const float zk = zc[k]; before += ((zk < zi) || (zk == zi && k < i)) ? 1 : 0; }
+                    }
+                    zn_[before + c] = zi; sn_[before + c] = sc[i];
+                    if (sidx) sidx[before + c] = i;
                 }
                 if (sidx && i >= cnt + 16) sidx[i] = -1;
             }
             if (g == 0) {
                 int lo = 0, hi = cnt;
-                while (lo < hi) { const int md = (lo + hi) >> 1; if (zc[md] <= znew) lo = md + 1; else hi = md; }
+                if (old_sorted) {
+                    while (lo < hi) { const int md = (lo + hi) >> 1; if (zc[md] <= znew) lo = md + 1; else hi = md; }
+                } else {
+                    for (int k = 0; k < cnt; ++k) lo += (zc[k] <= znew) ? 1 : 0;
+                }
                 int c = 0;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { const float zj = znl[j]; c += ((zj < znew) || (zj == znew && j < n)) ? 1 : 0; }

@@ -501,17 +501,27 @@ static void orc_up_sample(const float o[3], const float d[3], const float *z, co
 }
 
 /* cat_z_vals' torch.sort of cat([z, znew]) (instant_nsr.py:466-467), stable: position of
- * every old / new element, and the permutation "index". */
-static void orc_merge(const float *z, int n, const float *znew, int *pos_old, int *pos_new)
+ * every old / new element, and the permutation "index".  old_sorted = 0: the coarse z of a ray whose slab test gives
+ * far < near (it misses the cube) run from near DOWN to far, so the first sort really has to sort them. */
+static void orc_merge(const float *z, int n, const float *znew, int old_sorted, int *pos_old, int *pos_new)
 {
     for (int i = 0; i < n; i++) {
         int c = 0;
         for (int j = 0; j < 16; j++) c += (znew[j] < z[i]);
-        pos_old[i] = i + c;
+        int before = i;                              /* #old elements sorted before z[i] */
+        if (!old_sorted) {
+            before = 0;
+            for (int k = 0; k < n; k++) before += (z[k] < z[i]) || (z[k] == z[i] && k < i);
+        }
+        pos_old[i] = before + c;
     }
     for (int j = 0; j < 16; j++) {
-        int lo = 0, hi = n;                          /* #old <= znew[j] (old is sorted) */
-        while (lo < hi) { int md = (lo + hi) >> 1; if (z[md] <= znew[j]) lo = md + 1; else hi = md; }
+        int lo = 0, hi = n;                          /* #old <= znew[j] */
+        if (old_sorted) {
+            while (lo < hi) { int md = (lo + hi) >> 1; if (z[md] <= znew[j]) lo = md + 1; else hi = md; }
+        } else {
+            for (int k = 0; k < n; k++) lo += (z[k] <= znew[j]);
+        }
         int c = 0;
         for (int j2 = 0; j2 < 16; j2++)
             c += (znew[j2] < znew[j]) || (znew[j2] == znew[j] && j2 < j);
@@ -601,7 +611,7 @@ static void render_one_ray(const orc_field *f, const orc_render_opts *op, const 
                 }
             }
             int pos_old[ORC_MAXT], pos_new[16];
-            orc_merge(z, n, znew, pos_old, pos_new);
+            orc_merge(z, n, znew, !(it == 0 && span < 0.0f), pos_old, pos_new);
             float z2[ORC_MAXT], s2[ORC_MAXT];
             for (int i = 0; i < n; i++) { z2[pos_old[i]] = z[i]; s2[pos_old[i]] = sdf[i]; }
             for (int j = 0; j < 16; j++) { z2[pos_new[j]] = znew[j]; s2[pos_new[j]] = last ? 0.0f : sdfnew[j]; }

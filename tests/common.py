@@ -98,3 +98,15 @@ def make_body(n_lat=40, n_lon=80, seed=3):
     Ts[:, :3, 3] = 0.03 * rs.normal(size=(verts.shape[0], 3))
     Ts = Ts @ (np.eye(4) / 0.9)
     return verts, faces, Ts
+
+
+def edge_case_rays():
+    """rays the slab test and the samplers rarely see (tests/golden/run_edge_*.npz): parallel to an axis (a zero direction component:
+    the reference divides by d + 1e-15), starting inside the cube, missing the cube (far < near: the coarse z run backwards and the
+    first torch.sort of cat_z_vals really sorts), grazing a face, pointing away, an unnormalised direction"""
+    ro = np.array([[0.0, 0.0, 1.44], [0.0, 0.0, 1.44], [0.1, -0.2, 0.3], [3.0, 3.0, 3.0], [3.0, 0.0, 0.0], [1.6, 0.2, 2.0],
+                   [0.0, 0.0, 1.44], [0.3, 1.7, 0.1], [-2.5, 0.4, 0.2], [0.0, 0.0, 1.44], [0.2, 0.1, 2.2], [1.599, 1.599, 2.5]], np.float32)
+    rd = np.array([[0.0, 0.0, -1.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 1.0, 1.0], [-1.0, 0.0, 0.0], [0.0, 0.0, -1.0],
+                   [0.0, 0.0, 1.0], [0.0, -1.0, 0.0], [1.0, 1e-9, -1e-9], [1e-4, -1e-4, -1.0], [0.0, 0.0, -3.0], [0.0, 0.0, -1.0]], np.float32)
+    nrm = np.linalg.norm(rd, axis=1, keepdims=True); nrm[10] = 1.0              # ray 10 keeps its unnormalised direction
+    return ro, (rd / nrm).astype(np.float32)

@@ -481,3 +481,19 @@ def make_dataset_ray_golden():
 
 if __name__ == "__main__":
     make_dataset_ray_golden()
+
+
+def make_edge_ray_goldens():
+    """NeRFRenderer.run on the rays of tests/common.py:edge_case_rays (axis-parallel, inside the cube, missing it, grazing a face)"""
+    from tests.common import edge_case_rays
+    net = build_reference_net()
+    ro, rd = edge_case_rays()
+    bg = np.ones((ro.shape[0], 3), np.float32)
+    for name, train in (("eval_edge", False), ("train_edge", True)):
+        c = run_case(net, ro, rd, 64, 64, train, 9, bg)
+        np.savez_compressed(os.path.join(HERE, f"run_{name}.npz"), **c)
+        print(name, "weights_sum", c["weights_sum"])
+
+
+if __name__ == "__main__":
+    make_edge_ray_goldens()

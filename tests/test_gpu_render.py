@@ -40,14 +40,14 @@ def _compare_bitwise(g, r, up):
     assert_bitwise(g["gradient_error"].reshape(1), np.float32([r["gradient_error"]]), "gradient_error")
 
 
-@pytest.mark.parametrize("name", ["eval_64_64", "train_64_64", "eval_32_32", "eval_64_0"])
+@pytest.mark.parametrize("name", ["eval_64_64", "train_64_64", "eval_32_32", "eval_64_0", "eval_edge", "train_edge"])
 def test_render_bitwise_vs_oracle_on_golden_inputs(env, name):
     gd = load_golden(f"run_{name}.npz")
     g, r = _run_both(env, gd["rays_o"], gd["rays_d"], int(gd["num_steps"]), int(gd["upsample_steps"]), gd["bg"], gd.get("noise"))
     _compare_bitwise(g, r, int(gd["upsample_steps"]))
 
 
-@pytest.mark.parametrize("name", ["eval_64_64", "train_64_64", "eval_32_32", "eval_64_0"])
+@pytest.mark.parametrize("name", ["eval_64_64", "train_64_64", "eval_32_32", "eval_64_0", "eval_edge", "train_edge"])
 def test_render_vs_reference_golden(env, name):
     """GPU output against the reference's own run() output (tests/golden/make_golden.py)."""
     gd = load_golden(f"run_{name}.npz")
@@ -85,6 +85,20 @@ def test_render_bitwise_random_rays_4096(env):
             assert_bitwise(g[k][torch.from_numpy(sel).to(d)], r[k], k)
         assert_bitwise(g["ss_inds"][torch.from_numpy(sel).to(d)], r["ss_inds"], "ss_inds")
         assert_bitwise(g["sort_index"][torch.from_numpy(sel).to(d)], r["sort_index"], "sort_index")
+
+
+def test_render_bitwise_edge_case_rays(env):
+    """rays the slab test and the samplers rarely see: parallel to an axis (a zero direction component: the reference divides by
+    d + 1e-15), starting inside the cube, missing the cube (far < near), grazing a face, pointing away, a very long direction"""
+    from tests.common import edge_case_rays
+    ro, rd = edge_case_rays()
+    rs = np.random.RandomState(3)
+    noise = rs.uniform(0, 1, (ro.shape[0], 64)).astype(np.float32)
+    for nz in (None, noise):
+        g, r = _run_both(env, ro, rd, 64, 64, None, nz)
+        _compare_bitwise(g, r, 64)
+    g, r = _run_both(env, ro, rd, 32, 16, None, None)
+    _compare_bitwise(g, r, 16)
 
 
 def test_render_rough_field_and_anneal(oracle):
