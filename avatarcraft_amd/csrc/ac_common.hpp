@@ -20,6 +20,19 @@ inline int check_launch(const char *what)
     return AC_OK;
 }
 
+// Kernels that need more than 64 KB of dynamic LDS have to be told so once per DEVICE (a process may drive several GPUs):
+// `static uint64_t seen = 0; ac::allow_dynamic_lds(seen, kernel, bytes);` before the launch.  A race between two host threads
+// only repeats the (idempotent) call.
+inline void allow_dynamic_lds(uint64_t &seen_devices, const void *kernel, size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (seen_devices & bit) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    seen_devices |= bit;
+}
+
 // Per-level launch constants of the multiresolution hash grid (hashencoder.cu:121-123 and
 // get_grid_index :54-70), computed once on the host so that CPU oracle and GPU see the same
 // fp32 scale (level 15 of the default model sits exactly on scale = 2047).

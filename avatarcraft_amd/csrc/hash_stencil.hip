@@ -728,13 +728,10 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
                            fine_mask, priv, sc.n_priv, sc.entries, n_copies, direct_mask);
     if (sc.n_binned) {
         hipMemsetAsync(qcount, 0, (size_t)sc.n_binned * (NBUCKET + 1) * 4, st);
-        static bool attr_set = false;
+        static uint64_t seen1 = 0, seen2 = 0;
         const size_t lds1 = (size_t)4 * (3 * RCAP + 2 * NBUCKET) * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 16;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(hash_stencil_bwd_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-            hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            attr_set = true;
-        }
+        ac::allow_dynamic_lds(seen1, reinterpret_cast<const void *>(hash_stencil_bwd_binned_kernel), lds1);
+        ac::allow_dynamic_lds(seen2, reinterpret_cast<const void *>(bucket_accumulate_kernel), lds2);
         uint32_t gx = ((B + 63) / 64 + 3) / 4;
         if (gx > 256) gx = 256;                          // persistent waves: full record buffers per flush
         hipLaunchKernelGGL(hash_stencil_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, x, grad_embeddings, B, lt, eps, bound,
@@ -783,13 +780,10 @@ AC_API int ac_hash_encode_backward_ws(const float *grad, const float *inputs, co
     uint32_t *qcount = reinterpret_cast<uint32_t *>(sb + sc.qcount_off);
     Rec *queues = reinterpret_cast<Rec *>(sb + sc.queue_off);
     hipMemsetAsync(qcount, 0, (size_t)sc.n_binned * (NBUCKET + 1) * 4, st);
-    static bool attr_set = false;
+    static uint64_t seen1 = 0, seen2 = 0;
     const size_t lds1 = (size_t)4 * (3 * RCAP + 2 * NBUCKET) * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 16;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(hash_bwd_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        attr_set = true;
-    }
+    ac::allow_dynamic_lds(seen1, reinterpret_cast<const void *>(hash_bwd_binned_kernel), lds1);
+    ac::allow_dynamic_lds(seen2, reinterpret_cast<const void *>(bucket_accumulate_kernel), lds2);
     uint32_t gx = ((B + 63) / 64 + 3) / 4;
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(hash_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, inputs, grad_embeddings, B, lt, sc.binned_mask, qcount,

@@ -499,12 +499,9 @@ template <int MODE>
 static void launch_render(const RenderArgs &a, hipStream_t stream)
 {
     const int blocks = (a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    static bool attr_set = false;
+    static uint64_t seen = 0;                       // one flag per instantiation
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(render_rays_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-    }
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(render_rays_kernel<MODE>), lds_bytes);
     hipLaunchKernelGGL(render_rays_kernel<MODE>, dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
 }
 

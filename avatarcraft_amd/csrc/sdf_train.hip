@@ -724,8 +724,8 @@ AC_API int ac_sdf_stencil_forward(const ac_field *field, const float *x, uint32_
     RenderArgs a{};
     if (int rc = prep_args(a, field, bound, eps)) return rc;
     const size_t lds_bytes = FWD_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_stencil_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    static uint64_t seen = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(sdf_stencil_fwd_kernel), lds_bytes);
     uint32_t blocks = ((B + 15) / 16 + TW - 1) / TW;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sdf_stencil_fwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, B, eps, out16, grad);
@@ -748,8 +748,8 @@ AC_API int ac_sdf_stencil_backward(const ac_field *field, const float *x, const 
     RenderArgs a{};
     if (int rc = prep_args(a, field, bound, eps)) return rc;
     const size_t lds_bytes = BWD_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_stencil_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    static uint64_t seen = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(sdf_stencil_bwd_kernel), lds_bytes);
     const uint32_t blocks = train_grid(B);
     hipLaunchKernelGGL(sdf_stencil_bwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
                        static_cast<float *>(scratch));
@@ -787,8 +787,8 @@ AC_API int ac_color_backward(const ac_field *field, const float *x, const float 
     RenderArgs a{};
     if (int rc = prep_color_args(a, field)) return rc;
     const size_t lds_bytes = CBWD_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(color_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_set = true; }
+    static uint64_t seen = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(color_bwd_kernel), lds_bytes);
     const uint32_t blocks = train_grid(B);
     hipLaunchKernelGGL(color_bwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, normal, sdf16, g_rgb, B, g_normal, g_sdf16,
                        static_cast<float *>(scratch));

@@ -702,9 +702,9 @@ AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_
     if (need == 0) { ac::set_error("warp_accel_build: %u faces not supported (1..%u); use ac_warp_samples", F, MAX_ACCEL_FACES); return AC_ERR_BAD_ARG; }
     if (!verts || !faces || !accel || accel_bytes < need) { ac::set_error("warp_accel_build: NULL buffer or accel buffer smaller than %zu bytes", need); return AC_ERR_BAD_ARG; }
     const AccelView av = accel_view(accel);
-    static bool attr_set = false;
+    static uint64_t seen = 0;
     const size_t lds = (size_t)MAX_ACCEL_FACES * 8;
-    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(accel_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(accel_sort_kernel), lds);
     hipLaunchKernelGGL(accel_sort_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, verts, faces, F, av.sorted);
     hipLaunchKernelGGL(accel_tiles_kernel, dim3(MAX_TILES / TPB), dim3(256), 0, (hipStream_t)stream, verts, faces, F, av);
     return ac::check_launch("warp_accel_build");
@@ -723,11 +723,8 @@ AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int
     const uint32_t waves = (P + 63) / 64;
     const size_t ntp = (((size_t)F + TILE_F - 1) / TILE_F + 63) / 64 * 64;        // as in the kernel: tiles rounded up to 64
     const size_t lds = (size_t)NB * ntp * sizeof(float) + 4 * (RING + ntp) * sizeof(uint16_t);
-    static bool attr_set = false;
-    if (!attr_set) {                 // the limit for the largest mesh the search supports; a launch asks for what its mesh needs
-        const size_t lds_max = (size_t)NB * MAX_TILES * sizeof(float) + 4 * (RING + MAX_TILES) * sizeof(uint16_t);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(warp_samples_accel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_set = true;
-    }
+    static uint64_t seen = 0;        // the limit for the largest mesh the search supports; a launch asks for what its mesh needs
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(warp_samples_accel_kernel), (size_t)NB * MAX_TILES * sizeof(float) + 4 * (RING + MAX_TILES) * sizeof(uint16_t));
     hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + 3) / 4), dim3(256), lds, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av,
                        can_pts, can_pts_f32, closest, dist2, face_id, mask);
     return ac::check_launch("warp_samples_accel");
