@@ -70,7 +70,7 @@ def cpu_baseline(p, table, ro, rd, budget_s=12.0):
 def time_sds_step(dev, p, table, rank, world, dist, steps):
     """secondary metric: ms per 4096-ray SDS step (stylize.py coarse stage: 64x64 sub-sampled view of a 256x256 camera,
     3 renders + 3 backward passes per patch, Adam, all-reduce of the 49 MB flat gradient when world > 1).  Synthetic guidance
-    (the SD UNet is out of scope); differentiable render core currently on autograd over the HIP hash encoder."""
+    (the SD UNet is out of scope); the differentiable render core runs on the fused HIP training operators."""
     from avatarcraft_amd.instant_nsr import NeRFNetwork
     from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view
     from tests.common import make_rays
@@ -145,8 +145,8 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sds-steps", type=int, default=3, help="also time this many 4096-ray SDS steps (secondary metric); 0 = skip")
-    ap.add_argument("--posed-frames", type=int, default=2, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
+    ap.add_argument("--sds-steps", type=int, default=8, help="also time this many 4096-ray SDS steps (secondary metric); 0 = skip")
+    ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
