@@ -33,6 +33,14 @@ inline void allow_dynamic_lds(uint64_t &seen_devices, const void *kernel, size_t
     seen_devices |= bit;
 }
 
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+inline uint32_t cu_count()
+{
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return (uint32_t)n;
+}
+
 // Per-level launch constants of the multiresolution hash grid (hashencoder.cu:121-123 and
 // get_grid_index :54-70), computed once on the host so that CPU oracle and GPU see the same
 // fp32 scale (level 15 of the default model sits exactly on scale = 2047).

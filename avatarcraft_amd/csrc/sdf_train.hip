@@ -20,8 +20,10 @@
 
 namespace {
 
-constexpr int TW = 4;                              // waves per workgroup
+constexpr int TW = 4;                              // waves per workgroup of the backward kernels (296 / 284 VGPRs: one wave per SIMD)
 constexpr int TBLOCK = TW * 64;
+constexpr int FW = 8;                              // waves per workgroup of the forward SDF query (224 VGPRs: two waves per SIMD, like the renderer)
+constexpr int FBLOCK = FW * 64;
 constexpr int TLD = 17;                            // padded leading dimension of the transpose slabs
 constexpr int OFF_W2T = OFF_WAVE;                  // [4 tiles][4 ksteps][64]   A fragments of W2^T
 constexpr int OFF_W1T = OFF_W2T + 16 * 64;         // [2 tiles][16 ksteps][64]  A fragments of W1^T (feature rows)
@@ -31,7 +33,8 @@ constexpr int TS_TA = TS_T2 + 16 * TLD;            // a   [64][TLD]
 constexpr int TS_TD = TS_TA + 64 * TLD;            // d1  [64][TLD]
 constexpr int TS_TI = TS_TD + 64 * TLD;            // inp [48][TLD]  rows 0..34 inputs, 35 = 1 (bias column), 36..47 = 0
 constexpr int TRAIN_SLAB = ((TS_TI + 48 * TLD + 3) / 4) * 4;
-constexpr int FWD_LDS_FLOATS = OFF_WAVE + TW * FE_SLAB;
+constexpr int FWD_LDS_FLOATS = OFF_WAVE + FW * FE_SLAB;
+static_assert(FWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 constexpr int BWD_LDS_FLOATS = OFF_TW + TW * TRAIN_SLAB;
 static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 constexpr int NPART = 64 * 36 + 16 * 64 + 16;      // dW1 [64][36] (column 35 = db1), dW2 [16][64], db2 [16]
@@ -86,7 +89,7 @@ __device__ __forceinline__ void fd_forward(const float *__restrict__ lds, const 
     }
 }
 
-__global__ __launch_bounds__(TBLOCK) void sdf_stencil_fwd_kernel(const RenderArgs a, const float *__restrict__ x, uint32_t B, float eps,
+__global__ __launch_bounds__(FBLOCK) void sdf_stencil_fwd_kernel(const RenderArgs a, const float *__restrict__ x, uint32_t B, float eps,
                                                                  float *__restrict__ out16, float *__restrict__ grad)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_fwd_kernel(const RenderArg
     float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
     const FieldCtx fc = make_ctx(a);
     const uint32_t ntiles = (B + 15) / 16;
-    for (uint32_t tile = blockIdx.x * TW + wave; tile < ntiles; tile += gridDim.x * TW) {
+    for (uint32_t tile = blockIdx.x * FW + wave; tile < ntiles; tile += gridDim.x * FW) {
         const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
         const float px = x[3 * (size_t)bb], py = x[3 * (size_t)bb + 1], pz = x[3 * (size_t)bb + 2];
         float fe0[4][2];
@@ -726,9 +729,10 @@ AC_API int ac_sdf_stencil_forward(const ac_field *field, const float *x, uint32_
     const size_t lds_bytes = FWD_LDS_FLOATS * sizeof(float);
     static uint64_t seen = 0;
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(sdf_stencil_fwd_kernel), lds_bytes);
-    uint32_t blocks = ((B + 15) / 16 + TW - 1) / TW;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sdf_stencil_fwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, B, eps, out16, grad);
+    uint32_t blocks = ((B + 15) / 16 + FW - 1) / FW;              // persistent: the 140 KB of LDS allow one workgroup per CU, and every
+    const uint32_t cus = ac::cu_count();                          // workgroup first lays the weights out in LDS
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(sdf_stencil_fwd_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, x, B, eps, out16, grad);
     return ac::check_launch("sdf_stencil_forward");
 }
 
@@ -766,7 +770,8 @@ AC_API int ac_color_forward(const ac_field *field, const float *x, const float *
     if (int rc = prep_color_args(a, field)) return rc;
     const size_t lds_bytes = OFF_WAVE * sizeof(float);
     uint32_t blocks = ((B + 15) / 16 + TW - 1) / TW;
-    if (blocks > 2048) blocks = 2048;
+    const uint32_t resident = 3 * ac::cu_count();                 // 41 KB of LDS per workgroup: three per CU, persistent
+    if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL(color_fwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, normal, sdf16, B, rgb);
     return ac::check_launch("color_forward");
 }
