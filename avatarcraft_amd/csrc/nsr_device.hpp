@@ -303,6 +303,44 @@ __device__ __forceinline__ f32x4 sdf_l2(const float *__restrict__ lds, int lane,
     return o2;
 }
 
+// Layer 2 for an evaluation whose only consumer is the sdf value (the six finite-difference points of a sample): output row 0 as
+// a dot product on the vector pipe instead of 16 MFMA that would also produce the 15 unused feature rows (fp32 MFMA and fp32
+// VALU share the datapath: 16 x 32 clocks against ~20 x 4).  Every lane sums its own 16 hidden units (16t + 4g + r: t outer, r inner),
+// the four lane groups are joined as ((p0 + p1) + (p2 + p3)) + b2[0]; all lanes of a sample receive the same bits.
+// oracle/ac_oracle.c: orc_sdf_mlp_sdf.
+struct W2Row0 { float w[4][4]; };
+__device__ __forceinline__ W2Row0 load_w2_row0(const float *__restrict__ lds, int lane)
+{
+    W2Row0 r;                                         // fragment (4t + r) holds W2[l & 15][16t + 4(l >> 4) + r]: row 0 sits in lane 16 g
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r.w[t][q] = lds[OFF_W2F + (4 * t + q) * 64 + (lane & 48)];
+    return r;
+}
+__device__ __forceinline__ float sdf_l2_sdf(const float *__restrict__ lds, const Acc4 &acc, const W2Row0 &w0)
+{
+    float p = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#ifdef AC_ABL_SOFTPLUS
+            const float h = acc.a[t][r] * 0.5f;
+#else
+            const float h = dv_softplus100(lds + OFF_SPQ, acc.a[t][r]);
+#endif
+            p = fma_(w0.w[t][r], h, p);
+        }
+    const float other = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, p), (0x10 << 10) | 0x1f));   // lane ^ 16
+    // v_permlane32_swap exchanges lanes 32..63 of its first register with lanes 0..31 of its second: with s1 in both, the first ends up
+    // holding the lower-half sums in both halves and the second the upper-half sums.  (Inline assembly: the builtin of this compiler
+    // returns the first register for both results.  The s_nop covers the VALU write -> permlane read wait states.)
+    int lo = __builtin_bit_cast(int, p + other), hi = lo;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    return (__builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi)) + lds[OFF_B2];
+}
+
 __device__ __forceinline__ f32x4 sdf_mlp(const float *__restrict__ lds, int lane, float bxyz, const float (&f)[4][2])
 {
     const Acc4 acc = sdf_l1(lds, lane, bxyz, f);

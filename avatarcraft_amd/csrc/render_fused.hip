@@ -45,6 +45,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     float *znl = cdf + MAXT;                            // znew[16]
     float *fsl = znl + 32;                              // features of the finite-difference points [6][8][64]
     const FieldCtx fc = make_ctx(a);
+    const W2Row0 w2r0 = load_w2_row0(lds, lane);
     const float bound = a.bound;
     const int T0 = a.T0, nup = a.nup, T = T0 + 16 * nup;
 
@@ -287,27 +288,30 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             Acc4 acc = sdf_l1(lds, lane, pc0, fe0);
 #pragma unroll 1
             for (int e = 0; e < 7; ++e) {
-                const int en = e < 6 ? e + 1 : 6;                  // next evaluation (the last iteration recomputes #6: discarded)
-                const int kn = (en - 1) >> 1;
-                float fe[4][2];
+                Acc4 accn = acc;
+                if (e < 6) {                                       // layer 1 of the next evaluation
+                    const int kn = e >> 1;
+                    float fe[4][2];
 #pragma unroll
-                for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[((en - 1) * 8 + q_) * 64 + lane];
-                const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
-                const float poff = clampf(pk + (((en - 1) & 1) ? -bxe : bxe), -bound, bound);
-                const Acc4 accn = sdf_l1(lds, lane, g == kn ? poff : pc0, fe);
-                const f32x4 o = sdf_l2(lds, lane, acc);
-                acc = accn;
-                const int k = (e - 1) >> 1;
-                if (e == 0) oc = o;
-                else if (e & 1) spos = o[0];
-                else {
-                    const float gk = 0.5f * (spos - o[0]) / bxe;
-                    if (k == 0) gr[0] = gk; else if (k == 1) gr[1] = gk; else gr[2] = gk;
+                    for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[(e * 8 + q_) * 64 + lane];
+                    const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
+                    const float poff = clampf(pk + ((e & 1) ? -bxe : bxe), -bound, bound);
+                    accn = sdf_l1(lds, lane, g == kn ? poff : pc0, fe);
                 }
+                if (e == 0) oc = sdf_l2(lds, lane, acc);           // the centre needs all 16 outputs
+                else {                                             // the six offset points only their sdf
+                    const float s_e = sdf_l2_sdf(lds, acc, w2r0);
+                    const int k = (e - 1) >> 1;
+                    if (e & 1) spos = s_e;
+                    else {
+                        const float gk = 0.5f * (spos - s_e) / bxe;
+                        if (k == 0) gr[0] = gk; else if (k == 1) gr[1] = gk; else gr[2] = gk;
+                    }
+                }
+                acc = accn;
             }
             AC_TICK(4)
-            // lanes g==0 hold the sdf-based values; broadcast the gradient to the other groups
-            const float gx = __shfl(gr[0], n), gy = __shfl(gr[1], n), gz = __shfl(gr[2], n);
+            const float gx = gr[0], gy = gr[1], gz = gr[2];        // every lane of a sample holds the same finite-difference gradient
             const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
             const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
             float rgb[3];

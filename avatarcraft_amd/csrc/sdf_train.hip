@@ -57,7 +57,7 @@ __device__ __forceinline__ void softplus100_vg(const float *__restrict__ spg, fl
     der = (pos ? 1.0f : 0.0f) + (pos ? 100.0f : -100.0f) * dq;
 }
 
-// the 7 evaluations of one tile: centre outputs (o = 4g + r) and the finite-difference gradient (valid in the lanes g == 0)
+// the 7 evaluations of one tile: centre outputs (o = 4g + r) and the finite-difference gradient (the same in all four lanes of a sample)
 __device__ __forceinline__ void fd_forward(const float *__restrict__ lds, const float *__restrict__ fsl, int lane, float px, float py, float pz,
                                            float eps, float bound, const float (&fe0)[4][2], f32x4 &oc, float (&gr)[3])
 {
@@ -66,26 +66,31 @@ __device__ __forceinline__ void fd_forward(const float *__restrict__ lds, const 
     oc = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     gr[0] = gr[1] = gr[2] = 0.0f;
     float spos = 0.0f;
+    const W2Row0 w2r0 = load_w2_row0(lds, lane);
     Acc4 acc = sdf_l1(lds, lane, pc0, fe0);
 #pragma unroll 1
     for (int e = 0; e < 7; ++e) {
-        const int en = e < 6 ? e + 1 : 6;
-        const int kn = (en - 1) >> 1;
-        float fe[4][2];
+        Acc4 accn = acc;
+        if (e < 6) {                                               // layer 1 of the next evaluation
+            const int kn = e >> 1;
+            float fe[4][2];
 #pragma unroll
-        for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[((en - 1) * 8 + q_) * 64 + lane];
-        const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
-        const float poff = clampf(pk + (((en - 1) & 1) ? -eps : eps), -bound, bound);
-        const Acc4 accn = sdf_l1(lds, lane, g == kn ? poff : pc0, fe);
-        const f32x4 o = sdf_l2(lds, lane, acc);
-        acc = accn;
-        const int k = (e - 1) >> 1;
-        if (e == 0) oc = o;
-        else if (e & 1) spos = o[0];
-        else {
-            const float gk = 0.5f * (spos - o[0]) / eps;
-            if (k == 0) gr[0] = gk; else if (k == 1) gr[1] = gk; else gr[2] = gk;
+            for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[(e * 8 + q_) * 64 + lane];
+            const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
+            const float poff = clampf(pk + ((e & 1) ? -eps : eps), -bound, bound);
+            accn = sdf_l1(lds, lane, g == kn ? poff : pc0, fe);
         }
+        if (e == 0) oc = sdf_l2(lds, lane, acc);                   // the centre: all 16 outputs
+        else {                                                     // the six offset points: the sdf alone (same arithmetic as the renderer)
+            const float s_e = sdf_l2_sdf(lds, acc, w2r0);
+            const int k = (e - 1) >> 1;
+            if (e & 1) spos = s_e;
+            else {
+                const float gk = 0.5f * (spos - s_e) / eps;
+                if (k == 0) gr[0] = gk; else if (k == 1) gr[1] = gk; else gr[2] = gk;
+            }
+        }
+        acc = accn;
     }
 }
 

@@ -296,9 +296,8 @@ static void field_encode(const orc_field *f, const float x[3], float bound, floa
  *   layer 1: acc=b1[u]; k-step 0 feeds (x,y,z,0); k-steps 1..8 feed, for g=0..3,
  *            the feature (level 4*((s-1)>>1)+g, channel (s-1)&1);
  *   layer 2: acc=b2[o]; for t=0..3, r=0..3, g=0..3: hidden unit 16t+4g+r. */
-static void orc_sdf_mlp(const orc_field *f, const float x[3], const float enc[32], float out[16])
+static void orc_sdf_hidden(const orc_field *f, const float x[3], const float enc[32], float hid[64])
 {
-    float hid[64];
     for (int u = 0; u < 64; u++) {
         const float *w = f->W1 + u * 35;
         float acc = f->b1[u];
@@ -313,6 +312,12 @@ static void orc_sdf_mlp(const orc_field *f, const float x[3], const float enc[32
             }
         hid[u] = orc_softplus100(acc);
     }
+}
+
+static void orc_sdf_mlp(const orc_field *f, const float x[3], const float enc[32], float out[16])
+{
+    float hid[64];
+    orc_sdf_hidden(f, x, enc, hid);
     for (int o = 0; o < 16; o++) {
         const float *w = f->W2 + o * 64;
         float acc = f->b2[o];
@@ -326,11 +331,36 @@ static void orc_sdf_mlp(const orc_field *f, const float x[3], const float enc[32
     }
 }
 
+/* The sdf value alone (output row 0), as the fused renderer evaluates the six finite-difference points of a sample (only their sdf is
+ * used, instant_nsr.py:687-704): four partial dot products over the hidden units 16t + 4g + r of lane group g (t outer, r inner),
+ * joined as ((p0 + p1) + (p2 + p3)) + b2[0] -- a different summation order than orc_sdf_mlp's out[0], equal to it up to rounding. */
+static float orc_sdf_mlp_sdf(const orc_field *f, const float x[3], const float enc[32])
+{
+    float hid[64], p[4];
+    orc_sdf_hidden(f, x, enc, hid);
+    for (int g = 0; g < 4; g++) {
+        float acc = 0.0f;
+        for (int t = 0; t < 4; t++)
+            for (int r = 0; r < 4; r++) {
+                int u = 16 * t + 4 * g + r;
+                acc = fmaf(f->W2[u], hid[u], acc);
+            }
+        p[g] = acc;
+    }
+    return ((p[0] + p[1]) + (p[2] + p[3])) + f->b2[0];
+}
+
 static void field_sdf(const orc_field *f, const float x[3], float bound, float out[16])
 {
     float enc[32];
     field_encode(f, x, bound, enc);
     orc_sdf_mlp(f, x, enc, out);
+}
+static float field_sdf_only(const orc_field *f, const float x[3], float bound)
+{
+    float enc[32];
+    field_encode(f, x, bound, enc);
+    return orc_sdf_mlp_sdf(f, x, enc);
 }
 
 /* forward_color (instant_nsr.py:644-663), use_viewdirs=False: cat[x, n, feat] (21) ->
@@ -649,12 +679,12 @@ static void render_one_ray(const orc_field *f, const orc_render_opts *op, const 
         for (int k = 0; k < 3; k++) p[k] = wc ? mpts[3 * i + k] : clampf(o[k] + d[k] * zmid, -bound, bound);
         field_sdf(f, p, bound, s16);
         for (int k = 0; k < 3; k++) {               /* FD normals :687-704 */
-            float q[3] = { p[0], p[1], p[2] }, sp[16], sn[16];
+            float q[3] = { p[0], p[1], p[2] };
             q[k] = clampf(p[k] + eps, -bound, bound);
-            field_sdf(f, q, bound, sp);
+            const float sp = field_sdf_only(f, q, bound);
             q[k] = clampf(p[k] + (-eps), -bound, bound);
-            field_sdf(f, q, bound, sn);
-            g[k] = 0.5f * (sp[0] - sn[0]) / eps;
+            const float sn = field_sdf_only(f, q, bound);
+            g[k] = 0.5f * (sp - sn) / eps;
         }
         float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
         float nn[3];
