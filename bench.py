@@ -83,7 +83,7 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
         net.load_state_dict(sd)
         return net.to(dev).train(train)
     net, net_gt = make_net(True), make_net(False)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3, fused=os.environ.get("AC_FUSED_ADAM", "1") == "1")     # one kernel for the 12.2 M parameters
     flat = flat_grad_view(net.parameters())
     guidance = SyntheticGuidance(42 + rank)
     yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
