@@ -171,6 +171,12 @@ __device__ __forceinline__ bool run_reduce(float (&v)[N], bool head, int lane)
         if (lane >= d) f |= tf;
     }
 #else
+    // every value has to be final BEFORE the first DPP read (the scheduler may otherwise sink the instruction that produces v[i + 1]
+    // between two of the inline-assembly statements, inside the hazard window): empty volatile statements pin them
+    static_assert(N % 8 == 0, "run_reduce works on multiples of 8 values");
+#pragma unroll
+    for (int c = 0; c < N; c += 8)
+        asm volatile("" : "+v"(v[c]), "+v"(v[c + 1]), "+v"(v[c + 2]), "+v"(v[c + 3]), "+v"(v[c + 4]), "+v"(v[c + 5]), "+v"(v[c + 6]), "+v"(v[c + 7]));
     run_step<N, 0x111, 0xf>(v, f);
     run_step<N, 0x112, 0xf>(v, f);
     run_step<N, 0x114, 0xf>(v, f);
