@@ -41,7 +41,12 @@ __global__ __launch_bounds__(NF_WAVES * 64) void mesh_near_far_kernel(const floa
         for (uint32_t v = wave; v < cnt; v += NF_WAVES) {
             const float x = sv[3 * v] - ox, y = sv[3 * v + 1] - oy, z = sv[3 * v + 2] - oz;
             const float z0 = (x * dx + y * dy) + z * dz_;
-            const float nrm = __builtin_sqrtf((x * x + y * y) + z * z);
+            const float s2 = (x * x + y * y) + z * z;
+            // the sphere of this vertex is missed for sure (negative radicand -> NaN -> ignored below) when the squared distance of the
+            // vertex from the ray exceeds r^2 by more than the rounding of nrm * nrm; most vertices are far from all 64 rays of the
+            // wave, and then both square roots are skipped (wave-uniform branch; the arithmetic of the kept path is unchanged)
+            if (!__any((s2 - z0 * z0) - r2 <= 1e-6f * s2 + 1e-12f)) continue;
+            const float nrm = __builtin_sqrtf(s2);
             const float dz = __builtin_sqrtf(r2 - (nrm * nrm - z0 * z0));
             const float a = z0 - dz, b = z0 + dz;
             if (a == a && a < nr) nr = a;
