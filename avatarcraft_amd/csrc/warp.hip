@@ -491,6 +491,16 @@ __device__ __forceinline__ double wave_min_f64(double v)
 #undef AC_WAVE_MIN_STEPS
 __device__ __forceinline__ float lane_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
+#ifdef AC_PROFILE_WARP         // s_memtime per phase, summed over waves: tools/warp_profile.py
+__device__ unsigned long long g_warp_prof[8];
+#define WP_T0() unsigned long long wp_t_ = __builtin_amdgcn_s_memtime(), wp_acc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define WP_TICK(S) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); wp_acc_[S] += t2_ - wp_t_; wp_t_ = t2_; }
+#define WP_END() if (lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_warp_prof[i_], wp_acc_[i_]); }
+#else
+#define WP_T0()
+#define WP_TICK(S)
+#define WP_END()
+#endif
 __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
                                                                  const int32_t *__restrict__ faces, const double *__restrict__ T, uint32_t P,
                                                                  double threshold, AccelView av, double *__restrict__ can_pts,
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
     double rbest = __builtin_inf(), rbc[3] = { 0.0, 0.0, 0.0 };
     int rbf = 0;
     const uint32_t npts = (P - wave * 64 < 64u) ? P - wave * 64 : 64u;            // wave-uniform
+    WP_T0();
     for (uint32_t j = 0; j < npts; ++j) {
         const float qf[3] = { lane_f32(pf[0], (int)j), lane_f32(pf[1], (int)j), lane_f32(pf[2], (int)j) };
         const double q[3] = { (double)qf[0], (double)qf[1], (double)qf[2] };
@@ -545,6 +556,7 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
             }
             lb[it] = l * (1.0f - 1e-5f);                               // axes orthonormal up to fp32 rounding; +inf for padding tiles
         }
+        WP_TICK(0)
         const float ub = wave_min_f32(ubl);
         // seed: the faces of the tile with the nearest representative vertex (lanes 0..31) and of the tile with the smallest lower
         // bound (lanes 32..63) are tested first; their exact distances replace the vertex distance as the bound
@@ -555,6 +567,7 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
         const float lminw = wave_min_f32(lmin);
         const int tA = __builtin_amdgcn_readlane(tbest, __builtin_ctzll(__ballot(ubl == ub)));
         const int tB = __builtin_amdgcn_readlane(tlow, __builtin_ctzll(__ballot(lmin == lminw)));
+        WP_TICK(1)
         double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
         int bid = 0x7fffffff;
 #ifdef AC_ABL_NOSEED        // timing ablation: no exact seed test
@@ -574,15 +587,17 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
             // never accepted -- an unconditional assignment would poison this lane's running minimum for the rest of the sample
             if (d2 < best) { best = d2; bid = av.oid[slot]; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2]; }
         }
+        WP_TICK(2)
         const double seed = wave_min_f64(best);
         const double lim0 = (seed < (double)ub ? seed : (double)ub) * (1.0 + 1e-9);
         // 2. the candidate tiles (box distance^2 <= bound) are listed in LDS
         double lim = lim0;
+        const float lim0f = (float)lim0 * 1.000001f;                   // >= lim0
         uint32_t ntl = 0;                                              // wave-uniform
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if ((uint32_t)it >= nit) break;                            // wave-uniform
-            unsigned long long cand = __ballot((double)lb[it] <= lim);
+            unsigned long long cand = __ballot(lb[it] <= lim0f);           // fp32 compare against the bound rounded up: a superset
             if (it == (tA >> 6)) cand &= ~(1ull << (tA & 63));         // the seed tiles are done
             if (it == (tB >> 6)) cand &= ~(1ull << (tB & 63));
 #ifdef AC_ABL_NOCAND
@@ -595,6 +610,7 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
         if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 4), (unsigned long long)ntl);
 #endif
         wave_sync_lds();
+        WP_TICK(3)
         // 3. their faces, STEPS x 2 tiles per trip (the loads of a trip are in flight together): every face is first tested against its
         // bounding disc (a lower bound of its distance); the survivors are compacted into a ring in LDS and go through the fp64
         // Ericson routine 64 at a time
@@ -653,22 +669,38 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
                 if (pass) ring[(tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))) & (RING - 1)] = (uint16_t)slot[u];
                 tail += (uint32_t)__builtin_popcountll(pm);
             }
+            WP_TICK(4)
             while (tail - head >= 64u) exact_batch(64u);
+            WP_TICK(5)
         }
+        WP_TICK(4)
         if (tail != head) exact_batch(tail - head);
+        WP_TICK(5)
         const double wbest = wave_min_f64(best);
         const int wid = wave_min_i32(best == wbest ? bid : 0x7fffffff);
         const unsigned long long win = __ballot(best == wbest && bid == wid);
         const int wl = __builtin_ctzll(win);
         const double w0 = lane_f64(bc[0], wl), w1 = lane_f64(bc[1], wl), w2 = lane_f64(bc[2], wl);
         if (lane == (int)j) { rbest = wbest; rbf = wid; rbc[0] = w0; rbc[1] = w1; rbc[2] = w2; }
+        WP_TICK(6)
     }
 #undef SBOX
     if (!live) return;
     finish_sample(i, p, rbc, rbest, rbf, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
+    WP_TICK(7)
+    WP_END()
 }
 
 }  // namespace
+
+#ifdef AC_PROFILE_WARP
+AC_API void ac_debug_warp_prof(unsigned long long *out, int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_warp_prof), sizeof(unsigned long long) * 8);
+    if (reset) { static unsigned long long z[8] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warp_prof), z, sizeof(z)); }
+}
+#endif
 
 AC_API int ac_mesh_near_far(const float *rays_o, const float *rays_d, const float *verts, uint32_t N, uint32_t V, float geo_threshold,
                             float *near, float *far, ac_stream_t stream)
