@@ -570,11 +570,7 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
         WP_TICK(1)
         double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
         int bid = 0x7fffffff;
-#ifdef AC_ABL_NOSEED        // timing ablation: no exact seed test
-        if (lane > 1000) {
-#else
         if (lane < 2 * TILE_F) {
-#endif
             const int tmine = lane < TILE_F ? tA : tB;
             const uint32_t slot = (uint32_t)tmine * TILE_F + (uint32_t)(lane & (TILE_F - 1));
             const float *tp = av.tri + (size_t)slot * 9;

@@ -2,9 +2,9 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/abl_warp; mkdir -p $O
 C=$R/avatarcraft_amd/csrc
 SRC="$C/ac_capi.hip $C/hashgrid.hip $C/hash_stencil.hip $C/shencoder.hip $C/raymarching.hip $C/render_fused.hip $C/sdf_train.hip $C/warp.hip"
-V="base nocand nobatch noseed noseed_nocand count"
+V="base nocand nobatch count"
 for v in $V; do
-  fl=""; case $v in nocand) fl="-DAC_ABL_NOCAND";; nobatch) fl="-DAC_ABL_NOBATCH";; noseed) fl="-DAC_ABL_NOSEED";; noseed_nocand) fl="-DAC_ABL_NOSEED -DAC_ABL_NOCAND";; count) fl="-DAC_COUNT_CAND";; esac
+  fl=""; case $v in nocand) fl="-DAC_ABL_NOCAND";; nobatch) fl="-DAC_ABL_NOBATCH";; count) fl="-DAC_COUNT_CAND";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-result $fl -o $O/lib_$v.so $SRC > /dev/null 2>&1 &
 done
 wait
