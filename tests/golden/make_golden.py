@@ -149,7 +149,71 @@ def run_case(net, rays_o, rays_d, num_steps, upsample_steps, train, seed, bg):
                num_steps=np.int32(num_steps), upsample_steps=np.int32(upsample_steps), train=np.int32(train))
     if noise is not None:
         res["noise"] = noise
+    # The oracle's own sample indices on these inputs, compared with the reference's: positions (ray, iteration, sample) of the
+    # searchsorted indices that differ (knife-edge `cdf[k] <= u` decided by the last ulp of exp: Sleef in torch CPU, ac_math in the
+    # oracle and the GPU).  Recorded so that the parity test asserts "exactly these and no others" instead of a percentage.
+    if nup:
+        from tests.common import oracle_field_from_golden
+        global _ORACLE_FIELD
+        if "_ORACLE_FIELD" not in globals():
+            _ORACLE_FIELD = O.Field(net.encoder.embeddings.detach().numpy(), net.encoder.offsets.numpy(), *[effective_weights(net)[k] for k in
+                                    ("W1", "b1", "W2", "b2", "Wc1", "Wc2", "Wc3")], float(net.encoder.per_level_scale))
+        r = O.render_rays(_ORACLE_FIELD, rays_o, rays_d, num_steps, upsample_steps, 1.6, float(net.forward_variance().item()), bg=bg, noise=noise)
+        res["oracle_ss_flips"] = np.argwhere(r["ss_inds"] != ss).astype(np.int32).reshape(-1, 3)
+    else:
+        res["oracle_ss_flips"] = np.zeros((0, 3), np.int32)
     return res
+
+
+def hash_witness_fp64(x01, table, offsets, per_level_scale, H, grad=None):
+    """Second, independent witness of the hash-grid kernel's FLOAT output (hashencoder.cu:73-220 forward, :223-308 backward),
+    written from the formulas with its own index math in numpy fp64 -- it calls nothing under oracle/.
+        scale = exp2f(l*S)*H - 1 (fp32, :122), res = ceil(scale)+1 (:123), pos = x*scale + 0.5 (:131), cell = floor(pos), frac = pos - cell,
+        corner weight = prod_d (bit_d ? frac_d : 1 - frac_d) (:141-153),
+        index = (stride <= hashmap_size for all dims ? x + y*(res+1) + z*(res+1)^2 : x*1 ^ y*2654435761 ^ z*805459861 (u32)) % hashmap_size (:35-70)
+    Only `scale` is rounded to fp32 (it decides the cell); everything else is fp64, so a result agrees with any faithful fp32 evaluation
+    to ~1e-7 relative -- and disagrees at the 1e-2 level if a corner weight or index were swapped.
+    Returns enc [B, L*C] f64 (HashEncoder.forward's layout, hashgrid.py:41) and, with grad [B, L*C], d(table) [n_entries, C] f64."""
+    x = np.asarray(x01, np.float64)
+    B, D = x.shape
+    L, C = len(offsets) - 1, table.shape[1]
+    tab = np.asarray(table, np.float64)
+    S = np.float32(np.log2(per_level_scale))                       # hashgrid.py:27 -> `const float S`
+    enc = np.zeros((B, L * C), np.float64)
+    gtab = np.zeros_like(tab) if grad is not None else None
+    inside = ((x >= 0) & (x <= 1)).all(1)                          # :95-119 out-of-range input -> zeros
+    primes = (np.uint32(1), np.uint32(2654435761), np.uint32(805459861))
+    for l in range(L):
+        size = int(offsets[l + 1]) - int(offsets[l])
+        scale = np.float32(np.float32(2.0 ** float(np.float32(l) * S)) * np.float32(H)) - np.float32(1.0)
+        res = int(np.ceil(scale)) + 1
+        pos = x * float(scale) + 0.5
+        cell = np.floor(pos)
+        frac = pos - cell
+        cell = cell.astype(np.int64)
+        dense = (res + 1) ** D <= size                             # get_grid_index: hashed as soon as a stride exceeds the level size
+        for corner in range(1 << D):
+            w = np.ones(B, np.float64)
+            cc = np.empty((B, D), np.int64)
+            for d in range(D):
+                bit = (corner >> d) & 1
+                w *= frac[:, d] if bit else 1.0 - frac[:, d]
+                cc[:, d] = cell[:, d] + bit
+            if dense:
+                idx = np.zeros(B, np.int64); st = 1
+                for d in range(D):
+                    idx += cc[:, d] * st; st *= res + 1
+            else:
+                h = np.zeros(B, np.uint32)
+                for d in range(D):
+                    h ^= (cc[:, d].astype(np.uint64) * np.uint64(primes[d]) & np.uint64(0xffffffff)).astype(np.uint32)
+                idx = h.astype(np.int64)
+            idx = idx % size + int(offsets[l])
+            w = np.where(inside, w, 0.0)
+            enc[:, l * C:(l + 1) * C] += w[:, None] * tab[idx]
+            if gtab is not None:
+                np.add.at(gtab, idx, w[:, None] * np.asarray(grad, np.float64)[:, l * C:(l + 1) * C])
+    return enc, gtab
 
 
 def main():
@@ -219,8 +283,18 @@ def main():
         nrm = grad / (1e-5 + torch.linalg.norm(grad, ord=2, dim=-1, keepdim=True))
         col = net.forward_color(t, None, nrm, sdf[:, 1:], 1.6)
         enc = net.encoder(t, 1.6)
+    # independent fp64 witness of the hash kernel's float output (forward and table gradient), see hash_witness_fp64
+    x01 = (pts + np.float32(1.6)) / np.float32(3.2)                 # HashEncoder.forward: (x + size) / (2 size) in fp32, hashgrid.py:130
+    wgrad = np.random.RandomState(8).normal(0, 1, (pts.shape[0], 32))
+    enc_w, gtab_w = hash_witness_fp64(x01, net.encoder.embeddings.detach().numpy(), net.encoder.offsets.numpy(), net.encoder.per_level_scale, 16,
+                                      grad=wgrad)
+    nzw = np.flatnonzero(np.abs(gtab_w).sum(1))
+    pickw = np.sort(nzw[np.random.RandomState(9).choice(len(nzw), 4096, replace=False)])
+    print("hash witness: |enc - witness| max", np.abs(enc.numpy() - enc_w).max(), "table-gradient entries touched", len(nzw))
     np.savez_compressed(os.path.join(HERE, "field_points.npz"), pts=pts, sdf=sdf.numpy(), gradient=grad.numpy(),
-                        normal=nrm.numpy(), color=col.numpy(), enc=enc.numpy())
+                        normal=nrm.numpy(), color=col.numpy(), enc=enc.numpy(), enc_witness=enc_w, witness_grad=wgrad.astype(np.float32),
+                        witness_gtab_idx=pickw.astype(np.int64), witness_gtab=gtab_w[pickw], witness_gtab_nnz=np.int64(len(nzw)),
+                        witness_gtab_l1=np.float64(np.abs(gtab_w).sum()))
 
     # HashEncoder python-side facts (hashgrid.py:79-124): offsets, n_params, output_dim for a few configs
     from encoder import get_encoder

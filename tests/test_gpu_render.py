@@ -61,7 +61,7 @@ def test_render_vs_reference_golden(env, name):
     up = int(gd["upsample_steps"]) // 16
     if up:   # sample indices bit-exact on identical seeds
         from tests.test_oracle_golden import _indices_match
-        _indices_match(c("ss_inds"), gd["ss_inds"], c("sort_index")[:, :up], gd["sort_index"][:, :up])
+        _indices_match(c("ss_inds"), gd["ss_inds"], c("sort_index")[:, :up], gd["sort_index"][:, :up], gd["oracle_ss_flips"])
         assert np.abs(c("z_vals") - gd["z_vals"]).max() <= 2e-3
 
 
