@@ -153,6 +153,16 @@ class BodyModel:
             faces = g.integers(0, V, (13776, 3))
         return cls(v_template, shapedirs, posedirs, Jr, np.array(SMPL_PARENTS[:J]), W, faces)
 
+    def to(self, device):
+        """the same body with its buffers on `device` (lbs then runs there; calc_local_trans still hands numpy to the warp's uploader)"""
+        device = torch.device(device)
+        b = object.__new__(BodyModel)
+        b.__dict__.update(self.__dict__)
+        b.device = device
+        for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+            setattr(b, k, getattr(self, k).to(device))
+        return b
+
     def _args(self):
         return (self.v_template, self.shapedirs, self.posedirs, self.J_regressor, self.parents, self.lbs_weights)
 
@@ -186,6 +196,29 @@ class BodyModel:
         return (vertices[0], joints[0]) if return_joints else vertices[0]
 
     __call__ = forward
+
+
+def convert_amass(npz, sample_rate=10):
+    """AMASS sequence -> the pose array render_warp.py reads with --poseseq_path (utils/convert_amass.py:1-19): the first 63 axis-angle
+    values of every `sample_rate`-th frame (root + 20 body joints), the 3 x 3 hand values zeroed, -> [F, 24, 3] float32.  `npz` is a path
+    or an opened np.load(...) mapping with "poses" [F, >= 63]; returns (poses, betas[:10]) -- the script computes betas too but never stores them."""
+    data = np.load(npz) if isinstance(npz, (str, os.PathLike)) else npz
+    poses = np.asarray(data["poses"])[:, :63][::sample_rate]
+    betas = np.asarray(data["betas"])[:10] if "betas" in data else None
+    poses = np.concatenate([poses, np.zeros((poses.shape[0], 9), poses.dtype)], axis=1).reshape(-1, 24, 3).astype(np.float32)
+    return poses, betas
+
+
+def save_pose_sequence(path, poses):
+    """the file format of utils/convert_amass.py:16-17 / render_warp.py:28-30: a raw np.save stream (whatever the extension)"""
+    with open(path, "wb") as f:
+        np.save(f, np.asarray(poses, np.float32))
+
+
+def load_pose_sequence(path):
+    """render_warp.py:28-30; calc_local_trans indexes poses[i][None], so [F,24,3] and [F,72] both work -- flattened here to [F,72]"""
+    with open(path, "rb") as f:
+        return np.load(f).astype(np.float32).reshape(-1, 72)
 
 
 def da_pose():

@@ -571,3 +571,74 @@ def make_edge_ray_goldens():
 
 if __name__ == "__main__":
     make_edge_ray_goldens()
+
+
+# ---------------------------------------------------------------- render_warp.calc_local_trans + convert_amass
+def write_synthetic_smpl_pickle(path, seed=5):
+    """a file with the layout of the licensed SMPL_NEUTRAL.pkl (keys f, v_template, shapedirs, posedirs [V,3,207], J_regressor,
+    kintree_table [2,24], weights) holding BodyModel.synthetic(seed)'s buffers; V = 6890 and J = 24 because render_warp.py:184 hard-codes them"""
+    import pickle
+    from avatarcraft_amd.smpl import BodyModel, SMPL_PARENTS
+    bm = BodyModel.synthetic(seed=seed)
+    V = bm.v_template.shape[0]
+    kt = np.stack([np.array(SMPL_PARENTS, np.int64), np.arange(24, dtype=np.int64)])
+    kt[0, 0] = 2 ** 32 - 1                                           # the real file stores the root's parent as uint32(-1); SMPL.__init__ overwrites it
+    d = dict(f=np.asarray(bm.faces, np.uint32), v_template=bm.v_template.numpy().astype(np.float64), shapedirs=bm.shapedirs.numpy().astype(np.float64),
+             posedirs=bm.posedirs.numpy().T.reshape(V, 3, -1).astype(np.float64), J_regressor=bm.J_regressor.numpy().astype(np.float64),
+             kintree_table=kt, weights=bm.lbs_weights.numpy().astype(np.float64))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        pickle.dump(d, f, protocol=2)
+    return bm
+
+
+def make_calc_local_trans_golden():
+    """render_warp.calc_local_trans (render_warp.py:127-222) run on a synthetic SMPL_NEUTRAL.pkl written into a scratch directory (the
+    function loads 'data/smplx/smpl' relative to the working directory), for an animation and a shape interpolation; and
+    utils/convert_amass.py (a top-level script with a hard-coded path) run on a synthetic AMASS-layout .npz in the same scratch directory."""
+    import runpy
+    import tempfile
+    _prepare_render_utils()
+    for name in ("imageio", "joblib", "scipy.ndimage"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                _stub(name)
+    import render_warp as RW
+    keep = np.concatenate([np.arange(0, 6890, 53), np.arange(6890, 6914)])        # 130 vertices + the 24 joints
+    g = np.random.default_rng(21)
+    poses = (g.standard_normal((3, 72)) * 0.35).astype(np.float32)
+    poses[0] = 0.0                                                   # frame 0: the T pose (not the rest "da" pose: legs move)
+    shape_from = np.zeros((1, 10)); shape_from[0, 1] = 2.0           # render_warp.py:36-37,42-43 defaults
+    shape_to = np.zeros((1, 10)); shape_to[0, 1] = -2.0
+    cwd = os.getcwd()
+    out = dict(keep=keep.astype(np.int32), poses=poses, shape_from=shape_from, shape_to=shape_to)
+    with tempfile.TemporaryDirectory() as tmp:
+        write_synthetic_smpl_pickle(os.path.join(tmp, "data", "smplx", "smpl", "SMPL_NEUTRAL.pkl"))
+        os.chdir(tmp)
+        try:
+            wv, Ts, n = RW.calc_local_trans(render_type="animate", poses=poses, shape_from=shape_from, shape_to=shape_to, max_frames=100)   # as main() calls it
+            out["anim_world_verts"] = np.stack(wv)[:, ::53]; out["anim_Ts"] = np.stack(Ts)[:, keep]; out["anim_n"] = np.int32(n)
+            wv, Ts, n = RW.calc_local_trans(render_type="interp_shape", shape_from=shape_from, shape_to=shape_to, n_interp=4, max_frames=3)
+            out["shape_world_verts"] = np.stack(wv)[:, ::53]; out["shape_Ts"] = np.stack(Ts)[:, keep]; out["shape_n"] = np.int32(n)
+            wv, Ts, n = RW.calc_local_trans(scale=1.25, render_type="animate", poses=poses[1:2], shape_from=shape_from, shape_to=shape_to)
+            out["scaled_world_verts"] = np.stack(wv)[:, ::53]; out["scaled_Ts"] = np.stack(Ts)[:, keep]
+            # AMASS ingestion: poses [F,156] (SMPL-H), betas [16], 10x temporal sub-sampling, hands zeroed
+            os.makedirs(os.path.join(tmp, "path", "to", "amass")); os.makedirs(os.path.join(tmp, "data", "amass_processed"))
+            amass_poses = g.standard_normal((47, 156)); amass_betas = g.standard_normal(16)
+            np.savez(os.path.join(tmp, "path", "to", "amass", "*.npz"), poses=amass_poses, betas=amass_betas, trans=np.zeros((47, 3)),
+                     mocap_framerate=np.float64(120.0), gender="neutral")
+            runpy.run_path(os.path.join(REF, "utils", "convert_amass.py"), run_name="__main__")
+            with open(os.path.join(tmp, "data", "amass_processed", "amass_rope.pkl"), "rb") as f:
+                out["amass_out"] = np.load(f)
+            out["amass_poses"] = amass_poses; out["amass_betas"] = amass_betas
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "local_trans.npz"), **out)
+    print("calc_local_trans: frames", int(out["anim_n"]), int(out["shape_n"]), "Ts", out["anim_Ts"].shape, out["anim_Ts"].dtype,
+          "amass", out["amass_out"].shape, out["amass_out"].dtype)
+
+
+if __name__ == "__main__":
+    make_calc_local_trans_golden()

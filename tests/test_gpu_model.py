@@ -297,3 +297,27 @@ def test_inference_drivers():
     frames = list(DR.render_animation(net, bm, cam, poses=poses, resolution=32, max_frames=2))
     assert len(frames) == 2 and frames[0][1].shape == (32, 32, 3) and torch.isfinite(frames[1][1]).all()
     assert float((frames[0][1] - frames[1][1]).abs().max()) > 1e-3        # the pose matters
+
+
+def test_smpl_on_device_matches_reference_golden():
+    """lbs / calc_local_trans with the body model's buffers on the GPU against the reference goldens
+    (tests/golden/smpl.npz from models.smpl.lbs, local_trans.npz from render_warp.calc_local_trans), then straight into the posed renderer"""
+    from avatarcraft_amd import smpl as SM
+    from avatarcraft_amd.render_utils import render_instantnsr_naive
+    g = load_golden("smpl.npz")
+    bm = SM.BodyModel.synthetic(seed=3, n_verts=600).to(DEV)
+    T, v, dv = SM.lbs(torch.from_numpy(g["betas"]).to(DEV), torch.from_numpy(g["pose"]).to(DEV), *bm._args(), return_T=True, concat_joints=True)
+    assert T.is_cuda and np.abs(T.cpu().numpy() - g["T"]).max() < 5e-6 and np.abs(v.cpu().numpy() - g["v"]).max() < 2e-6
+    lt = load_golden("local_trans.npz")
+    bm2 = SM.BodyModel.synthetic(seed=5).to(DEV)
+    wv, Ts, n = SM.calc_local_trans(bm2, render_type="animate", poses=lt["poses"])
+    assert n == 3 and np.abs(np.stack(Ts)[:, lt["keep"]] - lt["anim_Ts"]).max() < 2e-5
+    assert np.abs(np.stack(wv)[:, ::53] - lt["anim_world_verts"]).max() < 2e-5
+    # Ts / world_verts of a frame feed the posed renderer unchanged (render_warp.py:88-106)
+    net, _ = golden_net()
+    net.eval()
+    from tests.common import make_rays
+    ro, rd = make_rays(8, 8, dist=1.8, f=6.0)
+    rgb, _, ex = render_instantnsr_naive(net, torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV), 64, requires_grad=False, render_can=False, perturb=False,
+                                         return_raw=True, verts=wv[1], faces=np.asarray(bm2.faces), Ts=Ts[1], num_steps=32, upsample_steps=32, bound=1.6)
+    assert rgb.shape == (64, 3) and torch.isfinite(rgb).all()

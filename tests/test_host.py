@@ -158,6 +158,53 @@ def test_calc_local_trans_properties():
         SM.calc_local_trans(bm, render_type="other")
 
 
+def test_calc_local_trans_matches_reference_golden(tmp_path):
+    """render_warp.calc_local_trans (render_warp.py:127-222) run by tests/golden/make_golden.py on a synthetic SMPL_NEUTRAL.pkl
+    (BodyModel.synthetic(5) in the licensed file's layout): Ts [V+24,4,4] fp64 and world_verts, animation / shape interpolation / scale"""
+    from avatarcraft_amd import smpl as SM
+    g = load_golden("local_trans.npz")
+    bm = SM.BodyModel.synthetic(seed=5)
+    keep = g["keep"]
+    for tag, kw in (("anim", dict(render_type="animate", poses=g["poses"], shape_from=g["shape_from"], shape_to=g["shape_to"])),
+                    ("shape", dict(render_type="interp_shape", shape_from=g["shape_from"], shape_to=g["shape_to"], n_interp=4, max_frames=3)),
+                    ("scaled", dict(scale=1.25, render_type="animate", poses=g["poses"][1:2]))):
+        wv, Ts, n = SM.calc_local_trans(bm, **kw)
+        if f"{tag}_n" in g:
+            assert n == int(g[f"{tag}_n"])
+        assert Ts[0].dtype == np.float64 and Ts[0].shape == (6914, 4, 4) and wv[0].dtype == np.float32 and wv[0].shape == (6890, 3)
+        assert np.abs(np.stack(Ts)[:, keep] - g[f"{tag}_Ts"]).max() < 5e-6
+        assert np.abs(np.stack(wv)[:, ::53] - g[f"{tag}_world_verts"]).max() < 5e-6
+    # the same through the pickle reader (the layout of the licensed file: posedirs [V,3,207], kintree_table, uint32(-1) root parent)
+    import pickle
+    kt = np.stack([np.array(SM.SMPL_PARENTS, np.int64), np.arange(24, dtype=np.int64)]); kt[0, 0] = 2 ** 32 - 1
+    d = dict(f=np.asarray(bm.faces, np.uint32), v_template=bm.v_template.numpy(), shapedirs=bm.shapedirs.numpy(),
+             posedirs=bm.posedirs.numpy().T.reshape(6890, 3, -1), J_regressor=bm.J_regressor.numpy(), kintree_table=kt, weights=bm.lbs_weights.numpy())
+    os.makedirs(tmp_path / "smpl")
+    with open(tmp_path / "smpl" / "SMPL_NEUTRAL.pkl", "wb") as f:
+        pickle.dump(d, f, protocol=2)
+    bm2 = SM.BodyModel.from_pickle(str(tmp_path / "smpl"))
+    wv2, Ts2, _ = SM.calc_local_trans(bm2, render_type="animate", poses=g["poses"][2:3])
+    assert np.abs(Ts2[0][keep] - g["anim_Ts"][2]).max() < 5e-6
+    with pytest.raises(FileNotFoundError):
+        SM.BodyModel.from_pickle(str(tmp_path / "nowhere"))
+
+
+def test_convert_amass_matches_reference_script(tmp_path):
+    """utils/convert_amass.py:1-19 run by make_golden.py on a synthetic AMASS-layout archive (poses [47,156], betas [16])"""
+    from avatarcraft_amd import smpl as SM
+    g = load_golden("local_trans.npz")
+    np.savez(tmp_path / "seq.npz", poses=g["amass_poses"], betas=g["amass_betas"])
+    poses, betas = SM.convert_amass(str(tmp_path / "seq.npz"))
+    assert poses.dtype == np.float32 and np.array_equal(poses, g["amass_out"])
+    assert np.array_equal(betas, g["amass_betas"][:10]) and (poses[:, 21:] == 0).all()
+    SM.save_pose_sequence(tmp_path / "seq.pkl", poses)
+    seq = SM.load_pose_sequence(tmp_path / "seq.pkl")
+    assert seq.shape == (5, 72) and np.array_equal(seq.reshape(5, 24, 3), poses)
+    bm = SM.BodyModel.synthetic(seed=5, n_verts=200)
+    wv, Ts, n = SM.calc_local_trans(bm, render_type="animate", poses=seq, max_frames=2)             # what render_warp.py --poseseq_path does next
+    assert n == 2 and Ts[1].shape == (224, 4, 4)
+
+
 # ------------------------------------------------------------------ config-1 plumbing (row a19)
 def test_vanilla_nerf_plumbing_matches_reference():
     """BASELINE config 1: 64x64 rays, 16 samples, PE(10)/PE(4), NeRF 8x256 with view directions, white background -- against the
