@@ -76,6 +76,9 @@ _stub("raymarching.backend", _backend=object())
 import models.instant_nsr as ref_nsr  # noqa: E402  (the reference)
 
 
+GT_SDF_BIAS = -0.40            # sdf_net.1.bias[0] of the frozen net_gt in the training golden (net_style: -0.45)
+
+
 def build_reference_net():
     """NeRFNetwork() with seed-0 init, then table/first-layer randomised so that all 16 levels matter
     (with the stock geometric init the hash features get zero weight)."""
@@ -257,7 +260,7 @@ def main():
                       bg_color=torch.from_numpy(bg2), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=True)
     img_grad = np.clip(np.random.RandomState(5).normal(0, 1, (ro2.shape[0], 3)), -1, 1).astype(np.float32)
     outg["rgb"][0].backward(gradient=torch.from_numpy(img_grad), retain_graph=True)
-    (outg["gradient_error"] * 0.01).backward()
+    (outg["gradient_error"] * 0.01).backward(retain_graph=True)
     gg = dict(rays_o=ro2, rays_d=rd2, bg=bg2, noise=noise_g, img_grad=img_grad, rgb=outg["rgb"][0].detach().numpy(),
               z_vals=outg["z_vals"].detach().numpy())
     for k, prm in net.named_parameters():
@@ -268,8 +271,41 @@ def main():
     pick = nz[np.random.RandomState(6).choice(len(nz), 4096, replace=False)]
     gg["emb_idx"] = pick.astype(np.int64); gg["emb_grad"] = ge[pick].copy()
     gg["emb_nnz"] = np.int64(len(nz)); gg["emb_l2"] = np.float64(np.sqrt((ge.astype(np.float64) ** 2).sum())); gg["emb_sum"] = np.float64(ge.astype(np.float64).sum())
+    # third term of the step (stylize.py:177-193): the frozen net_gt renders the same rays (eval mode: perturb has no effect,
+    # instant_nsr.py:161), opacity loss = smooth_l1(clamp(pred), clamp(gt).detach()) * 1e5, backward into the same .grad
+    import torch.nn.functional as F
+    net_gt = build_reference_net()
+    with torch.no_grad():
+        net_gt.sdf_net[1].bias[0] = GT_SDF_BIAS                    # a slightly different body, so that the opacities differ
+    net_gt.eval()
+    out_gt = net_gt.render(torch.from_numpy(ro2)[None], torch.from_numpy(rd2)[None], num_steps=64, bound=1.6, upsample_steps=64, staged=False,
+                           bg_color=torch.from_numpy(bg2), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=True)
+    opacity_pred = torch.clamp(outg["weight_sum"], 0.0, 1.0)
+    opacity_gt = torch.clamp(out_gt["weight_sum"], 0.0, 1.0).detach()
+    opacity_loss = F.smooth_l1_loss(opacity_pred, opacity_gt) * 1e5
+    opacity_loss.backward(retain_graph=False)
+    gg["opacity_loss"] = np.float64(opacity_loss.item()); gg["opacity_gt"] = opacity_gt[:, 0].numpy().copy(); gg["gt_sdf_bias"] = np.float32(GT_SDF_BIAS)
+    gg["opacity_pred"] = outg["weight_sum"][:, 0].detach().numpy().copy()
+    for k, prm in net.named_parameters():
+        if k != "encoder.embeddings":
+            gg["grad3." + k] = prm.grad.numpy().copy()
+    ge3 = net.encoder.embeddings.grad.numpy()
+    gg["emb_grad3"] = ge3[pick].copy(); gg["emb3_l2"] = np.float64(np.sqrt((ge3.astype(np.float64) ** 2).sum()))
+    # the optimizer step (stylize.py:199, :355-363): Adam(lr 5e-3) over all parameters, first step from zero moments
+    before = {k: prm.detach().clone() for k, prm in net.named_parameters()}
+    torch.optim.Adam([{"params": net.parameters(), "lr": 5e-3}]).step()
+    for k, prm in net.named_parameters():
+        d = (prm.detach() - before[k]).numpy()
+        if k == "encoder.embeddings":
+            gg["adam_delta.emb"] = d[pick].copy(); gg["adam_changed"] = np.int64((np.abs(d).sum(1) > 0).sum())
+        else:
+            gg["adam_delta." + k] = d.copy()
+    with torch.no_grad():                                          # put the parameters back: the goldens below use the same net
+        for k, prm in net.named_parameters():
+            prm.copy_(before[k])
     np.savez_compressed(os.path.join(HERE, "train_grad.npz"), **gg)
-    print("train_grad: emb nnz", len(nz), "l2", gg["emb_l2"], "variance grad", gg["grad.deviation_net.variance"])
+    print("train_grad: emb nnz", len(nz), "l2", gg["emb_l2"], "variance grad", gg["grad.deviation_net.variance"], "opacity loss", gg["opacity_loss"],
+          "emb l2 with the opacity term", gg["emb3_l2"])
     net.zero_grad()
 
     # forward_sdf / forward_color / gradient point-wise goldens (instant_nsr.py:627-704)

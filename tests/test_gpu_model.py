@@ -77,13 +77,18 @@ def test_training_gradients_match_reference_autograd():
     assert np.abs(out["rgb"][0].detach().cpu().numpy() - g["rgb"]).max() <= 1e-3
     out["rgb"][0].backward(gradient=torch.from_numpy(g["img_grad"]).to(DEV), retain_graph=True)
     (out["gradient_error"] * 0.01).backward()
+    worst = {}
     for k, prm in net.named_parameters():
         if k == "encoder.embeddings":
             continue
         ref = g["grad." + k]
         got = prm.grad.detach().cpu().numpy()
         scale = np.abs(ref).max() + 1e-12
+        worst[k] = float(np.abs(got - ref).max() / scale)
         assert np.abs(got - ref).max() <= 2e-2 * scale, (k, np.abs(got - ref).max(), scale)
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(worst, open("gpurun_out/train_grad_parity.json", "w"), indent=1)
     ge = net.encoder.embeddings.grad
     l2 = float(torch.sqrt((ge.double() ** 2).sum()))
     assert abs(l2 - float(g["emb_l2"])) <= 2e-2 * float(g["emb_l2"])
@@ -91,6 +96,57 @@ def test_training_gradients_match_reference_autograd():
     assert np.abs(sub - g["emb_grad"]).max() <= 3e-2 * np.abs(g["emb_grad"]).max()
     nnz = int((ge.abs().sum(1) > 0).sum())
     assert abs(nnz - int(g["emb_nnz"])) <= 0.01 * int(g["emb_nnz"])
+
+
+def test_sds_step_matches_reference_step():
+    """One whole optimisation step of stylize.py:143-199 against the reference's own autograd + torch.optim.Adam (train_grad.npz: grad3.* =
+    .grad after rgb.backward(image_grad), (0.01 eikonal).backward() and (1e5 smooth_l1(clamp(opacity), clamp(opacity_gt))).backward() with a
+    frozen net_gt that differs from net_style; adam_delta.* = parameter change of Adam(lr 5e-3)'s first step), through stylize.sds_step."""
+    from avatarcraft_amd.stylize import sds_step, flat_grad_view
+    g = load_golden("train_grad.npz")
+    net, p = golden_net(train=True)
+    net_gt, _ = golden_net(train=False)
+    with torch.no_grad():
+        net_gt.sdf_net[1].bias[0] = float(g["gt_sdf_bias"])
+    ro, rd = torch.from_numpy(g["rays_o"]).to(DEV), torch.from_numpy(g["rays_d"]).to(DEV)
+    n = ro.shape[0]
+    img_grad = torch.from_numpy(g["img_grad"]).to(DEV)
+    guidance = lambda img: img_grad.reshape(1, n, 1, 3).permute(0, 3, 1, 2).contiguous()        # d loss / d image, [1,3,h,w] with (h, w) = (n, 1)
+    opt = torch.optim.Adam([{"params": net.parameters(), "lr": 5e-3}])
+    flat = flat_grad_view(net.parameters())
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    orig_rand = torch.rand
+    torch.rand = lambda *a, **k: torch.from_numpy(g["noise"]).to(DEV)         # the reference's jitter (torch.rand streams differ across devices)
+    try:
+        stats = sds_step(net, net_gt, ro, rd, (n, 1), opt, guidance, batch_size=4096, w_eikonal=0.01, use_opacity=True, flat_grad=flat)
+    finally:
+        torch.rand = orig_rand
+    assert abs(float(stats["opacity"]) - float(g["opacity_loss"])) <= 2e-3 * float(g["opacity_loss"])
+    worst = {}
+    for k, prm in net.named_parameters():
+        got = prm.grad.detach().cpu().numpy()
+        if k == "encoder.embeddings":
+            ref, got = g["emb_grad3"], got[g["emb_idx"]]
+        else:
+            ref = g["grad3." + k]
+        scale = np.abs(ref).max() + 1e-12
+        worst[k] = float(np.abs(got - ref).max() / scale)
+        assert worst[k] <= 5e-3, (k, worst[k])
+        # Adam's first step is -lr * g / (|g| + 1e-8): every entry with a clear gradient moves by exactly lr against its sign
+        d = (prm.detach() - before[k]).cpu().numpy()
+        dref = g["adam_delta.emb"] if k == "encoder.embeddings" else g["adam_delta." + k]
+        if k == "encoder.embeddings":
+            d = d[g["emb_idx"]]
+        clear = np.abs(ref) > 1e-3 * scale
+        assert clear.mean() > 0.3 and np.abs(d[clear] - dref[clear]).max() <= 1e-6, k
+        assert np.abs(d - dref).max() <= 2 * 5e-3 + 1e-6
+    ge = net.encoder.embeddings.grad
+    assert abs(float(torch.sqrt((ge.double() ** 2).sum())) - float(g["emb3_l2"])) <= 2e-3 * float(g["emb3_l2"])
+    changed = int(((net.encoder.embeddings.detach() - before["encoder.embeddings"]).abs().sum(1) > 0).sum())
+    assert abs(changed - int(g["adam_changed"])) <= 0.01 * int(g["adam_changed"])
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(worst, open("gpurun_out/sds_step_parity.json", "w"), indent=1)
 
 
 def test_sds_step_updates_parameters_and_is_finite():
