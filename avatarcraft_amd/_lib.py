@@ -26,13 +26,25 @@ class ac_field(C.Structure):
 
 class ac_render_opts(C.Structure):
     _fields_ = [("n_rays", i32), ("num_steps", i32), ("upsample_steps", i32), ("bound", f32), ("inv_s", f32),
-                ("cos_anneal_ratio", f32), ("fd_eps", f32), ("perturb", i32)]
+                ("cos_anneal_ratio", f32), ("fd_eps", f32), ("perturb", i32), ("inv_s_dev", vp), ("near_m", vp), ("far_m", vp)]
 
 
 class ac_render_out(C.Structure):
     _fields_ = [("image", vp), ("weights_sum", vp), ("depth", vp), ("normal_map", vp), ("eik", vp), ("z_vals", vp),
                 ("weights", vp), ("alpha", vp), ("color", vp), ("sdf", vp), ("gradient", vp), ("ss_inds", vp),
-                ("sort_index", vp)]
+                ("sort_index", vp), ("sdf_out16", vp), ("pts", vp)]
+
+
+class ac_core_saved(C.Structure):
+    _fields_ = [("z_vals", vp), ("pts", vp), ("sdf", vp), ("sdf_out16", vp), ("gradient", vp), ("color", vp), ("eik_den", vp)]
+
+
+class ac_core_upstream(C.Structure):
+    _fields_ = [("g_image", vp), ("g_weights_sum", vp), ("g_depth", vp), ("g_normal_map", vp), ("g_eik", vp)]
+
+
+class ac_core_grads(C.Structure):
+    _fields_ = [("g_table", vp), ("g_sdf_params", vp), ("g_color_params", vp), ("g_inv_s_per_ray", vp)]
 
 
 class ac_warp_mesh(C.Structure):
@@ -60,6 +72,10 @@ _SIGS = {
     "ac_render_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_render_out), vp], C.c_int),
     "ac_sample_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_eikonal_reduce": ([vp, i32, vp, vp], C.c_int),
+    "ac_eikonal_reduce2": ([vp, i32, vp, vp], C.c_int),
+    "ac_render_core_backward_scratch": ([C.POINTER(ac_field), i32, i32], C.c_size_t),
+    "ac_render_core_backward": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, C.POINTER(ac_core_saved), C.POINTER(ac_core_upstream),
+                                 C.POINTER(ac_core_grads), vp, C.c_size_t, vp], C.c_int),
     "ac_field_sdf": ([C.POINTER(ac_field), vp, u32, f32, vp, vp], C.c_int),
     "ac_field_color": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),
     "ac_mesh_near_far": ([vp, vp, vp, u32, u32, f32, vp, vp, vp], C.c_int),
@@ -101,7 +117,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
             fn.argtypes = args
             fn.restype = res
-        if handle.ac_version() != 1:
+        if handle.ac_version() != 2:
             raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -78,6 +78,7 @@ struct RenderArgs {
     int jmode[4];          // per gather round j (levels 4j..4j+3): 0 all dense, 1 all hashed, 2 mixed
     int jfine[4];          // per round: 1 if the FD offset eps can span >= 1 cell on any of its levels
     float bound, two_bound, inv_s, car, one_m_car, eps;
+    const float *inv_s_dev;     // non-NULL: inv_s is read from device memory (ac_render_opts.inv_s_dev)
     int perturb;
     unsigned long long *prof;   // AC_PROFILE builds only: [n_waves][10]: 8 per-phase s_memtime counters, whole-wave s_memtime and s_memrealtime (100 MHz)
     // posed-space rendering (render_can=False) only: see ac_render_rays_warped

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     const FieldCtx fc = make_ctx(a);
     const W2Row0 w2r0 = load_w2_row0(lds, lane);
     const float bound = a.bound;
+    const float inv_s_core = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;     // forward_variance(): a launch constant, or one float on the device
     const int T0 = a.T0, nup = a.nup, T = T0 + 16 * nup;
 
 #ifdef AC_PROFILE
@@ -65,12 +66,10 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
         float near, far;
         cube_near_far(ox, oy, oz, dx, dy, dz, bound, near, far);
-        if constexpr (MODE != MODE_FULL) {                       // :148-153 mesh-guided range where the ray passes the body
-            if (a.near_m) {
-                const float nm = a.near_m[ray], fm = a.far_m[ray];
-                if (!is_inf(nm)) near = nm;
-                if (!is_inf(fm)) far = fm;
-            }
+        if (a.near_m) {                                          // :148-153 mesh-guided range where the ray passes the body
+            const float nm = a.near_m[ray], fm = a.far_m[ray];
+            if (!is_inf(nm)) near = nm;
+            if (!is_inf(fm)) far = fm;
         }
         const float span = far - near;
         const float sample_dist = span / (float)T0;
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float a2 = dv_softplus100(lds + OFF_SPQ, -tc) * a.car;
             const float iter_cos = -(a1 + a2);
             const float half = iter_cos * delta * 0.5f;
-            const float pc = dv_sigmoid((sdf0 - half) * a.inv_s), nc = dv_sigmoid((sdf0 + half) * a.inv_s);
+            const float pc = dv_sigmoid((sdf0 - half) * inv_s_core), nc = dv_sigmoid((sdf0 + half) * inv_s_core);
             float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
             if constexpr (MODE == MODE_FINAL) alpha = alpha * (a.mask[(size_t)ray * T + i] ? 1.0f : 0.0f);      // :246-249
             const float om = 1.0f - alpha + 1e-7f;
@@ -359,7 +358,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 if (a.out.sdf) a.out.sdf[si] = sdf0;
                 if (a.out.color) { a.out.color[3 * si] = rgb[0]; a.out.color[3 * si + 1] = rgb[1]; a.out.color[3 * si + 2] = rgb[2]; }
                 if (a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
+                if (a.out.pts) { a.out.pts[3 * si] = px; a.out.pts[3 * si + 1] = py; a.out.pts[3 * si + 2] = pz; }
             }
+            if (a.out.sdf_out16) *reinterpret_cast<f32x4 *>(a.out.sdf_out16 + ((size_t)ray * T + i) * 16 + 4 * g) = oc;     // lane (n, g) holds outputs 4g..4g+3
         }
         if (lane == 0) {
             const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(BLOCK) void field_color_kernel(const RenderArgs a, 
 }
 
 // gradient_error: fixed-order reduction of per-ray partials (oracle: orc_eikonal_reduce)
-__global__ __launch_bounds__(1024) void eikonal_reduce_kernel(const float *__restrict__ eik, int n_rays, float *__restrict__ result)
+__global__ __launch_bounds__(1024) void eikonal_reduce_kernel(const float *__restrict__ eik, int n_rays, float *__restrict__ result, int with_den)
 {
     __shared__ float pn[1024], pd[1024];
     const int t = threadIdx.x;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(1024) void eikonal_reduce_kernel(const float *__res
         if (t < s) { pn[t] += pn[t + s]; pd[t] += pd[t + s]; }
         __syncthreads();
     }
-    if (t == 0) result[0] = pn[0] / (pd[0] + 1e-5f);
+    if (t == 0) { result[0] = pn[0] / (pd[0] + 1e-5f); if (with_den) result[1] = pd[0] + 1e-5f; }
 }
 
 }  // namespace
@@ -472,6 +473,10 @@ static int check_render_args(const char *who, const ac_render_opts *op, const fl
                       op->num_steps, op->upsample_steps);
         return AC_ERR_BAD_ARG;
     }
+    if (!(op->fd_eps > 0.0f)) {      // the reference stops here too: `assert (gradient == gradient).all()` after dividing by eps = 0 (instant_nsr.py:274)
+        ac::set_error("%s: fd_eps = %g (normal_epsilon_ratio >= 1): the finite-difference normals divide by it, it must be positive", who, (double)op->fd_eps);
+        return AC_ERR_BAD_ARG;
+    }
     if (op->n_rays <= 0) return AC_OK;
     if (!rays_o || !rays_d || !lin_z || (op->upsample_steps && !lin_u) || (op->perturb && !noise) || !out->image ||
         !out->weights_sum || !out->depth || !out->normal_map || !out->eik) {
@@ -487,8 +492,10 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     a.rays_o = rays_o; a.rays_d = rays_d; a.bg = bg; a.noise = noise; a.lin_z = lin_z; a.lin_u = lin_u;
     a.out = *out;
     a.n_rays = op->n_rays; a.T0 = op->num_steps; a.nup = op->upsample_steps / 16;
-    a.inv_s = op->inv_s; a.car = op->cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
+    a.inv_s = op->inv_s; a.inv_s_dev = op->inv_s_dev; a.car = op->cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
     a.eps = op->fd_eps; a.perturb = op->perturb;
+    if ((op->near_m != nullptr) != (op->far_m != nullptr)) { ac::set_error("ac_render_opts: near_m and far_m go together"); return AC_ERR_BAD_ARG; }
+    a.near_m = op->near_m; a.far_m = op->far_m;
     for (int j = 0; j < 4; ++j) {           // finite-difference reach in cells, per gather round (see encode_stencil)
         a.jfine[j] = 0;
         for (int g = 0; g < 4; ++g) {
@@ -611,8 +618,15 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
 AC_API int ac_eikonal_reduce(const float *eik, int32_t n_rays, float *result, ac_stream_t stream)
 {
     if (!result || n_rays < 0 || (!eik && n_rays > 0)) { ac::set_error("eikonal_reduce: bad argument"); return AC_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, eik, n_rays, result);
+    hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, eik, n_rays, result, 0);
     return ac::check_launch("eikonal_reduce");
+}
+
+AC_API int ac_eikonal_reduce2(const float *eik, int32_t n_rays, float *result2, ac_stream_t stream)
+{
+    if (!result2 || n_rays < 0 || (!eik && n_rays > 0)) { ac::set_error("eikonal_reduce2: bad argument"); return AC_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, eik, n_rays, result2, 1);
+    return ac::check_launch("eikonal_reduce2");
 }
 
 AC_API int ac_field_sdf(const ac_field *field, const float *x, uint32_t B, float bound, float *out16, ac_stream_t stream)

@@ -515,6 +515,7 @@ struct CompArgs {
     const float *rays_o, *rays_d, *z, *sdf, *nrm, *col, *bg;
     int n_rays, T0, T;
     float bound, inv_s, car, one_m_car;
+    const float *inv_s_dev;      // non-NULL: inv_s lives in device memory (the trainable variance), read once per kernel
 };
 
 struct CompSample { float alpha, om, u, pc, nc, half, delta, tc, zn; };
@@ -538,10 +539,12 @@ __device__ __forceinline__ CompSample comp_sample(const float *__restrict__ spg,
     return s;
 }
 
-__global__ __launch_bounds__(256) void composite_fwd_kernel(const CompArgs a, float *__restrict__ image, float *__restrict__ wsum,
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const CompArgs a_in, float *__restrict__ image, float *__restrict__ wsum,
                                                             float *__restrict__ depth, float *__restrict__ nmap, float *__restrict__ weights,
                                                             float *__restrict__ alpha_out)
 {
+    CompArgs a = a_in;
+    if (a.inv_s_dev) a.inv_s = *a.inv_s_dev;
     __shared__ float spg[512];
     __shared__ float zsh[4][128];
     for (int e = threadIdx.x; e < 512; e += blockDim.x) spg[e] = AC_SP_G[e >> 2][e & 3];
@@ -590,11 +593,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompArgs a, fl
     }
 }
 
-__global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a, const float *__restrict__ g_image, const float *__restrict__ g_wsum,
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a_in, const float *__restrict__ g_image, const float *__restrict__ g_wsum,
                                                             const float *__restrict__ g_depth, const float *__restrict__ g_nmap,
                                                             float *__restrict__ g_sdf, float *__restrict__ g_nrm, float *__restrict__ g_col,
                                                             float *__restrict__ g_invs_ray)
 {
+    CompArgs a = a_in;
+    if (a.inv_s_dev) a.inv_s = *a.inv_s_dev;
     __shared__ float spg[512];
     __shared__ float zsh[4][128], tex[4][128], wq[4][128], psum[4][128];
     for (int e = threadIdx.x; e < 512; e += blockDim.x) spg[e] = AC_SP_G[e >> 2][e & 3];
@@ -609,9 +614,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a, co
         const float span = far - near, sample_dist = span / (float)a.T0;
         for (int i = lane; i < a.T; i += 64) zr[i] = a.z[(size_t)ray * a.T + i];
         wave_sync();
-        const float gi0 = g_image[3 * ray], gi1 = g_image[3 * ray + 1], gi2 = g_image[3 * ray + 2];
-        const float gws = g_wsum[ray], gdp = g_depth[ray];
-        const float gn0 = g_nmap[3 * ray], gn1 = g_nmap[3 * ray + 1], gn2 = g_nmap[3 * ray + 2];
+        const float gi0 = g_image ? g_image[3 * ray] : 0.0f, gi1 = g_image ? g_image[3 * ray + 1] : 0.0f, gi2 = g_image ? g_image[3 * ray + 2] : 0.0f;
+        const float gws = g_wsum ? g_wsum[ray] : 0.0f, gdp = g_depth ? g_depth[ray] : 0.0f;          // NULL upstream = zero gradient
+        const float gn0 = g_nmap ? g_nmap[3 * ray] : 0.0f, gn1 = g_nmap ? g_nmap[3 * ray + 1] : 0.0f, gn2 = g_nmap ? g_nmap[3 * ray + 2] : 0.0f;
         const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
         // pass A: transmittance, weights, d loss / d w_i, prefix sums of dw_i w_i
         float cT = 1.0f, run = 0.0f;
@@ -688,6 +693,43 @@ __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float *__re
         for (int k = 0; k < 16; ++k) t += red[k][o];
         out[i] = t;
     }
+}
+
+// ---- glue of the whole-core backward (ac_render_core_backward) -------------------------------------------------------------------
+// normal = gradient / (1e-5 + |gradient|)  (instant_nsr.py:215), the renderer's own arithmetic: the colour / compositing backward
+// kernels recompute their forward from exactly the normals the forward launch used
+__global__ __launch_bounds__(256) void core_normals_kernel(const float *__restrict__ grad, uint32_t B, float *__restrict__ nrm)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float gx = grad[3 * (size_t)b], gy = grad[3 * (size_t)b + 1], gz = grad[3 * (size_t)b + 2];
+    const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+    nrm[3 * (size_t)b] = gx / (1e-5f + gn); nrm[3 * (size_t)b + 1] = gy / (1e-5f + gn); nrm[3 * (size_t)b + 2] = gz / (1e-5f + gn);
+}
+
+// joins the gradients that reach the SDF query: d sdf_out = (colour backward) with column 0 += (compositing backward: d sdf);
+// d gradient = backward of n = g / (1e-5 + |g|) applied to d normal (compositing + colour), plus the eikonal term
+// d/dg [ sum relax (|g| - 1)^2 / (sum relax + 1e-5) ] = relax 2 (|g| - 1) / den * g / |g|   (instant_nsr.py:266-272; |g| = 0 -> 0 like
+// torch.linalg.norm's backward)
+__global__ __launch_bounds__(256) void core_mid_kernel(const float *__restrict__ grad, const float *__restrict__ pts, const float *__restrict__ g_sdf,
+                                                       const float *__restrict__ g_nrm_a, const float *__restrict__ g_nrm_b, const float *__restrict__ g_eik,
+                                                       const float *__restrict__ eik_den, uint32_t B, float *__restrict__ g_s16, float *__restrict__ g_grad)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t b3 = 3 * (size_t)b;
+    const float gx = grad[b3], gy = grad[b3 + 1], gz = grad[b3 + 2];
+    const float r = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz), c = 1e-5f + r;
+    const float ux = g_nrm_a[b3] + g_nrm_b[b3], uy = g_nrm_a[b3 + 1] + g_nrm_b[b3 + 1], uz = g_nrm_a[b3 + 2] + g_nrm_b[b3 + 2];
+    const float dot = (gx * ux + gy * uy) + gz * uz;
+    float k = r > 0.0f ? -dot / (r * c * c) : 0.0f;                   // d(1 / (1e-5 + r)) / dg = -g / (r c^2)
+    if (g_eik) {
+        const float px = pts[b3], py = pts[b3 + 1], pz = pts[b3 + 2];
+        const float relax = __builtin_sqrtf((px * px + py * py) + pz * pz) < 1.2f ? 1.0f : 0.0f;
+        if (r > 0.0f) k += g_eik[0] * relax * 2.0f * (r - 1.0f) / (eik_den[0] * r);
+    }
+    g_grad[b3] = ux / c + k * gx; g_grad[b3 + 1] = uy / c + k * gy; g_grad[b3 + 2] = uz / c + k * gz;
+    g_s16[(size_t)b * 16] += g_sdf[b];
 }
 
 uint32_t train_grid(uint32_t B)
@@ -814,6 +856,7 @@ static int comp_args(CompArgs &a, const char *who, const float *rays_o, const fl
     if (T0 <= 0 || T % 16 || T < T0 || T > 128) { ac::set_error("%s: T0=%d T=%d unsupported (T a multiple of 16, <= 128)", who, T0, T); return AC_ERR_BAD_ARG; }
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.sdf = sdf; a.nrm = nrm; a.col = col; a.bg = bg;
     a.n_rays = n_rays; a.T0 = T0; a.T = T; a.bound = bound; a.inv_s = inv_s; a.car = car; a.one_m_car = (float)(1.0 - (double)car);
+    a.inv_s_dev = nullptr;
     return AC_OK;
 }
 
@@ -845,4 +888,69 @@ AC_API int ac_composite_backward(const float *rays_o, const float *rays_d, const
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, g_image, g_weights_sum, g_depth, g_normal_map, g_sdf,
                        g_normal, g_color, g_inv_s_per_ray);
     return ac::check_launch("composite_backward");
+}
+
+// ---- the whole render core backward -----------------------------------------------------------------------------------------------
+namespace {
+struct CoreLayout { size_t nrm, g_sdf, g_nrm_a, g_col, g_nrm_b, g_s16, g_grad, gfeat, part_sdf, part_col, hash, total, hash_bytes; };
+CoreLayout core_layout(const ac_field *field, uint32_t B)
+{
+    CoreLayout l{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    l.nrm = take((size_t)B * 12); l.g_sdf = take((size_t)B * 4); l.g_nrm_a = take((size_t)B * 12); l.g_col = take((size_t)B * 12);
+    l.g_nrm_b = take((size_t)B * 12); l.g_s16 = take((size_t)B * 64); l.g_grad = take((size_t)B * 12);
+    l.gfeat = take((size_t)B * 7 * 16 * 2 * 4);
+    l.part_sdf = take(ac_sdf_stencil_backward_scratch(B)); l.part_col = take(ac_color_backward_scratch(B));
+    l.hash_bytes = field ? ac_hash_stencil_backward_scratch(field->offsets, 16, field->S, field->H, 16, B) : 0;
+    l.hash = take(l.hash_bytes);
+    l.total = o;
+    return l;
+}
+}  // namespace
+
+AC_API size_t ac_render_core_backward_scratch(const ac_field *field, int32_t n_rays, int32_t T)
+{
+    if (!field || n_rays <= 0 || T <= 0) return 0;
+    return core_layout(field, (uint32_t)n_rays * (uint32_t)T).total;
+}
+
+AC_API int ac_render_core_backward(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d, const float *bg,
+                                   const ac_core_saved *sv, const ac_core_upstream *up, const ac_core_grads *gr, void *scratch, size_t scratch_bytes,
+                                   ac_stream_t stream)
+{
+    if (!field || !op || !sv || !up || !gr) { ac::set_error("render_core_backward: NULL argument struct"); return AC_ERR_BAD_ARG; }
+    if (op->n_rays <= 0) return AC_OK;
+    const int N = op->n_rays, T0 = op->num_steps, T = T0 + op->upsample_steps;
+    if (!rays_o || !rays_d || !sv->z_vals || !sv->pts || !sv->sdf || !sv->sdf_out16 || !sv->gradient || !sv->color || (up->g_eik && !sv->eik_den) ||
+        !gr->g_table || !gr->g_sdf_params || !gr->g_color_params || !gr->g_inv_s_per_ray) {
+        ac::set_error("render_core_backward: NULL buffer"); return AC_ERR_BAD_ARG;
+    }
+    if (!(op->fd_eps > 0.0f)) { ac::set_error("render_core_backward: fd_eps must be positive"); return AC_ERR_BAD_ARG; }
+    const uint32_t B = (uint32_t)N * (uint32_t)T;
+    const CoreLayout l = core_layout(field, B);
+    if (!scratch || scratch_bytes < l.total) { ac::set_error("render_core_backward: scratch of %zu bytes needed, %zu given", l.total, scratch_bytes); return AC_ERR_BAD_ARG; }
+    char *sb = static_cast<char *>(scratch);
+    float *nrm = reinterpret_cast<float *>(sb + l.nrm), *g_sdf = reinterpret_cast<float *>(sb + l.g_sdf), *g_nrm_a = reinterpret_cast<float *>(sb + l.g_nrm_a);
+    float *g_col = reinterpret_cast<float *>(sb + l.g_col), *g_nrm_b = reinterpret_cast<float *>(sb + l.g_nrm_b), *g_s16 = reinterpret_cast<float *>(sb + l.g_s16);
+    float *g_grad = reinterpret_cast<float *>(sb + l.g_grad), *gfeat = reinterpret_cast<float *>(sb + l.gfeat);
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t eb = (B + 255) / 256;
+    hipLaunchKernelGGL(core_normals_kernel, dim3(eb), dim3(256), 0, st, sv->gradient, B, nrm);
+    {   // NeuS alpha + compositing (instant_nsr.py:219-263,290-299)
+        CompArgs a{};
+        if (int rc = comp_args(a, "render_core_backward", rays_o, rays_d, sv->z_vals, sv->sdf, nrm, sv->color, bg, N, T0, T, op->bound, op->inv_s, op->cos_anneal_ratio)) return rc;
+        a.inv_s_dev = op->inv_s_dev;
+        int blocks = (N + 3) / 4; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks), dim3(256), 0, st, a, up->g_image, up->g_weights_sum, up->g_depth, up->g_normal_map, g_sdf,
+                           g_nrm_a, g_col, gr->g_inv_s_per_ray);
+    }
+    if (int rc = ac_color_backward(field, sv->pts, nrm, sv->sdf_out16, g_col, B, g_nrm_b, g_s16, gr->g_color_params, sb + l.part_col,
+                                   ac_color_backward_scratch(B), stream)) return rc;
+    hipLaunchKernelGGL(core_mid_kernel, dim3(eb), dim3(256), 0, st, sv->gradient, sv->pts, g_sdf, g_nrm_a, g_nrm_b, up->g_eik, sv->eik_den, B, g_s16, g_grad);
+    if (int rc = ac_sdf_stencil_backward(field, sv->pts, g_s16, g_grad, B, op->bound, op->fd_eps, gfeat, gr->g_sdf_params, sb + l.part_sdf,
+                                         ac_sdf_stencil_backward_scratch(B), stream)) return rc;
+    if (int rc = ac_hash_stencil_backward(gfeat, sv->pts, field->offsets, gr->g_table, B, 2, 16, field->S, field->H, op->fd_eps, op->bound,
+                                          l.hash_bytes ? sb + l.hash : nullptr, l.hash_bytes, stream)) return rc;
+    return ac::check_launch("render_core_backward");
 }

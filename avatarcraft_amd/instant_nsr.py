@@ -60,14 +60,31 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ fused field handle
     def _field(self):
-        """ac_field view of the current parameters (effective = weight-normed matrices)."""
-        wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0).detach().contiguous()
+        """ac_field view of the current parameters (effective = weight-normed matrices).  Cached while no parameter changes
+        (tensor version counters): a frozen net (net_gt of stylize.py) builds it once, a training net once per optimizer step --
+        not once per ray batch (7 weight-norm launches and a struct each time otherwise)."""
         enc = self.encoder
-        return nsr_ops.Field(enc.embeddings.detach(), enc.offsets.tolist(), enc.per_level_scale, enc.base_resolution,
-                             wn(self.sdf_net[0]), self.sdf_net[0].bias.detach().contiguous(), wn(self.sdf_net[1]),
-                             self.sdf_net[1].bias.detach().contiguous(), wn(self.color_net[0]), wn(self.color_net[1]), wn(self.color_net[2]))
+        prm = [enc.embeddings, self.sdf_net[0].bias, self.sdf_net[1].bias] + [t for l in list(self.sdf_net) + list(self.color_net)
+                                                                             for t in (l.weight_v, l.weight_g)]
+        key = tuple((t.data_ptr(), t._version) for t in prm)
+        cached = getattr(self, "_field_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        with torch.no_grad():
+            wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0).contiguous()
+            f = nsr_ops.Field(enc.embeddings.detach(), self._offsets_host(), enc.per_level_scale, enc.base_resolution,
+                              wn(self.sdf_net[0]), self.sdf_net[0].bias.detach().contiguous(), wn(self.sdf_net[1]),
+                              self.sdf_net[1].bias.detach().contiguous(), wn(self.color_net[0]), wn(self.color_net[1]), wn(self.color_net[2]))
+        self._field_cache = (key, f)
+        return f
 
-    fused_training = True      # render core's SDF query through the fused forward/backward operator (False: torch MLP over the stencil encoder)
+    # How a render WITH gradients runs (stylize.py / reconstruct.py):
+    #   "core": one operator -- forward = the fused renderer itself (the launch an inference render makes, bit for bit), backward =
+    #           ac_render_core_backward (nsr_ops.render_core);
+    #   "ops" (or True): sampling launch + the fused SDF-query / colour / compositing operators with torch glue between them (round 1;
+    #           kept as the cross-check of "core");
+    #   False : sampling launch + torch autograd over the stencil hash encoder (any model configuration).
+    fused_training = "core"
 
     def _offsets_host(self):
         oh = getattr(self, "_offsets_cache", None)
@@ -75,20 +92,42 @@ class NeRFRenderer(nn.Module):
             oh = self._offsets_cache = self.encoder.offsets.tolist()
         return oh
 
-    def _fused_supported(self):
+    def _sdf_supported(self):
+        """the SDF side of the default model (16-level, 2-feature hash grid + the 35-64-16 SDF network): what the fused sampling stage needs"""
         enc = getattr(self, "encoder", None)
-        return (not self.use_viewdirs and self.include_input and self.num_layers == 2 and self.hidden_dim == 64 and self.geo_feat_dim == 15
-                and self.num_layers_color == 3 and self.hidden_dim_color == 64 and hasattr(enc, "embeddings")
-                and enc.num_levels == 16 and enc.level_dim == 2 and enc.input_dim == 3 and not self.curvature_loss)
+        return (self.include_input and self.num_layers == 2 and self.hidden_dim == 64 and self.geo_feat_dim == 15 and hasattr(enc, "embeddings")
+                and enc.num_levels == 16 and enc.level_dim == 2 and enc.input_dim == 3)
+
+    def _fused_supported(self):
+        """the whole default model: no view directions (colour net 21-64-64-3), no curvature term"""
+        return (self._sdf_supported() and not self.use_viewdirs and self.num_layers_color == 3 and self.hidden_dim_color == 64
+                and not self.curvature_loss)
+
+    def _field_sdf_only(self):
+        """ac_field with the SDF side only (zero colour matrices): the sampling stage of a model whose colour net the fused renderer does not cover"""
+        enc = self.encoder
+        prm = [enc.embeddings, self.sdf_net[0].bias, self.sdf_net[1].bias] + [t for l in self.sdf_net for t in (l.weight_v, l.weight_g)]
+        key = tuple((t.data_ptr(), t._version) for t in prm)
+        cached = getattr(self, "_field_sdf_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        dev = enc.embeddings.device
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0).contiguous()
+            f = nsr_ops.Field(enc.embeddings.detach(), self._offsets_host(), enc.per_level_scale, enc.base_resolution, wn(self.sdf_net[0]),
+                              self.sdf_net[0].bias.detach().contiguous(), wn(self.sdf_net[1]), self.sdf_net[1].bias.detach().contiguous(),
+                              z(64, 21), z(64, 64), z(3, 64))
+        self._field_sdf_cache = (key, f)
+        return f
 
     # ------------------------------------------------------------------ run == reference :133-299
     def run(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0,
             render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True):
-        if render_can and verts is not None and use_mesh_guide:
-            raise NotImplementedError("mesh-guided near/far is built for posed-space rendering (render_can=False) only; pass "
-                                      "use_mesh_guide=False or verts=None for a canonical-space render")
-        if not self._fused_supported():
-            raise NotImplementedError("the fused MI355X renderer supports the default NeRFNetwork configuration only")
+        if not self._sdf_supported():
+            raise NotImplementedError("the MI355X renderer needs the default SDF side of NeRFNetwork (16-level hash grid, include_input, "
+                                      "SDF network 35-64-16); other widths / depths have no sampling kernel")
+        full = self._fused_supported()
         B, N = rays_o.shape[:2]
         device = rays_o.device
         ro = rays_o.reshape(-1, 3).float().contiguous()
@@ -103,27 +142,50 @@ class NeRFRenderer(nn.Module):
             bg = bg.reshape(-1, 3) if bg.numel() >= 3 else bg.reshape(1, 1).expand(1, 3)
             bg = bg.expand(N, 3).contiguous() if bg.shape[0] == 1 else bg.contiguous()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        field = self._field()
         warp = None
+        near_far = None
         if not render_can:                                       # SMPL inverse warp :166-172,198-203 (inference path of render_warp.py)
             if needs_grad:
                 raise NotImplementedError("posed-space rendering (render_can=False) is an inference path: call it under torch.no_grad()")
+            if not full:
+                raise NotImplementedError("posed-space rendering is built for the default NeRFNetwork (use_viewdirs=False, no curvature term)")
             if verts is None or faces is None or Ts is None:
                 raise RuntimeError("render_can=False needs verts, faces and Ts")
             warp = verts if isinstance(verts, nsr_ops.WarpMesh) else nsr_ops.WarpMesh(verts, faces, Ts, device, DEFAULT_GEO_THRESH,
                                                                                       DEFAULT_GEO_THRESH, use_mesh_guide)
-        if needs_grad:                                           # only the sample positions come from the no-grad stage (:176-184)
-            z_vals = nsr_ops.sample_rays(field, ro, rd, num_steps, upsample_steps, bound, noise=noise)
-            return self._render_core_autograd(ro, rd, z_vals, num_steps, upsample_steps, bound, bg, cos_anneal_ratio, normal_epsilon_ratio, B, N)
-        out = nsr_ops.render_rays(field, ro, rd, num_steps, upsample_steps, bound, float(inv_s_t.detach().reshape(-1)[0]), bg=bg, noise=noise,
-                                  cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp)
+        elif verts is not None and use_mesh_guide:               # canonical render inside the mesh-guided range :147-153
+            from .ray_utils import geometry_guided_near_far
+            v = verts.verts if isinstance(verts, nsr_ops.WarpMesh) else verts
+            near_far = geometry_guided_near_far(ro, rd, v, DEFAULT_GEO_THRESH)
+        if needs_grad and full and self.fused_training == "core" and near_far is None:
+            wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0)
+            enc = self.encoder
+            (image, wsum, depth, nmap, gerr, weights, alpha, color, z_vals) = nsr_ops.render_core(
+                enc.embeddings, wn(self.sdf_net[0]), self.sdf_net[0].bias, wn(self.sdf_net[1]), self.sdf_net[1].bias, wn(self.color_net[0]),
+                wn(self.color_net[1]), wn(self.color_net[2]), inv_s_t, ro, rd, bg, noise, self._offsets_host(), enc.per_level_scale, enc.base_resolution,
+                num_steps, upsample_steps, bound, cos_anneal_ratio, normal_epsilon_ratio)
+            return depth.reshape(B, N), weights, wsum[:, None], image.reshape(B, N, 3), nmap, gerr, 0.0, color, alpha, z_vals
+        if needs_grad or not full:
+            # only the sample positions come from the fused (no-grad) stage (:176-184); the render core runs under autograd: through the fused
+            # operators for the default model, through torch MLPs over the HIP hash encoder for any colour-net variant (use_viewdirs, curvature)
+            z_vals = nsr_ops.sample_rays(self._field() if full else self._field_sdf_only(), ro, rd, num_steps, upsample_steps, bound, noise=noise,
+                                         near_far=near_far)
+            return self._render_core_autograd(ro, rd, z_vals, num_steps, upsample_steps, bound, bg, cos_anneal_ratio, normal_epsilon_ratio, B, N,
+                                              near_far=near_far)
+        out = nsr_ops.render_rays(self._field(), ro, rd, num_steps, upsample_steps, bound, inv_s_t, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
+                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp, near_far=near_far)
         return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
                 out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])
 
     def _render_core_autograd(self, rays_o, rays_d, z_vals, num_steps0, upsample_steps, bound, bg_color, cos_anneal_ratio,
-                              normal_epsilon_ratio, B, N):
+                              normal_epsilon_ratio, B, N, near_far=None):
         """The differentiable part of run() (reference :190-299) on the sample positions delivered by the fused kernel."""
         near, far = near_far_from_bound(rays_o, rays_d, bound, type='cube')
+        if near_far is not None:                                 # :148-153
+            nm, fm = near_far[0].reshape(-1, 1), near_far[1].reshape(-1, 1)
+            near = torch.where(torch.isinf(nm), near, nm)
+            far = torch.where(torch.isinf(fm), far, fm)
+        fused_ops = bool(self.fused_training) and self._fused_supported() and near_far is None
         sample_dist = (far - near) / num_steps0
         T = num_steps0 + upsample_steps
         deltas = z_vals[:, 1:] - z_vals[:, :-1]
@@ -140,7 +202,7 @@ class NeRFRenderer(nn.Module):
             gradient = self.gradient(flat, bound, fd_eps).squeeze()
         sdf, feat = sdf_out[:, :1], sdf_out[:, 1:]
         normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
-        if self.fused_training and self._fused_supported() and flat.is_cuda:
+        if fused_ops and flat.is_cuda:
             color = self.forward_color_fused(flat, normal.reshape(-1, 3), sdf_out)
         else:
             color = self.forward_color(flat, dirs.reshape(-1, 3), normal.reshape(-1, 3), feat, bound)
@@ -148,8 +210,16 @@ class NeRFRenderer(nn.Module):
         relax = (pts_norm < 1.2).float().detach()
         gerr = (torch.linalg.norm(gradient.reshape(N, T, 3), ord=2, dim=-1) - 1.0) ** 2
         gradient_error = (relax * gerr).sum() / (relax.sum() + 1e-5)
-        assert (gradient == gradient).all(), 'Nan or Inf found!'
-        if self.fused_training and self._fused_supported() and flat.is_cuda and T % 16 == 0 and T <= 128:
+        curvature_error = 0.0
+        if self.curvature_loss:                                  # :276-288
+            random_vec = 2.0 * torch.randn_like(normal) - 1.0
+            random_vec_norm = random_vec / (1e-5 + torch.linalg.norm(random_vec, ord=2, dim=-1, keepdim=True))
+            perturbed_pts = flat + torch.cross(normal, random_vec_norm, dim=-1) * 0.01 * (1.0 - normal_epsilon_ratio)
+            pg = self.gradient(perturbed_pts, bound, fd_eps).squeeze()
+            pn = pg / (1e-5 + torch.linalg.norm(pg, ord=2, dim=-1, keepdim=True))
+            cerr = (torch.sum(normal * pn, dim=-1) - 1.0) ** 2
+            curvature_error = (relax * cerr.reshape(N, T)).sum() / (relax.sum() + 1e-5)
+        if fused_ops and flat.is_cuda and T % 16 == 0 and T <= 128:
             # NeuS alpha + compositing as one fused op each way (same arithmetic as the inference renderer)
             bg = None
             if bg_color is not None:
@@ -159,8 +229,8 @@ class NeRFRenderer(nn.Module):
             image, wsum, depth, normal_map, weights, alpha = nsr_ops.composite(
                 z_vals, sdf.reshape(N, T), normal.reshape(N, T, 3), color.reshape(N, T, 3), self.forward_variance(), rays_o, rays_d, bg, num_steps0,
                 bound, cos_anneal_ratio)
-            return (depth.reshape(B, N), weights, wsum[:, None], image.reshape(B, N, 3), normal_map, gradient_error, 0.0, color.reshape(N, T, 3), alpha,
-                    z_vals)
+            return (depth.reshape(B, N), weights, wsum[:, None], image.reshape(B, N, 3), normal_map, gradient_error, curvature_error, color.reshape(N, T, 3),
+                    alpha, z_vals)
         inv_s = self.forward_variance().expand(N * T, 1)
         true_cos = (dirs.reshape(-1, 3) * normal).sum(-1, keepdim=True)
         act = nn.Softplus(beta=100)
@@ -178,7 +248,7 @@ class NeRFRenderer(nn.Module):
         if bg_color is None:
             bg_color = 1
         image = image + (1 - weights_sum) * bg_color
-        return depth.reshape(B, N), weights, weights_sum, image.reshape(B, N, 3), normal_map, gradient_error, 0.0, color, alpha, z_vals
+        return depth.reshape(B, N), weights, weights_sum, image.reshape(B, N, 3), normal_map, gradient_error, curvature_error, color, alpha, z_vals
 
     # ------------------------------------------------------------------ render == reference :358-408
     def render(self, rays_o, rays_d, num_steps, bound, upsample_steps, staged=False, max_ray_batch=4096, bg_color=None,
@@ -276,7 +346,7 @@ class NeRFNetwork(NeRFRenderer):
         """forward_sdf(x) (:627-642) and finite_difference_normals_approximator(x) (:687-704) together: the seven hash encodings
         come from one stencil launch (encoder.forward_stencil) and the SDF MLP runs once over the 7B points.
         Returns (sdf_out [B,16], gradient [B,3])."""
-        if self.fused_training and self._fused_supported() and x.is_cuda:           # one kernel forward, two backward (csrc/sdf_train.hip)
+        if self.fused_training and self._sdf_supported() and x.is_cuda:            # one kernel forward, two backward (csrc/sdf_train.hip)
             l0, l1, enc = self.sdf_net[0], self.sdf_net[1], self.encoder
             return nsr_ops.sdf_stencil(x, enc.embeddings, torch._weight_norm(l0.weight_v, l0.weight_g, 0), l0.bias,
                                        torch._weight_norm(l1.weight_v, l1.weight_g, 0), l1.bias, self._offsets_host(), enc.per_level_scale,
@@ -317,8 +387,9 @@ class NeRFNetwork(NeRFRenderer):
 
     def density(self, x, bound):
         """sdf only (reference :669-681); no-grad queries go through the fused field kernel"""
-        if not torch.is_grad_enabled() and x.is_cuda and self._fused_supported():
-            return nsr_ops.field_sdf(self._field(), x.reshape(-1, 3).float().contiguous(), bound)[:, 0].reshape(x.shape[:-1])
+        if not torch.is_grad_enabled() and x.is_cuda and self._sdf_supported():
+            f = self._field() if self._fused_supported() else self._field_sdf_only()
+            return nsr_ops.field_sdf(f, x.reshape(-1, 3).float().contiguous(), bound)[:, 0].reshape(x.shape[:-1])
         return self.forward_sdf(x, bound)[..., 0]
 
     def gradient(self, x, bound, epsilon=0.0005):

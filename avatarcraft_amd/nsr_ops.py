@@ -68,11 +68,26 @@ def linspace_tables(num_steps, device):
     return _LIN_CACHE[key]
 
 
+def _inv_s_arg(inv_s):
+    """(float for ac_render_opts.inv_s, device tensor or None for .inv_s_dev): a CUDA tensor (forward_variance()) is handed over as a
+    pointer -- the trainable variance never takes a host round trip"""
+    if isinstance(inv_s, torch.Tensor):
+        if inv_s.is_cuda:
+            t = inv_s.detach().reshape(-1)[:1].to(_F32).contiguous()
+            return 0.0, t
+        return float(inv_s.detach().reshape(-1)[0]), None
+    return float(inv_s), None
+
+
 def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg=None, noise=None,
-                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None, events=None, warp=None):
+                cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None, events=None, warp=None,
+                train_extras=False, near_far=None):
     """One launch of the fused renderer for N rays.  Returns a dict of CUDA tensors:
     image[N,3] weights_sum[N] depth[N] normal_map[N,3] eik[N,2] gradient_error[] (+ z_vals, weights,
-    alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices).
+    alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices; + sdf_out16 [N,T,16], pts [N,T,3] and
+    eik_res = (gradient_error, eikonal denominator) when train_extras: what the render-core backward needs).
+    inv_s: a float, or forward_variance() as a CUDA tensor (read on the device).
+    near_far = (near [N], far [N]): per-ray sampling range that overrides the cube's where finite (the mesh-guided range of a canonical render).
     warp = WarpMesh(...) renders in posed space (run(render_can=False)): + can_mid[N,T,3], mask[N,T] views of the scratch."""
     rays_o = _chk(rays_o.reshape(-1, 3), "rays_o")
     rays_d = _chk(rays_d.reshape(-1, 3), "rays_d")
@@ -102,6 +117,9 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
         o.color = buf("color", (N, T, 3)).data_ptr()
         o.sdf = buf("sdf", (N, T)).data_ptr()
         o.gradient = buf("gradient", (N, T, 3)).data_ptr()
+    if train_extras:
+        o.sdf_out16 = buf("sdf_out16", (N, T, 16)).data_ptr()
+        o.pts = buf("pts", (N, T, 3)).data_ptr()
     if debug_indices:
         o.ss_inds = buf("ss_inds", (N, max(nup, 1), 16), torch.int32).data_ptr()
         o.sort_index = buf("sort_index", (N, max(nup, 1), 128), torch.int32).data_ptr()
@@ -110,8 +128,13 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     if noise is not None:
         noise = _chk(noise.reshape(N, num_steps), "noise")
     import numpy as np
-    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), float(inv_s), float(cos_anneal_ratio),
-                          float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None))
+    inv_s_f, inv_s_t = _inv_s_arg(inv_s)
+    nm = fm = None
+    if near_far is not None:
+        nm, fm = _chk(near_far[0].reshape(-1), "near", (N,)), _chk(near_far[1].reshape(-1), "far", (N,))
+    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), inv_s_f, float(cos_anneal_ratio),
+                          float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None), L.ptr(inv_s_t), L.ptr(nm), L.ptr(fm))
+    res["_opts"] = (op, inv_s_t, nm, fm)
     st = L.current_stream(dev)
     if events is not None:          # (start, end) torch.cuda.Event pair around the render kernel only (bench.py roofline)
         events[0].record()
@@ -129,12 +152,17 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
         res["mask"] = scratch[offs[4]:offs[4] + N * T].view(N, T)
     if events is not None:
         events[1].record()
-    ge = buf("gradient_error", ())
-    L.check(L.lib().ac_eikonal_reduce(res["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
+    if train_extras:
+        er = buf("eik_res", (2,))
+        L.check(L.lib().ac_eikonal_reduce2(res["eik"].data_ptr(), N, er.data_ptr(), st), "eikonal_reduce")
+        res["gradient_error"] = er[0]
+    else:
+        ge = buf("gradient_error", ())
+        L.check(L.lib().ac_eikonal_reduce(res["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
     return res
 
 
-def sample_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, noise=None):
+def sample_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, noise=None, near_far=None):
     """the no-grad sampling stage of run() only -> z_vals [N, num_steps + upsample_steps] (identical to render_rays' z_vals)"""
     rays_o = _chk(rays_o.reshape(-1, 3), "rays_o")
     rays_d = _chk(rays_d.reshape(-1, 3), "rays_d")
@@ -143,7 +171,10 @@ def sample_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     if noise is not None:
         noise = _chk(noise.reshape(N, num_steps), "noise")
     z = torch.empty((N, num_steps + upsample_steps), dtype=_F32, device=dev)
-    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), 1.0, 1.0, 0.005, int(noise is not None))
+    nm = fm = None
+    if near_far is not None:
+        nm, fm = _chk(near_far[0].reshape(-1), "near", (N,)), _chk(near_far[1].reshape(-1), "far", (N,))
+    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), 1.0, 1.0, 0.005, int(noise is not None), None, L.ptr(nm), L.ptr(fm))
     L.check(L.lib().ac_sample_rays(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(noise), lin_z.data_ptr(),
                                    lin_u.data_ptr(), z.data_ptr(), L.current_stream(dev)), "sample_rays")
     return z
@@ -173,6 +204,88 @@ class WarpMesh:
                                                 self.accel.data_ptr(), nbytes, L.current_stream(torch.device(device))), "warp_accel_build")
         self.c = L.ac_warp_mesh(self.verts.data_ptr(), self.faces.data_ptr(), self.T.data_ptr(), self.verts.shape[0], self.faces.shape[0],
                                 float(threshold), float(geo_threshold), int(bool(use_mesh_guide)), L.ptr(self.accel))
+
+
+_CORE_SCRATCH = {}
+
+
+def core_scratch(field, N, T, dev):
+    """device scratch of ac_render_core_backward, one buffer per (device, stream): grown to the largest batch seen, never shrunk
+    (free_scratch() releases everything).  Keyed by stream so that two streams never share queues."""
+    need = int(L.lib().ac_render_core_backward_scratch(C.byref(field.c), int(N), int(T)))
+    key = (str(dev), int(L.current_stream(dev) or 0))
+    cur = _CORE_SCRATCH.get(key)
+    if cur is None or cur.numel() < need:
+        _CORE_SCRATCH[key] = None
+        cur = _CORE_SCRATCH[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    return cur, need
+
+
+def free_scratch():
+    """drop every cached scratch buffer of this module and of the hash encoder back end (multi-GB queues of the table-gradient scatter)"""
+    _CORE_SCRATCH.clear()
+    from .encoder.hashencoder import backend as BK
+    BK._SCRATCH.clear()
+
+
+class _RenderCore(torch.autograd.Function):
+    """NeRFRenderer.run with gradients (reference models/instant_nsr.py:133-299 under torch.enable_grad) as ONE operator:
+    forward  = the fused renderer itself (ac_render_rays: sampling + render core, the launch an inference render makes) with its
+               per-sample outputs kept;
+    backward = ac_render_core_backward: compositing -> colour MLP -> normal normalisation + eikonal -> SDF query -> table scatter.
+    Differentiable w.r.t. the hash table, the EFFECTIVE MLP matrices (weight norm stays in torch) and inv_s; the sample positions
+    are constants, as in the reference (they are computed under no_grad, :176-184)."""
+
+    @staticmethod
+    def forward(ctx, table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, cfg):
+        offsets, pls, H, T0, up, bound, car, ner = cfg
+        ctx.set_materialize_grads(False)              # an output the loss does not use arrives as None -> a NULL upstream pointer
+        d = lambda t: t.detach().contiguous()
+        field = Field(d(table), offsets, pls, H, d(W1), d(b1), d(W2), d(b2), d(Wc1), d(Wc2), d(Wc3))
+        out = render_rays(field, rays_o, rays_d, T0, up, bound, inv_s, bg=bg, noise=noise, cos_anneal_ratio=car, normal_epsilon_ratio=ner,
+                          extras=True, train_extras=True)
+        ctx.field, ctx.out, ctx.cfg = field, out, cfg
+        ctx.rays = (rays_o, rays_d, bg)
+        ctx.table = table
+        ctx.inv_s_shape = inv_s.shape
+        ctx.mark_non_differentiable(out["weights"], out["alpha"], out["color"], out["z_vals"])
+        return (out["image"], out["weights_sum"], out["depth"], out["normal_map"], out["eik_res"][0], out["weights"], out["alpha"], out["color"],
+                out["z_vals"])
+
+    @staticmethod
+    def backward(ctx, g_image, g_wsum, g_depth, g_nmap, g_eik, *_unused):
+        field, out = ctx.field, ctx.out
+        rays_o, rays_d, bg = ctx.rays
+        N, T = out["z_vals"].shape
+        dev = rays_o.device
+        c = lambda g: None if g is None else g.contiguous().to(_F32)
+        g_image, g_wsum, g_depth, g_nmap, g_eik = c(g_image), c(g_wsum), c(g_depth), c(g_nmap), c(g_eik)
+        table = ctx.table
+        in_place = table.grad is not None and table.grad.is_contiguous() and table.grad.dtype == _F32
+        g_table = table.grad if in_place else torch.zeros_like(table)       # accumulated into, like hash_encode_backward (hashgrid.py:61-68)
+        g_sdf_p = torch.empty(64 * 36 + 16 * 64 + 16, dtype=_F32, device=dev)
+        g_col_p = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)
+        g_invs = torch.empty(N, dtype=_F32, device=dev)
+        sv = L.ac_core_saved(out["z_vals"].data_ptr(), out["pts"].data_ptr(), out["sdf"].data_ptr(), out["sdf_out16"].data_ptr(),
+                             out["gradient"].data_ptr(), out["color"].data_ptr(), out["eik_res"][1:].data_ptr())
+        upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
+        gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
+        scratch, need = core_scratch(field, N, T, dev)
+        op = out["_opts"][0]
+        L.check(L.lib().ac_render_core_backward(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), C.byref(sv), C.byref(upg),
+                                                C.byref(gr), scratch.data_ptr(), need, L.current_stream(dev)), "render_core_backward")
+        gW1b = g_sdf_p[:64 * 36].view(64, 36)
+        return (None if in_place else g_table, gW1b[:, :35], gW1b[:, 35], g_sdf_p[64 * 36:64 * 36 + 1024].view(16, 64), g_sdf_p[64 * 36 + 1024:],
+                g_col_p[:2048].view(64, 32)[:, :21], g_col_p[2048:6144].view(64, 64), g_col_p[6144:].view(16, 64)[:3],
+                g_invs.sum().reshape(ctx.inv_s_shape), None, None, None, None, None)
+
+
+def render_core(table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, offsets, per_level_scale, base_resolution, num_steps,
+                upsample_steps, bound, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0):
+    """-> image [N,3], weights_sum [N], depth [N], normal_map [N,3], gradient_error [], weights [N,T], alpha [N,T], color [N,T,3], z_vals [N,T]"""
+    cfg = ([int(v) for v in offsets], per_level_scale, int(base_resolution), int(num_steps), int(upsample_steps), float(bound),
+           float(cos_anneal_ratio), float(normal_epsilon_ratio))
+    return _RenderCore.apply(table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, cfg)
 
 
 class _SdfStencil(torch.autograd.Function):

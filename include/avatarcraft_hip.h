@@ -42,7 +42,7 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 1 */
+int ac_version(void);                /* ABI version, currently 2 */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
 
 /* ---- hash-grid encoder -------------------------------------------------------------------
@@ -138,6 +138,11 @@ typedef struct ac_render_opts {
     float cos_anneal_ratio;
     float fd_eps;             /* 0.005 * (1 - normal_epsilon_ratio)                               */
     int32_t perturb;          /* 1: z += (noise-0.5)*sample_dist (training && perturb_overwrite)  */
+    const float *inv_s_dev;   /* optional: inv_s as ONE float in device memory (then `inv_s` above is ignored): the trainable
+                                 variance stays on the device, no host read-back per render                                */
+    const float *near_m, *far_m; /* optional [N]: per-ray sampling range that replaces the cube's where finite (+-inf = keep the cube's):
+                                 the mesh-guided range of run(render_can=True, verts=..., use_mesh_guide=True), instant_nsr.py:147-153,
+                                 as produced by ac_mesh_near_far.  NULL = cube only.  (ac_render_rays_warped computes its own.)       */
 } ac_render_opts;
 
 typedef struct ac_render_out {
@@ -155,6 +160,8 @@ typedef struct ac_render_out {
     float *gradient;          /* [N,T,3]                                                          */
     int32_t *ss_inds;         /* [N, upsample_steps/16, 16]  searchsorted indices of sample_pdf   */
     int32_t *sort_index;      /* [N, upsample_steps/16, 128] sort permutation of cat_z_vals, -1 pad */
+    float *sdf_out16;         /* [N,T,16] forward_sdf at the mid points: sdf + the 15 geometry features   */
+    float *pts;               /* [N,T,3]  the mid points themselves (clamped to the bound)                */
 } ac_render_out;
 
 /* rays_o, rays_d [N,3]; bg [N,3] or NULL (= white, bg_color None -> 1); noise [N,num_steps] U[0,1)
@@ -167,6 +174,8 @@ int ac_render_rays(const ac_field *field, const ac_render_opts *opts, const floa
 /* gradient_error = sum(relax*err) / (sum(relax) + 1e-5) over the per-ray partials, fixed order
  * (instant_nsr.py:270-272); result: 1 float (device) */
 int ac_eikonal_reduce(const float *eik, int32_t n_rays, float *result, ac_stream_t stream);
+/* same, result: 2 floats (device) = { gradient_error, sum(relax) + 1e-5 } -- the denominator is what the backward of the term needs */
+int ac_eikonal_reduce2(const float *eik, int32_t n_rays, float *result2, ac_stream_t stream);
 
 /* SDF-only / field queries used by density(), extract_geometry() and the unit tests:
  * out16 [B,16] = forward_sdf(x) (instant_nsr.py:627-642), x [B,3] in [-bound,bound] */
@@ -278,6 +287,26 @@ int ac_composite_backward(const float *rays_o, const float *rays_d, const float 
                           const float *bg, int32_t n_rays, int32_t num_steps, int32_t T, float bound, float inv_s, float cos_anneal_ratio,
                           const float *g_image, const float *g_weights_sum, const float *g_depth, const float *g_normal_map,
                           float *g_sdf, float *g_normal, float *g_color, float *g_inv_s_per_ray, ac_stream_t stream);
+
+/* ---- the whole differentiable render core (models/instant_nsr.py:190-299) backward in one call (training path).
+ * The forward is ac_render_rays itself with the per-sample outputs kept (z_vals, pts, sdf, sdf_out16, gradient, color and the
+ * eikonal denominator of ac_eikonal_reduce2): the training render and the inference render are the same launch, bit for bit.
+ * The backward chains, on `stream`: normals from the finite-difference gradients -> NeuS alpha / compositing backward ->
+ * colour MLP backward -> normalisation + eikonal backward -> fused SDF-query backward -> table-gradient scatter.
+ *   upstream: d image [N,3], d weights_sum [N], d depth [N], d normal_map [N,3] (any may be NULL = 0), d gradient_error (1 float, device, or NULL)
+ *   results : g_table [offsets[16],2] ACCUMULATED into (like hash_encode_backward); g_sdf_params [3344] and g_color_params [7168]
+ *             (layouts of ac_sdf_stencil_backward / ac_color_backward, w.r.t. the EFFECTIVE matrices); g_inv_s_per_ray [N].
+ *   scratch : ac_render_core_backward_scratch(field, n_rays, T) bytes (~9 KB per sample, dominated by the scatter queues). */
+typedef struct ac_core_saved {
+    const float *z_vals, *pts, *sdf, *sdf_out16, *gradient, *color;      /* per-sample outputs of the forward launch */
+    const float *eik_den;                                                 /* result2[1] of ac_eikonal_reduce2          */
+} ac_core_saved;
+typedef struct ac_core_upstream { const float *g_image, *g_weights_sum, *g_depth, *g_normal_map, *g_eik; } ac_core_upstream;
+typedef struct ac_core_grads { float *g_table, *g_sdf_params, *g_color_params, *g_inv_s_per_ray; } ac_core_grads;
+size_t ac_render_core_backward_scratch(const ac_field *field, int32_t n_rays, int32_t T);
+int ac_render_core_backward(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d, const float *bg,
+                            const ac_core_saved *saved, const ac_core_upstream *upstream, const ac_core_grads *grads,
+                            void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
 /* ---- posed-space rendering: NeRFRenderer.run(render_can=False, verts, faces, Ts, use_mesh_guide)
  * models/instant_nsr.py:147-172 (mesh-guided near/far, warp of the coarse samples), :198-203 (warp of the mid points),

@@ -377,3 +377,122 @@ def test_smpl_on_device_matches_reference_golden():
     rgb, _, ex = render_instantnsr_naive(net, torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV), 64, requires_grad=False, render_can=False, perturb=False,
                                          return_raw=True, verts=wv[1], faces=np.asarray(bm2.faces), Ts=Ts[1], num_steps=32, upsample_steps=32, bound=1.6)
     assert rgb.shape == (64, 3) and torch.isfinite(rgb).all()
+
+
+@pytest.mark.parametrize("n_side,T0,up,perturb", [(10, 64, 64, True), (7, 32, 32, False), (3, 64, 0, True)])
+def test_render_core_operator(n_side, T0, up, perturb):
+    """nsr_ops.render_core ("core": forward = the fused renderer itself, backward = ac_render_core_backward) against
+    (a) the no-grad render: every forward output bit for bit (the training render IS the inference launch);
+    (b) the operator-by-operator training path of round 1 ("ops": sampling launch + fused SDF query / colour / compositing operators with
+        torch autograd between them) and (c) plain torch autograd over the stencil hash encoder (False): all parameter gradients, with a loss
+        that uses every differentiable output (image, weights_sum, depth, normal_map, gradient_error)."""
+    net, p = golden_net(train=True)
+    ro, rd = make_rays(n_side, n_side, dist=1.8, f=0.6 * n_side, jitter_seed=n_side)
+    ro, rd = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    N = ro.shape[0]
+    rs = np.random.RandomState(N)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(DEV)
+    noise = t(rs.uniform(0, 1, (N, T0)))
+    bg = t(rs.uniform(0, 1, (N, 3)))
+    w_img, w_ws, w_dp, w_nm = t(rs.normal(size=(N, 3))), t(rs.normal(size=(N, 1))), t(rs.normal(size=(1, N))), t(rs.normal(size=(N, 3)))
+
+    def run(mode):
+        net.fused_training = mode
+        net.zero_grad()
+        orig = torch.rand
+        torch.rand = lambda *a, **k: noise
+        try:
+            out = net.render(ro[None], rd[None], num_steps=T0, bound=1.6, upsample_steps=up, staged=False, bg_color=bg, cos_anneal_ratio=1.0,
+                             normal_epsilon_ratio=0.0, render_can=True, perturb=perturb)
+        finally:
+            torch.rand = orig
+        loss = ((out["rgb"][0] * w_img).sum() + (out["weight_sum"] * w_ws).sum() + (out["depth"] * w_dp).sum() + (out["normal"] * w_nm).sum()
+                + 3.0 * out["gradient_error"])
+        loss.backward()
+        return {k: v.detach().clone() for k, v in out.items() if isinstance(v, torch.Tensor)}, {k: q.grad.detach().clone() for k, q in net.named_parameters()}
+    o_core, g_core = run("core")
+    o_ops, g_ops = run("ops")
+    o_ag, g_ag = run(False)
+    with torch.no_grad():
+        orig = torch.rand
+        torch.rand = lambda *a, **k: noise
+        try:
+            o_ng = net.render(ro[None], rd[None], num_steps=T0, bound=1.6, upsample_steps=up, staged=False, bg_color=bg, cos_anneal_ratio=1.0,
+                              normal_epsilon_ratio=0.0, render_can=True, perturb=perturb)
+        finally:
+            torch.rand = orig
+    for k in ("rgb", "weight_sum", "depth", "normal", "weights", "pts_color", "pts_alpha", "z_vals", "gradient_error"):
+        assert torch.equal(o_core[k], o_ng[k]), k                       # (a)
+        assert torch.allclose(o_core[k], o_ops[k], atol=2e-5, rtol=1e-4), k
+    assert set(g_core) == set(g_ops) == set(g_ag) and len(g_core) == 15
+    worst = {}
+    for k in g_core:
+        scale = float(g_ag[k].abs().max())
+        assert scale > 0, k
+        worst[k] = (float((g_core[k] - g_ops[k]).abs().max()) / scale, float((g_core[k] - g_ag[k]).abs().max()) / scale)
+        assert worst[k][0] <= 1e-3 and worst[k][1] <= 3e-3, (k, worst[k])    # (b), (c)
+    # gradients accumulate into an existing .grad (stylize.py back-propagates three terms one after the other) ...
+    net.fused_training = "core"
+    net.zero_grad()
+    from avatarcraft_amd.stylize import flat_grad_view
+    flat = flat_grad_view(net.parameters())
+    orig = torch.rand
+    torch.rand = lambda *a, **k: noise
+    try:
+        out = net.render(ro[None], rd[None], num_steps=T0, bound=1.6, upsample_steps=up, staged=False, bg_color=bg, cos_anneal_ratio=1.0,
+                         normal_epsilon_ratio=0.0, render_can=True, perturb=perturb)
+    finally:
+        torch.rand = orig
+    (out["rgb"][0] * w_img).sum().backward(retain_graph=True)
+    ((out["weight_sum"] * w_ws).sum() + (out["depth"] * w_dp).sum()).backward(retain_graph=True)
+    ((out["normal"] * w_nm).sum() + 3.0 * out["gradient_error"]).backward()
+    for k, q in net.named_parameters():                                     # ... and the three partial backward passes add up to the joint one
+        scale = float(g_core[k].abs().max())
+        assert float((q.grad - g_core[k]).abs().max()) <= 2e-4 * scale + 1e-12, k
+        assert q.grad.data_ptr() >= flat.data_ptr() and q.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4        # still views of the flat buffer
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(worst, open(f"gpurun_out/render_core_parity_{N}.json", "w"), indent=1)
+
+
+def test_render_variants_generic_path():
+    """model variants the fused renderer does not cover run through the generic path (fused sampling + torch MLPs over the HIP hash encoder):
+    use_viewdirs=True (SH-encoded directions into the colour net, models/instant_nsr.py:564-569,652-653) and curvature_loss=True (:276-288),
+    with and without gradients; a canonical render inside the mesh-guided range (verts given, :147-153); normal_epsilon_ratio >= 1 is refused"""
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    from tests.common import make_body
+    torch.manual_seed(1)
+    ro, rd = make_rays(6, 6, dist=1.8, f=4.0)
+    ro, rd = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    kw = dict(num_steps=32, bound=1.6, upsample_steps=32, staged=False, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True)
+    for opts in (dict(use_viewdirs=True), dict(curvature_loss=True)):
+        net = NeRFNetwork(**opts).to(DEV).train()
+        with torch.no_grad():
+            net.encoder.embeddings.uniform_(-0.05, 0.05)
+            net.sdf_net[0].weight_v[:, 3:].normal_(0, 0.05)
+        out = net.render(ro[None], rd[None], perturb=True, **kw)
+        assert out["rgb"].shape == (1, 36, 3) and torch.isfinite(out["rgb"]).all()
+        (out["rgb"].sum() + out["gradient_error"] + out["curvature_error"]).backward()
+        assert net.color_net[0].weight_v.grad is not None and float(net.encoder.embeddings.grad.abs().sum()) > 0
+        if opts.get("use_viewdirs"):
+            assert net.color_net[0].weight_v.shape == (64, 37)
+        else:
+            assert float(out["curvature_error"]) > 0
+        with torch.no_grad():
+            out2 = net.eval().render(ro[None], rd[None], perturb=False, **kw)
+        assert torch.isfinite(out2["rgb"]).all() and out2["weights"].shape == (36, 64)
+    net, _ = golden_net()
+    verts, faces, Ts = make_body(n_lat=12, n_lon=16)
+    with torch.no_grad():
+        a = net.render(ro[None], rd[None], verts=verts, faces=faces, Ts=Ts, use_mesh_guide=True, **kw)
+        b = net.render(ro[None], rd[None], verts=verts, faces=faces, Ts=Ts, use_mesh_guide=False, **kw)
+        c = net.render(ro[None], rd[None], **kw)
+    assert torch.equal(b["rgb"], c["rgb"]) and not torch.equal(a["z_vals"], c["z_vals"])
+    from avatarcraft_amd.ray_utils import geometry_guided_near_far
+    nm, fm = geometry_guided_near_far(ro, rd, verts, 0.05)
+    hit = torch.isfinite(nm)
+    assert hit.any() and (~hit).any()
+    assert torch.allclose(a["z_vals"][hit].min(1).values, nm[hit], atol=1e-6) and torch.equal(a["z_vals"][~hit], c["z_vals"][~hit])
+    with pytest.raises(RuntimeError, match="fd_eps"):
+        with torch.no_grad():
+            net.render(ro[None], rd[None], num_steps=32, bound=1.6, upsample_steps=32)      # the reference's default normal_epsilon_ratio = 1: eps = 0

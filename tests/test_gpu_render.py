@@ -209,7 +209,7 @@ def test_warped_render_bad_arguments(env):
     with pytest.raises(RuntimeError, match="unsupported"):
         nsr_ops.render_rays(env["f"], t(ro), t(rd), 24, 32, 1.6, 1.0, warp=wm)
     # scratch too small is refused
-    op = L.ac_render_opts(16, 32, 32, 1.6, 1.0, 1.0, 0.005, 0)
+    op = L.ac_render_opts(16, 32, 32, 1.6, 1.0, 1.0, 0.005, 0, None, None, None)
     o = L.ac_render_out()
     for k in ("image", "weights_sum", "depth", "normal_map", "eik"):
         setattr(o, k, torch.empty(64, device="cuda:0").data_ptr())
