@@ -244,8 +244,12 @@ class _RenderCore(torch.autograd.Function):
         field = Field(d(table), offsets, pls, H, d(W1), d(b1), d(W2), d(b2), d(Wc1), d(Wc2), d(Wc3))
         out = render_rays(field, rays_o, rays_d, T0, up, bound, inv_s, bg=bg, noise=noise, cos_anneal_ratio=car, normal_epsilon_ratio=ner,
                           extras=True, train_extras=True)
-        ctx.field, ctx.out, ctx.cfg = field, out, cfg
-        ctx.rays = (rays_o, rays_d, bg)
+        ctx.field, ctx.cfg = field, cfg
+        ctx.opts = out["_opts"]                                    # the launch's ac_render_opts (+ the tensors its pointers refer to)
+        ctx.has_bg = bg is not None
+        # outputs among the saved tensors (z_vals, color) must go through save_for_backward (no reference cycle through ctx)
+        ctx.save_for_backward(out["z_vals"], out["pts"], out["sdf"], out["sdf_out16"], out["gradient"], out["color"], out["eik_res"], rays_o, rays_d,
+                              bg if bg is not None else rays_o)
         ctx.table = table
         ctx.inv_s_shape = inv_s.shape
         ctx.mark_non_differentiable(out["weights"], out["alpha"], out["color"], out["z_vals"])
@@ -254,9 +258,11 @@ class _RenderCore(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_image, g_wsum, g_depth, g_nmap, g_eik, *_unused):
-        field, out = ctx.field, ctx.out
-        rays_o, rays_d, bg = ctx.rays
-        N, T = out["z_vals"].shape
+        field = ctx.field
+        z_vals, pts, sdf, sdf16, gradient, color, eik_res, rays_o, rays_d, bg = ctx.saved_tensors
+        if not ctx.has_bg:
+            bg = None
+        N, T = z_vals.shape
         dev = rays_o.device
         c = lambda g: None if g is None else g.contiguous().to(_F32)
         g_image, g_wsum, g_depth, g_nmap, g_eik = c(g_image), c(g_wsum), c(g_depth), c(g_nmap), c(g_eik)
@@ -266,12 +272,12 @@ class _RenderCore(torch.autograd.Function):
         g_sdf_p = torch.empty(64 * 36 + 16 * 64 + 16, dtype=_F32, device=dev)
         g_col_p = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)
         g_invs = torch.empty(N, dtype=_F32, device=dev)
-        sv = L.ac_core_saved(out["z_vals"].data_ptr(), out["pts"].data_ptr(), out["sdf"].data_ptr(), out["sdf_out16"].data_ptr(),
-                             out["gradient"].data_ptr(), out["color"].data_ptr(), out["eik_res"][1:].data_ptr())
+        sv = L.ac_core_saved(z_vals.data_ptr(), pts.data_ptr(), sdf.data_ptr(), sdf16.data_ptr(), gradient.data_ptr(), color.data_ptr(),
+                             eik_res[1:].data_ptr())
         upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
         gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
         scratch, need = core_scratch(field, N, T, dev)
-        op = out["_opts"][0]
+        op = ctx.opts[0]
         L.check(L.lib().ac_render_core_backward(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), C.byref(sv), C.byref(upg),
                                                 C.byref(gr), scratch.data_ptr(), need, L.current_stream(dev)), "render_core_backward")
         gW1b = g_sdf_p[:64 * 36].view(64, 36)

@@ -47,17 +47,25 @@ def flat_grad_view(params):
 
 
 def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_size=4096, w_eikonal=0.01, use_opacity=True,
-             bkg_key=WHITE_BKG, flat_grad=None, process_group=None, num_steps=64, upsample_steps=64):
-    """rays_o, rays_d: [h*w, 3] of the (sub-sampled) training view; hw = (h, w).  Returns a dict of scalars."""
+             bkg_key=WHITE_BKG, flat_grad=None, process_group=None, num_steps=64, upsample_steps=64, timers=None):
+    """rays_o, rays_d: [h*w, 3] of the (sub-sampled) training view; hw = (h, w).  Returns a dict of scalars.
+    timers: a list that receives (phase name, torch.cuda.Event) marks on the current stream (bench.py's per-phase times)."""
     h, w = hw
     n_rays = h * w
+
+    def mark(name):
+        if timers is not None:
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); timers.append((name, ev))
+    mark("start")
     # (A) render_val: net_style stays in train mode (stylize.py never calls eval()), no grad
     rgb_val, _ = render_instantnsr_naive(net_style, rays_o, rays_d, rays_per_batch=batch_size, requires_grad=False, bkg_key=bkg_key,
                                          render_can=True, perturb=True, num_steps=num_steps, upsample_steps=upsample_steps, bound=NSR_BOUND)
     img = rgb_val.reshape(h, w, 3).permute(2, 0, 1).unsqueeze(0)             # "(h w) c -> 1 c h w"
+    mark("render_val")
     # (B) gradient of the guidance loss w.r.t. the whole image
     grad_img = guidance(img.detach())
     grad_rays = grad_img.squeeze(0).permute(1, 2, 0).reshape(n_rays, 3).detach()
+    mark("guidance")
     # (C) patch-wise backward
     if flat_grad is not None:
         flat_grad.zero_()
@@ -71,6 +79,7 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                                                   return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
                                                   upsample_steps=upsample_steps)
         opacity_pred = extra["weight_sum"]
+        mark("render_grad_forward")
         # The reference back-propagates the three terms one after the other through the same retained graph
         # (stylize.py:163,169,193).  Gradients are linear in the loss, so ONE backward pass of their sum gives the same
         # parameter gradients with a third of the hash-table scatter traffic.
@@ -86,17 +95,24 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
         opa_vals.append(opacity_loss.detach())
         if use_opacity:
             total = total + opacity_loss
+        mark("render_gt_and_losses")
         total.backward()
-    # data parallel: one collective over the flat gradient
+        mark("backward")
+    # data parallel: one collective over the flat gradient (issued whenever a process group exists, world size 1 included: the call
+    # path RCCL sees on an 8-GPU node is then the one every single-GPU run exercises)
     if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
         world = torch.distributed.get_world_size(process_group)
-        if world > 1:
-            if flat_grad is None:
+        if flat_grad is None:
+            if world > 1:
                 raise RuntimeError("data-parallel sds_step needs flat_grad = flat_grad_view(net_style.parameters())")
+        else:
             torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
-            flat_grad.div_(world)
+            if world > 1:
+                flat_grad.div_(world)
+            mark("grad_allreduce")
     # (D)
     optimizer.step()
+    mark("optimizer")
     return {"eikonal": torch.stack(eik_vals).mean() if eik_vals else torch.zeros(()), "opacity": torch.stack(opa_vals).mean()}
 
 

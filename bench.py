@@ -67,63 +67,174 @@ def cpu_baseline(p, table, ro, rd, budget_s=12.0):
                 sample=f"{n} rays (every {max(1, ro.shape[0] // n)}-th ray of the 256x256 view), 64+64 samples, {dt:.1f} s wall, OpenMP over rays")
 
 
+SAMPLES = NUM_STEPS + UPSAMPLE_STEPS
+# ALGORITHMIC bytes of one 4096-ray SDS step (SURVEY 8d per-unit figures: 1024 B gathered per hash evaluation forward, 2048 B
+# read-modify-write per evaluation backward), for the work this implementation actually launches ...
+SDS_BYTES_LAUNCHED = {
+    "render_val (no-grad render of net_style)": RAYS_PER_BATCH * BYTES_PER_RAY,
+    "grad render forward (the same fused launch, per-sample outputs kept)": RAYS_PER_BATCH * BYTES_PER_RAY,
+    "net_gt render (frozen avatar, opacity target)": RAYS_PER_BATCH * BYTES_PER_RAY,
+    "sdf_stencil_bwd (re-gather of the 7 stencil points of every sample)": RAYS_PER_BATCH * SAMPLES * 7 * 1024,
+    "table-gradient scatter (hash_stencil_bwd_binned + bucket_accumulate)": RAYS_PER_BATCH * SAMPLES * 7 * 2048,
+}
+# ... and SURVEY 8(d)'s contract figure for the reference's schedule (3 forward renders + 3 backward passes of 7, 6 and 7 evaluations per sample)
+SDS_BYTES_SURVEY = 3 * RAYS_PER_BATCH * BYTES_PER_RAY + (7 + 6 + 7) * RAYS_PER_BATCH * SAMPLES * 2048
+
+
+def make_net(p, table, dev, train):
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    torch.manual_seed(0)
+    net = NeRFNetwork()
+    sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
+    sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
+    net.load_state_dict(sd)
+    return net.to(dev).train(train)
+
+
+def sds_view(rank):
+    """the 64x64 stride-4 sub-sampled rays of a 256x256 training camera (stylize.py:98-107), one view per rank"""
+    from tests.common import make_rays
+    yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
+    ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=yaw, pitch=0.0)
+    return ro.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy(), rd.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy()
+
+
 def time_sds_step(dev, p, table, rank, world, dist, steps):
     """secondary metric: ms per 4096-ray SDS step (stylize.py coarse stage: 64x64 sub-sampled view of a 256x256 camera,
-    3 renders + 3 backward passes per patch, Adam, all-reduce of the 49 MB flat gradient when world > 1).  Synthetic guidance
-    (the SD UNet is out of scope); the differentiable render core runs on the fused HIP training operators."""
-    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    3 renders + the backward of the three loss terms per patch, Adam, all-reduce of the 49 MB flat gradient when a process group exists).
+    Synthetic guidance (the SD UNet is out of scope).  Carries its own roofline (algorithmic bytes of the launched work / step time) and
+    HIP-event times per phase of the step."""
     from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view
-    from tests.common import make_rays
-
-    def make_net(train):
-        torch.manual_seed(0)
-        net = NeRFNetwork()
-        sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
-        sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
-        net.load_state_dict(sd)
-        return net.to(dev).train(train)
-    net, net_gt = make_net(True), make_net(False)
+    net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
     opt = torch.optim.Adam(net.parameters(), lr=5e-3, fused=os.environ.get("AC_FUSED_ADAM", "1") == "1")     # one kernel for the 12.2 M parameters
     flat = flat_grad_view(net.parameters())
     guidance = SyntheticGuidance(42 + rank)
-    yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
-    ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=yaw, pitch=0.0)
-    ro = torch.from_numpy(ro.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy()).to(dev)      # stride-4 sub-sampling -> 64x64
-    rd = torch.from_numpy(rd.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy()).to(dev)
-    sds_step(net, net_gt, ro, rd, (64, 64), opt, guidance, batch_size=4096, flat_grad=flat)        # warm-up
+    ro, rd = sds_view(rank)
+    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    for _ in range(2):
+        sds_step(net, net_gt, ro, rd, (64, 64), opt, guidance, batch_size=4096, flat_grad=flat)        # warm-up
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier(); torch.cuda.synchronize()
+    marks = []
     t0 = time.perf_counter()
     for _ in range(steps):
-        sds_step(net, net_gt, ro, rd, (64, 64), opt, guidance, batch_size=4096, flat_grad=flat)
+        sds_step(net, net_gt, ro, rd, (64, 64), opt, guidance, batch_size=4096, flat_grad=flat, timers=marks)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
-    return {"ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad + 1 frozen",
-            "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)", "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if world > 1 else 0,
-            "core": "HIP sampling launch + fused SDF query / colour MLP / compositing operators (MFMA forward + backward with recomputation), binned two-pass table scatter; torch: weight norm, losses, Adam"}
+    phases = {}
+    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+        if n1 != "start":
+            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
+    ms = dt / steps * 1e3
+    launched = sum(SDS_BYTES_LAUNCHED.values())
+    ach = launched / (ms * 1e-3) / 1e9
+    res = {"ms_per_step": ms, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad + 1 frozen",
+           "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)", "phase_ms": {k: round(v, 4) for k, v in phases.items()},
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_step": launched, "bytes_by_kernel": SDS_BYTES_LAUNCHED,
+                        "survey_contract_bytes_per_step": SDS_BYTES_SURVEY, "frac_of_survey_contract": SDS_BYTES_SURVEY / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None},
+           "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if dist is not None else 0,
+           "grad_allreduce_ms": round(phases.get("grad_allreduce", 0.0), 4),
+           "core": "training render = ONE operator: forward = ac_render_rays (the inference launch, per-sample outputs kept), backward = "
+                   "ac_render_core_backward (compositing, colour MLP, normalisation + eikonal, fused SDF query with recomputation, binned two-pass "
+                   "table scatter); torch: weight norm, the three loss terms, fused Adam"}
+    return res, (net, net_gt)
 
 
-def time_posed_frame(dev, p, table, frames):
+def cpu_baseline_sds(p, table, n_side=16):
+    """CPU leg of the SDS step on a bounded sample (n_side^2 rays of the same training view): the no-grad renders through the C oracle
+    (OpenMP), the differentiable render core as torch-CPU autograd (MKL threads) over a hash encoder served by the oracle's forward /
+    backward -- the structure of the reference's own CPU path (pure PyTorch + its hash kernel), with the reference's three backward
+    passes folded into one like the GPU path.  kind = "port"."""
+    import torch.nn as nn
+    from oracle import oracle as O
+    from tests.gpu_common import oracle_field
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    class _Enc(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x01, emb, offsets, S):
+            out, _, _ = O.hash_encode_forward(x01.detach().numpy(), emb.detach().numpy(), offsets, S, 16)
+            ctx.save_for_backward(x01, emb); ctx.o = (offsets, S)
+            return torch.from_numpy(np.ascontiguousarray(out.transpose(1, 0, 2).reshape(x01.shape[0], -1)))
+
+        @staticmethod
+        def backward(ctx, g):
+            x01, emb = ctx.saved_tensors
+            gl = np.ascontiguousarray(g.numpy().reshape(x01.shape[0], 16, 2).transpose(1, 0, 2))
+            gg, _ = O.hash_encode_backward(gl, x01.numpy(), emb.detach().numpy(), ctx.o[0], ctx.o[1], 16, None)
+            return None, torch.from_numpy(gg), None, None
+
+    class OracleEncoder(nn.Module):               # stands where HashEncoder stands (no forward_stencil: 7 encoder calls per sample, like the reference)
+        def __init__(self, emb, offsets, pls):
+            super().__init__()
+            self.embeddings = nn.Parameter(emb); self.offsets_np = offsets; self.S = np.float32(np.log2(pls))
+            self.num_levels, self.level_dim, self.input_dim, self.per_level_scale, self.base_resolution = 16, 2, 3, pls, 16
+
+        def forward(self, x, size=1):
+            return _Enc.apply((x + size) / (2 * size), self.embeddings, self.offsets_np, self.S)
+
+    def cpu_net(train):
+        torch.manual_seed(0)
+        net = NeRFNetwork()
+        sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
+        net.load_state_dict(sd, strict=False)
+        net.encoder = OracleEncoder(torch.from_numpy(table.copy()), np.asarray(p["offsets"], np.int32), float(p["per_level_scale"]))
+        net.fused_training = False
+        return net.train(train)
+    net = cpu_net(True)
+    of = oracle_field(p, table)
+    ro, rd = sds_view(0)
+    idx = np.arange(0, 4096, 4096 // (n_side * n_side))[:n_side * n_side]
+    ro, rd = ro[idx], rd[idx]
+    n = ro.shape[0]
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    rs = np.random.RandomState(0)
+    inv_s = float(p["inv_s"])
+
+    def step():
+        noise = rs.uniform(0, 1, (n, NUM_STEPS)).astype(np.float32)
+        O.render_rays(of, ro, rd, NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, noise=noise, extras=False)                       # (A) render_val
+        g_img = torch.from_numpy(np.clip(rs.normal(0, 1, (n, 3)), -1, 1).astype(np.float32))                              # (B) synthetic guidance
+        opt.zero_grad()
+        noise = rs.uniform(0, 1, (n, NUM_STEPS)).astype(np.float32)
+        z = O.render_rays(of, ro, rd, NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, noise=noise)["z_vals"]                       # (C) sampling stage (no grad)
+        tro, trd = torch.from_numpy(ro), torch.from_numpy(rd)
+        out = net._render_core_autograd(tro, trd, torch.from_numpy(z), NUM_STEPS, UPSAMPLE_STEPS, 1.6, None, 1.0, 0.0, 1, n)
+        wgt = O.render_rays(of, ro, rd, NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, extras=False)["weights_sum"]             # frozen net_gt
+        opa = torch.nn.functional.smooth_l1_loss(out[2].clamp(0, 1), torch.from_numpy(wgt).reshape(-1, 1).clamp(0, 1)) * 1e5
+        ((out[3][0] * g_img).sum() + 0.01 * out[5] + opa).backward()
+        opt.step()                                                                                                        # (D)
+    step()
+    t0 = time.time(); reps = 0
+    while reps < 1 or (time.time() - t0 < 8.0 and reps < 8):
+        step(); reps += 1
+    dt = (time.time() - t0) / reps
+    return dict(value=n / dt, unit="rays/s (SDS steps)", ms_per_4096_ray_step_equivalent=dt * 1e3 * 4096 / n, cores=cores, kind="port",
+                sample=f"{reps} step(s) of {n} rays (every {4096 // n}-th ray of the 4096-ray training view), 64+64 samples, {dt:.2f} s each: C oracle (OpenMP) "
+                       f"for the two no-grad renders and the sampling stage, torch-CPU autograd ({torch.get_num_threads()} threads) over the oracle's hash "
+                       f"forward/backward for the render core, torch Adam on 12.2 M parameters")
+
+
+def time_posed_frame(dev, p, table, frames, cpu=True):
     """secondary metric: ms per 256x256 frame of render_warp.py (BASELINE config 4): posed-space rendering, 32+32 samples per ray,
     8192-ray batches like the reference driver, SMPL-sized synthetic body (6 891 vertices / 13 778 faces, per-vertex 4x4), mesh uploaded
-    and its culling structure rebuilt once per frame.  The reference does the two warps of every batch on the CPU (libigl)."""
-    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    and its culling structure rebuilt once per frame.  The reference does the two warps of every batch on the CPU (libigl).
+    roofline: SURVEY 8(d)'s 507 904 gather bytes per ray (496 hash evaluations) x 65 536 rays / frame time."""
     from avatarcraft_amd.render_utils import render_instantnsr_naive
     from tests.common import make_rays, make_body
-    torch.manual_seed(0)
-    net = NeRFNetwork()
-    sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
-    sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
-    net.load_state_dict(sd)
-    net = net.to(dev).eval()
+    net = make_net(p, table, dev, False)
     verts, faces, Ts = make_body(n_lat=83, n_lon=83)
-    ro, rd = make_rays(256, 256, dist=1.8, f=443.405 / 2, yaw=0.3, pitch=-0.1)
-    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    ro_h, rd_h = make_rays(256, 256, dist=1.8, f=443.405 / 2, yaw=0.3, pitch=-0.1)
+    ro, rd = torch.from_numpy(ro_h).to(dev), torch.from_numpy(rd_h).to(dev)
 
     def frame():
         rgb, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=8192, requires_grad=False, render_can=False, perturb=False, verts=verts, faces=faces,
@@ -135,8 +246,24 @@ def time_posed_frame(dev, p, table, frames):
         rgb = frame()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / frames
-    return {"ms_per_frame": dt * 1e3, "rays_per_s": 65536 / dt, "frames": frames, "samples_per_ray": "32+32", "mesh": "synthetic 6891 verts / 13778 faces",
-            "covered": float((rgb < 0.999).any(dim=1).float().mean())}
+    bytes_frame = 65536 * 496 * 1024
+    ach = bytes_frame / dt / 1e9
+    res = {"ms_per_frame": dt * 1e3, "rays_per_s": 65536 / dt, "frames": frames, "samples_per_ray": "32+32", "mesh": "synthetic 6891 verts / 13778 faces",
+           "covered": float((rgb < 0.999).any(dim=1).float().mean()),
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_frame": bytes_frame, "note": "gather bytes of the field only; the frame also runs 6.3 M exact closest-face "
+                        "searches over 13 778 faces (warp_samples_accel_kernel), which no byte count prices", "traffic": None}}
+    if cpu:
+        from oracle import oracle as O
+        from tests.gpu_common import oracle_field
+        of = oracle_field(p, table)
+        idx = np.arange(0, 65536, 65536 // 48)[:48]
+        t0 = time.time()
+        O.render_rays(of, ro_h[idx], rd_h[idx], 32, 32, 1.6, float(p["inv_s"]), warp=dict(verts=verts, faces=faces, Ts=Ts, use_mesh_guide=True), extras=False)
+        dtc = time.time() - t0
+        res["cpu_baseline"] = dict(value=48 / dtc, unit="rays/s", cores=os.cpu_count() or 1, kind="port",
+                                   sample=f"48 rays of the frame (every {65536 // 48}-th), 32+32 samples, exhaustive fp64 closest-face search (OpenMP over rays), {dtc:.1f} s")
+    return res
 
 
 def main():
@@ -205,9 +332,16 @@ def main():
     sds = None
     if a.sds_steps > 0:
         try:                                   # secondary metric: never let it take the headline line down with it
-            sds = time_sds_step(dev, p, table, rank, world, dist, a.sds_steps)
+            sds, _nets = time_sds_step(dev, p, table, rank, world, dist, a.sds_steps)
+            del _nets
+            if rank == 0 and world == 1 and not a.no_cpu_baseline:
+                sds["cpu_baseline"] = cpu_baseline_sds(p, table)
+            pt = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(pt):
+                sds["roofline"]["traffic"] = json.load(open(pt)).get("sds_step_hbm_bytes_per_step")
         except Exception as e:                 # noqa: BLE001
-            sds = {"error": f"{type(e).__name__}: {e}"}
+            import traceback
+            sds = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-600:]}
 
     if rank == 0:
         total_rays = world * a.steps * RAYS_PER_BATCH
@@ -234,11 +368,13 @@ def main():
             res["sds_step"] = sds
         if world == 1 and a.posed_frames > 0:
             try:
-                res["posed_frame"] = time_posed_frame(dev, p, table, a.posed_frames)
+                res["posed_frame"] = time_posed_frame(dev, p, table, a.posed_frames, cpu=not a.no_cpu_baseline)
             except Exception as e:             # noqa: BLE001
                 res["posed_frame"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, table, ro, rd)
+        if world > 1 and sds is not None and "error" not in sds:
+            res["sds_step"]["note"] = "N > 1: one view per rank, one all-reduce (RCCL, sum then / world) of the flat 49 MB gradient per step"
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
