@@ -594,12 +594,29 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
     n = n < cap ? n : cap;
     const uint32_t mbits = qcount[(size_t)gridDim.y * NBUCKET + blockIdx.y];
     if (n == 0 || mbits == 0 || mine == 0) return;                                   // wave-uniform: nothing queued for this bucket
+    const Rec *q = queues + ((size_t)blockIdx.y * NBUCKET + bucket) * cap;
+    float *dst = grad_grid + ((size_t)lt.offset[level] + (size_t)first) * 2;
+    if ((mbits >> 23) == 255u) {
+        // an Inf or NaN record on this level (the largest |v| carries exponent 255): no fixed-point scale exists.  Sum this bucket in float
+        // instead (slow LDS float atomics, but only ever on a diverged step), so that Inf / NaN reach the table exactly as the
+        // reference's atomicAdd would deliver them (hashencoder.cu:302-305) instead of being quantised away.
+        float *accf = reinterpret_cast<float *>(acc);
+        for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) accf[e] = 0.0f;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const Rec r = q[i];
+            atomicAdd(&accf[2 * r.idx], r.v0); atomicAdd(&accf[2 * r.idx + 1], r.v1);
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < mine * 2; e += blockDim.x)
+            if (accf[e] != 0.0f) dst[e] += accf[e];                                  // NaN != 0 is true: NaN is written
+        return;
+    }
     for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) acc[e] = 0ull;
     __syncthreads();
     const int emax = (int)(mbits >> 23) - 126;                                       // |v| < 2^emax for every record of the level
     const int head = 32 - __builtin_clz(n);                                          // ceil(log2(n + 1))
     const int k = 62 - head - emax;
-    const Rec *q = queues + ((size_t)blockIdx.y * NBUCKET + bucket) * cap;
     constexpr int U = 4;
     for (uint32_t i0 = threadIdx.x; i0 < n; i0 += blockDim.x * U) {
         Rec r[U];
@@ -616,7 +633,6 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
         }
     }
     __syncthreads();
-    float *dst = grad_grid + ((size_t)lt.offset[level] + (size_t)first) * 2;
     for (uint32_t e = threadIdx.x; e < mine * 2; e += blockDim.x) {
         const long long v = (long long)acc[e];
         if (v != 0) dst[e] += (float)ldexp((double)v, -k);

@@ -14,22 +14,35 @@ def _floating(t, name):
 
 
 PRIVATE_COPIES = 16         # private copies of the small dense levels in the stencil backward (same-address atomic bursts)
-_SCRATCH = {}
+_SCRATCH = {}               # (kind, device, stream, layout) -> uint8 tensor, grown to the largest batch seen (free_scratch() drops them)
 
 
 BINNED_SCATTER = True       # hashed levels through the binned two-pass scatter (needs ~8 KB of device scratch per sample)
 
 
+def _scratch_buffer(key, nbytes, device):
+    """One buffer per (kind, device, STREAM, table layout): two streams never share queues (concurrent backward passes would race on the
+    slot counters), a smaller batch (the last partial batch of an epoch) re-uses the buffer of the largest one instead of re-allocating."""
+    key = key + (int(L.current_stream(device) or 0),)
+    cur = _SCRATCH.get(key)
+    if nbytes and (cur is None or cur.numel() < nbytes):
+        _SCRATCH[key] = None                       # release the old one first
+        cur = _SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return cur
+
+
+def free_scratch():
+    """release the cached scatter queues (multi-GB for training batches)"""
+    _SCRATCH.clear()
+
+
 def stencil_scratch(offsets_host, L_, S, H, device, B=0):
-    """(tensor, nbytes): device scratch for ac_hash_stencil_backward, cached per (device, layout, batch size); (None, 0) if not needed"""
+    """(tensor, nbytes): device scratch for ac_hash_stencil_backward on the current stream; (None, 0) if not needed"""
     B = int(B) if BINNED_SCATTER else 0
-    key = (str(device), int(offsets_host[-1]), L_, S, H, B)
-    if key not in _SCRATCH:
-        for k in [k for k in _SCRATCH if k[:5] == key[:5]]:          # one batch size at a time per layout: free the previous queues
-            del _SCRATCH[k]
-        nbytes = int(L.lib().ac_hash_stencil_backward_scratch(offsets_host.ctypes.data, L_, S, H, PRIVATE_COPIES, B))
-        _SCRATCH[key] = (torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None, nbytes)
-    return _SCRATCH[key]
+    nbytes = int(L.lib().ac_hash_stencil_backward_scratch(offsets_host.ctypes.data, L_, S, H, PRIVATE_COPIES, B))
+    if not nbytes:
+        return None, 0
+    return _scratch_buffer(("stencil", str(device), int(offsets_host[-1]), L_, S, H, bool(B)), nbytes, device), nbytes
 
 
 class _Backend:
@@ -64,13 +77,10 @@ class _Backend:
             _floating(t, n)
         oh = _Backend._offsets_host(offsets)
         Sf = float(np.float32(S))
-        key = ("enc", str(inputs.device), int(oh[-1]), D, C, L_, Sf, H, int(B))
-        if BINNED_SCATTER and not calc_grad_inputs and key not in _SCRATCH:
-            for k in [k for k in _SCRATCH if k[:8] == key[:8]]:
-                del _SCRATCH[k]
+        scratch, nbytes = None, 0
+        if BINNED_SCATTER and not calc_grad_inputs:
             nbytes = int(L.lib().ac_hash_encode_backward_scratch(oh.ctypes.data, D, C, L_, Sf, H, B))
-            _SCRATCH[key] = (torch.empty(nbytes, dtype=torch.uint8, device=inputs.device) if nbytes else None, nbytes)
-        scratch, nbytes = _SCRATCH.get(key, (None, 0)) if BINNED_SCATTER and not calc_grad_inputs else (None, 0)
+            scratch = _scratch_buffer(("enc", str(inputs.device), int(oh[-1]), D, C, L_, Sf, H), nbytes, inputs.device) if nbytes else None
         L.check(L.lib().ac_hash_encode_backward_ws(grad.data_ptr(), inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(),
                                                    oh.ctypes.data, grad_embeddings.data_ptr(), B, D, C, L_, Sf, H,
                                                    int(bool(calc_grad_inputs)), dy_dx.data_ptr(), grad_inputs.data_ptr(), L.ptr(scratch), nbytes,

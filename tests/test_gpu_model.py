@@ -496,3 +496,38 @@ def test_render_variants_generic_path():
     with pytest.raises(RuntimeError, match="fd_eps"):
         with torch.no_grad():
             net.render(ro[None], rd[None], num_steps=32, bound=1.6, upsample_steps=32)      # the reference's default normal_epsilon_ratio = 1: eps = 0
+
+
+def test_sds_step_through_rccl_world_size_1():
+    """BASELINE config 5 readiness without an 8-GPU node: the REAL NeRFNetwork's flat 49 MB gradient goes through an RCCL all-reduce
+    (torch.distributed backend "nccl", world size 1 on this box) inside sds_step, and the step equals the step without a process group
+    bit for bit (sum over one rank, no division)."""
+    import os
+    import torch.distributed as dist
+    from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view
+    ro, rd = make_rays(16, 16, dist=1.8, f=12.0)
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+
+    def one_step():
+        net, _ = golden_net(train=True)
+        net_gt, _ = golden_net(train=False)
+        opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+        flat = flat_grad_view(net.parameters())
+        torch.manual_seed(7)
+        marks = []
+        sds_step(net, net_gt, ro_t, rd_t, (16, 16), opt, SyntheticGuidance(3), batch_size=256, flat_grad=flat, timers=marks)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in net.named_parameters()}, flat.clone(), [n for n, _ in marks]
+    p0, f0, m0 = one_step()
+    assert "grad_allreduce" not in m0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        p1, f1, m1 = one_step()
+        probe = torch.ones(4, device=DEV); dist.all_reduce(probe); assert float(probe.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()
+    assert "grad_allreduce" in m1 and f1.numel() == 12248902
+    assert torch.equal(f0, f1)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k

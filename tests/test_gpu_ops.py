@@ -525,3 +525,41 @@ def test_hash_backward_binned_equals_direct(oracle):
     scale = np.abs(gg_o).max()
     assert np.abs(res[0] - gg_o).max() <= 2e-5 * scale and np.abs(res[1] - gg_o).max() <= 2e-5 * scale
     assert Lb.lib().ac_hash_encode_backward_scratch(offs.ctypes.data, 3, 4, 16, S, 16, B) == 0          # C = 4: direct path only
+
+
+def test_hash_backward_binned_nonfinite_gradients(oracle):
+    """An Inf / NaN upstream gradient must reach the table like the reference's atomicAdd delivers it (hashencoder.cu:302-305), not be
+    quantised away by the fixed-point sums of the binned scatter: the level that holds it is summed in float, every other level keeps
+    its exact fixed-point sums.  Also documents the quantisation floor: contributions below 2^-42 of a level's largest |v| vanish."""
+    from avatarcraft_amd import _lib as Lb
+    O = oracle
+    offs, pls = O.hash_offsets(desired_resolution=2048)
+    S = float(np.float32(np.log2(pls)))
+    rs = np.random.RandomState(3)
+    B = 4099
+    x = rs.uniform(0.05, 0.95, size=(B, 3)).astype(np.float32)
+    g = rs.normal(size=(16, B, 2)).astype(np.float32)
+    g[7, 11, 0] = np.inf; g[12, 500, 1] = np.nan
+    g[3, :, :] *= 1e-20; g[3, 77, 0] = 1.0                       # level 3: one record 2^66 times larger than the rest -> the rest falls below the floor
+    emb = torch.zeros(int(offs[-1]), 2, device=DEV)
+    ot = torch.from_numpy(offs).to(DEV)
+    dummy = torch.zeros(1, device=DEV)
+    nbytes = int(Lb.lib().ac_hash_encode_backward_scratch(offs.ctypes.data, 3, 2, 16, S, 16, B))
+    sc = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    gg = torch.zeros_like(emb)
+    Lb.check(Lb.lib().ac_hash_encode_backward_ws(T(g).data_ptr(), T(x).data_ptr(), emb.data_ptr(), ot.data_ptr(), offs.ctypes.data, gg.data_ptr(), B, 3, 2, 16,
+                                                 S, 16, 0, dummy.data_ptr(), dummy.data_ptr(), sc.data_ptr(), nbytes, None))
+    torch.cuda.synchronize()
+    got = gg.cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        ref, _ = O.hash_encode_backward(g, x, np.zeros((int(offs[-1]), 2), np.float32), offs, S, 16, None)
+    lv = lambda a, l: a[offs[l]:offs[l + 1]]
+    assert np.array_equal(np.isinf(lv(got, 7)), np.isinf(lv(ref, 7))) and np.isinf(lv(got, 7)).sum() == 8          # the 8 corners of sample 11
+    assert np.array_equal(np.isnan(lv(got, 12)), np.isnan(lv(ref, 12))) and np.isnan(lv(got, 12)).sum() == 8
+    fin7 = np.isfinite(lv(ref, 7))
+    assert np.abs(lv(got, 7)[fin7] - lv(ref, 7)[fin7]).max() <= 2e-5 * np.abs(lv(ref, 7)[fin7]).max()               # the rest of that level: float sums
+    for l in (0, 5, 9, 15):
+        assert np.isfinite(lv(got, l)).all() and np.abs(lv(got, l) - lv(ref, l)).max() <= 2e-5 * np.abs(lv(ref, l)).max()
+    big = np.abs(lv(ref, 3)) > 1e-3                                                                                  # level 3: the large record is exact ...
+    assert big.sum() == 8 and np.allclose(lv(got, 3)[big], lv(ref, 3)[big], rtol=1e-6)
+    assert np.abs(lv(got, 3)[~big]).max() <= 1e-19                                                                  # ... and nothing else is invented
