@@ -20,6 +20,9 @@
 
 namespace {
 
+#ifndef AC_SDFBWD_RANK1
+#define AC_SDFBWD_RANK1 1     // offset evaluations of the backward: rank-1 shortcuts instead of 32 of their 148 MFMA (0: every evaluation alike)
+#endif
 constexpr int TW = 4;                              // waves per workgroup of the backward kernels (296 / 284 VGPRs: one wave per SIMD)
 constexpr int TBLOCK = TW * 64;
 constexpr int FW = 8;                              // waves per workgroup of the forward SDF query (224 VGPRs: two waves per SIMD, like the renderer)
@@ -150,6 +153,14 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
     const float bound = a.bound;
     f32x4 gW1[4][3], gW2[4];
     float gb2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#if AC_SDFBWD_RANK1
+    float a6[4][4];                                   // running sum over samples and offset evaluations of s * a[unit 16t + 4g + r] (-> dW2 row 0)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a6[t][r] = 0.0f;
+    const W2Row0 w2r0 = load_w2_row0(lds, lane);
+#endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         gW2[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -184,11 +195,12 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
             const float bx = (e > 0 && g == k) ? poff : pc0;
             // upstream gradient of this evaluation's 16 outputs, in the forward's register layout (o = 4g + r)
             f32x4 d2;
+            float s_all = 0.0f;                                                 // the offset evaluations' only upstream value, in every lane of the sample
             if (e == 0) d2 = go;
             else {
                 const float gk = k == 0 ? gg[0] : (k == 1 ? gg[1] : gg[2]);
-                const float s = ((e - 1) & 1) ? -(gk * hs) : gk * hs;          // d gradient_k / d sdf(x +- eps e_k) = +-0.5 / eps
-                d2 = f32x4{ g == 0 ? s : 0.0f, 0.0f, 0.0f, 0.0f };
+                s_all = ((e - 1) & 1) ? -(gk * hs) : gk * hs;                   // d gradient_k / d sdf(x +- eps e_k) = +-0.5 / eps
+                d2 = f32x4{ g == 0 ? s_all : 0.0f, 0.0f, 0.0f, 0.0f };
             }
             // recompute layer 1, softplus and its derivative
             const Acc4 h1 = sdf_l1(lds, lane, bx, fe);
@@ -197,15 +209,32 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { float v_, d_; softplus100_vg(lds + OFF_SPQ, h1.a[t][r], v_, d_); av.a[t][r] = v_; dv.a[t][r] = d_; }
-            // ga = W2^T d2, d1 = ga * softplus'
             Acc4 d1;
+#if AC_SDFBWD_RANK1
+            // The six offset evaluations feed the finite-difference gradient through their sdf alone: d2 = (s, 0, ..., 0).  Then
+            // ga = W2^T d2 = s * W2[0, :] (16 multiplies instead of 16 MFMA), and their share of dW2 / db2 is row 0 only:
+            // dW2[0, u] += sum over samples of s * a[u], kept as a per-lane running sum (reduced over the samples once, at the end).
+            const bool rank1 = e > 0;
+            if (rank1) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f32x4 ga = { 0.0f, 0.0f, 0.0f, 0.0f };
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) ga = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2T + (t * 4 + s) * 64 + lane], d2[s], ga, 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+                        d1.a[t][r] = (s_all * w2r0.w[t][r]) * dv.a[t][r];
+                        a6[t][r] = fma_(s_all, av.a[t][r], a6[t][r]);
+                    }
+            } else
+#endif
+            {
+                // ga = W2^T d2, d1 = ga * softplus'
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d1.a[t][r] = ga[r] * dv.a[t][r];
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 ga = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) ga = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2T + (t * 4 + s) * 64 + lane], d2[s], ga, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d1.a[t][r] = ga[r] * dv.a[t][r];
+                }
             }
             // dinp = W1^T d1: this lane's own features (j = 2t' + (r >> 1), c = r & 1)
 #pragma unroll
@@ -225,25 +254,36 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
                 }
             }
             // transposes for the weight gradients (K = the 16 samples of the tile)
+#if AC_SDFBWD_RANK1
+            if (!rank1)
+#endif
+            {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T2[(4 * g + r) * TLD + n] = d2[r];
+                for (int r = 0; r < 4; ++r) T2[(4 * g + r) * TLD + n] = d2[r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TA[(16 * t + 4 * g + r) * TLD + n] = av.a[t][r];
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    TA[(16 * t + 4 * g + r) * TLD + n] = av.a[t][r];
-                    TD[(16 * t + 4 * g + r) * TLD + n] = d1.a[t][r];
-                }
+                for (int r = 0; r < 4; ++r) TD[(16 * t + 4 * g + r) * TLD + n] = d1.a[t][r];
             if (g < 3) TI[g * TLD + n] = bx;
 #pragma unroll
             for (int s1 = 0; s1 < 8; ++s1) TI[(3 + 2 * (4 * (s1 >> 1) + g) + (s1 & 1)) * TLD + n] = fe[s1 >> 1][s1 & 1];
             wave_sync();
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float a2 = T2[n * TLD + 4 * s + g];                     // A: d2[o = lane & 15][sample 4s + kk]
+#if AC_SDFBWD_RANK1
+                if (!rank1)
+#endif
+                {
+                    const float a2 = T2[n * TLD + 4 * s + g];                     // A: d2[o = lane & 15][sample 4s + kk]
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    gW2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, TA[(16 * c + n) * TLD + 4 * s + g], gW2[c], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c)
+                        gW2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, TA[(16 * c + n) * TLD + 4 * s + g], gW2[c], 0, 0, 0);
+                }
                 float bi[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) bi[c] = TI[(16 * c + n) * TLD + 4 * s + g];
@@ -270,6 +310,18 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
                 const int unit = 16 * t + 4 * g + r, kcol = 16 * c + n;
                 if (kcol < 36) part[unit * 36 + kcol] = gW1[t][c][r];
             }
+#if AC_SDFBWD_RANK1
+    // row 0 of dW2 also receives the offset evaluations' running sums: unit u = 16c + n of lane (n, g = 0) is held, after a row reduction over
+    // the 16 samples, by lane 15 of lane group n >> 2 in register a6[c][n & 3]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float tot[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot[r] = __shfl(row_scan<false>(a6[c][r]), 16 * (n >> 2) + 15);
+        const float add = (n & 3) == 0 ? tot[0] : ((n & 3) == 1 ? tot[1] : ((n & 3) == 2 ? tot[2] : tot[3]));
+        if (g == 0) gW2[c][0] += add;
+    }
+#endif
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
