@@ -155,11 +155,15 @@ __device__ __forceinline__ void run_step(float (&v)[N], int &f)
 // 16-lane row (row_shr 1, 2, 4, 8), then the open tail of the previous row(s) is carried over with row_bcast15 / row_bcast31.
 // Returns true in the last lane of every run (the one that holds the run's total).
 template <int N>
-__device__ __forceinline__ bool run_reduce(float (&v)[N], bool head, int lane)
+__device__ __forceinline__ bool run_reduce(float (&v)[N], bool head, int lane, bool norun = false)
 {
 #ifdef AC_ABL_NORUN         // timing ablation: every lane is its own run
     return true;
 #endif
+    // norun (wave-uniform): a lane of this wave carries an Inf / NaN upstream gradient.  The scan below adds `neighbour * {0, 1}`, and
+    // Inf * 0 = NaN would leak into every lane of the row: such a group scatters lane by lane, so that a non-finite gradient reaches
+    // exactly the entries the reference's atomicAdd would give it (hashencoder.cu:302-305)
+    if (norun) return true;
     int f = head ? 1 : 0;
 #ifdef AC_RUN_SHUFFLE       // the first implementation: 6 Kogge-Stone steps over the whole wave with ds_bpermute
 #pragma unroll
@@ -216,15 +220,21 @@ struct DirectSink {
 };
 
 constexpr int NBUCKET = 64;
+#ifndef AC_FLUSH_SORTED
+#define AC_FLUSH_SORTED 1   // records leave a wave's buffer in bucket order (coalesced queue writes); 0: in arrival order
+#endif
 #ifndef AC_RCAP
-#define AC_RCAP 1536
+#define AC_RCAP (AC_FLUSH_SORTED ? 1280 : 1536)
 #endif
 constexpr int RCAP = AC_RCAP;              // records per wave buffer; add8 reserves room for 8 x 64 records
+constexpr int WAVE_WORDS = 3 * RCAP + (AC_FLUSH_SORTED ? RCAP / 2 + NBUCKET : 0) + 2 * NBUCKET;     // LDS words per wave: ridx, rv0, rv1 [RCAP], perm [RCAP] u16 + pre [64], hist, base [64]
+static_assert(RCAP % 2 == 0 && RCAP >= 1024, "wave buffer: room for two batches of 8 x 64 records");
 struct Rec { uint32_t idx; float v0, v1; };
 
 struct BinSink {
     uint32_t *ridx; float *rv0, *rv1;      // this wave's LDS record buffer [RCAP]; ridx = entry | rank inside its bucket << 19
     uint32_t *hist, *base;                 // this wave's LDS [NBUCKET] each (hist zero between flushes)
+    uint16_t *perm; uint32_t *pre;         // AC_FLUSH_SORTED: bucket-ordered record indices [RCAP], bucket start offsets [NBUCKET]
     uint32_t cnt;                          // wave-uniform
     uint32_t sh;                           // bucket = index >> sh (2^sh entries per bucket, <= NBUCKET buckets per level)
     uint32_t mx;                           // per lane: bits of the largest |v| recorded since the last flush
@@ -286,18 +296,44 @@ struct BinSink {
             const uint32_t c = hist[lane];
             base[lane] = c ? atomicAdd(&qcount[lane], c) : 0u;
             hist[lane] = 0u;
+#if AC_FLUSH_SORTED
+            uint32_t incl = c;                               // exclusive prefix of the bucket counts: where bucket `lane` starts in bucket order
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
+            pre[lane] = incl - c;
+#endif
         }
         wave_sync_lds();
         tick(2);
+#if AC_FLUSH_SORTED
+        // A store instruction whose 64 lanes hit 64 different queues costs the CU what a 64-line gather costs (~600 clocks,
+        // profiles/r01_gather_bench.txt), and an unsorted buffer produces exactly that: 24 such stores per flush were the ~17 K clocks a flush
+        // took "whatever the record count".  So the records leave in BUCKET ORDER: perm[pre[bucket] + rank] = i (one pass over the
+        // indices), then lane j writes record perm[j] -- neighbouring lanes now write neighbouring slots of the same queue, a flush
+        // touches ~5 lines per bucket instead of one line per record.
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const uint32_t pk = ridx[i];
+            perm[pre[(pk & 0x7ffffu) >> sh] + (pk >> 19)] = (uint16_t)i;
+        }
+        wave_sync_lds();
+#endif
         // write-out, WU records per lane and trip: the LDS reads of a trip are issued together (one LDS latency per trip, not per record)
         constexpr uint32_t WU = 4;
         for (uint32_t i0 = lane; i0 < cnt; i0 += 64 * WU) {
             uint32_t packed[WU]; float v0[WU], v1[WU]; uint32_t bs[WU];
+#if AC_FLUSH_SORTED
+            uint32_t src[WU];
+#pragma unroll
+            for (uint32_t u = 0; u < WU; ++u) { const uint32_t i = i0 + 64 * u; src[u] = perm[i < cnt ? i : i0]; }
+#pragma unroll
+            for (uint32_t u = 0; u < WU; ++u) { packed[u] = ridx[src[u]]; v0[u] = rv0[src[u]]; v1[u] = rv1[src[u]]; }
+#else
 #pragma unroll
             for (uint32_t u = 0; u < WU; ++u) {
                 const uint32_t i = i0 + 64 * u, ic = i < cnt ? i : i0;
                 packed[u] = ridx[ic]; v0[u] = rv0[ic]; v1[u] = rv1[ic];
             }
+#endif
 #pragma unroll
             for (uint32_t u = 0; u < WU; ++u) bs[u] = base[(packed[u] & 0x7ffffu) >> sh];
 #pragma unroll
@@ -335,8 +371,10 @@ __host__ __device__ __forceinline__ uint32_t bucket_shift(uint32_t size)
 
 
 // one point's 8 corners, combined over the run of lanes in the same cell
+__device__ __forceinline__ bool nonfinite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
+
 template <class Sink>
-__device__ __forceinline__ void scatter8_runs(Sink &sink, const LevelC &L, const Loc (&q)[3], float g0, float g1, int lane)
+__device__ __forceinline__ void scatter8_runs(Sink &sink, const LevelC &L, const Loc (&q)[3], float g0, float g1, int lane, bool norun = false)
 {
     const bool ok = !(q[0].oob | q[1].oob | q[2].oob);
     float v[16];
@@ -350,7 +388,7 @@ __device__ __forceinline__ void scatter8_runs(Sink &sink, const LevelC &L, const
 #ifdef AC_FINE_NORUN        // experiment: no run combining on the per-point path (few same-cell neighbours on the fine levels)
     const bool tail = ok;
 #else
-    const bool tail = run_reduce<16>(v, run_head(q, ok, lane), lane) && ok;
+    const bool tail = run_reduce<16>(v, run_head(q, ok, lane), lane, norun) && ok;
 #endif
     sink.tick(0);
     bool pred[8];
@@ -370,13 +408,17 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
 #pragma unroll
     for (int d = 0; d < 3; ++d) c[d] = locate(xc[d], bound, two_bound, L.scale);
     const bool cen_ok = !(c[0].oob | c[1].oob | c[2].oob);
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) bad |= nonfinite(gp[p].x) | nonfinite(gp[p].y);
+    const bool norun = __any(bad);                       // wave-uniform: Inf / NaN somewhere in this group of 64 samples (see run_reduce)
 
-    if (fine || !__all(cen_ok)) {                        // wave-uniform: every lane takes the same path (shuffles inside)
+    if (fine || norun || !__all(cen_ok)) {               // wave-uniform: every lane takes the same path (shuffles inside)
 #pragma unroll
         for (int p = 0; p < 7; ++p) {
             Loc q[3] = { c[0], c[1], c[2] };
             if (p > 0) { const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale); }
-            scatter8_runs(sink, L, q, gp[p].x, gp[p].y, lane);
+            scatter8_runs(sink, L, q, gp[p].x, gp[p].y, lane, norun);
         }
         return;
     }
@@ -489,10 +531,11 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
     const uint32_t Lc = lt.L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const LevelC L = level_of(lt, level);
-    uint32_t *wbase = smem + wave * (3 * RCAP + 2 * NBUCKET);
+    uint32_t *wbase = smem + wave * WAVE_WORDS;
     BinSink sink;
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
+    sink.pre = sink.base + NBUCKET; sink.perm = reinterpret_cast<uint16_t *>(sink.pre + NBUCKET);
     sink.cnt = 0; sink.lane = lane;
     sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
     sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
@@ -541,10 +584,11 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
     for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const LevelC L = level_of(lt, level);
-    uint32_t *wbase = smem + wave * (3 * RCAP + 2 * NBUCKET);
+    uint32_t *wbase = smem + wave * WAVE_WORDS;
     BinSink sink;
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
+    sink.pre = sink.base + NBUCKET; sink.perm = reinterpret_cast<uint16_t *>(sink.pre + NBUCKET);
     sink.cnt = 0; sink.lane = lane;
     sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
     sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
@@ -569,7 +613,7 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
         }
         float2 g = reinterpret_cast<const float2 *>(grad)[(size_t)level * B + b];
         if (!valid) g = make_float2(0.0f, 0.0f);
-        scatter8_runs(sink, L, q, g.x, g.y, lane);
+        scatter8_runs(sink, L, q, g.x, g.y, lane, __any(nonfinite(g.x) | nonfinite(g.y)) != 0);
     }
     sink.flush();
 }
@@ -751,7 +795,7 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
     if (sc.n_binned) {
         hipMemsetAsync(qcount, 0, (size_t)sc.n_binned * (NBUCKET + 1) * 4, st);
         static uint64_t seen1 = 0, seen2 = 0;
-        const size_t lds1 = (size_t)4 * (3 * RCAP + 2 * NBUCKET) * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 16;
+        const size_t lds1 = (size_t)4 * WAVE_WORDS * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 16;
         ac::allow_dynamic_lds(seen1, reinterpret_cast<const void *>(hash_stencil_bwd_binned_kernel), lds1);
         ac::allow_dynamic_lds(seen2, reinterpret_cast<const void *>(bucket_accumulate_kernel), lds2);
         uint32_t gx = ((B + 63) / 64 + 3) / 4;
@@ -803,7 +847,7 @@ AC_API int ac_hash_encode_backward_ws(const float *grad, const float *inputs, co
     Rec *queues = reinterpret_cast<Rec *>(sb + sc.queue_off);
     hipMemsetAsync(qcount, 0, (size_t)sc.n_binned * (NBUCKET + 1) * 4, st);
     static uint64_t seen1 = 0, seen2 = 0;
-    const size_t lds1 = (size_t)4 * (3 * RCAP + 2 * NBUCKET) * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 16;
+    const size_t lds1 = (size_t)4 * WAVE_WORDS * 4, lds2 = (size_t)(1u << 19) / NBUCKET * 16;
     ac::allow_dynamic_lds(seen1, reinterpret_cast<const void *>(hash_bwd_binned_kernel), lds1);
     ac::allow_dynamic_lds(seen2, reinterpret_cast<const void *>(bucket_accumulate_kernel), lds2);
     uint32_t gx = ((B + 63) / 64 + 3) / 4;

@@ -58,7 +58,10 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     // slab of rays so that neighbouring pixels share one L2 instead of eight
     int bid = blockIdx.x;
 #ifndef AC_NO_XCD_REMAP
-    if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    {   // XCD k runs the workgroups b with b % 8 == k: give it the k-th contiguous range (ranges differ by one when 8 does not divide the grid)
+        const int k = blockIdx.x & 7, q = gridDim.x >> 3, r = gridDim.x & 7;
+        bid = k * q + (k < r ? k : r) + (blockIdx.x >> 3);
+    }
 #endif
     for (int ray = bid * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
         AC_T0();
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                     const int kn = e >> 1;
                     float fe[4][2];
 #pragma unroll
-                    for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[(e * 8 + q_) * 64 + lane];
+                    for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[(AC_FE_E(e) * 8 + q_) * 64 + lane];
                     const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
                     const float poff = clampf(pk + ((e & 1) ? -bxe : bxe), -bound, bound);
                     accn = sdf_l1(lds, lane, g == kn ? poff : pc0, fe);

@@ -68,6 +68,11 @@ def linspace_tables(num_steps, device):
     return _LIN_CACHE[key]
 
 
+class RenderResult(dict):
+    """the tensors a render launch produced (a dict), plus `.opts`: the launch's ac_render_opts and the tensors its pointers refer to"""
+    opts = None
+
+
 def _inv_s_arg(inv_s):
     """(float for ac_render_opts.inv_s, device tensor or None for .inv_s_dev): a CUDA tensor (forward_variance()) is handed over as a
     pointer -- the trainable variance never takes a host round trip"""
@@ -96,7 +101,7 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     T = num_steps + upsample_steps
     nup = upsample_steps // 16
     lin_z, lin_u = linspace_tables(num_steps, dev)
-    res = out if out is not None else {}
+    res = out if out is not None else RenderResult()
 
     def buf(name, shape, dtype=_F32):
         t = res.get(name)
@@ -134,7 +139,8 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
         nm, fm = _chk(near_far[0].reshape(-1), "near", (N,)), _chk(near_far[1].reshape(-1), "far", (N,))
     op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), inv_s_f, float(cos_anneal_ratio),
                           float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None), L.ptr(inv_s_t), L.ptr(nm), L.ptr(fm))
-    res["_opts"] = (op, inv_s_t, nm, fm)
+    if isinstance(res, RenderResult):
+        res.opts = (op, inv_s_t, nm, fm)
     st = L.current_stream(dev)
     if events is not None:          # (start, end) torch.cuda.Event pair around the render kernel only (bench.py roofline)
         events[0].record()
@@ -245,7 +251,7 @@ class _RenderCore(torch.autograd.Function):
         out = render_rays(field, rays_o, rays_d, T0, up, bound, inv_s, bg=bg, noise=noise, cos_anneal_ratio=car, normal_epsilon_ratio=ner,
                           extras=True, train_extras=True)
         ctx.field, ctx.cfg = field, cfg
-        ctx.opts = out["_opts"]                                    # the launch's ac_render_opts (+ the tensors its pointers refer to)
+        ctx.opts = out.opts                                        # the launch's ac_render_opts (+ the tensors its pointers refer to)
         ctx.has_bg = bg is not None
         # outputs among the saved tensors (z_vals, color) must go through save_for_backward (no reference cycle through ctx)
         ctx.save_for_backward(out["z_vals"], out["pts"], out["sdf"], out["sdf_out16"], out["gradient"], out["color"], out["eik_res"], rays_o, rays_d,

@@ -85,7 +85,7 @@ def test_training_gradients_match_reference_autograd():
         got = prm.grad.detach().cpu().numpy()
         scale = np.abs(ref).max() + 1e-12
         worst[k] = float(np.abs(got - ref).max() / scale)
-        assert np.abs(got - ref).max() <= 2e-2 * scale, (k, np.abs(got - ref).max(), scale)
+        assert np.abs(got - ref).max() <= 3e-3 * scale, (k, np.abs(got - ref).max(), scale)      # observed <= 7.4e-4 (gpurun_out/train_grad_parity.json)
     import json, os
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(worst, open("gpurun_out/train_grad_parity.json", "w"), indent=1)
@@ -138,7 +138,7 @@ def test_sds_step_matches_reference_step():
         if k == "encoder.embeddings":
             d = d[g["emb_idx"]]
         clear = np.abs(ref) > 1e-3 * scale
-        assert clear.mean() > 0.3 and np.abs(d[clear] - dref[clear]).max() <= 1e-6, k
+        assert clear.mean() > (0.01 if k == "encoder.embeddings" else 0.3) and np.abs(d[clear] - dref[clear]).max() <= 1e-6, k
         assert np.abs(d - dref).max() <= 2 * 5e-3 + 1e-6
     ge = net.encoder.embeddings.grad
     assert abs(float(torch.sqrt((ge.double() ** 2).sum())) - float(g["emb3_l2"])) <= 2e-3 * float(g["emb3_l2"])
@@ -424,7 +424,7 @@ def test_render_core_operator(n_side, T0, up, perturb):
     for k in ("rgb", "weight_sum", "depth", "normal", "weights", "pts_color", "pts_alpha", "z_vals", "gradient_error"):
         assert torch.equal(o_core[k], o_ng[k]), k                       # (a)
         assert torch.allclose(o_core[k], o_ops[k], atol=2e-5, rtol=1e-4), k
-    assert set(g_core) == set(g_ops) == set(g_ag) and len(g_core) == 15
+    assert set(g_core) == set(g_ops) == set(g_ag) and len(g_core) == 14
     worst = {}
     for k in g_core:
         scale = float(g_ag[k].abs().max())

@@ -228,7 +228,8 @@ def test_vanilla_nerf_plumbing_matches_reference():
         v, ref = val.numpy(), g[name]
         assert np.array_equal(np.isnan(v), np.isnan(ref)), name            # disp = 1/max(1e-10, depth/acc) is NaN where acc == 0 (0/0), as in the reference
         ok = ~np.isnan(ref)
-        assert np.abs(v[ok] - ref[ok]).max() <= 2e-6 * max(1.0, np.abs(ref[ok]).max()), name
+        tol = 1e-4 if name == "disp" else 2e-6        # disp = 1 / (depth / acc) amplifies the last bits of two sums where acc is tiny (2.4e-5 between two hosts' BLAS)
+        assert np.abs(v[ok] - ref[ok]).max() <= tol * max(1.0, np.abs(ref[ok]).max()), name
     batch = dict(origin=ro, direction=rd, near=torch.full((4096, 1), 1.0), far=torch.full((4096, 1), 4.0))
     pts, dirs, z = NF.ray_to_samples(batch, 16)
     assert np.array_equal(z.numpy(), g["z"]) and pts.shape == (4096, 16, 3) and dirs.shape == (4096, 16, 3)
