@@ -220,21 +220,17 @@ struct DirectSink {
 };
 
 constexpr int NBUCKET = 64;
-#ifndef AC_FLUSH_SORTED
-#define AC_FLUSH_SORTED 1   // records leave a wave's buffer in bucket order (coalesced queue writes); 0: in arrival order
-#endif
 #ifndef AC_RCAP
-#define AC_RCAP (AC_FLUSH_SORTED ? 1280 : 1536)
+#define AC_RCAP 1536
 #endif
 constexpr int RCAP = AC_RCAP;              // records per wave buffer; add8 reserves room for 8 x 64 records
-constexpr int WAVE_WORDS = 3 * RCAP + (AC_FLUSH_SORTED ? RCAP / 2 + NBUCKET : 0) + 2 * NBUCKET;     // LDS words per wave: ridx, rv0, rv1 [RCAP], perm [RCAP] u16 + pre [64], hist, base [64]
+constexpr int WAVE_WORDS = 3 * RCAP + 2 * NBUCKET;     // LDS words per wave: ridx, rv0, rv1 [RCAP], hist, base [64]
 static_assert(RCAP % 2 == 0 && RCAP >= 1024, "wave buffer: room for two batches of 8 x 64 records");
 struct Rec { uint32_t idx; float v0, v1; };
 
 struct BinSink {
     uint32_t *ridx; float *rv0, *rv1;      // this wave's LDS record buffer [RCAP]; ridx = entry | rank inside its bucket << 19
     uint32_t *hist, *base;                 // this wave's LDS [NBUCKET] each (hist zero between flushes)
-    uint16_t *perm; uint32_t *pre;         // AC_FLUSH_SORTED: bucket-ordered record indices [RCAP], bucket start offsets [NBUCKET]
     uint32_t cnt;                          // wave-uniform
     uint32_t sh;                           // bucket = index >> sh (2^sh entries per bucket, <= NBUCKET buckets per level)
     uint32_t mx;                           // per lane: bits of the largest |v| recorded since the last flush
@@ -296,44 +292,18 @@ struct BinSink {
             const uint32_t c = hist[lane];
             base[lane] = c ? atomicAdd(&qcount[lane], c) : 0u;
             hist[lane] = 0u;
-#if AC_FLUSH_SORTED
-            uint32_t incl = c;                               // exclusive prefix of the bucket counts: where bucket `lane` starts in bucket order
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
-            pre[lane] = incl - c;
-#endif
         }
         wave_sync_lds();
         tick(2);
-#if AC_FLUSH_SORTED
-        // A store instruction whose 64 lanes hit 64 different queues costs the CU what a 64-line gather costs (~600 clocks,
-        // profiles/r01_gather_bench.txt), and an unsorted buffer produces exactly that: 24 such stores per flush were the ~17 K clocks a flush
-        // took "whatever the record count".  So the records leave in BUCKET ORDER: perm[pre[bucket] + rank] = i (one pass over the
-        // indices), then lane j writes record perm[j] -- neighbouring lanes now write neighbouring slots of the same queue, a flush
-        // touches ~5 lines per bucket instead of one line per record.
-        for (uint32_t i = lane; i < cnt; i += 64) {
-            const uint32_t pk = ridx[i];
-            perm[pre[(pk & 0x7ffffu) >> sh] + (pk >> 19)] = (uint16_t)i;
-        }
-        wave_sync_lds();
-#endif
         // write-out, WU records per lane and trip: the LDS reads of a trip are issued together (one LDS latency per trip, not per record)
         constexpr uint32_t WU = 4;
         for (uint32_t i0 = lane; i0 < cnt; i0 += 64 * WU) {
             uint32_t packed[WU]; float v0[WU], v1[WU]; uint32_t bs[WU];
-#if AC_FLUSH_SORTED
-            uint32_t src[WU];
-#pragma unroll
-            for (uint32_t u = 0; u < WU; ++u) { const uint32_t i = i0 + 64 * u; src[u] = perm[i < cnt ? i : i0]; }
-#pragma unroll
-            for (uint32_t u = 0; u < WU; ++u) { packed[u] = ridx[src[u]]; v0[u] = rv0[src[u]]; v1[u] = rv1[src[u]]; }
-#else
 #pragma unroll
             for (uint32_t u = 0; u < WU; ++u) {
                 const uint32_t i = i0 + 64 * u, ic = i < cnt ? i : i0;
                 packed[u] = ridx[ic]; v0[u] = rv0[ic]; v1[u] = rv1[ic];
             }
-#endif
 #pragma unroll
             for (uint32_t u = 0; u < WU; ++u) bs[u] = base[(packed[u] & 0x7ffffu) >> sh];
 #pragma unroll
@@ -535,7 +505,6 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
     BinSink sink;
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
-    sink.pre = sink.base + NBUCKET; sink.perm = reinterpret_cast<uint16_t *>(sink.pre + NBUCKET);
     sink.cnt = 0; sink.lane = lane;
     sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
     sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
@@ -588,7 +557,6 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
     BinSink sink;
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
-    sink.pre = sink.base + NBUCKET; sink.perm = reinterpret_cast<uint16_t *>(sink.pre + NBUCKET);
     sink.cnt = 0; sink.lane = lane;
     sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
     sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;

@@ -47,14 +47,7 @@ constexpr int OFF_LVL = OFF_B2 + 16;             // [16 levels][8 words]
 constexpr int OFF_LIN = OFF_LVL + 16 * 8;        // lin_z[64] + lin_u[16]
 constexpr int OFF_SPQ = OFF_LIN + 80;           // softplus G table [128][4]
 constexpr int OFF_WAVE = OFF_SPQ + 512;         // per-wave slabs start here
-#ifdef AC_ABL_FE_ALIAS   // TIMING ablation only (wrong results): the feature slab holds 3 of the 6 offset points, the other 3 alias them --
-#define AC_FE_ROWS 3    // what 12 resident waves per CU (3 per SIMD) would buy if the slab were staged in two halves
-#define AC_FE_E(E) ((E) % 3)
-#else
-#define AC_FE_ROWS 6
-#define AC_FE_E(E) (E)
-#endif
-constexpr int FE_SLAB = AC_FE_ROWS * 8 * 64;               // hash features of the 6 finite-difference points: [e-1][2j+c][lane]
+constexpr int FE_SLAB = 6 * 8 * 64;                        // hash features of the 6 finite-difference points: [e-1][2j+c][lane]
 constexpr int WAVE_SLAB = 2 * MAXT * 2 + MAXT + 16 + 16 + FE_SLAB;   // zs[2][128], sd[2][128], cdf[128], znew[16], pad, fe
 constexpr int LDS_FLOATS = OFF_WAVE + WAVES_PER_BLOCK * WAVE_SLAB;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget: one workgroup per CU");
@@ -465,7 +458,7 @@ __device__ __forceinline__ void fine_issue(rsrc_t table, const LvlC &L, const ui
     }
 }
 
-#define AC_FSTORE(E, F0, F1) { fslab[(AC_FE_E(E - 1) * 8 + 2 * j) * 64 + lane] = F0; fslab[(AC_FE_E(E - 1) * 8 + 2 * j + 1) * 64 + lane] = F1; }
+#define AC_FSTORE(E, F0, F1) { fslab[((E - 1) * 8 + 2 * j) * 64 + lane] = F0; fslab[((E - 1) * 8 + 2 * j + 1) * 64 + lane] = F1; }
 
 __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, float *__restrict__ fslab, const FieldCtx &fc, int lane,
                                                float px, float py, float pz, float eps, float (&fe0)[4][2])

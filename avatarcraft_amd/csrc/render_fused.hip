@@ -295,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                     const int kn = e >> 1;
                     float fe[4][2];
 #pragma unroll
-                    for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[(AC_FE_E(e) * 8 + q_) * 64 + lane];
+                    for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[(e * 8 + q_) * 64 + lane];
                     const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
                     const float poff = clampf(pk + ((e & 1) ? -bxe : bxe), -bound, bound);
                     accn = sdf_l1(lds, lane, g == kn ? poff : pc0, fe);
