@@ -678,3 +678,51 @@ def make_calc_local_trans_golden():
 
 if __name__ == "__main__":
     make_calc_local_trans_golden()
+
+
+# ---------------------------------------------------------------- SDS guidance
+def make_sds_golden():
+    """models/diffusion.py:StableDiffusion imported over stub `diffusers` / `transformers` / `torchvision` modules whose classes are the tiny
+    seeded stand-ins of tests/common_sd.py (no library, no weights offline): get_text_embeds and the image gradient of mannual_backward
+    (resize to 512^2, VAE encode with grad, add_noise at a random t, UNet x2, CFG 100, (1 - abar_t) weight, clamp, manual backward)."""
+    from tests import common_sd as SD
+    import torch.nn.functional as F
+    saved = {k: sys.modules.get(k) for k in ("transformers", "diffusers", "torchvision", "torchvision.transforms", "torchvision.transforms.functional", "prompt_toolkit")}
+    try:
+        _stub("prompt_toolkit", prompt=lambda *a, **k: "")
+        _stub("transformers", CLIPTextModel=SD.TinyTextEncoder, CLIPTokenizer=SD.TinyTokenizer, logging=types.SimpleNamespace(set_verbosity_error=lambda: None))
+        _stub("diffusers", AutoencoderKL=SD.TinyVAE, UNet2DConditionModel=SD.TinyUNet, PNDMScheduler=SD.StubPNDMScheduler)
+
+        def pad(img, padding, fill=0, padding_mode="constant"):            # torchvision.transforms.functional.pad for a 1-tuple: all four sides
+            p = padding[0]
+            return F.pad(img, (p, p, p, p), mode=padding_mode, value=fill)
+        tvf = _stub("torchvision.transforms.functional", pad=pad)
+        tvt = _stub("torchvision.transforms", functional=tvf)
+        _stub("torchvision", transforms=tvt)
+        sys.modules.pop("models.diffusion", None)
+        import models.diffusion as RD
+        sd = RD.StableDiffusion(torch.device("cpu"), "1.5")
+        emb = sd.get_text_embeds(["Hulk, photorealistic style"])
+        out = dict(text_embeds=emb.numpy(), alphas_cumprod=sd.alphas.numpy()[::50])
+        g = torch.Generator().manual_seed(5)
+        for seed, hw in ((11, (64, 64)), (12, (48, 80))):
+            pred = torch.rand((1, 3) + hw, generator=g)
+            pred.requires_grad_(True)
+            torch.manual_seed(seed)
+            sd.mannual_backward(emb, pred, 100)
+            torch.manual_seed(seed)
+            t = torch.randint(sd.min_step, sd.max_step + 1, [1])
+            out[f"rgb_{seed}"] = pred.detach().numpy(); out[f"grad_{seed}"] = pred.grad.numpy().copy(); out[f"t_{seed}"] = np.int64(t.item())
+            print("sds golden: seed", seed, "t", int(t), "|grad| max", float(pred.grad.abs().max()), "nonzero", float((pred.grad != 0).float().mean()))
+        np.savez_compressed(os.path.join(HERE, "sds.npz"), **out)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        sys.modules.pop("models.diffusion", None)
+
+
+if __name__ == "__main__":
+    make_sds_golden()
