@@ -726,3 +726,43 @@ def make_sds_golden():
 
 if __name__ == "__main__":
     make_sds_golden()
+
+
+# ---------------------------------------------------------------- reconstruct.py step
+def make_reconstruct_golden():
+    """one optimisation step of main_reconstruct (reconstruct.py:92-112): render with perturbation, smooth_l1(rgb, gt) + 0.1 * eikonal,
+    backward on the reference's own autograd graph, Adam(lr 5e-4, betas (0.9, 0.99), eps 1e-15): gradients and parameter deltas"""
+    import torch.nn.functional as F
+    net = build_reference_net()
+    net.train(True)
+    ro, rd = make_rays(6, 6, dist=1.8, f=4.0, jitter_seed=4)
+    n = ro.shape[0]
+    bg = np.ones((n, 3), np.float32)
+    gt = np.random.RandomState(15).uniform(0, 1, (n, 3)).astype(np.float32)
+    torch.manual_seed(21)
+    noise = torch.rand(n, 64).numpy().copy()
+    torch.manual_seed(21)
+    out = net.render(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], num_steps=64, bound=1.6, upsample_steps=64, staged=False,
+                     bg_color=torch.from_numpy(bg), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=True)
+    loss = F.smooth_l1_loss(out["rgb"][0], torch.from_numpy(gt), reduction='mean') + out["gradient_error"] * 0.1
+    net.zero_grad()
+    loss.backward()
+    gg = dict(rays_o=ro, rays_d=rd, gt=gt, noise=noise, loss=np.float64(loss.item()), rgb=out["rgb"][0].detach().numpy())
+    ge = net.encoder.embeddings.grad.numpy()
+    nz = np.flatnonzero(np.abs(ge).sum(1))
+    pick = np.sort(nz[np.random.RandomState(16).choice(len(nz), 4096, replace=False)])
+    gg["emb_idx"] = pick.astype(np.int64); gg["emb_grad"] = ge[pick].copy(); gg["emb_l2"] = np.float64(np.sqrt((ge.astype(np.float64) ** 2).sum()))
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    for k, p in net.named_parameters():
+        if k != "encoder.embeddings":
+            gg["grad." + k] = p.grad.numpy().copy()
+    torch.optim.Adam(net.parameters(), lr=5e-4, betas=(0.9, 0.99), eps=1e-15).step()
+    for k, p in net.named_parameters():
+        d = (p.detach() - before[k]).numpy()
+        gg["adam_delta." + ("emb" if k == "encoder.embeddings" else k)] = d[pick].copy() if k == "encoder.embeddings" else d.copy()
+    np.savez_compressed(os.path.join(HERE, "reconstruct_grad.npz"), **gg)
+    print("reconstruct golden: loss", gg["loss"], "emb l2", gg["emb_l2"])
+
+
+if __name__ == "__main__":
+    make_reconstruct_golden()

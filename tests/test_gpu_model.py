@@ -531,3 +531,57 @@ def test_sds_step_through_rccl_world_size_1():
     assert torch.equal(f0, f1)
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+
+
+def test_reconstruct_step_matches_reference_step(tmp_path):
+    """one step of reconstruct.py:92-112 (smooth_l1(rgb, gt) + 0.1 eikonal, Adam(5e-4, (0.9, 0.99), eps 1e-15)) against the reference's own
+    autograd + optimizer (tests/golden/reconstruct_grad.npz), through avatarcraft_amd.reconstruct; then the epoch loop and the dataset reader"""
+    from avatarcraft_amd import reconstruct as RC
+    g = load_golden("reconstruct_grad.npz")
+    net, _ = golden_net(train=True)
+    opt, sched = RC.make_optimizer(net, epochs=10)
+    assert opt.defaults["lr"] == 5e-4 and opt.defaults["betas"] == (0.9, 0.99) and opt.defaults["eps"] == 1e-15 and sched.eta_min == 0.0
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    ro, rd, gt = (torch.from_numpy(g[k]).to(DEV) for k in ("rays_o", "rays_d", "gt"))
+    orig = torch.rand
+    torch.rand = lambda *a, **k: torch.from_numpy(g["noise"]).to(DEV)
+    try:
+        loss = RC.reconstruct_step(net, opt, ro, rd, gt, white_bkg=True)
+    finally:
+        torch.rand = orig
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * float(g["loss"])
+    for k, prm in net.named_parameters():
+        got = prm.grad.detach().cpu().numpy()
+        ref = g["emb_grad"] if k == "encoder.embeddings" else g["grad." + k]
+        if k == "encoder.embeddings":
+            got = got[g["emb_idx"]]
+        scale = np.abs(ref).max() + 1e-20
+        assert np.abs(got - ref).max() <= 5e-3 * scale, (k, float(np.abs(got - ref).max() / scale))
+        d = (prm.detach() - before[k]).cpu().numpy()
+        dref = g["adam_delta.emb"] if k == "encoder.embeddings" else g["adam_delta." + k]
+        if k == "encoder.embeddings":
+            d = d[g["emb_idx"]]
+        clear = np.abs(ref) > 1e-3 * scale
+        assert clear.any() and np.abs(d[clear] - dref[clear]).max() <= 1e-7, k           # -lr sign(g) where the gradient is clear
+    # the dataset reader + two short epochs on a synthetic 3-view set in the reference's layout
+    import json
+    from PIL import Image
+    os = __import__("os")
+    root = tmp_path / "set"; (root / "img").mkdir(parents=True)
+    rs = np.random.RandomState(0)
+    frames = []
+    for i in range(3):
+        img = (rs.uniform(0, 1, (16, 16, 3)) * 255).astype(np.uint8)
+        Image.fromarray(img).save(root / "img" / f"{i:04d}.png")
+        c2w = np.eye(4); c2w[:3, 3] = [0.3 * i, 0.0, 2.0]
+        frames.append(dict(file_path=f"img/{i:04d}", transform_matrix=c2w.tolist()))
+    json.dump(dict(camera_angle_x=float(np.pi / 3), frames=frames), open(root / "transforms_train.json", "w"))
+    ds = RC.NeusDataset(str(root), device=DEV)
+    assert ds.n_images == 3 and (ds.H, ds.W) == (16, 16) and abs(ds.focal - 8 / np.tan(np.pi / 6)) < 1e-9
+    first = np.asarray(Image.open(root / "img" / "0000.png")).astype(np.float32) / 255.0
+    assert np.allclose(ds.images[0].numpy(), first[:, ::-1])                              # the reference's flip of the width axis
+    aro, ard, argb = ds.all_rays()
+    assert aro.shape == (3 * 256, 3) and argb.shape == (3 * 256, 3) and torch.allclose(ard.norm(dim=-1), torch.ones(768, device=DEV), atol=1e-5)
+    losses = []
+    n = RC.reconstruct_epochs(net, opt, sched, aro, ard, argb, epochs=2, batch_size=256, on_step=lambda s, e, l: losses.append(float(l)))
+    assert n == 6 and len(losses) == 6 and np.isfinite(losses).all() and abs(sched.get_last_lr()[0] - 5e-4 * 0.5 * (1 + np.cos(np.pi * 2 / 10))) < 1e-9
