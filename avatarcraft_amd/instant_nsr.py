@@ -404,20 +404,68 @@ class NeRFNetwork(NeRFRenderer):
             outs.append(0.5 * (pos - neg) / epsilon)
         return torch.cat(outs, dim=-1)
 
-    def extract_geometry(self, bound: float, resolution: int, threshold: int = 0.0, device=None):
-        """marching cubes on the SDF grid (reference :706-764); PyMCubes is an optional dependency"""
-        import mcubes
+    def extract_fields(self, bound: float, resolution: int):
+        """the SDF on a resolution^3 grid over [-bound, bound]^3 (extract_fields, reference :728-745): blocks of 256^3 points through the
+        fused field kernel (ac_field_sdf), assembled on the device; returns a float32 numpy array [res, res, res] like the reference"""
         N = 256
+        dev = self.encoder.embeddings.device
         xs = torch.linspace(-bound, bound, resolution).split(N)
-        u = np.zeros([resolution] * 3, dtype=np.float32)
+        u = torch.empty([resolution] * 3, dtype=torch.float32, device=dev)
         with torch.no_grad():
             for xi, x in enumerate(xs):
                 for yi, y in enumerate(xs):
                     for zi, z in enumerate(xs):
                         xx, yy, zz = torch.meshgrid(x, y, z, indexing="ij")
-                        pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1).to(self.encoder.embeddings.device)
-                        val = self.density(pts, bound).reshape(len(x), len(y), len(z))
-                        u[xi * N: xi * N + len(x), yi * N: yi * N + len(y), zi * N: zi * N + len(z)] = val.cpu().numpy()
-        vertices, triangles = mcubes.marching_cubes(-1.0 * u, threshold)
+                        pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).to(dev)
+                        u[xi * N: xi * N + len(x), yi * N: yi * N + len(y), zi * N: zi * N + len(z)] = self.density(pts, bound).reshape(len(x), len(y), len(z))
+        return u.cpu().numpy()
+
+    def extract_geometry(self, bound: float, resolution: int, threshold: int = 0.0, device=None):
+        """iso-surface of the SDF (reference :706-764): vertices [V,3] in world units, triangles [F,3].  The reference runs PyMCubes'
+        marching cubes on -sdf; PyMCubes is used when it is installed, otherwise the built-in marching tetrahedra (geometry.py) on the
+        device: the same surface (every vertex on an sdf = threshold crossing of a grid edge), a different triangulation."""
+        u = -1.0 * self.extract_fields(bound, resolution)
+        try:
+            import mcubes
+            vertices, triangles = mcubes.marching_cubes(u, threshold)
+        except ImportError:
+            from .geometry import marching_tetrahedra
+            v, t = marching_tetrahedra(torch.from_numpy(u).to(self.encoder.embeddings.device), float(threshold))
+            vertices, triangles = v.cpu().numpy().astype(np.float64), t.cpu().numpy()
         vertices = vertices / (resolution - 1.0) * (2 * bound) - bound
         return vertices, triangles
+
+    # ------------------------------------------------------------------ occupancy grid of the ray marcher, reference :303-356
+    def update_extra_state(self, bound, decay=0.95):
+        """density grid for raymarching.march_rays_train / march_rays (only with cuda_ray=True, like the reference): the SDF on the 129^3
+        grid -> a logistic density with inv_s = 512 (inv_s * sigmoid'(-|...|) written in two overflow-free branches), dilated by a 2^3 max
+        pool, merged into the running grid with max(grid * decay, new); mean density and the step-counter bookkeeping."""
+        if not self.cuda_ray:
+            return
+        resolution = self.density_grid.shape[0]
+        dev = self.density_grid.device
+        axes = torch.linspace(-bound, bound, resolution).split(128)
+        tmp_grid = torch.zeros_like(self.density_grid)
+        inv_s = 512.0
+        with torch.no_grad():
+            for xi, xs in enumerate(axes):
+                for yi, ys in enumerate(axes):
+                    for zi, zs in enumerate(axes):
+                        lx, ly, lz = len(xs), len(ys), len(zs)
+                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                        pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).to(dev)
+                        sdf = self.density(pts, bound).detach().float().reshape(-1)
+                        mask = sdf > 0
+                        density = torch.zeros_like(sdf)
+                        density[mask] = inv_s * torch.exp(-inv_s * sdf[mask]) / (1 + torch.exp(-inv_s * sdf[mask]))
+                        density[~mask] = inv_s * torch.exp(inv_s * sdf[~mask]) / (1 + torch.exp(inv_s * sdf[~mask]))
+                        tmp_grid[xi * 128: xi * 128 + lx, yi * 128: yi * 128 + ly, zi * 128: zi * 128 + lz] = density.reshape(lx, ly, lz)
+            tmp_grid = F.pad(tmp_grid, (0, 1, 0, 1, 0, 1))
+            tmp_grid = F.max_pool3d(tmp_grid.unsqueeze(0).unsqueeze(0), kernel_size=2, stride=1).squeeze(0).squeeze(0)
+            self.density_grid = torch.maximum(self.density_grid * decay, tmp_grid)
+        self.mean_density = torch.mean(self.density_grid).item()
+        self.iter_density += 1
+        total_step = min(64, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0

@@ -341,3 +341,25 @@ def warp_samples(pts, verts, faces, T, threshold=0.05):
                            C.c_double(threshold), can.ctypes.data_as(dp), clo.ctypes.data_as(dp), d2.ctypes.data_as(dp), _p(fid, i32p),
                            mask.ctypes.data_as(C.POINTER(C.c_uint8)))
     return can, clo, d2, fid, mask.astype(bool)
+
+
+def update_density_grid(field, grid, bound, decay=0.95, inv_s=512.0, resolution=129):
+    """NeRFRenderer.update_extra_state's grid update (models/instant_nsr.py:309-343): sdf on linspace(-bound, bound, 129)^3 -> logistic
+    density inv_s * e^(-inv_s |sdf|) / (1 + e^(-inv_s |sdf|)) -> zero-pad by one at the far ends, 2x2x2 max pool (stride 1) ->
+    maximum(grid * decay, new).  Returns (new grid, mean density).  numpy fp32 over the C oracle's forward_sdf."""
+    ax = np.linspace(-bound, bound, resolution, dtype=np.float32)            # torch.linspace(-b, b, 129) in fp32
+    xx, yy, zz = np.meshgrid(ax, ax, ax, indexing="ij")
+    pts = np.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], 1).astype(np.float32)
+    sdf = field.sdf(pts, bound)[:, 0].astype(np.float32)
+    a = np.float32(inv_s) * np.abs(sdf)
+    e = np.exp(-a, dtype=np.float32)
+    dens = (np.float32(inv_s) * e / (np.float32(1) + e)).reshape(resolution, resolution, resolution)
+    pad = np.zeros((resolution + 1,) * 3, np.float32)
+    pad[:-1, :-1, :-1] = dens
+    pooled = pad[:-1, :-1, :-1]
+    for dx in (0, 1):
+        for dy in (0, 1):
+            for dz in (0, 1):
+                pooled = np.maximum(pooled, pad[dx:dx + resolution, dy:dy + resolution, dz:dz + resolution])
+    new = np.maximum(np.asarray(grid, np.float32) * np.float32(decay), pooled)
+    return new, float(new.mean(dtype=np.float64))

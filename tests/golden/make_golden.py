@@ -766,3 +766,30 @@ def make_reconstruct_golden():
 
 if __name__ == "__main__":
     make_reconstruct_golden()
+
+
+# ---------------------------------------------------------------- occupancy grid + SDF volume
+def make_density_golden():
+    """NeRFRenderer.update_extra_state (models/instant_nsr.py:303-356) of a cuda_ray=True reference net (the golden weights) and
+    extract_fields (:728-745; extract_geometry's marching cubes needs the absent PyMCubes).  The 129^3 grid is stored at every 4th index."""
+    torch.manual_seed(0)
+    net = ref_nsr.NeRFNetwork(cuda_ray=True)
+    src = build_reference_net()
+    net.load_state_dict(src.state_dict(), strict=False)
+    net.eval()
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        net.update_extra_state(1.6)
+        g1 = net.density_grid.numpy().copy(); m1 = net.mean_density
+        with torch.no_grad():
+            net.sdf_net[1].bias[0] += 0.1                              # a second update on a changed field: the decay / maximum merge
+        net.update_extra_state(1.6)
+    g2 = net.density_grid.numpy().copy()
+    u = ref_nsr.extract_fields(torch.tensor([-1.6] * 3), torch.tensor([1.6] * 3), 33, lambda pts: src.density(pts, 1.6).detach())
+    np.savez_compressed(os.path.join(HERE, "density_grid.npz"), grid1=g1[::4, ::4, ::4], grid2=g2[::4, ::4, ::4], mean1=np.float64(m1), mean2=np.float64(net.mean_density),
+                        max1=np.float32(g1.max()), nnz1=np.int64((g1 > 1e-3).sum()), iter_density=np.int64(net.iter_density), sdf33=u)
+    print("density grid: mean", m1, net.mean_density, "max", g1.max(), "cells > 1e-3:", int((g1 > 1e-3).sum()), "sdf33 range", u.min(), u.max())
+
+
+if __name__ == "__main__":
+    make_density_golden()

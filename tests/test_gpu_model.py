@@ -585,3 +585,59 @@ def test_reconstruct_step_matches_reference_step(tmp_path):
     losses = []
     n = RC.reconstruct_epochs(net, opt, sched, aro, ard, argb, epochs=2, batch_size=256, on_step=lambda s, e, l: losses.append(float(l)))
     assert n == 6 and len(losses) == 6 and np.isfinite(losses).all() and abs(sched.get_last_lr()[0] - 5e-4 * 0.5 * (1 + np.cos(np.pi * 2 / 10))) < 1e-9
+
+
+def test_density_grid_mesh_export_and_marcher(oracle):
+    """update_extra_state (models/instant_nsr.py:303-356) on the fused SDF kernel against the reference's grid and the
+    oracle's restatement, two updates (decay / maximum merge); the grid drives raymarching.march_rays_train exactly as the oracle's marcher;
+    extract_fields against the reference's SDF volume; extract_geometry returns a closed, outward-oriented surface of the field"""
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    from avatarcraft_amd import raymarching
+    from tests.gpu_common import oracle_field as make_of
+    g = load_golden("density_grid.npz")
+    src, p = golden_net()
+    torch.manual_seed(0)
+    net = NeRFNetwork(cuda_ray=True)
+    net.load_state_dict(src.state_dict(), strict=False)
+    net = net.to(DEV).eval()
+    assert tuple(net.density_grid.shape) == (129, 129, 129) and tuple(net.step_counter.shape) == (64, 2)
+    net.update_extra_state(1.6)
+    grid1 = net.density_grid.cpu().numpy()
+    assert np.abs(grid1[::4, ::4, ::4] - g["grid1"]).max() <= 5e-3 * float(g["max1"]) and abs(net.mean_density - float(g["mean1"])) <= 1e-3 * float(g["mean1"])
+    table = src.encoder.embeddings.detach().cpu().numpy()
+    of = make_of(p, table)
+    og, om = oracle.update_density_grid(of, np.zeros((129,) * 3, np.float32), 1.6)
+    # GPU sdf == oracle sdf bit for bit; the density differs only by torch.exp vs numpy exp (both fp32)
+    assert np.abs(grid1 - og).max() <= 2e-4 * float(og.max())
+    with torch.no_grad():
+        net.sdf_net[1].bias[0] += 0.1
+    net.update_extra_state(1.6)
+    assert net.iter_density == int(g["iter_density"]) == 2
+    assert np.abs(net.density_grid.cpu().numpy()[::4, ::4, ::4] - g["grid2"]).max() <= 5e-3 * float(g["max1"]) and abs(net.mean_density - float(g["mean2"])) <= 1e-3 * float(g["mean2"])
+    # the marcher on this grid: GPU == oracle on the same grid values, bit for bit
+    ro, rd = make_rays(8, 8, dist=1.8, f=6.0)
+    gd = net.density_grid
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV), 1.6, gd, net.mean_density, net.iter_density,
+                                                           force_all_rays=True)
+    x_o, d_o, dl_o, r_o, c_o = oracle.march_rays_train(ro, rd, gd.cpu().numpy(), net.mean_density, 1.6)
+    assert np.array_equal(rays.cpu().numpy(), r_o) and int(c_o[0]) > 0
+    M = int(c_o[0])
+    assert np.array_equal(xyzs[:M].cpu().numpy().view(np.uint32), x_o[:M].view(np.uint32)) and np.array_equal(deltas[:M].cpu().numpy().view(np.uint32), dl_o[:M].view(np.uint32))
+    # SDF volume and mesh export
+    u = src.extract_fields(1.6, 33)
+    assert u.shape == (33, 33, 33) and u.dtype == np.float32 and np.abs(u - g["sdf33"]).max() < 1e-5
+    verts, tris = src.extract_geometry(1.6, 48)
+    assert verts.shape[1] == 3 and tris.shape[1] == 3 and len(tris) > 500 and np.abs(verts).max() <= 1.6
+    sd = src.density(torch.from_numpy(verts.astype(np.float32)).to(DEV), 1.6).cpu().numpy()
+    assert np.abs(sd).max() < 2e-2                                       # vertices lie on the zero level set (linear interpolation on a 48^3 grid)
+    e = np.concatenate([tris[:, [0, 1]], tris[:, [1, 2]], tris[:, [2, 0]]])
+    key = e[:, 0].astype(np.int64) * len(verts) + e[:, 1]; rkey = e[:, 1].astype(np.int64) * len(verts) + e[:, 0]
+    assert len(np.unique(key)) == len(key) and np.isin(rkey, key).all()          # closed and consistently oriented
+    a, b, c = (verts[tris[:, k]] for k in range(3))
+    nrm = np.cross(b - a, c - a)
+    with torch.enable_grad():
+        cen = torch.from_numpy(((a + b + c) / 3).astype(np.float32)).to(DEV)
+    gsd = src.gradient(cen, 1.6, 0.005).cpu().numpy() if False else None
+    with torch.no_grad():
+        gsd = src.gradient(cen, 1.6, 0.005).cpu().numpy()
+    assert ((nrm * gsd).sum(1) > 0).mean() > 0.97                         # normals point along the SDF gradient: out of the body
