@@ -635,9 +635,7 @@ def test_density_grid_mesh_export_and_marcher(oracle):
     assert len(np.unique(key)) == len(key) and np.isin(rkey, key).all()          # closed and consistently oriented
     a, b, c = (verts[tris[:, k]] for k in range(3))
     nrm = np.cross(b - a, c - a)
-    with torch.enable_grad():
-        cen = torch.from_numpy(((a + b + c) / 3).astype(np.float32)).to(DEV)
-    gsd = src.gradient(cen, 1.6, 0.005).cpu().numpy() if False else None
+    cen = torch.from_numpy(((a + b + c) / 3).astype(np.float32)).to(DEV)
     with torch.no_grad():
         gsd = src.gradient(cen, 1.6, 0.005).cpu().numpy()
     assert ((nrm * gsd).sum(1) > 0).mean() > 0.97                         # normals point along the SDF gradient: out of the body
