@@ -147,7 +147,7 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
     return res, (net, net_gt)
 
 
-def cpu_baseline_sds(p, table, n_side=16):
+def cpu_baseline_sds(p, table, n_side=16, threads=None):
     """CPU leg of the SDS step on a bounded sample (n_side^2 rays of the same training view): the no-grad renders through the C oracle
     (OpenMP), the differentiable render core as torch-CPU autograd (MKL threads) over a hash encoder served by the oracle's forward /
     backward -- the structure of the reference's own CPU path (pure PyTorch + its hash kernel), with the reference's three backward
@@ -156,8 +156,15 @@ def cpu_baseline_sds(p, table, n_side=16):
     from oracle import oracle as O
     from tests.gpu_common import oracle_field
     from avatarcraft_amd.instant_nsr import NeRFNetwork
-    cores = os.cpu_count() or 1
+    # threads: this leg is many medium-sized torch ops and a hash backward that is parallel over its 16 levels only; on a 256-core host the
+    # full thread count is SLOWER than 32 (51 s per 256-ray step against a few seconds), so the leg runs on min(cores, 32) threads and says so
+    cores = min(os.cpu_count() or 1, 32) if threads is None else int(threads)
     torch.set_num_threads(cores)
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
 
     class _Enc(torch.autograd.Function):
         @staticmethod

@@ -628,7 +628,8 @@ def test_density_grid_mesh_export_and_marcher(oracle):
     assert u.shape == (33, 33, 33) and u.dtype == np.float32 and np.abs(u - g["sdf33"]).max() < 1e-5
     verts, tris = src.extract_geometry(1.6, 48)
     assert verts.shape[1] == 3 and tris.shape[1] == 3 and len(tris) > 500 and np.abs(verts).max() <= 1.6
-    sd = src.density(torch.from_numpy(verts.astype(np.float32)).to(DEV), 1.6).cpu().numpy()
+    with torch.no_grad():
+        sd = src.density(torch.from_numpy(verts.astype(np.float32)).to(DEV), 1.6).cpu().numpy()
     assert np.abs(sd).max() < 2e-2                                       # vertices lie on the zero level set (linear interpolation on a 48^3 grid)
     e = np.concatenate([tris[:, [0, 1]], tris[:, [1, 2]], tris[:, [2, 0]]])
     key = e[:, 0].astype(np.int64) * len(verts) + e[:, 1]; rkey = e[:, 1].astype(np.int64) * len(verts) + e[:, 0]
