@@ -46,12 +46,22 @@ constexpr int OFF_B2 = OFF_B1 + 64;              // [16]
 constexpr int OFF_LVL = OFF_B2 + 16;             // [16 levels][8 words]
 constexpr int OFF_LIN = OFF_LVL + 16 * 8;        // lin_z[64] + lin_u[16]
 constexpr int OFF_SPQ = OFF_LIN + 80;           // softplus G table [128][4]
-constexpr int OFF_WAVE = OFF_SPQ + 512;         // per-wave slabs start here
+constexpr int OFF_WAVE = OFF_SPQ + 512;         // end of the weights every kernel shares; per-wave slabs of the training kernels start here
 constexpr int FE_SLAB = 6 * 8 * 64;                        // hash features of the 6 finite-difference points: [e-1][2j+c][lane]
-constexpr int WAVE_SLAB = 2 * MAXT * 2 + MAXT + 16 + 16 + FE_SLAB;   // zs[2][128], sd[2][128], cdf[128], znew[16], pad, fe
-constexpr int LDS_FLOATS = OFF_WAVE + WAVES_PER_BLOCK * WAVE_SLAB;
+// the renderer only: layer 1 of sdf_net for the "fast" precision (ac_render_opts.precision = 1) -- the 32 feature columns of W1 split into
+// bf16 hi + lo in the A-fragment order of v_mfma_f32_16x16x32_bf16 (lane (unit m, group kk) holds k = 8 kk .. 8 kk + 7 = the eight
+// features lane group kk gathers: 16 bytes per lane and tile), and the three coordinate columns as plain fp32
+constexpr int OFF_W1H = OFF_WAVE;                // [4 tiles][64 lanes][4 dwords]
+constexpr int OFF_W1L = OFF_W1H + 4 * 64 * 4;
+constexpr int OFF_W1C = OFF_W1L + 4 * 64 * 4;    // [3 axes][64 units]
+constexpr int OFF_RWAVE = OFF_W1C + 3 * 64;      // per-wave slabs of the renderer
+// per-wave slab of the renderer: the final z values (zs0) + ONE region that holds the up-sampling state (second z buffer, the two sdf
+// buffers, cdf, new samples) until the sampling of the ray is finished and the finite-difference feature slab afterwards
+constexpr int UPS_FLOATS = MAXT + 2 * MAXT + MAXT + 32;              // zs1[128], sd[2][128], cdf[128], znew[16] + pad
+constexpr int WAVE_SLAB = MAXT + (FE_SLAB > UPS_FLOATS ? FE_SLAB : UPS_FLOATS);
+constexpr int LDS_FLOATS = OFF_RWAVE + WAVES_PER_BLOCK * WAVE_SLAB;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget: one workgroup per CU");
-static_assert(OFF_WAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
+static_assert(OFF_WAVE % 4 == 0 && OFF_RWAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
 
 // per-level launch constants: index = (hashed ? x ^ y*my ^ z*mz : x + y*my + z*mz) & mask [% wsize if wsize]
 // (my,mz) = (P1,P2) for hashed levels, (res+1, (res+1)^2) for dense ones; mask = size-1 for power-of-two hashed
@@ -79,6 +89,7 @@ struct RenderArgs {
     int jfine[4];          // per round: 1 if the FD offset eps can span >= 1 cell on any of its levels
     float bound, two_bound, inv_s, car, one_m_car, eps;
     const float *inv_s_dev;     // non-NULL: inv_s is read from device memory (ac_render_opts.inv_s_dev)
+    int fast;                   // ac_render_opts.precision
     int perturb;
     unsigned long long *prof;   // AC_PROFILE builds only: [n_waves][10]: 8 per-phase s_memtime counters, whole-wave s_memtime and s_memrealtime (100 MHz)
     // posed-space rendering (render_can=False) only: see ac_render_rays_warped
@@ -193,6 +204,32 @@ __device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
     for (int e = threadIdx.x; e < 512; e += blockDim.x) lds[OFF_SPQ + e] = AC_SP_G[e >> 2][e & 3];
 }
 
+// ---- "fast" precision: bf16 hi / lo fragments of W1's feature columns, fp32 coordinate columns ----------
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f)       // finite inputs (weights): round to nearest even
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void fill_lds_fast(float *lds, const RenderArgs &a)
+{
+    uint32_t *lw = reinterpret_cast<uint32_t *>(lds);
+    for (int e = threadIdx.x; e < 4 * 64 * 4; e += blockDim.x) {          // dword q of lane l, tile t: slots i = 2q, 2q + 1 of lane group kk
+        const int q = e & 3, l = (e >> 2) & 63, t = e >> 8;
+        const int u = 16 * t + (l & 15), kk = l >> 4;
+        uint32_t hi2 = 0, lo2 = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * q + h;                                      // feature slot 2 j + c of lane group kk = level 4 j + kk, channel c
+            const float w = a.W1[u * 35 + 3 + 2 * (4 * (i >> 1) + kk) + (i & 1)];
+            const uint32_t hb = bf16_rne_bits(w);
+            const uint32_t lb = bf16_rne_bits(w - __uint_as_float(hb << 16));
+            hi2 |= hb << (16 * h); lo2 |= lb << (16 * h);
+        }
+        lw[OFF_W1H + e] = hi2; lw[OFF_W1L + e] = lo2;
+    }
+    for (int e = threadIdx.x; e < 3 * 64; e += blockDim.x) lds[OFF_W1C + e] = a.W1[(e & 63) * 35 + (e >> 6)];
+}
+
 // ---- hash-grid features of this lane's 4 levels (HashEncoder.forward + kernel_grid) -------------------
 // p: world position (clamped to +-bound); returns f[j][c] for level 4j+g.  The gathers go through a
 // buffer descriptor (32-bit byte offsets, hardware bounds check) and are issued ROUND levels at a time.
@@ -281,6 +318,44 @@ __device__ __forceinline__ Acc4 sdf_l1(const float *__restrict__ lds, int lane, 
             acc.a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W1F + (t * 9 + s) * 64 + lane], b, acc.a[t], 0, 0, 0);
     }
     return acc;
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// layer 1 of one finite-difference evaluation from the centre's layer 1 (acc0, exact fp32):
+//   l1(x +- eps e_k) = acc0 + W1[:, features] (fe - fe0) + W1[:, k] (p_off - p)
+// the middle product on the bf16 matrix pipe with both factors split hi + lo (3 of the 4 partial products; the dropped lo x lo is
+// 2^-16 of a term that is itself ~1e-2 of l1).  The differences are split by truncation: d = hi + (d - hi) exactly, lo = the top 16
+// bits of (d - hi).  B operand: this lane's eight differences = k 8g .. 8g+7, the order fill_lds_fast gives the A rows.
+__device__ __forceinline__ Acc4 sdf_l1_delta(const float *__restrict__ lds, int lane, const Acc4 &acc0, const float (&fe)[4][2],
+                                             const float (&fe0)[4][2], int kn, float dcoord)
+{
+    const int g = lane >> 4;
+    u32x4 bh, bl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float d0 = fe[q][0] - fe0[q][0], d1 = fe[q][1] - fe0[q][1];
+        const uint32_t u0 = __float_as_uint(d0), u1 = __float_as_uint(d1);
+        const float r0 = d0 - __uint_as_float(u0 & 0xffff0000u), r1 = d1 - __uint_as_float(u1 & 0xffff0000u);
+        bh[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);               // (top half of d1) << 16 | top half of d0
+        bl[q] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+    }
+    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+    Acc4 r;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + OFF_W1H + (t * 64 + lane) * 4));
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + OFF_W1L + (t * 64 + lane) * 4));
+        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, acc0.a[t], 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
+        const f32x4 wc = *reinterpret_cast<const f32x4 *>(lds + OFF_W1C + kn * 64 + 16 * t + 4 * g);     // W1[16t + 4g + r][kn]
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) c[rr] = fma_(dcoord, wc[rr], c[rr]);
+        r.a[t] = c;
+    }
+    return r;
 }
 
 __device__ __forceinline__ f32x4 sdf_l2(const float *__restrict__ lds, int lane, const Acc4 &acc)

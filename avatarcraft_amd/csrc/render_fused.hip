@@ -30,20 +30,22 @@
 
 namespace {
 
-template <int MODE>
+template <int MODE, bool FAST>
 __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fill_lds(lds, a);
+    if constexpr (FAST) fill_lds_fast(lds, a);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    float *zs = lds + OFF_WAVE + wave * WAVE_SLAB;      // zs[2][128]
-    float *sd = zs + 2 * MAXT;                          // sd[2][128]
+    float *zs0 = lds + OFF_RWAVE + wave * WAVE_SLAB;    // z buffer 0 [128]: where the final samples of the ray end up
+    float *zs1 = zs0 + MAXT;                            // --- from here on: up-sampling state while the ray is being sampled ...
+    float *sd = zs1 + MAXT;                             // sd[2][128]
     float *cdf = sd + 2 * MAXT;                         // cdf[128]
     float *znl = cdf + MAXT;                            // znew[16]
-    float *fsl = znl + 32;                              // features of the finite-difference points [6][8][64]
+    float *fsl = zs1;                                   // ... and the features of the finite-difference points [6][8][64] afterwards
     const FieldCtx fc = make_ctx(a);
     const W2Row0 w2r0 = load_w2_row0(lds, lane);
     const float bound = a.bound;
@@ -76,11 +78,12 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         }
         const float span = far - near;
         const float sample_dist = span / (float)T0;
-        int cur = 0, cnt = T0;
+        int cur = (MODE == MODE_FINAL) ? 0 : (nup & 1), cnt = T0;      // the buffers swap once per up-sampling iteration: start so that the last lands in zs0
+        float *const zs_first = cur ? zs1 : zs0;
 
         // ---- coarse samples :155-180 -------------------------------------------------------------
         if constexpr (MODE == MODE_FINAL) {
-            for (int i = lane; i < T; i += 64) zs[i] = a.zbuf[(size_t)ray * T + i];
+            for (int i = lane; i < T; i += 64) zs0[i] = a.zbuf[(size_t)ray * T + i];
         } else {
             for (int c = 0; c < T0 / 16; ++c) {
                 const int i = 16 * c + n;
@@ -96,9 +99,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                         pz = clampf(oz + dz * zi, -bound, bound);
                     }
                     const f32x4 o2 = sdf_tile(lds, fc, lane, px, py, pz);
-                    if (g == 0) sd[i] = o2[0];
+                    if (g == 0) sd[cur * MAXT + i] = o2[0];
                 }
-                if (g == 0) zs[i] = zi;
+                if (g == 0) zs_first[i] = zi;
             }
         }
         wave_sync();
@@ -106,8 +109,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 
         // ---- NeuS up-sampling :182-184, :410-475 -----------------------------------------------------
         for (int it = 0; it < (MODE == MODE_FINAL ? 0 : nup); ++it) {
-            const float *zc = zs + cur * MAXT, *sc = sd + cur * MAXT;
-            float *zn_ = zs + (cur ^ 1) * MAXT, *sn_ = sd + (cur ^ 1) * MAXT;
+            const float *zc = cur ? zs1 : zs0, *sc = sd + cur * MAXT;
+            float *zn_ = cur ? zs0 : zs1, *sn_ = sd + (cur ^ 1) * MAXT;
             const int m = cnt - 1;
             const float inv_s = (float)(64 << it);
             float w[2];
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         }
 
         // ---- render core :190-299 ---------------------------------------------------------------------
-        const float *zf = zs + cur * MAXT;
+        const float *zf = zs0;                                  // cur == 0 here by construction
         if constexpr (MODE == MODE_UPSAMPLE) {                 // hand z and the posed-space mid points to the warp
             for (int i = lane; i < T; i += 64) {
                 const float zi = zf[i];
@@ -282,11 +285,33 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             encode_stencil(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
             AC_TICK(3)
             const float pc0 = sel4(g, px, py, pz, 0.0f);
-            // 7 MLP passes, software-pipelined: layer 1 of evaluation e+1 (MFMA) is issued next to the softplus +
-            // layer 2 of evaluation e (VALU), so the matrix and vector pipes of the SIMD overlap inside one wave.
             f32x4 oc = { 0.0f, 0.0f, 0.0f, 0.0f };
             float gr[3] = { 0.0f, 0.0f, 0.0f };
             float spos = 0.0f;
+            if constexpr (FAST) {
+                // precision 1: the centre evaluation exactly (fp32 MFMA), the six offset evaluations as corrections of its layer 1 on the
+                // bf16 matrix pipe (sdf_l1_delta): 12 short MFMA + ~50 VALU per evaluation instead of 36 fp32 MFMA of 32 clocks each
+                const Acc4 acc0 = sdf_l1(lds, lane, pc0, fe0);
+                oc = sdf_l2(lds, lane, acc0);
+#pragma unroll 1
+                for (int e = 0; e < 6; ++e) {
+                    const int kn = e >> 1;
+                    float fe[4][2];
+#pragma unroll
+                    for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fsl[(e * 8 + q_) * 64 + lane];
+                    const float pk = kn == 0 ? px : (kn == 1 ? py : pz);
+                    const float poff = clampf(pk + ((e & 1) ? -bxe : bxe), -bound, bound);
+                    const Acc4 acc = sdf_l1_delta(lds, lane, acc0, fe, fe0, kn, poff - pk);
+                    const float s_e = sdf_l2_sdf(lds, acc, w2r0);
+                    if (!(e & 1)) spos = s_e;
+                    else {
+                        const float gk = 0.5f * (spos - s_e) / bxe;
+                        if (kn == 0) gr[0] = gk; else if (kn == 1) gr[1] = gk; else gr[2] = gk;
+                    }
+                }
+            } else {
+            // 7 MLP passes, software-pipelined: layer 1 of evaluation e+1 (MFMA) is issued next to the softplus +
+            // layer 2 of evaluation e (VALU), so the matrix and vector pipes of the SIMD overlap inside one wave.
             Acc4 acc = sdf_l1(lds, lane, pc0, fe0);
 #pragma unroll 1
             for (int e = 0; e < 7; ++e) {
@@ -311,6 +336,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                     }
                 }
                 acc = accn;
+            }
             }
             AC_TICK(4)
             const float gx = gr[0], gy = gr[1], gz = gr[2];        // every lane of a sample holds the same finite-difference gradient
@@ -497,6 +523,8 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     a.n_rays = op->n_rays; a.T0 = op->num_steps; a.nup = op->upsample_steps / 16;
     a.inv_s = op->inv_s; a.inv_s_dev = op->inv_s_dev; a.car = op->cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
     a.eps = op->fd_eps; a.perturb = op->perturb;
+    if (op->precision != 0 && op->precision != 1) { ac::set_error("ac_render_opts: precision %d unknown (0 = exact, 1 = fast)", op->precision); return AC_ERR_BAD_ARG; }
+    a.fast = op->precision;
     if ((op->near_m != nullptr) != (op->far_m != nullptr)) { ac::set_error("ac_render_opts: near_m and far_m go together"); return AC_ERR_BAD_ARG; }
     a.near_m = op->near_m; a.far_m = op->far_m;
     for (int j = 0; j < 4; ++j) {           // finite-difference reach in cells, per gather round (see encode_stencil)
@@ -509,14 +537,22 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     return AC_OK;
 }
 
-template <int MODE>
-static void launch_render(const RenderArgs &a, hipStream_t stream)
+template <int MODE, bool FAST>
+static void launch_render_p(const RenderArgs &a, hipStream_t stream)
 {
     const int blocks = (a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     static uint64_t seen = 0;                       // one flag per instantiation
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(render_rays_kernel<MODE>), lds_bytes);
-    hipLaunchKernelGGL(render_rays_kernel<MODE>, dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(render_rays_kernel<MODE, FAST>), lds_bytes);
+    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
+}
+template <int MODE>
+static void launch_render(const RenderArgs &a, hipStream_t stream)
+{
+    if constexpr (MODE != MODE_UPSAMPLE) {          // (the sampling-only launch has no finite-difference stage)
+        if (a.fast) { launch_render_p<MODE, true>(a, stream); return; }
+    }
+    launch_render_p<MODE, false>(a, stream);
 }
 
 AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,

@@ -85,6 +85,10 @@ class NeRFRenderer(nn.Module):
     #           kept as the cross-check of "core");
     #   False : sampling launch + torch autograd over the stencil hash encoder (any model configuration).
     fused_training = "core"
+    # arithmetic of the fused renderer (ac_render_opts.precision): "fast" = the six finite-difference evaluations of a sample as split-bf16
+    # corrections of the centre's layer 1 (normals within 6e-5 of "exact", sample positions / indices / sdf bit-identical); "exact" = every
+    # product an fp32 fma in the oracle's order (GPU == CPU oracle bit for bit)
+    render_precision = "fast"
 
     def _offsets_host(self):
         oh = getattr(self, "_offsets_cache", None)
@@ -163,7 +167,7 @@ class NeRFRenderer(nn.Module):
             (image, wsum, depth, nmap, gerr, weights, alpha, color, z_vals) = nsr_ops.render_core(
                 enc.embeddings, wn(self.sdf_net[0]), self.sdf_net[0].bias, wn(self.sdf_net[1]), self.sdf_net[1].bias, wn(self.color_net[0]),
                 wn(self.color_net[1]), wn(self.color_net[2]), inv_s_t, ro, rd, bg, noise, self._offsets_host(), enc.per_level_scale, enc.base_resolution,
-                num_steps, upsample_steps, bound, cos_anneal_ratio, normal_epsilon_ratio)
+                num_steps, upsample_steps, bound, cos_anneal_ratio, normal_epsilon_ratio, precision=self.render_precision)
             return depth.reshape(B, N), weights, wsum[:, None], image.reshape(B, N, 3), nmap, gerr, 0.0, color, alpha, z_vals
         if needs_grad or not full:
             # only the sample positions come from the fused (no-grad) stage (:176-184); the render core runs under autograd: through the fused
@@ -173,7 +177,7 @@ class NeRFRenderer(nn.Module):
             return self._render_core_autograd(ro, rd, z_vals, num_steps, upsample_steps, bound, bg, cos_anneal_ratio, normal_epsilon_ratio, B, N,
                                               near_far=near_far)
         out = nsr_ops.render_rays(self._field(), ro, rd, num_steps, upsample_steps, bound, inv_s_t, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
-                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp, near_far=near_far)
+                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp, near_far=near_far, precision=self.render_precision)
         return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
                 out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])
 

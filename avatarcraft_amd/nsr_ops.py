@@ -68,6 +68,9 @@ def linspace_tables(num_steps, device):
     return _LIN_CACHE[key]
 
 
+PRECISIONS = {"exact": 0, "fast": 1}
+
+
 class RenderResult(dict):
     """the tensors a render launch produced (a dict), plus `.opts`: the launch's ac_render_opts and the tensors its pointers refer to"""
     opts = None
@@ -86,13 +89,15 @@ def _inv_s_arg(inv_s):
 
 def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg=None, noise=None,
                 cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None, events=None, warp=None,
-                train_extras=False, near_far=None):
+                train_extras=False, near_far=None, precision="exact"):
     """One launch of the fused renderer for N rays.  Returns a dict of CUDA tensors:
     image[N,3] weights_sum[N] depth[N] normal_map[N,3] eik[N,2] gradient_error[] (+ z_vals, weights,
     alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices; + sdf_out16 [N,T,16], pts [N,T,3] and
     eik_res = (gradient_error, eikonal denominator) when train_extras: what the render-core backward needs).
     inv_s: a float, or forward_variance() as a CUDA tensor (read on the device).
     near_far = (near [N], far [N]): per-ray sampling range that overrides the cube's where finite (the mesh-guided range of a canonical render).
+    precision: "exact" (every product an fp32 fma, bit-identical to the CPU oracle) or "fast" (layer 1 of the six finite-difference
+    evaluations as a split-bf16 correction of the centre's; sample positions, indices and sdf unchanged bit for bit; ac_render_opts.precision).
     warp = WarpMesh(...) renders in posed space (run(render_can=False)): + can_mid[N,T,3], mask[N,T] views of the scratch."""
     rays_o = _chk(rays_o.reshape(-1, 3), "rays_o")
     rays_d = _chk(rays_d.reshape(-1, 3), "rays_d")
@@ -138,7 +143,8 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     if near_far is not None:
         nm, fm = _chk(near_far[0].reshape(-1), "near", (N,)), _chk(near_far[1].reshape(-1), "far", (N,))
     op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), inv_s_f, float(cos_anneal_ratio),
-                          float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None), L.ptr(inv_s_t), L.ptr(nm), L.ptr(fm))
+                          float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None), L.ptr(inv_s_t), L.ptr(nm), L.ptr(fm),
+                          PRECISIONS[precision], 0)
     if isinstance(res, RenderResult):
         res.opts = (op, inv_s_t, nm, fm)
     st = L.current_stream(dev)
@@ -180,7 +186,7 @@ def sample_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     nm = fm = None
     if near_far is not None:
         nm, fm = _chk(near_far[0].reshape(-1), "near", (N,)), _chk(near_far[1].reshape(-1), "far", (N,))
-    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), 1.0, 1.0, 0.005, int(noise is not None), None, L.ptr(nm), L.ptr(fm))
+    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), 1.0, 1.0, 0.005, int(noise is not None), None, L.ptr(nm), L.ptr(fm), 0, 0)
     L.check(L.lib().ac_sample_rays(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(noise), lin_z.data_ptr(),
                                    lin_u.data_ptr(), z.data_ptr(), L.current_stream(dev)), "sample_rays")
     return z
@@ -244,12 +250,12 @@ class _RenderCore(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, cfg):
-        offsets, pls, H, T0, up, bound, car, ner = cfg
+        offsets, pls, H, T0, up, bound, car, ner, precision = cfg
         ctx.set_materialize_grads(False)              # an output the loss does not use arrives as None -> a NULL upstream pointer
         d = lambda t: t.detach().contiguous()
         field = Field(d(table), offsets, pls, H, d(W1), d(b1), d(W2), d(b2), d(Wc1), d(Wc2), d(Wc3))
         out = render_rays(field, rays_o, rays_d, T0, up, bound, inv_s, bg=bg, noise=noise, cos_anneal_ratio=car, normal_epsilon_ratio=ner,
-                          extras=True, train_extras=True)
+                          extras=True, train_extras=True, precision=precision)
         ctx.field, ctx.cfg = field, cfg
         ctx.opts = out.opts                                        # the launch's ac_render_opts (+ the tensors its pointers refer to)
         ctx.has_bg = bg is not None
@@ -293,10 +299,10 @@ class _RenderCore(torch.autograd.Function):
 
 
 def render_core(table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, offsets, per_level_scale, base_resolution, num_steps,
-                upsample_steps, bound, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0):
+                upsample_steps, bound, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, precision="exact"):
     """-> image [N,3], weights_sum [N], depth [N], normal_map [N,3], gradient_error [], weights [N,T], alpha [N,T], color [N,T,3], z_vals [N,T]"""
     cfg = ([int(v) for v in offsets], per_level_scale, int(base_resolution), int(num_steps), int(upsample_steps), float(bound),
-           float(cos_anneal_ratio), float(normal_epsilon_ratio))
+           float(cos_anneal_ratio), float(normal_epsilon_ratio), precision)
     return _RenderCore.apply(table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, cfg)
 
 

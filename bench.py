@@ -279,6 +279,9 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fast", "exact"], default="fast",
+                    help="arithmetic of the render kernel (ac_render_opts.precision): fast = the product's default (split-bf16 correction for the six "
+                         "finite-difference evaluations; sample positions bit-identical, pixels within 2e-4 of exact); exact = every product an fp32 fma, == CPU oracle")
     ap.add_argument("--sds-steps", type=int, default=8, help="also time this many 4096-ray SDS steps (secondary metric); 0 = skip")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
@@ -313,7 +316,7 @@ def main():
     def step(k, ev=None):
         b = k % nb
         sl = slice(b * RAYS_PER_BATCH, (b + 1) * RAYS_PER_BATCH)
-        nsr_ops.render_rays(field, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=outs[b], events=ev)
+        nsr_ops.render_rays(field, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=outs[b], events=ev, precision=a.precision)
 
     for k in range(a.warmup):
         step(k)
@@ -365,7 +368,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "render_canonical 256x256, hash-grid Instant-NSR, 64+64 samples/ray, 16 x 4096-ray batches, eval, 1 view per rank",
-                       "rays_per_step": RAYS_PER_BATCH, "table_mb": round(table.nbytes / 1e6, 2), "parallelism": f"dp{world} (independent views, no collective)"},
+                       "rays_per_step": RAYS_PER_BATCH, "table_mb": round(table.nbytes / 1e6, 2), "parallelism": f"dp{world} (independent views, no collective)",
+                       "precision": a.precision},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "render_rays_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_RAY * RAYS_PER_BATCH,

@@ -143,6 +143,14 @@ typedef struct ac_render_opts {
     const float *near_m, *far_m; /* optional [N]: per-ray sampling range that replaces the cube's where finite (+-inf = keep the cube's):
                                  the mesh-guided range of run(render_can=True, verts=..., use_mesh_guide=True), instant_nsr.py:147-153,
                                  as produced by ac_mesh_near_far.  NULL = cube only.  (ac_render_rays_warped computes its own.)       */
+    int32_t precision;        /* 0 = exact: every product an fp32 fma in a stated order (bit-identical to the CPU oracle);
+                                 1 = fast: layer 1 of the six finite-difference evaluations of a sample as
+                                     l1(x +- eps e_k) = l1(x) [exact fp32] + W1 (h(x +- eps e_k) - h(x)) + W1[:,k] (+-eps)
+                                 with the middle product on the bf16 matrix pipe, both factors split into hi + lo bf16 (3 products, fp32
+                                 accumulate): the correction term is ~1e-2 of l1, its 2^-16 relative error is below fp32 round-off of l1
+                                 itself (normals within 6e-5 of the exact mode).  Sample positions (everything that feeds searchsorted / the
+                                 sort), the centre evaluation and the colour network are unaffected: z_vals, indices and sdf stay bit-identical. */
+    int32_t reserved_;
 } ac_render_opts;
 
 typedef struct ac_render_out {

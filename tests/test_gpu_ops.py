@@ -547,7 +547,8 @@ def test_hash_backward_binned_nonfinite_gradients(oracle):
     nbytes = int(Lb.lib().ac_hash_encode_backward_scratch(offs.ctypes.data, 3, 2, 16, S, 16, B))
     sc = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     gg = torch.zeros_like(emb)
-    Lb.check(Lb.lib().ac_hash_encode_backward_ws(T(g).data_ptr(), T(x).data_ptr(), emb.data_ptr(), ot.data_ptr(), offs.ctypes.data, gg.data_ptr(), B, 3, 2, 16,
+    gt_, xt = T(g), T(x)                          # (named: a temporary's memory may be handed to the next allocation before the kernel runs)
+    Lb.check(Lb.lib().ac_hash_encode_backward_ws(gt_.data_ptr(), xt.data_ptr(), emb.data_ptr(), ot.data_ptr(), offs.ctypes.data, gg.data_ptr(), B, 3, 2, 16,
                                                  S, 16, 0, dummy.data_ptr(), dummy.data_ptr(), sc.data_ptr(), nbytes, None))
     torch.cuda.synchronize()
     got = gg.cpu().numpy()

@@ -20,12 +20,12 @@ def env(oracle):
     return dict(p=p, f=f, of=oracle_field(p, table), O=oracle)
 
 
-def _run_both(env, ro, rd, T0, up, bg=None, noise=None, car=1.0):
+def _run_both(env, ro, rd, T0, up, bg=None, noise=None, car=1.0, precision="exact"):
     from avatarcraft_amd import nsr_ops
     d = "cuda:0"
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(d)
     g = nsr_ops.render_rays(env["f"], t(ro), t(rd), T0, up, 1.6, float(env["p"]["inv_s"]), bg=t(bg), noise=t(noise),
-                            cos_anneal_ratio=car, extras=True, debug_indices=True)
+                            cos_anneal_ratio=car, extras=True, debug_indices=True, precision=precision)
     torch.cuda.synchronize()
     r = env["O"].render_rays(env["of"], ro, rd, T0, up, 1.6, float(env["p"]["inv_s"]), bg=bg, noise=noise, cos_anneal_ratio=car)
     return g, r
@@ -47,11 +47,12 @@ def test_render_bitwise_vs_oracle_on_golden_inputs(env, name):
     _compare_bitwise(g, r, int(gd["upsample_steps"]))
 
 
+@pytest.mark.parametrize("precision", ["exact", "fast"])
 @pytest.mark.parametrize("name", ["eval_64_64", "train_64_64", "eval_32_32", "eval_64_0", "eval_edge", "train_edge"])
-def test_render_vs_reference_golden(env, name):
-    """GPU output against the reference's own run() output (tests/golden/make_golden.py)."""
+def test_render_vs_reference_golden(env, name, precision):
+    """GPU output against the reference's own run() output (tests/golden/make_golden.py), in both arithmetic modes of the renderer."""
     gd = load_golden(f"run_{name}.npz")
-    g, _ = _run_both(env, gd["rays_o"], gd["rays_d"], int(gd["num_steps"]), int(gd["upsample_steps"]), gd["bg"], gd.get("noise"))
+    g, _ = _run_both(env, gd["rays_o"], gd["rays_d"], int(gd["num_steps"]), int(gd["upsample_steps"]), gd["bg"], gd.get("noise"), precision=precision)
     c = lambda k: g[k].cpu().numpy()
     assert np.abs(c("image") - gd["image"]).max() <= 1e-3          # north-star tolerance: RGB within 1e-3 L_inf
     assert np.abs(c("weights_sum") - gd["weights_sum"]).max() <= 1e-3
@@ -63,6 +64,51 @@ def test_render_vs_reference_golden(env, name):
         from tests.test_oracle_golden import _indices_match
         _indices_match(c("ss_inds"), gd["ss_inds"], c("sort_index")[:, :up], gd["sort_index"][:, :up], gd["oracle_ss_flips"])
         assert np.abs(c("z_vals") - gd["z_vals"]).max() <= 2e-3
+
+
+def test_fast_precision_against_exact(env):
+    """ac_render_opts.precision = 1 ("fast": the six finite-difference evaluations of a sample as split-bf16 corrections of the centre's layer 1)
+    against precision = 0 (every product an fp32 fma, == the CPU oracle): everything that decides WHERE the samples are -- z values,
+    searchsorted indices, sort permutations -- and the sdf itself must be identical bit for bit; normals, colours, weights and pixels
+    differ by less than fp32 round-off of the exact mode differs from an fp64 evaluation (observed differences are written to gpurun_out/)"""
+    from avatarcraft_amd import nsr_ops
+    worst = {}
+    cases = [("eval_64_64", None), ("train_64_64", None), ("eval_edge", None), ("eval_32_32", None)]
+    ro, rd = make_rays(64, 64, dist=1.7, f=50.0)
+    cases.append(("view4096", (ro, rd)))
+    for name, rays in cases:
+        if rays is None:
+            gd = load_golden(f"run_{name}.npz")
+            args = (gd["rays_o"], gd["rays_d"], int(gd["num_steps"]), int(gd["upsample_steps"]), gd["bg"], gd.get("noise"))
+        else:
+            args = (rays[0], rays[1], 64, 64, None, None)
+        d = "cuda:0"
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(d)
+        run = lambda prec: nsr_ops.render_rays(env["f"], t(args[0]), t(args[1]), args[2], args[3], 1.6, float(env["p"]["inv_s"]), bg=t(args[4]), noise=t(args[5]),
+                                               extras=True, debug_indices=True, precision=prec)
+        e, f = run("exact"), run("fast")
+        for k in ("z_vals", "sdf") + (("ss_inds", "sort_index") if args[3] else ()):
+            assert torch.equal(e[k], f[k]), (name, k)
+        for k, tol in (("image", 2e-4), ("weights_sum", 2e-4), ("depth", 2e-4), ("normal_map", 5e-4), ("weights", 3e-4), ("alpha", 3e-4), ("color", 2e-4)):
+            dmax = float((e[k] - f[k]).abs().max())
+            worst[f"{name}.{k}"] = dmax
+            assert dmax <= tol, (name, k, dmax)
+        gn = e["gradient"].norm(dim=-1, keepdim=True).clamp_min(1e-3)
+        dg = float(((e["gradient"] - f["gradient"]).abs() / gn).max())
+        worst[f"{name}.gradient_rel"] = dg
+        assert dg <= 2e-3, (name, dg)
+        assert abs(float(e["gradient_error"]) - float(f["gradient_error"])) <= 1e-5
+    with pytest.raises(RuntimeError, match="precision"):
+        from avatarcraft_amd import _lib as L
+        import ctypes as C
+        op = L.ac_render_opts(8, 32, 32, 1.6, 1.0, 1.0, 0.005, 0, None, None, None, 7, 0)
+        o = L.ac_render_out(); z = torch.zeros(64, device="cuda:0")
+        for k in ("image", "weights_sum", "depth", "normal_map", "eik"):
+            setattr(o, k, z.data_ptr())
+        L.check(L.lib().ac_render_rays(C.byref(env["f"].c), C.byref(op), z.data_ptr(), z.data_ptr(), None, None, z.data_ptr(), z.data_ptr(), C.byref(o), None))
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(worst, open("gpurun_out/fast_vs_exact.json", "w"), indent=1)
 
 
 def test_render_bitwise_random_rays_4096(env):
@@ -209,7 +255,7 @@ def test_warped_render_bad_arguments(env):
     with pytest.raises(RuntimeError, match="unsupported"):
         nsr_ops.render_rays(env["f"], t(ro), t(rd), 24, 32, 1.6, 1.0, warp=wm)
     # scratch too small is refused
-    op = L.ac_render_opts(16, 32, 32, 1.6, 1.0, 1.0, 0.005, 0, None, None, None)
+    op = L.ac_render_opts(16, 32, 32, 1.6, 1.0, 1.0, 0.005, 0, None, None, None, 0, 0)
     o = L.ac_render_out()
     for k in ("image", "weights_sum", "depth", "normal_map", "eik"):
         setattr(o, k, torch.empty(64, device="cuda:0").data_ptr())
