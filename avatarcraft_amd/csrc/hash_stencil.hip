@@ -233,7 +233,7 @@ struct BinSink {
     uint32_t *hist, *base;                 // this wave's LDS [NBUCKET] each (hist zero between flushes)
     uint32_t cnt;                          // wave-uniform
     uint32_t sh;                           // bucket = index >> sh (2^sh entries per bucket, <= NBUCKET buckets per level)
-    uint32_t mx;                           // per lane: bits of the largest |v| recorded since the last flush
+    uint32_t mx;                           // per lane: bits of the largest |v| this lane has recorded (published once, by finish())
     uint32_t *qcount;                      // global [NBUCKET] of this level
     uint32_t *vmax;                        // global: bits of max |v| over this level's records (positive floats order like uints)
     Rec *queue;                            // global [NBUCKET][cap] of this level
@@ -276,17 +276,22 @@ struct BinSink {
             cnt += (uint32_t)__builtin_popcountll(m[k]);
         }
     }
+    // the level's largest |v| (the fixed-point scale of bucket_accumulate_kernel): one wave reduction and one global atomic per WAVE,
+    // after its last flush (it used to be per flush: 0.26 of the fill's 1.8 ms, profiles/r01_sds.txt "without the max pass")
+    __device__ __forceinline__ void finish()
+    {
+        flush();
+        uint32_t wmx = mx;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)wmx, d); wmx = wmx > o ? wmx : o; }
+        if (lane == 0 && wmx) atomicMax(vmax, wmx);
+    }
     __device__ __forceinline__ void flush()
     {
 #if AC_ABL_FLUSH == 1       // timing ablation: drop the records
         cnt = 0; return;
 #endif
         tick(1);
-        uint32_t wmx = mx;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)wmx, d); wmx = wmx > o ? wmx : o; }
-        if (lane == 0 && wmx) atomicMax(vmax, wmx);
-        mx = 0u;
         wave_sync_lds();
         {
             const uint32_t c = hist[lane];
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
         }
         stencil_scatter(sink, L, fine, xc, gp, eps, bound, two_bound, lane);
     }
-    sink.flush();
+    sink.finish();
 #ifdef AC_PROFILE_FILL
     if (lane == 0) {
         unsigned long long *o = g_fill_prof + (size_t)level * 6;
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
         if (!valid) g = make_float2(0.0f, 0.0f);
         scatter8_runs(sink, L, q, g.x, g.y, lane, __any(nonfinite(g.x) | nonfinite(g.y)) != 0);
     }
-    sink.flush();
+    sink.finish();
 }
 
 // one workgroup per (bucket, binned level): sum the bucket's queue in LDS, then add the slice to the table (no atomics: the
@@ -629,7 +634,10 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
     const int emax = (int)(mbits >> 23) - 126;                                       // |v| < 2^emax for every record of the level
     const int head = 32 - __builtin_clz(n);                                          // ceil(log2(n + 1))
     const int k = 62 - head - emax;
-    constexpr int U = 4;
+#ifndef AC_ACC_U
+#define AC_ACC_U 4
+#endif
+    constexpr int U = AC_ACC_U;                          // queue records in flight per thread
     for (uint32_t i0 = threadIdx.x; i0 < n; i0 += blockDim.x * U) {
         Rec r[U];
 #pragma unroll
@@ -767,7 +775,10 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
         ac::allow_dynamic_lds(seen1, reinterpret_cast<const void *>(hash_stencil_bwd_binned_kernel), lds1);
         ac::allow_dynamic_lds(seen2, reinterpret_cast<const void *>(bucket_accumulate_kernel), lds2);
         uint32_t gx = ((B + 63) / 64 + 3) / 4;
-        if (gx > 256) gx = 256;                          // persistent waves: full record buffers per flush
+#ifndef AC_FILL_GX
+#define AC_FILL_GX 128     // workgroups per level: 256 -> 128 is 3.66 -> 3.39 ms of backward per step (96: 3.51, 64: 3.53, 32: 3.77; profiles/r02_experiments.txt)
+#endif
+        if (gx > AC_FILL_GX) gx = AC_FILL_GX;            // persistent waves: full record buffers per flush, few partial last ones
         hipLaunchKernelGGL(hash_stencil_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, x, grad_embeddings, B, lt, eps, bound,
                            two_bound, fine_mask, sc.binned_mask, qcount, queues, sc.cap);
         hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount,
@@ -819,7 +830,7 @@ AC_API int ac_hash_encode_backward_ws(const float *grad, const float *inputs, co
     ac::allow_dynamic_lds(seen1, reinterpret_cast<const void *>(hash_bwd_binned_kernel), lds1);
     ac::allow_dynamic_lds(seen2, reinterpret_cast<const void *>(bucket_accumulate_kernel), lds2);
     uint32_t gx = ((B + 63) / 64 + 3) / 4;
-    if (gx > 256) gx = 256;
+    if (gx > AC_FILL_GX) gx = AC_FILL_GX;
     hipLaunchKernelGGL(hash_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, inputs, grad_embeddings, B, lt, sc.binned_mask, qcount,
                        queues, sc.cap);
     hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount, queues,
