@@ -342,8 +342,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float gx = gr[0], gy = gr[1], gz = gr[2];        // every lane of a sample holds the same finite-difference gradient
             const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
             const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
-            float rgb[3] = { 0.0f, 0.0f, 0.0f };
-            if (a.out.image || a.out.color) color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);      // (wave-uniform) no pixel wanted: opacity / depth / normals only
+            float rgb[3];
+            color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
             AC_TICK(5)
             // NeuS alpha :219-248
             const float sdf0 = oc[0];
@@ -393,11 +393,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         }
         if (lane == 0) {
             const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
-            if (a.out.image) {
-                a.out.image[3 * ray] = s_r + (1.0f - s_w) * b0;
-                a.out.image[3 * ray + 1] = s_g + (1.0f - s_w) * b1;
-                a.out.image[3 * ray + 2] = s_b + (1.0f - s_w) * b2;
-            }
+            a.out.image[3 * ray] = s_r + (1.0f - s_w) * b0;
+            a.out.image[3 * ray + 1] = s_g + (1.0f - s_w) * b1;
+            a.out.image[3 * ray + 2] = s_b + (1.0f - s_w) * b2;
             a.out.normal_map[3 * ray] = s_nx; a.out.normal_map[3 * ray + 1] = s_ny; a.out.normal_map[3 * ray + 2] = s_nz;
             a.out.weights_sum[ray] = s_w;
             a.out.depth[ray] = s_d;
@@ -509,7 +507,7 @@ static int check_render_args(const char *who, const ac_render_opts *op, const fl
         return AC_ERR_BAD_ARG;
     }
     if (op->n_rays <= 0) return AC_OK;
-    if (!rays_o || !rays_d || !lin_z || (op->upsample_steps && !lin_u) || (op->perturb && !noise) ||
+    if (!rays_o || !rays_d || !lin_z || (op->upsample_steps && !lin_u) || (op->perturb && !noise) || !out->image ||
         !out->weights_sum || !out->depth || !out->normal_map || !out->eik) {
         ac::set_error("%s: NULL buffer", who); return AC_ERR_BAD_ARG;
     }

@@ -127,9 +127,7 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ run == reference :133-299
     def run(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0,
-            render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True, opacity_only: bool = False):
-        """opacity_only (not in the reference's signature): a no-grad render whose caller only reads weight_sum / depth / normal -- the colour
-        network is skipped and `rgb`, `pts_color` come back as None (the frozen net_gt of the stylisation step)"""
+            render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True):
         if not self._sdf_supported():
             raise NotImplementedError("the MI355X renderer needs the default SDF side of NeRFNetwork (16-level hash grid, include_input, "
                                       "SDF network 35-64-16); other widths / depths have no sampling kernel")
@@ -178,12 +176,8 @@ class NeRFRenderer(nn.Module):
                                          near_far=near_far)
             return self._render_core_autograd(ro, rd, z_vals, num_steps, upsample_steps, bound, bg, cos_anneal_ratio, normal_epsilon_ratio, B, N,
                                               near_far=near_far)
-        lean = opacity_only and warp is None
         out = nsr_ops.render_rays(self._field(), ro, rd, num_steps, upsample_steps, bound, inv_s_t, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
-                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=not lean, warp=warp, near_far=near_far, precision=self.render_precision,
-                                  want_image=not lean)
-        if lean:
-            return (out["depth"].reshape(B, N), None, out["weights_sum"][:, None], None, out["normal_map"], out["gradient_error"], 0.0, None, None, None)
+                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp, near_far=near_far, precision=self.render_precision)
         return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
                 out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])
 
@@ -283,7 +277,7 @@ class NeRFRenderer(nn.Module):
         else:
             (depth, weights, weight_sum, image, normal, gradient_error, curvature_error, pts_color, pts_alpha, z_vals) = self.run(
                 rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio, normal_epsilon_ratio, render_can=render_can,
-                verts=verts, faces=faces, Ts=Ts, perturb_overwrite=perturb, use_mesh_guide=use_mesh_guide, opacity_only=bool(kwargs.get("opacity_only", False)))
+                verts=verts, faces=faces, Ts=Ts, perturb_overwrite=perturb, use_mesh_guide=use_mesh_guide)
         return {'depth': depth, 'weights': weights, 'weight_sum': weight_sum, 'rgb': image, 'normal': normal,
                 'gradient_error': gradient_error, 'curvature_error': curvature_error, 'pts_color': pts_color, 'pts_alpha': pts_alpha,
                 'z_vals': z_vals}

@@ -89,7 +89,7 @@ def _inv_s_arg(inv_s):
 
 def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg=None, noise=None,
                 cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None, events=None, warp=None,
-                train_extras=False, near_far=None, precision="exact", want_image=True):
+                train_extras=False, near_far=None, precision="exact"):
     """One launch of the fused renderer for N rays.  Returns a dict of CUDA tensors:
     image[N,3] weights_sum[N] depth[N] normal_map[N,3] eik[N,2] gradient_error[] (+ z_vals, weights,
     alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices; + sdf_out16 [N,T,16], pts [N,T,3] and
@@ -115,8 +115,7 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
             res[name] = t
         return t
     o = L.ac_render_out()
-    if want_image:                      # False: no pixels (and no colour network): weights_sum / depth / normal_map only
-        o.image = buf("image", (N, 3)).data_ptr()
+    o.image = buf("image", (N, 3)).data_ptr()
     o.weights_sum = buf("weights_sum", (N,)).data_ptr()
     o.depth = buf("depth", (N,)).data_ptr()
     o.normal_map = buf("normal_map", (N, 3)).data_ptr()

@@ -71,10 +71,9 @@ def _background_on(device, shape, key):
 # ------------------------------------------------------------------ the batching harness
 def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_grad=False, return_torch=True, bkg_key: int = WHITE_BKG,
                             render_can: bool = False, perturb: bool = True, return_raw: bool = False, verts=None, faces=None, Ts=None,
-                            num_steps: int = 64, upsample_steps=64, bound: float = 1.6, opacity_only: bool = False):
+                            num_steps: int = 64, upsample_steps=64, bound: float = 1.6):
     """Same signature, defaults and outputs as the reference (render_utils.py:514-600):
-    returns (rgb[Ntot,3], sum of eikonal terms[, {depth[Ntot,1], weight_sum[Ntot,1], normal[Ntot,3]}]).
-    opacity_only (extra, no-grad only): the caller reads the extras alone -- no colour network, rgb is None."""
+    returns (rgb[Ntot,3], sum of eikonal terms[, {depth[Ntot,1], weight_sum[Ntot,1], normal[Ntot,3]}])."""
     device = rays_o.device
     total = rays_o.shape[0]
     rgbs, depths, wsums, normals = [], [], [], []
@@ -87,14 +86,14 @@ def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_g
             background_rgb = _background_on(device, ro.shape, bkg_key)
             out = net.render(ro.unsqueeze(0), rd.unsqueeze(0), num_steps=num_steps, upsample_steps=upsample_steps, bound=bound, staged=False,
                              bg_color=background_rgb, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=render_can, verts=verts,
-                             faces=faces, Ts=Ts, perturb=perturb, opacity_only=opacity_only and not requires_grad)
+                             faces=faces, Ts=Ts, perturb=perturb)
             total_eikonal = total_eikonal + out["gradient_error"]
             rgbs.append(out['rgb']); wsums.append(out['weight_sum']); depths.append(out['depth']); normals.append(out['normal'])
-        rgb = torch.cat(rgbs, dim=1).squeeze(0).reshape(-1, 3) if rgbs[0] is not None else None
+        rgb = torch.cat(rgbs, dim=1).squeeze(0).reshape(-1, 3)
         extra = {"depth": torch.cat(depths, dim=1).squeeze(0).reshape(-1, 1), "weight_sum": torch.cat(wsums).reshape(-1, 1),
                  "normal": torch.cat(normals).reshape(-1, 3)}
     if not return_torch:
-        rgb = rgb.detach().cpu().numpy() if rgb is not None else None
+        rgb = rgb.detach().cpu().numpy()
         extra = {k: v.detach().cpu().numpy() for k, v in extra.items()}
     if return_raw:
         return rgb, total_eikonal, extra

@@ -90,8 +90,7 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
             total = total + eik_loss
         with torch.no_grad():       # frozen reference avatar: its graph is never used (the reference detaches it, :187)
             _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
-                                                     return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps,
-                                                     opacity_only=True)             # only its accumulated opacity is read (stylize.py:186)
+                                                     return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps)
         opacity_loss = F.smooth_l1_loss(opacity_pred.clamp(0.0, 1.0), extra_gt["weight_sum"].clamp(0.0, 1.0).detach()) * 1e5
         opa_vals.append(opacity_loss.detach())
         if use_opacity:

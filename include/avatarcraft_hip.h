@@ -154,8 +154,7 @@ typedef struct ac_render_opts {
 } ac_render_opts;
 
 typedef struct ac_render_out {
-    float *image;             /* [N,3]  rgb incl. background blend; NULL (with color NULL) = the colour network is
-                                 skipped: opacity / depth / normals only (the frozen net_gt of stylize.py:177-186)  */
+    float *image;             /* [N,3]  rgb incl. background blend                                */
     float *weights_sum;       /* [N]                                                              */
     float *depth;             /* [N]                                                              */
     float *normal_map;        /* [N,3]                                                            */

@@ -55,10 +55,6 @@ def test_render_instantnsr_naive_batches_and_shapes():
     rgbk, _ = render_instantnsr_naive(net, ro_t, rd_t, rays_per_batch=256, bkg_key=BLACK_BKG, render_can=True, perturb=False)
     ws = extra["weight_sum"]
     assert torch.allclose(rgb - rgbk, (1 - ws).expand(-1, 3), atol=1e-6)          # image = colour + (1 - w) * bg
-    # opacity_only: no colour network, the same opacity / depth / normals bit for bit (the frozen net_gt render of the stylisation step)
-    none_rgb, _, lean = render_instantnsr_naive(net, ro_t, rd_t, rays_per_batch=100, bkg_key=WHITE_BKG, render_can=True, perturb=False, return_raw=True,
-                                                opacity_only=True)
-    assert none_rgb is None and torch.equal(lean["weight_sum"], extra["weight_sum"]) and torch.equal(lean["depth"], extra["depth"]) and torch.equal(lean["normal"], extra["normal"])
     with pytest.raises(RuntimeError, match="needs verts"):
         render_instantnsr_naive(net, ro_t, rd_t, render_can=False)       # the reference's default: posed space, needs the frame's mesh
 
