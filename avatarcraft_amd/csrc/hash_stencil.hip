@@ -500,9 +500,12 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
                                                                       uint32_t *__restrict__ qcount, Rec *__restrict__ queues, uint32_t cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    // the blockIdx.y-th set bit of binned_mask
+    // the finest levels cost 2.5x the coarse ones (every stencil point scatters on its own): dispatch them FIRST, so that the cheap
+    // levels fill the tail of the launch.  ylev = which binned level this workgroup serves (queue / counter index), highest first.
+    const uint32_t ylev = gridDim.y - 1u - blockIdx.y;
+    // the ylev-th set bit of binned_mask
     uint32_t level = 0, seen = 0;
-    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
+    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == ylev) level = l; ++seen; }
     const uint32_t Lc = lt.L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const LevelC L = level_of(lt, level);
@@ -512,9 +515,9 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
     sink.cnt = 0; sink.lane = lane;
     sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
-    sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
-    sink.vmax = qcount + (size_t)gridDim.y * NBUCKET + blockIdx.y;
-    sink.queue = queues + (size_t)blockIdx.y * NBUCKET * cap;
+    sink.qcount = qcount + (size_t)ylev * NBUCKET;
+    sink.vmax = qcount + (size_t)gridDim.y * NBUCKET + ylev;
+    sink.queue = queues + (size_t)ylev * NBUCKET * cap;
     sink.cap = cap;
     sink.gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
     sink.hist[lane] = 0u;
@@ -554,8 +557,9 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
                                                               uint32_t *__restrict__ qcount, Rec *__restrict__ queues, uint32_t cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t ylev = gridDim.y - 1u - blockIdx.y;            // finest level first (see hash_stencil_bwd_binned_kernel)
     uint32_t level = 0, seen = 0;
-    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
+    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == ylev) level = l; ++seen; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const LevelC L = level_of(lt, level);
     uint32_t *wbase = smem + wave * WAVE_WORDS;
@@ -564,9 +568,9 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
     sink.cnt = 0; sink.lane = lane;
     sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
-    sink.qcount = qcount + (size_t)blockIdx.y * NBUCKET;
-    sink.vmax = qcount + (size_t)gridDim.y * NBUCKET + blockIdx.y;
-    sink.queue = queues + (size_t)blockIdx.y * NBUCKET * cap;
+    sink.qcount = qcount + (size_t)ylev * NBUCKET;
+    sink.vmax = qcount + (size_t)gridDim.y * NBUCKET + ylev;
+    sink.queue = queues + (size_t)ylev * NBUCKET * cap;
     sink.cap = cap;
     sink.gg = reinterpret_cast<float2 *>(grad_grid) + lt.offset[level];
     sink.hist[lane] = 0u;
@@ -602,16 +606,17 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
                                                                  const uint32_t *__restrict__ qcount, const Rec *__restrict__ queues, uint32_t cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];        // [entries per bucket][2]
+    const uint32_t ylev = gridDim.y - 1u - blockIdx.y;            // longest queues (finest levels) first
     uint32_t level = 0, seen = 0;
-    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == blockIdx.y) level = l; ++seen; }
+    for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == ylev) level = l; ++seen; }
     const uint32_t per = 1u << bucket_shift(lt.size[level]), bucket = blockIdx.x;
     const uint32_t first = bucket * per;
     const uint32_t mine = first >= lt.size[level] ? 0u : (lt.size[level] - first < per ? lt.size[level] - first : per);     // the last bucket may be short
-    uint32_t n = qcount[(size_t)blockIdx.y * NBUCKET + bucket];
+    uint32_t n = qcount[(size_t)ylev * NBUCKET + bucket];
     n = n < cap ? n : cap;
-    const uint32_t mbits = qcount[(size_t)gridDim.y * NBUCKET + blockIdx.y];
+    const uint32_t mbits = qcount[(size_t)gridDim.y * NBUCKET + ylev];
     if (n == 0 || mbits == 0 || mine == 0) return;                                   // wave-uniform: nothing queued for this bucket
-    const Rec *q = queues + ((size_t)blockIdx.y * NBUCKET + bucket) * cap;
+    const Rec *q = queues + ((size_t)ylev * NBUCKET + bucket) * cap;
     float *dst = grad_grid + ((size_t)lt.offset[level] + (size_t)first) * 2;
     if ((mbits >> 23) == 255u) {
         // an Inf or NaN record on this level (the largest |v| carries exponent 255): no fixed-point scale exists.  Sum this bucket in float
