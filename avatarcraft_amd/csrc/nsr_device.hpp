@@ -156,7 +156,9 @@ __device__ __forceinline__ float sel4(int g, float a, float b, float c, float d)
 }
 
 // ---- workgroup prologue: weights -> MFMA A-fragment order in LDS -------------------------------------
-__device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
+// the SDF side (sdf_net fragments, biases, level records, sampling tables, softplus table) and the colour side are laid out separately: the
+// SDF-query training kernels never touch the colour fragments and use their 26 KB for their own
+__device__ __forceinline__ void fill_lds_sdf(float *lds, const RenderArgs &a)
 {
     for (int e = threadIdx.x; e < 4 * 9 * 64; e += blockDim.x) {          // sdf_net.0 [64,35]
         int l = e & 63, fs = e >> 6, t = fs / 9, s = fs % 9;
@@ -167,23 +169,6 @@ __device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
     for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {             // sdf_net.1 [16,64]
         int l = e & 63, kk = e >> 6, t = kk >> 2, r = kk & 3;
         lds[OFF_W2F + e] = a.W2[(l & 15) * 64 + 16 * t + 4 * (l >> 4) + r];
-    }
-    for (int e = threadIdx.x; e < 4 * 6 * 64; e += blockDim.x) {          // color_net.0 [64,21] = [x(3), n(3), feat(15)]
-        int l = e & 63, fs = e >> 6, t = fs / 6, s = fs % 6;
-        int u = 16 * t + (l & 15), g = l >> 4;
-        float v;
-        if (s < 4) { int o = 4 * g + s; v = (o == 0) ? 0.0f : a.Wc1[u * 21 + 6 + (o - 1)]; }
-        else if (s == 4) v = g < 3 ? a.Wc1[u * 21 + g] : 0.0f;
-        else v = g < 3 ? a.Wc1[u * 21 + 3 + g] : 0.0f;
-        lds[OFF_C1F + e] = v;
-    }
-    for (int e = threadIdx.x; e < 4 * 16 * 64; e += blockDim.x) {         // color_net.1 [64,64]
-        int l = e & 63, fs = e >> 6, to = fs >> 4, kk = fs & 15, t = kk >> 2, r = kk & 3;
-        lds[OFF_C2F + e] = a.Wc2[(16 * to + (l & 15)) * 64 + 16 * t + 4 * (l >> 4) + r];
-    }
-    for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {             // color_net.2 [3,64]
-        int l = e & 63, kk = e >> 6, t = kk >> 2, r = kk & 3, o = l & 15;
-        lds[OFF_C3F + e] = o < 3 ? a.Wc3[o * 64 + 16 * t + 4 * (l >> 4) + r] : 0.0f;
     }
     for (int e = threadIdx.x; e < 64; e += blockDim.x) lds[OFF_B1 + e] = a.b1[e];
     for (int e = threadIdx.x; e < 16; e += blockDim.x) lds[OFF_B2 + e] = a.b2[e];
@@ -204,12 +189,40 @@ __device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
     for (int e = threadIdx.x; e < 512; e += blockDim.x) lds[OFF_SPQ + e] = AC_SP_G[e >> 2][e & 3];
 }
 
+__device__ __forceinline__ void fill_lds_color(float *lds, const RenderArgs &a)
+{
+    for (int e = threadIdx.x; e < 4 * 6 * 64; e += blockDim.x) {          // color_net.0 [64,21] = [x(3), n(3), feat(15)]
+        int l = e & 63, fs = e >> 6, t = fs / 6, s = fs % 6;
+        int u = 16 * t + (l & 15), g = l >> 4;
+        float v;
+        if (s < 4) { int o = 4 * g + s; v = (o == 0) ? 0.0f : a.Wc1[u * 21 + 6 + (o - 1)]; }
+        else if (s == 4) v = g < 3 ? a.Wc1[u * 21 + g] : 0.0f;
+        else v = g < 3 ? a.Wc1[u * 21 + 3 + g] : 0.0f;
+        lds[OFF_C1F + e] = v;
+    }
+    for (int e = threadIdx.x; e < 4 * 16 * 64; e += blockDim.x) {         // color_net.1 [64,64]
+        int l = e & 63, fs = e >> 6, to = fs >> 4, kk = fs & 15, t = kk >> 2, r = kk & 3;
+        lds[OFF_C2F + e] = a.Wc2[(16 * to + (l & 15)) * 64 + 16 * t + 4 * (l >> 4) + r];
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {             // color_net.2 [3,64]
+        int l = e & 63, kk = e >> 6, t = kk >> 2, r = kk & 3, o = l & 15;
+        lds[OFF_C3F + e] = o < 3 ? a.Wc3[o * 64 + 16 * t + 4 * (l >> 4) + r] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void fill_lds(float *lds, const RenderArgs &a)
+{
+    fill_lds_sdf(lds, a);
+    fill_lds_color(lds, a);
+}
+
 // ---- "fast" precision: bf16 hi / lo fragments of W1's feature columns, fp32 coordinate columns ----------
 __device__ __forceinline__ uint32_t bf16_rne_bits(float f)       // finite inputs (weights): round to nearest even
 {
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+template <int W1H = OFF_W1H, int W1L = OFF_W1L, int W1C = OFF_W1C>
 __device__ __forceinline__ void fill_lds_fast(float *lds, const RenderArgs &a)
 {
     uint32_t *lw = reinterpret_cast<uint32_t *>(lds);
@@ -225,9 +238,9 @@ __device__ __forceinline__ void fill_lds_fast(float *lds, const RenderArgs &a)
             const uint32_t lb = bf16_rne_bits(w - __uint_as_float(hb << 16));
             hi2 |= hb << (16 * h); lo2 |= lb << (16 * h);
         }
-        lw[OFF_W1H + e] = hi2; lw[OFF_W1L + e] = lo2;
+        lw[W1H + e] = hi2; lw[W1L + e] = lo2;
     }
-    for (int e = threadIdx.x; e < 3 * 64; e += blockDim.x) lds[OFF_W1C + e] = a.W1[(e & 63) * 35 + (e >> 6)];
+    for (int e = threadIdx.x; e < 3 * 64; e += blockDim.x) lds[W1C + e] = a.W1[(e & 63) * 35 + (e >> 6)];
 }
 
 // ---- hash-grid features of this lane's 4 levels (HashEncoder.forward + kernel_grid) -------------------
@@ -328,29 +341,38 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // the middle product on the bf16 matrix pipe with both factors split hi + lo (3 of the 4 partial products; the dropped lo x lo is
 // 2^-16 of a term that is itself ~1e-2 of l1).  The differences are split by truncation: d = hi + (d - hi) exactly, lo = the top 16
 // bits of (d - hi).  B operand: this lane's eight differences = k 8g .. 8g+7, the order fill_lds_fast gives the A rows.
+// 8 fp32 values -> their bf16 hi parts and the bf16 hi parts of the remainders, packed in B-operand order (value 2q in the low half of dword q)
+__device__ __forceinline__ void split8_bf16(const float (&d)[8], u32x4 &bh, u32x4 &bl)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t u0 = __float_as_uint(d[2 * q]), u1 = __float_as_uint(d[2 * q + 1]);
+        const float r0 = d[2 * q] - __uint_as_float(u0 & 0xffff0000u), r1 = d[2 * q + 1] - __uint_as_float(u1 & 0xffff0000u);
+        bh[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);               // (top half of d[2q+1]) << 16 | top half of d[2q]
+        bl[q] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+    }
+}
+
+template <int W1H = OFF_W1H, int W1L = OFF_W1L, int W1C = OFF_W1C>
 __device__ __forceinline__ Acc4 sdf_l1_delta(const float *__restrict__ lds, int lane, const Acc4 &acc0, const float (&fe)[4][2],
                                              const float (&fe0)[4][2], int kn, float dcoord)
 {
     const int g = lane >> 4;
     u32x4 bh, bl;
+    float dlt[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float d0 = fe[q][0] - fe0[q][0], d1 = fe[q][1] - fe0[q][1];
-        const uint32_t u0 = __float_as_uint(d0), u1 = __float_as_uint(d1);
-        const float r0 = d0 - __uint_as_float(u0 & 0xffff0000u), r1 = d1 - __uint_as_float(u1 & 0xffff0000u);
-        bh[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);               // (top half of d1) << 16 | top half of d0
-        bl[q] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-    }
+    for (int q = 0; q < 4; ++q) { dlt[2 * q] = fe[q][0] - fe0[q][0]; dlt[2 * q + 1] = fe[q][1] - fe0[q][1]; }
+    split8_bf16(dlt, bh, bl);
     const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
     Acc4 r;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + OFF_W1H + (t * 64 + lane) * 4));
-        const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + OFF_W1L + (t * 64 + lane) * 4));
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + W1H + (t * 64 + lane) * 4));
+        const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + W1L + (t * 64 + lane) * 4));
         f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, acc0.a[t], 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
-        const f32x4 wc = *reinterpret_cast<const f32x4 *>(lds + OFF_W1C + kn * 64 + 16 * t + 4 * g);     // W1[16t + 4g + r][kn]
+        const f32x4 wc = *reinterpret_cast<const f32x4 *>(lds + W1C + kn * 64 + 16 * t + 4 * g);     // W1[16t + 4g + r][kn]
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) c[rr] = fma_(dcoord, wc[rr], c[rr]);
         r.a[t] = c;

@@ -28,9 +28,16 @@ constexpr int TBLOCK = TW * 64;
 constexpr int FW = 8;                              // waves per workgroup of the forward SDF query (224 VGPRs: two waves per SIMD, like the renderer)
 constexpr int FBLOCK = FW * 64;
 constexpr int TLD = 17;                            // padded leading dimension of the transpose slabs
-constexpr int OFF_W2T = OFF_WAVE;                  // [4 tiles][4 ksteps][64]   A fragments of W2^T
-constexpr int OFF_W1T = OFF_W2T + 16 * 64;         // [2 tiles][16 ksteps][64]  A fragments of W1^T (feature rows)
-constexpr int OFF_TW = OFF_W1T + 32 * 64;          // per-wave slabs
+// The SDF-query backward never evaluates the colour network: the 26 KB the shared layout reserves for its fragments hold this kernel's
+// own ones instead (fill_lds_sdf leaves that region alone).
+constexpr int OFF_W2T = OFF_C1F;                   // [4 tiles][4 ksteps][64]   fp32 A fragments of W2^T (the centre evaluation's ga = W2^T d2)
+constexpr int OFF_W1TH = OFF_W2T + 16 * 64;        // [2 tiles][2 k blocks][64 lanes][4 dwords]  bf16 hi A fragments of W1^T (feature rows), 16x16x32 order
+constexpr int OFF_W1TL = OFF_W1TH + 2 * 2 * 64 * 4;   // ... and the bf16 lo parts
+constexpr int OFF_BW1H = OFF_W1TL + 2 * 2 * 64 * 4;   // layer-1 recomputation of the six offset evaluations (sdf_l1_delta): W1 hi / lo / coordinate columns
+constexpr int OFF_BW1L = OFF_BW1H + 4 * 64 * 4;
+constexpr int OFF_BW1C = OFF_BW1L + 4 * 64 * 4;
+static_assert(OFF_BW1C + 3 * 64 <= OFF_B1, "the backward's fragments fit the colour region");
+constexpr int OFF_TW = OFF_WAVE;                   // per-wave slabs
 constexpr int TS_T2 = FE_SLAB;                     // d2  [16][TLD]
 constexpr int TS_TA = TS_T2 + 16 * TLD;            // a   [64][TLD]
 constexpr int TS_TD = TS_TA + 64 * TLD;            // d1  [64][TLD]
@@ -122,19 +129,31 @@ __global__ __launch_bounds__(FBLOCK) void sdf_stencil_fwd_kernel(const RenderArg
     }
 }
 
-// extra weight fragments of the backward: W2^T (ga = W2^T d2) and the feature rows of W1^T (dinp = W1^T d1)
+// extra weight fragments of the backward: W2^T (ga = W2^T d2, fp32) and the feature rows of W1^T (dinp = W1^T d1) split into bf16 hi + lo
+// for v_mfma_f32_16x16x32_bf16: K = the 64 hidden units in two blocks of 32; within block b lane group kk supplies slots i = 0..7 =
+// units 16 (2b + (i >> 2)) + 4 kk + (i & 3) -- exactly the sixteen d1 values lane (n, kk) holds (accumulator tiles 2b, 2b+1), no data movement
 __device__ __forceinline__ void fill_lds_bwd(float *lds, const RenderArgs &a)
 {
     for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {       // fragment (t, s): lane (m, kk) = W2[o = 4 kk + s][unit = 16 t + m]
         const int l = e & 63, fs = e >> 6, t = fs >> 2, s = fs & 3, m = l & 15, kk = l >> 4;
         lds[OFF_W2T + e] = a.W2[(4 * kk + s) * 64 + 16 * t + m];
     }
-    for (int e = threadIdx.x; e < 32 * 64; e += blockDim.x) {       // fragment (t', ks = 4t + r): lane (m, kk) = W1[unit = 16t + 4kk + r][col(t', m)]
-        const int l = e & 63, fs = e >> 6, tp = fs >> 4, ks = fs & 15, t = ks >> 2, r = ks & 3, m = l & 15, kk = l >> 4;
-        const int s1 = 4 * tp + (m & 3);                            // feature slot 2j + c of lane group m >> 2
+    uint32_t *lw = reinterpret_cast<uint32_t *>(lds);
+    for (int e = threadIdx.x; e < 2 * 2 * 64 * 4; e += blockDim.x) { // dword q of lane l, k block b, output tile tp
+        const int q = e & 3, l = (e >> 2) & 63, b = (e >> 8) & 1, tp = e >> 9, m = l & 15, kk = l >> 4;
+        const int s1 = 4 * tp + (m & 3);                            // output row m = feature slot 2j + c of lane group m >> 2
         const int col = 3 + 2 * (4 * (s1 >> 1) + (m >> 2)) + (s1 & 1);
-        lds[OFF_W1T + e] = a.W1[(16 * t + 4 * kk + r) * 35 + col];
+        uint32_t hi2 = 0, lo2 = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * q + h, unit = 16 * (2 * b + (i >> 2)) + 4 * kk + (i & 3);
+            const float w = a.W1[unit * 35 + col];
+            const uint32_t hb = bf16_rne_bits(w), lb = bf16_rne_bits(w - __uint_as_float(hb << 16));
+            hi2 |= hb << (16 * h); lo2 |= lb << (16 * h);
+        }
+        lw[OFF_W1TH + e] = hi2; lw[OFF_W1TL + e] = lo2;
     }
+    fill_lds_fast<OFF_BW1H, OFF_BW1L, OFF_BW1C>(lds, a);
 }
 
 __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ g_out,
@@ -142,7 +161,7 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
                                                                  float *__restrict__ gfeat, float *__restrict__ partials)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    fill_lds(lds, a);
+    fill_lds_sdf(lds, a);
     fill_lds_bwd(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     float *slab = lds + OFF_TW + wave * TRAIN_SLAB;
@@ -179,6 +198,9 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
         float fe0[4][2];
         encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
         const float pc0 = sel4(g, px, py, pz, 0.0f);
+        Acc4 h10;                                               // layer 1 of the centre evaluation (set at e == 0)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h10.a[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll 1
         for (int e = 0; e < 7; ++e) {
             const int k = e > 0 ? (e - 1) >> 1 : 3;
@@ -202,8 +224,11 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
                 s_all = ((e - 1) & 1) ? -(gk * hs) : gk * hs;                   // d gradient_k / d sdf(x +- eps e_k) = +-0.5 / eps
                 d2 = f32x4{ g == 0 ? s_all : 0.0f, 0.0f, 0.0f, 0.0f };
             }
-            // recompute layer 1, softplus and its derivative
-            const Acc4 h1 = sdf_l1(lds, lane, bx, fe);
+            // recompute layer 1, softplus and its derivative: the centre in fp32, the six offset evaluations as split-bf16 corrections of it
+            // (sdf_l1_delta; the arithmetic of the renderer's "fast" precision: 12 short MFMA instead of 36 fp32 ones)
+            Acc4 h1;
+            if (e == 0) { h1 = sdf_l1(lds, lane, bx, fe); h10 = h1; }
+            else h1 = sdf_l1_delta<OFF_BW1H, OFF_BW1L, OFF_BW1C>(lds, lane, h10, fe, fe0, k, poff - pk);
             Acc4 av, dv;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -236,20 +261,34 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
                     for (int r = 0; r < 4; ++r) d1.a[t][r] = ga[r] * dv.a[t][r];
                 }
             }
-            // dinp = W1^T d1: this lane's own features (j = 2t' + (r >> 1), c = r & 1)
+            // dinp = W1^T d1: this lane's own features (j = 2t' + (r >> 1), c = r & 1), on the bf16 matrix pipe with both factors split
+            // hi + lo (3 products, fp32 accumulate: 2^-16 relative, far below the tolerance of a gradient): 12 short MFMA instead of 32 fp32 ones
+            {
+                u32x4 bh[2], bl[2];
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
-                f32x4 gi = { 0.0f, 0.0f, 0.0f, 0.0f };
+                for (int b = 0; b < 2; ++b) {
+                    const float dd[8] = { d1.a[2 * b][0], d1.a[2 * b][1], d1.a[2 * b][2], d1.a[2 * b][3],
+                                          d1.a[2 * b + 1][0], d1.a[2 * b + 1][1], d1.a[2 * b + 1][2], d1.a[2 * b + 1][3] };
+                    split8_bf16(dd, bh[b], bl[b]);
+                }
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int tp = 0; tp < 2; ++tp) {
+                    f32x4 gi = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        gi = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W1T + (tp * 16 + 4 * t + r) * 64 + lane], d1.a[t][r], gi, 0, 0, 0);
-                if (live) {
+                    for (int b = 0; b < 2; ++b) {
+                        const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + OFF_W1TH + ((tp * 2 + b) * 64 + lane) * 4));
+                        const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + OFF_W1TL + ((tp * 2 + b) * 64 + lane) * 4));
+                        const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[b]), Bl = __builtin_bit_cast(bf16x8, bl[b]);
+                        gi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, gi, 0, 0, 0);
+                        gi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, gi, 0, 0, 0);
+                        gi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, gi, 0, 0, 0);
+                    }
+                    if (live) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const int j = 2 * tp + m;
-                        *reinterpret_cast<float2 *>(gfeat + (((size_t)e * 16 + 4 * j + g) * B + b) * 2) = make_float2(gi[2 * m], gi[2 * m + 1]);
+                        for (int m = 0; m < 2; ++m) {
+                            const int j = 2 * tp + m;
+                            *reinterpret_cast<float2 *>(gfeat + (((size_t)e * 16 + 4 * j + g) * B + b) * 2) = make_float2(gi[2 * m], gi[2 * m + 1]);
+                        }
                     }
                 }
             }
