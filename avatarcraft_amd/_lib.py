@@ -21,7 +21,7 @@ f32 = C.c_float
 
 class ac_field(C.Structure):
     _fields_ = [("table", vp), ("offsets", i32 * 17), ("S", f32), ("H", u32),
-                ("W1", vp), ("b1", vp), ("W2", vp), ("b2", vp), ("Wc1", vp), ("Wc2", vp), ("Wc3", vp)]
+                ("W1", vp), ("b1", vp), ("W2", vp), ("b2", vp), ("Wc1", vp), ("Wc2", vp), ("Wc3", vp), ("prepared", vp)]
 
 
 class ac_render_opts(C.Structure):
@@ -69,6 +69,7 @@ _SIGS = {
     "ac_march_rays": ([u32, u32, vp, vp, vp, vp, f32, u32, vp, f32, vp, vp, vp, vp, vp, u32, vp], C.c_int),
     "ac_composite_rays": ([u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_compact_rays": ([u32, vp, vp, vp, vp, vp, vp, vp], C.c_int),
+    "ac_field_prepare": ([C.POINTER(ac_field), vp, vp], C.c_int),
     "ac_render_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_render_out), vp], C.c_int),
     "ac_sample_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_eikonal_reduce": ([vp, i32, vp, vp], C.c_int),

@@ -81,6 +81,7 @@ struct RenderArgs {
     const float *table;
     uint32_t table_bytes;
     const float *W1, *b1, *W2, *b2, *Wc1, *Wc2, *Wc3;
+    const float *prepared;      // ac_field.prepared: the renderer's LDS image [0, OFF_RWAVE) of these parameters, or NULL
     const float *rays_o, *rays_d, *bg, *noise, *lin_z, *lin_u;
     ac_render_out out;
     LevelRec lvl[16];
@@ -767,6 +768,7 @@ int fill_args(RenderArgs &a, const ac_field *f, float bound)
         for (int g = 0; g < 4; ++g) nh += lt.hashed[4 * j + g] ? 1 : 0;
         a.jmode[j] = nh == 0 ? 0 : (nh == 4 ? 1 : 2);
     }
+    a.prepared = static_cast<const float *>(f->prepared);
     a.table = f->table; a.table_bytes = (uint32_t)f->offsets[16] * 8u; a.W1 = f->W1; a.b1 = f->b1; a.W2 = f->W2; a.b2 = f->b2; a.Wc1 = f->Wc1; a.Wc2 = f->Wc2; a.Wc3 = f->Wc3;
     a.bound = bound; a.two_bound = (float)(2.0 * (double)bound);
     return AC_OK;

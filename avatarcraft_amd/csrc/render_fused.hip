@@ -34,8 +34,19 @@ template <int MODE, bool FAST>
 __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    fill_lds(lds, a);
-    if constexpr (FAST) fill_lds_fast(lds, a);
+    if (a.prepared) {
+        // the weights arrive in LDS order (ac_field_prepare): a linear copy, 16 bytes per lane and trip, instead of ~27 dependent
+        // gather-and-place trips per thread in each of the 512 workgroups of a launch; only the per-launch sampling tables are added
+        const float4 *src = reinterpret_cast<const float4 *>(a.prepared);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int e = threadIdx.x; e < OFF_RWAVE / 4; e += blockDim.x) dst[e] = src[e];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64; e += blockDim.x) lds[OFF_LIN + e] = e < a.T0 ? a.lin_z[e] : 0.0f;
+        for (int e = threadIdx.x; e < 16; e += blockDim.x) lds[OFF_LIN + 64 + e] = a.lin_u ? a.lin_u[e] : 0.0f;
+    } else {
+        fill_lds(lds, a);
+        if constexpr (FAST) fill_lds_fast(lds, a);
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -445,6 +456,16 @@ __global__ __launch_bounds__(BLOCK) void field_color_kernel(const RenderArgs a, 
     }
 }
 
+// ac_field_prepare: one workgroup lays the weights out in LDS exactly like a render workgroup would and dumps the image
+__global__ __launch_bounds__(BLOCK) void field_prepare_kernel(const RenderArgs a, float *__restrict__ image)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    fill_lds_fast(lds, a);
+    __syncthreads();
+    for (int e = threadIdx.x; e < OFF_RWAVE; e += blockDim.x) image[e] = lds[e];
+}
+
 // gradient_error: fixed-order reduction of per-ray partials (oracle: orc_eikonal_reduce)
 __global__ __launch_bounds__(1024) void eikonal_reduce_kernel(const float *__restrict__ eik, int n_rays, float *__restrict__ result, int with_den)
 {
@@ -652,6 +673,20 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
     a.mask = mask;
     launch_render<MODE_FINAL>(a, st);
     return ac::check_launch("render_rays_warped");
+}
+
+static_assert(OFF_RWAVE * sizeof(float) <= AC_FIELD_PREPARED_BYTES, "the prepared image fits its buffer");
+AC_API int ac_field_prepare(const ac_field *field, void *prepared, ac_stream_t stream)
+{
+    if (!prepared) { ac::set_error("field_prepare: NULL buffer"); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = fill_args(a, field, 1.0f)) return rc;
+    a.T0 = 0; a.lin_z = nullptr; a.lin_u = nullptr;            // the sampling tables are per launch, not part of the image
+    const size_t lds_bytes = OFF_RWAVE * sizeof(float);
+    static uint64_t seen = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(field_prepare_kernel), lds_bytes);
+    hipLaunchKernelGGL(field_prepare_kernel, dim3(1), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a, static_cast<float *>(prepared));
+    return ac::check_launch("field_prepare");
 }
 
 AC_API int ac_eikonal_reduce(const float *eik, int32_t n_rays, float *result, ac_stream_t stream)

@@ -827,7 +827,10 @@ uint32_t train_grid(uint32_t B)
 {
     const uint32_t ntiles = (B + 15) / 16;
     uint32_t blocks = (ntiles + TW - 1) / TW;
-    if (blocks > 512) blocks = 512;                    // persistent: 2 workgroups' worth of tiles in flight per CU at most
+#ifndef AC_TRAIN_GRID
+#define AC_TRAIN_GRID 512
+#endif
+    if (blocks > AC_TRAIN_GRID) blocks = AC_TRAIN_GRID;   // persistent: 2 workgroups' worth of tiles in flight per CU at most
     return blocks ? blocks : 1;
 }
 

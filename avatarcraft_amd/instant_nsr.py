@@ -75,6 +75,7 @@ class NeRFRenderer(nn.Module):
             f = nsr_ops.Field(enc.embeddings.detach(), self._offsets_host(), enc.per_level_scale, enc.base_resolution,
                               wn(self.sdf_net[0]), self.sdf_net[0].bias.detach().contiguous(), wn(self.sdf_net[1]),
                               self.sdf_net[1].bias.detach().contiguous(), wn(self.color_net[0]), wn(self.color_net[1]), wn(self.color_net[2]))
+        f.prepare()                     # the weights in LDS order, once per parameter version (every render workgroup then copies them linearly)
         self._field_cache = (key, f)
         return f
 

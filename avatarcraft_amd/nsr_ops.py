@@ -52,6 +52,17 @@ class Field:
             setattr(f, k, self.t[k].data_ptr())
         self.c = f
         self.device = table.device
+        self.prepared = None
+
+    def prepare(self):
+        """ac_field_prepare: lay the weights out once in the order the renderer keeps them in LDS (its 512 workgroups per launch then copy
+        the image linearly).  Call again whenever a parameter tensor of this Field is modified in place."""
+        if self.prepared is None:
+            self.prepared = torch.empty(65536, dtype=torch.uint8, device=self.device)
+        self.c.prepared = None
+        L.check(L.lib().ac_field_prepare(C.byref(self.c), self.prepared.data_ptr(), L.current_stream(self.device)), "field_prepare")
+        self.c.prepared = self.prepared.data_ptr()
+        return self
 
 
 _LIN_CACHE = {}
@@ -253,7 +264,7 @@ class _RenderCore(torch.autograd.Function):
         offsets, pls, H, T0, up, bound, car, ner, precision = cfg
         ctx.set_materialize_grads(False)              # an output the loss does not use arrives as None -> a NULL upstream pointer
         d = lambda t: t.detach().contiguous()
-        field = Field(d(table), offsets, pls, H, d(W1), d(b1), d(W2), d(b2), d(Wc1), d(Wc2), d(Wc3))
+        field = Field(d(table), offsets, pls, H, d(W1), d(b1), d(W2), d(b2), d(Wc1), d(Wc2), d(Wc3)).prepare()
         out = render_rays(field, rays_o, rays_d, T0, up, bound, inv_s, bg=bg, noise=noise, cos_anneal_ratio=car, normal_epsilon_ratio=ner,
                           extras=True, train_extras=True, precision=precision)
         ctx.field, ctx.cfg = field, cfg

@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prepared-field", action="store_true", help="A/B: every render workgroup derives the LDS weight layout itself (no ac_field_prepare)")
     ap.add_argument("--precision", choices=["fast", "exact"], default="fast",
                     help="arithmetic of the render kernel (ac_render_opts.precision): fast = the product's default (split-bf16 correction for the six "
                          "finite-difference evaluations; sample positions bit-identical, pixels within 2e-4 of exact); exact = every product an fp32 fma, == CPU oracle")
@@ -308,6 +309,8 @@ def main():
 
     from avatarcraft_amd import nsr_ops
     p, field, table, ro, rd = make_inputs(dev, rank)
+    if not a.no_prepared_field:
+        field.prepare()                 # the weights in LDS order, once (like NeRFRenderer does per parameter version)
     ro_t, rd_t = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
     inv_s = float(p["inv_s"])
     nb = (H * W) // RAYS_PER_BATCH

@@ -127,7 +127,14 @@ typedef struct ac_field {
     const float *Wc1;         /* effective color_net.0 weight [64,21]                             */
     const float *Wc2;         /* effective color_net.1 weight [64,64]                             */
     const float *Wc3;         /* effective color_net.2 weight [3,64]                              */
+    const void *prepared;     /* optional: AC_FIELD_PREPARED_BYTES of device memory filled by ac_field_prepare() for THESE
+                                 parameters (the weights in the order the renderer keeps them in LDS: its workgroups then
+                                 copy 52 KB linearly instead of re-deriving the layout from the row-major matrices, 512 times
+                                 per launch).  NULL = derive it in every workgroup.  Must be re-prepared when a parameter changes. */
 } ac_field;
+#define AC_FIELD_PREPARED_BYTES 65536
+/* fills `prepared` (device, AC_FIELD_PREPARED_BYTES) from the other members of `field`; enqueue on `stream` before the launches that use it */
+int ac_field_prepare(const ac_field *field, void *prepared, ac_stream_t stream);
 
 typedef struct ac_render_opts {
     int32_t n_rays;

@@ -111,6 +111,23 @@ def test_fast_precision_against_exact(env):
     json.dump(worst, open("gpurun_out/fast_vs_exact.json", "w"), indent=1)
 
 
+def test_prepared_field_is_bit_identical(env):
+    """ac_field_prepare (the weights pre-arranged in LDS order) changes nothing but the workgroups' prologue: every output identical, both precisions"""
+    from avatarcraft_amd import nsr_ops
+    from tests.gpu_common import device_field
+    gd = load_golden("run_train_64_64.npz")
+    f2, _ = device_field(env["p"])
+    f2.prepare()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to("cuda:0")
+    for prec in ("exact", "fast"):
+        run = lambda f: nsr_ops.render_rays(f, t(gd["rays_o"]), t(gd["rays_d"]), 64, 64, 1.6, float(env["p"]["inv_s"]), bg=t(gd["bg"]), noise=t(gd["noise"]),
+                                            extras=True, debug_indices=True, precision=prec)
+        a, b = run(env["f"]), run(f2)
+        for k in FLOAT_KEYS + ["ss_inds", "sort_index"]:
+            assert torch.equal(a[k], b[k]), (prec, k)
+    assert env["f"].c.prepared is None and f2.c.prepared
+
+
 def test_render_bitwise_random_rays_4096(env):
     """a full 4096-ray batch (64x64 view), eval and perturbed"""
     ro, rd = make_rays(64, 64, dist=1.7, f=50.0)
