@@ -381,23 +381,26 @@ __device__ __forceinline__ Acc4 sdf_l1_delta(const float *__restrict__ lds, int 
     return r;
 }
 
+#ifndef AC_SP_BATCH
+#define AC_SP_BATCH 4        // softplus values per LDS round trip (table rows in flight: 4 x 4 registers)
+#endif
 __device__ __forceinline__ f32x4 sdf_l2(const float *__restrict__ lds, int lane, const Acc4 &acc)
 {
     const int g = lane >> 4;
     f32x4 o2 = *reinterpret_cast<const f32x4 *>(lds + OFF_B2 + 4 * g);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-            v2f xin = { acc.a[t][r], acc.a[t][r + 1] };
+        float h[4];
 #ifdef AC_ABL_SOFTPLUS
-            const v2f h = xin * splat2(0.5f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = acc.a[t][r] * 0.5f;
 #else
-            const v2f h = dv_softplus100_x2(lds + OFF_SPQ, xin);
+        const float xin[4] = { acc.a[t][0], acc.a[t][1], acc.a[t][2], acc.a[t][3] };
+        dv_softplus100_n<4>(lds + OFF_SPQ, xin, h);
 #endif
-            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r) * 64 + lane], h.x, o2, 0, 0, 0);
-            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r + 1) * 64 + lane], h.y, o2, 0, 0, 0);
-        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_W2F + (4 * t + r) * 64 + lane], h[r], o2, 0, 0, 0);
     }
     return o2;
 }
@@ -421,16 +424,20 @@ __device__ __forceinline__ float sdf_l2_sdf(const float *__restrict__ lds, const
 {
     float p = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t0 = 0; t0 < 4; t0 += AC_SP_BATCH / 4) {
+        constexpr int NB_ = AC_SP_BATCH;
+        float xin[NB_], h[NB_];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int i = 0; i < NB_; ++i) xin[i] = acc.a[t0 + (i >> 2)][i & 3];
 #ifdef AC_ABL_SOFTPLUS
-            const float h = acc.a[t][r] * 0.5f;
+#pragma unroll
+        for (int i = 0; i < NB_; ++i) h[i] = xin[i] * 0.5f;
 #else
-            const float h = dv_softplus100(lds + OFF_SPQ, acc.a[t][r]);
+        dv_softplus100_n<NB_>(lds + OFF_SPQ, xin, h);
 #endif
-            p = fma_(w0.w[t][r], h, p);
-        }
+#pragma unroll
+        for (int i = 0; i < NB_; ++i) p = fma_(w0.w[t0 + (i >> 2)][i & 3], h[i], p);
+    }
     const float other = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, p), (0x10 << 10) | 0x1f));   // lane ^ 16
     // v_permlane32_swap exchanges lanes 32..63 of its first register with lanes 0..31 of its second: with s1 in both, the first ends up
     // holding the lower-half sums in both halves and the second the upper-half sums.  (Inline assembly: the builtin of this compiler

@@ -67,6 +67,31 @@ __device__ __forceinline__ void softplus100_vg(const float *__restrict__ spg, fl
     der = (pos ? 1.0f : 0.0f) + (pos ? 100.0f : -100.0f) * dq;
 }
 
+// four values at once: the table rows are requested together (one LDS round trip per batch, see dv_softplus100_n)
+__device__ __forceinline__ void softplus100_vg4(const float *__restrict__ spg, const f32x4 &x, f32x4 &val, f32x4 &der)
+{
+    float v[4]; float4 c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t = x[i] * 100.0f;
+        const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
+        int idx = (int)(am * 4.0f);
+        idx = idx > 127 ? 127 : idx;
+        v[i] = fma_(-0.25f, (float)idx, am);
+        c[i] = *reinterpret_cast<const float4 *>(spg + idx * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float q = c[i].w;
+        q = fma_(q, v[i], c[i].z); q = fma_(q, v[i], c[i].y); q = fma_(q, v[i], c[i].x);
+        float dq = 3.0f * c[i].w;
+        dq = fma_(dq, v[i], 2.0f * c[i].z); dq = fma_(dq, v[i], c[i].y);
+        const bool pos = x[i] > 0.0f;
+        val[i] = (pos ? x[i] : 0.0f) + q;
+        der[i] = (pos ? 1.0f : 0.0f) + (pos ? 100.0f : -100.0f) * dq;
+    }
+}
+
 // the 7 evaluations of one tile: centre outputs (o = 4g + r) and the finite-difference gradient (the same in all four lanes of a sample)
 __device__ __forceinline__ void fd_forward(const float *__restrict__ lds, const float *__restrict__ fsl, int lane, float px, float py, float pz,
                                            float eps, float bound, const float (&fe0)[4][2], f32x4 &oc, float (&gr)[3])
@@ -231,9 +256,7 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
             else h1 = sdf_l1_delta<OFF_BW1H, OFF_BW1L, OFF_BW1C>(lds, lane, h10, fe, fe0, k, poff - pk);
             Acc4 av, dv;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { float v_, d_; softplus100_vg(lds + OFF_SPQ, h1.a[t][r], v_, d_); av.a[t][r] = v_; dv.a[t][r] = d_; }
+            for (int t = 0; t < 4; ++t) softplus100_vg4(lds + OFF_SPQ, h1.a[t], av.a[t], dv.a[t]);
             Acc4 d1;
 #if AC_SDFBWD_RANK1
             // The six offset evaluations feed the finite-difference gradient through their sdf alone: d2 = (s, 0, ..., 0).  Then
