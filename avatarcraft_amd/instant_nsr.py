@@ -388,6 +388,17 @@ class NeRFNetwork(NeRFRenderer):
         return torch.sigmoid(h)
 
     def forward_variance(self):
+        v = self.deviation_net.variance
+        if not (torch.is_grad_enabled() and v.requires_grad):
+            # no graph wanted: the value only changes with the parameter (five small launches per render otherwise; the frozen net_gt of the
+            # stylisation step never changes at all)
+            key = (v.data_ptr(), v._version, v.device)
+            c = getattr(self, "_inv_s_cache", None)
+            if c is None or c[0] != key:
+                with torch.no_grad():
+                    c = (key, self.deviation_net(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6))
+                self._inv_s_cache = c
+            return c[1]
         return self.deviation_net(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6)
 
     def density(self, x, bound):

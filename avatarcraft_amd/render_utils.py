@@ -89,9 +89,9 @@ def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_g
                              faces=faces, Ts=Ts, perturb=perturb)
             total_eikonal = total_eikonal + out["gradient_error"]
             rgbs.append(out['rgb']); wsums.append(out['weight_sum']); depths.append(out['depth']); normals.append(out['normal'])
-        rgb = torch.cat(rgbs, dim=1).squeeze(0).reshape(-1, 3)
-        extra = {"depth": torch.cat(depths, dim=1).squeeze(0).reshape(-1, 1), "weight_sum": torch.cat(wsums).reshape(-1, 1),
-                 "normal": torch.cat(normals).reshape(-1, 3)}
+        cat = lambda ts, dim=0: ts[0] if len(ts) == 1 else torch.cat(ts, dim=dim)      # one batch (every training patch): nothing to copy
+        rgb = cat(rgbs, 1).squeeze(0).reshape(-1, 3)
+        extra = {"depth": cat(depths, 1).squeeze(0).reshape(-1, 1), "weight_sum": cat(wsums).reshape(-1, 1), "normal": cat(normals).reshape(-1, 3)}
     if not return_torch:
         rgb = rgb.detach().cpu().numpy()
         extra = {k: v.detach().cpu().numpy() for k, v in extra.items()}

@@ -150,6 +150,36 @@ def test_render_bitwise_random_rays_4096(env):
         assert_bitwise(g["sort_index"][torch.from_numpy(sel).to(d)], r["sort_index"], "sort_index")
 
 
+def test_render_full_baseline_view_vs_oracle(env):
+    """BASELINE configuration 2 at full size: EVERY ray of the 256x256 view (16 launches of 4096 rays, 64+64 samples) against the oracle
+    (OpenMP over rays: seconds on the GPU box's host cores).  exact mode: every output bit for bit.  fast mode: sample positions, indices and
+    sdf bit for bit, pixels / normals within the tolerance DESIGN section 2 states for it."""
+    from avatarcraft_amd import nsr_ops
+    ro, rd = make_rays(256, 256, dist=1.7, f=200.0)
+    d = "cuda:0"
+    inv_s = float(env["p"]["inv_s"])
+    r = env["O"].render_rays(env["of"], ro, rd, 64, 64, 1.6, inv_s)
+    ro_t, rd_t = torch.from_numpy(ro).to(d), torch.from_numpy(rd).to(d)
+    worst = {}
+    for precision in ("exact", "fast"):
+        for i in range(0, 65536, 4096):
+            g = nsr_ops.render_rays(env["f"], ro_t[i:i + 4096], rd_t[i:i + 4096], 64, 64, 1.6, inv_s, extras=True, debug_indices=True,
+                                    precision=precision)
+            torch.cuda.synchronize()
+            sl = slice(i, i + 4096)
+            exact_keys = FLOAT_KEYS if precision == "exact" else ["z_vals", "sdf"]
+            for k in exact_keys:
+                assert_bitwise(g[k], r[k][sl], f"{k} [{precision}, rays {i}..]")
+            assert_bitwise(g["ss_inds"], r["ss_inds"][sl], "ss_inds")
+            assert_bitwise(g["sort_index"], r["sort_index"][sl], "sort_index")
+            if precision == "fast":
+                for k, tol in (("image", 2e-5), ("weights_sum", 2e-5), ("normal_map", 5e-5), ("weights", 2e-5), ("color", 2e-5)):
+                    e = float(np.abs(g[k].cpu().numpy() - r[k][sl]).max())
+                    worst[k] = max(worst.get(k, 0.0), e)
+                    assert e <= tol, (k, e, i)
+    assert float(np.asarray(r["weights_sum"]).max()) > 0.9 and float(np.asarray(r["weights_sum"]).min()) < 0.1      # the view holds body and background
+
+
 def test_render_bitwise_edge_case_rays(env):
     """rays the slab test and the samplers rarely see: parallel to an axis (a zero direction component: the reference divides by
     d + 1e-15), starting inside the cube, missing the cube (far < near), grazing a face, pointing away, a very long direction"""

@@ -32,8 +32,13 @@ for S in (32, 64):
 if os.environ.get("COUNT"):
     # -DAC_COUNT_CAND build: candidate tiles per sample, near the body vs the whole frustum
     nb = int(L.lib().ac_warp_accel_bytes(faces.shape[0]))
-    for name, zz in (("whole ray 0.8..2.8", torch.linspace(0.8, 2.8, 64, device=dev)), ("near the body 1.5..2.1", torch.linspace(1.5, 2.1, 64, device=dev))):
-        pts = (tro[:, None, :] + trd[:, None, :] * zz[None, :, None]).contiguous().reshape(-1, 3)
+    nr, fr = RY.geometry_guided_near_far(tro, trd, tv, 0.05)
+    hit = torch.isfinite(nr) & torch.isfinite(fr)
+    zg = nr[hit][:, None] + (fr[hit] - nr[hit])[:, None] * torch.linspace(0.0, 1.0, 64, device=dev)[None, :]
+    for name, pp in (("whole ray 0.8..2.8", tro[:, None, :] + trd[:, None, :] * torch.linspace(0.8, 2.8, 64, device=dev)[None, :, None]),
+                     ("near the body 1.5..2.1", tro[:, None, :] + trd[:, None, :] * torch.linspace(1.5, 2.1, 64, device=dev)[None, :, None]),
+                     ("mesh-guided range (%d rays)" % int(hit.sum()), tro[hit][:, None, :] + trd[hit][:, None, :] * zg[:, :, None])):
+        pts = pp.contiguous().reshape(-1, 3)
         acc = torch.zeros(nb, dtype=torch.uint8, device=dev)
         st = L.current_stream(torch.device(dev))
         L.check(L.lib().ac_warp_accel_build(tv.data_ptr(), tf.data_ptr(), tv.shape[0], tf.shape[0], acc.data_ptr(), nb, st))
@@ -43,4 +48,8 @@ if os.environ.get("COUNT"):
                                               can.data_ptr(), None, None, None, mask.data_ptr(), st))
         torch.cuda.synchronize()
         cnt = int(acc[16:24].view(torch.int64)[0]); cf = int(acc[24:32].view(torch.int64)[0])
-        print("candidate tiles per sample, %s: %.2f, faces through the sphere test: %.1f  (mask fraction %.3f)" % (name, cnt / P, cf / P, float(mask.float().mean())))
+        full = cf >> 40; cf &= (1 << 40) - 1                     # samples that took the full bounding pass (no cell list) are counted in the high bits
+        hdr = acc[:256].view(torch.int32)
+        print("candidate tiles per sample, %s: %.2f, faces through the disc test: %.1f, full bounding pass for %.1f %% of the samples  (mask fraction %.3f; "
+              "grid %s cells of %.2f cm)" % (name, cnt / P, cf / P, 100.0 * full / P, float(mask.float().mean()), hdr[13:16].tolist(),
+                                            100.0 / float(hdr[11:12].view(torch.float32)[0])))

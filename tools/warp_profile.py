@@ -3,12 +3,7 @@
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
-csrc = os.path.join(ROOT, "avatarcraft_amd", "csrc")
-out = os.path.join(ROOT, "gpurun_out", "libac_warpprof.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
-srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "hash_stencil.hip", "sdf_train.hip", "warp.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DAC_PROFILE_WARP",
-                       "-Wno-unused-result", "-o", out] + srcs + sys.argv[1:])
+out = os.path.join(ROOT, "tools", "_bin", "lib_wprof.so")           # python tools/build_variants.py wprof:"-DAC_PROFILE_WARP" (here, before the GPU job)
 from avatarcraft_amd import _lib as L
 L.LIB_PATH = out
 L._SIGS["ac_debug_warp_prof"] = ([ctypes.c_void_p, ctypes.c_int], None)
@@ -17,9 +12,18 @@ dev = "cuda:0"
 verts, faces, Ts = make_body(n_lat=83, n_lon=83)
 ro, rd = make_rays(128, 128, dist=1.8, f=0.78125 * 128)
 tro, trd, tv, tf, tT = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (ro, rd, verts, faces.astype(np.int32), Ts))
-names = ["bounding pass", "bound reductions + seed choice", "seed test (exact, 2 tiles)", "candidate tile list", "disc tests + ring", "exact batches", "final reduction", "epilogue (blend, inverse)"]
-for label, zz in (("whole ray 0.8..2.8", torch.linspace(0.8, 2.8, 64, device=dev)), ("near the body 1.5..2.1", torch.linspace(1.5, 2.1, 64, device=dev))):
-    pts = (tro[:, None, :] + trd[:, None, :] * zz[None, :, None]).contiguous().reshape(-1, 3)
+names = ["cell path: listed boxes + candidates", "full path: bounding pass + seed choice", "full path: seed test (exact, 2 tiles)", "candidate tile list / sync",
+         "disc tests + ring", "exact batches", "final reduction", "prologue (cell, seed face) + epilogue (blend, inverse)"]
+from avatarcraft_amd import ray_utils as RY
+nr, fr = RY.geometry_guided_near_far(tro, trd, tv, 0.05)
+hit = torch.isfinite(nr) & torch.isfinite(fr)
+u = torch.linspace(0.0, 1.0, 64, device=dev)
+zg = nr[hit][:, None] + (fr[hit] - nr[hit])[:, None] * u[None, :]
+sets = [("whole ray 0.8..2.8", (tro[:, None, :] + trd[:, None, :] * torch.linspace(0.8, 2.8, 64, device=dev)[None, :, None])),
+        ("near the body 1.5..2.1", (tro[:, None, :] + trd[:, None, :] * torch.linspace(1.5, 2.1, 64, device=dev)[None, :, None])),
+        ("mesh-guided range of the %d rays that have one" % int(hit.sum()), tro[hit][:, None, :] + trd[hit][:, None, :] * zg[:, :, None])]
+for label, pp in sets:
+    pts = pp.contiguous().reshape(-1, 3)
     P = pts.shape[0]
     nb = int(L.lib().ac_warp_accel_bytes(faces.shape[0]))
     acc = torch.zeros(nb, dtype=torch.uint8, device=dev)
