@@ -247,19 +247,28 @@ constexpr int NB = 18;              // floats of bounds per tile
 constexpr int STEPS = AC_WARP_STEPS;            // trips of the face loop handle STEPS x GROUPS tiles
 constexpr uint32_t RING = 512;      // per-wave ring of faces that passed the disc test: < 64 left over + STEPS x 64 new ones per trip
 
-// Cell grid over the body (round 2): an axis-aligned grid of <= MAX_CELLS cells around the mesh; every cell knows, for ALL points inside it, a
-// superset of the tiles that can hold their closest face (<= CELL_K of them, else the cell is marked OVERFLOW and its samples take the full
-// bounding pass) and one face near its centre (the "seed", an upper bound for any sample of the cell).  The search then tests the <= 64 listed
-// boxes of a sample in ONE lane-parallel step instead of all (431 for SMPL) in seven, and needs no seed search.
-constexpr uint32_t MAX_CELLS = 1u << 19;
-constexpr int CELL_K = 64;                       // listed tiles per cell (one bounding step of 64 lanes)
+// Cell grids around the body (round 2): two axis-aligned grids -- a fine one hugging the mesh and a coarse one for the rest of the scene; every
+// cell knows, for ALL points inside it, a superset of the tiles that can hold their closest face (<= K of them, else the cell is marked OVERFLOW)
+// and one face near its centre (the "seed": its exact distance is an upper bound for any sample of the cell).  The search then tests the listed
+// boxes of a sample in one to three lane-parallel steps instead of all tiles (431 for SMPL) in seven, and needs no seed search.  Samples without a
+// usable cell (outside both grids, overflow) take the full bounding pass.
+constexpr int GRID_LEVELS = 2;
+constexpr uint32_t LVL_CELLS[GRID_LEVELS] = { 1u << 19, 1u << 17 };     // capacity in cells
+constexpr uint32_t LVL_K[GRID_LEVELS] = { 64, 192 };                    // listed tiles per cell
+constexpr uint32_t LVL_CELL0[GRID_LEVELS] = { 0, LVL_CELLS[0] };        // first cell of the level in AccelView::cell
+constexpr uint32_t LVL_CTL0[GRID_LEVELS] = { 0, LVL_CELLS[0] * LVL_K[0] };   // first entry of the level in AccelView::ctl
+constexpr uint32_t CTL_ENTRIES = LVL_CELLS[0] * LVL_K[0] + LVL_CELLS[1] * LVL_K[1];
 constexpr uint32_t CELL_OVERFLOW = 0xffffu;      // count field of a cell without a list
-#ifndef AC_GRID_MARGIN
-#define AC_GRID_MARGIN 0.15f                     // metres of grid around the mesh's bounding box; samples outside take the full bounding pass
+#ifndef AC_GRID_MARGIN0
+#define AC_GRID_MARGIN0 0.15f                    // metres of fine grid around the mesh's bounding box
+#endif
+#ifndef AC_GRID_MARGIN1
+#define AC_GRID_MARGIN1 1.25f                    // ... of coarse grid
 #endif
 constexpr int HDR_WORDS = 64;
-// hdr words: [0] tiles, [1] F, [2] cells, [4..7] debug counters (64-bit x 2), [8..10] grid origin (float), [11] 1 / cell size, [12] 2 x padded half
-// diagonal of a cell (float), [13..15] nx, ny, nz
+constexpr int HDR_LVL = 8, HDR_LVL_STRIDE = 12;
+// hdr words: [0] tiles, [1] F, [4..7] debug counters (64-bit x 2), level l at [8 + 12 l]: grid origin (3 floats), 1 / cell size, 2 x padded half
+// diagonal of a cell (float), nx, ny, nz, cells
 struct AccelView {                   // pointers into the caller's accel buffer
     uint32_t *hdr;                   // [HDR_WORDS]
     uint32_t *sorted;                // [16384] face ids along the curve
@@ -267,15 +276,15 @@ struct AccelView {                   // pointers into the caller's accel buffer
     int32_t *oid;                    // [MAX_ACCEL_FACES] original face id of each slot
     float *box;                      // [NB][MAX_TILES]: oriented box: axes u0 (mean normal), u1, u2 (9), lo (3), hi (3); representative vertex (3)
     float4 *sph;                     // [MAX_ACCEL_FACES][2] bounding disc of each slot's face: (centre, padded radius), (unit normal or 0, -)
-    uint32_t *cell;                  // [MAX_CELLS] (count << 16) | seed slot; count = CELL_OVERFLOW: no list
-    uint16_t *ctl;                   // [MAX_CELLS][CELL_K] the cell's candidate tiles
+    uint32_t *cell;                  // [cells of all levels] (count << 16) | seed slot; count = CELL_OVERFLOW: no list
+    uint16_t *ctl;                   // [CTL_ENTRIES] the cells' candidate tiles
 };
 constexpr int ACCEL_SEGS = 8;
 __host__ __device__ inline size_t accel_offsets(size_t (&o)[ACCEL_SEGS])
 {
     size_t off = 0;
     const size_t sz[ACCEL_SEGS] = { HDR_WORDS * 4, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)NB * MAX_TILES * 4,
-                                    (size_t)MAX_ACCEL_FACES * 32, (size_t)MAX_CELLS * 4, (size_t)MAX_CELLS * CELL_K * 2 };
+                                    (size_t)MAX_ACCEL_FACES * 32, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4, (size_t)CTL_ENTRIES * 2 };
     for (int i = 0; i < ACCEL_SEGS; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
     return off;
 }
@@ -590,7 +599,7 @@ __device__ __forceinline__ void seed_test(const AccelView &av, const double (&q)
     }
 }
 
-// grid parameters from the vertex bounding box (one workgroup)
+// grid parameters of both levels from the vertex bounding box (one workgroup)
 __global__ __launch_bounds__(1024) void accel_grid_setup_kernel(const float *__restrict__ verts, uint32_t V, AccelView av)
 {
     __shared__ float red[6][1024];
@@ -612,46 +621,58 @@ __global__ __launch_bounds__(1024) void accel_grid_setup_kernel(const float *__r
         }
         __syncthreads();
     }
-    if (t == 0) {
+    if (t < (uint32_t)GRID_LEVELS) {
+        const int l = (int)t;
+        const float margin = l == 0 ? AC_GRID_MARGIN0 : AC_GRID_MARGIN1;
+        const uint32_t cap = LVL_CELLS[l];
         float org[3], ext[3];
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            org[k] = red[k][0] - AC_GRID_MARGIN; ext[k] = (red[3 + k][0] - red[k][0]) + 2.0f * AC_GRID_MARGIN;
+            org[k] = red[k][0] - margin; ext[k] = (red[3 + k][0] - red[k][0]) + 2.0f * margin;
             ok = ok && ext[k] > 0.0f && ext[k] < 1e6f;           // NaN / inf vertices: no grid, every sample takes the full bounding pass
         }
         uint32_t n[3] = { 0, 0, 0 };
         float cs = 1.0f;
         if (ok) {
-            cs = cbrtf(ext[0] * ext[1] * ext[2] / (float)MAX_CELLS);
+            cs = cbrtf(ext[0] * ext[1] * ext[2] / (float)cap);
             cs = cs > 0.005f ? cs : 0.005f;                        // cells below 5 mm buy nothing (faces are ~1 cm)
             for (int trial = 0; trial < 64; ++trial) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) n[k] = (uint32_t)(ext[k] / cs) + 1u;
-                if ((unsigned long long)n[0] * n[1] * n[2] <= MAX_CELLS) break;
+                if ((unsigned long long)n[0] * n[1] * n[2] <= cap) break;
                 cs *= 1.02f;
             }
-            if ((unsigned long long)n[0] * n[1] * n[2] > MAX_CELLS) { n[0] = n[1] = n[2] = 0; }
+            if ((unsigned long long)n[0] * n[1] * n[2] > cap) { n[0] = n[1] = n[2] = 0; }
         }
-        av.hdr[2] = n[0] * n[1] * n[2];
+        uint32_t *h = av.hdr + HDR_LVL + HDR_LVL_STRIDE * l;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { av.hdr[8 + k] = __builtin_bit_cast(uint32_t, org[k]); av.hdr[13 + k] = n[k]; }
-        av.hdr[11] = __builtin_bit_cast(uint32_t, 1.0f / cs);
+        for (int k = 0; k < 3; ++k) { h[k] = __builtin_bit_cast(uint32_t, org[k]); h[5 + k] = n[k]; }
+        h[3] = __builtin_bit_cast(uint32_t, 1.0f / cs);
         // |q - centre| <= h for every q that the search maps to the cell: half diagonal, plus the rounding of the index computation
         // ((q - org) * inv: relative 2^-23 of a value < 2^10 cells) and of the centre itself
-        const float h = 0.8660254f * cs * (1.0f + 1e-3f) + 1e-6f;
-        av.hdr[12] = __builtin_bit_cast(uint32_t, 2.0f * h);
+        const float hd = 0.8660254f * cs * (1.0f + 1e-3f) + 1e-6f;
+        h[4] = __builtin_bit_cast(uint32_t, 2.0f * hd);
+        h[8] = n[0] * n[1] * n[2];
     }
 }
 
 struct GridParams { float org[3], inv, h2; uint32_t n[3], cells; };
-__device__ __forceinline__ GridParams grid_params(const AccelView &av)
+__device__ __forceinline__ GridParams grid_params(const AccelView &av, int l)
 {
     GridParams g;
+    const uint32_t *h = av.hdr + HDR_LVL + HDR_LVL_STRIDE * l;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { g.org[k] = __builtin_bit_cast(float, av.hdr[8 + k]); g.n[k] = av.hdr[13 + k]; }
-    g.inv = __builtin_bit_cast(float, av.hdr[11]); g.h2 = __builtin_bit_cast(float, av.hdr[12]); g.cells = av.hdr[2];
+    for (int k = 0; k < 3; ++k) { g.org[k] = __builtin_bit_cast(float, h[k]); g.n[k] = h[5 + k]; }
+    g.inv = __builtin_bit_cast(float, h[3]); g.h2 = __builtin_bit_cast(float, h[4]); g.cells = h[8];
     return g;
+}
+// cell of a point in level g, or ~0u (outside; NaN coordinates fail every comparison)
+__device__ __forceinline__ uint32_t grid_cell(const GridParams &g, const float (&pf)[3])
+{
+    const float gx = (pf[0] - g.org[0]) * g.inv, gy = (pf[1] - g.org[1]) * g.inv, gz = (pf[2] - g.org[2]) * g.inv;
+    const bool inside = g.cells != 0 && gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < (float)g.n[0] && gy < (float)g.n[1] && gz < (float)g.n[2];
+    return inside ? ((uint32_t)gz * g.n[1] + (uint32_t)gy) * g.n[0] + (uint32_t)gx : ~0u;
 }
 
 // one wave per cell (strided): the full bounding pass + seed test at the cell centre c, then the list of tiles t with
@@ -666,51 +687,67 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
     const uint32_t ntp = nit * 64;
     load_boxes(sbox_raw, av, ntp);
     __syncthreads();
-    const GridParams g = grid_params(av);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const float cs = 1.0f / g.inv;
-    for (uint32_t cell = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); cell < g.cells; cell += nwaves) {
-        const uint32_t ix = cell % g.n[0], iy = (cell / g.n[0]) % g.n[1], iz = cell / (g.n[0] * g.n[1]);
-        const float qf[3] = { g.org[0] + ((float)ix + 0.5f) * cs, g.org[1] + ((float)iy + 0.5f) * cs, g.org[2] + ((float)iz + 0.5f) * cs };
-        const double q[3] = { (double)qf[0], (double)qf[1], (double)qf[2] };
-        float lb[NIT];
-        int tA, tB;
-        (void)bounding_pass(sbox_raw, ntp, nit, lane, qf, lb, tA, tB);
-        double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
-        int bid = 0x7fffffff;
-        uint32_t myslot;
-        seed_test(av, q, tA, tB, lane, best, bid, bc, myslot);
-        const double seed = wave_min_f64(best);
-        uint32_t info = CELL_OVERFLOW << 16;
-        if (seed < 1e30) {                                           // false for inf / NaN: a cell next to nothing but degenerate faces
-            const uint32_t sslot = (uint32_t)__builtin_amdgcn_readlane((int)myslot, __builtin_ctzll(__ballot(best == seed)));
-            const float su = __builtin_sqrtf((float)seed * (1.0f + 1e-6f)) * (1.0f + 1e-6f) + g.h2 * (1.0f + 1e-6f);      // >= sqrt(seed) + 2 h
-            uint32_t cnt = 0;
-            unsigned long long cand[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                cand[it] = 0;
-                if ((uint32_t)it >= nit) continue;
-                cand[it] = __ballot(__builtin_sqrtf(lb[it]) * (1.0f - 1e-6f) <= su);      // <= sqrt(lb): a superset
-                cnt += (uint32_t)__builtin_popcountll(cand[it]);
-            }
-            if (cnt <= (uint32_t)CELL_K) {
-                uint32_t at = 0;
+#pragma unroll 1
+    for (int l = 0; l < GRID_LEVELS; ++l) {
+        const GridParams g = grid_params(av, l);
+        const float cs = 1.0f / g.inv;
+        const uint32_t K = LVL_K[l];
+        for (uint32_t cell = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); cell < g.cells; cell += nwaves) {
+            const uint32_t ix = cell % g.n[0], iy = (cell / g.n[0]) % g.n[1], iz = cell / (g.n[0] * g.n[1]);
+            const float qf[3] = { g.org[0] + ((float)ix + 0.5f) * cs, g.org[1] + ((float)iy + 0.5f) * cs, g.org[2] + ((float)iz + 0.5f) * cs };
+            const double q[3] = { (double)qf[0], (double)qf[1], (double)qf[2] };
+            float lb[NIT];
+            int tA, tB;
+            (void)bounding_pass(sbox_raw, ntp, nit, lane, qf, lb, tA, tB);
+            double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
+            int bid = 0x7fffffff;
+            uint32_t myslot;
+            seed_test(av, q, tA, tB, lane, best, bid, bc, myslot);
+            const double seed = wave_min_f64(best);
+            uint32_t info = CELL_OVERFLOW << 16;
+            if (seed < 1e30) {                                           // false for inf / NaN: a cell next to nothing but degenerate faces
+                const uint32_t sslot = (uint32_t)__builtin_amdgcn_readlane((int)myslot, __builtin_ctzll(__ballot(best == seed)));
+                const float su = __builtin_sqrtf((float)seed * (1.0f + 1e-6f)) * (1.0f + 1e-6f) + g.h2 * (1.0f + 1e-6f);      // >= sqrt(seed) + 2 h
+                uint32_t cnt = 0;
+                unsigned long long cand[NIT];
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
+                    cand[it] = 0;
                     if ((uint32_t)it >= nit) continue;
-                    if ((cand[it] >> lane) & 1ull)
-                        av.ctl[(size_t)cell * CELL_K + at + (uint32_t)__builtin_popcountll(cand[it] & ((1ull << lane) - 1ull))] = (uint16_t)(it * 64 + lane);
-                    at += (uint32_t)__builtin_popcountll(cand[it]);
+                    cand[it] = __ballot(__builtin_sqrtf(lb[it]) * (1.0f - 1e-6f) <= su);      // <= sqrt(lb): a superset
+                    cnt += (uint32_t)__builtin_popcountll(cand[it]);
                 }
-                info = (cnt << 16) | sslot;
+                if (cnt <= K) {
+                    uint16_t *dst = av.ctl + LVL_CTL0[l] + (size_t)cell * K;
+                    uint32_t at = 0;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        if ((uint32_t)it >= nit) continue;
+                        if ((cand[it] >> lane) & 1ull) dst[at + (uint32_t)__builtin_popcountll(cand[it] & ((1ull << lane) - 1ull))] = (uint16_t)(it * 64 + lane);
+                        at += (uint32_t)__builtin_popcountll(cand[it]);
+                    }
+                    info = (cnt << 16) | sslot;
+                }
             }
+            if (lane == 0) av.cell[LVL_CELL0[l] + cell] = info;
         }
-        if (lane == 0) av.cell[cell] = info;
     }
 }
 
-__global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
+// ---- the search: one wave owns 64 consecutive samples -------------------------------------------------------------------------------------------
+// The work of the wave's samples is PACKED: (sample, tile) pairs whose box can hold the answer go to a queue; a disc trip takes 8 pairs of whatever
+// samples and tests their 8 x 32 faces against the bounding discs; the surviving (sample, face) pairs go to a second queue and through the fp64
+// Ericson routine 64 at a time.  Every trip and every exact batch is full (up to the wave's last one) whatever the number of candidates of a single
+// sample is -- with one sample at a time a batch held 17 faces on average.  Running minima live in LDS: best[s] as the bit pattern of the (non-negative)
+// fp64 distance^2 under an unsigned 64-bit minimum, the lowest face id among equal distances under a second minimum; the result does not depend on the
+// order of the pairs, and equals the exhaustive kernel's bit for bit.
+constexpr uint32_t TQ = 1024, FQ = 512;         // pair queues (rings): a sample adds <= NIT x 64 = 512 tile pairs to < 8 left over, a disc trip <= STEPS x 64 face pairs to < 64
+static_assert(TQ >= NIT * 64 + GROUPS * STEPS && FQ >= STEPS * 64 + 64 && MAX_TILES <= 512, "queue capacities / pair encoding");
+constexpr int PK_WAVES = 8;                     // waves per workgroup (they share the 32 KB of boxes)
+constexpr uint32_t PK_WAVE_BYTES = 64 * 8 + 64 * 4 + 3 * 64 * 4 + FQ * 4 + TQ * 2;
+
+__global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_accel_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
                                                                  const int32_t *__restrict__ faces, const double *__restrict__ T, uint32_t P,
                                                                  double threshold, AccelView av, double *__restrict__ can_pts,
                                                                  float *__restrict__ can_pts_f32, double *__restrict__ closest,
@@ -721,191 +758,241 @@ __global__ __launch_bounds__(256, AC_WARP_WAVES) void warp_samples_accel_kernel(
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nt = av.hdr[0];
     const uint32_t nit = (nt + 63) >> 6;
-    // bounds of all tiles in LDS (28 KB), lane = tile in the bounding pass
     extern __shared__ __attribute__((aligned(16))) float sbox_raw[];
     const uint32_t ntp = nit * 64;                                     // tiles rounded up to whole bounding-pass iterations: the LDS row length
-    uint16_t *ring = reinterpret_cast<uint16_t *>(sbox_raw + NB * ntp) + (threadIdx.x >> 6) * (RING + ntp);   // this wave's candidate faces (slots)
-    uint16_t *tlist = ring + RING;                                                                            // ... and candidate tiles
+    char *wl = reinterpret_cast<char *>(sbox_raw + NB * ntp) + (threadIdx.x >> 6) * PK_WAVE_BYTES;
+    unsigned long long *sbest = reinterpret_cast<unsigned long long *>(wl);      // [64] bits of the running minimum distance^2 of sample s
+    uint32_t *sbid = reinterpret_cast<uint32_t *>(wl + 512);                     // [64] lowest face id at that distance
+    float *sq = reinterpret_cast<float *>(wl + 768);                             // [3][64] the samples
+    uint32_t *fq = reinterpret_cast<uint32_t *>(wl + 1536);                      // [FQ] (sample << 14) | slot
+    uint16_t *tq = reinterpret_cast<uint16_t *>(wl + 1536 + FQ * 4);             // [TQ] (sample << 9) | tile
     load_boxes(sbox_raw, av, ntp);
     __syncthreads();
+    if (wave * 64 >= P) return;                                        // (after the barrier) a wave without samples
     const uint32_t i = wave * 64 + lane;
     const bool live = i < P;
     const uint32_t ii = live ? i : P - 1;
     const float pf[3] = { pts[3 * (size_t)ii], pts[3 * (size_t)ii + 1], pts[3 * (size_t)ii + 2] };
     const double p[3] = { (double)pf[0], (double)pf[1], (double)pf[2] };
-    double rbest = __builtin_inf(), rbc[3] = { 0.0, 0.0, 0.0 };
-    int rbf = 0;
     const uint32_t npts = (P - wave * 64 < 64u) ? P - wave * 64 : 64u;            // wave-uniform
     WP_T0();
-    // 0. lane = sample: the sample's cell, its tile count and the exact distance^2 to the cell's seed face (an upper bound of the result)
-    uint32_t mycell = 0, mycnt = CELL_OVERFLOW;
+    // 0. lane = sample: the sample's cell (finest level that has a list), and the exact distance^2 to the cell's seed face: an upper bound of the
+    // result and a real face's distance, so the running minimum may start from it
+    uint32_t mybase = 0, mycnt = CELL_OVERFLOW;
     double myseed = __builtin_inf();
 #ifndef AC_ABL_NOGRID
-    {
-        const GridParams g = grid_params(av);
-        const float gx = (pf[0] - g.org[0]) * g.inv, gy = (pf[1] - g.org[1]) * g.inv, gz = (pf[2] - g.org[2]) * g.inv;
-        // written so that NaN coordinates fail
-        const bool inside = g.cells != 0 && gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < (float)g.n[0] && gy < (float)g.n[1] && gz < (float)g.n[2];
-        if (inside) {
-            mycell = ((uint32_t)gz * g.n[1] + (uint32_t)gy) * g.n[0] + (uint32_t)gx;
-            const uint32_t info = av.cell[mycell];
-            mycnt = info >> 16;
-            if (mycnt != CELL_OVERFLOW) {
+#pragma unroll
+    for (int l = 0; l < GRID_LEVELS; ++l) {
+        if (mycnt != CELL_OVERFLOW) continue;
+        const GridParams g = grid_params(av, l);
+        const uint32_t cell = grid_cell(g, pf);
+        if (cell != ~0u) {
+            const uint32_t info = av.cell[LVL_CELL0[l] + cell];
+            if ((info >> 16) != CELL_OVERFLOW) {
                 const uint32_t slot = info & 0xffffu;
                 const float *tp = av.tri + (size_t)slot * 9;
                 const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
                              c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
                 double cq[3];
                 closest_pt_tri(p, a, b, c, cq);
-                const double ex = p[0] - cq[0], ey = p[1] - cq[1], ez = p[2] - cq[2];
-                myseed = ex * ex + ey * ey + ez * ez;
-                if (!(myseed < 1e30)) mycnt = CELL_OVERFLOW;         // NaN from a degenerate seed face in this sample's region: full pass
+                const double ex = p[0] - cq[0], ey = p[1] - cq[1], ez = p[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
+                if (d2 < 1e30) {                                       // NaN from a degenerate seed face in this sample's region: next level / full pass
+                    myseed = d2; mycnt = info >> 16; mybase = LVL_CTL0[l] + cell * LVL_K[l];
+                }
             }
         }
     }
 #endif
+    sbest[lane] = __builtin_bit_cast(unsigned long long, myseed);
+    sbid[lane] = 0x7fffffffu;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sq[k * 64 + lane] = pf[k];
+    wave_sync_lds();
     WP_TICK(7)
-    uint32_t tl_next = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, 0) != CELL_OVERFLOW
-                           ? av.ctl[(size_t)__builtin_amdgcn_readlane((int)mycell, 0) * CELL_K + lane] : 0u;
-    for (uint32_t j = 0; j < npts; ++j) {
-        const float qf[3] = { lane_f32(pf[0], (int)j), lane_f32(pf[1], (int)j), lane_f32(pf[2], (int)j) };
-        const double q[3] = { (double)qf[0], (double)qf[1], (double)qf[2] };
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, (int)j);          // wave-uniform
-        const uint32_t tl_mine = tl_next;
-        if (j + 1 < npts) {                                                                     // the next sample's list is requested a sample ahead
-            const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, (int)(j + 1));
-            if (cn != CELL_OVERFLOW) tl_next = av.ctl[(size_t)__builtin_amdgcn_readlane((int)mycell, (int)(j + 1)) * CELL_K + lane];
+    uint32_t th = 0, tt = 0, fh = 0, ft = 0;                             // wave-uniform ring positions: tile pairs, face pairs
+
+    // exact distances of n queued (sample, face) pairs, folded into the samples' running minima
+    auto exact_batch = [&](uint32_t n) {
+        wave_sync_lds();
+        bool act = (uint32_t)lane < n;
+#ifdef AC_ABL_NOBATCH
+        act = false;
+#endif
+        const uint32_t e = fq[(fh + (act ? (uint32_t)lane : 0u)) & (FQ - 1)];
+        const uint32_t s = e >> 14, slot = e & 16383u;
+        unsigned long long d2b = ~0ull;
+        int id = 0x7fffffff;
+        if (act) {
+            const double q[3] = { (double)sq[s], (double)sq[64 + s], (double)sq[128 + s] };
+            const float *tp = av.tri + (size_t)slot * 9;
+            const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
+                         c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
+            double cq[3];
+            closest_pt_tri(q, a, b, c, cq);
+            const double ex = q[0] - cq[0], ey = q[1] - cq[1], ez = q[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
+            id = av.oid[slot];
+            act = d2 == d2;                                              // a degenerate face (0 / 0 in an edge region) is never accepted
+            d2b = __builtin_bit_cast(unsigned long long, d2);             // d2 >= +0: the bit patterns order like the values
         }
-        double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
-        int bid = 0x7fffffff;
-        double lim;
-        uint32_t ntl = 0;                                              // wave-uniform
+        const unsigned long long prev = sbest[s];
+        wave_sync_lds();
+        if (act) atomicMin(&sbest[s], d2b);
+        wave_sync_lds();
+        const unsigned long long cur = sbest[s];
+        if (act && d2b == cur && cur < prev) sbid[s] = 0x7fffffffu;      // a strictly better distance: ids recorded for the old one are void
+        wave_sync_lds();
+        if (act && d2b == cur) atomicMin(&sbid[s], (uint32_t)id);
+        fh += n;
+        wave_sync_lds();
+    };
+    // up to STEPS x 2 queued (sample, tile) pairs: every face of the tile against its bounding disc (a lower bound of its distance) under the
+    // sample's current bound; survivors are queued for the exact routine
+    auto disc_trip = [&]() {
+        wave_sync_lds();
+        const uint32_t np = (tt - th) < (uint32_t)(GROUPS * STEPS) ? (tt - th) : (uint32_t)(GROUPS * STEPS);
+        uint32_t slot[STEPS], smp[STEPS]; bool have[STEPS];
+        float4 sp[STEPS], sn[STEPS];
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            const uint32_t pi = (uint32_t)(GROUPS * u + lane / TILE_F);
+            have[u] = pi < np;
+            const uint32_t e = tq[(th + (have[u] ? pi : 0u)) & (TQ - 1)];
+            smp[u] = e >> 9;
+            slot[u] = (e & 511u) * TILE_F + (uint32_t)(lane & (TILE_F - 1));
+            sp[u] = av.sph[2 * (size_t)slot[u]]; sn[u] = av.sph[2 * (size_t)slot[u] + 1];
+        }
+        th += np;
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            if ((uint32_t)(GROUPS * u) >= np) break;                     // wave-uniform
+            // lower bound of the face's distance from its bounding disc (accel_tiles_kernel), in fp32: q, the disc and the normal are
+            // fp32 data, and every rounding below is padded towards "pass" (a face that passes wrongly only costs an exact test)
+            const float q0 = sq[smp[u]], q1 = sq[64 + smp[u]], q2 = sq[128 + smp[u]];
+            const double lim = __builtin_bit_cast(double, sbest[smp[u]]) * (1.0 + 1e-9);
+            const float limf = (float)lim * 1.000001f;                   // >= lim (+inf stays +inf)
+            const float ex = q0 - sp[u].x, ey = q1 - sp[u].y, ez = q2 - sp[u].z;
+            const float e1 = (__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez);
+            const float e2 = (ex * ex + ey * ey) + ez * ez;
+            const float apd = __builtin_fabsf((ex * sn[u].x + ey * sn[u].y) + ez * sn[u].z);
+            const float err = 1e-6f * e1 + 1e-6f;                              // rounding of the dot product, of the stored normal and centre
+            const float pdl = apd > err ? apd - err : 0.0f, pdh = apd + err;   // plane distance of q: lower / upper bound
+            const float rem = (limf - pdl * pdl) + 1e-6f * (limf + pdl * pdl); // >= what the bound leaves for the in-plane distance^2
+            const float rho2 = (e2 - pdh * pdh) - 2e-6f * (e2 + pdh * pdh);    // <= (in-plane distance of q from the disc centre)^2
+            const float rr = (sp[u].w + __builtin_sqrtf(rem > 0.0f ? rem : 0.0f) * 1.000001f) + 1e-12f;
+            const bool pass = have[u] && rem >= 0.0f && rho2 <= rr * rr * 1.000001f;
+            const unsigned long long pm = __ballot(pass);
+#ifdef AC_COUNT_CAND
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 6), (unsigned long long)__builtin_popcountll(pm));
+#endif
+            if (pass) fq[(ft + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))) & (FQ - 1)] = (smp[u] << 14) | slot[u];
+            ft += (uint32_t)__builtin_popcountll(pm);
+        }
+        WP_TICK(4)
+    };
+    // queue the tiles in `cand` (lane = position, tile id `tl`) for sample j
+    auto push_tiles = [&](uint32_t j, unsigned long long cand, uint32_t tl) {
+        if ((cand >> lane) & 1ull) tq[(tt + (uint32_t)__builtin_popcountll(cand & ((1ull << lane) - 1ull))) & (TQ - 1)] = (uint16_t)((j << 9) | tl);
+        tt += (uint32_t)__builtin_popcountll(cand);
+#ifdef AC_COUNT_CAND
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 4), (unsigned long long)__builtin_popcountll(cand));
+#endif
+    };
+
+    // the first 64 entries of a sample's list are requested PF samples ahead (a sample's front end is ~100 instructions: one sample of distance
+    // leaves the load's latency exposed); further chunks of a coarse-level list are requested together when the sample's turn comes
+    constexpr int PF = 4;
+    uint32_t tlq[PF];
+    auto list_head = [&](uint32_t jj) -> uint32_t {
+        if (jj >= npts) return 0u;
+        const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, (int)jj);
+        return cn != CELL_OVERFLOW ? (uint32_t)av.ctl[(size_t)__builtin_amdgcn_readlane((int)mybase, (int)jj) + lane] : 0u;
+    };
+#pragma unroll
+    for (int d = 0; d < PF; ++d) tlq[d] = list_head((uint32_t)d);
+    for (uint32_t j = 0; j <= npts; ++j) {                                 // j == npts: drain the queues
+        const bool last = j == npts;
+        if (!last) {
+        const float qf[3] = { lane_f32(pf[0], (int)j), lane_f32(pf[1], (int)j), lane_f32(pf[2], (int)j) };
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, (int)j);          // wave-uniform
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)mybase, (int)j);
+        uint32_t tl_mine = tlq[0];
+#pragma unroll
+        for (int d = 0; d + 1 < PF; ++d) tlq[d] = tlq[d + 1];
+        tlq[PF - 1] = list_head(j + (uint32_t)PF);
+        uint32_t tl_c1 = 0, tl_c2 = 0;
+        if (cnt != CELL_OVERFLOW && cnt > 64u) {
+            tl_c1 = av.ctl[(size_t)base + 64u + lane];
+            if (cnt > 128u) tl_c2 = av.ctl[(size_t)base + 128u + lane];
+        }
         if (cnt != CELL_OVERFLOW) {
-            // 1'. the sample's cell lists the only tiles that matter: one lane-parallel box test against the seed bound
+            // 1'. the sample's cell lists the only tiles that matter: lane-parallel box tests against the seed bound
             const float padq = 4e-7f * ((__builtin_fabsf(qf[0]) + __builtin_fabsf(qf[1])) + __builtin_fabsf(qf[2]));
-            const bool mine = (uint32_t)lane < cnt;
-            const float l = box_lower_bound(sbox_raw, ntp, mine ? (int)tl_mine : 0, qf, padq);
-            lim = lane_f64(myseed, (int)j) * (1.0 + 1e-9);
-            const float lim0f = (float)lim * 1.000001f;
-            const unsigned long long cand = __ballot(mine && l <= lim0f);
-            if ((cand >> lane) & 1ull) tlist[(uint32_t)__builtin_popcountll(cand & ((1ull << lane) - 1ull))] = (uint16_t)tl_mine;
-            ntl = (uint32_t)__builtin_popcountll(cand);
+            const double lim0 = lane_f64(myseed, (int)j) * (1.0 + 1e-9);
+            const float lim0f = (float)lim0 * 1.000001f;
+            for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {                  // one step for the fine grid, up to three for the coarse one
+                if (c0) tl_mine = c0 == 64u ? tl_c1 : tl_c2;
+                const bool mine = c0 + (uint32_t)lane < cnt;
+                const uint32_t tl = mine ? tl_mine : 0u;
+                const float l = box_lower_bound(sbox_raw, ntp, (int)tl, qf, padq);
+                const unsigned long long cand = __ballot(mine && l <= lim0f);
+                push_tiles(j, cand, tl);
+            }
             WP_TICK(0)
         } else {
-            // 1. upper bound from the representative vertices, lower bound of every tile (kept in registers).  Both are bounds, not results:
-            // fp32 with every rounding padded to the safe side (the vector fp32 rate is twice the fp64 rate, and the boxes are fp32)
+            // 1. no cell list: lower bound of every tile (fp32 with every rounding padded to the safe side), exact test of the two most promising
+            // tiles; the best of their faces is the sample's first bound (a real face's distance)
             float lb[NIT];
             int tA, tB;
-            const float ub = bounding_pass(sbox_raw, ntp, nit, lane, qf, lb, tA, tB);
+            (void)bounding_pass(sbox_raw, ntp, nit, lane, qf, lb, tA, tB);
             WP_TICK(1)
-            // seed: the faces of the tile with the nearest representative vertex (lanes 0..31) and of the tile with the smallest lower
-            // bound (lanes 32..63) are tested first; their exact distances replace the vertex distance as the bound
+            const double q[3] = { (double)qf[0], (double)qf[1], (double)qf[2] };
+            double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
+            int bid = 0x7fffffff;
             uint32_t myslot;
             seed_test(av, q, tA, tB, lane, best, bid, bc, myslot);
+            const double seed = wave_min_f64(best);                      // +inf if every seed face is degenerate
+            if (lane == 0) sbest[j] = __builtin_bit_cast(unsigned long long, seed);
             WP_TICK(2)
-            const double seed = wave_min_f64(best);
-            const double lim0 = (seed < (double)ub ? seed : (double)ub) * (1.0 + 1e-9);
-            // 2. the candidate tiles (box distance^2 <= bound) are listed in LDS
-            lim = lim0;
-            const float lim0f = (float)lim0 * 1.000001f;                   // >= lim0
+            const float lim0f = (float)(seed * (1.0 + 1e-9)) * 1.000001f;
+            // 2. the candidate tiles (box distance^2 <= bound): the seed tiles among them -- their faces go through the queues like all others
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 if ((uint32_t)it >= nit) break;                            // wave-uniform
-                unsigned long long cand = __ballot(lb[it] <= lim0f);           // fp32 compare against the bound rounded up: a superset
-                if (it == (tA >> 6)) cand &= ~(1ull << (tA & 63));         // the seed tiles are done
-                if (it == (tB >> 6)) cand &= ~(1ull << (tB & 63));
+                unsigned long long cand = __ballot(lb[it] <= lim0f);       // fp32 compare against the bound rounded up: a superset
 #ifdef AC_ABL_NOCAND
                 cand = 0;
 #endif
-                if ((cand >> lane) & 1ull) tlist[ntl + (uint32_t)__builtin_popcountll(cand & ((1ull << lane) - 1ull))] = (uint16_t)(it * 64 + lane);
-                ntl += (uint32_t)__builtin_popcountll(cand);
+                push_tiles(j, cand, (uint32_t)(it * 64 + lane));
             }
 #ifdef AC_COUNT_CAND
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 4) + 1, 1ull << 40);      // samples through the full pass: high bits of counter 1
 #endif
+            WP_TICK(3)
         }
-#ifdef AC_COUNT_CAND
-        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 4), (unsigned long long)ntl);
-#endif
-        wave_sync_lds();
-        WP_TICK(3)
-        // 3. their faces, STEPS x 2 tiles per trip (the loads of a trip are in flight together): every face is first tested against its
-        // bounding disc (a lower bound of its distance); the survivors are compacted into a ring in LDS and go through the fp64
-        // Ericson routine 64 at a time
-        uint32_t head = 0, tail = 0;                                   // wave-uniform ring positions
-        float limf = (float)lim * 1.000001f;                           // >= lim
-        auto exact_batch = [&](uint32_t n) {
-            wave_sync_lds();
-#ifdef AC_ABL_NOBATCH       // timing ablation: survivors of the disc test are dropped
-            if ((uint32_t)lane > 1000u) {
-#else
-            if ((uint32_t)lane < n) {
-#endif
-                const uint32_t slot = ring[(head + (uint32_t)lane) & (RING - 1)];
-                const float *tp = av.tri + (size_t)slot * 9;
-                const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
-                             c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
-                double cq[3];
-                closest_pt_tri(q, a, b, c, cq);
-                const double ex = q[0] - cq[0], ey = q[1] - cq[1], ez = q[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
-                const int id = av.oid[slot];
-                if (d2 < best || (d2 == best && id < bid)) { best = d2; bid = id; bc[0] = cq[0]; bc[1] = cq[1]; bc[2] = cq[2]; }
-            }
-            head += n;
-            const double nb = wave_min_f64(best) * (1.0 + 1e-9);       // a better bound prunes the faces still to come
-            if (nb < lim) { lim = nb; limf = (float)nb * 1.000001f; }
-            wave_sync_lds();
-        };
-        for (uint32_t t0 = 0; t0 < ntl; t0 += GROUPS * STEPS) {
-            uint32_t slot[STEPS]; bool have[STEPS];
-            float4 sp[STEPS], sn[STEPS];
-#pragma unroll
-            for (int u = 0; u < STEPS; ++u) {
-                const uint32_t ti = t0 + (uint32_t)(GROUPS * u + lane / TILE_F);
-                have[u] = ti < ntl;
-                slot[u] = (uint32_t)tlist[have[u] ? ti : t0] * TILE_F + (uint32_t)(lane & (TILE_F - 1));
-                sp[u] = av.sph[2 * (size_t)slot[u]]; sn[u] = av.sph[2 * (size_t)slot[u] + 1];
-            }
-#pragma unroll
-            for (int u = 0; u < STEPS; ++u) {
-                // lower bound of the face's distance from its bounding disc (accel_tiles_kernel), in fp32: q, the disc and the normal are
-                // fp32 data, and every rounding below is padded towards "pass" (a face that passes wrongly only costs an exact test)
-                const float ex = qf[0] - sp[u].x, ey = qf[1] - sp[u].y, ez = qf[2] - sp[u].z;
-                const float e1 = (__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez);
-                const float e2 = (ex * ex + ey * ey) + ez * ez;
-                const float apd = __builtin_fabsf((ex * sn[u].x + ey * sn[u].y) + ez * sn[u].z);
-                const float err = 1e-6f * e1 + 1e-6f;                              // rounding of the dot product, of the stored normal and centre
-                const float pdl = apd > err ? apd - err : 0.0f, pdh = apd + err;   // plane distance of q: lower / upper bound
-                const float rem = (limf - pdl * pdl) + 1e-6f * (limf + pdl * pdl); // >= what the bound leaves for the in-plane distance^2
-                const float rho2 = (e2 - pdh * pdh) - 2e-6f * (e2 + pdh * pdh);    // <= (in-plane distance of q from the disc centre)^2
-                const float rr = (sp[u].w + __builtin_sqrtf(rem > 0.0f ? rem : 0.0f) * 1.000001f) + 1e-12f;
-                const bool pass = have[u] && rem >= 0.0f && rho2 <= rr * rr * 1.000001f;
-                const unsigned long long pm = __ballot(pass);
-#ifdef AC_COUNT_CAND
-                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(av.hdr + 6), (unsigned long long)__builtin_popcountll(pm));
-#endif
-                if (pass) ring[(tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))) & (RING - 1)] = (uint16_t)slot[u];
-                tail += (uint32_t)__builtin_popcountll(pm);
-            }
-            WP_TICK(4)
-            while (tail - head >= 64u) exact_batch(64u);
-            WP_TICK(5)
         }
-        WP_TICK(4)
-        if (tail != head) exact_batch(tail - head);
-        WP_TICK(5)
-        const double wbest = wave_min_f64(best);
-        const int wid = wave_min_i32(best == wbest ? bid : 0x7fffffff);
-        const unsigned long long win = __ballot(best == wbest && bid == wid);
-        const int wl = __builtin_ctzll(win);
-        const double w0 = lane_f64(bc[0], wl), w1 = lane_f64(bc[1], wl), w2 = lane_f64(bc[2], wl);
-        if (lane == (int)j) { rbest = wbest; rbf = wid; rbc[0] = w0; rbc[1] = w1; rbc[2] = w2; }
-        WP_TICK(6)
+        // ONE inlined copy of the trip and of the batch: full trips / batches while samples are still coming, the leftovers at the end
+        while (tt - th >= (uint32_t)(GROUPS * STEPS) || (last && (tt != th || ft != fh))) {
+            if (tt != th) disc_trip();
+            while (ft - fh >= 64u || (last && tt == th && ft != fh)) { exact_batch((ft - fh) < 64u ? (ft - fh) : 64u); WP_TICK(5) }
+        }
     }
 #undef SBOX
+    WP_TICK(5)
     if (!live) return;
-    finish_sample(i, p, rbc, rbest, rbf, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
-    WP_TICK(7)
+    // lane = sample again: the closest point on the winning face (the same routine on the same operands as in the batch that found it)
+    const double rbest = __builtin_bit_cast(double, sbest[lane]);
+    uint32_t rb = sbid[lane];
+    double rbc[3] = { 0.0, 0.0, 0.0 };
+    if (rb == 0x7fffffffu) rb = 0;                                       // no face with a distance (all degenerate): what the exhaustive kernel reports
+    else {
+        const int32_t f0v = faces[3 * (size_t)rb], f1v = faces[3 * (size_t)rb + 1], f2v = faces[3 * (size_t)rb + 2];
+        double a[3], b[3], c[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { a[k] = (double)verts[3 * (size_t)f0v + k]; b[k] = (double)verts[3 * (size_t)f1v + k]; c[k] = (double)verts[3 * (size_t)f2v + k]; }
+        closest_pt_tri(p, a, b, c, rbc);
+    }
+    finish_sample(i, p, rbc, rbest, (int)rb, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
+    WP_TICK(6)
     WP_END()
 }
 
@@ -983,10 +1070,10 @@ AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int
     const AccelView av = accel_view(const_cast<void *>(accel));
     const uint32_t waves = (P + 63) / 64;
     const size_t ntp = (((size_t)F + TILE_F - 1) / TILE_F + 63) / 64 * 64;        // as in the kernel: tiles rounded up to 64
-    const size_t lds = (size_t)NB * ntp * sizeof(float) + 4 * (RING + ntp) * sizeof(uint16_t);
+    const size_t lds = (size_t)NB * ntp * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES;
     static uint64_t seen = 0;        // the limit for the largest mesh the search supports; a launch asks for what its mesh needs
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(warp_samples_accel_kernel), (size_t)NB * MAX_TILES * sizeof(float) + 4 * (RING + MAX_TILES) * sizeof(uint16_t));
-    hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + 3) / 4), dim3(256), lds, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av,
-                       can_pts, can_pts_f32, closest, dist2, face_id, mask);
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(warp_samples_accel_kernel), (size_t)NB * MAX_TILES * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES);
+    hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + PK_WAVES - 1) / PK_WAVES), dim3(PK_WAVES * 64), lds, (hipStream_t)stream, pts, verts, faces, T, P,
+                       threshold, av, can_pts, can_pts_f32, closest, dist2, face_id, mask);
     return ac::check_launch("warp_samples_accel");
 }

@@ -24,6 +24,9 @@ def to_homogeneous(pts):
     return np.concatenate([pts, np.ones_like(pts[..., 0:1])], axis=-1)
 
 
+_ACCEL_CACHE = None
+
+
 def warp_samples_to_canonical(pts, verts, faces, T, threshold=0.2, device=None, return_torch=None, accel=True):
     """pts [num_rays, num_samples, 3]; verts [V,3]; faces [F,>=3] (first three columns); T [V',4,4] (fp64).
     Returns (can_pts [R,S,3] fp64, can_dirs [R,S,3], closest [R,S,3], mask [R*S] bool) -- numpy if pts is numpy."""
@@ -43,8 +46,16 @@ def warp_samples_to_canonical(pts, verts, faces, T, threshold=0.2, device=None, 
     st = L.current_stream(device)
     nbytes = int(L.lib().ac_warp_accel_bytes(f.shape[0])) if accel else 0
     if nbytes:                                    # exact culling (same results bit for bit); brute force for meshes it does not cover
-        acc = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        L.check(L.lib().ac_warp_accel_build(v.data_ptr(), f.data_ptr(), v.shape[0], f.shape[0], acc.data_ptr(), nbytes, st), "warp_accel_build")
+        # the per-mesh structure (face tiles + cell grids, ~1 ms to build) is kept for the next call on the same device tensors: the reference
+        # calls this function twice per ray batch with one mesh per frame
+        key = (v.data_ptr(), v._version, tuple(v.shape), f.data_ptr(), f._version, tuple(f.shape), str(device), st)
+        global _ACCEL_CACHE
+        if _ACCEL_CACHE is not None and _ACCEL_CACHE[0] == key and isinstance(verts, torch.Tensor) and verts.is_cuda:
+            acc = _ACCEL_CACHE[1]
+        else:
+            acc = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            L.check(L.lib().ac_warp_accel_build(v.data_ptr(), f.data_ptr(), v.shape[0], f.shape[0], acc.data_ptr(), nbytes, st), "warp_accel_build")
+            _ACCEL_CACHE = (key, acc, v, f) if isinstance(verts, torch.Tensor) and verts.is_cuda else None
         L.check(L.lib().ac_warp_samples_accel(p.data_ptr(), v.data_ptr(), f.data_ptr(), Tm.data_ptr(), P, v.shape[0], f.shape[0], float(threshold),
                                               acc.data_ptr(), can.data_ptr(), None, clo.data_ptr(), None, None, mask.data_ptr(), st),
                 "warp_samples_to_canonical")
