@@ -278,13 +278,16 @@ struct AccelView {                   // pointers into the caller's accel buffer
     float4 *sph;                     // [MAX_ACCEL_FACES][2] bounding disc of each slot's face: (centre, padded radius), (unit normal or 0, -)
     uint32_t *cell;                  // [cells of all levels] (count << 16) | seed slot; count = CELL_OVERFLOW: no list
     uint16_t *ctl;                   // [CTL_ENTRIES] the cells' candidate tiles
+    float *sub;                      // [MAX_TILES * SUBS][6] lo (3), hi (3) of each group of TILE_F / SUBS consecutive faces of a tile, in the tile's frame
 };
-constexpr int ACCEL_SEGS = 8;
+constexpr int SUBS = 4, SUB_F = TILE_F / SUBS;   // sub-boxes per tile, faces per sub-box
+constexpr int ACCEL_SEGS = 9;
 __host__ __device__ inline size_t accel_offsets(size_t (&o)[ACCEL_SEGS])
 {
     size_t off = 0;
     const size_t sz[ACCEL_SEGS] = { HDR_WORDS * 4, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)NB * MAX_TILES * 4,
-                                    (size_t)MAX_ACCEL_FACES * 32, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4, (size_t)CTL_ENTRIES * 2 };
+                                    (size_t)MAX_ACCEL_FACES * 32, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4, (size_t)CTL_ENTRIES * 2,
+                                    (size_t)MAX_TILES * SUBS * 6 * 4 };
     for (int i = 0; i < ACCEL_SEGS; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
     return off;
 }
@@ -296,7 +299,7 @@ __host__ __device__ inline AccelView accel_view(void *base)
     v.hdr = reinterpret_cast<uint32_t *>(b + o[0]); v.sorted = reinterpret_cast<uint32_t *>(b + o[1]);
     v.tri = reinterpret_cast<float *>(b + o[2]); v.oid = reinterpret_cast<int32_t *>(b + o[3]); v.box = reinterpret_cast<float *>(b + o[4]);
     v.sph = reinterpret_cast<float4 *>(b + o[5]);
-    v.cell = reinterpret_cast<uint32_t *>(b + o[6]); v.ctl = reinterpret_cast<uint16_t *>(b + o[7]);
+    v.cell = reinterpret_cast<uint32_t *>(b + o[6]); v.ctl = reinterpret_cast<uint16_t *>(b + o[7]); v.sub = reinterpret_cast<float *>(b + o[8]);
     return v;
 }
 
@@ -447,16 +450,25 @@ __global__ __launch_bounds__(256) void accel_tiles_kernel(const float *__restric
                     ax[1][0] = t0; ax[1][1] = t1; ax[1][2] = t2;
                     ax[2][0] = n1 * t2 - n2 * t1; ax[2][1] = n2 * t0 - n0 * t2; ax[2][2] = n0 * t1 - n1 * t0;
                 }
-                for (int j = 0; j < TILE_F; ++j)
+                for (int gI = 0; gI < SUBS; ++gI) {                   // per group of SUB_F consecutive faces (compact along the curve): its own box in the tile's frame
+                    float slo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, shi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+                    for (int j = gI * SUB_F; j < (gI + 1) * SUB_F; ++j)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float *t = sb[threadIdx.x * TILE_F + j] + 3 * c;
+                        for (int c = 0; c < 3; ++c) {
+                            const float *t = sb[threadIdx.x * TILE_F + j] + 3 * c;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const float d = ax[k][0] * t[0] + ax[k][1] * t[1] + ax[k][2] * t[2];
-                            lo[k] = d < lo[k] ? d : lo[k]; hi[k] = d > hi[k] ? d : hi[k];
+                            for (int k = 0; k < 3; ++k) {
+                                const float d = ax[k][0] * t[0] + ax[k][1] * t[1] + ax[k][2] * t[2];
+                                slo[k] = d < slo[k] ? d : slo[k]; shi[k] = d > shi[k] ? d : shi[k];
+                            }
                         }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        lo[k] = slo[k] < lo[k] ? slo[k] : lo[k]; hi[k] = shi[k] > hi[k] ? shi[k] : hi[k];
+                        const float pad = 1e-5f * (1.0f + __builtin_fabsf(slo[k]) + __builtin_fabsf(shi[k]));      // as for the tile's box below
+                        av.sub[((size_t)tile * SUBS + gI) * 6 + k] = slo[k] - pad; av.sub[((size_t)tile * SUBS + gI) * 6 + 3 + k] = shi[k] + pad;
                     }
+                }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {                        // fp32 dot products and axes: stay conservative
                     const float pad = 1e-5f * (1.0f + __builtin_fabsf(lo[k]) + __builtin_fabsf(hi[k]));
@@ -742,10 +754,13 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
 // sample is -- with one sample at a time a batch held 17 faces on average.  Running minima live in LDS: best[s] as the bit pattern of the (non-negative)
 // fp64 distance^2 under an unsigned 64-bit minimum, the lowest face id among equal distances under a second minimum; the result does not depend on the
 // order of the pairs, and equals the exhaustive kernel's bit for bit.
-constexpr uint32_t TQ = 1024, FQ = 512;         // pair queues (rings): a sample adds <= NIT x 64 = 512 tile pairs to < 8 left over, a disc trip <= STEPS x 64 face pairs to < 64
-static_assert(TQ >= NIT * 64 + GROUPS * STEPS && FQ >= STEPS * 64 + 64 && MAX_TILES <= 512, "queue capacities / pair encoding");
+constexpr uint32_t TQ = 1024, GQ = 256, FQ = 256;     // pair queues (rings): a sample adds <= NIT x 64 = 512 (sample, tile) pairs to < 32 left over; a group trip
+                                                       // <= 128 (sample, tile, group) triples to < 16; a disc trip <= 128 (sample, face) pairs to < 64
+constexpr int GSTEPS = 2, DSTEPS = 2;                  // steps per group trip (16 tile pairs each) and per disc trip (8 triples each)
+static_assert(TQ >= NIT * 64 + 16 * GSTEPS && GQ >= 64 * GSTEPS + 8 * DSTEPS && FQ >= 64 * DSTEPS + 64 && MAX_TILES <= 512 && SUBS == 4 && SUB_F == 8,
+              "queue capacities / pair encoding");
 constexpr int PK_WAVES = 8;                     // waves per workgroup (they share the 32 KB of boxes)
-constexpr uint32_t PK_WAVE_BYTES = 64 * 8 + 64 * 4 + 3 * 64 * 4 + FQ * 4 + TQ * 2;
+constexpr uint32_t PK_WAVE_BYTES = 64 * 8 + 64 * 4 + 3 * 64 * 4 + FQ * 4 + GQ * 4 + TQ * 2;
 
 __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_accel_kernel(const float *__restrict__ pts, const float *__restrict__ verts,
                                                                  const int32_t *__restrict__ faces, const double *__restrict__ T, uint32_t P,
@@ -765,7 +780,8 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     uint32_t *sbid = reinterpret_cast<uint32_t *>(wl + 512);                     // [64] lowest face id at that distance
     float *sq = reinterpret_cast<float *>(wl + 768);                             // [3][64] the samples
     uint32_t *fq = reinterpret_cast<uint32_t *>(wl + 1536);                      // [FQ] (sample << 14) | slot
-    uint16_t *tq = reinterpret_cast<uint16_t *>(wl + 1536 + FQ * 4);             // [TQ] (sample << 9) | tile
+    uint32_t *gq = reinterpret_cast<uint32_t *>(wl + 1536 + FQ * 4);             // [GQ] (sample << 11) | (tile << 2) | group
+    uint16_t *tq = reinterpret_cast<uint16_t *>(wl + 1536 + FQ * 4 + GQ * 4);    // [TQ] (sample << 9) | tile
     load_boxes(sbox_raw, av, ntp);
     __syncthreads();
     if (wave * 64 >= P) return;                                        // (after the barrier) a wave without samples
@@ -809,7 +825,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     for (int k = 0; k < 3; ++k) sq[k * 64 + lane] = pf[k];
     wave_sync_lds();
     WP_TICK(7)
-    uint32_t th = 0, tt = 0, fh = 0, ft = 0;                             // wave-uniform ring positions: tile pairs, face pairs
+    uint32_t th = 0, tt = 0, gh = 0, gt = 0, fh = 0, ft = 0;             // wave-uniform ring positions: tile pairs, group triples, face pairs
 
     // exact distances of n queued (sample, face) pairs, folded into the samples' running minima
     auto exact_batch = [&](uint32_t n) {
@@ -845,26 +861,61 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
         fh += n;
         wave_sync_lds();
     };
-    // up to STEPS x 2 queued (sample, tile) pairs: every face of the tile against its bounding disc (a lower bound of its distance) under the
-    // sample's current bound; survivors are queued for the exact routine
-    auto disc_trip = [&]() {
+    // up to GSTEPS x 16 queued (sample, tile) pairs: the four sub-boxes of the tile (groups of 8 consecutive faces, boxes in the tile's frame) against
+    // the sample's current bound, lane = (pair, group); the survivors are queued as (sample, tile, group)
+    auto group_trip = [&]() {
         wave_sync_lds();
-        const uint32_t np = (tt - th) < (uint32_t)(GROUPS * STEPS) ? (tt - th) : (uint32_t)(GROUPS * STEPS);
-        uint32_t slot[STEPS], smp[STEPS]; bool have[STEPS];
-        float4 sp[STEPS], sn[STEPS];
+        const uint32_t np = (tt - th) < (uint32_t)(16 * GSTEPS) ? (tt - th) : (uint32_t)(16 * GSTEPS);
 #pragma unroll
-        for (int u = 0; u < STEPS; ++u) {
-            const uint32_t pi = (uint32_t)(GROUPS * u + lane / TILE_F);
-            have[u] = pi < np;
-            const uint32_t e = tq[(th + (have[u] ? pi : 0u)) & (TQ - 1)];
-            smp[u] = e >> 9;
-            slot[u] = (e & 511u) * TILE_F + (uint32_t)(lane & (TILE_F - 1));
-            sp[u] = av.sph[2 * (size_t)slot[u]]; sn[u] = av.sph[2 * (size_t)slot[u] + 1];
+        for (int u = 0; u < GSTEPS; ++u) {
+            if ((uint32_t)(16 * u) >= np) break;                         // wave-uniform
+            const uint32_t pi = (uint32_t)(16 * u + (lane >> 2));
+            const bool have = pi < np;
+            const uint32_t e = tq[(th + (have ? pi : 0u)) & (TQ - 1)];
+            const uint32_t smp = e >> 9, tile = e & 511u, tg = tile * SUBS + (uint32_t)(lane & 3);
+            const float2 *sb2 = reinterpret_cast<const float2 *>(av.sub + (size_t)tg * 6);
+            const float2 b0 = sb2[0], b1 = sb2[1], b2 = sb2[2];          // lo.x lo.y | lo.z hi.x | hi.y hi.z
+            const float q0 = sq[smp], q1 = sq[64 + smp], q2 = sq[128 + smp];
+            const float padq = 4e-7f * ((__builtin_fabsf(q0) + __builtin_fabsf(q1)) + __builtin_fabsf(q2));
+            const float limf = (float)(__builtin_bit_cast(double, sbest[smp]) * (1.0 + 1e-9)) * 1.000001f;      // >= the bound (+inf stays +inf)
+            const float blo[3] = { b0.x, b0.y, b1.x }, bhi[3] = { b1.y, b2.x, b2.y };
+            float l = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float sk = q0 * SBOX(3 * k, tile) + q1 * SBOX(3 * k + 1, tile) + q2 * SBOX(3 * k + 2, tile);
+                const float lo = blo[k] - sk, hi = sk - bhi[k];
+                float d = (lo > hi ? lo : hi) - padq;
+                d = d > 0.0f ? d : 0.0f;
+                l += d * d;
+            }
+            const bool pass = have && l * (1.0f - 1e-5f) <= limf;
+            const unsigned long long pm = __ballot(pass);
+            if (pass) gq[(gt + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))) & (GQ - 1)] = (smp << 11) | tg;
+            gt += (uint32_t)__builtin_popcountll(pm);
         }
         th += np;
+        WP_TICK(3)
+    };
+    // up to DSTEPS x 8 queued (sample, tile, group) triples: the group's 8 faces against their bounding discs (a lower bound of a face's distance)
+    // under the sample's current bound, lane = (triple, face); survivors are queued for the exact routine
+    auto disc_trip = [&]() {
+        wave_sync_lds();
+        const uint32_t ne = (gt - gh) < (uint32_t)(8 * DSTEPS) ? (gt - gh) : (uint32_t)(8 * DSTEPS);
+        uint32_t slot[DSTEPS], smp[DSTEPS]; bool have[DSTEPS];
+        float4 sp[DSTEPS], sn[DSTEPS];
 #pragma unroll
-        for (int u = 0; u < STEPS; ++u) {
-            if ((uint32_t)(GROUPS * u) >= np) break;                     // wave-uniform
+        for (int u = 0; u < DSTEPS; ++u) {
+            const uint32_t ei = (uint32_t)(8 * u + (lane >> 3));
+            have[u] = ei < ne;
+            const uint32_t e = gq[(gh + (have[u] ? ei : 0u)) & (GQ - 1)];
+            smp[u] = e >> 11;
+            slot[u] = (e & 2047u) * SUB_F + (uint32_t)(lane & 7);        // (tile * 4 + group) * 8 + face = tile * 32 + ...
+            sp[u] = av.sph[2 * (size_t)slot[u]]; sn[u] = av.sph[2 * (size_t)slot[u] + 1];
+        }
+        gh += ne;
+#pragma unroll
+        for (int u = 0; u < DSTEPS; ++u) {
+            if ((uint32_t)(8 * u) >= ne) break;                          // wave-uniform
             // lower bound of the face's distance from its bounding disc (accel_tiles_kernel), in fp32: q, the disc and the normal are
             // fp32 data, and every rounding below is padded towards "pass" (a face that passes wrongly only costs an exact test)
             const float q0 = sq[smp[u]], q1 = sq[64 + smp[u]], q2 = sq[128 + smp[u]];
@@ -970,10 +1021,17 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             WP_TICK(3)
         }
         }
-        // ONE inlined copy of the trip and of the batch: full trips / batches while samples are still coming, the leftovers at the end
-        while (tt - th >= (uint32_t)(GROUPS * STEPS) || (last && (tt != th || ft != fh))) {
-            if (tt != th) disc_trip();
-            while (ft - fh >= 64u || (last && tt == th && ft != fh)) { exact_batch((ft - fh) < 64u ? (ft - fh) : 64u); WP_TICK(5) }
+        // ONE inlined copy of each stage; downstream first (that bounds the queues): full trips / batches while samples are still coming, the
+        // leftovers at the end
+        for (;;) {
+            const uint32_t ntq = tt - th, ngq = gt - gh, nfq = ft - fh;
+            const bool do_e = nfq >= 64u || (last && !ntq && !ngq && nfq);
+            const bool do_d = !do_e && (ngq >= (uint32_t)(8 * DSTEPS) || (last && !ntq && ngq));
+            const bool do_g = !do_e && !do_d && (ntq >= (uint32_t)(16 * GSTEPS) || (last && ntq));
+            if (do_e) { exact_batch(nfq < 64u ? nfq : 64u); WP_TICK(5) }
+            else if (do_d) disc_trip();
+            else if (do_g) group_trip();
+            else break;
         }
     }
 #undef SBOX
