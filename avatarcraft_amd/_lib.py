@@ -47,6 +47,14 @@ class ac_core_grads(C.Structure):
     _fields_ = [("g_table", vp), ("g_sdf_params", vp), ("g_color_params", vp), ("g_inv_s_per_ray", vp)]
 
 
+class ac_wn_layer(C.Structure):
+    _fields_ = [("v", vp), ("g", vp), ("w", vp), ("rows", u32), ("cols", u32), ("w_stride", u32), ("reserved_", u32)]
+
+
+class ac_pg_entry(C.Structure):
+    _fields_ = [("src", vp), ("v", vp), ("g", vp), ("dst", vp), ("dst2", vp), ("rows", u32), ("cols", u32), ("src_stride", u32), ("kind", i32)]
+
+
 class ac_warp_mesh(C.Structure):
     _fields_ = [("verts", vp), ("faces", vp), ("T", vp), ("V", u32), ("F", u32), ("threshold", C.c_double), ("geo_threshold", f32),
                 ("use_mesh_guide", i32), ("accel", vp)]
@@ -74,6 +82,9 @@ _SIGS = {
     "ac_sample_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_eikonal_reduce": ([vp, i32, vp, vp], C.c_int),
     "ac_eikonal_reduce2": ([vp, i32, vp, vp], C.c_int),
+    "ac_weight_norm_forward": ([C.POINTER(ac_wn_layer), u32, vp], C.c_int),
+    "ac_param_grads": ([C.POINTER(ac_pg_entry), u32, vp], C.c_int),
+    "ac_sds_upstream": ([vp, vp, u32, f32, vp, vp, vp], C.c_int),
     "ac_render_core_backward_scratch": ([C.POINTER(ac_field), i32, i32], C.c_size_t),
     "ac_render_core_backward": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, C.POINTER(ac_core_saved), C.POINTER(ac_core_upstream),
                                  C.POINTER(ac_core_grads), vp, C.c_size_t, vp], C.c_int),
@@ -118,7 +129,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
             fn.argtypes = args
             fn.restype = res
-        if handle.ac_version() != 2:
+        if handle.ac_version() != 3:
             raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
         _lib = handle
     return _lib

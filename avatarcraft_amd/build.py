@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libavatarcraft_hip.so")
-SOURCES = ["ac_capi.hip", "hashgrid.hip", "hash_stencil.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "sdf_train.hip", "warp.hip"]
+SOURCES = ["ac_capi.hip", "hashgrid.hip", "hash_stencil.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "sdf_train.hip", "warp.hip", "step_glue.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wno-unused-result"]
 

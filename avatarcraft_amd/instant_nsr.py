@@ -71,13 +71,53 @@ class NeRFRenderer(nn.Module):
         if cached is not None and cached[0] == key:
             return cached[1]
         with torch.no_grad():
-            wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0).contiguous()
+            W = self._effective_weights()
             f = nsr_ops.Field(enc.embeddings.detach(), self._offsets_host(), enc.per_level_scale, enc.base_resolution,
-                              wn(self.sdf_net[0]), self.sdf_net[0].bias.detach().contiguous(), wn(self.sdf_net[1]),
-                              self.sdf_net[1].bias.detach().contiguous(), wn(self.color_net[0]), wn(self.color_net[1]), wn(self.color_net[2]))
+                              W[0], self.sdf_net[0].bias.detach().contiguous(), W[1], self.sdf_net[1].bias.detach().contiguous(), W[2], W[3], W[4])
         f.prepare()                     # the weights in LDS order, once per parameter version (every render workgroup then copies them linearly)
         self._field_cache = (key, f)
         return f
+
+    def _effective_weights(self):
+        """weight-normed matrices of the five layers (torch.nn.utils.weight_norm: w = v g / ||v||_row), all in ONE launch"""
+        layers = list(self.sdf_net) + list(self.color_net)
+        dev = layers[0].weight_v.device
+        shapes = [tuple(l.weight_v.shape) for l in layers]
+        buf = torch.empty(sum(r * c for r, c in shapes), dtype=torch.float32, device=dev)
+        outs, off = [], 0
+        for r, c in shapes:
+            outs.append(buf[off:off + r * c].view(r, c)); off += r * c
+        return nsr_ops.weight_norm_forward([(l.weight_v.detach(), l.weight_g.detach()) for l in layers], outs)
+
+    # ---- a training render WITHOUT autograd (stylize.sds_step): run() keeps the launch's per-sample outputs, backward_last() turns upstream
+    # gradients of (image, weights_sum, gradient_error) into parameter gradients: ac_render_core_backward + ac_param_grads, accumulated into .grad
+    _manual_backward = False
+
+    def manual_backward_supported(self):
+        return self.fused_training == "core" and self._fused_supported() and self.encoder.embeddings.is_cuda
+
+    def backward_last(self, g_image=None, g_weights_sum=None, g_eik=None):
+        out, ro, rd, bg, field = self._last_train
+        self._last_train = None
+        enc = self.encoder
+        prm = [enc.embeddings, self.deviation_net.variance] + [t for l in self.sdf_net for t in (l.weight_v, l.weight_g, l.bias)] + \
+              [t for l in self.color_net for t in (l.weight_v, l.weight_g)]
+        for t in prm:
+            if t.grad is None:
+                t.grad = torch.zeros_like(t)
+        g_sdf_p, g_col_p, g_invs = nsr_ops.render_core_backward(field, out.opts, out, ro, rd, bg, g_image, g_weights_sum, None, None, g_eik, enc.embeddings.grad)
+        s0, s1, c0, c1, c2 = self.sdf_net[0], self.sdf_net[1], self.color_net[0], self.color_net[1], self.color_net[2]
+        WN, ADD, VAR = nsr_ops.PG_WEIGHT_NORM, nsr_ops.PG_ADD, nsr_ops.PG_VARIANCE
+        var = self.deviation_net.variance
+        with torch.no_grad():
+            inv_s = self.forward_variance()
+        wn = lambda src, off, stride, l: (WN, (src, off), stride, l.weight_v.shape[0], l.weight_v.shape[1], l.weight_v.detach(), l.weight_g.detach(),
+                                          l.weight_v.grad, l.weight_g.grad)
+        nsr_ops.param_grads([
+            wn(g_sdf_p, 0, 36, s0), (ADD, (g_sdf_p, 35), 36, 64, 1, None, None, s0.bias.grad, None),
+            wn(g_sdf_p, 64 * 36, 64, s1), (ADD, (g_sdf_p, 64 * 36 + 1024), 1, 16, 1, None, None, s1.bias.grad, None),
+            wn(g_col_p, 0, 32, c0), wn(g_col_p, 2048, 64, c1), wn(g_col_p, 6144, 64, c2),
+            (VAR, g_invs, 1, g_invs.shape[0], 1, None, inv_s.reshape(-1), var.grad.reshape(-1), None)], ro.device)
 
     # How a render WITH gradients runs (stylize.py / reconstruct.py):
     #   "core": one operator -- forward = the fused renderer itself (the launch an inference render makes, bit for bit), backward =
@@ -119,9 +159,9 @@ class NeRFRenderer(nn.Module):
         dev = enc.embeddings.device
         z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
         with torch.no_grad():
-            wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0).contiguous()
-            f = nsr_ops.Field(enc.embeddings.detach(), self._offsets_host(), enc.per_level_scale, enc.base_resolution, wn(self.sdf_net[0]),
-                              self.sdf_net[0].bias.detach().contiguous(), wn(self.sdf_net[1]), self.sdf_net[1].bias.detach().contiguous(),
+            W = nsr_ops.weight_norm_all(list(self.sdf_net))
+            f = nsr_ops.Field(enc.embeddings.detach(), self._offsets_host(), enc.per_level_scale, enc.base_resolution, W[0],
+                              self.sdf_net[0].bias.detach().contiguous(), W[1], self.sdf_net[1].bias.detach().contiguous(),
                               z(64, 21), z(64, 64), z(3, 64))
         self._field_sdf_cache = (key, f)
         return f
@@ -162,12 +202,19 @@ class NeRFRenderer(nn.Module):
             from .ray_utils import geometry_guided_near_far
             v = verts.verts if isinstance(verts, nsr_ops.WarpMesh) else verts
             near_far = geometry_guided_near_far(ro, rd, v, DEFAULT_GEO_THRESH)
+        if needs_grad and full and self.fused_training == "core" and near_far is None and self._manual_backward:
+            with torch.no_grad():
+                field, inv_s_ng = self._field(), self.forward_variance()
+                out = nsr_ops.render_rays(field, ro, rd, num_steps, upsample_steps, bound, inv_s_ng, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
+                                          normal_epsilon_ratio=normal_epsilon_ratio, extras=True, train_extras=True, precision=self.render_precision)
+            self._last_train = (out, ro, rd, bg, field)
+            return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3), out["normal_map"],
+                    out["eik_res"][0], 0.0, out["color"], out["alpha"], out["z_vals"])
         if needs_grad and full and self.fused_training == "core" and near_far is None:
-            wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0)
+            W = nsr_ops.weight_norm_all(list(self.sdf_net) + list(self.color_net))
             enc = self.encoder
             (image, wsum, depth, nmap, gerr, weights, alpha, color, z_vals) = nsr_ops.render_core(
-                enc.embeddings, wn(self.sdf_net[0]), self.sdf_net[0].bias, wn(self.sdf_net[1]), self.sdf_net[1].bias, wn(self.color_net[0]),
-                wn(self.color_net[1]), wn(self.color_net[2]), inv_s_t, ro, rd, bg, noise, self._offsets_host(), enc.per_level_scale, enc.base_resolution,
+                enc.embeddings, W[0], self.sdf_net[0].bias, W[1], self.sdf_net[1].bias, W[2], W[3], W[4], inv_s_t, ro, rd, bg, noise, self._offsets_host(), enc.per_level_scale, enc.base_resolution,
                 num_steps, upsample_steps, bound, cos_anneal_ratio, normal_epsilon_ratio, precision=self.render_precision)
             return depth.reshape(B, N), weights, wsum[:, None], image.reshape(B, N, 3), nmap, gerr, 0.0, color, alpha, z_vals
         if needs_grad or not full:
@@ -353,8 +400,8 @@ class NeRFNetwork(NeRFRenderer):
         Returns (sdf_out [B,16], gradient [B,3])."""
         if self.fused_training and self._sdf_supported() and x.is_cuda:            # one kernel forward, two backward (csrc/sdf_train.hip)
             l0, l1, enc = self.sdf_net[0], self.sdf_net[1], self.encoder
-            return nsr_ops.sdf_stencil(x, enc.embeddings, torch._weight_norm(l0.weight_v, l0.weight_g, 0), l0.bias,
-                                       torch._weight_norm(l1.weight_v, l1.weight_g, 0), l1.bias, self._offsets_host(), enc.per_level_scale,
+            W = nsr_ops.weight_norm_all([l0, l1])                                   # the same effective matrices as every other fused path, bit for bit
+            return nsr_ops.sdf_stencil(x, enc.embeddings, W[0], l0.bias, W[1], l1.bias, self._offsets_host(), enc.per_level_scale,
                                        enc.base_resolution, bound, epsilon)
         B = x.shape[0]
         h7 = self.encoder.forward_stencil(x, bound, epsilon)                       # [7,B,32]: x, +x, -x, +y, -y, +z, -z
@@ -373,8 +420,8 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward_color_fused(self, x, n, sdf_out):
         """forward_color on the outputs of forward_sdf (sdf_out [B,16] = [sdf, feat]) as one fused op with a fused backward"""
-        wn = lambda l: torch._weight_norm(l.weight_v, l.weight_g, 0)
-        return nsr_ops.color_mlp(x, n, sdf_out, wn(self.color_net[0]), wn(self.color_net[1]), wn(self.color_net[2]))
+        W = nsr_ops.weight_norm_all(list(self.color_net))
+        return nsr_ops.color_mlp(x, n, sdf_out, W[0], W[1], W[2])
 
     def forward_color(self, x, d, n, geo_feat, bound):
         if self.use_viewdirs:

@@ -317,6 +317,106 @@ def render_core(table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg,
     return _RenderCore.apply(table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, cfg)
 
 
+def weight_norm_forward(pairs, outs):
+    """outs[i][r, :] = v[r, :] * g[r] / ||v[r, :]|| for every (v, g) in pairs, ONE launch (ac_weight_norm_forward); outs may be row-strided views"""
+    n = len(pairs)
+    arr = (L.ac_wn_layer * n)()
+    for i, ((v, g), w) in enumerate(zip(pairs, outs)):
+        assert v.is_contiguous() and g.is_contiguous() and v.dtype == _F32 and w.dtype == _F32 and w.stride(1) == 1 and tuple(w.shape) == tuple(v.shape)
+        arr[i] = L.ac_wn_layer(v.data_ptr(), g.data_ptr(), w.data_ptr(), v.shape[0], v.shape[1], w.stride(0), 0)
+    L.check(L.lib().ac_weight_norm_forward(arr, n, L.current_stream(pairs[0][0].device)), "weight_norm_forward")
+    return outs
+
+
+PG_WEIGHT_NORM, PG_ADD, PG_VARIANCE = 0, 1, 2
+
+
+class _WeightNormAll(torch.autograd.Function):
+    """torch.nn.utils.weight_norm (dim 0) of several layers as ONE operator: forward = ac_weight_norm_forward, backward = ac_param_grads -- the same
+    effective matrices, bit for bit, for every path that renders a NeRFNetwork (inference, the training operators, the step without autograd)."""
+
+    @staticmethod
+    def forward(ctx, *vg):
+        pairs = [(vg[2 * i].detach().contiguous(), vg[2 * i + 1].detach().contiguous()) for i in range(len(vg) // 2)]
+        outs = [torch.empty_like(v) for v, _ in pairs]
+        weight_norm_forward(pairs, outs)
+        ctx.save_for_backward(*vg)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gw):
+        vg = ctx.saved_tensors
+        dev = vg[0].device
+        flat = torch.zeros(sum(t.numel() for t in vg), dtype=_F32, device=dev)
+        res, entries, off = [], [], 0
+        for i in range(len(vg) // 2):
+            v, g = vg[2 * i].detach().contiguous(), vg[2 * i + 1].detach().contiguous()
+            gv = flat[off:off + v.numel()].view_as(v); off += v.numel()
+            gg = flat[off:off + g.numel()].view_as(g); off += g.numel()
+            if gw[i] is None:
+                res += [None, None]
+                continue
+            gwi = gw[i].contiguous().to(_F32)
+            entries.append((PG_WEIGHT_NORM, gwi, gwi.shape[1], v.shape[0], v.shape[1], v, g, gv, gg.reshape(-1)))
+            res += [gv, gg]
+        if entries:
+            param_grads(entries, dev)
+        return tuple(res)
+
+
+def weight_norm_all(layers):
+    """[W_l = weight_norm(l.weight_v, l.weight_g)] for the given nn.Linear-like modules, differentiable, one launch each way"""
+    args = [t for l in layers for t in (l.weight_v, l.weight_g)]
+    return list(_WeightNormAll.apply(*args))
+
+
+def param_grads(entries, device):
+    """entries: (kind, src tensor / (tensor, element offset), src_stride, rows, cols, v, g, dst, dst2); everything ACCUMULATED into dst / dst2, ONE launch"""
+    n = len(entries)
+    arr = (L.ac_pg_entry * n)()
+    keep = []
+    for i, (kind, src, stride, rows, cols, v, g, dst, dst2) in enumerate(entries):
+        off = 0
+        if isinstance(src, tuple):
+            src, off = src
+        for t in (src, v, g, dst, dst2):
+            assert t is None or (t.dtype == _F32 and t.is_contiguous())
+        keep.append((src, v, g, dst, dst2))
+        arr[i] = L.ac_pg_entry(src.data_ptr() + 4 * off, L.ptr(v), L.ptr(g), dst.data_ptr(), L.ptr(dst2), rows, cols, stride, kind)
+    L.check(L.lib().ac_param_grads(arr, n, L.current_stream(device)), "param_grads")
+
+
+def sds_upstream(weights_sum, weights_sum_gt, scale, want_grad=True):
+    """opacity term of the stylisation loss: -> (d loss / d weights_sum [N] or None, loss [1]); loss = sum smooth_l1(clamp, clamp) * scale"""
+    ws, wg = weights_sum.reshape(-1).contiguous(), weights_sum_gt.reshape(-1).contiguous()
+    N, dev = ws.shape[0], ws.device
+    g = torch.empty(N, dtype=_F32, device=dev) if want_grad else None
+    loss = torch.empty(1, dtype=_F32, device=dev)
+    L.check(L.lib().ac_sds_upstream(ws.data_ptr(), wg.data_ptr(), N, float(scale), L.ptr(g), loss.data_ptr(), L.current_stream(dev)), "sds_upstream")
+    return g, loss
+
+
+def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, g_depth, g_nmap, g_eik, g_table):
+    """ac_render_core_backward on the outputs of a render_rays(..., train_extras=True) launch (`out`, its .opts): the table gradient is accumulated
+    into g_table; returns (g_sdf_params [3344], g_color_params [7168], g_inv_s_per_ray [N]) w.r.t. the EFFECTIVE matrices."""
+    z_vals = out["z_vals"]
+    N, T = z_vals.shape
+    dev = rays_o.device
+    c = lambda g: None if g is None else g.contiguous().to(_F32)
+    g_image, g_wsum, g_depth, g_nmap, g_eik = c(g_image), c(g_wsum), c(g_depth), c(g_nmap), c(g_eik)
+    g_sdf_p = torch.empty(64 * 36 + 16 * 64 + 16, dtype=_F32, device=dev)
+    g_col_p = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)
+    g_invs = torch.empty(N, dtype=_F32, device=dev)
+    sv = L.ac_core_saved(z_vals.data_ptr(), out["pts"].data_ptr(), out["sdf"].data_ptr(), out["sdf_out16"].data_ptr(), out["gradient"].data_ptr(),
+                         out["color"].data_ptr(), out["eik_res"][1:].data_ptr())
+    upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
+    gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
+    scratch, need = core_scratch(field, N, T, dev)
+    L.check(L.lib().ac_render_core_backward(C.byref(field.c), C.byref(opts[0]), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), C.byref(sv), C.byref(upg),
+                                            C.byref(gr), scratch.data_ptr(), need, L.current_stream(dev)), "render_core_backward")
+    return g_sdf_p, g_col_p, g_invs
+
+
 class _SdfStencil(torch.autograd.Function):
     """forward_sdf(x) + finite_difference_normals_approximator(x) of the render core as one fused op with a fused backward
     (csrc/sdf_train.hip).  Inputs: x [B,3] (no grad), the hash table, the EFFECTIVE sdf_net matrices (weight norm stays in torch)."""

@@ -15,6 +15,7 @@ Data parallel (BASELINE config 5): one view per rank, paramet
 then / world) of the flat fp32 gradient (12 248 902 elements = 49 MB) before the optimizer step.
 """
 import torch
+from . import nsr_ops
 import torch.nn.functional as F
 
 from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG
@@ -46,6 +47,16 @@ def flat_grad_view(params):
     return flat
 
 
+_CONSTS = {}
+
+
+def _const_scalar(v, device):
+    k = (float(v), str(device))
+    if k not in _CONSTS:
+        _CONSTS[k] = torch.tensor(float(v), dtype=torch.float32, device=device)
+    return _CONSTS[k]
+
+
 def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_size=4096, w_eikonal=0.01, use_opacity=True,
              bkg_key=WHITE_BKG, flat_grad=None, process_group=None, num_steps=64, upsample_steps=64, timers=None):
     """rays_o, rays_d: [h*w, 3] of the (sub-sampled) training view; hw = (h, w).  Returns a dict of scalars.
@@ -73,7 +84,33 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
         optimizer.zero_grad()
     bs = min(batch_size, n_rays)
     eik_vals, opa_vals = [], []
-    for i in range(0, n_rays, bs):
+    manual = rays_o.is_cuda and getattr(net_style, "manual_backward_supported", lambda: False)()
+    for i in range(0, n_rays, bs) if manual else ():
+        # The same three terms WITHOUT autograd (avatarcraft_amd.NeRFNetwork): the training render keeps its per-sample outputs, the upstream
+        # gradients of (image, weights_sum, gradient_error) are written down directly (d sum(rgb * g) = g; d (eik * w) = w; the opacity term through
+        # ac_sds_upstream) and go through ac_render_core_backward + ac_param_grads into .grad -- ~15 launches instead of ~80 per patch.
+        ro, rd = rays_o[i:i + bs], rays_d[i:i + bs]
+        net_style._manual_backward = True
+        try:
+            rgb, eik, extra = render_instantnsr_naive(net_style, ro, rd, requires_grad=True, bkg_key=bkg_key, rays_per_batch=bs, perturb=1.0,
+                                                      return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
+                                                      upsample_steps=upsample_steps)
+        finally:
+            net_style._manual_backward = False
+        mark("render_grad_forward")
+        with torch.no_grad():
+            _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
+                                                     return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps)
+            g_ws, opa = nsr_ops.sds_upstream(extra["weight_sum"], extra_gt["weight_sum"], 1e5 / ro.shape[0], want_grad=use_opacity)
+            opa_vals.append(opa[0])
+            g_eik = None
+            if w_eikonal > 0.0:
+                g_eik = _const_scalar(w_eikonal, ro.device)
+                eik_vals.append(eik * g_eik)
+            mark("render_gt_and_losses")
+            net_style.backward_last(g_image=grad_rays[i:i + bs], g_weights_sum=g_ws, g_eik=g_eik)
+        mark("backward")
+    for i in range(0, n_rays, bs) if not manual else ():
         ro, rd = rays_o[i:i + bs], rays_d[i:i + bs]
         rgb, eik, extra = render_instantnsr_naive(net_style, ro, rd, requires_grad=True, bkg_key=bkg_key, rays_per_batch=bs, perturb=1.0,
                                                   return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,

@@ -42,7 +42,7 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 2 */
+int ac_version(void);                /* ABI version, currently 3 */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
 
 /* ---- hash-grid encoder -------------------------------------------------------------------
@@ -322,6 +322,28 @@ size_t ac_render_core_backward_scratch(const ac_field *field, int32_t n_rays, in
 int ac_render_core_backward(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d, const float *bg,
                             const ac_core_saved *saved, const ac_core_upstream *upstream, const ac_core_grads *grads,
                             void *scratch, size_t scratch_bytes, ac_stream_t stream);
+
+/* ---- the per-step pieces around the training render (stylize.py:95-199), so that a stylisation step runs no framework kernel between the
+ * guidance gradient and the optimizer.
+ * ac_weight_norm_forward: w[r, :] = v[r, :] * g[r] / ||v[r, :]|| for every layer in ONE launch -- torch.nn.utils.weight_norm(dim = 0) of the
+ *   sdf_net / color_net layers (models/instant_nsr.py:557-590).  w may be a strided view (row stride w_stride >= cols). */
+#define AC_WN_MAX_LAYERS 8
+typedef struct ac_wn_layer { const float *v, *g; float *w; uint32_t rows, cols, w_stride, reserved_; } ac_wn_layer;
+int ac_weight_norm_forward(const ac_wn_layer *layers, uint32_t n_layers, ac_stream_t stream);
+/* ac_param_grads: gradients w.r.t. the EFFECTIVE matrices (g_sdf_params / g_color_params of ac_render_core_backward) -> the parameters' own
+ *   gradient buffers, ACCUMULATED (+=, like autograd's), one launch for up to AC_PG_MAX_ENTRIES entries:
+ *   AC_PG_WEIGHT_NORM: src = d W [rows, cols] (row stride src_stride), v, g -> dst = d weight_v [rows, cols], dst2 = d weight_g [rows]
+ *   AC_PG_ADD        : dst[i] += src[i * src_stride], i < rows                              (biases)
+ *   AC_PG_VARIANCE   : dst[0] += 10 * inv_s * sum_{i < rows} src[i] if 1e-6 < inv_s < 1e6;  g = device pointer to inv_s = exp(10 variance)
+ *                      (SingleVarianceNetwork + clip, models/instant_nsr.py:35-45, 666-667; src = g_inv_s_per_ray) */
+#define AC_PG_MAX_ENTRIES 12
+enum { AC_PG_WEIGHT_NORM = 0, AC_PG_ADD = 1, AC_PG_VARIANCE = 2 };
+typedef struct ac_pg_entry { const float *src, *v, *g; float *dst, *dst2; uint32_t rows, cols, src_stride; int32_t kind; } ac_pg_entry;
+int ac_param_grads(const ac_pg_entry *entries, uint32_t n_entries, ac_stream_t stream);
+/* ac_sds_upstream: the opacity term of the stylisation loss (stylize.py:183-193): loss = sum_i smooth_l1(clamp(ws_i, 0, 1), clamp(ws_gt_i, 0, 1)) *
+ *   scale (scale = 1e5 / n_rays for F.smooth_l1_loss(...) * 1e5); g_weights_sum [n_rays] = d loss / d ws (or NULL), loss = 1 float (device, or NULL) */
+int ac_sds_upstream(const float *weights_sum, const float *weights_sum_gt, uint32_t n_rays, float scale, float *g_weights_sum, float *loss,
+                    ac_stream_t stream);
 
 /* ---- posed-space rendering: NeRFRenderer.run(render_can=False, verts, faces, Ts, use_mesh_guide)
  * models/instant_nsr.py:147-172 (mesh-guided near/far, warp of the coarse samples), :198-203 (warp of the mid points),

@@ -533,6 +533,42 @@ def test_sds_step_through_rccl_world_size_1():
         assert torch.equal(p0[k], p1[k]), k
 
 
+def test_sds_step_without_autograd_equals_autograd_step():
+    """sds_step's default path for NeRFNetwork writes the upstream gradients down and calls ac_render_core_backward + ac_param_grads itself
+    (weight-norm backward, biases, d variance fused, no torch autograd); the autograd formulation of the same step (the operator
+    nsr_ops.render_core under torch's weight norm / losses) must give the same gradients -- two patches, multi-patch accumulation included --
+    and the same parameters after Adam.  Also: ac_weight_norm_forward == torch._weight_norm."""
+    from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view
+    ro, rd = make_rays(32, 16, dist=1.8, f=14.0)
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+
+    def one_step(manual):
+        net, _ = golden_net(train=True)
+        net_gt, _ = golden_net(train=False)
+        if not manual:
+            net.manual_backward_supported = lambda: False
+        opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+        flat = flat_grad_view(net.parameters())
+        torch.manual_seed(11)
+        stats = sds_step(net, net_gt, ro_t, rd_t, (32, 16), opt, SyntheticGuidance(5), batch_size=256, flat_grad=flat)
+        torch.cuda.synchronize()
+        return net, {k: v.grad.detach().clone() for k, v in net.named_parameters()}, {k: v.detach().clone() for k, v in net.named_parameters()}, stats
+    n1, g1, p1, s1 = one_step(True)
+    n0, g0, p0, s0 = one_step(False)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert scale > 0 or k.endswith("bias"), k
+        err = float((g1[k] - g0[k]).abs().max())
+        assert err <= 2e-5 * scale + 1e-12, (k, err, scale)
+        assert float((p1[k] - p0[k]).abs().max()) <= 1e-6, k
+    assert abs(float(s1["opacity"]) - float(s0["opacity"])) <= 1e-5 * abs(float(s0["opacity"])) + 1e-6
+    assert abs(float(s1["eikonal"]) - float(s0["eikonal"])) <= 1e-6 * abs(float(s0["eikonal"])) + 1e-9
+    W = n1._effective_weights()
+    for l, w in zip(list(n1.sdf_net) + list(n1.color_net), W):
+        ref = torch._weight_norm(l.weight_v.detach(), l.weight_g.detach(), 0)
+        assert float((w - ref).abs().max()) <= 2e-7 * float(ref.abs().max())
+
+
 def test_reconstruct_step_matches_reference_step(tmp_path):
     """one step of reconstruct.py:92-112 (smooth_l1(rgb, gt) + 0.1 eikonal, Adam(5e-4, (0.9, 0.99), eps 1e-15)) against the reference's own
     autograd + optimizer (tests/golden/reconstruct_grad.npz), through avatarcraft_amd.reconstruct; then the epoch loop and the dataset reader"""
