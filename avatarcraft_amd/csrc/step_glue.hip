@@ -20,10 +20,12 @@ struct WnArgs { ac_wn_layer l[AC_WN_MAX_LAYERS]; uint32_t row0[AC_WN_MAX_LAYERS 
 
 __global__ __launch_bounds__(64) void weight_norm_fwd_kernel(const WnArgs a)
 {
-    uint32_t li = 0;
-    while (li + 1 < a.n && blockIdx.x >= a.row0[li + 1]) ++li;
-    const ac_wn_layer L = a.l[li];
-    const uint32_t r = blockIdx.x - a.row0[li];
+    // static indexing of the by-value argument (a dynamic index would move the whole struct to scratch memory)
+    ac_wn_layer L = a.l[0];
+    uint32_t r = blockIdx.x;
+#pragma unroll
+    for (int i = 1; i < AC_WN_MAX_LAYERS; ++i)
+        if ((uint32_t)i < a.n && blockIdx.x >= a.row0[i]) { L = a.l[i]; r = blockIdx.x - a.row0[i]; }
     const int lane = threadIdx.x;
     const float *v = L.v + (size_t)r * L.cols;
     float s = 0.0f;
@@ -36,34 +38,47 @@ __global__ __launch_bounds__(64) void weight_norm_fwd_kernel(const WnArgs a)
 
 struct PgArgs { ac_pg_entry e[AC_PG_MAX_ENTRIES]; uint32_t blk0[AC_PG_MAX_ENTRIES + 1]; uint32_t n; };
 
-__global__ __launch_bounds__(64) void param_grads_kernel(const PgArgs a)
+constexpr int PG_BLOCK = 256;
+__device__ __forceinline__ float block_sum(float v, float *red)       // PG_BLOCK threads; every thread gets the total (fixed order)
 {
-    uint32_t ei = 0;
-    while (ei + 1 < a.n && blockIdx.x >= a.blk0[ei + 1]) ++ei;
-    const ac_pg_entry E = a.e[ei];
-    const uint32_t r = blockIdx.x - a.blk0[ei];
-    const int lane = threadIdx.x;
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(PG_BLOCK) void param_grads_kernel(const PgArgs a)
+{
+    __shared__ float red[4];
+    // static indexing of the by-value argument (a dynamic index would move the whole struct to scratch memory)
+    ac_pg_entry E = a.e[0];
+    uint32_t r = blockIdx.x;
+#pragma unroll
+    for (int i = 1; i < AC_PG_MAX_ENTRIES; ++i)
+        if ((uint32_t)i < a.n && blockIdx.x >= a.blk0[i]) { E = a.e[i]; r = blockIdx.x - a.blk0[i]; }
+    const uint32_t t = threadIdx.x;
     if (E.kind == AC_PG_WEIGHT_NORM) {
         // w = v g / n  =>  dg = (dw . v) / n,  dv = (g / n) (dw - v (dw . v) / n^2)
         const float *v = E.v + (size_t)r * E.cols, *gw = E.src + (size_t)r * E.src_stride;
         float s = 0.0f, d = 0.0f;
-        for (uint32_t c = lane; c < E.cols; c += 64) { s += v[c] * v[c]; d += gw[c] * v[c]; }
-        s = wave_sum(s); d = wave_sum(d);
+        for (uint32_t c = t; c < E.cols; c += PG_BLOCK) { s += v[c] * v[c]; d += gw[c] * v[c]; }
+        s = block_sum(s, red); d = block_sum(d, red);
         const float norm = __builtin_sqrtf(s), g = E.g[r];
-        if (lane == 0) E.dst2[r] += d / norm;
+        if (t == 0) E.dst2[r] += d / norm;
         const float k = g / norm, m = d / s;
         float *gv = E.dst + (size_t)r * E.cols;
-        for (uint32_t c = lane; c < E.cols; c += 64) gv[c] += k * (gw[c] - v[c] * m);
+        for (uint32_t c = t; c < E.cols; c += PG_BLOCK) gv[c] += k * (gw[c] - v[c] * m);
     } else if (E.kind == AC_PG_ADD) {
-        for (uint32_t i = lane; i < E.rows; i += 64) E.dst[i] += E.src[(size_t)i * E.src_stride];
+        for (uint32_t i = t; i < E.rows; i += PG_BLOCK) E.dst[i] += E.src[(size_t)i * E.src_stride];
     } else {
         // AC_PG_VARIANCE: inv_s = clip(exp(10 variance), 1e-6, 1e6) (models/instant_nsr.py:35-45, 666-667): d / d variance = 10 inv_s sum_rays(d / d inv_s)
         // inside the clip range, 0 outside (torch.clip's backward passes the gradient on [min, max])
         float s = 0.0f;
-        for (uint32_t i = lane; i < E.rows; i += 64) s += E.src[i];
-        s = wave_sum(s);
+        for (uint32_t i = t; i < E.rows; i += PG_BLOCK) s += E.src[i];
+        s = block_sum(s, red);
         const float inv_s = E.g[0];
-        if (lane == 0 && inv_s > 1e-6f && inv_s < 1e6f) E.dst[0] += 10.0f * inv_s * s;
+        if (t == 0 && inv_s > 1e-6f && inv_s < 1e6f) E.dst[0] += 10.0f * inv_s * s;
     }
 }
 
@@ -123,7 +138,7 @@ AC_API int ac_param_grads(const ac_pg_entry *entries, uint32_t n, ac_stream_t st
         }
         a.e[i] = e; a.blk0[i + 1] = a.blk0[i] + (wn ? e.rows : 1u);
     }
-    hipLaunchKernelGGL(param_grads_kernel, dim3(a.blk0[n]), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(param_grads_kernel, dim3(a.blk0[n]), dim3(PG_BLOCK), 0, (hipStream_t)stream, a);
     return ac::check_launch("param_grads");
 }
 
