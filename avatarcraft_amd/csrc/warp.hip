@@ -253,7 +253,13 @@ constexpr uint32_t RING = 512;      // per-wave ring of faces that passed the di
 // boxes of a sample in one to three lane-parallel steps instead of all tiles (431 for SMPL) in seven, and needs no seed search.  Samples without a
 // usable cell (outside both grids, overflow) take the full bounding pass.
 constexpr int GRID_LEVELS = 2;
-constexpr uint32_t LVL_CELLS[GRID_LEVELS] = { 1u << 19, 1u << 17 };     // capacity in cells
+#ifndef AC_LVL0_LOG2
+#define AC_LVL0_LOG2 19
+#endif
+#ifndef AC_LVL1_LOG2
+#define AC_LVL1_LOG2 17
+#endif
+constexpr uint32_t LVL_CELLS[GRID_LEVELS] = { 1u << AC_LVL0_LOG2, 1u << AC_LVL1_LOG2 };     // capacity in cells
 constexpr uint32_t LVL_K[GRID_LEVELS] = { 64, 192 };                    // listed tiles per cell
 constexpr uint32_t LVL_CELL0[GRID_LEVELS] = { 0, LVL_CELLS[0] };        // first cell of the level in AccelView::cell
 constexpr uint32_t LVL_CTL0[GRID_LEVELS] = { 0, LVL_CELLS[0] * LVL_K[0] };   // first entry of the level in AccelView::ctl

@@ -379,7 +379,7 @@ def test_smpl_on_device_matches_reference_golden():
     assert rgb.shape == (64, 3) and torch.isfinite(rgb).all()
 
 
-@pytest.mark.parametrize("n_side,T0,up,perturb", [(10, 64, 64, True), (7, 32, 32, False), (3, 64, 0, True)])
+@pytest.mark.parametrize("n_side,T0,up,perturb", [(10, 64, 64, True), (7, 32, 32, False), (3, 64, 0, True), (64, 64, 64, True)])   # the last: BASELINE configuration 3's 4096-ray patch
 def test_render_core_operator(n_side, T0, up, perturb):
     """nsr_ops.render_core ("core": forward = the fused renderer itself, backward = ac_render_core_backward) against
     (a) the no-grad render: every forward output bit for bit (the training render IS the inference launch);
@@ -423,7 +423,12 @@ def test_render_core_operator(n_side, T0, up, perturb):
             torch.rand = orig
     for k in ("rgb", "weight_sum", "depth", "normal", "weights", "pts_color", "pts_alpha", "z_vals", "gradient_error"):
         assert torch.equal(o_core[k], o_ng[k]), k                       # (a)
-        assert torch.allclose(o_core[k], o_ops[k], atol=2e-5, rtol=1e-4), k
+        if N < 1024:
+            assert torch.allclose(o_core[k], o_ops[k], atol=2e-5, rtol=1e-4), k
+        else:       # half a million samples: alpha sits on a steep sigmoid for a few of them -- bound the outliers instead of every element
+            dlt = (o_core[k].float() - o_ops[k].float()).abs()
+            bad = dlt > (2e-5 + 1e-4 * o_ops[k].float().abs())
+            assert float(bad.float().mean()) <= 1e-4 and float(dlt.max()) <= 2e-3 and float(dlt.mean()) <= 2e-6, (k, float(bad.float().mean()), float(dlt.max()), float(dlt.mean()))
     assert set(g_core) == set(g_ops) == set(g_ag) and len(g_core) == 14
     worst = {}
     for k in g_core:

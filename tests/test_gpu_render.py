@@ -281,6 +281,22 @@ def test_warped_render_bitwise_vs_oracle(env, T0, up, guide, perturb):
     assert 0.02 < r["mask"].mean() < 0.7 and r["weights_sum"].max() > 0.5
 
 
+def test_warped_render_full_batch_vs_oracle(env):
+    """BASELINE configuration 4 at its real size: one 8192-ray batch of the 256x256 posed frame (32+32 samples, mesh-guided range, SMPL-sized body of
+    6 891 vertices / 13 778 faces) -- every output of the posed-space renderer, the warp mask and the warped mid points, bit for bit against the oracle
+    (whose closest-face search is exhaustive, fp64, OpenMP over rays: seconds on the GPU box's host cores)."""
+    from tests.common import make_body
+    body = make_body(n_lat=83, n_lon=83)
+    assert body[0].shape[0] == 6891 and body[1].shape[0] == 13778
+    ro, rd = make_rays(256, 256, dist=1.8, f=0.78125 * 256)
+    sl = slice(3 * 8192, 4 * 8192)                                  # rows 96..127: body and background
+    g, r = _warp_both(env, ro[sl], rd[sl], 32, 32, True, body=body)
+    _compare_bitwise(g, r, 32)
+    assert_bitwise(g["can_mid"].clamp(-1.6, 1.6), r["can_mid"], "can_mid")
+    assert np.array_equal(g["mask"].cpu().numpy(), r["mask"])
+    assert 0.02 < r["mask"].mean() < 0.9 and r["weights_sum"].max() > 0.5 and r["weights_sum"].min() < 0.05
+
+
 @pytest.mark.parametrize("tag,guide", [("guide", True), ("noguide", False)])
 def test_warped_render_vs_reference_golden(env, tag, guide):
     from tests.test_oracle_golden import check_warp_render_vs_golden
