@@ -254,10 +254,10 @@ constexpr uint32_t RING = 512;      // per-wave ring of faces that passed the di
 // usable cell (outside both grids, overflow) take the full bounding pass.
 constexpr int GRID_LEVELS = 2;
 #ifndef AC_LVL0_LOG2
-#define AC_LVL0_LOG2 19
+#define AC_LVL0_LOG2 17
 #endif
 #ifndef AC_LVL1_LOG2
-#define AC_LVL1_LOG2 17
+#define AC_LVL1_LOG2 16
 #endif
 constexpr uint32_t LVL_CELLS[GRID_LEVELS] = { 1u << AC_LVL0_LOG2, 1u << AC_LVL1_LOG2 };     // capacity in cells
 constexpr uint32_t LVL_K[GRID_LEVELS] = { 64, 192 };                    // listed tiles per cell
