@@ -111,6 +111,7 @@ _SIGS = {
     "ac_warp_samples": ([vp, vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp, vp, vp, vp, vp], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
+FIELD_PREPARED_BYTES = 98304          # AC_FIELD_PREPARED_BYTES of include/avatarcraft_hip.h
 
 
 def lib():

@@ -54,7 +54,16 @@ constexpr int FE_SLAB = 6 * 8 * 64;                        // hash features of t
 constexpr int OFF_W1H = OFF_WAVE;                // [4 tiles][64 lanes][4 dwords]
 constexpr int OFF_W1L = OFF_W1H + 4 * 64 * 4;
 constexpr int OFF_W1C = OFF_W1L + 4 * 64 * 4;    // [3 axes][64 units]
-constexpr int OFF_RWAVE = OFF_W1C + 3 * 64;      // per-wave slabs of the renderer
+// ... and the colour network in split bf16 (fast precision): 14 A-fragments [64 lanes][4 dwords] (layer 1: 4 output tiles; layer 2: 4 tiles x 2 k-steps
+// of 32; layer 3: 2 k-steps), hi and lo parts.  They OVERLAY the fp32 colour fragments [OFF_C1F, OFF_B1) -- 14 hi + the first 12 lo fill it exactly --
+// and the last two lo fragments (layer 3) sit behind W1C.
+constexpr int CF_FRAGS = 14, CF_FRAG = 64 * 4;
+constexpr int OFF_CFH = OFF_C1F;                            // hi fragments 0..13
+constexpr int OFF_CFL = OFF_C1F + CF_FRAGS * CF_FRAG;       // lo fragments 0..11
+constexpr int OFF_C3L = OFF_W1C + 3 * 64;                   // lo fragments 12, 13
+static_assert(OFF_CFL + 12 * CF_FRAG == OFF_B1, "the bf16 colour fragments fill the fp32 colour region exactly");
+constexpr int OFF_RWAVE = OFF_C3L + 2 * CF_FRAG;  // per-wave slabs of the renderer
+constexpr int CF_OVERLAY = OFF_B1 - OFF_C1F;      // floats of the overlay: the prepared image keeps it behind the exact image
 // per-wave slab of the renderer: the final z values (zs0) + ONE region that holds the up-sampling state (second z buffer, the two sdf
 // buffers, cdf, new samples) until the sampling of the ray is finished and the finite-difference feature slab afterwards
 constexpr int UPS_FLOATS = MAXT + 2 * MAXT + MAXT + 32;              // zs1[128], sd[2][128], cdf[128], znew[16] + pad
@@ -242,6 +251,47 @@ __device__ __forceinline__ void fill_lds_fast(float *lds, const RenderArgs &a)
         lw[W1H + e] = hi2; lw[W1L + e] = lo2;
     }
     for (int e = threadIdx.x; e < 3 * 64; e += blockDim.x) lds[W1C + e] = a.W1[(e & 63) * 35 + (e >> 6)];
+}
+
+// colour network, fast precision.  B operand of v_mfma_f32_16x16x32_bf16: lane (sample n, group g) supplies k = 8g .. 8g+7; the eight slots of a lane
+// are values it already holds, so no data moves between lanes:
+//   layer 1: slots 0..3 = sdf_out[4g + i] (the SDF network's output rows of this lane; row 0, the sdf itself, gets weight 0), slots 4..6 = x (g = 0) or
+//            the normal (g = 1), everything else 0;
+//   layer 2 / 3, k-step s: slots i = the lane's rows r = i & 3 of the previous layer's output tiles 2s + (i >> 2), i.e. units 16 (2s + (i >> 2)) + 4g + r.
+// The weights (A operand, lane (row m, group g)) are permuted to match and split hi + lo by round-to-nearest; the activations are split by
+// truncation (split8_bf16); three of the four partial products are formed.  Weight of fragment f, lane l, slot i:
+__device__ __forceinline__ float color_fast_weight(const RenderArgs &a, int f, int l, int i)
+{
+    const int m = l & 15, g = l >> 4;
+    if (f < 4) {                                                          // layer 1, output tile f
+        const int u = 16 * f + m;
+        if (i < 4) { const int o = 4 * g + i; return o == 0 ? 0.0f : a.Wc1[u * 21 + 5 + o]; }
+        if (i < 7 && g < 2) return a.Wc1[u * 21 + 3 * g + (i - 4)];
+        return 0.0f;
+    }
+    const int s = (f - 4) & 1, unit = 16 * (2 * s + (i >> 2)) + 4 * g + (i & 3);
+    if (f < 12) return a.Wc2[(16 * ((f - 4) >> 1) + m) * 64 + unit];    // layer 2, output tile (f - 4) / 2, k-step s
+    return m < 3 ? a.Wc3[m * 64 + unit] : 0.0f;                           // layer 3, k-step s
+}
+template <bool OVERLAY, bool TAIL>
+__device__ __forceinline__ void fill_lds_color_fast(float *lds, const RenderArgs &a)
+{
+    uint32_t *lw = reinterpret_cast<uint32_t *>(lds);
+    for (int e = threadIdx.x; e < CF_FRAGS * CF_FRAG; e += blockDim.x) {
+        const int q = e & 3, l = (e >> 2) & 63, f = e >> 8;
+        if (!(f < 12 ? OVERLAY : (OVERLAY || TAIL))) continue;
+        uint32_t hi2 = 0, lo2 = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float w = color_fast_weight(a, f, l, 2 * q + h);
+            const uint32_t hb = bf16_rne_bits(w);
+            const uint32_t lb = bf16_rne_bits(w - __uint_as_float(hb << 16));
+            hi2 |= hb << (16 * h); lo2 |= lb << (16 * h);
+        }
+        if (OVERLAY) lw[OFF_CFH + e] = hi2;
+        if (f < 12) { if (OVERLAY) lw[OFF_CFL + e] = lo2; }
+        else if (TAIL) lw[OFF_C3L + (e - 12 * CF_FRAG)] = lo2;
+    }
 }
 
 // ---- hash-grid features of this lane's 4 levels (HashEncoder.forward + kernel_grid) -------------------
@@ -714,6 +764,60 @@ __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int la
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C3F + kk * 64 + lane], h2[kk >> 2][kk & 3], acc, 0, 0, 0);
+    rgb[0] = dv_sigmoid(acc[0]); rgb[1] = dv_sigmoid(acc[1]); rgb[2] = dv_sigmoid(acc[2]);
+}
+
+// the same network in split bf16 (fast precision; fragments of fill_lds_color_fast): 42 MFMA of 16 clocks instead of 104 of 32
+__device__ __forceinline__ f32x4 cf_mma(const float *__restrict__ lds, int f, int lane, const u32x4 &bh, const u32x4 &bl, f32x4 acc)
+{
+    const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + OFF_CFH + (f * 64 + lane) * 4));
+    const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + (f < 12 ? OFF_CFL + f * CF_FRAG : OFF_C3L + (f - 12) * CF_FRAG) + lane * 4));
+    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void color_tile_fast(const float *__restrict__ lds, int lane, float px, float py, float pz,
+                                                float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3])
+{
+    const int g = lane >> 4;
+    u32x4 bh, bl;
+    {
+        const float in[8] = { sdfout[0], sdfout[1], sdfout[2], sdfout[3], g == 0 ? px : (g == 1 ? nx : 0.0f), g == 0 ? py : (g == 1 ? ny : 0.0f),
+                              g == 0 ? pz : (g == 1 ? nz : 0.0f), 0.0f };
+        split8_bf16(in, bh, bl);
+    }
+    f32x4 h1[4], h2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 acc = cf_mma(lds, t, lane, bh, bl, f32x4{ 0.0f, 0.0f, 0.0f, 0.0f });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+        h1[t] = acc;
+    }
+    u32x4 ch[2], cl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float in[8] = { h1[2 * s][0], h1[2 * s][1], h1[2 * s][2], h1[2 * s][3], h1[2 * s + 1][0], h1[2 * s + 1][1], h1[2 * s + 1][2], h1[2 * s + 1][3] };
+        split8_bf16(in, ch[s], cl[s]);
+    }
+#pragma unroll
+    for (int to = 0; to < 4; ++to) {
+        f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = cf_mma(lds, 4 + 2 * to + s, lane, ch[s], cl[s], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+        h2[to] = acc;
+    }
+    f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float in[8] = { h2[2 * s][0], h2[2 * s][1], h2[2 * s][2], h2[2 * s][3], h2[2 * s + 1][0], h2[2 * s + 1][1], h2[2 * s + 1][2], h2[2 * s + 1][3] };
+        u32x4 dh, dl;
+        split8_bf16(in, dh, dl);
+        acc = cf_mma(lds, 12 + s, lane, dh, dl, acc);
+    }
     rgb[0] = dv_sigmoid(acc[0]); rgb[1] = dv_sigmoid(acc[1]); rgb[2] = dv_sigmoid(acc[2]);
 }
 

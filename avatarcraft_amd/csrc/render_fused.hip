@@ -30,22 +30,30 @@
 
 namespace {
 
+#ifndef AC_FAST_COLOR
+#define AC_FAST_COLOR 1            // fast precision: the colour network in split bf16 too (0: only layer 1 of the finite-difference evaluations)
+#endif
 template <int MODE, bool FAST>
 __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 {
+    constexpr bool FC = FAST && AC_FAST_COLOR;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (a.prepared) {
         // the weights arrive in LDS order (ac_field_prepare): a linear copy, 16 bytes per lane and trip, instead of ~27 dependent
         // gather-and-place trips per thread in each of the 512 workgroups of a launch; only the per-launch sampling tables are added
         const float4 *src = reinterpret_cast<const float4 *>(a.prepared);
         float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int e = threadIdx.x; e < OFF_RWAVE / 4; e += blockDim.x) dst[e] = src[e];
+        // (fast precision: the colour region holds the split-bf16 fragments, which the image keeps behind the exact one)
+        for (int e = threadIdx.x; e < OFF_RWAVE / 4; e += blockDim.x)
+            dst[e] = src[(FC && 4 * e >= OFF_C1F && 4 * e < OFF_B1) ? e + (OFF_RWAVE - OFF_C1F) / 4 : e];
         __syncthreads();
         for (int e = threadIdx.x; e < 64; e += blockDim.x) lds[OFF_LIN + e] = e < a.T0 ? a.lin_z[e] : 0.0f;
         for (int e = threadIdx.x; e < 16; e += blockDim.x) lds[OFF_LIN + 64 + e] = a.lin_u ? a.lin_u[e] : 0.0f;
     } else {
-        fill_lds(lds, a);
+        fill_lds_sdf(lds, a);
         if constexpr (FAST) fill_lds_fast(lds, a);
+        if constexpr (FC) fill_lds_color_fast<true, true>(lds, a);
+        else fill_lds_color(lds, a);
     }
     __syncthreads();
 
@@ -354,7 +362,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
             const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
             float rgb[3];
-            color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+            if constexpr (FC) color_tile_fast(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+            else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
             AC_TICK(5)
             // NeuS alpha :219-248
             const float sdf0 = oc[0];
@@ -462,8 +471,13 @@ __global__ __launch_bounds__(BLOCK) void field_prepare_kernel(const RenderArgs a
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fill_lds(lds, a);
     fill_lds_fast(lds, a);
+    fill_lds_color_fast<false, true>(lds, a);                 // the two fragments outside the overlay
     __syncthreads();
     for (int e = threadIdx.x; e < OFF_RWAVE; e += blockDim.x) image[e] = lds[e];
+    __syncthreads();
+    fill_lds_color_fast<true, false>(lds, a);                 // the overlay of the colour region (fast precision), kept behind the exact image
+    __syncthreads();
+    for (int e = threadIdx.x; e < CF_OVERLAY; e += blockDim.x) image[OFF_RWAVE + e] = lds[OFF_C1F + e];
 }
 
 // gradient_error: fixed-order reduction of per-ray partials (oracle: orc_eikonal_reduce)
@@ -675,7 +689,7 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
     return ac::check_launch("render_rays_warped");
 }
 
-static_assert(OFF_RWAVE * sizeof(float) <= AC_FIELD_PREPARED_BYTES, "the prepared image fits its buffer");
+static_assert((OFF_RWAVE + CF_OVERLAY) * sizeof(float) <= AC_FIELD_PREPARED_BYTES && OFF_C1F % 4 == 0 && OFF_B1 % 4 == 0 && OFF_RWAVE % 4 == 0, "the prepared image fits its buffer");
 AC_API int ac_field_prepare(const ac_field *field, void *prepared, ac_stream_t stream)
 {
     if (!prepared) { ac::set_error("field_prepare: NULL buffer"); return AC_ERR_BAD_ARG; }

@@ -58,7 +58,7 @@ class Field:
         """ac_field_prepare: lay the weights out once in the order the renderer keeps them in LDS (its 512 workgroups per launch then copy
         the image linearly).  Call again whenever a parameter tensor of this Field is modified in place."""
         if self.prepared is None:
-            self.prepared = torch.empty(65536, dtype=torch.uint8, device=self.device)
+            self.prepared = torch.empty(L.FIELD_PREPARED_BYTES, dtype=torch.uint8, device=self.device)
         self.c.prepared = None
         L.check(L.lib().ac_field_prepare(C.byref(self.c), self.prepared.data_ptr(), L.current_stream(self.device)), "field_prepare")
         self.c.prepared = self.prepared.data_ptr()

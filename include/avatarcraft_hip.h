@@ -132,7 +132,7 @@ typedef struct ac_field {
                                  copy 52 KB linearly instead of re-deriving the layout from the row-major matrices, 512 times
                                  per launch).  NULL = derive it in every workgroup.  Must be re-prepared when a parameter changes. */
 } ac_field;
-#define AC_FIELD_PREPARED_BYTES 65536
+#define AC_FIELD_PREPARED_BYTES 98304
 /* fills `prepared` (device, AC_FIELD_PREPARED_BYTES) from the other members of `field`; enqueue on `stream` before the launches that use it */
 int ac_field_prepare(const ac_field *field, void *prepared, ac_stream_t stream);
 
