@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT; O=gpurun_out/j31; mkdir -p $O
+timeout 1200 python -m pytest tests -m gpu -q --maxfail=15 -p no:cacheprovider --durations=5 > $O/pytest.log 2>&1; echo "pytest rc $?" | tee $O/pytest.rc
+tail -9 $O/pytest.log | head -8; grep -n "^E  " $O/pytest.log | cut -c1-300 | head -20
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+bash tools/prof_r02.sh r02c 2>&1 | tail -22 | cut -c1-200
