@@ -47,27 +47,14 @@ template <> struct Feat<8> { float v[8]; __device__ void load(const float *p) {
     float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; } };
 
-#ifndef AC_HASH_XCD
-#define AC_HASH_XCD 1
-#endif
 template <uint32_t D, uint32_t C>
 __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__ inputs, const float *__restrict__ grid,
                                                        float *__restrict__ outputs, uint32_t B, ac::LevelTable lt,
                                                        int calc_grad, float *__restrict__ dy_dx)
 {
-    // Level -> XCD affinity (1-D launch, L % 8 == 0): workgroup w runs on XCD w % 8, and every XCD has its own 4 MB L2 -- exactly one hashed level
-    // of the default table.  XCD k therefore works through levels k, k + 8, ... one after the other (all point chunks of a level before the next), so
-    // that the level it is gathering from stays L2 resident instead of all 16 levels (49 MB) competing for every L2.
-    uint32_t level = blockIdx.y, chunk = blockIdx.x;
-    const uint32_t L = lt.L;
-#if AC_HASH_XCD
-    if (gridDim.y == 1 && L > 1) {
-        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, chunks = (B + blockDim.x - 1) / blockDim.x;
-        level = xcd + 8u * (slot / chunks); chunk = slot % chunks;
-    }
-#endif
-    const uint32_t b = chunk * blockDim.x + threadIdx.x;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const uint32_t level = blockIdx.y, L = lt.L;
     const float scale = lt.scale[level];
     const uint32_t stride1 = lt.stride1[level], size = lt.size[level], hashed = lt.hashed[level], mask = lt.pow2mask[level];
     const float *g = grid + (size_t)lt.offset[level] * C;
@@ -264,7 +251,6 @@ AC_API int ac_hash_encode_forward(const float *inputs, const float *embeddings, 
     if (!inputs || !embeddings || !outputs || (calc_grad_inputs && !dy_dx)) { ac::set_error("hash_encode_forward: NULL buffer"); return AC_ERR_BAD_ARG; }
     ac::LevelTable lt; ac::make_level_table(lt, L, D, S, H, offsets_host);
     dim3 grid((B + 255) / 256, L);
-    if (AC_HASH_XCD && L % 8 == 0) grid = dim3(((B + 255) / 256) * L, 1);        // level -> XCD affinity (hash_fwd_kernel)
     hipStream_t st = (hipStream_t)stream;
     int rc = (D == 2) ? launch_fwd<2>(C, grid, st, inputs, embeddings, outputs, B, lt, calc_grad_inputs, dy_dx)
                       : launch_fwd<3>(C, grid, st, inputs, embeddings, outputs, B, lt, calc_grad_inputs, dy_dx);

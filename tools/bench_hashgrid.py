@@ -4,10 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np, torch
 from avatarcraft_amd import _lib as L
 if os.environ.get('AC_LIB_PATH'): L.LIB_PATH = os.environ['AC_LIB_PATH']
-from avatarcraft_amd.encoder import get_encoder
+from avatarcraft_amd.encoder.hashencoder.hashgrid import HashEncoder
 dev = "cuda:0"
-enc, _ = get_encoder("hashgrid", input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048)
-enc = enc.to(dev)
+enc = HashEncoder(3, 16, 2, 1.381912879967776, 16, 19, 2048).to(dev)          # the default NeRFNetwork's grid
 with torch.no_grad():
     enc.embeddings.uniform_(-0.1, 0.1)
 def timeit(fn, n=20):
