@@ -27,7 +27,10 @@ constexpr int TW = 4;                              // waves per workgroup of the
 constexpr int TBLOCK = TW * 64;
 constexpr int FW = 8;                              // waves per workgroup of the forward SDF query (224 VGPRs: two waves per SIMD, like the renderer)
 constexpr int FBLOCK = FW * 64;
-constexpr int TLD = 17;                            // padded leading dimension of the transpose slabs
+#ifndef AC_TLD
+#define AC_TLD 17
+#endif
+constexpr int TLD = AC_TLD;                         // padded leading dimension of the transpose slabs
 // The SDF-query backward never evaluates the colour network: the 26 KB the shared layout reserves for its fragments hold this kernel's
 // own ones instead (fill_lds_sdf leaves that region alone).
 constexpr int OFF_W2T = OFF_C1F;                   // [4 tiles][4 ksteps][64]   fp32 A fragments of W2^T (the centre evaluation's ga = W2^T d2)

@@ -341,6 +341,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
+    # the same launches in the OTHER arithmetic mode, outside the timed region (rank 0 reports it next to the headline: `exact` is bit-identical to the
+    # CPU oracle, `fast` keeps sample positions / indices / sdf bit-identical and moves pixels by ~1e-6)
+    other = "exact" if a.precision == "fast" else "fast"
+    ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for k in range(min(a.warmup, 2)):
+        nsr_ops.render_rays(field, ro_t[:RAYS_PER_BATCH], rd_t[:RAYS_PER_BATCH], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=outs[0], precision=other)
+    for k in range(a.steps):
+        b = k % nb
+        sl = slice(b * RAYS_PER_BATCH, (b + 1) * RAYS_PER_BATCH)
+        nsr_ops.render_rays(field, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=outs[b], events=ev2[k], precision=other)
+    torch.cuda.synchronize()
+    other_ms = float(np.mean([s.elapsed_time(e) for s, e in ev2]))
 
     sds = None
     if a.sds_steps > 0:
@@ -376,7 +388,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "render_rays_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_RAY * RAYS_PER_BATCH,
-                         "mfma_f32_tflops": FLOP_PER_RAY * RAYS_PER_BATCH / (kern_ms * 1e-3) / 1e12, "mfma_f32_peak_tflops": 157.3},
+                         "mfma_f32_tflops": FLOP_PER_RAY * RAYS_PER_BATCH / (kern_ms * 1e-3) / 1e12, "mfma_f32_peak_tflops": 157.3,
+                         "other_precision": {"precision": other, "kernel_ms": other_ms, "rays_per_s_per_gpu": RAYS_PER_BATCH / (other_ms * 1e-3),
+                                             "frac": BYTES_PER_RAY * RAYS_PER_BATCH / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
         if sds is not None:
             res["sds_step"] = sds

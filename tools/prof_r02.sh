@@ -8,7 +8,8 @@ i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_WR" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_SMEM"; do
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $grp --output-format csv -d $O/g$i -o p -- $B > $O/g$i.log 2>&1 || echo "group $i failed: $(tail -2 $O/g$i.log | cut -c1-200)"
 done
