@@ -384,7 +384,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "render_canonical 256x256, hash-grid Instant-NSR, 64+64 samples/ray, 16 x 4096-ray batches, eval, 1 view per rank",
                        "rays_per_step": RAYS_PER_BATCH, "table_mb": round(table.nbytes / 1e6, 2), "parallelism": f"dp{world} (independent views, no collective)",
-                       "precision": a.precision},
+                       "precision": a.precision,
+                       "precision_note": ("fast: fp32 everywhere except layer 1 of the six finite-difference SDF evaluations (a split-bf16, hi + lo, 3-product "
+                                          "correction of the exact fp32 centre evaluation) and the colour network (split-bf16 x 3); sample positions, indices "
+                                          "and sdf bit-identical to exact mode, pixels within 4e-6; exact: every product an fp32 fma, GPU == CPU oracle bit "
+                                          "for bit; the other mode's timing is in roofline.other_precision")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "render_rays_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_RAY * RAYS_PER_BATCH,
