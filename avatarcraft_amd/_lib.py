@@ -32,11 +32,11 @@ class ac_render_opts(C.Structure):
 class ac_render_out(C.Structure):
     _fields_ = [("image", vp), ("weights_sum", vp), ("depth", vp), ("normal_map", vp), ("eik", vp), ("z_vals", vp),
                 ("weights", vp), ("alpha", vp), ("color", vp), ("sdf", vp), ("gradient", vp), ("ss_inds", vp),
-                ("sort_index", vp), ("sdf_out16", vp), ("pts", vp)]
+                ("sort_index", vp), ("sdf_out16", vp), ("pts", vp), ("feat7", vp)]
 
 
 class ac_core_saved(C.Structure):
-    _fields_ = [("z_vals", vp), ("pts", vp), ("sdf", vp), ("sdf_out16", vp), ("gradient", vp), ("color", vp), ("eik_den", vp)]
+    _fields_ = [("z_vals", vp), ("pts", vp), ("sdf", vp), ("sdf_out16", vp), ("gradient", vp), ("color", vp), ("eik_den", vp), ("feat7", vp)]
 
 
 class ac_core_upstream(C.Structure):

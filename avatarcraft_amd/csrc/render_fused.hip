@@ -302,6 +302,15 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             AC_TICK(7)
             float fe0[4][2];
             encode_stencil(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
+            if (a.out.feat7) {                                     // training render: keep the 7 x 8 features of this lane (the backward streams them back)
+                const size_t nt4 = (size_t)a.n_rays * T * 4, at = ((size_t)ray * T + i) * 4 + g;
+#pragma unroll
+                for (int q_ = 0; q_ < 8; ++q_) a.out.feat7[q_ * nt4 + at] = fe0[q_ >> 1][q_ & 1];
+#pragma unroll 1
+                for (int e = 0; e < 6; ++e)
+#pragma unroll
+                    for (int q_ = 0; q_ < 8; ++q_) a.out.feat7[((e + 1) * 8 + q_) * nt4 + at] = fsl[(e * 8 + q_) * 64 + lane];
+            }
             AC_TICK(3)
             const float pc0 = sel4(g, px, py, pz, 0.0f);
             f32x4 oc = { 0.0f, 0.0f, 0.0f, 0.0f };

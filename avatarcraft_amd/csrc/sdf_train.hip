@@ -184,9 +184,13 @@ __device__ __forceinline__ void fill_lds_bwd(float *lds, const RenderArgs &a)
     fill_lds_fast<OFF_BW1H, OFF_BW1L, OFF_BW1C>(lds, a);
 }
 
+// SAVED: the features of the seven stencil points come from the forward launch (ac_render_out.feat7, [7][8][B][4] in this kernel's lane order) as 56
+// coalesced loads per lane instead of being gathered from the table again (index arithmetic + ~100 scattered 8-byte loads per lane and tile)
+template <bool SAVED>
 __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ g_out,
                                                                  const float *__restrict__ g_grad, uint32_t B, float eps,
-                                                                 float *__restrict__ gfeat, float *__restrict__ partials)
+                                                                 float *__restrict__ gfeat, float *__restrict__ partials,
+                                                                 const float *__restrict__ feat7)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fill_lds_sdf(lds, a);
@@ -224,7 +228,18 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
         float gg[3] = { g_grad[3 * (size_t)bb], g_grad[3 * (size_t)bb + 1], g_grad[3 * (size_t)bb + 2] };
         if (!live) { go = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; gg[0] = gg[1] = gg[2] = 0.0f; }
         float fe0[4][2];
-        encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
+        if constexpr (SAVED) {
+            const size_t b4 = (size_t)B * 4, at = (size_t)bb * 4 + g;
+            float v[56];
+#pragma unroll
+            for (int k = 0; k < 56; ++k) v[k] = feat7[k * b4 + at];
+#pragma unroll
+            for (int q_ = 0; q_ < 8; ++q_) fe0[q_ >> 1][q_ & 1] = v[q_];
+#pragma unroll
+            for (int k = 8; k < 56; ++k) fsl[(k - 8) * 64 + lane] = v[k];
+        } else {
+            encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
+        }
         const float pc0 = sel4(g, px, py, pz, 0.0f);
         Acc4 h10;                                               // layer 1 of the centre evaluation (set at e == 0)
 #pragma unroll
@@ -910,8 +925,8 @@ AC_API size_t ac_sdf_stencil_backward_scratch(uint32_t B)
     return (size_t)train_grid(B) * TW * NPART * sizeof(float);
 }
 
-AC_API int ac_sdf_stencil_backward(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
-                                   float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream)
+static int sdf_stencil_backward_impl(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
+                                     float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream, const float *feat7)
 {
     if (!gparams) { ac::set_error("sdf_stencil_backward: NULL gparams"); return AC_ERR_BAD_ARG; }
     if (B == 0) { hipMemsetAsync(gparams, 0, NPART * sizeof(float), (hipStream_t)stream); return AC_OK; }
@@ -921,14 +936,25 @@ AC_API int ac_sdf_stencil_backward(const ac_field *field, const float *x, const 
     RenderArgs a{};
     if (int rc = prep_args(a, field, bound, eps)) return rc;
     const size_t lds_bytes = BWD_LDS_FLOATS * sizeof(float);
-    static uint64_t seen = 0;
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(sdf_stencil_bwd_kernel), lds_bytes);
+    static uint64_t seen = 0, seen_s = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(sdf_stencil_bwd_kernel<false>), lds_bytes);
+    ac::allow_dynamic_lds(seen_s, reinterpret_cast<const void *>(sdf_stencil_bwd_kernel<true>), lds_bytes);
     const uint32_t blocks = train_grid(B);
-    hipLaunchKernelGGL(sdf_stencil_bwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
-                       static_cast<float *>(scratch));
+    if (feat7)
+        hipLaunchKernelGGL(sdf_stencil_bwd_kernel<true>, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
+                           static_cast<float *>(scratch), feat7);
+    else
+        hipLaunchKernelGGL(sdf_stencil_bwd_kernel<false>, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
+                           static_cast<float *>(scratch), feat7);
     hipLaunchKernelGGL(sdf_partials_reduce_kernel, dim3((NPART + 63) / 64), dim3(1024), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
                        blocks * TW, gparams);
     return ac::check_launch("sdf_stencil_backward");
+}
+
+AC_API int ac_sdf_stencil_backward(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
+                                   float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream)
+{
+    return sdf_stencil_backward_impl(field, x, g_out16, g_grad, B, bound, eps, gfeat, gparams, scratch, scratch_bytes, stream, nullptr);
 }
 
 AC_API int ac_color_forward(const ac_field *field, const float *x, const float *normal, const float *sdf16, uint32_t B, float *rgb, ac_stream_t stream)
@@ -1070,8 +1096,8 @@ AC_API int ac_render_core_backward(const ac_field *field, const ac_render_opts *
     if (int rc = ac_color_backward(field, sv->pts, nrm, sv->sdf_out16, g_col, B, g_nrm_b, g_s16, gr->g_color_params, sb + l.part_col,
                                    ac_color_backward_scratch(B), stream)) return rc;
     hipLaunchKernelGGL(core_mid_kernel, dim3(eb), dim3(256), 0, st, sv->gradient, sv->pts, g_sdf, g_nrm_a, g_nrm_b, up->g_eik, sv->eik_den, B, g_s16, g_grad);
-    if (int rc = ac_sdf_stencil_backward(field, sv->pts, g_s16, g_grad, B, op->bound, op->fd_eps, gfeat, gr->g_sdf_params, sb + l.part_sdf,
-                                         ac_sdf_stencil_backward_scratch(B), stream)) return rc;
+    if (int rc = sdf_stencil_backward_impl(field, sv->pts, g_s16, g_grad, B, op->bound, op->fd_eps, gfeat, gr->g_sdf_params, sb + l.part_sdf,
+                                           ac_sdf_stencil_backward_scratch(B), stream, sv->feat7)) return rc;
     if (int rc = ac_hash_stencil_backward(gfeat, sv->pts, field->offsets, gr->g_table, B, 2, 16, field->S, field->H, op->fd_eps, op->bound,
                                           l.hash_bytes ? sb + l.hash : nullptr, l.hash_bytes, stream)) return rc;
     return ac::check_launch("render_core_backward");

@@ -8,6 +8,7 @@ libavatarcraft_hip.so; there is no eager fallback.
 import ctypes as C
 import math
 
+import os
 import torch
 
 from . import _lib as L
@@ -141,6 +142,8 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     if train_extras:
         o.sdf_out16 = buf("sdf_out16", (N, T, 16)).data_ptr()
         o.pts = buf("pts", (N, T, 3)).data_ptr()
+        if SAVE_STENCIL_FEATURES:
+            o.feat7 = buf("feat7", (7, 8, N * T, 4)).data_ptr()
     if debug_indices:
         o.ss_inds = buf("ss_inds", (N, max(nup, 1), 16), torch.int32).data_ptr()
         o.sort_index = buf("sort_index", (N, max(nup, 1), 128), torch.int32).data_ptr()
@@ -251,6 +254,11 @@ def free_scratch():
     BK._SCRATCH.clear()
 
 
+# a training render keeps the hash features of every sample's 7-point stencil (0.9 KB per sample) so that the backward streams them back instead of
+# gathering them again; AC_NO_FEAT7=1 restores the re-gathering backward (A/B timing)
+SAVE_STENCIL_FEATURES = os.environ.get("AC_NO_FEAT7", "0") != "1"
+
+
 class _RenderCore(torch.autograd.Function):
     """NeRFRenderer.run with gradients (reference models/instant_nsr.py:133-299 under torch.enable_grad) as ONE operator:
     forward  = the fused renderer itself (ac_render_rays: sampling + render core, the launch an inference render makes) with its
@@ -272,7 +280,8 @@ class _RenderCore(torch.autograd.Function):
         ctx.has_bg = bg is not None
         # outputs among the saved tensors (z_vals, color) must go through save_for_backward (no reference cycle through ctx)
         ctx.save_for_backward(out["z_vals"], out["pts"], out["sdf"], out["sdf_out16"], out["gradient"], out["color"], out["eik_res"], rays_o, rays_d,
-                              bg if bg is not None else rays_o)
+                              bg if bg is not None else rays_o, out["feat7"] if "feat7" in out else rays_o)
+        ctx.has_feat = "feat7" in out
         ctx.table = table
         ctx.inv_s_shape = inv_s.shape
         ctx.mark_non_differentiable(out["weights"], out["alpha"], out["color"], out["z_vals"])
@@ -282,7 +291,7 @@ class _RenderCore(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_image, g_wsum, g_depth, g_nmap, g_eik, *_unused):
         field = ctx.field
-        z_vals, pts, sdf, sdf16, gradient, color, eik_res, rays_o, rays_d, bg = ctx.saved_tensors
+        z_vals, pts, sdf, sdf16, gradient, color, eik_res, rays_o, rays_d, bg, feat7 = ctx.saved_tensors
         if not ctx.has_bg:
             bg = None
         N, T = z_vals.shape
@@ -296,7 +305,7 @@ class _RenderCore(torch.autograd.Function):
         g_col_p = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)
         g_invs = torch.empty(N, dtype=_F32, device=dev)
         sv = L.ac_core_saved(z_vals.data_ptr(), pts.data_ptr(), sdf.data_ptr(), sdf16.data_ptr(), gradient.data_ptr(), color.data_ptr(),
-                             eik_res[1:].data_ptr())
+                             eik_res[1:].data_ptr(), feat7.data_ptr() if ctx.has_feat else None)
         upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
         gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
         scratch, need = core_scratch(field, N, T, dev)
@@ -408,7 +417,7 @@ def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, 
     g_col_p = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)
     g_invs = torch.empty(N, dtype=_F32, device=dev)
     sv = L.ac_core_saved(z_vals.data_ptr(), out["pts"].data_ptr(), out["sdf"].data_ptr(), out["sdf_out16"].data_ptr(), out["gradient"].data_ptr(),
-                         out["color"].data_ptr(), out["eik_res"][1:].data_ptr())
+                         out["color"].data_ptr(), out["eik_res"][1:].data_ptr(), L.ptr(out.get("feat7") if hasattr(out, "get") else None))
     upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
     gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
     scratch, need = core_scratch(field, N, T, dev)

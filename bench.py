@@ -74,7 +74,8 @@ SDS_BYTES_LAUNCHED = {
     "render_val (no-grad render of net_style)": RAYS_PER_BATCH * BYTES_PER_RAY,
     "grad render forward (the same fused launch, per-sample outputs kept)": RAYS_PER_BATCH * BYTES_PER_RAY,
     "net_gt render (frozen avatar, opacity target)": RAYS_PER_BATCH * BYTES_PER_RAY,
-    "sdf_stencil_bwd (re-gather of the 7 stencil points of every sample)": RAYS_PER_BATCH * SAMPLES * 7 * 1024,
+    "stencil features of the grad render: written once by the forward, streamed back by sdf_stencil_bwd (7 points x 32 floats per sample, each way) "
+    "-- the re-gather they replace would be 3.758 GB": 2 * RAYS_PER_BATCH * SAMPLES * 7 * 32 * 4,
     "table-gradient scatter (hash_stencil_bwd_binned + bucket_accumulate)": RAYS_PER_BATCH * SAMPLES * 7 * 2048,
 }
 # ... and SURVEY 8(d)'s contract figure for the reference's schedule (3 forward renders + 3 backward passes of 7, 6 and 7 evaluations per sample)
@@ -141,9 +142,9 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
                         "traffic": None},
            "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if dist is not None else 0,
            "grad_allreduce_ms": round(phases.get("grad_allreduce", 0.0), 4),
-           "core": "training render = ONE operator: forward = ac_render_rays (the inference launch, per-sample outputs kept), backward = "
-                   "ac_render_core_backward (compositing, colour MLP, normalisation + eikonal, fused SDF query with recomputation, binned two-pass "
-                   "table scatter); torch: weight norm, the three loss terms, fused Adam"}
+           "core": "no autograd graph: forward = ac_render_rays (the inference launch, per-sample outputs and stencil features kept), upstream gradients "
+                   "written down (ac_sds_upstream), backward = ac_render_core_backward (compositing, colour MLP, normalisation + eikonal, fused SDF "
+                   "query on the kept features, binned two-pass table scatter) + ac_param_grads (weight norm, biases, variance); torch: noise, fused Adam"}
     return res, (net, net_gt)
 
 

@@ -177,6 +177,9 @@ typedef struct ac_render_out {
     int32_t *sort_index;      /* [N, upsample_steps/16, 128] sort permutation of cat_z_vals, -1 pad */
     float *sdf_out16;         /* [N,T,16] forward_sdf at the mid points: sdf + the 15 geometry features   */
     float *pts;               /* [N,T,3]  the mid points themselves (clamped to the bound)                */
+    float *feat7;             /* [7,8,N*T,4] the hash features of the 7 points of every sample's finite-difference stencil, in the kernel's own
+                               * lane order (evaluation e, slot 2q + c, sample, level group g: level 4q + g, channel c): what the backward would
+                               * otherwise gather again (0.9 KB per sample; training renders only)                                               */
 } ac_render_out;
 
 /* rays_o, rays_d [N,3]; bg [N,3] or NULL (= white, bg_color None -> 1); noise [N,num_steps] U[0,1)
@@ -315,6 +318,7 @@ int ac_composite_backward(const float *rays_o, const float *rays_d, const float 
 typedef struct ac_core_saved {
     const float *z_vals, *pts, *sdf, *sdf_out16, *gradient, *color;      /* per-sample outputs of the forward launch */
     const float *eik_den;                                                 /* result2[1] of ac_eikonal_reduce2          */
+    const float *feat7;                                                   /* ac_render_out.feat7 of the forward, or NULL: gather again */
 } ac_core_saved;
 typedef struct ac_core_upstream { const float *g_image, *g_weights_sum, *g_depth, *g_normal_map, *g_eik; } ac_core_upstream;
 typedef struct ac_core_grads { float *g_table, *g_sdf_params, *g_color_params, *g_inv_s_per_ray; } ac_core_grads;
