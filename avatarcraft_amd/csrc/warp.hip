@@ -218,34 +218,27 @@ __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restri
 
 // ---- exact closest-face search with culling ---------------------------------------------------------------------------------
 // Per frame (ac_warp_accel_build): faces sorted along a Morton curve of their centroids (one workgroup, bitonic sort of
-// 16384 64-bit keys in 128 KB of LDS), cut into tiles of TILE_F faces with an oriented box (axis 0 = mean normal) and one
-// representative vertex.
-// Per sample (warp_samples_accel_kernel): one WAVE searches for one sample at a time -- lane = tile in the bounding pass
-// (bounds of all tiles in LDS), lane = face in the exact pass, so the lanes never diverge:
-//   1. ub = min over tiles of |p - representative vertex|^2          (a point of the mesh: upper bound of the answer)
-//   2. tiles whose oriented-box distance^2 <= bound (1 + 1e-9) are the candidates (a lower bound for every face inside)
-//   3. the faces of two candidate tiles at a time go through the same fp64 Ericson routine as the brute-force kernel; each lane
-//      keeps its own best (d2, face id), one wave reduction per sample, ties -> lowest face id (order independent).
-// A wave owns 64 consecutive samples: the search runs sample by sample, the result of sample j parks in lane j, and the
-// barycentric blend / 4x4 inverse epilogue runs lane-parallel for the 64 samples.  Bit-identical to warp_samples_kernel.
+// 16384 64-bit keys in 128 KB of LDS), cut into tiles of TILE_F faces with an oriented box (axis 0 = mean normal), four sub-boxes
+// (groups of 8 consecutive faces, in the tile's frame), a bounding disc per face and one representative vertex; then two cell
+// grids whose cells list the tiles that matter for any point inside them (below).
+// Per sample (warp_samples_accel_kernel): a wave owns 64 consecutive samples.  A sample's candidate tiles come from its cell's list
+// (or, without a cell, from a pass over all tile boxes) and the rest is a pipeline of packed LDS queues shared by the wave's samples:
+//   (sample, tile) -> sub-box test -> (sample, tile, group) -> disc test -> (sample, face) -> fp64 Ericson routine -> running minimum of the sample
+// with lanes = 16 pairs x 4 groups, 8 triples x 8 faces and 64 pairs respectively, so the lanes never diverge and every step is full.
+// Every test before the last is a conservative lower bound; the exact routine is the brute-force kernel's; ties -> lowest face id.
+// The barycentric blend / 4x4 inverse epilogue runs lane-parallel for the 64 samples.  Bit-identical to warp_samples_kernel.
 #ifndef AC_TILE_F
 #define AC_TILE_F 32
 #endif
-constexpr int TILE_F = AC_TILE_F;   // faces per tile; 16 was tried: twice the boxes to bound costs more than the smaller candidates save (6.0 vs 4.3 ms / 1 M samples)
+constexpr int TILE_F = AC_TILE_F;   // faces per tile (the pair encodings of the queues assume 32)
 constexpr int MAX_TILES = 16384 / TILE_F;
 constexpr int NIT = MAX_TILES / 64; // bounding-pass iterations of 64 lanes
-constexpr int GROUPS = 64 / TILE_F; // tiles tested per exact step
 constexpr int TPB = 256 / TILE_F;   // tiles per block of the tile builder
 constexpr uint32_t MAX_ACCEL_FACES = MAX_TILES * TILE_F;     // 16384
 constexpr int NB = 18;              // floats of bounds per tile
 #ifndef AC_WARP_WAVES
-#define AC_WARP_WAVES 4                // waves per SIMD the search kernel is compiled for (<= 128 VGPRs; 29.5 instead of 31.6 ms per posed frame)
+#define AC_WARP_WAVES 4                // waves per SIMD the search kernel is compiled for (<= 128 VGPRs)
 #endif
-#ifndef AC_WARP_STEPS
-#define AC_WARP_STEPS 4
-#endif
-constexpr int STEPS = AC_WARP_STEPS;            // trips of the face loop handle STEPS x GROUPS tiles
-constexpr uint32_t RING = 512;      // per-wave ring of faces that passed the disc test: < 64 left over + STEPS x 64 new ones per trip
 
 // Cell grids around the body (round 2): two axis-aligned grids -- a fine one hugging the mesh and a coarse one for the rest of the scene; every
 // cell knows, for ALL points inside it, a superset of the tiles that can hold their closest face (<= K of them, else the cell is marked OVERFLOW)

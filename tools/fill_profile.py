@@ -4,13 +4,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-csrc = os.path.join(ROOT, "avatarcraft_amd", "csrc")
-out = os.path.join(ROOT, "gpurun_out", "libac_fillprof.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
-srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "hash_stencil.hip",
-                                        "sdf_train.hip", "warp.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                       "-DAC_PROFILE_FILL", "-Wno-unused-result", "-o", out] + srcs + sys.argv[1:])
+out = os.path.join(ROOT, "tools", "_bin", "lib_fprof.so")           # python tools/build_variants.py fprof:"-DAC_PROFILE_FILL" (here, before the GPU job)
 from avatarcraft_amd import _lib as L
 L.LIB_PATH = out
 L._SIGS["ac_debug_fill_prof"] = ([ctypes.c_void_p, ctypes.c_int], None)
