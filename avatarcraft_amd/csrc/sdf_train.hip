@@ -367,6 +367,9 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
                 float bi[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) bi[c] = TI[(16 * c + n) * TLD + 4 * s + g];
+#ifdef AC_ABL_NODW1           // timing ablation: the weight-gradient products of the six offset evaluations are skipped
+                if (e == 0)
+#endif
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float a1 = TD[(16 * t + n) * TLD + 4 * s + g];
