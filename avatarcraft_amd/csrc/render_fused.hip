@@ -300,6 +300,14 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             // centre + 6 finite-difference evaluations (:687-704): features of all 7 points first (shared corner
             // fetches), then 7 MLP passes as one loop body over a rotating feature register file.
             AC_TICK(7)
+            // posed space: a tile whose 16 samples the warp masks out contributes alpha * 0 whatever the field says there (opt-in: skip_masked)
+            bool skip = false;
+            if constexpr (MODE == MODE_FINAL) {
+                if (a.skip_masked) skip = __ballot(a.mask[(size_t)ray * T + i] != 0) == 0ull;       // wave-uniform
+            }
+            f32x4 oc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            float gr[3] = { 0.0f, 0.0f, 0.0f };
+            if (!skip) {
             float fe0[4][2];
             encode_stencil(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
             if (a.out.feat7) {                                     // training render: keep the 7 x 8 features of this lane (the backward streams them back)
@@ -313,8 +321,6 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             AC_TICK(3)
             const float pc0 = sel4(g, px, py, pz, 0.0f);
-            f32x4 oc = { 0.0f, 0.0f, 0.0f, 0.0f };
-            float gr[3] = { 0.0f, 0.0f, 0.0f };
             float spos = 0.0f;
             if constexpr (FAST) {
                 // precision 1: the centre evaluation exactly (fp32 MFMA), the six offset evaluations as corrections of its layer 1 on the
@@ -366,13 +372,16 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 acc = accn;
             }
             }
+            }
             AC_TICK(4)
             const float gx = gr[0], gy = gr[1], gz = gr[2];        // every lane of a sample holds the same finite-difference gradient
             const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
             const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
-            float rgb[3];
-            if constexpr (FC) color_tile_fast(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
-            else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+            float rgb[3] = { 0.0f, 0.0f, 0.0f };
+            if (!skip) {
+                if constexpr (FC) color_tile_fast(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+                else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+            }
             AC_TICK(5)
             // NeuS alpha :219-248
             const float sdf0 = oc[0];
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float wgt = alpha * Tex;
             const float zn01 = clampf((zi - near) / span, 0.0f, 1.0f);
             const float pn = __builtin_sqrtf((px * px + py * py) + pz * pz);
-            const float relax = pn < 1.2f ? 1.0f : 0.0f;
+            const float relax = (pn < 1.2f && !skip) ? 1.0f : 0.0f;
             const float eerr = relax * ((gn - 1.0f) * (gn - 1.0f));
             // reductions (lane 15 of row 0 holds the tile totals)
 #define AC_ACC(S, V) { const float t_ = lane_bcast(row_scan<false>(V), 15); S = (c == 0) ? t_ : S + t_; }
@@ -569,6 +578,8 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     a.eps = op->fd_eps; a.perturb = op->perturb;
     if (op->precision != 0 && op->precision != 1) { ac::set_error("ac_render_opts: precision %d unknown (0 = exact, 1 = fast)", op->precision); return AC_ERR_BAD_ARG; }
     a.fast = op->precision;
+    if (op->skip_masked != 0 && op->skip_masked != 1) { ac::set_error("ac_render_opts: skip_masked must be 0 or 1"); return AC_ERR_BAD_ARG; }
+    a.skip_masked = op->skip_masked;
     if ((op->near_m != nullptr) != (op->far_m != nullptr)) { ac::set_error("ac_render_opts: near_m and far_m go together"); return AC_ERR_BAD_ARG; }
     a.near_m = op->near_m; a.far_m = op->far_m;
     for (int j = 0; j < 4; ++j) {           // finite-difference reach in cells, per gather round (see encode_stencil)

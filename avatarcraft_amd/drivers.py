@@ -50,6 +50,8 @@ def render_animation(net, body_model, cam_pose, poses=None, render_type="animate
                      white_bkg=True, rays_per_batch=64 * 128, device="cuda"):
     """yields (frame index, rgb [res,res,3]) for an SMPL pose sequence (render_type "animate", poses [F,72]) or a shape interpolation
     ("interp_shape", shape_from / shape_to [1,10]), seen from the dataset camera `cam_pose` [4,4]; 32 + 32 samples per ray like the reference"""
+    if hasattr(net, "skip_masked_samples"):
+        net.skip_masked_samples = True          # the loop keeps rgb only: samples the warp masks out (alpha * 0) need no field evaluation (bit-identical pixels)
     world_verts, Ts, n_frames = calc_local_trans(body_model, render_type=render_type, poses=poses, shape_from=shape_from, shape_to=shape_to,
                                                  max_frames=max_frames)
     faces = np.asarray(body_model.faces)

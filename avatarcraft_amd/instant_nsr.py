@@ -130,6 +130,11 @@ class NeRFRenderer(nn.Module):
     # corrections of the centre's layer 1 (normals within 6e-5 of "exact", sample positions / indices / sdf bit-identical); "exact" = every
     # product an fp32 fma in the oracle's order (GPU == CPU oracle bit for bit)
     render_precision = "fast"
+    # posed-space inference (render_can=False): samples the SMPL warp masks out contribute alpha * 0 = nothing.  True: tiles of 16 such samples are
+    # not evaluated (pixels, depth, normals, weights unchanged bit for bit; the per-sample sdf / colour of skipped samples are 0 and gradient_error,
+    # which no inference driver reads, covers the evaluated samples only).  False (default): every output as the reference computes it.
+    # drivers.render_animation (render_warp.py's loop, which keeps rgb only) switches it on.
+    skip_masked_samples = False
 
     def _offsets_host(self):
         oh = getattr(self, "_offsets_cache", None)
@@ -225,7 +230,8 @@ class NeRFRenderer(nn.Module):
             return self._render_core_autograd(ro, rd, z_vals, num_steps, upsample_steps, bound, bg, cos_anneal_ratio, normal_epsilon_ratio, B, N,
                                               near_far=near_far)
         out = nsr_ops.render_rays(self._field(), ro, rd, num_steps, upsample_steps, bound, inv_s_t, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
-                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp, near_far=near_far, precision=self.render_precision)
+                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp, near_far=near_far, precision=self.render_precision,
+                                  skip_masked=self.skip_masked_samples)
         return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
                 out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])
 

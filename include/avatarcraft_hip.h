@@ -157,7 +157,11 @@ typedef struct ac_render_opts {
                                  accumulate): the correction term is ~1e-2 of l1, its 2^-16 relative error is below fp32 round-off of l1
                                  itself (normals within 6e-5 of the exact mode).  Sample positions (everything that feeds searchsorted / the
                                  sort), the centre evaluation and the colour network are unaffected: z_vals, indices and sdf stay bit-identical. */
-    int32_t reserved_;
+    int32_t skip_masked;      /* posed-space rendering (ac_render_rays_warped) only: 1 = tiles of 16 samples that the warp masks out entirely
+                                 (alpha * 0, instant_nsr.py:246-249) are not evaluated.  image, weights_sum, depth, normal_map and the per-sample
+                                 weights / alpha are unchanged bit for bit (their contribution is exactly zero; the transmittance factor
+                                 1 + 1e-7 of a masked sample is kept); the per-sample sdf / color / gradient of skipped samples are 0 and
+                                 gradient_error covers the evaluated samples only.  0 = evaluate everything like the reference (default). */
 } ac_render_opts;
 
 typedef struct ac_render_out {
