@@ -656,11 +656,11 @@ AC_API size_t ac_render_rays_warped_scratch(int32_t n_rays, int32_t T, size_t of
     return o;
 }
 
-static int warp_any(const ac_warp_mesh *m, const float *pts, uint32_t P, float *can, uint8_t *mask, ac_stream_t stream)
+static int warp_any(const ac_warp_mesh *m, const float *pts, uint32_t P, float *can, uint8_t *mask, ac_stream_t stream, int skip_far = 0)
 {
     if (m->accel)
-        return ac_warp_samples_accel(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, m->accel, nullptr, can, nullptr, nullptr, nullptr,
-                                     mask, stream);
+        return ac::warp_samples_accel_impl(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, m->accel, nullptr, can, nullptr, nullptr, nullptr,
+                                           mask, stream, skip_far);
     return ac_warp_samples(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, nullptr, can, nullptr, nullptr, nullptr, mask, stream);
 }
 
@@ -703,7 +703,8 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
     a.ext_pts = can;
     launch_render<MODE_UPSAMPLE>(a, st);                          // coarse sdf, up-sampling, mid points (posed space)
     if (int rc = ac::check_launch("render_rays_warped (up-sampling)")) return rc;
-    if (int rc = warp_any(mesh, pts, (uint32_t)(N * T), can, mask, stream)) return rc;     // :198-203
+    // (skip_masked: the final pass does not evaluate masked-out samples, so the search may leave out those the cell grids prove masked)
+    if (int rc = warp_any(mesh, pts, (uint32_t)(N * T), can, mask, stream, op->skip_masked)) return rc;     // :198-203
     a.mask = mask;
     launch_render<MODE_FINAL>(a, st);
     return ac::check_launch("render_rays_warped");

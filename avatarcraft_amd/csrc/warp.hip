@@ -278,15 +278,16 @@ struct AccelView {                   // pointers into the caller's accel buffer
     uint32_t *cell;                  // [cells of all levels] (count << 16) | seed slot; count = CELL_OVERFLOW: no list
     uint16_t *ctl;                   // [CTL_ENTRIES] the cells' candidate tiles
     float *sub;                      // [MAX_TILES * SUBS][6] lo (3), hi (3) of each group of TILE_F / SUBS consecutive faces of a tile, in the tile's frame
+    float *cfar;                     // [cells of all levels] a conservative LOWER bound of dist(q, mesh)^2 over the points q of the cell
 };
 constexpr int SUBS = 4, SUB_F = TILE_F / SUBS;   // sub-boxes per tile, faces per sub-box
-constexpr int ACCEL_SEGS = 9;
+constexpr int ACCEL_SEGS = 10;
 __host__ __device__ inline size_t accel_offsets(size_t (&o)[ACCEL_SEGS])
 {
     size_t off = 0;
     const size_t sz[ACCEL_SEGS] = { HDR_WORDS * 4, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)NB * MAX_TILES * 4,
                                     (size_t)MAX_ACCEL_FACES * 32, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4, (size_t)CTL_ENTRIES * 2,
-                                    (size_t)MAX_TILES * SUBS * 6 * 4 };
+                                    (size_t)MAX_TILES * SUBS * 6 * 4, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4 };
     for (int i = 0; i < ACCEL_SEGS; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
     return off;
 }
@@ -298,7 +299,7 @@ __host__ __device__ inline AccelView accel_view(void *base)
     v.hdr = reinterpret_cast<uint32_t *>(b + o[0]); v.sorted = reinterpret_cast<uint32_t *>(b + o[1]);
     v.tri = reinterpret_cast<float *>(b + o[2]); v.oid = reinterpret_cast<int32_t *>(b + o[3]); v.box = reinterpret_cast<float *>(b + o[4]);
     v.sph = reinterpret_cast<float4 *>(b + o[5]);
-    v.cell = reinterpret_cast<uint32_t *>(b + o[6]); v.ctl = reinterpret_cast<uint16_t *>(b + o[7]); v.sub = reinterpret_cast<float *>(b + o[8]);
+    v.cell = reinterpret_cast<uint32_t *>(b + o[6]); v.ctl = reinterpret_cast<uint16_t *>(b + o[7]); v.sub = reinterpret_cast<float *>(b + o[8]); v.cfar = reinterpret_cast<float *>(b + o[9]);
     return v;
 }
 
@@ -711,6 +712,14 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
             float lb[NIT];
             int tA, tB;
             (void)bounding_pass(sbox_raw, ntp, nit, lane, qf, lb, tA, tB);
+            {   // every face lies in its tile's box: dist(q, mesh) >= min_t boxdist(c, t) - h for all q of the cell
+                float mn = lb[0];
+#pragma unroll
+                for (int it = 1; it < NIT; ++it) mn = lb[it] < mn ? lb[it] : mn;
+                mn = wave_min_f32(mn);
+                const float dl = __builtin_sqrtf(mn) * (1.0f - 1e-6f) - 0.5f * g.h2;
+                if (lane == 0) av.cfar[LVL_CELL0[l] + cell] = dl > 0.0f ? dl * dl * (1.0f - 1e-6f) : 0.0f;
+            }
             double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
             int bid = 0x7fffffff;
             uint32_t myslot;
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
                                                                  double threshold, AccelView av, double *__restrict__ can_pts,
                                                                  float *__restrict__ can_pts_f32, double *__restrict__ closest,
                                                                  double *__restrict__ dist2, int32_t *__restrict__ face_id,
-                                                                 uint8_t *__restrict__ mask)
+                                                                 uint8_t *__restrict__ mask, float skip_thr)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -795,7 +804,21 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     // result and a real face's distance, so the running minimum may start from it
     uint32_t mybase = 0, mycnt = CELL_OVERFLOW;
     double myseed = __builtin_inf();
+    // skip_thr >= 0 (the caller only wants mask and the canonical points of UNMASKED samples): a sample whose cell proves dist^2 >= threshold is
+    // masked out whatever its closest face is -- it is not searched at all (dead).  Outside both grids the mesh is >= the coarse margin away.
+    bool dead = false;
 #ifndef AC_ABL_NOGRID
+    if (skip_thr >= 0.0f) {
+        bool in_any = false;
+#pragma unroll
+        for (int l = 0; l < GRID_LEVELS; ++l) {
+            const uint32_t cell = grid_cell(grid_params(av, l), pf);
+            if (cell != ~0u && !in_any) { in_any = true; dead = av.cfar[LVL_CELL0[l] + cell] >= skip_thr; }
+        }
+        if (!in_any && av.hdr[HDR_LVL + HDR_LVL_STRIDE * (GRID_LEVELS - 1) + 8] != 0u)
+            dead = AC_GRID_MARGIN1 * AC_GRID_MARGIN1 * (1.0f - 1e-5f) >= skip_thr;
+        if (dead) mycnt = 0;                                           // no list, no full pass
+    }
 #pragma unroll
     for (int l = 0; l < GRID_LEVELS; ++l) {
         if (mycnt != CELL_OVERFLOW) continue;
@@ -1036,6 +1059,18 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
 #undef SBOX
     WP_TICK(5)
     if (!live) return;
+    if (dead) {                                                          // certainly masked out: no closest face was looked for
+        mask[i] = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (can_pts) can_pts[3 * (size_t)i + r] = p[r];
+            if (can_pts_f32) can_pts_f32[3 * (size_t)i + r] = pf[r];
+            if (closest) closest[3 * (size_t)i + r] = p[r];
+        }
+        if (dist2) dist2[i] = __builtin_inf();
+        if (face_id) face_id[i] = 0;
+        return;
+    }
     // lane = sample again: the closest point on the winning face (the same routine on the same operands as in the batch that found it)
     const double rbest = __builtin_bit_cast(double, sbest[lane]);
     uint32_t rb = sbid[lane];
@@ -1115,9 +1150,11 @@ AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_
     return ac::check_launch("warp_accel_build");
 }
 
-AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V,
-                                 uint32_t F, double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest,
-                                 double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream)
+// skip_far: samples that the cell grids prove to be masked out (dist^2 >= threshold) are not searched; their canonical point is reported as the
+// sample itself (ac_render_rays_warped with skip_masked: the final pass never evaluates them)
+int ac::warp_samples_accel_impl(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V,
+                                uint32_t F, double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest,
+                                double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream, int skip_far)
 {
     (void)V;
     if (P == 0) return AC_OK;
@@ -1131,6 +1168,14 @@ AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int
     static uint64_t seen = 0;        // the limit for the largest mesh the search supports; a launch asks for what its mesh needs
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(warp_samples_accel_kernel), (size_t)NB * MAX_TILES * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES);
     hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + PK_WAVES - 1) / PK_WAVES), dim3(PK_WAVES * 64), lds, (hipStream_t)stream, pts, verts, faces, T, P,
-                       threshold, av, can_pts, can_pts_f32, closest, dist2, face_id, mask);
+                       threshold, av, can_pts, can_pts_f32, closest, dist2, face_id, mask,
+                       skip_far ? (float)threshold * (1.0f + 1e-6f) : -1.0f);
     return ac::check_launch("warp_samples_accel");
+}
+
+AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V,
+                                 uint32_t F, double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest,
+                                 double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream)
+{
+    return ac::warp_samples_accel_impl(pts, verts, faces, T, P, V, F, threshold, accel, can_pts, can_pts_f32, closest, dist2, face_id, mask, stream, 0);
 }

@@ -317,14 +317,17 @@ def test_warped_render_skip_masked_tiles(env, precision):
         torch.cuda.synchronize()
         outs.append({k: v.clone() for k, v in g.items() if isinstance(v, torch.Tensor)})
     a, b = outs
-    for k in ("image", "weights_sum", "depth", "normal_map", "weights", "alpha", "z_vals", "mask", "can_mid"):
+    for k in ("image", "weights_sum", "depth", "normal_map", "weights", "alpha", "z_vals", "mask"):
         assert torch.equal(a[k], b[k]), k
+    live = a["mask"].bool()                                           # the canonical points of unmasked samples are the exact ones; the search may
+    assert torch.equal(a["can_mid"][live], b["can_mid"][live])        # leave out samples its cell grids prove masked (their point is not used)
+    assert int((a["can_mid"][~live] != b["can_mid"][~live]).any(-1).sum()) > 0
     m = a["mask"].reshape(-1, 4, 16).bool()                           # [ray, tile, sample]
     dead = ~m.any(-1)                                                 # tiles without a live sample
     assert 0.2 < float(dead.float().mean()) < 0.95
     sdf_b = b["sdf"].reshape(-1, 4, 16)
     assert float(sdf_b[dead].abs().max()) == 0.0 and float(b["color"].reshape(-1, 4, 16, 3)[dead].abs().max()) == 0.0
-    assert torch.equal(a["sdf"].reshape(-1, 4, 16)[~dead], sdf_b[~dead])          # evaluated tiles: untouched
+    assert torch.equal(a["sdf"][live], b["sdf"][live]) and torch.equal(a["color"][live], b["color"][live])       # unmasked samples: untouched
 
 
 @pytest.mark.parametrize("tag,guide", [("guide", True), ("noguide", False)])
