@@ -100,6 +100,22 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         int cur = (MODE == MODE_FINAL) ? 0 : (nup & 1), cnt = T0;      // the buffers swap once per up-sampling iteration: start so that the last lands in zs0
         float *const zs_first = cur ? zs1 : zs0;
 
+        if constexpr (MODE == MODE_UPSAMPLE) {
+            // skip_masked: no sample of this ray can be unmasked (ray_cull_kernel) -- its pixel is the background whatever the field says, so neither
+            // the coarse SDF nor the up-sampling runs; the z array is the coarse one padded with its last value (sorted, finite)
+            if (a.ray_dead && a.ray_dead[ray]) {
+                for (int i = lane; i < T; i += 64) {
+                    const int ic = i < T0 ? i : T0 - 1;
+                    float zi = near + span * lds[OFF_LIN + ic];
+                    if (a.perturb) zi = zi + (a.noise[(size_t)ray * T0 + ic] - 0.5f) * sample_dist;
+                    const size_t si = (size_t)ray * T + i;
+                    a.zbuf[si] = zi;
+                    if (a.mid_pts) { a.mid_pts[3 * si] = ox + dx * zi; a.mid_pts[3 * si + 1] = oy + dy * zi; a.mid_pts[3 * si + 2] = oz + dz * zi; }
+                }
+                wave_sync();
+                continue;
+            }
+        }
         // ---- coarse samples :155-180 -------------------------------------------------------------
         if constexpr (MODE == MODE_FINAL) {
             for (int i = lane; i < T; i += 64) zs0[i] = a.zbuf[(size_t)ray * T + i];
@@ -653,14 +669,15 @@ AC_API size_t ac_render_rays_warped_scratch(int32_t n_rays, int32_t T, size_t of
     const size_t sz[6] = { N * 4, N * 4, NT * 12, NT * 12, NT, NT * 4 };
     size_t o = 0;
     for (int i = 0; i < 6; ++i) { if (offs) offs[i] = o; o += (sz[i] + 255) & ~(size_t)255; }
-    return o;
+    return o + ((N + 255) & ~(size_t)255);                     // + ray_dead [N] u8 (skip_masked), behind the six documented segments
 }
 
-static int warp_any(const ac_warp_mesh *m, const float *pts, uint32_t P, float *can, uint8_t *mask, ac_stream_t stream, int skip_far = 0)
+static int warp_any(const ac_warp_mesh *m, const float *pts, uint32_t P, float *can, uint8_t *mask, ac_stream_t stream, int skip_far = 0,
+                    const uint8_t *ray_dead = nullptr, uint32_t spr = 1)
 {
     if (m->accel)
         return ac::warp_samples_accel_impl(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, m->accel, nullptr, can, nullptr, nullptr, nullptr,
-                                           mask, stream, skip_far);
+                                           mask, stream, skip_far, ray_dead, spr);
     return ac_warp_samples(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, nullptr, can, nullptr, nullptr, nullptr, mask, stream);
 }
 
@@ -686,6 +703,7 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
     float *pts = reinterpret_cast<float *>(sc + offs[2]), *can = reinterpret_cast<float *>(sc + offs[3]);
     uint8_t *mask = reinterpret_cast<uint8_t *>(sc + offs[4]);
     float *zbuf = reinterpret_cast<float *>(sc + offs[5]);
+    const uint8_t *ray_dead = nullptr;
     hipStream_t st = (hipStream_t)stream;
     RenderArgs a{};
     if (int rc = fill_render_args(a, field, op, rays_o, rays_d, bg, noise, lin_z, lin_u, out)) return rc;
@@ -698,13 +716,19 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
         hipLaunchKernelGGL(coarse_pts_kernel, dim3((N * T0 + 255) / 256), dim3(256), 0, st, rays_o, rays_d, a.near_m, a.far_m, lin_z, noise, N, T0,
                            op->bound, op->perturb, pts);
         if (int rc = ac::check_launch("render_rays_warped (coarse points)")) return rc;
-        if (int rc = warp_any(mesh, pts, (uint32_t)(N * T0), can, mask, stream)) return rc;
+        if (op->skip_masked && mesh->accel) {                     // rays that cannot hold an unmasked sample: no search, no field evaluation
+            uint8_t *rdead = reinterpret_cast<uint8_t *>(sc + ac_render_rays_warped_scratch(N, T, nullptr) - (((size_t)N + 255) & ~(size_t)255));
+            if (int rc = ac::warp_ray_cull(pts, (uint32_t)N, (uint32_t)T0, mesh->threshold, mesh->accel, rdead, stream)) return rc;
+            ray_dead = rdead;
+        }
+        if (int rc = warp_any(mesh, pts, (uint32_t)(N * T0), can, mask, stream, 0, ray_dead, (uint32_t)T0)) return rc;
     }
     a.ext_pts = can;
+    a.ray_dead = ray_dead;
     launch_render<MODE_UPSAMPLE>(a, st);                          // coarse sdf, up-sampling, mid points (posed space)
     if (int rc = ac::check_launch("render_rays_warped (up-sampling)")) return rc;
     // (skip_masked: the final pass does not evaluate masked-out samples, so the search may leave out those the cell grids prove masked)
-    if (int rc = warp_any(mesh, pts, (uint32_t)(N * T), can, mask, stream, op->skip_masked)) return rc;     // :198-203
+    if (int rc = warp_any(mesh, pts, (uint32_t)(N * T), can, mask, stream, op->skip_masked, ray_dead, (uint32_t)T)) return rc;     // :198-203
     a.mask = mask;
     launch_render<MODE_FINAL>(a, st);
     return ac::check_launch("render_rays_warped");

@@ -755,6 +755,42 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
     }
 }
 
+// conservative lower bound of dist(q, mesh)^2 from the cell grids (0 when nothing is known; the coarse margin outside both grids)
+__device__ __forceinline__ float grid_far_bound(const AccelView &av, const float (&pf)[3])
+{
+#pragma unroll
+    for (int l = 0; l < GRID_LEVELS; ++l) {
+        const uint32_t cell = grid_cell(grid_params(av, l), pf);
+        if (cell != ~0u) return av.cfar[LVL_CELL0[l] + cell];
+    }
+    return av.hdr[HDR_LVL + HDR_LVL_STRIDE * (GRID_LEVELS - 1) + 8] != 0u ? AC_GRID_MARGIN1 * AC_GRID_MARGIN1 * (1.0f - 1e-5f) : 0.0f;
+}
+
+// skip_masked rendering: a ray none of whose samples can come within the mask threshold of the mesh renders to the background whatever the field
+// says.  pts = the coarse samples [N, T0, 3] (posed space); every later sample of the ray (up-sampled z, mid points) lies within half a coarse step
+// of one of them, so the ray is DEAD if  sqrt(far_bound(p_i)) - step_i / 2 >= sqrt(threshold)  for every coarse sample.  One lane per ray.
+__global__ __launch_bounds__(256) void ray_cull_kernel(const float *__restrict__ pts, uint32_t N, uint32_t T0, AccelView av, float thr,
+                                                       uint8_t *__restrict__ ray_dead)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const float rt = __builtin_sqrtf(thr) * (1.0f + 1e-6f);
+    bool dead = true;
+    float prev[3] = { 0.0f, 0.0f, 0.0f }, dprev = 0.0f;
+    for (uint32_t i = 0; i < T0 && dead; ++i) {
+        const float *pp = pts + ((size_t)r * T0 + i) * 3;
+        const float p[3] = { pp[0], pp[1], pp[2] };
+        float dnext = 0.0f;
+        if (i + 1 < T0) { const float ex = pp[3] - p[0], ey = pp[4] - p[1], ez = pp[5] - p[2]; dnext = __builtin_sqrtf((ex * ex + ey * ey) + ez * ez); }
+        const float step = (dprev > dnext ? dprev : dnext) * (1.0f + 1e-5f);
+        const float lo = __builtin_sqrtf(grid_far_bound(av, p)) * (1.0f - 1e-6f) - 0.5f * step;
+        dead = lo >= rt;                                               // NaN points / steps compare false: the ray is searched
+        dprev = dnext; prev[0] = p[0];
+    }
+    (void)prev;
+    ray_dead[r] = dead ? 1 : 0;
+}
+
 // ---- the search: one wave owns 64 consecutive samples -------------------------------------------------------------------------------------------
 // The work of the wave's samples is PACKED: (sample, tile) pairs whose box can hold the answer go to a queue; a disc trip takes 8 pairs of whatever
 // samples and tests their 8 x 32 faces against the bounding discs; the surviving (sample, face) pairs go to a second queue and through the fp64
@@ -775,10 +811,14 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
                                                                  double threshold, AccelView av, double *__restrict__ can_pts,
                                                                  float *__restrict__ can_pts_f32, double *__restrict__ closest,
                                                                  double *__restrict__ dist2, int32_t *__restrict__ face_id,
-                                                                 uint8_t *__restrict__ mask, float skip_thr)
+                                                                 uint8_t *__restrict__ mask, float skip_thr,
+                                                                 const uint8_t *__restrict__ ray_dead, uint32_t spr, uint32_t perm_mul)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // which 64 samples this wave owns: consecutive waves take chunks perm_mul apart (a bijection: gcd(perm_mul, chunks) = 1, chosen by the host), so
+    // that the eight waves of a workgroup -- and the two workgroups of a compute unit -- hold a mix of cheap chunks (rays far from the body, samples the
+    // caller lets the search skip) and expensive ones instead of 16 neighbouring rays of the same kind
+    const uint32_t wave = (uint32_t)(((unsigned long long)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * perm_mul) % ((P + 63u) >> 6));
     const uint32_t nt = av.hdr[0];
     const uint32_t nit = (nt + 63) >> 6;
     extern __shared__ __attribute__((aligned(16))) float sbox_raw[];
@@ -792,7 +832,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     uint16_t *tq = reinterpret_cast<uint16_t *>(wl + 1536 + FQ * 4 + GQ * 4);    // [TQ] (sample << 9) | tile
     load_boxes(sbox_raw, av, ntp);
     __syncthreads();
-    if (wave * 64 >= P) return;                                        // (after the barrier) a wave without samples
+    if (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) >= ((P + 63u) >> 6)) return;       // (after the barrier) a wave without samples
     const uint32_t i = wave * 64 + lane;
     const bool live = i < P;
     const uint32_t ii = live ? i : P - 1;
@@ -806,9 +846,10 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     double myseed = __builtin_inf();
     // skip_thr >= 0 (the caller only wants mask and the canonical points of UNMASKED samples): a sample whose cell proves dist^2 >= threshold is
     // masked out whatever its closest face is -- it is not searched at all (dead).  Outside both grids the mesh is >= the coarse margin away.
-    bool dead = false;
+    bool dead = ray_dead ? ray_dead[ii / spr] != 0 : false;              // skip_masked: the sample's whole ray is provably masked out (ray_cull_kernel)
 #ifndef AC_ABL_NOGRID
-    if (skip_thr >= 0.0f) {
+    if (dead) mycnt = 0;
+    else if (skip_thr >= 0.0f) {
         bool in_any = false;
 #pragma unroll
         for (int l = 0; l < GRID_LEVELS; ++l) {
@@ -1058,8 +1099,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     }
 #undef SBOX
     WP_TICK(5)
-    if (!live) return;
-    if (dead) {                                                          // certainly masked out: no closest face was looked for
+    if (live && dead) {                                                  // certainly masked out: no closest face was looked for
         mask[i] = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1069,21 +1109,21 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
         }
         if (dist2) dist2[i] = __builtin_inf();
         if (face_id) face_id[i] = 0;
-        return;
-    }
-    // lane = sample again: the closest point on the winning face (the same routine on the same operands as in the batch that found it)
-    const double rbest = __builtin_bit_cast(double, sbest[lane]);
-    uint32_t rb = sbid[lane];
-    double rbc[3] = { 0.0, 0.0, 0.0 };
-    if (rb == 0x7fffffffu) rb = 0;                                       // no face with a distance (all degenerate): what the exhaustive kernel reports
-    else {
-        const int32_t f0v = faces[3 * (size_t)rb], f1v = faces[3 * (size_t)rb + 1], f2v = faces[3 * (size_t)rb + 2];
-        double a[3], b[3], c[3];
+    } else if (live) {
+        // lane = sample again: the closest point on the winning face (the same routine on the same operands as in the batch that found it)
+        const double rbest = __builtin_bit_cast(double, sbest[lane]);
+        uint32_t rb = sbid[lane];
+        double rbc[3] = { 0.0, 0.0, 0.0 };
+        if (rb == 0x7fffffffu) rb = 0;                                   // no face with a distance (all degenerate): what the exhaustive kernel reports
+        else {
+            const int32_t f0v = faces[3 * (size_t)rb], f1v = faces[3 * (size_t)rb + 1], f2v = faces[3 * (size_t)rb + 2];
+            double a[3], b[3], c[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { a[k] = (double)verts[3 * (size_t)f0v + k]; b[k] = (double)verts[3 * (size_t)f1v + k]; c[k] = (double)verts[3 * (size_t)f2v + k]; }
-        closest_pt_tri(p, a, b, c, rbc);
+            for (int k = 0; k < 3; k++) { a[k] = (double)verts[3 * (size_t)f0v + k]; b[k] = (double)verts[3 * (size_t)f1v + k]; c[k] = (double)verts[3 * (size_t)f2v + k]; }
+            closest_pt_tri(p, a, b, c, rbc);
+        }
+        finish_sample(i, p, rbc, rbest, (int)rb, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
     }
-    finish_sample(i, p, rbc, rbest, (int)rb, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
     WP_TICK(6)
     WP_END()
 }
@@ -1154,7 +1194,8 @@ AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_
 // sample itself (ac_render_rays_warped with skip_masked: the final pass never evaluates them)
 int ac::warp_samples_accel_impl(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V,
                                 uint32_t F, double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest,
-                                double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream, int skip_far)
+                                double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream, int skip_far, const uint8_t *ray_dead,
+                                uint32_t samples_per_ray)
 {
     (void)V;
     if (P == 0) return AC_OK;
@@ -1167,15 +1208,29 @@ int ac::warp_samples_accel_impl(const float *pts, const float *verts, const int3
     const size_t lds = (size_t)NB * ntp * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES;
     static uint64_t seen = 0;        // the limit for the largest mesh the search supports; a launch asks for what its mesh needs
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(warp_samples_accel_kernel), (size_t)NB * MAX_TILES * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES);
+    uint32_t perm_mul = 1;
+    for (uint32_t m : { 37u, 41u, 43u, 47u, 53u }) {
+        uint32_t a = waves, b = m;
+        while (b) { const uint32_t t = a % b; a = b; b = t; }
+        if (a == 1u) { perm_mul = m; break; }
+    }
     hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + PK_WAVES - 1) / PK_WAVES), dim3(PK_WAVES * 64), lds, (hipStream_t)stream, pts, verts, faces, T, P,
                        threshold, av, can_pts, can_pts_f32, closest, dist2, face_id, mask,
-                       skip_far ? (float)threshold * (1.0f + 1e-6f) : -1.0f);
+                       skip_far ? (float)threshold * (1.0f + 1e-6f) : -1.0f, ray_dead, samples_per_ray ? samples_per_ray : 1u, perm_mul);
     return ac::check_launch("warp_samples_accel");
+}
+
+int ac::warp_ray_cull(const float *coarse_pts, uint32_t N, uint32_t T0, double threshold, const void *accel, uint8_t *ray_dead, ac_stream_t stream)
+{
+    if (N == 0) return AC_OK;
+    const AccelView av = accel_view(const_cast<void *>(accel));
+    hipLaunchKernelGGL(ray_cull_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, coarse_pts, N, T0, av, (float)threshold * (1.0f + 1e-6f), ray_dead);
+    return ac::check_launch("warp_ray_cull");
 }
 
 AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V,
                                  uint32_t F, double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest,
                                  double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream)
 {
-    return ac::warp_samples_accel_impl(pts, verts, faces, T, P, V, F, threshold, accel, can_pts, can_pts_f32, closest, dist2, face_id, mask, stream, 0);
+    return ac::warp_samples_accel_impl(pts, verts, faces, T, P, V, F, threshold, accel, can_pts, can_pts_f32, closest, dist2, face_id, mask, stream, 0, nullptr, 1);
 }

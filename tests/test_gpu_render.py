@@ -317,8 +317,11 @@ def test_warped_render_skip_masked_tiles(env, precision):
         torch.cuda.synchronize()
         outs.append({k: v.clone() for k, v in g.items() if isinstance(v, torch.Tensor)})
     a, b = outs
-    for k in ("image", "weights_sum", "depth", "normal_map", "weights", "alpha", "z_vals", "mask"):
+    for k in ("image", "weights_sum", "depth", "normal_map", "weights", "alpha", "mask"):
         assert torch.equal(a[k], b[k]), k
+    lr = a["mask"].bool().any(1)                                      # rays with an unmasked sample: same sample positions; a ray that provably has
+    assert torch.equal(a["z_vals"][lr], b["z_vals"][lr])             # none is not sampled at all (coarse z, padded): finite and sorted is all it needs
+    assert torch.isfinite(b["z_vals"]).all() and (b["z_vals"][:, 1:] >= b["z_vals"][:, :-1]).all() and 0.05 < float((~lr).float().mean()) < 0.9
     live = a["mask"].bool()                                           # the canonical points of unmasked samples are the exact ones; the search may
     assert torch.equal(a["can_mid"][live], b["can_mid"][live])        # leave out samples its cell grids prove masked (their point is not used)
     assert int((a["can_mid"][~live] != b["can_mid"][~live]).any(-1).sum()) > 0
