@@ -301,7 +301,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AC_BENCH_FORCE_DIST") == "1":      # (forced at world size 1: the RCCL code path of an N > 1 run on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("AC_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" lets the N > 1 path be exercised on a 1-GPU box
