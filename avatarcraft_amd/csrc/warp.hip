@@ -25,6 +25,7 @@ __global__ __launch_bounds__(NF_WAVES * 64) void mesh_near_far_kernel(const floa
                                                                       float *__restrict__ near, float *__restrict__ far)
 {
     __shared__ float sv[VT * 3];
+    __shared__ float sg[VT / 32][4];                      // bounding sphere of every run of 32 consecutive vertices of the tile (centre, padded radius)
     __shared__ float snr[NF_WAVES][64], sfr[NF_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * 64 + lane;
@@ -33,12 +34,48 @@ __global__ __launch_bounds__(NF_WAVES * 64) void mesh_near_far_kernel(const floa
     const float ox = rays_o[3 * nn], oy = rays_o[3 * nn + 1], oz = rays_o[3 * nn + 2];
     const float dx = rays_d[3 * nn], dy = rays_d[3 * nn + 1], dz_ = rays_d[3 * nn + 2];
     float nr = __builtin_inff(), fr = -__builtin_inff();
-    for (uint32_t v0 = 0; v0 < V; v0 += VT) {
-        const uint32_t cnt = (V - v0 < (uint32_t)VT) ? V - v0 : (uint32_t)VT;
+    const float rad = __builtin_sqrtf(r2) * (1.0f + 1e-6f);
+    // gridDim.y > 1: this workgroup scans ONE vertex tile and the tiles' results meet in near / far through atomic min / max (both exact and order
+    // independent; the host presets +inf / -inf).  A 8192-ray batch is only 128 workgroups otherwise -- half the device idle, and seven dependent
+    // load -> barrier -> scan rounds each.
+    const uint32_t v_begin = gridDim.y > 1 ? blockIdx.y * (uint32_t)VT : 0u;
+    const uint32_t v_end = gridDim.y > 1 ? (v_begin + (uint32_t)VT < V ? v_begin + (uint32_t)VT : V) : V;
+    // the run test below bounds a DISTANCE; the per-vertex formula (the reference's) is one only for unit directions: with |d|^2 = 1 +- 2e-6 the two
+    // differ by < 2e-6 z0^2, inside the 1e-5 s2 slack of the test.  Other rays (never produced by the drivers): every run is scanned.
+    const bool cull_ok = __all(!live || __builtin_fabsf(((dx * dx + dy * dy) + dz_ * dz_) - 1.0f) <= 2e-6f) != 0;
+    for (uint32_t v0 = v_begin; v0 < v_end; v0 += VT) {
+        const uint32_t cnt = (v_end - v0 < (uint32_t)VT) ? v_end - v0 : (uint32_t)VT;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cnt * 3; i += blockDim.x) sv[i] = verts[(size_t)v0 * 3 + i];
         __syncthreads();
-        for (uint32_t v = wave; v < cnt; v += NF_WAVES) {
+        // mesh vertex order is spatially coherent (body parts): a run of 32 vertices sits in a small sphere, and the 64 rays of a wave are a thin fan
+        // (neighbouring pixels) -- most runs are missed by the whole fan and cost one test instead of 32
+        const uint32_t ngr = (cnt + 31u) >> 5;
+        if (threadIdx.x < ngr) {
+            const uint32_t b0 = threadIdx.x * 32u, b1 = (b0 + 32u < cnt) ? b0 + 32u : cnt;
+            float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+            for (uint32_t v = b0; v < b1; ++v) { cx += sv[3 * v]; cy += sv[3 * v + 1]; cz += sv[3 * v + 2]; }
+            const float inv = 1.0f / (float)(b1 - b0);
+            cx *= inv; cy *= inv; cz *= inv;
+            float m2 = 0.0f;
+            for (uint32_t v = b0; v < b1; ++v) {
+                const float ex = sv[3 * v] - cx, ey = sv[3 * v + 1] - cy, ez = sv[3 * v + 2] - cz, e2 = (ex * ex + ey * ey) + ez * ez;
+                m2 = e2 > m2 ? e2 : m2;                    // NaN vertices compare false: they are handled (ignored) by the per-vertex code below
+            }
+            sg[threadIdx.x][0] = cx; sg[threadIdx.x][1] = cy; sg[threadIdx.x][2] = cz;
+            sg[threadIdx.x][3] = __builtin_sqrtf(m2) * (1.0f + 1e-5f) + 1e-6f;
+        }
+        __syncthreads();
+        for (uint32_t gi = wave; gi < ngr; gi += NF_WAVES) {
+            {   // the whole run: a ray farther than R + r from the centre (as a line, like the per-vertex formula) touches none of its spheres
+                const float x = sg[gi][0] - ox, y = sg[gi][1] - oy, z = sg[gi][2] - oz;
+                const float z0 = (x * dx + y * dy) + z * dz_, s2 = (x * x + y * y) + z * z;
+                const float rr = sg[gi][3] + rad;
+                // (a NaN centre -- a NaN vertex in the run -- compares false everywhere: `!(... > ...)` keeps the run)
+                if (cull_ok && !__any(!((s2 - z0 * z0) > rr * rr * (1.0f + 1e-5f) + 1e-5f * s2 + 1e-10f))) continue;
+            }
+            const uint32_t e1 = (gi * 32u + 32u < cnt) ? gi * 32u + 32u : cnt;
+        for (uint32_t v = gi * 32u; v < e1; ++v) {
             const float x = sv[3 * v] - ox, y = sv[3 * v + 1] - oy, z = sv[3 * v + 2] - oz;
             const float z0 = (x * dx + y * dy) + z * dz_;
             const float s2 = (x * x + y * y) + z * z;
@@ -52,13 +89,19 @@ __global__ __launch_bounds__(NF_WAVES * 64) void mesh_near_far_kernel(const floa
             if (a == a && a < nr) nr = a;
             if (b == b && b > fr) fr = b;
         }
+        }
     }
     snr[wave][lane] = nr; sfr[wave][lane] = fr;
     __syncthreads();
     if (wave == 0 && live) {
 #pragma unroll
         for (int w = 1; w < NF_WAVES; ++w) { const float a = snr[w][lane], b = sfr[w][lane]; nr = a < nr ? a : nr; fr = b > fr ? b : fr; }
-        near[n] = nr; far[n] = fr;
+        if (gridDim.y == 1) { near[n] = nr; far[n] = fr; }
+        else {
+            uint32_t *pn = reinterpret_cast<uint32_t *>(near + n), *pf = reinterpret_cast<uint32_t *>(far + n);
+            for (uint32_t old = *pn; nr < __uint_as_float(old);) { const uint32_t was = atomicCAS(pn, old, __float_as_uint(nr)); if (was == old) break; old = was; }
+            for (uint32_t old = *pf; fr > __uint_as_float(old);) { const uint32_t was = atomicCAS(pf, old, __float_as_uint(fr)); if (was == old) break; old = was; }
+        }
     }
 }
 
@@ -1145,7 +1188,13 @@ AC_API int ac_mesh_near_far(const float *rays_o, const float *rays_d, const floa
     if (N == 0) return AC_OK;
     if (!rays_o || !rays_d || !verts || !near || !far || V == 0) { ac::set_error("mesh_near_far: NULL buffer or empty mesh"); return AC_ERR_BAD_ARG; }
     const float r2 = (float)((double)geo_threshold * (double)geo_threshold);
-    hipLaunchKernelGGL(mesh_near_far_kernel, dim3((N + 63) / 64), dim3(NF_WAVES * 64), 0, (hipStream_t)stream, rays_o, rays_d, verts, N, V, r2, near, far);
+    uint32_t tiles = (V + VT - 1) / VT;
+    if ((N + 63) / 64 >= ac::cu_count()) tiles = 1;                  // enough ray blocks to fill the device: one workgroup walks all vertex tiles
+    if (tiles > 1) {                                                 // one workgroup per (64 rays, vertex tile): results meet through atomic min / max
+        (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(near), 0x7f800000, N, (hipStream_t)stream);      // +inf
+        (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(far), (int)0xff800000u, N, (hipStream_t)stream); // -inf
+    }
+    hipLaunchKernelGGL(mesh_near_far_kernel, dim3((N + 63) / 64, tiles), dim3(NF_WAVES * 64), 0, (hipStream_t)stream, rays_o, rays_d, verts, N, V, r2, near, far);
     return ac::check_launch("mesh_near_far");
 }
 
