@@ -107,6 +107,7 @@ struct RenderArgs {
     const float *near_m, *far_m;   // [N] mesh-guided range (+-inf where the ray misses the body) or NULL
     const float *ext_pts;          // MODE_UPSAMPLE: warped coarse points [N,T0,3]; MODE_FINAL: warped mid points [N,T,3]
     const uint8_t *mask;           // MODE_FINAL: [N,T] alpha mask
+    uint32_t *ray_counter;         // AC_DYNAMIC_RAYS: [8] per-XCD ray counters (zeroed before the launch): waves fetch their next ray instead of owning a fixed one
     const uint8_t *ray_dead;       // MODE_UPSAMPLE, skip_masked: [N] rays that cannot hold an unmasked sample (no field evaluation, coarse z only)
     float *zbuf;                   // [N,T] final z values: written by MODE_UPSAMPLE, read by MODE_FINAL
     float *mid_pts;                // MODE_UPSAMPLE: posed-space mid points [N,T,3]

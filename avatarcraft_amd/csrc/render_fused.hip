@@ -26,10 +26,14 @@
 //
 // Numerics contract: see ac_devmath.hpp and DESIGN.md; every value produced here is bit-identical
 // to oracle/ac_oracle.c:orc_render_rays on the same inputs.
+#include <atomic>
 #include "nsr_device.hpp"
 
 namespace {
 
+#ifndef AC_DYNAMIC_RAYS
+#define AC_DYNAMIC_RAYS 1          // persistent workgroups (one per compute unit), rays handed out by per-XCD counters; 0: eight fixed rays per workgroup
+#endif
 #ifndef AC_FAST_COLOR
 #define AC_FAST_COLOR 1            // fast precision: the colour network in split bf16 too (0: only layer 1 of the finite-difference evaluations)
 #endif
@@ -84,7 +88,19 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         bid = k * q + (k < r ? k : r) + (blockIdx.x >> 3);
     }
 #endif
+#if AC_DYNAMIC_RAYS
+    // waves fetch rays one at a time from their XCD's counter (XCD k owns the k-th contiguous eighth of the batch, as with the static mapping): a
+    // workgroup no longer waits for the slowest of its eight rays before the next eight start (per-ray time varies by ~9 %)
+    const int xper = ((a.n_rays + 7) / 8 + 7) & ~7, xlo = (blockIdx.x & 7) * xper, xhi = (xlo + xper < a.n_rays) ? xlo + xper : a.n_rays;
+    for (;;) {
+        int ray = 0;
+        if (lane == 0) ray = (int)atomicAdd(a.ray_counter + (blockIdx.x & 7), 1u);
+        ray = xlo + __builtin_amdgcn_readfirstlane(ray);
+        if (ray >= xhi) break;
+        (void)bid;
+#else
     for (int ray = bid * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
+#endif
         AC_T0();
         const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
         const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
@@ -608,14 +624,46 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     return AC_OK;
 }
 
+// eight per-XCD ray counters for one launch: 64 rotating sets per device (launches of one stream run in order; 64 launches in flight across streams
+// would be needed for two of them to share a set), allocated once per device and kept for the life of the process
+static uint32_t *ray_counters()
+{
+    static std::atomic<uint32_t *> pool[64];
+    static std::atomic<uint32_t> turn{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    dev &= 63;
+    uint32_t *p = pool[dev].load(std::memory_order_acquire);
+    if (!p) {
+        uint32_t *fresh = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&fresh), 64 * 8 * sizeof(uint32_t)) != hipSuccess) return nullptr;
+        if (pool[dev].compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) p = fresh;
+        else (void)hipFree(fresh);                                   // another host thread was first
+    }
+    return p + 8 * (turn.fetch_add(1, std::memory_order_relaxed) & 63u);
+}
+
 template <int MODE, bool FAST>
 static void launch_render_p(const RenderArgs &a, hipStream_t stream)
 {
-    const int blocks = (a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    int blocks = (a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     static uint64_t seen = 0;                       // one flag per instantiation
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(render_rays_kernel<MODE, FAST>), lds_bytes);
+#if AC_DYNAMIC_RAYS
+    RenderArgs b = a;
+    {
+        b.ray_counter = ray_counters();
+        if (b.ray_counter) (void)hipMemsetAsync(b.ray_counter, 0, 8 * sizeof(uint32_t), stream);
+        const int cus = (int)ac::cu_count();
+        if (blocks > cus) blocks = cus;
+        blocks = (blocks + 7) & ~7;                                      // every XCD gets the same number of workgroups
+        if (!b.ray_counter) blocks = 0;                                  // (2 KB could not be allocated: an empty grid is a launch error the caller reports)
+    }
+    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, b);
+#else
     hipLaunchKernelGGL((render_rays_kernel<MODE, FAST>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
+#endif
 }
 template <int MODE>
 static void launch_render(const RenderArgs &a, hipStream_t stream)

@@ -4,12 +4,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-csrc = os.path.join(ROOT, "avatarcraft_amd", "csrc")
-out = os.path.join(ROOT, "gpurun_out", "libac_prof.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
-srcs = [os.path.join(csrc, f) for f in ("ac_capi.hip", "hashgrid.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "hash_stencil.hip", "sdf_train.hip", "warp.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                       "-DAC_PROFILE", "-Wno-unused-result", "-o", out] + srcs)
+out = os.path.join(ROOT, "tools", "_bin", "lib_rprof.so")           # python tools/build_variants.py rprof:"-DAC_PROFILE" (here, before the GPU job)
 from avatarcraft_amd import _lib
 _lib.LIB_PATH = out
 _lib._SIGS["ac_debug_set_prof"] = ([ctypes.c_void_p], None)
@@ -22,7 +17,7 @@ ro, rd = torch.from_numpy(ro[:4096].copy()).cuda(), torch.from_numpy(rd[:4096].c
 prof = torch.zeros(4096 * 10, dtype=torch.int64, device="cuda")
 _lib.lib().ac_debug_set_prof(prof.data_ptr())
 for _ in range(3):
-    prof.zero_(); nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, float(p["inv_s"])); torch.cuda.synchronize()
+    prof.zero_(); nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, float(p["inv_s"]), precision=os.environ.get("PRECISION", "fast")); torch.cuda.synchronize()
 pa = prof.cpu().numpy().reshape(4096, 10).astype(np.float64)
 pr = pa[:, :8]
 names = ["coarse(64 sdf evals)", "upsample math+merge", "upsample sdf eval", "final: stencil gather+interp", "final: 7x sdf mlp", "final: colour mlp",
@@ -33,3 +28,11 @@ print("whole wave: %.0f s_memtime ticks in %.0f s_memrealtime ticks (100 MHz) = 
       % (pa[:, 8].mean(), pa[:, 9].mean(), pa[:, 9].mean() / 100.0, pa[:, 8].mean() / pa[:, 9].mean() * 0.1))
 for n, v in zip(names, pr.mean(0)):
     print("  %-32s %9.0f  %5.1f%%" % (n, v, 100 * v / tot))
+
+# how evenly the work of a launch is spread: one wave = one ray here (512 workgroups of 8 rays, one workgroup per CU at a time, two rounds)
+us = pa[:, 9] / 100.0
+wg = us.reshape(512, 8)
+print("per-ray wall time (us): mean %.1f  std %.1f  min %.1f  max %.1f" % (us.mean(), us.std(), us.min(), us.max()))
+print("per-workgroup (8 rays): mean of the rays %.1f, max of the rays: mean %.1f  min %.1f  max %.1f" % (wg.mean(), wg.max(1).mean(), wg.max(1).min(), wg.max(1).max()))
+print("=> a workgroup waits for its slowest ray: %.1f %% above the mean ray; two rounds of 256 workgroups: sum of the two slowest-ray times per CU slot ~ %.1f us vs 2 x mean ray %.1f us"
+      % (100 * (wg.max(1).mean() / us.mean() - 1), 2 * wg.max(1).mean(), 2 * us.mean()))
