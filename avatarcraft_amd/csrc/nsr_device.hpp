@@ -77,7 +77,7 @@ static_assert(OFF_WAVE % 4 == 0 && OFF_RWAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16
 // levels, ~0 otherwise (a dense index is < size by construction); wsize = size only for a hashed level whose size
 // is not a power of two (never the case for tables allocated by HashEncoder, handled for completeness).
 #ifdef AC_PROFILE
-#define AC_T0() unsigned long long t_prof_ = __builtin_amdgcn_s_memtime()
+#define AC_T0() unsigned long long t_prof_ = __builtin_amdgcn_s_memtime(); const unsigned long long ray_r0_ = __builtin_amdgcn_s_memrealtime()
 #define AC_TICK(SLOT) { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); prof_acc[SLOT] += t2_ - t_prof_; t_prof_ = t2_; }
 #else
 #define AC_T0()

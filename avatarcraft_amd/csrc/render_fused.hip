@@ -472,6 +472,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             a.out.eik[2 * ray] = s_en; a.out.eik[2 * ray + 1] = s_ed;
         }
         wave_sync();
+#ifdef AC_PROFILE               // per-ray wall time (100 MHz ticks) behind the per-wave records: [n_rays * 10 + ray]
+        if (a.prof && lane == 0) a.prof[(size_t)a.n_rays * 10 + ray] = __builtin_amdgcn_s_memrealtime() - ray_r0_;
+#endif
     }
 #ifdef AC_PROFILE
     if (a.prof && lane == 0) { const int w_ = blockIdx.x * WAVES_PER_BLOCK + wave; for (int i = 0; i < 8; ++i) a.prof[w_ * 10 + i] = prof_acc[i];

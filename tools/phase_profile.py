@@ -14,11 +14,15 @@ from tests.gpu_common import device_field
 p = load_golden("nsr_params.npz"); f, _ = device_field(p)
 ro, rd = make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)
 ro, rd = torch.from_numpy(ro[:4096].copy()).cuda(), torch.from_numpy(rd[:4096].copy()).cuda()
-prof = torch.zeros(4096 * 10, dtype=torch.int64, device="cuda")
+prof = torch.zeros(4096 * 11, dtype=torch.int64, device="cuda")
 _lib.lib().ac_debug_set_prof(prof.data_ptr())
 for _ in range(3):
-    prof.zero_(); nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, float(p["inv_s"]), precision=os.environ.get("PRECISION", "fast")); torch.cuda.synchronize()
-pa = prof.cpu().numpy().reshape(4096, 10).astype(np.float64)
+    prof.zero_(); o_ = nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, float(p["inv_s"]), precision=os.environ.get("PRECISION", "fast")); torch.cuda.synchronize()
+pall = prof.cpu().numpy().astype(np.float64)
+pa = pall[:40960].reshape(4096, 10)
+nw = int((pa[:, 8] > 0).sum())
+pa = pa[pa[:, 8] > 0]                      # the waves that ran (rays are handed out dynamically: fewer waves than rays)
+ray_us = pall[40960:] / 100.0
 pr = pa[:, :8]
 names = ["coarse(64 sdf evals)", "upsample math+merge", "upsample sdf eval", "final: stencil gather+interp", "final: 7x sdf mlp", "final: colour mlp",
          "final: alpha+composite", "final: tile setup"]
@@ -29,10 +33,11 @@ print("whole wave: %.0f s_memtime ticks in %.0f s_memrealtime ticks (100 MHz) = 
 for n, v in zip(names, pr.mean(0)):
     print("  %-32s %9.0f  %5.1f%%" % (n, v, 100 * v / tot))
 
-# how evenly the work of a launch is spread: one wave = one ray here (512 workgroups of 8 rays, one workgroup per CU at a time, two rounds)
-us = pa[:, 9] / 100.0
-wg = us.reshape(512, 8)
-print("per-ray wall time (us): mean %.1f  std %.1f  min %.1f  max %.1f" % (us.mean(), us.std(), us.min(), us.max()))
-print("per-workgroup (8 rays): mean of the rays %.1f, max of the rays: mean %.1f  min %.1f  max %.1f" % (wg.mean(), wg.max(1).mean(), wg.max(1).min(), wg.max(1).max()))
-print("=> a workgroup waits for its slowest ray: %.1f %% above the mean ray; two rounds of 256 workgroups: sum of the two slowest-ray times per CU slot ~ %.1f us vs 2 x mean ray %.1f us"
-      % (100 * (wg.max(1).mean() / us.mean() - 1), 2 * wg.max(1).mean(), 2 * us.mean()))
+# how evenly the work of a launch is spread: waves fetch rays dynamically; per-ray wall times and what they correlate with
+ws = o_["weights_sum"].cpu().numpy()
+hit = ws > 0.5
+print("%d waves; per-ray wall time (us): mean %.1f  std %.1f  min %.1f  max %.1f;  rays that hit the body (%d): %.1f, that miss: %.1f"
+      % (nw, ray_us.mean(), ray_us.std(), ray_us.min(), ray_us.max(), int(hit.sum()), ray_us[hit].mean() if hit.any() else 0, ray_us[~hit].mean()))
+col = np.arange(4096) % 256
+print("by image column (16 bins):", " ".join("%.0f" % ray_us[(col // 16) == b].mean() for b in range(16)))
+print("per-wave busy time (us): mean %.1f  min %.1f  max %.1f  (kernel ends with the slowest wave)" % ((pa[:, 9] / 100).mean(), (pa[:, 9] / 100).min(), (pa[:, 9] / 100).max()))
