@@ -88,6 +88,14 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         bid = k * q + (k < r ? k : r) + (blockIdx.x >> 3);
     }
 #endif
+    // Staggered start: wave w of a workgroup begins AC_START_STAGGER x 4096 clocks (~2 us each) x w late.  All 2048 waves of a launch would otherwise walk
+    // through the same phases of their first ray together (every wave gathering, then every wave in the MLPs): rays of the first round took 350 .. 420 us
+    // against 280 .. 330 us for the ones fetched later, when the waves have drifted apart (tools/phase_profile.py).  3 = 6 us per wave index, 41 us for
+    // the last wave of a workgroup; the plateau is wide (4 .. 8 us per index), larger steps lose more at the end of the launch than they gain.
+#ifndef AC_START_STAGGER
+#define AC_START_STAGGER 3
+#endif
+    for (int k_ = 0; k_ < AC_START_STAGGER * wave; ++k_) __builtin_amdgcn_s_sleep(64);
 #if AC_DYNAMIC_RAYS
     // waves fetch rays one at a time from their XCD's counter (XCD k owns the k-th contiguous eighth of the batch, as with the static mapping): a
     // workgroup no longer waits for the slowest of its eight rays before the next eight start (per-ray time varies by ~9 %)

@@ -13,7 +13,8 @@ from tests.common import load_golden, make_rays
 from tests.gpu_common import device_field
 p = load_golden("nsr_params.npz"); f, _ = device_field(p)
 ro, rd = make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)
-ro, rd = torch.from_numpy(ro[:4096].copy()).cuda(), torch.from_numpy(rd[:4096].copy()).cuda()
+B0 = int(os.environ.get("BATCH", 0)) * 4096
+ro, rd = torch.from_numpy(ro[B0:B0 + 4096].copy()).cuda(), torch.from_numpy(rd[B0:B0 + 4096].copy()).cuda()
 prof = torch.zeros(4096 * 11, dtype=torch.int64, device="cuda")
 _lib.lib().ac_debug_set_prof(prof.data_ptr())
 for _ in range(3):
@@ -39,5 +40,7 @@ hit = ws > 0.5
 print("%d waves; per-ray wall time (us): mean %.1f  std %.1f  min %.1f  max %.1f;  rays that hit the body (%d): %.1f, that miss: %.1f"
       % (nw, ray_us.mean(), ray_us.std(), ray_us.min(), ray_us.max(), int(hit.sum()), ray_us[hit].mean() if hit.any() else 0, ray_us[~hit].mean()))
 col = np.arange(4096) % 256
+rowi = np.arange(4096) // 256
+print("by image row (16):", " ".join("%.0f" % ray_us[rowi == b].mean() for b in range(16)))
 print("by image column (16 bins):", " ".join("%.0f" % ray_us[(col // 16) == b].mean() for b in range(16)))
 print("per-wave busy time (us): mean %.1f  min %.1f  max %.1f  (kernel ends with the slowest wave)" % ((pa[:, 9] / 100).mean(), (pa[:, 9] / 100).min(), (pa[:, 9] / 100).max()))
