@@ -353,68 +353,68 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)      // 10 bits -> ever
     return v;
 }
 
-// one workgroup of 1024 threads: centroid bounds, Morton keys, bitonic sort (key << 32 | face id) in LDS
-__global__ __launch_bounds__(1024) void accel_sort_kernel(const float *__restrict__ verts, const int32_t *__restrict__ faces, uint32_t F,
-                                                          uint32_t *__restrict__ sorted)
+// Face order along a Morton curve.  Keys ((30-bit code of the centroid, quantised in the vertex bounding box that accel_grid_setup_kernel left in
+// the header) << 32 | face id) are unique, so the position of a face is the number of smaller keys: accel_keys_kernel writes the keys, the
+// (face block, key slice) grid of accel_rank_kernel counts, and the last slice of a face block to finish writes its part of the order.
+constexpr int HDR_BBOX = 32;                   // hdr[32..37]: vertex bounding box lo (3), hi (3)
+constexpr uint32_t SORT_SLICE = 1024;          // keys per slice (staged in LDS)
+struct SortScratch { unsigned long long *keys; uint32_t *rank, *done; };     // lives in the cfar segment until accel_cells_kernel overwrites it
+__host__ __device__ inline SortScratch sort_scratch(const AccelView &av)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];       // [16384]
-    __shared__ float red[6][1024];
-    const uint32_t t = threadIdx.x;
-    float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
-    for (uint32_t f = t; f < F; f += 1024) {
+    SortScratch s;
+    s.keys = reinterpret_cast<unsigned long long *>(av.cfar);
+    s.rank = reinterpret_cast<uint32_t *>(s.keys + MAX_ACCEL_FACES);
+    s.done = s.rank + MAX_ACCEL_FACES;
+    return s;
+}
+static_assert(((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4 >= (size_t)MAX_ACCEL_FACES * 12 + 4 * (MAX_ACCEL_FACES / 256), "sort scratch must fit the cfar segment");
+
+__global__ __launch_bounds__(256) void accel_keys_kernel(const float *__restrict__ verts, const int32_t *__restrict__ faces, uint32_t F, AccelView av)
+{
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    const SortScratch ss = sort_scratch(av);
+    if (threadIdx.x == 0) ss.done[blockIdx.x] = 0;
+    if (f >= MAX_ACCEL_FACES) return;
+    ss.rank[f] = 0;
+    if (f >= F) return;
+    uint32_t q[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float c = (verts[3 * (size_t)faces[3 * f] + k] + verts[3 * (size_t)faces[3 * f + 1] + k]) + verts[3 * (size_t)faces[3 * f + 2] + k];
-            lo[k] = c < lo[k] ? c : lo[k]; hi[k] = c > hi[k] ? c : hi[k];
-        }
+    for (int k = 0; k < 3; ++k) {
+        const float lo = __builtin_bit_cast(float, av.hdr[HDR_BBOX + k]), ext = __builtin_bit_cast(float, av.hdr[HDR_BBOX + 3 + k]) - lo;
+        const float inv = ext > 0.0f ? 1023.0f / (3.0f * ext) : 0.0f;
+        const float c = (verts[3 * (size_t)faces[3 * f] + k] + verts[3 * (size_t)faces[3 * f + 1] + k]) + verts[3 * (size_t)faces[3 * f + 2] + k];
+        float g = (c - 3.0f * lo) * inv;
+        g = g < 0.0f ? 0.0f : (g > 1023.0f ? 1023.0f : g);
+        q[k] = (uint32_t)g;
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { red[k][t] = lo[k]; red[3 + k][t] = hi[k]; }
+    const uint32_t m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    ss.keys[f] = ((unsigned long long)m << 32) | f;
+}
+
+__global__ __launch_bounds__(256) void accel_rank_kernel(uint32_t F, AccelView av)
+{
+    __shared__ unsigned long long sk[SORT_SLICE];
+    __shared__ uint32_t last;
+    const SortScratch ss = sort_scratch(av);
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t k0 = blockIdx.y * SORT_SLICE, kn = F - k0 < SORT_SLICE ? F - k0 : SORT_SLICE;
+    for (uint32_t i = threadIdx.x; i < kn; i += 256) sk[i] = ss.keys[k0 + i];
     __syncthreads();
-    for (uint32_t s = 512; s > 0; s >>= 1) {
-        if (t < s) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                red[k][t] = red[k][t + s] < red[k][t] ? red[k][t + s] : red[k][t];
-                red[3 + k][t] = red[3 + k][t + s] > red[3 + k][t] ? red[3 + k][t + s] : red[3 + k][t];
-            }
-        }
-        __syncthreads();
+    if (f < F) {
+        const unsigned long long mine = ss.keys[f];
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < kn; ++i) cnt += sk[i] < mine ? 1u : 0u;
+        if (cnt) atomicAdd(&ss.rank[f], cnt);
     }
-    float org[3], inv[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { org[k] = red[k][0]; const float ext = red[3 + k][0] - red[k][0]; inv[k] = ext > 0.0f ? 1023.0f / ext : 0.0f; }
-    for (uint32_t f = t; f < MAX_ACCEL_FACES; f += 1024) {
-        unsigned long long key = ~0ull;
-        if (f < F) {
-            uint32_t q[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float c = (verts[3 * (size_t)faces[3 * f] + k] + verts[3 * (size_t)faces[3 * f + 1] + k]) + verts[3 * (size_t)faces[3 * f + 2] + k];
-                float g = (c - org[k]) * inv[k];
-                g = g < 0.0f ? 0.0f : (g > 1023.0f ? 1023.0f : g);
-                q[k] = (uint32_t)g;
-            }
-            const uint32_t m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-            key = ((unsigned long long)m << 32) | f;
-        }
-        keys[f] = key;
-    }
+    __threadfence();
     __syncthreads();
-    for (uint32_t k = 2; k <= MAX_ACCEL_FACES; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = t; i < MAX_ACCEL_FACES; i += 1024) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = keys[i], b = keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t f = t; f < MAX_ACCEL_FACES; f += 1024) sorted[f] = (uint32_t)(keys[f] & 0xffffffffull);
+    if (threadIdx.x == 0) last = atomicAdd(&ss.done[blockIdx.x], 1u) == gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (f < F) av.sorted[__hip_atomic_load(&ss.rank[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = f;
+    // the slots behind the last face (the tile builder repeats the last face there and never reads them)
+    for (uint32_t p = F + f; p < MAX_ACCEL_FACES; p += gridDim.x * 256) av.sorted[p] = 0xffffffffu;
 }
 
 // identity order (meshes the sort kernel does not cover are not accelerated at all; kept for tests of the tile builder)
@@ -676,6 +676,7 @@ __global__ __launch_bounds__(1024) void accel_grid_setup_kernel(const float *__r
         }
         __syncthreads();
     }
+    if (t < 6) av.hdr[HDR_BBOX + t] = __builtin_bit_cast(uint32_t, red[t][0]);
     if (t < (uint32_t)GRID_LEVELS) {
         const int l = (int)t;
         const float margin = l == 0 ? AC_GRID_MARGIN0 : AC_GRID_MARGIN1;
@@ -1224,13 +1225,12 @@ AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_
     if (need == 0) { ac::set_error("warp_accel_build: %u faces not supported (1..%u); use ac_warp_samples", F, MAX_ACCEL_FACES); return AC_ERR_BAD_ARG; }
     if (!verts || !faces || !accel || accel_bytes < need) { ac::set_error("warp_accel_build: NULL buffer or accel buffer smaller than %zu bytes", need); return AC_ERR_BAD_ARG; }
     const AccelView av = accel_view(accel);
-    static uint64_t seen = 0;
-    const size_t lds = (size_t)MAX_ACCEL_FACES * 8;
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(accel_sort_kernel), lds);
-    hipLaunchKernelGGL(accel_sort_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, verts, faces, F, av.sorted);
-    hipLaunchKernelGGL(accel_tiles_kernel, dim3(MAX_TILES / TPB), dim3(256), 0, (hipStream_t)stream, verts, faces, F, av);
-    // the cell grid: parameters from the vertex bounding box, then one wave per cell (strided over a grid that fills the device)
+    // grid parameters and the vertex bounding box (one workgroup), the Morton order of the faces (keys, then ranks), the tiles, then one wave per
+    // cell (strided over a grid that fills the device)
     hipLaunchKernelGGL(accel_grid_setup_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, verts, V, av);
+    hipLaunchKernelGGL(accel_keys_kernel, dim3(MAX_ACCEL_FACES / 256), dim3(256), 0, (hipStream_t)stream, verts, faces, F, av);
+    hipLaunchKernelGGL(accel_rank_kernel, dim3((F + 255) / 256, (F + SORT_SLICE - 1) / SORT_SLICE), dim3(256), 0, (hipStream_t)stream, F, av);
+    hipLaunchKernelGGL(accel_tiles_kernel, dim3(MAX_TILES / TPB), dim3(256), 0, (hipStream_t)stream, verts, faces, F, av);
     const size_t ntp = (((size_t)F + TILE_F - 1) / TILE_F + 63) / 64 * 64;
     const size_t lds_c = (size_t)NB * ntp * sizeof(float);
     static uint64_t seen_c = 0;
