@@ -34,6 +34,9 @@ namespace {
 #ifndef AC_DYNAMIC_RAYS
 #define AC_DYNAMIC_RAYS 1          // persistent workgroups (one per compute unit), rays handed out by per-XCD counters; 0: eight fixed rays per workgroup
 #endif
+#ifndef AC_XCD_CHUNK
+#define AC_XCD_CHUNK 512
+#endif
 #ifndef AC_FAST_COLOR
 #define AC_FAST_COLOR 1            // fast precision: the colour network in split bf16 too (0: only layer 1 of the finite-difference evaluations)
 #endif
@@ -97,14 +100,21 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 #endif
     for (int k_ = 0; k_ < AC_START_STAGGER * wave; ++k_) __builtin_amdgcn_s_sleep(64);
 #if AC_DYNAMIC_RAYS
-    // waves fetch rays one at a time from their XCD's counter (XCD k owns the k-th contiguous eighth of the batch, as with the static mapping): a
-    // workgroup no longer waits for the slowest of its eight rays before the next eight start (per-ray time varies by ~9 %)
-    const int xper = ((a.n_rays + 7) / 8 + 7) & ~7, xlo = (blockIdx.x & 7) * xper, xhi = (xlo + xper < a.n_rays) ? xlo + xper : a.n_rays;
+    // waves fetch rays one at a time from their XCD's counter: a workgroup no longer waits for the slowest of its eight rays before the next eight
+    // start (per-ray time varies by ~9 %).  The batch is dealt to the XCDs in chunks of AC_XCD_CHUNK consecutive rays (two image rows of a 256-wide
+    // view: neighbouring rays share grid cells in the XCD's L2), chunk c to XCD c % 8; a batch of up to 8 chunks is cut into eight contiguous parts.
+    // Large batches stay balanced that way when the body covers only some rows of the image (posed frames, skip_masked).
+    const int xper = ((a.n_rays + 7) / 8 + 7) & ~7, xchunk = xper < AC_XCD_CHUNK ? xper : AC_XCD_CHUNK, xcd = blockIdx.x & 7;
     for (;;) {
         int ray = 0;
-        if (lane == 0) ray = (int)atomicAdd(a.ray_counter + (blockIdx.x & 7), 1u);
-        ray = xlo + __builtin_amdgcn_readfirstlane(ray);
-        if (ray >= xhi) break;
+        if (lane == 0) ray = (int)atomicAdd(a.ray_counter + xcd, 1u);
+        ray = __builtin_amdgcn_readfirstlane(ray);
+        {
+            const int k = ray / xchunk, base = (k * 8 + xcd) * xchunk;
+            if (base >= a.n_rays) break;
+            ray = base + (ray - k * xchunk);
+            if (ray >= a.n_rays) continue;
+        }
         (void)bid;
 #else
     for (int ray = bid * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {

@@ -393,17 +393,19 @@ __global__ __launch_bounds__(256) void accel_keys_kernel(const float *__restrict
 
 __global__ __launch_bounds__(256) void accel_rank_kernel(uint32_t F, AccelView av)
 {
-    __shared__ unsigned long long sk[SORT_SLICE];
+    __shared__ __attribute__((aligned(16))) unsigned long long sk[SORT_SLICE];
     __shared__ uint32_t last;
     const SortScratch ss = sort_scratch(av);
     const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t k0 = blockIdx.y * SORT_SLICE, kn = F - k0 < SORT_SLICE ? F - k0 : SORT_SLICE;
-    for (uint32_t i = threadIdx.x; i < kn; i += 256) sk[i] = ss.keys[k0 + i];
+    const uint32_t k0 = blockIdx.y * SORT_SLICE;
+    for (uint32_t i = threadIdx.x; i < SORT_SLICE; i += 256) sk[i] = k0 + i < F ? ss.keys[k0 + i] : ~0ull;      // (no key is below a padding key)
     __syncthreads();
     if (f < F) {
         const unsigned long long mine = ss.keys[f];
+        const ulonglong2 *sk2 = reinterpret_cast<const ulonglong2 *>(sk);
         uint32_t cnt = 0;
-        for (uint32_t i = 0; i < kn; ++i) cnt += sk[i] < mine ? 1u : 0u;
+#pragma unroll 16
+        for (uint32_t i = 0; i < SORT_SLICE / 2; ++i) { const ulonglong2 v = sk2[i]; cnt += (v.x < mine ? 1u : 0u) + (v.y < mine ? 1u : 0u); }
         if (cnt) atomicAdd(&ss.rank[f], cnt);
     }
     __threadfence();

@@ -47,9 +47,13 @@ def render_canonical_360(net, n_views=100, render_hw=(256, 256), center=(0.0, 0.
 
 
 def render_animation(net, body_model, cam_pose, poses=None, render_type="animate", shape_from=None, shape_to=None, resolution=256, max_frames=100,
-                     white_bkg=True, rays_per_batch=64 * 128, device="cuda"):
+                     white_bkg=True, rays_per_batch=None, device="cuda"):
     """yields (frame index, rgb [res,res,3]) for an SMPL pose sequence (render_type "animate", poses [F,72]) or a shape interpolation
-    ("interp_shape", shape_from / shape_to [1,10]), seen from the dataset camera `cam_pose` [4,4]; 32 + 32 samples per ray like the reference"""
+    ("interp_shape", shape_from / shape_to [1,10]), seen from the dataset camera `cam_pose` [4,4]; 32 + 32 samples per ray like the reference.
+    rays_per_batch: the reference cuts a frame into 64 * 128 = 8192-ray batches (render_warp.py) to bound its memory; the default here is the whole
+    frame in one batch (0.5 GB of scratch at 256 x 256): same pixels, and the launches are full when the body covers a fraction of the image"""
+    if rays_per_batch is None:
+        rays_per_batch = resolution * resolution
     if hasattr(net, "skip_masked_samples"):
         net.skip_masked_samples = True          # the loop keeps rgb only: samples the warp masks out (alpha * 0) need no field evaluation (bit-identical pixels)
     world_verts, Ts, n_frames = calc_local_trans(body_model, render_type=render_type, poses=poses, shape_from=shape_from, shape_to=shape_to,

@@ -234,7 +234,7 @@ def cpu_baseline_sds(p, table, n_side=16, threads=None):
 
 def time_posed_frame(dev, p, table, frames, cpu=True):
     """secondary metric: ms per 256x256 frame of render_warp.py (BASELINE config 4): posed-space rendering, 32+32 samples per ray,
-    8192-ray batches like the reference driver, SMPL-sized synthetic body (6 891 vertices / 13 778 faces, per-vertex 4x4), mesh uploaded
+    the whole frame in one ray batch as drivers.render_animation does (the reference driver's 8192-ray batches are timed beside it), SMPL-sized synthetic body (6 891 vertices / 13 778 faces, per-vertex 4x4), mesh uploaded
     and its culling structure rebuilt once per frame.  The reference does the two warps of every batch on the CPU (libigl).
     roofline: SURVEY 8(d)'s 507 904 gather bytes per ray (496 hash evaluations) x 65 536 rays / frame time."""
     from avatarcraft_amd.render_utils import render_instantnsr_naive
@@ -245,20 +245,26 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     ro_h, rd_h = make_rays(256, 256, dist=1.8, f=443.405 / 2, yaw=0.3, pitch=-0.1)
     ro, rd = torch.from_numpy(ro_h).to(dev), torch.from_numpy(rd_h).to(dev)
 
-    def frame():
-        rgb, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=8192, requires_grad=False, render_can=False, perturb=False, verts=verts, faces=faces,
+    def frame(rpb=65536):
+        rgb, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=rpb, requires_grad=False, render_can=False, perturb=False, verts=verts, faces=faces,
                                          Ts=Ts, num_steps=32, upsample_steps=32, bound=1.6)
         return rgb
-    frame(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(frames):
-        rgb = frame()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / frames
+
+    def timed(rpb):
+        rgb = frame(rpb); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            rgb = frame(rpb)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / frames, rgb
+    dt8, rgb8 = timed(8192)
+    dt, rgb = timed(65536)
+    same = bool(torch.equal(rgb, rgb8))
     bytes_frame = 65536 * 496 * 1024
     ach = bytes_frame / dt / 1e9
     res = {"ms_per_frame": dt * 1e3, "rays_per_s": 65536 / dt, "frames": frames, "samples_per_ray": "32+32", "mesh": "synthetic 6891 verts / 13778 faces",
-           "skip_masked": True,
+           "skip_masked": True, "rays_per_batch": 65536,
+           "ms_per_frame_8192_ray_batches": dt8 * 1e3, "pixels_identical_across_batch_sizes": same,
            "covered": float((rgb < 0.999).any(dim=1).float().mean()),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_frame": bytes_frame, "note": "NOMINAL gather bytes of the field (every sample of every ray evaluated, as the reference does); with skip_masked the final pass evaluates only the tiles that hold an unmasked sample, so the achieved figure is an upper bound of the traffic actually moved; the frame also runs 6.3 M exact closest-face "
