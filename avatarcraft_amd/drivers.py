@@ -51,7 +51,7 @@ def render_animation(net, body_model, cam_pose, poses=None, render_type="animate
     """yields (frame index, rgb [res,res,3]) for an SMPL pose sequence (render_type "animate", poses [F,72]) or a shape interpolation
     ("interp_shape", shape_from / shape_to [1,10]), seen from the dataset camera `cam_pose` [4,4]; 32 + 32 samples per ray like the reference.
     rays_per_batch: the reference cuts a frame into 64 * 128 = 8192-ray batches (render_warp.py) to bound its memory; the default here is the whole
-    frame in one batch (0.5 GB of scratch at 256 x 256): same pixels, and the launches are full when the body covers a fraction of the image"""
+    frame in one batch (0.13 GB of scratch at 256 x 256): same pixels, and the launches are full when the body covers a fraction of the image"""
     if rays_per_batch is None:
         rays_per_batch = resolution * resolution
     if hasattr(net, "skip_masked_samples"):
