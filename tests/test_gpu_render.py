@@ -281,6 +281,47 @@ def test_warped_render_bitwise_vs_oracle(env, T0, up, guide, perturb):
     assert 0.02 < r["mask"].mean() < 0.7 and r["weights_sum"].max() > 0.5
 
 
+@pytest.mark.parametrize("n", [4097, 5000, 8192 + 24, 65536])
+def test_render_batching_invariance_large_and_ragged(env, n):
+    """one launch of n rays == 4096-ray launches, bit for bit: above 4096 rays the kernel deals the batch to the XCDs in interleaved 512-ray chunks
+    (render_fused.hip, AC_XCD_CHUNK), with a partial last chunk for ragged n -- every ray must be rendered exactly once"""
+    from avatarcraft_amd import nsr_ops
+    ro, rd = make_rays(256, 256, dist=1.7, f=200.0)
+    d = "cuda:0"
+    ro_t, rd_t = torch.from_numpy(ro[:n]).to(d).contiguous(), torch.from_numpy(rd[:n]).to(d).contiguous()
+    keys = ("image", "depth", "weights_sum", "z_vals", "weights")
+    parts = []
+    for i in range(0, n, 4096):
+        o = nsr_ops.render_rays(env["f"], ro_t[i:i + 4096], rd_t[i:i + 4096], 64, 64, 1.6, float(env["p"]["inv_s"]), extras=True)
+        parts.append({k: o[k].clone() for k in keys})
+    big = nsr_ops.render_rays(env["f"], ro_t, rd_t, 64, 64, 1.6, float(env["p"]["inv_s"]), extras=True)
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(big[k], torch.cat([q[k] for q in parts])), k
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_warped_render_whole_frame_in_one_batch(env, skip):
+    """what drivers.render_animation does by default: the 65 536 rays of a posed 256x256 frame in ONE batch == the reference driver's 8192-ray batches"""
+    from avatarcraft_amd import nsr_ops
+    from tests.common import make_body
+    verts, faces, Ts = make_body(n_lat=83, n_lon=83)
+    ro, rd = make_rays(256, 256, dist=1.8, f=0.78125 * 256)
+    d = "cuda:0"
+    ro_t, rd_t = torch.from_numpy(ro).to(d), torch.from_numpy(rd).to(d)
+    wm = nsr_ops.WarpMesh(verts, faces, Ts, d, use_mesh_guide=True)
+    kw = dict(warp=wm, skip_masked=skip)
+    parts = []
+    for i in range(0, 65536, 8192):
+        o = nsr_ops.render_rays(env["f"], ro_t[i:i + 8192], rd_t[i:i + 8192], 32, 32, 1.6, float(env["p"]["inv_s"]), **kw)
+        parts.append({k: o[k].clone() for k in ("image", "depth", "weights_sum")})
+    big = nsr_ops.render_rays(env["f"], ro_t, rd_t, 32, 32, 1.6, float(env["p"]["inv_s"]), **kw)
+    torch.cuda.synchronize()
+    for k in ("image", "depth", "weights_sum"):
+        assert torch.equal(big[k], torch.cat([q[k] for q in parts])), k
+    assert 0.05 < float((big["weights_sum"] > 0.5).float().mean()) < 0.6
+
+
 def test_warped_render_full_batch_vs_oracle(env):
     """BASELINE configuration 4 at its real size: one 8192-ray batch of the 256x256 posed frame (32+32 samples, mesh-guided range, SMPL-sized body of
     6 891 vertices / 13 778 faces) -- every output of the posed-space renderer, the warp mask and the warped mid points, bit for bit against the oracle

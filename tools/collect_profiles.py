@@ -25,6 +25,9 @@ dst = os.path.join(ROOT, "profiles")
 short = lambda n: re.sub(r"\(anonymous namespace\)::|void ", "", n).split("(")[0]
 
 
+WHOLE_VIEW = 4          # bench.py's informational whole-view launches of the same kernel, between the main bench and the SDS steps
+
+
 def main():
     shutil.copy(glob.glob(src + "/kt/**/p_kernel_stats.csv", recursive=True)[0], f"{dst}/{rnd}_kernel_stats.csv")
     shutil.copy(src + "/summary.json", f"{dst}/{rnd}_pmc_summary.json")
@@ -38,7 +41,8 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     full = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "render_rays_kernel<0" in r["Kernel_Name"]]
     split = {"render_rays_kernel<0> main bench, timed launches": full[W:W + K], "render_rays_kernel<0> main bench, warm-up": full[:W],
-             "render_rays_kernel<0> SDS step (training view: every ray hits the body)": full[W + K:]}
+             "render_rays_kernel<0> whole view (65 536 rays) in one launch": full[W + K:W + K + WHOLE_VIEW],
+             "render_rays_kernel<0> SDS step (training view: every ray hits the body)": full[W + K + WHOLE_VIEW:]}
     byw = {k: dict(calls=len(v), avg_us=sum(v) / len(v), min_us=min(v), max_us=max(v)) for k, v in split.items() if v}
     byw["bench_line"] = dict(kernel_ms_hip_events=bench["roofline"]["kernel_ms"], ms_per_step=bench["ms_per_step"])
     json.dump(byw, open(f"{dst}/{rnd}_kernel_stats_by_workload.json", "w"), indent=1)
@@ -57,7 +61,7 @@ def main():
     n_main = pb["warmup"] + pb["steps"]
     rk = [k for k in fetch if k.startswith("render_rays_kernel<0")][0]
     main_f = fetch[rk][:n_main]
-    sds_f, sds_w = fetch[rk][n_main:], write[rk][n_main:]
+    sds_f, sds_w = fetch[rk][n_main + WHOLE_VIEW:], write[rk][n_main + WHOLE_VIEW:]
     KB = 1024
     mean = lambda v: sum(v) / len(v)
     step = 3 * (mean(sds_f) + mean(sds_w))
@@ -65,6 +69,19 @@ def main():
     for k in fetch:
         if any(s in k for s in ("hash_stencil_bwd", "bucket_acc", "sdf_stencil_bwd", "color_bwd", "composite_bwd", "core_mid", "core_normals")):
             parts[k] = (mean(fetch[k]) + mean(write[k])) * KB
+    # every counter of the render kernel split by workload (summary.json averages over all dispatches of a kernel name, and the fast kernel serves
+    # the main bench, the whole-view launches and the renders of the SDS steps)
+    byc = {}
+    for f in glob.glob(src + "/g*/p_counter_collection.csv"):
+        vals = collections.defaultdict(dict)
+        for r in csv.DictReader(open(f)):
+            if short(r["Kernel_Name"]) == rk:
+                vals[r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
+        for c, v in vals.items():
+            seq = [v[i] for i in sorted(v)]
+            byc[c] = {"main bench (4096 rays)": mean(seq[:n_main]), "whole view (65 536 rays)": mean(seq[n_main:n_main + WHOLE_VIEW]),
+                      "SDS renders (4096 rays, training view)": mean(seq[n_main + WHOLE_VIEW:])}
+    json.dump({"kernel": rk, "per_launch_mean_by_workload": byc}, open(f"{dst}/{rnd}_pmc_render_by_workload.json", "w"), indent=1)
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     traffic = {
         "render_rays_kernel_hbm_bytes_per_launch": int(mean(main_f) * KB),
@@ -78,6 +95,12 @@ def main():
                   "(profiles/r01_fetch_calibration.txt): for 8-byte gathers FETCH_SIZE is 64 B per L2 miss, no correction factor; memory-side counter, "
                   "Infinity-Cache hits included (L2-miss traffic, an upper bound of DRAM traffic).")}
     json.dump(traffic, open(f"{dst}/traffic.json", "w"), indent=1)
+    # the bench line of the trace pass read the PREVIOUS profile's traffic.json; the copy kept next to this profile carries this profile's counters
+    bench["roofline"]["traffic"] = traffic["render_rays_kernel_hbm_bytes_per_launch"]
+    if isinstance(bench.get("sds_step"), dict) and "roofline" in bench["sds_step"]:
+        bench["sds_step"]["roofline"]["traffic"] = traffic["sds_step_hbm_bytes_per_step"]
+    bench["_traffic_fields"] = f"from the PMC passes of this profile ({tag}), see traffic.json; everything else as printed by bench.py under rocprofv3 --kernel-trace"
+    json.dump(bench, open(f"{dst}/{rnd}_bench.json", "w"), indent=1)
     print(json.dumps(byw, indent=1))
     print(json.dumps({k: v for k, v in traffic.items() if k != "_note"}, indent=1))
 

@@ -1,2 +1,2 @@
-cd /tmp && export TMPDIR=/tmp
-SKIPS=1 SIZES=65536 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/posedprof -o s -- python $GRAFT_REPO_ROOT/tools/posed_batch_sweep.py 2>&1 | grep "ms per frame"
+cd $GRAFT_REPO_ROOT
+timeout 300 python tools/ray_order_probe.py 2>&1 | tail -6
