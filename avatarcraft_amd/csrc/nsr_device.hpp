@@ -525,9 +525,13 @@ __device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, const F
 // fe[e][j][c]: e = 0 centre, 1..6 = +x,-x,+y,-y,+z,-z ; pe[e] = the offset coordinate (clamped) of evaluation e.
 struct LvlC { float scale; uint32_t my, mz, offset, mask, hashed; };
 
+// GM (wave-uniform, RenderArgs::jmode of the level group): 1 = all four levels of the group are hashed -- xor only, which the compiler folds with the mask
+// into one three-input bit operation per corner; anything else = the per-lane choice between the dense and the hashed index
+template <int GM>
 __device__ __forceinline__ uint32_t gidx(const LvlC &L, uint32_t tx, uint32_t ty, uint32_t tz)
 {
-    return (L.hashed ? (tx ^ ty ^ tz) : (tx + ty + tz)) & L.mask;
+    if constexpr (GM == 1) return (tx ^ ty ^ tz) & L.mask;
+    else return (L.hashed ? (tx ^ ty ^ tz) : (tx + ty + tz)) & L.mask;
 }
 __device__ __forceinline__ void interp8(const u32x2 (&v)[8], float qx, float qy, float qz, bool oob, float &f0, float &f1)
 {
@@ -557,7 +561,7 @@ template <int K> __device__ __forceinline__ constexpr int face_corner(int b, int
 template <int K, int SIGN>   // SIGN 0: +eps, 1: -eps
 struct AxisGeo { float qk; bool need, oob; };
 
-template <int K, int SIGN>
+template <int K, int SIGN, int GM>
 __device__ __forceinline__ AxisGeo<K, SIGN> coarse_issue(rsrc_t table, const LvlC &L, const uint32_t (&gc)[3], const uint32_t (&tx)[2],
                                                        const uint32_t (&ty)[2], const uint32_t (&tz)[2], bool oob_c, float u,
                                                        u32x2 (&w)[4])
@@ -575,7 +579,7 @@ __device__ __forceinline__ AxisGeo<K, SIGN> coarse_issue(rsrc_t table, const Lvl
     for (int i = 0; i < 4; ++i) {
         const int c = face_corner<K>(0, i);
         const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
-        const uint32_t off = a.need ? (L.offset + gidx(L, ax, ay, az)) * 8u : 0xfffffff8u;
+        const uint32_t off = a.need ? (L.offset + gidx<GM>(L, ax, ay, az)) * 8u : 0xfffffff8u;
         w[i] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF(off), 0, 0);
     }
     return a;
@@ -598,7 +602,7 @@ __device__ __forceinline__ void coarse_finish(const AxisGeo<K, SIGN> &a, const u
 }
 
 // ---- fine level (eps spans one cell or more): every offset point gathers its own 8 corners ---------------------------
-template <int K>
+template <int K, int GM>
 __device__ __forceinline__ void fine_issue(rsrc_t table, const LvlC &L, const uint32_t (&tx)[2], const uint32_t (&ty)[2],
                                            const uint32_t (&tz)[2], bool oob_c, float u, u32x2 (&v)[8], float &qk, bool &oob)
 {
@@ -612,11 +616,115 @@ __device__ __forceinline__ void fine_issue(rsrc_t table, const LvlC &L, const ui
     for (int c = 0; c < 8; ++c) {
         const uint32_t tk = ((c >> K) & 1) ? t1 : t0;
         const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
-        v[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx(L, ax, ay, az)) * 8u), 0, 0);
+        v[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx<GM>(L, ax, ay, az)) * 8u), 0, 0);
     }
 }
 
 #define AC_FSTORE(E, F0, F1) { fslab[((E - 1) * 8 + 2 * j) * 64 + lane] = F0; fslab[((E - 1) * 8 + 2 * j + 1) * 64 + lane] = F1; }
+
+#ifndef AC_STENCIL_SPECIALIZE
+#define AC_STENCIL_SPECIALIZE 1      // a second copy of the stencil code for level groups that are hashed throughout (xor-only index arithmetic)
+#endif
+// one group of four levels (4j + g) of the stencil: centre features in c0 / c1, the six offset points' features to the slab
+template <int GM>
+__device__ __forceinline__ void stencil_levels(const float *__restrict__ lds, float *__restrict__ fslab, rsrc_t table, int lane, int g, int j, bool fine,
+                                               float ux, float uy, float uz, bool oob, float xp, float xm, float yp, float ym, float zp, float zm,
+                                               float &c0, float &c1)
+{
+    const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8);
+    const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
+    LvlC L; L.scale = __uint_as_float(r0.x); L.my = r0.y; L.mz = r0.z; L.offset = r0.w; L.mask = r1.x; L.hashed = r1.y;
+    float qc[3]; uint32_t gc[3];
+    {
+        const float qx = fma_(ux, L.scale, 0.5f), qy = fma_(uy, L.scale, 0.5f), qz = fma_(uz, L.scale, 0.5f);
+        gc[0] = (uint32_t)__builtin_floorf(qx); gc[1] = (uint32_t)__builtin_floorf(qy); gc[2] = (uint32_t)__builtin_floorf(qz);
+        qc[0] = qx - (float)gc[0]; qc[1] = qy - (float)gc[1]; qc[2] = qz - (float)gc[2];
+    }
+    uint32_t tx[2], ty[2], tz[2];
+    tx[0] = gc[0]; tx[1] = gc[0] + 1u; ty[0] = gc[1] * L.my; ty[1] = ty[0] + L.my; tz[0] = gc[2] * L.mz; tz[1] = tz[0] + L.mz;
+    u32x2 vc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        vc[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx<GM>(L, tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2])) * 8u), 0, 0);
+    if (!fine) {
+        u32x2 w0[4], w1[4], w2[4], w3[4], w4[4], w5[4];
+        const auto a0 = coarse_issue<0, 0, GM>(table, L, gc, tx, ty, tz, oob, xp, w0);
+        const auto a1 = coarse_issue<0, 1, GM>(table, L, gc, tx, ty, tz, oob, xm, w1);
+        const auto a2 = coarse_issue<1, 0, GM>(table, L, gc, tx, ty, tz, oob, yp, w2);
+        const auto a3 = coarse_issue<1, 1, GM>(table, L, gc, tx, ty, tz, oob, ym, w3);
+        const auto a4 = coarse_issue<2, 0, GM>(table, L, gc, tx, ty, tz, oob, zp, w4);
+        const auto a5 = coarse_issue<2, 1, GM>(table, L, gc, tx, ty, tz, oob, zm, w5);
+        __builtin_amdgcn_sched_barrier(0);
+        interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+        float f0, f1;
+        coarse_finish<0, 0>(a0, vc, w0, qc, f0, f1); AC_FSTORE(1, f0, f1)
+        coarse_finish<0, 1>(a1, vc, w1, qc, f0, f1); AC_FSTORE(2, f0, f1)
+        coarse_finish<1, 0>(a2, vc, w2, qc, f0, f1); AC_FSTORE(3, f0, f1)
+        coarse_finish<1, 1>(a3, vc, w3, qc, f0, f1); AC_FSTORE(4, f0, f1)
+        coarse_finish<2, 0>(a4, vc, w4, qc, f0, f1); AC_FSTORE(5, f0, f1)
+        coarse_finish<2, 1>(a5, vc, w5, qc, f0, f1); AC_FSTORE(6, f0, f1)
+    } else {
+#if AC_FINE_BATCH == 3     // all 48 gathers of the six offset points in flight at once: one memory round trip instead of three
+        u32x2 va[8], vb[8], vc2[8], vd[8], ve[8], vf[8];
+        float qa, qb, qc2, qd, qe, qf, f0, f1; bool oa, ob, oc2, od, oe, of;
+        fine_issue<0, GM>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
+        fine_issue<0, GM>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
+        fine_issue<1, GM>(table, L, tx, ty, tz, oob, yp, vc2, qc2, oc2);
+        fine_issue<1, GM>(table, L, tx, ty, tz, oob, ym, vd, qd, od);
+        fine_issue<2, GM>(table, L, tx, ty, tz, oob, zp, ve, qe, oe);
+        fine_issue<2, GM>(table, L, tx, ty, tz, oob, zm, vf, qf, of);
+        __builtin_amdgcn_sched_barrier(0);
+        interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+        interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
+        interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
+        interp8(vc2, qc[0], qc2, qc[2], oc2, f0, f1); AC_FSTORE(3, f0, f1)
+        interp8(vd, qc[0], qd, qc[2], od, f0, f1); AC_FSTORE(4, f0, f1)
+        interp8(ve, qc[0], qc[1], qe, oe, f0, f1); AC_FSTORE(5, f0, f1)
+        interp8(vf, qc[0], qc[1], qf, of, f0, f1); AC_FSTORE(6, f0, f1)
+#elif AC_FINE_BATCH == 2   // x and y offsets in one round trip, z offsets in a second one
+        u32x2 va[8], vb[8], vc2[8], vd[8];
+        float qa, qb, qc2, qd, f0, f1; bool oa, ob, oc2, od;
+        fine_issue<0, GM>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
+        fine_issue<0, GM>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
+        fine_issue<1, GM>(table, L, tx, ty, tz, oob, yp, vc2, qc2, oc2);
+        fine_issue<1, GM>(table, L, tx, ty, tz, oob, ym, vd, qd, od);
+        __builtin_amdgcn_sched_barrier(0);
+        interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+        interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
+        interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
+        __builtin_amdgcn_sched_barrier(0);
+        fine_issue<2, GM>(table, L, tx, ty, tz, oob, zp, va, qa, oa);
+        fine_issue<2, GM>(table, L, tx, ty, tz, oob, zm, vb, qb, ob);
+        __builtin_amdgcn_sched_barrier(0);
+        interp8(vc2, qc[0], qc2, qc[2], oc2, f0, f1); AC_FSTORE(3, f0, f1)
+        interp8(vd, qc[0], qd, qc[2], od, f0, f1); AC_FSTORE(4, f0, f1)
+        __builtin_amdgcn_sched_barrier(0);
+        interp8(va, qc[0], qc[1], qa, oa, f0, f1); AC_FSTORE(5, f0, f1)
+        interp8(vb, qc[0], qc[1], qb, ob, f0, f1); AC_FSTORE(6, f0, f1)
+#else
+        u32x2 va[8], vb[8];
+        float qa, qb, f0, f1; bool oa, ob;
+        fine_issue<0, GM>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
+        fine_issue<0, GM>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
+        __builtin_amdgcn_sched_barrier(0);
+        interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
+        interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
+        interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
+        __builtin_amdgcn_sched_barrier(0);
+        fine_issue<1, GM>(table, L, tx, ty, tz, oob, yp, va, qa, oa);
+        fine_issue<1, GM>(table, L, tx, ty, tz, oob, ym, vb, qb, ob);
+        __builtin_amdgcn_sched_barrier(0);
+        interp8(va, qc[0], qa, qc[2], oa, f0, f1); AC_FSTORE(3, f0, f1)
+        interp8(vb, qc[0], qb, qc[2], ob, f0, f1); AC_FSTORE(4, f0, f1)
+        __builtin_amdgcn_sched_barrier(0);
+        fine_issue<2, GM>(table, L, tx, ty, tz, oob, zp, va, qa, oa);
+        fine_issue<2, GM>(table, L, tx, ty, tz, oob, zm, vb, qb, ob);
+        __builtin_amdgcn_sched_barrier(0);
+        interp8(va, qc[0], qc[1], qa, oa, f0, f1); AC_FSTORE(5, f0, f1)
+        interp8(vb, qc[0], qc[1], qb, ob, f0, f1); AC_FSTORE(6, f0, f1)
+#endif
+    }
+}
 
 __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, float *__restrict__ fslab, const FieldCtx &fc, int lane,
                                                float px, float py, float pz, float eps, float (&fe0)[4][2])
@@ -632,100 +740,9 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
     const float zp = (clampf(pz + eps, -bound, bound) + bound) / two_bound, zm = (clampf(pz + (-eps), -bound, bound) + bound) / two_bound;
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {                           // one copy of each code path; results go to LDS / a rotating fe0
-        const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8);
-        const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + OFF_LVL + (4 * j + g) * 8 + 4);
-        LvlC L; L.scale = __uint_as_float(r0.x); L.my = r0.y; L.mz = r0.z; L.offset = r0.w; L.mask = r1.x; L.hashed = r1.y;
-        float qc[3]; uint32_t gc[3];
-        {
-            const float qx = fma_(ux, L.scale, 0.5f), qy = fma_(uy, L.scale, 0.5f), qz = fma_(uz, L.scale, 0.5f);
-            gc[0] = (uint32_t)__builtin_floorf(qx); gc[1] = (uint32_t)__builtin_floorf(qy); gc[2] = (uint32_t)__builtin_floorf(qz);
-            qc[0] = qx - (float)gc[0]; qc[1] = qy - (float)gc[1]; qc[2] = qz - (float)gc[2];
-        }
-        uint32_t tx[2], ty[2], tz[2];
-        tx[0] = gc[0]; tx[1] = gc[0] + 1u; ty[0] = gc[1] * L.my; ty[1] = ty[0] + L.my; tz[0] = gc[2] * L.mz; tz[1] = tz[0] + L.mz;
-        u32x2 vc[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            vc[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx(L, tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2])) * 8u), 0, 0);
         float c0, c1;
-        if (!fc.jfine[j]) {
-            u32x2 w0[4], w1[4], w2[4], w3[4], w4[4], w5[4];
-            const auto a0 = coarse_issue<0, 0>(table, L, gc, tx, ty, tz, oob, xp, w0);
-            const auto a1 = coarse_issue<0, 1>(table, L, gc, tx, ty, tz, oob, xm, w1);
-            const auto a2 = coarse_issue<1, 0>(table, L, gc, tx, ty, tz, oob, yp, w2);
-            const auto a3 = coarse_issue<1, 1>(table, L, gc, tx, ty, tz, oob, ym, w3);
-            const auto a4 = coarse_issue<2, 0>(table, L, gc, tx, ty, tz, oob, zp, w4);
-            const auto a5 = coarse_issue<2, 1>(table, L, gc, tx, ty, tz, oob, zm, w5);
-            __builtin_amdgcn_sched_barrier(0);
-            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
-            float f0, f1;
-            coarse_finish<0, 0>(a0, vc, w0, qc, f0, f1); AC_FSTORE(1, f0, f1)
-            coarse_finish<0, 1>(a1, vc, w1, qc, f0, f1); AC_FSTORE(2, f0, f1)
-            coarse_finish<1, 0>(a2, vc, w2, qc, f0, f1); AC_FSTORE(3, f0, f1)
-            coarse_finish<1, 1>(a3, vc, w3, qc, f0, f1); AC_FSTORE(4, f0, f1)
-            coarse_finish<2, 0>(a4, vc, w4, qc, f0, f1); AC_FSTORE(5, f0, f1)
-            coarse_finish<2, 1>(a5, vc, w5, qc, f0, f1); AC_FSTORE(6, f0, f1)
-        } else {
-#if AC_FINE_BATCH == 3     // all 48 gathers of the six offset points in flight at once: one memory round trip instead of three
-            u32x2 va[8], vb[8], vc2[8], vd[8], ve[8], vf[8];
-            float qa, qb, qc2, qd, qe, qf, f0, f1; bool oa, ob, oc2, od, oe, of;
-            fine_issue<0>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
-            fine_issue<0>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
-            fine_issue<1>(table, L, tx, ty, tz, oob, yp, vc2, qc2, oc2);
-            fine_issue<1>(table, L, tx, ty, tz, oob, ym, vd, qd, od);
-            fine_issue<2>(table, L, tx, ty, tz, oob, zp, ve, qe, oe);
-            fine_issue<2>(table, L, tx, ty, tz, oob, zm, vf, qf, of);
-            __builtin_amdgcn_sched_barrier(0);
-            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
-            interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
-            interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
-            interp8(vc2, qc[0], qc2, qc[2], oc2, f0, f1); AC_FSTORE(3, f0, f1)
-            interp8(vd, qc[0], qd, qc[2], od, f0, f1); AC_FSTORE(4, f0, f1)
-            interp8(ve, qc[0], qc[1], qe, oe, f0, f1); AC_FSTORE(5, f0, f1)
-            interp8(vf, qc[0], qc[1], qf, of, f0, f1); AC_FSTORE(6, f0, f1)
-#elif AC_FINE_BATCH == 2   // x and y offsets in one round trip, z offsets in a second one
-            u32x2 va[8], vb[8], vc2[8], vd[8];
-            float qa, qb, qc2, qd, f0, f1; bool oa, ob, oc2, od;
-            fine_issue<0>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
-            fine_issue<0>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
-            fine_issue<1>(table, L, tx, ty, tz, oob, yp, vc2, qc2, oc2);
-            fine_issue<1>(table, L, tx, ty, tz, oob, ym, vd, qd, od);
-            __builtin_amdgcn_sched_barrier(0);
-            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
-            interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
-            interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
-            __builtin_amdgcn_sched_barrier(0);
-            fine_issue<2>(table, L, tx, ty, tz, oob, zp, va, qa, oa);
-            fine_issue<2>(table, L, tx, ty, tz, oob, zm, vb, qb, ob);
-            __builtin_amdgcn_sched_barrier(0);
-            interp8(vc2, qc[0], qc2, qc[2], oc2, f0, f1); AC_FSTORE(3, f0, f1)
-            interp8(vd, qc[0], qd, qc[2], od, f0, f1); AC_FSTORE(4, f0, f1)
-            __builtin_amdgcn_sched_barrier(0);
-            interp8(va, qc[0], qc[1], qa, oa, f0, f1); AC_FSTORE(5, f0, f1)
-            interp8(vb, qc[0], qc[1], qb, ob, f0, f1); AC_FSTORE(6, f0, f1)
-#else
-            u32x2 va[8], vb[8];
-            float qa, qb, f0, f1; bool oa, ob;
-            fine_issue<0>(table, L, tx, ty, tz, oob, xp, va, qa, oa);
-            fine_issue<0>(table, L, tx, ty, tz, oob, xm, vb, qb, ob);
-            __builtin_amdgcn_sched_barrier(0);
-            interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
-            interp8(va, qa, qc[1], qc[2], oa, f0, f1); AC_FSTORE(1, f0, f1)
-            interp8(vb, qb, qc[1], qc[2], ob, f0, f1); AC_FSTORE(2, f0, f1)
-            __builtin_amdgcn_sched_barrier(0);
-            fine_issue<1>(table, L, tx, ty, tz, oob, yp, va, qa, oa);
-            fine_issue<1>(table, L, tx, ty, tz, oob, ym, vb, qb, ob);
-            __builtin_amdgcn_sched_barrier(0);
-            interp8(va, qc[0], qa, qc[2], oa, f0, f1); AC_FSTORE(3, f0, f1)
-            interp8(vb, qc[0], qb, qc[2], ob, f0, f1); AC_FSTORE(4, f0, f1)
-            __builtin_amdgcn_sched_barrier(0);
-            fine_issue<2>(table, L, tx, ty, tz, oob, zp, va, qa, oa);
-            fine_issue<2>(table, L, tx, ty, tz, oob, zm, vb, qb, ob);
-            __builtin_amdgcn_sched_barrier(0);
-            interp8(va, qc[0], qc[1], qa, oa, f0, f1); AC_FSTORE(5, f0, f1)
-            interp8(vb, qc[0], qc[1], qb, ob, f0, f1); AC_FSTORE(6, f0, f1)
-#endif
-        }
+        if (AC_STENCIL_SPECIALIZE && fc.jmode[j] == 1) stencil_levels<1>(lds, fslab, table, lane, g, j, fc.jfine[j] != 0, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
+        else stencil_levels<2>(lds, fslab, table, lane, g, j, fc.jfine[j] != 0, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
         // rotate the centre features into place: after the 4th iteration fe0[j] holds level 4j+g
         fe0[0][0] = fe0[1][0]; fe0[0][1] = fe0[1][1]; fe0[1][0] = fe0[2][0]; fe0[1][1] = fe0[2][1];
         fe0[2][0] = fe0[3][0]; fe0[2][1] = fe0[3][1]; fe0[3][0] = c0; fe0[3][1] = c1;

@@ -39,10 +39,15 @@ def main():
     # --- kernel trace split by workload: dispatch order is main bench (W + K launches), then the SDS steps, then the posed frames
     rows = list(csv.DictReader(open(glob.glob(src + "/kt/**/p_kernel_trace.csv", recursive=True)[0])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    full = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "render_rays_kernel<0" in r["Kernel_Name"]]
-    split = {"render_rays_kernel<0> main bench, timed launches": full[W:W + K], "render_rays_kernel<0> main bench, warm-up": full[:W],
-             "render_rays_kernel<0> whole view (65 536 rays) in one launch": full[W + K:W + K + WHOLE_VIEW],
-             "render_rays_kernel<0> SDS step (training view: every ray hits the body)": full[W + K + WHOLE_VIEW:]}
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    fast = [dur(r) for r in rows if "render_rays_kernel<0, true>" in r["Kernel_Name"]]
+    exact = [dur(r) for r in rows if "render_rays_kernel<0, false>" in r["Kernel_Name"]]
+    # bench.py (default precision fast): W + K fast launches, then the other mode (min(W, 2) + K exact launches), WHOLE_VIEW fast launches of 65 536
+    # rays, then the SDS steps (three fast renders each)
+    split = {"render_rays_kernel<0, fast> main bench, timed launches": fast[W:W + K], "render_rays_kernel<0, fast> main bench, warm-up": fast[:W],
+             "render_rays_kernel<0, exact> the other arithmetic mode, same launches (roofline.other_precision)": exact[min(W, 2):min(W, 2) + K],
+             "render_rays_kernel<0, fast> whole view (65 536 rays) in one launch": fast[W + K:W + K + WHOLE_VIEW],
+             "render_rays_kernel<0, fast> SDS step (training view: every ray hits the body)": fast[W + K + WHOLE_VIEW:]}
     byw = {k: dict(calls=len(v), avg_us=sum(v) / len(v), min_us=min(v), max_us=max(v)) for k, v in split.items() if v}
     byw["bench_line"] = dict(kernel_ms_hip_events=bench["roofline"]["kernel_ms"], ms_per_step=bench["ms_per_step"])
     json.dump(byw, open(f"{dst}/{rnd}_kernel_stats_by_workload.json", "w"), indent=1)
