@@ -738,11 +738,16 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
     const float xp = (clampf(px + eps, -bound, bound) + bound) / two_bound, xm = (clampf(px + (-eps), -bound, bound) + bound) / two_bound;
     const float yp = (clampf(py + eps, -bound, bound) + bound) / two_bound, ym = (clampf(py + (-eps), -bound, bound) + bound) / two_bound;
     const float zp = (clampf(pz + eps, -bound, bound) + bound) / two_bound, zm = (clampf(pz + (-eps), -bound, bound) + bound) / two_bound;
+    // jmode (2 bits each) and jfine (1 bit each) of the four level groups in one scalar register: indexed by the loop counter as arrays they
+    // would live in scratch memory, and the load of jfine[j] would sit between the centre's gathers and the offset points' (one more round trip)
+    const uint32_t jbits = (uint32_t)fc.jmode[0] | ((uint32_t)fc.jmode[1] << 2) | ((uint32_t)fc.jmode[2] << 4) | ((uint32_t)fc.jmode[3] << 6)
+                         | ((fc.jfine[0] ? 1u : 0u) << 8) | ((fc.jfine[1] ? 1u : 0u) << 9) | ((fc.jfine[2] ? 1u : 0u) << 10) | ((fc.jfine[3] ? 1u : 0u) << 11);
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {                           // one copy of each code path; results go to LDS / a rotating fe0
         float c0, c1;
-        if (AC_STENCIL_SPECIALIZE && fc.jmode[j] == 1) stencil_levels<1>(lds, fslab, table, lane, g, j, fc.jfine[j] != 0, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
-        else stencil_levels<2>(lds, fslab, table, lane, g, j, fc.jfine[j] != 0, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
+        const bool fine = (jbits >> (8 + j)) & 1u, hashed4 = ((jbits >> (2 * j)) & 3u) == 1u;
+        if (AC_STENCIL_SPECIALIZE && hashed4) stencil_levels<1>(lds, fslab, table, lane, g, j, fine, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
+        else stencil_levels<2>(lds, fslab, table, lane, g, j, fine, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
         // rotate the centre features into place: after the 4th iteration fe0[j] holds level 4j+g
         fe0[0][0] = fe0[1][0]; fe0[0][1] = fe0[1][1]; fe0[1][0] = fe0[2][0]; fe0[1][1] = fe0[2][1];
         fe0[2][0] = fe0[3][0]; fe0[2][1] = fe0[3][1]; fe0[3][0] = c0; fe0[3][1] = c1;
