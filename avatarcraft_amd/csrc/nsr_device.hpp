@@ -557,7 +557,10 @@ template <int K> __device__ __forceinline__ constexpr int face_corner(int b, int
 // ---- coarse level (eps*scale < 1 cell): an offset point lies in the centre cell or in the adjacent one, so it needs at
 // most ONE face the centre does not have (coordinate g+2 for +eps, g-1 for -eps).  All 8 + 6*4 gathers of the level
 // are issued as one batch (lanes that need nothing send an out-of-range offset: dropped by the descriptor's bounds
-// check), then the 7 interpolations run from registers: one memory round trip per level instead of seven.
+// check), then the 7 interpolations run from registers: one memory round trip per level instead of seven.  (As compiled, the compiler folds
+// coarse_finish's select into the offset points' loads -- register pre-set to the centre's corner, load under an exec mask, skipped when no lane of the
+// wave needs it -- so they leave after the centre's have returned: two round trips.  Forcing one batch was measured and changes nothing, the other wave
+// of the SIMD covers the second trip: profiles/r02_experiments.txt.)
 template <int K, int SIGN>   // SIGN 0: +eps, 1: -eps
 struct AxisGeo { float qk; bool need, oob; };
 
