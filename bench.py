@@ -64,7 +64,9 @@ def cpu_baseline(p, table, ro, rd, budget_s=12.0):
     idx = np.arange(0, ro.shape[0], max(1, ro.shape[0] // n))[:n]
     t0 = time.time(); O.render_rays(of, ro[idx], rd[idx], NUM_STEPS, UPSAMPLE_STEPS, 1.6, float(p["inv_s"]), extras=False); dt = time.time() - t0
     return dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
-                sample=f"{n} rays (every {max(1, ro.shape[0] // n)}-th ray of the 256x256 view), 64+64 samples, {dt:.1f} s wall, OpenMP over rays")
+                sample=f"{n} rays (every {max(1, ro.shape[0] // n)}-th ray of the 256x256 view), 64+64 samples, {dt:.1f} s wall, OpenMP over rays",
+                note="the C restatement of the reference's algorithm (oracle/), OpenMP over rays on every host core: faster than the reference's own "
+                     "torch-CPU path would be; a reported baseline, not the target")
 
 
 SAMPLES = NUM_STEPS + UPSAMPLE_STEPS
