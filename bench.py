@@ -284,6 +284,16 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     return res
 
 
+def _flush_c_stdio():
+    """RCCL printf()s a version banner when the first communicator is created; with stdout a pipe or a file it sits in C stdio's buffer until exit,
+    i.e. it would land AFTER a line printed from Python"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                         # noqa: BLE001
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -430,9 +440,17 @@ def main():
             res["cpu_baseline"] = cpu_baseline(p, table, ro, rd)
         if world > 1 and sds is not None and "error" not in sds:
             res["sds_step"]["note"] = "N > 1: one view per rank, one all-reduce (RCCL, sum then / world) of the flat 49 MB gradient per step"
-        print(json.dumps(res))
+        line = json.dumps(res)
+    else:
+        line = None
     if dist is not None:
+        _flush_c_stdio()                      # every rank: RCCL's banner out of C stdio's buffer now, not at exit (after rank 0's line)
+        dist.barrier()
         dist.destroy_process_group()
+    if line is not None:                      # the JSON line is the last thing the job writes to stdout
+        sys.stdout.flush(); sys.stderr.flush()
+        _flush_c_stdio()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
