@@ -79,20 +79,19 @@ __device__ __forceinline__ float dv_log1p(float x)
 }
 
 // torch.nn.Softplus(beta=100, threshold=20) (reference models/instant_nsr.py:231,591):
-//   softplus_100(x) = max(x, 0) + G(|100 x|),  G(a) = log1p(exp(-a)) / 100 from a 128-piece cubic table on [0, 32]
-//   (ac_sp_table.hpp; tools/gen_softplus_table.py) -- no exponential, no division: 14 VALU + one ds_read_b128.
-// spg: the table, [128][4] floats (LDS or global).  Bit-identical to oracle/ac_math.h: orc_softplus100.
+//   softplus_100(x) = max(x, 0) + G(|100 x|),  G(a) = log1p(exp(-a)) / 100 from a 128-piece cubic table on [0, 32] indexed in a4 = |400 x|
+//   (ac_sp_table.hpp; tools/gen_softplus_table.py; row 128 = 0) -- no exponential, no division: 10 VALU + one ds_read_b128
+//   (v_mul | v_min |.| | v_cvt_u32 | v_fract | v_lshlrev | 3 v_fma | 2 v_fma adding max(x, 0) as 0.5 x + 0.5 |x|); 14 before round 3.
+// spg: the table, [129][4] floats (LDS or global).  Bit-identical to oracle/ac_math.h: orc_softplus100.
 __device__ __forceinline__ float dv_softplus100(const float *__restrict__ spg, float x)
 {
-    const float t = x * 100.0f;
-    const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
-    int idx = (int)(am * 4.0f);
-    idx = idx > 127 ? 127 : idx;
-    const float v = fma_(-0.25f, (float)idx, am);
+    const float a4 = __builtin_fminf(__builtin_fabsf(x * 400.0f), 128.0f);
+    const uint32_t idx = (uint32_t)a4;
+    const float v = __builtin_amdgcn_fractf(a4);
     const float4 c = *reinterpret_cast<const float4 *>(spg + idx * 4);
     float q = c.w;
     q = fma_(q, v, c.z); q = fma_(q, v, c.y); q = fma_(q, v, c.x);
-    return fma_(x, 0.0f, (x > 0.0f ? x : 0.0f) + q);          // x * 0: NaN / inf propagate, finite x adds an exact zero
+    return fma_(0.5f, __builtin_fabsf(x), fma_(0.5f, x, q));
 }
 
 // N values at once: all table rows are requested before any of them is used -- one LDS round trip per batch instead of one per value
@@ -105,18 +104,16 @@ __device__ __forceinline__ void dv_softplus100_n(const float *__restrict__ spg, 
     float4 c[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const float t = x[i] * 100.0f;
-        const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
-        int idx = (int)(am * 4.0f);
-        idx = idx > 127 ? 127 : idx;
-        v[i] = fma_(-0.25f, (float)idx, am);
+        const float a4 = __builtin_fminf(__builtin_fabsf(x[i] * 400.0f), 128.0f);
+        const uint32_t idx = (uint32_t)a4;
+        v[i] = __builtin_amdgcn_fractf(a4);
         c[i] = *reinterpret_cast<const float4 *>(spg + idx * 4);
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         float q = c[i].w;
         q = fma_(q, v[i], c[i].z); q = fma_(q, v[i], c[i].y); q = fma_(q, v[i], c[i].x);
-        o[i] = fma_(x[i], 0.0f, (x[i] > 0.0f ? x[i] : 0.0f) + q);
+        o[i] = fma_(0.5f, __builtin_fabsf(x[i]), fma_(0.5f, x[i], q));
     }
 }
 

@@ -45,8 +45,9 @@ constexpr int OFF_B1 = OFF_C3F + 16 * 64;        // [64]
 constexpr int OFF_B2 = OFF_B1 + 64;              // [16]
 constexpr int OFF_LVL = OFF_B2 + 16;             // [16 levels][8 words]
 constexpr int OFF_LIN = OFF_LVL + 16 * 8;        // lin_z[64] + lin_u[16]
-constexpr int OFF_SPQ = OFF_LIN + 80;           // softplus G table [128][4]
-constexpr int OFF_WAVE = OFF_SPQ + 512;         // end of the weights every kernel shares; per-wave slabs of the training kernels start here
+constexpr int SPQ_FLOATS = 129 * 4;              // softplus G table [129][4] (row 128 = 0)
+constexpr int OFF_SPQ = OFF_LIN + 80;
+constexpr int OFF_WAVE = OFF_SPQ + SPQ_FLOATS;        // end of the weights every kernel shares; per-wave slabs of the training kernels start here
 constexpr int FE_SLAB = 6 * 8 * 64;                        // hash features of the 6 finite-difference points: [e-1][2j+c][lane]
 // the renderer only: layer 1 of sdf_net for the "fast" precision (ac_render_opts.precision = 1) -- the 32 feature columns of W1 split into
 // bf16 hi + lo in the A-fragment order of v_mfma_f32_16x16x32_bf16 (lane (unit m, group kk) holds k = 8 kk .. 8 kk + 7 = the eight
@@ -199,7 +200,7 @@ __device__ __forceinline__ void fill_lds_sdf(float *lds, const RenderArgs &a)
     }
     for (int e = threadIdx.x; e < 64; e += blockDim.x) lds[OFF_LIN + e] = e < a.T0 ? a.lin_z[e] : 0.0f;
     for (int e = threadIdx.x; e < 16; e += blockDim.x) lds[OFF_LIN + 64 + e] = a.lin_u ? a.lin_u[e] : 0.0f;
-    for (int e = threadIdx.x; e < 512; e += blockDim.x) lds[OFF_SPQ + e] = AC_SP_G[e >> 2][e & 3];
+    for (int e = threadIdx.x; e < SPQ_FLOATS; e += blockDim.x) lds[OFF_SPQ + e] = AC_SP_G[e >> 2][e & 3];
 }
 
 __device__ __forceinline__ void fill_lds_color(float *lds, const RenderArgs &a)

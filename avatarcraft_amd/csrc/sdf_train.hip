@@ -52,22 +52,20 @@ constexpr int BWD_LDS_FLOATS = OFF_TW + TW * TRAIN_SLAB;
 static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 constexpr int NPART = 64 * 36 + 16 * 64 + 16;      // dW1 [64][36] (column 35 = db1), dW2 [16][64], db2 [16]
 
-// softplus_100 and its derivative from the same table row: d/dx [max(x,0) + G(|100 x|)] = [x > 0] + sign(x) 100 G'(|100 x|)
+// softplus_100 and its derivative from the same table row: d/dx [max(x,0) + q(fract(|400 x|))] = [x > 0] + sign(x) 400 q'(v)
 __device__ __forceinline__ void softplus100_vg(const float *__restrict__ spg, float x, float &val, float &der)
 {
-    const float t = x * 100.0f;
-    const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
-    int idx = (int)(am * 4.0f);
-    idx = idx > 127 ? 127 : idx;
-    const float v = fma_(-0.25f, (float)idx, am);
+    const float a4 = __builtin_fminf(__builtin_fabsf(x * 400.0f), 128.0f);
+    const uint32_t idx = (uint32_t)a4;
+    const float v = __builtin_amdgcn_fractf(a4);
     const float4 c = *reinterpret_cast<const float4 *>(spg + idx * 4);
     float q = c.w;
     q = fma_(q, v, c.z); q = fma_(q, v, c.y); q = fma_(q, v, c.x);
     float dq = 3.0f * c.w;
     dq = fma_(dq, v, 2.0f * c.z); dq = fma_(dq, v, c.y);
     const bool pos = x > 0.0f;
-    val = (pos ? x : 0.0f) + q;
-    der = (pos ? 1.0f : 0.0f) + (pos ? 100.0f : -100.0f) * dq;
+    val = fma_(0.5f, __builtin_fabsf(x), fma_(0.5f, x, q));
+    der = (pos ? 1.0f : 0.0f) + (pos ? 400.0f : -400.0f) * dq;
 }
 
 // four values at once: the table rows are requested together (one LDS round trip per batch, see dv_softplus100_n)
@@ -76,11 +74,9 @@ __device__ __forceinline__ void softplus100_vg4(const float *__restrict__ spg, c
     float v[4]; float4 c[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float t = x[i] * 100.0f;
-        const float am = __builtin_fminf(__builtin_fabsf(t), 32.0f);
-        int idx = (int)(am * 4.0f);
-        idx = idx > 127 ? 127 : idx;
-        v[i] = fma_(-0.25f, (float)idx, am);
+        const float a4 = __builtin_fminf(__builtin_fabsf(x[i] * 400.0f), 128.0f);
+        const uint32_t idx = (uint32_t)a4;
+        v[i] = __builtin_amdgcn_fractf(a4);
         c[i] = *reinterpret_cast<const float4 *>(spg + idx * 4);
     }
 #pragma unroll
@@ -90,8 +86,8 @@ __device__ __forceinline__ void softplus100_vg4(const float *__restrict__ spg, c
         float dq = 3.0f * c[i].w;
         dq = fma_(dq, v[i], 2.0f * c[i].z); dq = fma_(dq, v[i], c[i].y);
         const bool pos = x[i] > 0.0f;
-        val[i] = (pos ? x[i] : 0.0f) + q;
-        der[i] = (pos ? 1.0f : 0.0f) + (pos ? 100.0f : -100.0f) * dq;
+        val[i] = fma_(0.5f, __builtin_fabsf(x[i]), fma_(0.5f, x[i], q));
+        der[i] = (pos ? 1.0f : 0.0f) + (pos ? 400.0f : -400.0f) * dq;
     }
 }
 
@@ -680,9 +676,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompArgs a_in,
 {
     CompArgs a = a_in;
     if (a.inv_s_dev) a.inv_s = *a.inv_s_dev;
-    __shared__ float spg[512];
+    __shared__ float spg[SPQ_FLOATS];
     __shared__ float zsh[4][128];
-    for (int e = threadIdx.x; e < 512; e += blockDim.x) spg[e] = AC_SP_G[e >> 2][e & 3];
+    for (int e = threadIdx.x; e < SPQ_FLOATS; e += blockDim.x) spg[e] = AC_SP_G[e >> 2][e & 3];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15;
     float *zr = zsh[wave];
@@ -735,9 +731,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a_in,
 {
     CompArgs a = a_in;
     if (a.inv_s_dev) a.inv_s = *a.inv_s_dev;
-    __shared__ float spg[512];
+    __shared__ float spg[SPQ_FLOATS];
     __shared__ float zsh[4][128], tex[4][128], wq[4][128], psum[4][128];
-    for (int e = threadIdx.x; e < 512; e += blockDim.x) spg[e] = AC_SP_G[e >> 2][e & 3];
+    for (int e = threadIdx.x; e < SPQ_FLOATS; e += blockDim.x) spg[e] = AC_SP_G[e >> 2][e & 3];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15;
     float *zr = zsh[wave];

@@ -89,21 +89,21 @@ static inline float orc_log1pf(float x)
 
 /* torch.nn.Softplus(beta=100, threshold=20) (reference models/instant_nsr.py:231,591):
  *     softplus_100(x) = log1p(exp(100 x)) / 100 = max(x, 0) + G(|100 x|),   G(a) = log1p(exp(-a)) / 100
- * G comes from a 128-piece cubic table on [0, 32] (ac_sp_table.h, tools/gen_softplus_table.py; max abs error 1.9e-9): one
- * multiply, one 16-byte table lookup, three fma, one add -- no exponential and no division.  For 100 x > 20 (torch's linear branch)
- * G < 2.1e-11 is below half an ulp of x, so x is returned exactly, as by torch.  NaN / inf inputs give NaN (x * 0). */
+ * G comes from a 128-piece cubic table on [0, 32] (ac_sp_table.h, tools/gen_softplus_table.py; max abs error 1.9e-9), indexed in
+ * a4 = |400 x| (index = int(a4), polynomial in fract(a4); row 128 = 0 for a >= 32): one multiply, one 16-byte table lookup, three fma --
+ * no exponential and no division.  max(x, 0) is added as 0.5 x + 0.5 |x| by two fma (NaN propagates; exact for 100 x > 20, torch's
+ * linear branch, where G < 2.1e-11 is far below half an ulp of x / 2; elsewhere two roundings of magnitude <= ulp(x / 2) / 2, which is
+ * the uncertainty x itself carries as a sum of 35 products).  +inf -> +inf; -inf -> NaN (torch: 0). */
 #include "ac_sp_table.h"
 static inline float orc_softplus100(float x)
 {
-    float t = x * 100.0f;
-    float am = fminf(fabsf(t), 32.0f);
-    int idx = (int)(am * 4.0f);
-    if (idx > 127) idx = 127;
-    float v = fmaf(-0.25f, (float)idx, am);
+    float a4 = fminf(fabsf(x * 400.0f), 128.0f);
+    int idx = (int)a4;
+    float v = a4 - floorf(a4);                       /* fract: exact */
     const float *c = AC_SP_G[idx];
     float q = c[3];
     q = fmaf(q, v, c[2]); q = fmaf(q, v, c[1]); q = fmaf(q, v, c[0]);
-    return fmaf(x, 0.0f, (x > 0.0f ? x : 0.0f) + q);
+    return fmaf(0.5f, fabsf(x), fmaf(0.5f, x, q));
 }
 
 /* torch.sigmoid: 1 / (1 + exp(-x)) */

@@ -66,7 +66,7 @@ def test_composite_kat(oracle):
 
 
 def test_deterministic_math_accuracy(oracle):
-    """exp/log1p/sigmoid of ac_math.h against float64 (<= 1.5 ulp); softplus within 2.1e-9 absolute + 1 ulp"""
+    """exp/log1p/sigmoid of ac_math.h against float64 (<= 1.5 ulp); softplus within 2.1e-9 absolute + 1 ulp of the value + half an ulp of x / 2"""
     L = oracle.lib()
     rs = np.random.RandomState(0)
     xs = rs.uniform(-87, 88, 4000).astype(np.float32)
@@ -79,8 +79,9 @@ def test_deterministic_math_accuracy(oracle):
     sp = np.array([L.orc_test_softplus100(float(v)) for v in ts])
     t32 = (ts * np.float32(100.0)).astype(np.float64)        # the reference rounds x*beta in fp32 too
     ref = np.where(t32 > 20, ts, np.log1p(np.exp(t32)) / 100)
-    # table softplus: max(x,0) + G(|100x|), |error of G| <= 1.9e-9 (tools/gen_softplus_table.py) + one rounding of the sum
-    assert np.max(np.abs(sp - ref) - 1.3e-7 * np.abs(ref)) < 2.1e-9
+    # table softplus: 0.5 x + 0.5 |x| + G(|100x|), |error of G| <= 1.9e-9 (tools/gen_softplus_table.py) + the rounding of the result + the rounding
+    # of the intermediate 0.5 x + G (<= half an ulp of x / 2: the uncertainty x itself carries as a sum of 35 fp32 products)
+    assert np.max(np.abs(sp - ref) - 1.3e-7 * np.abs(ref) - 3.0e-8 * np.abs(ts)) < 2.1e-9
     big = ts[t32 > 20]
     assert len(big) and all(L.orc_test_softplus100(float(v)) == np.float32(v) for v in big)      # torch's linear branch: x, exactly
     assert L.orc_test_softplus100(-5.0) >= 0.0 and L.orc_test_softplus100(-5.0) < 1e-15 and np.isnan(L.orc_test_softplus100(float("nan")))
