@@ -31,6 +31,18 @@ constexpr int MAXT = 128;
 #ifndef AC_FINE_BATCH
 #define AC_FINE_BATCH 3     // fine stencil levels: offset-point pairs gathered per memory round trip (1: x | y | z, 2: x+y | z, 3: all six: 221 VGPRs, -2 % time)
 #endif
+#ifndef AC_FACE_VALUE
+#define AC_FACE_VALUE 0     // fast precision: coarse-level features of the six offset points from bilinear face values (see coarse_finish_fv)
+#endif
+#ifndef AC_FV_SIGNS
+#define AC_FV_SIGNS 3       // (debug) bit 0: +eps, bit 1: -eps along z use the face-value form
+#endif
+#ifndef AC_FV_AXES
+#define AC_FV_AXES 7        // (debug) bit k: the face-value form is used for the offset points along axis k
+#endif
+#ifndef AC_SENTINEL_LOADS
+#define AC_SENTINEL_LOADS 0  // 1: lanes of a coarse level that need no new face send an out-of-range offset instead of being masked out (round 1 / 2; see coarse_issue)
+#endif
 #ifndef AC_ENC_ROUND
 #define AC_ENC_ROUND 2      // hash levels gathered per round per lane (registers vs loads in flight)
 #endif
@@ -583,8 +595,13 @@ __device__ __forceinline__ AxisGeo<K, SIGN> coarse_issue(rsrc_t table, const Lvl
     for (int i = 0; i < 4; ++i) {
         const int c = face_corner<K>(0, i);
         const uint32_t ax = K == 0 ? tk : tx[c & 1], ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
+#if AC_SENTINEL_LOADS
         const uint32_t off = a.need ? (L.offset + gidx<GM>(L, ax, ay, az)) * 8u : 0xfffffff8u;
         w[i] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF(off), 0, 0);
+#else
+        w[i] = u32x2{ 0u, 0u };
+        if (a.need) w[i] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx<GM>(L, ax, ay, az)) * 8u), 0, 0);
+#endif
     }
     return a;
 }
@@ -603,6 +620,41 @@ __device__ __forceinline__ void coarse_finish(const AxisGeo<K, SIGN> &a, const u
         else { v2[c].x = a.need ? vc[c ^ (1 << K)].x : vc[c].x; v2[c].y = a.need ? vc[c ^ (1 << K)].y : vc[c].y; }
     }
     interp8(v2, K == 0 ? a.qk : qc[0], K == 1 ? a.qk : qc[1], K == 2 ? a.qk : qc[2], a.oob, f0, f1);
+}
+
+// ---- fast precision only (AC_FACE_VALUE): an offset point differs from the centre along ONE axis, so its feature is the linear
+// interpolation, along that axis, of two bilinear FACE values -- (A, B) of the centre cell, (B, N) one cell up, (N, A) one cell down, N = the
+// gathered face -- with the centre's weights for the other two axes: 4 + 3 x (4 + 4 x 8) + 6 x 11 vector instructions per level instead of
+// 7 full 8-corner interpolations and their corner selects.  Same function, different rounding (not the oracle's order): the offset features
+// only feed the split-bf16 correction of layer 1, whose own error is 2^-16 of the difference.
+template <int K> __device__ __forceinline__ void face_weights(const float (&qc)[3], float (&fw)[4])
+{
+    const float qa = K == 0 ? qc[1] : qc[0], qb = K == 2 ? qc[1] : qc[2];        // the two other axes, in increasing order
+    const float a0 = 1.0f - qa, b0 = 1.0f - qb;
+    fw[0] = a0 * b0; fw[1] = qa * b0; fw[2] = a0 * qb; fw[3] = qa * qb;
+}
+template <int K> __device__ __forceinline__ void face_value(const u32x2 (&vc)[8], int b, const float (&fw)[4], float (&f)[2])
+{
+    float s0 = fw[0] * __uint_as_float(vc[face_corner<K>(b, 0)].x), s1 = fw[0] * __uint_as_float(vc[face_corner<K>(b, 0)].y);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        s0 = fma_(fw[i], __uint_as_float(vc[face_corner<K>(b, i)].x), s0);
+        s1 = fma_(fw[i], __uint_as_float(vc[face_corner<K>(b, i)].y), s1);
+    }
+    f[0] = s0; f[1] = s1;
+}
+template <int K, int SIGN>
+__device__ __forceinline__ void coarse_finish_fv(const AxisGeo<K, SIGN> &a, const float (&A)[2], const float (&B)[2], const u32x2 (&w)[4],
+                                                 const float (&fw)[4], float &f0, float &f1)
+{
+    float n0 = fw[0] * __uint_as_float(w[0].x), n1 = fw[0] * __uint_as_float(w[0].y);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) { n0 = fma_(fw[i], __uint_as_float(w[i].x), n0); n1 = fma_(fw[i], __uint_as_float(w[i].y), n1); }
+    const float x0 = a.need ? (SIGN == 0 ? B[0] : n0) : A[0], x1 = a.need ? (SIGN == 0 ? B[1] : n1) : A[1];
+    const float y0 = a.need ? (SIGN == 0 ? n0 : A[0]) : B[0], y1 = a.need ? (SIGN == 0 ? n1 : A[1]) : B[1];
+    const float r0 = fma_(a.qk, y0 - x0, x0), r1 = fma_(a.qk, y1 - x1, x1);
+    f0 = a.oob ? 0.0f : r0;
+    f1 = a.oob ? 0.0f : r1;
 }
 
 // ---- fine level (eps spans one cell or more): every offset point gathers its own 8 corners ---------------------------
@@ -630,7 +682,7 @@ __device__ __forceinline__ void fine_issue(rsrc_t table, const LvlC &L, const ui
 #define AC_STENCIL_SPECIALIZE 1      // a second copy of the stencil code for level groups that are hashed throughout (xor-only index arithmetic)
 #endif
 // one group of four levels (4j + g) of the stencil: centre features in c0 / c1, the six offset points' features to the slab
-template <int GM>
+template <int GM, int FV = 0>
 __device__ __forceinline__ void stencil_levels(const float *__restrict__ lds, float *__restrict__ fslab, rsrc_t table, int lane, int g, int j, bool fine,
                                                float ux, float uy, float uz, bool oob, float xp, float xm, float yp, float ym, float zp, float zm,
                                                float &c0, float &c1)
@@ -661,12 +713,45 @@ __device__ __forceinline__ void stencil_levels(const float *__restrict__ lds, fl
         __builtin_amdgcn_sched_barrier(0);
         interp8(vc, qc[0], qc[1], qc[2], oob, c0, c1);
         float f0, f1;
+        if constexpr (FV != 0) {
+            float fw[4], A[2], B[2];
+            if constexpr ((AC_FV_AXES & 1) != 0) {
+                face_weights<0>(qc, fw); face_value<0>(vc, 0, fw, A); face_value<0>(vc, 1, fw, B);
+                coarse_finish_fv<0, 0>(a0, A, B, w0, fw, f0, f1); AC_FSTORE(1, f0, f1)
+                coarse_finish_fv<0, 1>(a1, A, B, w1, fw, f0, f1); AC_FSTORE(2, f0, f1)
+            } else {
+                coarse_finish<0, 0>(a0, vc, w0, qc, f0, f1); AC_FSTORE(1, f0, f1)
+                coarse_finish<0, 1>(a1, vc, w1, qc, f0, f1); AC_FSTORE(2, f0, f1)
+            }
+            if constexpr ((AC_FV_AXES & 2) != 0) {
+                face_weights<1>(qc, fw); face_value<1>(vc, 0, fw, A); face_value<1>(vc, 1, fw, B);
+                coarse_finish_fv<1, 0>(a2, A, B, w2, fw, f0, f1); AC_FSTORE(3, f0, f1)
+                coarse_finish_fv<1, 1>(a3, A, B, w3, fw, f0, f1); AC_FSTORE(4, f0, f1)
+            } else {
+                coarse_finish<1, 0>(a2, vc, w2, qc, f0, f1); AC_FSTORE(3, f0, f1)
+                coarse_finish<1, 1>(a3, vc, w3, qc, f0, f1); AC_FSTORE(4, f0, f1)
+            }
+            if constexpr ((AC_FV_AXES & 4) != 0) {
+#ifdef AC_FV_DEBUG_NOP
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+                face_weights<2>(qc, fw); face_value<2>(vc, 0, fw, A); face_value<2>(vc, 1, fw, B);
+                if constexpr ((AC_FV_SIGNS & 1) != 0) { coarse_finish_fv<2, 0>(a4, A, B, w4, fw, f0, f1); } else { coarse_finish<2, 0>(a4, vc, w4, qc, f0, f1); }
+                AC_FSTORE(5, f0, f1)
+                if constexpr ((AC_FV_SIGNS & 2) != 0) { coarse_finish_fv<2, 1>(a5, A, B, w5, fw, f0, f1); } else { coarse_finish<2, 1>(a5, vc, w5, qc, f0, f1); }
+                AC_FSTORE(6, f0, f1)
+            } else {
+                coarse_finish<2, 0>(a4, vc, w4, qc, f0, f1); AC_FSTORE(5, f0, f1)
+                coarse_finish<2, 1>(a5, vc, w5, qc, f0, f1); AC_FSTORE(6, f0, f1)
+            }
+        } else {
         coarse_finish<0, 0>(a0, vc, w0, qc, f0, f1); AC_FSTORE(1, f0, f1)
         coarse_finish<0, 1>(a1, vc, w1, qc, f0, f1); AC_FSTORE(2, f0, f1)
         coarse_finish<1, 0>(a2, vc, w2, qc, f0, f1); AC_FSTORE(3, f0, f1)
         coarse_finish<1, 1>(a3, vc, w3, qc, f0, f1); AC_FSTORE(4, f0, f1)
         coarse_finish<2, 0>(a4, vc, w4, qc, f0, f1); AC_FSTORE(5, f0, f1)
         coarse_finish<2, 1>(a5, vc, w5, qc, f0, f1); AC_FSTORE(6, f0, f1)
+        }
     } else {
 #if AC_FINE_BATCH == 3     // all 48 gathers of the six offset points in flight at once: one memory round trip instead of three
         u32x2 va[8], vb[8], vc2[8], vd[8], ve[8], vf[8];
@@ -730,6 +815,7 @@ __device__ __forceinline__ void stencil_levels(const float *__restrict__ lds, fl
     }
 }
 
+template <int FV = 0>
 __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, float *__restrict__ fslab, const FieldCtx &fc, int lane,
                                                float px, float py, float pz, float eps, float (&fe0)[4][2])
 {
@@ -750,8 +836,8 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
     for (int j = 0; j < 4; ++j) {                           // one copy of each code path; results go to LDS / a rotating fe0
         float c0, c1;
         const bool fine = (jbits >> (8 + j)) & 1u, hashed4 = ((jbits >> (2 * j)) & 3u) == 1u;
-        if (AC_STENCIL_SPECIALIZE && hashed4) stencil_levels<1>(lds, fslab, table, lane, g, j, fine, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
-        else stencil_levels<2>(lds, fslab, table, lane, g, j, fine, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
+        if (AC_STENCIL_SPECIALIZE && hashed4) stencil_levels<1, FV>(lds, fslab, table, lane, g, j, fine, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
+        else stencil_levels<2, FV>(lds, fslab, table, lane, g, j, fine, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
         // rotate the centre features into place: after the 4th iteration fe0[j] holds level 4j+g
         fe0[0][0] = fe0[1][0]; fe0[0][1] = fe0[1][1]; fe0[1][0] = fe0[2][0]; fe0[1][1] = fe0[2][1];
         fe0[2][0] = fe0[3][0]; fe0[2][1] = fe0[3][1]; fe0[3][0] = c0; fe0[3][1] = c1;

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             float gr[3] = { 0.0f, 0.0f, 0.0f };
             if (!skip) {
             float fe0[4][2];
-            encode_stencil(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
+            encode_stencil<(FAST && AC_FACE_VALUE) ? 1 : 0>(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
             if (a.out.feat7) {                                     // training render: keep the 7 x 8 features of this lane (the backward streams them back)
                 const size_t nt4 = (size_t)a.n_rays * T * 4, at = ((size_t)ray * T + i) * 4 + g;
 #pragma unroll

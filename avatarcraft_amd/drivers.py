@@ -54,15 +54,22 @@ def render_animation(net, body_model, cam_pose, poses=None, render_type="animate
     frame in one batch (0.13 GB of scratch at 256 x 256): same pixels, and the launches are full when the body covers a fraction of the image"""
     if rays_per_batch is None:
         rays_per_batch = resolution * resolution
-    if hasattr(net, "skip_masked_samples"):
-        net.skip_masked_samples = True          # the loop keeps rgb only: samples the warp masks out (alpha * 0) need no field evaluation (bit-identical pixels)
     world_verts, Ts, n_frames = calc_local_trans(body_model, render_type=render_type, poses=poses, shape_from=shape_from, shape_to=shape_to,
                                                  max_frames=max_frames)
     faces = np.asarray(body_model.faces)
     ro, rd = gen_rays_pose(cam_pose, int(512 / resolution), device=device)
     ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
     for i in range(n_frames):
-        rgb, _, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch, requires_grad=False, bkg_key=WHITE_BKG if white_bkg else BLACK_BKG,
-                                            return_torch=True, perturb=False, return_raw=True, render_can=False, verts=world_verts[i], faces=faces,
-                                            Ts=Ts[i], num_steps=32, upsample_steps=32, bound=NSR_BOUND)
+        # the loop keeps rgb only: samples the warp masks out (alpha * 0) need no field evaluation (bit-identical pixels).  The switch is set around
+        # each frame's render and restored (also when the consumer abandons the generator): the caller's net keeps its documented default
+        prev = getattr(net, "skip_masked_samples", None)
+        if prev is not None:
+            net.skip_masked_samples = True
+        try:
+            rgb, _, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch, requires_grad=False, bkg_key=WHITE_BKG if white_bkg else BLACK_BKG,
+                                                return_torch=True, perturb=False, return_raw=True, render_can=False, verts=world_verts[i], faces=faces,
+                                                Ts=Ts[i], num_steps=32, upsample_steps=32, bound=NSR_BOUND)
+        finally:
+            if prev is not None:
+                net.skip_masked_samples = prev
         yield i, rgb.reshape(resolution, resolution, 3)

@@ -59,6 +59,71 @@ class NeRFRenderer(nn.Module):
             self.local_step = 0
 
     # ------------------------------------------------------------------ fused field handle
+    # The prepared ac_field views (ctypes structs holding raw device pointers) and the outputs of the last training render are caches, not state:
+    # they are left out of pickling / copy.deepcopy / torch.save(net) and rebuilt on the next render.
+    _CACHE_ATTRS = ("_field_cache", "_field_sdf_cache", "_last_train", "_offsets_cache", "_nan_pending")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._CACHE_ATTRS:
+            state.pop(k, None)
+        return state
+
+    def __deepcopy__(self, memo):
+        # (through pickling: the caches are dropped by __getstate__, and torch's own deepcopy refuses the non-leaf `weight` attribute that the
+        # old-style weight_norm hook leaves on every layer -- the reference's networks cannot be deep-copied at all)
+        import io
+        buf = io.BytesIO()
+        torch.save(self, buf)
+        buf.seek(0)
+        new = torch.load(buf, weights_only=False)
+        memo[id(self)] = new
+        return new
+
+    def invalidate_caches(self):
+        """Drop the prepared field views.  The caches are keyed by (data_ptr, tensor version) of every parameter and by the stream they were built
+        on, so ordinary training / load_state_dict invalidate them by themselves; call this after writing parameters behind autograd's back
+        (`param.data.copy_`, raw-pointer kernels, another stream) -- those do not bump the version counter."""
+        for k in self._CACHE_ATTRS:
+            self.__dict__.pop(k, None)
+        from . import ray_utils
+        ray_utils.invalidate_caches()
+
+    # The reference stops a training render on a NaN normal (`assert (gradient == gradient).all()`, instant_nsr.py:274), which costs it a host
+    # round trip per render.  Here every training render leaves a one-word "gradient_error is not finite" flag in pinned host memory behind an
+    # event; the flags of earlier renders are looked at (never waited for) on the next one, and check_finite() waits for all of them.
+    # A NaN therefore surfaces at most one step late instead of flowing into the optimizer unnoticed.  nan_guard = False switches it off.
+    nan_guard = True
+
+    def _guard_finite(self, gerr):
+        if not self.nan_guard or not isinstance(gerr, torch.Tensor) or not gerr.is_cuda:
+            if self.nan_guard and isinstance(gerr, torch.Tensor) and not bool(torch.isfinite(gerr).all()):
+                raise FloatingPointError("NaN / Inf in the finite-difference normals of a training render (reference: instant_nsr.py:274)")
+            return
+        pend = self.__dict__.setdefault("_nan_pending", [])
+        self._poll_finite(wait=False)
+        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(torch.isfinite(gerr.detach()).logical_not().reshape(1).to(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        pend.append((ev, host))
+
+    def _poll_finite(self, wait):
+        pend = self.__dict__.get("_nan_pending", [])
+        while pend and (wait or pend[0][0].query()):
+            ev, host = pend.pop(0)
+            ev.synchronize()
+            if int(host[0]):
+                pend.clear()
+                raise FloatingPointError("NaN / Inf in the finite-difference normals of a training render (reference: instant_nsr.py:274)")
+
+    def check_finite(self):
+        """wait for the NaN flags of every training render issued so far; raises FloatingPointError if one of them was set"""
+        self._poll_finite(wait=True)
+
+    def _cache_key(self, prm):
+        from . import _lib as L
+        return (int(L.current_stream(prm[0].device) or 0),) + tuple((t.data_ptr(), t._version) for t in prm)
+
     def _field(self):
         """ac_field view of the current parameters (effective = weight-normed matrices).  Cached while no parameter changes
         (tensor version counters): a frozen net (net_gt of stylize.py) builds it once, a training net once per optimizer step --
@@ -66,7 +131,7 @@ class NeRFRenderer(nn.Module):
         enc = self.encoder
         prm = [enc.embeddings, self.sdf_net[0].bias, self.sdf_net[1].bias] + [t for l in list(self.sdf_net) + list(self.color_net)
                                                                              for t in (l.weight_v, l.weight_g)]
-        key = tuple((t.data_ptr(), t._version) for t in prm)
+        key = self._cache_key(prm)
         cached = getattr(self, "_field_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -126,10 +191,11 @@ class NeRFRenderer(nn.Module):
     #           kept as the cross-check of "core");
     #   False : sampling launch + torch autograd over the stencil hash encoder (any model configuration).
     fused_training = "core"
-    # arithmetic of the fused renderer (ac_render_opts.precision): "fast" = the six finite-difference evaluations of a sample as split-bf16
-    # corrections of the centre's layer 1 (normals within 6e-5 of "exact", sample positions / indices / sdf bit-identical); "exact" = every
-    # product an fp32 fma in the oracle's order (GPU == CPU oracle bit for bit)
-    render_precision = "fast"
+    # arithmetic of the fused renderer (ac_render_opts.precision): "exact" (default since round 3: the mode that is pinned bit for bit) = every
+    # product an fp32 fma in the oracle's order, GPU == CPU oracle; "fast" (opt-in) = the six finite-difference evaluations of a sample as
+    # split-bf16 corrections of the centre's layer 1 and the colour network in split bf16 (normals within 6e-5 of "exact", sample positions /
+    # indices / sdf bit-identical).  A training render's backward differentiates the formulation its forward ran.
+    render_precision = "exact"
     # posed-space inference (render_can=False): samples the SMPL warp masks out contribute alpha * 0 = nothing.  True: tiles of 16 such samples are
     # not evaluated (pixels, depth, normals, weights unchanged bit for bit; the per-sample sdf / colour of skipped samples are 0 and gradient_error,
     # which no inference driver reads, covers the evaluated samples only).  False (default): every output as the reference computes it.
@@ -157,7 +223,7 @@ class NeRFRenderer(nn.Module):
         """ac_field with the SDF side only (zero colour matrices): the sampling stage of a model whose colour net the fused renderer does not cover"""
         enc = self.encoder
         prm = [enc.embeddings, self.sdf_net[0].bias, self.sdf_net[1].bias] + [t for l in self.sdf_net for t in (l.weight_v, l.weight_g)]
-        key = tuple((t.data_ptr(), t._version) for t in prm)
+        key = self._cache_key(prm)
         cached = getattr(self, "_field_sdf_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -213,6 +279,7 @@ class NeRFRenderer(nn.Module):
                 out = nsr_ops.render_rays(field, ro, rd, num_steps, upsample_steps, bound, inv_s_ng, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
                                           normal_epsilon_ratio=normal_epsilon_ratio, extras=True, train_extras=True, precision=self.render_precision)
             self._last_train = (out, ro, rd, bg, field)
+            self._guard_finite(out["eik_res"][0])
             return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3), out["normal_map"],
                     out["eik_res"][0], 0.0, out["color"], out["alpha"], out["z_vals"])
         if needs_grad and full and self.fused_training == "core" and near_far is None:
@@ -221,6 +288,7 @@ class NeRFRenderer(nn.Module):
             (image, wsum, depth, nmap, gerr, weights, alpha, color, z_vals) = nsr_ops.render_core(
                 enc.embeddings, W[0], self.sdf_net[0].bias, W[1], self.sdf_net[1].bias, W[2], W[3], W[4], inv_s_t, ro, rd, bg, noise, self._offsets_host(), enc.per_level_scale, enc.base_resolution,
                 num_steps, upsample_steps, bound, cos_anneal_ratio, normal_epsilon_ratio, precision=self.render_precision)
+            self._guard_finite(gerr)
             return depth.reshape(B, N), weights, wsum[:, None], image.reshape(B, N, 3), nmap, gerr, 0.0, color, alpha, z_vals
         if needs_grad or not full:
             # only the sample positions come from the fused (no-grad) stage (:176-184); the render core runs under autograd: through the fused
@@ -268,6 +336,7 @@ class NeRFRenderer(nn.Module):
         relax = (pts_norm < 1.2).float().detach()
         gerr = (torch.linalg.norm(gradient.reshape(N, T, 3), ord=2, dim=-1) - 1.0) ** 2
         gradient_error = (relax * gerr).sum() / (relax.sum() + 1e-5)
+        self._guard_finite(torch.linalg.norm(gradient.detach()) if gradient.is_cuda else gradient.detach().sum())    # :274 assert (gradient == gradient).all()
         curvature_error = 0.0
         if self.curvature_loss:                                  # :276-288
             random_vec = 2.0 * torch.randn_like(normal) - 1.0

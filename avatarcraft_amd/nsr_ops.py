@@ -262,6 +262,10 @@ def free_scratch():
 SAVE_STENCIL_FEATURES = os.environ.get("AC_NO_FEAT7", "0") != "1"
 
 
+# see _RenderCore.backward: False = the table gradient goes through autograd (default); True = accumulated into table.grad in place
+ACCUMULATE_TABLE_GRAD_IN_PLACE = False
+
+
 class _RenderCore(torch.autograd.Function):
     """NeRFRenderer.run with gradients (reference models/instant_nsr.py:133-299 under torch.enable_grad) as ONE operator:
     forward  = the fused renderer itself (ac_render_rays: sampling + render core, the launch an inference render makes) with its
@@ -302,7 +306,10 @@ class _RenderCore(torch.autograd.Function):
         c = lambda g: None if g is None else g.contiguous().to(_F32)
         g_image, g_wsum, g_depth, g_nmap, g_eik = c(g_image), c(g_wsum), c(g_depth), c(g_nmap), c(g_eik)
         table = ctx.table
-        in_place = table.grad is not None and table.grad.is_contiguous() and table.grad.dtype == _F32
+        # The table gradient is RETURNED to autograd like every other gradient (torch.autograd.grad, backward(inputs=...), hooks and DDP-style
+        # reducers see it).  ACCUMULATE_TABLE_GRAD_IN_PLACE (opt-in, off by default) adds it straight into an existing contiguous fp32 table.grad
+        # and returns None for that input instead: it saves one 49 MB zero-fill + add per backward pass for callers that only ever read .grad.
+        in_place = ACCUMULATE_TABLE_GRAD_IN_PLACE and table.grad is not None and table.grad.is_contiguous() and table.grad.dtype == _F32
         g_table = table.grad if in_place else torch.zeros_like(table)       # accumulated into, like hash_encode_backward (hashgrid.py:61-68)
         g_sdf_p = torch.empty(64 * 36 + 16 * 64 + 16, dtype=_F32, device=dev)
         g_col_p = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)

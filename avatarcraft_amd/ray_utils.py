@@ -27,6 +27,13 @@ def to_homogeneous(pts):
 _ACCEL_CACHE = None
 
 
+def invalidate_caches():
+    """drop the cached search structure of the last mesh (keyed by data_ptr / tensor version / stream: in-place writes that bypass the version
+    counter -- `.data.copy_`, raw-pointer kernels -- need this call before the next warp)"""
+    global _ACCEL_CACHE
+    _ACCEL_CACHE = None
+
+
 def warp_samples_to_canonical(pts, verts, faces, T, threshold=0.2, device=None, return_torch=None, accel=True):
     """pts [num_rays, num_samples, 3]; verts [V,3]; faces [F,>=3] (first three columns); T [V',4,4] (fp64).
     Returns (can_pts [R,S,3] fp64, can_dirs [R,S,3], closest [R,S,3], mask [R*S] bool) -- numpy if pts is numpy."""

@@ -33,6 +33,11 @@ def reconstruct_step(net, optimizer, rays_o, rays_d, rgb_gt, white_bkg=True, w_e
                      flat_grad=None, process_group=None):
     """one optimisation step on one ray batch (reconstruct.py:92-112).  rays_o, rays_d, rgb_gt: [n, 3] on the net's device.
     With a process group every rank takes its own ray batch and the flat gradient is all-reduced (sum, / world) like stylize.sds_step."""
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if flat_grad is None and dist_on and torch.distributed.get_world_size(process_group) > 1:
+        # every rank draws its own ray batch: without the all-reduce the replicas would silently drift apart (stylize.sds_step refuses the same way)
+        raise RuntimeError("reconstruct_step under torch.distributed (world size > 1) needs flat_grad = stylize.flat_grad_view(net.parameters()): "
+                           "the gradients of the ranks are averaged through that buffer")
     with torch.enable_grad():
         rgb, eikonal, _ = render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=batch_size, requires_grad=True, bkg_key=WHITE_BKG if white_bkg else BLACK_BKG,
                                                   return_torch=True, perturb=1.0, return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
@@ -53,14 +58,14 @@ def reconstruct_step(net, optimizer, rays_o, rays_d, rgb_gt, white_bkg=True, w_e
 
 
 def reconstruct_epochs(net, optimizer, scheduler, all_rays_o, all_rays_d, gt_rgb, epochs, batch_size=BATCH_SIZE, white_bkg=True, seed=42, on_step=None,
-                       max_steps=None, flat_grad=None):
+                       max_steps=None, flat_grad=None, process_group=None):
     """the training loop of main_reconstruct (reconstruct.py:80-162): per epoch one random permutation of ALL rays (every view), batches of
     1600, scheduler.step() per epoch.  all_rays_o / all_rays_d / gt_rgb: [n_views * H * W, 3].  Under torch.distributed every rank draws the
     same permutation and takes the batches rank, rank + world, ...  Returns the number of optimizer steps taken by this rank."""
     gen = torch.Generator(); gen.manual_seed(seed)
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
-    rank = torch.distributed.get_rank() if dist_on else 0
-    world = torch.distributed.get_world_size() if dist_on else 1
+    rank = torch.distributed.get_rank(process_group) if dist_on else 0
+    world = torch.distributed.get_world_size(process_group) if dist_on else 1
     n = all_rays_o.shape[0]
     step = 0
     for epoch in range(epochs):
@@ -70,7 +75,7 @@ def reconstruct_epochs(net, optimizer, scheduler, all_rays_o, all_rays_d, gt_rgb
         for i in starts:
             idx = perm[i:i + batch_size]
             loss = reconstruct_step(net, optimizer, all_rays_o[idx].contiguous(), all_rays_d[idx].contiguous(), gt_rgb[idx], white_bkg=white_bkg,
-                                    batch_size=batch_size, flat_grad=flat_grad)
+                                    batch_size=batch_size, flat_grad=flat_grad, process_group=process_group)
             if on_step is not None:
                 on_step(step, epoch, loss)
             step += 1

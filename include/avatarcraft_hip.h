@@ -155,8 +155,10 @@ typedef struct ac_render_opts {
                                      l1(x +- eps e_k) = l1(x) [exact fp32] + W1 (h(x +- eps e_k) - h(x)) + W1[:,k] (+-eps)
                                  with the middle product on the bf16 matrix pipe, both factors split into hi + lo bf16 (3 products, fp32
                                  accumulate): the correction term is ~1e-2 of l1, its 2^-16 relative error is below fp32 round-off of l1
-                                 itself (normals within 6e-5 of the exact mode).  Sample positions (everything that feeds searchsorted / the
-                                 sort), the centre evaluation and the colour network are unaffected: z_vals, indices and sdf stay bit-identical. */
+                                 itself (normals within 6e-5 of the exact mode), and the colour network (21-64-64-3) in split bf16 as well
+                                 (hi + lo, 3 products per layer; colours move by ~1e-6).  Sample positions (everything that feeds
+                                 searchsorted / the sort) and the centre SDF evaluation are unaffected: z_vals, indices and sdf stay
+                                 bit-identical.  The product's default is 0. */
     int32_t skip_masked;      /* posed-space rendering (ac_render_rays_warped) only: 1 = tiles of 16 samples that the warp masks out entirely
                                  (alpha * 0, instant_nsr.py:246-249) are not evaluated.  image, weights_sum, depth, normal_map and the per-sample
                                  weights / alpha are unchanged bit for bit (their contribution is exactly zero; the transmittance factor

@@ -37,8 +37,7 @@
 #include <string.h>
 #include <math.h>
 #include "ac_math.h"
-
-#define ORC_API __attribute__((visibility("default")))
+#include "ac_oracle.h"
 
 /* ------------------------------------------------------------------ */
 /* pcg32  (reference: raymarching/src/pcg32.h:44-116)                  */
@@ -266,17 +265,7 @@ ORC_API int orc_hash_encode_backward(const float *grad, const float *inputs, con
 /* Instant-NSR field: SDF MLP, FD normals, colour MLP                   */
 /* (reference: models/instant_nsr.py:627-663,687-704)                   */
 /* ------------------------------------------------------------------ */
-typedef struct {
-    const float *table;        /* embeddings [n_entries, 2] */
-    const int32_t *offsets;    /* [17] */
-    float scale[16];           /* per-level table (orc_hash_level_table) */
-    uint32_t res[16];
-    const float *W1, *b1;      /* effective (weight-normed) sdf_net.0: [64,35], [64] */
-    const float *W2, *b2;      /* sdf_net.1: [16,64], [16] */
-    const float *Wc1;          /* color_net.0: [64,21] */
-    const float *Wc2;          /* color_net.1: [64,64] */
-    const float *Wc3;          /* color_net.2: [3,64] */
-} orc_field;
+/* orc_field: ac_oracle.h */
 
 /* HashEncoder.forward (hashgrid.py:126-142) for L=16,C=2,D=3: enc[2*l+c] */
 static void field_encode(const orc_field *f, const float x[3], float bound, float enc[32])
@@ -450,16 +439,7 @@ static void orc_tilescan(int op, const float *x, int m, float *out)
 /* ------------------------------------------------------------------ */
 /* NeRFRenderer.run (models/instant_nsr.py:133-299), render_can=True     */
 /* ------------------------------------------------------------------ */
-typedef struct {
-    int32_t n_rays;
-    int32_t num_steps;        /* coarse samples T0: multiple of 16, 16..64  */
-    int32_t upsample_steps;   /* multiple of 16, T0+up <= 128 */
-    float bound;
-    float inv_s;              /* forward_variance(): exp(10*variance).clip(1e-6,1e6) */
-    float cos_anneal_ratio;
-    float fd_eps;             /* 0.005*(1-normal_epsilon_ratio) */
-    int32_t perturb;          /* training && perturb_overwrite: use noise[n, T0] */
-} orc_render_opts;
+/* orc_render_opts: ac_oracle.h */
 
 typedef struct {
     float *image;        /* [N,3] */

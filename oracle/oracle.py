@@ -20,7 +20,7 @@ u32p = C.POINTER(C.c_uint32)
 def build(force=False):
     """Compile libac_oracle.so with the committed Makefile (gcc, seconds)."""
     so = os.path.join(_HERE, "libac_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_math.h", "ac_sh_table.h", "ac_sp_table.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_oracle_bwd.c", "ac_oracle.h", "ac_math.h", "ac_sh_table.h", "ac_sp_table.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libac_oracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -363,3 +363,53 @@ def update_density_grid(field, grid, bound, decay=0.95, inv_s=512.0, resolution=
                 pooled = np.maximum(pooled, pad[dx:dx + resolution, dy:dy + resolution, dz:dz + resolution])
     new = np.maximum(np.asarray(grid, np.float32) * np.float32(decay), pooled)
     return new, float(new.mean(dtype=np.float64))
+
+
+# ------------------------------------------------------------------ backward of the render core (fp64 witness, ac_oracle_bwd.c)
+class _CoreGrads(C.Structure):
+    _fields_ = [("g_table", C.POINTER(C.c_double)), ("g_params", C.POINTER(C.c_double)), ("g_inv_s", C.POINTER(C.c_double)),
+                ("fwd", C.POINTER(C.c_double)), ("gradient_error", C.POINTER(C.c_double))]
+
+
+CORE_PARAM_SHAPES = (("W1", (64, 35)), ("b1", (64,)), ("W2", (16, 64)), ("b2", (16,)), ("Wc1", (64, 21)), ("Wc2", (64, 64)), ("Wc3", (3, 64)))
+
+
+def render_core_backward(field, rays_o, rays_d, z_vals, num_steps, upsample_steps, bound, inv_s, bg=None, g_image=None, g_weights_sum=None,
+                         g_depth=None, g_normal_map=None, g_eik=0.0, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0):
+    """d loss / d (hash table, effective MLP matrices, inv_s) for loss = <g_image, image> + <g_weights_sum, weights_sum> + <g_depth, depth> +
+    <g_normal_map, normal_map> + g_eik * gradient_error of NeRFRenderer.run's render core at the given (constant) sample positions z_vals [N,T]
+    -- float64, analytic (reference models/instant_nsr.py:190-299 under autograd).  Returns a dict: g_table [n_entries,2], g_W1 ... g_Wc3,
+    g_inv_s, and the fp64 forward (image, weights_sum, depth, normal_map, gradient_error)."""
+    rays_o = _f(rays_o).reshape(-1, 3); rays_d = _f(rays_d).reshape(-1, 3)
+    N = rays_o.shape[0]
+    T = num_steps + upsample_steps
+    z = _f(z_vals).reshape(N, T)
+    op = _Opts(N, num_steps, upsample_steps, bound, float(inv_s), float(cos_anneal_ratio), float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), 0)
+    dp = C.POINTER(C.c_double)
+    g_table = np.zeros(field.arrs["table"].shape, np.float64)
+    npar = sum(int(np.prod(s)) for _, s in CORE_PARAM_SHAPES)
+    g_par = np.zeros(npar, np.float64); g_s = np.zeros(1, np.float64); fwd = np.zeros((N, 8), np.float64); ge = np.zeros(1, np.float64)
+    cg = _CoreGrads(g_table.ctypes.data_as(dp), g_par.ctypes.data_as(dp), g_s.ctypes.data_as(dp), fwd.ctypes.data_as(dp), ge.ctypes.data_as(dp))
+    opt = lambda a, shape: None if a is None else _f(a).reshape(shape)
+    gi, gw, gd, gm, bgc = opt(g_image, (N, 3)), opt(g_weights_sum, (N,)), opt(g_depth, (N,)), opt(g_normal_map, (N, 3)), opt(bg, (N, 3))
+    fn = lib().orc_render_core_backward
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_double, C.c_void_p]
+    rc = fn(C.byref(field.c), C.byref(op), _p(rays_o), _p(rays_d), _p(bgc), _p(z), _p(gi), _p(gw), _p(gd), _p(gm), float(g_eik), C.byref(cg))
+    if rc:
+        raise RuntimeError("render_core_backward: unsupported configuration")
+    res = dict(g_table=g_table, g_inv_s=float(g_s[0]), image=fwd[:, 0:3], weights_sum=fwd[:, 3], depth=fwd[:, 4], normal_map=fwd[:, 5:8],
+               gradient_error=float(ge[0]))
+    off = 0
+    for name, shape in CORE_PARAM_SHAPES:
+        n = int(np.prod(shape))
+        res["g_" + name] = g_par[off:off + n].reshape(shape).copy(); off += n
+    return res
+
+
+def weight_norm_backward(v, g, g_w):
+    """float64 chain rule of torch.nn.utils.weight_norm (dim 0): w = g v / |v|_row  ->  (d/dv, d/dg) from d/dw"""
+    v = np.asarray(v, np.float64); g = np.asarray(g, np.float64).reshape(-1, 1); g_w = np.asarray(g_w, np.float64)
+    nrm = np.sqrt((v * v).sum(1, keepdims=True))
+    dot = (g_w * v).sum(1, keepdims=True)
+    return g / nrm * (g_w - v * dot / (nrm * nrm)), dot / nrm

@@ -425,3 +425,32 @@ def test_sample_rays_equals_render_z(env, T0, up, perturb):
     full = nsr_ops.render_rays(env["f"], t(ro), t(rd), T0, up, 1.6, float(env["p"]["inv_s"]), noise=t(noise), extras=True)
     z = nsr_ops.sample_rays(env["f"], t(ro), t(rd), T0, up, 1.6, noise=t(noise))
     assert torch.equal(z, full["z_vals"])
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("view", ["bench_batch", "sds_view"])
+def test_repeat_launch_soak_is_bit_identical(env, view, precision):
+    """Soak of the machinery that could make a launch timing dependent -- rays handed out to waves dynamically from per-XCD counters, the
+    staggered start, the finite-difference feature slab aliasing the up-sampling buffers in LDS, gathers under exec masks: the first 4096-ray
+    batch of the BASELINE view and the stride-4 training view of the SDS step (jittered samples), rendered 50 times each with every optional
+    output kept (per-sample arrays, sample indices, the 7 x 32 stencil features of every sample).  Every repeat must equal the first bit for bit,
+    in both arithmetic modes."""
+    from avatarcraft_amd import nsr_ops
+    import bench
+    dev = "cuda:0"
+    if view == "bench_batch":
+        ro, rd = make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)
+        ro, rd, noise = ro[:4096], rd[:4096], None
+    else:
+        ro, rd = bench.sds_view(0)
+        noise = torch.rand((ro.shape[0], 64), generator=torch.Generator().manual_seed(7)).to(dev)
+    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    f = env["f"]
+    run = lambda: nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, float(env["p"]["inv_s"]), noise=noise, extras=True, train_extras=True, debug_indices=True,
+                                      precision=precision)
+    first = {k: v.clone() for k, v in run().items() if isinstance(v, torch.Tensor)}
+    assert "feat7" in first and first["feat7"].numel() == 7 * 8 * 4096 * 128 * 4
+    for rep in range(1, 50):
+        out = run()
+        for k, v in first.items():
+            assert torch.equal(v, out[k]), f"repeat {rep}: {k} differs from the first launch ({int((v != out[k]).sum())} values)"
