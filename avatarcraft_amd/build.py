@@ -4,6 +4,7 @@
 
 hipcc cross-compiles without a GPU.  Flags that are part of the numerics contract:
   -ffp-contract=off   every fused multiply-add in the kernels is an explicit fma
+  -fno-slp-vectorize  no compiler-formed packed-fp32 arithmetic (see FLAGS)
   (no -ffast-math; fp32 divide / sqrt stay correctly rounded, denormals are kept)
 """
 import os
@@ -16,7 +17,12 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libavatarcraft_hip.so")
 SOURCES = ["ac_capi.hip", "hashgrid.hip", "hash_stencil.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "sdf_train.hip", "warp.hip", "step_glue.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-         "-Wno-unused-result"]
+         "-Wno-unused-result",
+         # no compiler-formed packed-fp32 (v_pk_*_f32) code: the one run-to-run non-determinism ever observed in the renderer (round 2: the "face-value"
+         # stencil variant; round 3: reproduced and bisected) appears exactly when the SLP vectorizer packs the xy weight
+         # products and the two feature channels of that variant into v_pk_mul / v_pk_fma with crossed op_sel, and disappears with this flag;
+         # measured cost of the flag on the shipped kernels: none (render 0.799 vs 0.796 ms, posed frame 8.50 vs 8.75 ms, same box)
+         "-fno-slp-vectorize"]
 
 
 def _hipcc():

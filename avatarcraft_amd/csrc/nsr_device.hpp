@@ -28,6 +28,7 @@ namespace {
 constexpr int WAVES_PER_BLOCK = AC_WPB;
 constexpr int BLOCK = WAVES_PER_BLOCK * 64;
 constexpr int MAXT = 128;
+constexpr int SEG_STATE = MAXT + 16;   // floats per ray handed from one segment of a ray to the next: z [128] | cT, 10 running sums | pad
 #ifndef AC_FINE_BATCH
 #define AC_FINE_BATCH 3     // fine stencil levels: offset-point pairs gathered per memory round trip (1: x | y | z, 2: x+y | z, 3: all six: 221 VGPRs, -2 % time)
 #endif
@@ -120,7 +121,11 @@ struct RenderArgs {
     const float *near_m, *far_m;   // [N] mesh-guided range (+-inf where the ray misses the body) or NULL
     const float *ext_pts;          // MODE_UPSAMPLE: warped coarse points [N,T0,3]; MODE_FINAL: warped mid points [N,T,3]
     const uint8_t *mask;           // MODE_FINAL: [N,T] alpha mask
-    uint32_t *ray_counter;         // AC_DYNAMIC_RAYS: [8] per-XCD ray counters (zeroed before the launch): waves fetch their next ray instead of owning a fixed one
+    uint32_t *ray_counter;         // AC_DYNAMIC_RAYS: [8 XCDs][8 segments] work counters (zeroed before the launch): waves fetch their next (ray, segment) instead of owning fixed rays
+    uint32_t *seg_flags;           // [N] number of finished segments of each ray (zeroed before the launch), or NULL when seg_n == 1
+    float *seg_state;              // [N][SEG_STATE] what a ray's next segment continues from: z values + running sums (library scratch)
+    uint32_t seg_cb;               // first tile of segment s in bits 4s .. 4s+3, s = 0 .. seg_n
+    int seg_n;                     // segments per ray (1 .. 4)
     const uint8_t *ray_dead;       // MODE_UPSAMPLE, skip_masked: [N] rays that cannot hold an unmasked sample (no field evaluation, coarse z only)
     float *zbuf;                   // [N,T] final z values: written by MODE_UPSAMPLE, read by MODE_FINAL
     float *mid_pts;                // MODE_UPSAMPLE: posed-space mid points [N,T,3]

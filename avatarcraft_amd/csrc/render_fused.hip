@@ -27,6 +27,7 @@
 // Numerics contract: see ac_devmath.hpp and DESIGN.md; every value produced here is bit-identical
 // to oracle/ac_oracle.c:orc_render_rays on the same inputs.
 #include <atomic>
+#include <mutex>
 #include "nsr_device.hpp"
 
 namespace {
@@ -100,14 +101,24 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 #endif
     for (int k_ = 0; k_ < AC_START_STAGGER * wave; ++k_) __builtin_amdgcn_s_sleep(64);
 #if AC_DYNAMIC_RAYS
-    // waves fetch rays one at a time from their XCD's counter: a workgroup no longer waits for the slowest of its eight rays before the next eight
-    // start (per-ray time varies by ~9 %).  The batch is dealt to the XCDs in chunks of AC_XCD_CHUNK consecutive rays (two image rows of a 256-wide
-    // view: neighbouring rays share grid cells in the XCD's L2), chunk c to XCD c % 8; a batch of up to 8 chunks is cut into eight contiguous parts.
-    // Large batches stay balanced that way when the body covers only some rows of the image (posed frames, skip_masked).
+    // Work items are (ray, segment) pairs fetched one at a time from per-XCD counters.  A ray is cut into seg_n segments of the tile loop (segment 0 =
+    // the sampling stage + the first tiles); a wave that finishes a segment leaves the ray's z values and running sums in seg_state and raises the ray's
+    // flag, whichever wave of the XCD fetches the next segment of that ray continues the SAME sequential arithmetic from there (bit-identical results).
+    // Every wave works through all segment-0 items of its XCD first, then the segment-1 items, ...: a 4096-ray launch is only two rays per wave slot,
+    // and with whole rays as work items it ended with the slowest pair (per-wave busy time: mean 664 us, max 802 us); now the last items are a
+    // quarter-ray long.  A wave never waits for an item nobody has started: segment s + 1 of a ray is handed out only after every segment-s item
+    // of the XCD has been fetched by a running wave.
+    // The batch is dealt to the XCDs in chunks of AC_XCD_CHUNK consecutive rays (two image rows of a 256-wide view: neighbouring rays share grid
+    // cells in the XCD's L2), chunk c to XCD c % 8; a batch of up to 8 chunks is cut into eight contiguous parts.  Large batches stay balanced
+    // that way when the body covers only some rows of the image (posed frames, skip_masked).
     const int xper = ((a.n_rays + 7) / 8 + 7) & ~7, xchunk = xper < AC_XCD_CHUNK ? xper : AC_XCD_CHUNK, xcd = blockIdx.x & 7;
+    const int seg_n = (MODE == MODE_UPSAMPLE) ? 1 : a.seg_n;
+    for (int seg = 0; seg < seg_n; ++seg) {
+    const int c_begin = (MODE == MODE_UPSAMPLE) ? 0 : (int)((a.seg_cb >> (4 * seg)) & 15u), c_end = (MODE == MODE_UPSAMPLE) ? 0 : (int)((a.seg_cb >> (4 * seg + 4)) & 15u);
+    const bool seg_first = seg == 0, seg_last = seg + 1 == seg_n;
     for (;;) {
         int ray = 0;
-        if (lane == 0) ray = (int)atomicAdd(a.ray_counter + xcd, 1u);
+        if (lane == 0) ray = (int)atomicAdd(a.ray_counter + xcd * 8 + seg, 1u);
         ray = __builtin_amdgcn_readfirstlane(ray);
         {
             const int k = ray / xchunk, base = (k * 8 + xcd) * xchunk;
@@ -117,6 +128,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         }
         (void)bid;
 #else
+    const int seg_n = 1, seg = 0, c_begin = 0, c_end = MAXT / 16;
+    const bool seg_first = true, seg_last = true;
+    {
     for (int ray = bid * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
 #endif
         AC_T0();
@@ -150,10 +164,30 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 continue;
             }
         }
+        float cT = 1.0f;                                        // transmittance carry (cumprod)
+        float s_w = 0.0f, s_r = 0.0f, s_g = 0.0f, s_b = 0.0f, s_nx = 0.0f, s_ny = 0.0f, s_nz = 0.0f, s_d = 0.0f,
+              s_en = 0.0f, s_ed = 0.0f;
+        if (!seg_first) {
+            // continue a ray another wave (of this XCD) started: wait until its previous segment is published, then take over z and the running sums.
+            // All accesses to seg_flags / seg_state are agent-scope atomics = served by the XCD's L2, past the (incoherent) vector L1 caches.
+            if (lane == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(a.seg_flags + ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)seg && spins < (1 << 21)) {
+                    __builtin_amdgcn_s_sleep(8); ++spins;       // (bounded: ~1 s; a ray's previous segment takes ~100 us)
+                }
+            }
+            wave_sync();
+            const uint32_t *st = reinterpret_cast<const uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
+            if constexpr (MODE != MODE_FINAL)
+                for (int i = lane; i < T; i += 64) zs0[i] = __uint_as_float(__hip_atomic_load(st + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float cv = __uint_as_float(__hip_atomic_load(st + MAXT + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            cT = lane_bcast(cv, 0); s_w = lane_bcast(cv, 1); s_r = lane_bcast(cv, 2); s_g = lane_bcast(cv, 3); s_b = lane_bcast(cv, 4);
+            s_nx = lane_bcast(cv, 5); s_ny = lane_bcast(cv, 6); s_nz = lane_bcast(cv, 7); s_d = lane_bcast(cv, 8); s_en = lane_bcast(cv, 9); s_ed = lane_bcast(cv, 10);
+        }
         // ---- coarse samples :155-180 -------------------------------------------------------------
         if constexpr (MODE == MODE_FINAL) {
             for (int i = lane; i < T; i += 64) zs0[i] = a.zbuf[(size_t)ray * T + i];
-        } else {
+        } else if (seg_first) {
             for (int c = 0; c < T0 / 16; ++c) {
                 const int i = 16 * c + n;
                 float zi = near + span * lds[OFF_LIN + i];
@@ -177,7 +211,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         AC_TICK(0)
 
         // ---- NeuS up-sampling :182-184, :410-475 -----------------------------------------------------
-        for (int it = 0; it < (MODE == MODE_FINAL ? 0 : nup); ++it) {
+        for (int it = 0; it < ((MODE == MODE_FINAL || !seg_first) ? 0 : nup); ++it) {
             const float *zc = cur ? zs1 : zs0, *sc = sd + cur * MAXT;
             float *zn_ = cur ? zs0 : zs1, *sn_ = sd + (cur ^ 1) * MAXT;
             const int m = cnt - 1;
@@ -330,11 +364,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             wave_sync();
             continue;
         }
-        float cT = 1.0f;                                        // transmittance carry (cumprod)
-        float s_w = 0.0f, s_r = 0.0f, s_g = 0.0f, s_b = 0.0f, s_nx = 0.0f, s_ny = 0.0f, s_nz = 0.0f, s_d = 0.0f,
-              s_en = 0.0f, s_ed = 0.0f;
         const float bxe = a.eps;
-        for (int c = 0; c < T / 16; ++c) {
+        const int c_hi = c_end < T / 16 ? c_end : T / 16;
+        for (int c = c_begin; c < c_hi; ++c) {
             const int i = 16 * c + n;
             const float zi = zf[i];
             const float delta = (i < T - 1) ? zf[i + 1] - zi : sample_dist;
@@ -479,6 +511,23 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             if (a.out.sdf_out16) *reinterpret_cast<f32x4 *>(a.out.sdf_out16 + ((size_t)ray * T + i) * 16 + 4 * g) = oc;     // lane (n, g) holds outputs 4g..4g+3
         }
+        if (!seg_last) {
+            // hand the ray to its next segment: z values (once), the running sums, then the flag -- in that order (the stores are complete in L2
+            // before the flag leaves: s_waitcnt vmcnt(0); the reader's loads are issued after it has seen the flag)
+            uint32_t *st = reinterpret_cast<uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
+            if (MODE != MODE_FINAL && seg_first)
+                for (int i = lane; i < T; i += 64) __hip_atomic_store(st + i, __float_as_uint(zf[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 11) {
+                const float cv = lane == 0 ? cT : lane == 1 ? s_w : lane == 2 ? s_r : lane == 3 ? s_g : lane == 4 ? s_b : lane == 5 ? s_nx : lane == 6 ? s_ny :
+                                 lane == 7 ? s_nz : lane == 8 ? s_d : lane == 9 ? s_en : s_ed;
+                __hip_atomic_store(st + MAXT + lane, __float_as_uint(cv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_sync();
+            if (lane == 0) __hip_atomic_store(a.seg_flags + ray, (uint32_t)(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_sync();
+            continue;
+        }
         if (lane == 0) {
             const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
             a.out.image[3 * ray] = s_r + (1.0f - s_w) * b0;
@@ -493,6 +542,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 #ifdef AC_PROFILE               // per-ray wall time (100 MHz ticks) behind the per-wave records: [n_rays * 10 + ray]
         if (a.prof && lane == 0) a.prof[(size_t)a.n_rays * 10 + ray] = __builtin_amdgcn_s_memrealtime() - ray_r0_;
 #endif
+    }
     }
 #ifdef AC_PROFILE
     if (a.prof && lane == 0) { const int w_ = blockIdx.x * WAVES_PER_BLOCK + wave; for (int i = 0; i < 8; ++i) a.prof[w_ * 10 + i] = prof_acc[i];
@@ -645,23 +695,31 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     return AC_OK;
 }
 
-// eight per-XCD ray counters for one launch: 64 rotating sets per device (launches of one stream run in order; 64 launches in flight across streams
-// would be needed for two of them to share a set), allocated once per device and kept for the life of the process
-static uint32_t *ray_counters()
+// Per-launch scratch of the dynamic hand-out: [8 XCDs][8 segments] work counters (256 B) | flags [N] u32 | state [N][SEG_STATE] f32.
+// 16 rotating slots per device, each grown to the largest batch it has served and kept for the life of the process (launches of one stream run in
+// order; 16 launches in flight across streams would be needed for two of them to share a slot).  Counters and flags are zeroed before every launch.
+#ifndef AC_RAY_SEGMENTS
+#define AC_RAY_SEGMENTS 4           // segments a ray is cut into (1 = whole rays as work items, rounds 1 - 2)
+#endif
+struct SegSlot { char *p; size_t bytes; };
+static char *seg_scratch(size_t need)
 {
-    static std::atomic<uint32_t *> pool[64];
-    static std::atomic<uint32_t> turn{0};
+    static std::mutex mu;
+    static SegSlot pool[64][16];
+    static uint32_t turn[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     dev &= 63;
-    uint32_t *p = pool[dev].load(std::memory_order_acquire);
-    if (!p) {
-        uint32_t *fresh = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&fresh), 64 * 8 * sizeof(uint32_t)) != hipSuccess) return nullptr;
-        if (pool[dev].compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) p = fresh;
-        else (void)hipFree(fresh);                                   // another host thread was first
+    std::lock_guard<std::mutex> lock(mu);
+    SegSlot &sl = pool[dev][turn[dev]++ & 15u];
+    if (sl.bytes < need) {
+        if (sl.p) (void)hipFree(sl.p);                                   // (synchronises the device: no launch can still be using the slot)
+        sl.p = nullptr; sl.bytes = 0;
+        const size_t want = (need + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        if (hipMalloc(reinterpret_cast<void **>(&sl.p), want) != hipSuccess) { sl.p = nullptr; return nullptr; }
+        sl.bytes = want;
     }
-    return p + 8 * (turn.fetch_add(1, std::memory_order_relaxed) & 63u);
+    return sl.p;
 }
 
 template <int MODE, bool FAST>
@@ -674,12 +732,23 @@ static void launch_render_p(const RenderArgs &a, hipStream_t stream)
 #if AC_DYNAMIC_RAYS
     RenderArgs b = a;
     {
-        b.ray_counter = ray_counters();
-        if (b.ray_counter) (void)hipMemsetAsync(b.ray_counter, 0, 8 * sizeof(uint32_t), stream);
+        // segments: the tiles of a ray in seg_n nearly equal runs; the sampling stage (about 1.6 tiles' worth of time) rides with the first
+        const int nt = (a.T0 + 16 * a.nup) / 16;
+        int sn = (MODE == MODE_UPSAMPLE) ? 1 : (nt < AC_RAY_SEGMENTS ? nt : AC_RAY_SEGMENTS);
+        if (sn < 1) sn = 1;
+        b.seg_n = sn; b.seg_cb = 0;
+        for (int q = 0; q <= sn; ++q) b.seg_cb |= (uint32_t)((nt * q) / sn) << (4 * q);
+        const size_t N = (size_t)a.n_rays, head = 256, flags = (N * 4 + 255) & ~(size_t)255;
+        const size_t need = head + (sn > 1 ? flags + N * SEG_STATE * sizeof(float) : 0);
+        char *sc = seg_scratch(need);
+        b.ray_counter = reinterpret_cast<uint32_t *>(sc);
+        b.seg_flags = sn > 1 ? reinterpret_cast<uint32_t *>(sc + head) : nullptr;
+        b.seg_state = sn > 1 ? reinterpret_cast<float *>(sc + head + flags) : nullptr;
+        if (sc) (void)hipMemsetAsync(sc, 0, head + (sn > 1 ? N * 4 : 0), stream);
         const int cus = (int)ac::cu_count();
         if (blocks > cus) blocks = cus;
         blocks = (blocks + 7) & ~7;                                      // every XCD gets the same number of workgroups
-        if (!b.ray_counter) blocks = 0;                                  // (2 KB could not be allocated: an empty grid is a launch error the caller reports)
+        if (!sc) blocks = 0;                                             // (the scratch could not be allocated: an empty grid is a launch error the caller reports)
     }
     hipLaunchKernelGGL((render_rays_kernel<MODE, FAST>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, b);
 #else

@@ -415,19 +415,19 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
 // out[i] = sum over waves of partials[w][i]: 64 outputs x 16 wave slices per workgroup, fixed summation order (deterministic)
 __global__ __launch_bounds__(1024) void sdf_partials_reduce_kernel(const float *__restrict__ partials, uint32_t nwaves, float *__restrict__ out)
 {
-    __shared__ float red[16][64];
+    __shared__ double red[16][64];          // (double: the order of the partials must not show up in the last bits of a sum of ~1000 of them)
     const uint32_t o = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const uint32_t i = blockIdx.x * 64 + o;
-    float s = 0.0f;
+    double s = 0.0;
     if (i < (uint32_t)NPART)
-        for (uint32_t w = sl; w < nwaves; w += 16) s += partials[(size_t)w * NPART + i];
+        for (uint32_t w = sl; w < nwaves; w += 16) s += (double)partials[(size_t)w * NPART + i];
     red[sl][o] = s;
     __syncthreads();
     if (sl == 0 && i < (uint32_t)NPART) {
-        float t = 0.0f;
+        double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][o];
-        out[i] = t;
+        out[i] = (float)t;
     }
 }
 
@@ -810,19 +810,19 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a_in,
 // generic: out[i] = sum over waves of partials[w][i], i < n_out
 __global__ __launch_bounds__(1024) void partials_reduce_kernel(const float *__restrict__ partials, uint32_t nwaves, uint32_t n_out, float *__restrict__ out)
 {
-    __shared__ float red[16][64];
+    __shared__ double red[16][64];          // (double: the order of the partials must not show up in the last bits of a sum of ~1000 of them)
     const uint32_t o = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const uint32_t i = blockIdx.x * 64 + o;
-    float s = 0.0f;
+    double s = 0.0;
     if (i < n_out)
-        for (uint32_t w = sl; w < nwaves; w += 16) s += partials[(size_t)w * n_out + i];
+        for (uint32_t w = sl; w < nwaves; w += 16) s += (double)partials[(size_t)w * n_out + i];
     red[sl][o] = s;
     __syncthreads();
     if (sl == 0 && i < n_out) {
-        float t = 0.0f;
+        double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][o];
-        out[i] = t;
+        out[i] = (float)t;
     }
 }
 

@@ -251,9 +251,9 @@ def main():
 
     # gradients of one training render: rgb.backward(image_grad) + (0.01 * eikonal).backward(),
     # stylize.py:163-169, on the reference's own autograd graph (hash backward served by the oracle)
-    # (round 3: 256 rays instead of 36 -- a 16 x 16 view with jittered pixel positions, random per-ray backgrounds)
+    # (round 3: 256 rays instead of 36 -- a 16 x 16 view with jittered pixel positions; white background, what stylize.py renders by default)
     ro2, rd2 = make_rays(16, 16, dist=1.8, f=10.0, jitter_seed=11)
-    bg2 = np.random.RandomState(12).uniform(0, 1, size=(ro2.shape[0], 3)).astype(np.float32)
+    bg2 = np.ones((ro2.shape[0], 3), np.float32)
     net.train(True)
     net.zero_grad()
     torch.manual_seed(42)

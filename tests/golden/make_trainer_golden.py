@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""tests/golden/trainer_step.npz: step 0 of the reference's own training loop -- stylize.py:Trainer.train (47-217) -- run HERE on the CPU
+by importing the reference (it cannot travel to the GPU box; only the recorded vectors do):
+
+    python tests/golden/make_trainer_golden.py [/root/reference]
+
+What runs is the reference's code: Trainer.train with its camera path (style_360_path with jitter and head close-ups), pose2cap / cap2rays,
+sparse_ray_sampling, background / prompt augmentation, render_val, StableDiffusion.mannual_backward, the patch loop with its three backward
+passes, up to the first optimizer.step().  What is NOT the reference: the hash back end (served by oracle/, like every other golden), the
+pretrained SD networks (tiny seeded stand-ins of tests/common_sd.py behind stub `diffusers` / `transformers` modules, as in sds.npz), the
+checkpoint (`build_reference_net()` of make_golden.py instead of bare_smpl.pth.tar) and the device: cap2rays hard-codes "cuda"
+(utils/render_utils.py:372), so Tensor.to is wrapped to keep everything on the CPU.
+
+Recorded: every random draw the step consumed, in order (torch.randperm, random.randint, torch.rand jitter of the renders, the noise
+background, SD's timestep and latent noise), the camera pose, the sub-sampled rays, the background, the prompt, the image handed to the guidance,
+its gradient, the three loss values and the accumulated .grad of every parameter at the first optimizer.step() (4096 sampled table entries)."""
+import os
+import random
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as MG           # stubs the CUDA back ends, imports the reference's models/instant_nsr.py   # noqa: E402
+
+import numpy as np                 # noqa: E402
+import torch                       # noqa: E402
+import torch.nn.functional as F    # noqa: E402
+
+
+class _Stop(Exception):
+    pass
+
+
+def main():
+    from tests import common_sd as SD
+    MG._prepare_render_utils()
+    MG._stub("prompt_toolkit", prompt=lambda *a, **k: "")
+    MG._stub("transformers", CLIPTextModel=SD.TinyTextEncoder, CLIPTokenizer=SD.TinyTokenizer, logging=types.SimpleNamespace(set_verbosity_error=lambda: None))
+    MG._stub("diffusers", AutoencoderKL=SD.TinyVAE, UNet2DConditionModel=SD.TinyUNet, PNDMScheduler=SD.StubPNDMScheduler)
+
+    def pad(img, padding, fill=0, padding_mode="constant"):
+        p = padding[0]
+        return F.pad(img, (p, p, p, p), mode=padding_mode, value=fill)
+    tvf = MG._stub("torchvision.transforms.functional", pad=pad)
+    tvt = MG._stub("torchvision.transforms", functional=tvf)
+    MG._stub("torchvision", transforms=tvt)
+    import importlib
+    for name in ("matplotlib", "matplotlib.pyplot", "imageio", "cv2", "open3d", "pytorch3d", "trimesh"):          # absent third-party modules
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                MG._stub(name)
+    sys.modules.pop("models.diffusion", None)
+    import models.diffusion as RD
+    import stylize as RS                      # the reference's stylize.py (its argparse block is under __main__)
+    import utils.render_utils as RU
+
+    opt = types.SimpleNamespace(use_cuda=False, coarse_epochs=1, fine_epochs=0, augment_cam=True, stylize_head=True, coarse_head=0.5, fine_head=0.5,
+                                augment_bkg=True, white_bkg=True, augment_text=True, subsample_scale=4, guidance_type="diffusion", guidance_scale=100,
+                                batch_size=4096, implicit_model="instant_nsr", w_eikonal=0.01, use_opacity=True, w_clip=0.0, clip_type="abs",
+                                i_val=10 ** 9, i_save=10 ** 9, i_mesh=10 ** 9, exp_name="golden", lr=5e-3, epochs=2, tgt_text="Hulk, photorealistic style",
+                                sd_version="1.5")
+    RS.opt = opt                               # the module reads a global `opt` in a few places (stylize.py:326, :361)
+    RS.utils.fix_randomness(42)                # Trainer.__init__ (stylize.py:34)
+    tr = RS.Trainer.__new__(RS.Trainer)
+    tr.opt, tr.device = opt, torch.device("cpu")
+    tr.center, tr.up, tr.n_cap, tr.H, tr.W, tr.cap_id, tr.tgt_text = np.array([0.0, 0.0, 0.0]), np.array([0.0, 1.0, 0.0]), 4, 64, 64, 0, opt.tgt_text
+    tr.net_style = MG.build_reference_net().train()
+    tr.net_gt = MG.build_reference_net()
+    with torch.no_grad():
+        tr.net_gt.sdf_net[1].bias[0] = MG.GT_SDF_BIAS
+    tr.net_gt.eval()
+    tr.loss = {"style": RD.StableDiffusion(torch.device("cpu"), "1.5")}
+    tr.optimizer, tr.scheduler = tr.setup_optimizer()
+    tr.log_img = lambda *a, **k: None
+    tr.log_model = lambda *a, **k: None
+    tr.log_mesh = lambda *a, **k: None
+
+    rec = {"draws": []}
+
+    # ---- keep everything on the CPU (cap2rays: device = "cuda", hard-coded) and record what the step consumes -----------------------
+    orig_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+            k["device"] = "cpu"
+        return orig_to(self, *a, **k)
+    torch.Tensor.to = to_cpu
+    o_rand, o_randperm, o_randint, o_randn_like, o_pyrandint, o_normal = torch.rand, torch.randperm, torch.randint, torch.randn_like, random.randint, torch.nn.init.normal_
+
+    def rand(*a, **k):
+        r = o_rand(*a, **k); rec.setdefault("rand", []).append(r.numpy().copy()); return r
+
+    def randperm(*a, **k):
+        r = o_randperm(*a, **k); rec["perm"] = r.numpy().copy(); return r
+
+    def randint(*a, **k):
+        r = o_randint(*a, **k); rec.setdefault("randint", []).append(r.numpy().copy()); return r
+
+    def randn_like(*a, **k):
+        r = o_randn_like(*a, **k); rec.setdefault("randn_like", []).append(r.numpy().copy()); return r
+
+    def pyrandint(lo, hi):
+        r = o_pyrandint(lo, hi); rec.setdefault("py_randint", []).append((lo, hi, r)); return r
+
+    def normal_(t, mean=0.0, std=1.0):
+        r = o_normal(t, mean=mean, std=std); rec.setdefault("normal", []).append(r.detach().numpy().copy()); return r
+    torch.rand, torch.randperm, torch.randint, torch.randn_like, random.randint, torch.nn.init.normal_ = rand, randperm, randint, randn_like, pyrandint, normal_
+    o_pose2cap, o_sel_bkg, o_text, o_mb = RU.pose2cap, RU.select_background, tr.loss["style"].get_text_embeds, tr.loss["style"].mannual_backward
+
+    def pose2cap(hw, pose):
+        rec.setdefault("pose_c2w", np.asarray(pose.camera_to_world, np.float64).copy()); return o_pose2cap(hw, pose)
+
+    def select_background(shape, key):
+        b = o_sel_bkg(shape, key); rec.setdefault("bkg", []).append((int(key), b.numpy().copy())); return b
+
+    def get_text_embeds(prompt):
+        rec.setdefault("prompt", prompt[0]); return o_text(prompt)
+
+    def mannual_backward(emb, pred, scale):
+        rec["guidance_image"] = pred.detach().numpy().copy()
+        r = o_mb(emb, pred, scale)
+        rec["guidance_grad"] = pred.grad.numpy().copy()
+        return r
+    RU.pose2cap, RU.select_background = pose2cap, select_background
+    tr.loss["style"].get_text_embeds, tr.loss["style"].mannual_backward = get_text_embeds, mannual_backward
+    o_naive = RU.render_instantnsr_naive
+
+    def naive(net, rays_o, rays_d, *a, **k):
+        out = o_naive(net, rays_o, rays_d, *a, **k)
+        rec.setdefault("renders", []).append(dict(rays_o=rays_o.detach().numpy().copy(), rays_d=rays_d.detach().numpy().copy(), rgb=out[0].detach().numpy().copy(),
+                                                  eikonal=float(out[1]), weight_sum=out[2]["weight_sum"].detach().numpy().copy(), train=bool(net.training),
+                                                  requires_grad=bool(k.get("requires_grad", False))))
+        return out
+    RU.render_instantnsr_naive = naive
+    o_step = tr.optimizer.step
+
+    def step(*a, **k):
+        rec["grads"] = {kk: p.grad.numpy().copy() for kk, p in tr.net_style.named_parameters()}
+        raise _Stop()
+    tr.optimizer.step = step
+    o_sl1 = F.smooth_l1_loss
+
+    def sl1(*a, **k):
+        r = o_sl1(*a, **k); rec.setdefault("smooth_l1", []).append(float(r)); return r
+    F.smooth_l1_loss = sl1
+    try:
+        tr.train()
+    except _Stop:
+        pass
+    finally:
+        torch.Tensor.to = orig_to
+        torch.rand, torch.randperm, torch.randint, torch.randn_like, random.randint, torch.nn.init.normal_ = o_rand, o_randperm, o_randint, o_randn_like, o_pyrandint, o_normal
+        RU.pose2cap, RU.select_background, RU.render_instantnsr_naive = o_pose2cap, o_sel_bkg, o_naive
+        F.smooth_l1_loss = o_sl1
+
+    rn = rec["renders"]
+    assert len(rn) == 3 and rn[0]["train"] and not rn[0]["requires_grad"] and rn[1]["requires_grad"] and not rn[2]["train"], [(r["train"], r["requires_grad"]) for r in rn]
+    ge = rec["grads"]["encoder.embeddings"]
+    nz = np.flatnonzero(np.abs(ge).sum(1))
+    pick = np.sort(nz[np.random.RandomState(13).choice(len(nz), 4096, replace=False)])
+    out = dict(perm=rec["perm"], py_randint=np.array(rec["py_randint"], np.int64), pose_c2w=rec["pose_c2w"], prompt=np.array(rec["prompt"]),
+               rays_o=rn[1]["rays_o"].astype(np.float32), rays_d=rn[1]["rays_d"].astype(np.float32), bkg_key=np.int64(rec["bkg"][0][0]), bkg=rec["bkg"][1][1].astype(np.float32),
+               bkg_val=rec["bkg"][0][1].astype(np.float32),
+               noise_val=rec["rand"][0], noise_grad=rec["rand"][1], sd_t=rec["randint"][0], sd_randn_like=np.stack(rec["randn_like"]),           # [VAE posterior sample, SDS noise]
+               
+               guidance_image=rec["guidance_image"], guidance_grad=rec["guidance_grad"], rgb_val=rn[0]["rgb"], rgb_grad_render=rn[1]["rgb"],
+               eikonal=np.float64(rn[1]["eikonal"]), weight_sum=rn[1]["weight_sum"], weight_sum_gt=rn[2]["weight_sum"], opacity_loss=np.float64(rec["smooth_l1"][0] * 1e5),
+               emb_idx=pick.astype(np.int64), emb_grad=ge[pick].copy(), emb_nnz=np.int64(len(nz)), emb_l2=np.float64(np.sqrt((ge.astype(np.float64) ** 2).sum())),
+               gt_sdf_bias=np.float32(MG.GT_SDF_BIAS), n_rand=np.int64(len(rec["rand"])), n_normal=np.int64(len(rec.get("normal", []))))
+    if rec.get("normal"):
+        out["bkg_normal_draws"] = np.stack([x for x in rec["normal"]])
+    for k, v in rec["grads"].items():
+        if k != "encoder.embeddings":
+            out["grad." + k] = v
+    np.savez_compressed(os.path.join(HERE, "trainer_step.npz"), **out)
+    print("trainer golden: view", int(rec["perm"][0]), "prompt", repr(rec["prompt"]), "bkg key", out["bkg_key"], "py randint", rec["py_randint"], "rays", out["rays_o"].shape,
+          "t", int(out["sd_t"][0]), "opacity loss", out["opacity_loss"], "eikonal", out["eikonal"], "emb nnz", len(nz), "torch.rand draws", len(rec["rand"]), "randn_like draws", len(rec["randn_like"]), "randint draws", len(rec["randint"]),
+          "bkg draws", len(rec["bkg"]), "max |grad sdf0.v|", float(np.abs(out["grad.sdf_net.0.weight_v"]).max()))
+
+
+if __name__ == "__main__":
+    main()
