@@ -81,7 +81,8 @@ constexpr int CF_OVERLAY = OFF_B1 - OFF_C1F;      // floats of the overlay: the 
 // per-wave slab of the renderer: the final z values (zs0) + ONE region that holds the up-sampling state (second z buffer, the two sdf
 // buffers, cdf, new samples) until the sampling of the ray is finished and the finite-difference feature slab afterwards
 constexpr int UPS_FLOATS = MAXT + 2 * MAXT + MAXT + 32;              // zs1[128], sd[2][128], cdf[128], znew[16] + pad
-constexpr int WAVE_SLAB = MAXT + (FE_SLAB > UPS_FLOATS ? FE_SLAB : UPS_FLOATS);
+constexpr int SLAB_ACC = MAXT + (FE_SLAB > UPS_FLOATS ? FE_SLAB : UPS_FLOATS);     // the ray's ten running sums (compositing, eikonal): [16] floats, kept by lane 15
+constexpr int WAVE_SLAB = SLAB_ACC + 16;
 constexpr int LDS_FLOATS = OFF_RWAVE + WAVES_PER_BLOCK * WAVE_SLAB;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget: one workgroup per CU");
 static_assert(OFF_WAVE % 4 == 0 && OFF_RWAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
@@ -124,8 +125,8 @@ struct RenderArgs {
     uint32_t *ray_counter;         // AC_DYNAMIC_RAYS: [8 XCDs][8 segments] work counters (zeroed before the launch): waves fetch their next (ray, segment) instead of owning fixed rays
     uint32_t *seg_flags;           // [N] number of finished segments of each ray (zeroed before the launch), or NULL when seg_n == 1
     float *seg_state;              // [N][SEG_STATE] what a ray's next segment continues from: z values + running sums (library scratch)
-    uint32_t seg_cb;               // first tile of segment s in bits 4s .. 4s+3, s = 0 .. seg_n
-    int seg_n;                     // segments per ray (1 .. 4)
+    uint64_t seg_cb;               // first tile of segment s in bits 4s .. 4s+3, s = 0 .. seg_n
+    int seg_n;                     // segments per ray (1 .. 8)
     const uint8_t *ray_dead;       // MODE_UPSAMPLE, skip_masked: [N] rays that cannot hold an unmasked sample (no field evaluation, coarse z only)
     float *zbuf;                   // [N,T] final z values: written by MODE_UPSAMPLE, read by MODE_FINAL
     float *mid_pts;                // MODE_UPSAMPLE: posed-space mid points [N,T,3]

@@ -41,7 +41,9 @@ namespace {
 #ifndef AC_FAST_COLOR
 #define AC_FAST_COLOR 1            // fast precision: the colour network in split bf16 too (0: only layer 1 of the finite-difference evaluations)
 #endif
-template <int MODE, bool FAST>
+// EX = false: a launch that wants the per-ray results only (image, weights_sum, depth, normal_map, eik): none of the optional per-sample outputs is
+// compiled in, which takes their sixteen pointers (and the address arithmetic on them) out of the register budget of the tile loop
+template <int MODE, bool FAST, bool EX>
 __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 {
     constexpr bool FC = FAST && AC_FAST_COLOR;
@@ -164,26 +166,6 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 continue;
             }
         }
-        float cT = 1.0f;                                        // transmittance carry (cumprod)
-        float s_w = 0.0f, s_r = 0.0f, s_g = 0.0f, s_b = 0.0f, s_nx = 0.0f, s_ny = 0.0f, s_nz = 0.0f, s_d = 0.0f,
-              s_en = 0.0f, s_ed = 0.0f;
-        if (!seg_first) {
-            // continue a ray another wave (of this XCD) started: wait until its previous segment is published, then take over z and the running sums.
-            // All accesses to seg_flags / seg_state are agent-scope atomics = served by the XCD's L2, past the (incoherent) vector L1 caches.
-            if (lane == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(a.seg_flags + ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)seg && spins < (1 << 21)) {
-                    __builtin_amdgcn_s_sleep(8); ++spins;       // (bounded: ~1 s; a ray's previous segment takes ~100 us)
-                }
-            }
-            wave_sync();
-            const uint32_t *st = reinterpret_cast<const uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
-            if constexpr (MODE != MODE_FINAL)
-                for (int i = lane; i < T; i += 64) zs0[i] = __uint_as_float(__hip_atomic_load(st + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const float cv = __uint_as_float(__hip_atomic_load(st + MAXT + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            cT = lane_bcast(cv, 0); s_w = lane_bcast(cv, 1); s_r = lane_bcast(cv, 2); s_g = lane_bcast(cv, 3); s_b = lane_bcast(cv, 4);
-            s_nx = lane_bcast(cv, 5); s_ny = lane_bcast(cv, 6); s_nz = lane_bcast(cv, 7); s_d = lane_bcast(cv, 8); s_en = lane_bcast(cv, 9); s_ed = lane_bcast(cv, 10);
-        }
         // ---- coarse samples :155-180 -------------------------------------------------------------
         if constexpr (MODE == MODE_FINAL) {
             for (int i = lane; i < T; i += 64) zs0[i] = a.zbuf[(size_t)ray * T + i];
@@ -297,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             if (g == 0) {
                 znl[n] = znew;
-                if (a.out.ss_inds) a.out.ss_inds[((size_t)ray * nup + it) * 16 + n] = ind;
+                if (EX && a.out.ss_inds) a.out.ss_inds[((size_t)ray * nup + it) * 16 + n] = ind;
             }
             AC_TICK(1)
             const bool last_it = (it + 1 == nup);
@@ -313,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             // stable merge == torch.sort(cat([z, znew])) :466-473.  The old z are sorted except in the first iteration of a ray whose slab
             // test gave far < near (it misses the cube: its coarse z run from near DOWN to far): there the old elements are ranked too
             const bool old_sorted = !(it == 0 && span < 0.0f);         // wave-uniform
-            int32_t *sidx = a.out.sort_index ? a.out.sort_index + ((size_t)ray * nup + it) * 128 : nullptr;
+            int32_t *sidx = (EX && a.out.sort_index) ? a.out.sort_index + ((size_t)ray * nup + it) * 128 : nullptr;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const int i = 64 * ch + lane;
@@ -364,6 +346,29 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             wave_sync();
             continue;
         }
+        float cT = 1.0f;                                        // transmittance carry (cumprod)
+        // the ten running sums of the ray (weights, colour, normal, depth, eikonal numerator / denominator) live in the wave's LDS slab, not in
+        // registers: they are touched once per tile by one lane (lane 15, which holds the tile totals of the row scans), and ten registers less at the
+        // peak of the stencil / MLP code is the difference between ~30 and ~10 spilled registers.  Slots: 1 s_w 2..4 rgb 5..7 normal 8 depth 9 10 eikonal
+        float *const accs = zs0 + SLAB_ACC;
+        if (!seg_first) {
+            // continue a ray another wave (of this XCD) started: wait until its previous segment is published, then take over z and the running sums.
+            // All accesses to seg_flags / seg_state are agent-scope atomics = served by the XCD's L2, past the (incoherent) vector L1 caches.
+            if (lane == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(a.seg_flags + ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)seg && spins < (1 << 21)) {
+                    __builtin_amdgcn_s_sleep(8); ++spins;       // (bounded: ~1 s; a ray's previous segment takes ~100 us)
+                }
+            }
+            wave_sync();
+            const uint32_t *st = reinterpret_cast<const uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
+            if constexpr (MODE != MODE_FINAL)
+                for (int i = lane; i < T; i += 64) zs0[i] = __uint_as_float(__hip_atomic_load(st + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float cv = __uint_as_float(__hip_atomic_load(st + MAXT + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            cT = lane_bcast(cv, 0);
+            if (lane < 16) accs[lane] = cv;
+            wave_sync();
+        }
         const float bxe = a.eps;
         const int c_hi = c_end < T / 16 ? c_end : T / 16;
         for (int c = c_begin; c < c_hi; ++c) {
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             if (!skip) {
             float fe0[4][2];
             encode_stencil<(FAST && AC_FACE_VALUE) ? 1 : 0>(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
-            if (a.out.feat7) {                                     // training render: keep the 7 x 8 features of this lane (the backward streams them back)
+            if (EX && a.out.feat7) {                                     // training render: keep the 7 x 8 features of this lane (the backward streams them back)
                 const size_t nt4 = (size_t)a.n_rays * T * 4, at = ((size_t)ray * T + i) * 4 + g;
 #pragma unroll
                 for (int q_ = 0; q_ < 8; ++q_) a.out.feat7[q_ * nt4 + at] = fe0[q_ >> 1][q_ & 1];
@@ -490,26 +495,29 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float relax = (pn < 1.2f && !skip) ? 1.0f : 0.0f;
             const float eerr = relax * ((gn - 1.0f) * (gn - 1.0f));
             // reductions (lane 15 of row 0 holds the tile totals)
-#define AC_ACC(S, V) { const float t_ = lane_bcast(row_scan<false>(V), 15); S = (c == 0) ? t_ : S + t_; }
-            AC_ACC(s_w, wgt)
-            AC_ACC(s_r, rgb[0] * wgt) AC_ACC(s_nx, nx * wgt)
-            AC_ACC(s_g, rgb[1] * wgt) AC_ACC(s_ny, ny * wgt)
-            AC_ACC(s_b, rgb[2] * wgt) AC_ACC(s_nz, nz * wgt)
-            AC_ACC(s_d, wgt * zn01)
-            AC_ACC(s_en, eerr) AC_ACC(s_ed, relax)
+            // reductions: lane 15 holds the tile totals of the row scans and adds them to the ray's running sums (sequential over the tiles, like the oracle)
+            {
+                const float t1 = row_scan<false>(wgt), t2 = row_scan<false>(rgb[0] * wgt), t3 = row_scan<false>(rgb[1] * wgt), t4 = row_scan<false>(rgb[2] * wgt),
+                            t5 = row_scan<false>(nx * wgt), t6 = row_scan<false>(ny * wgt), t7 = row_scan<false>(nz * wgt), t8 = row_scan<false>(wgt * zn01),
+                            t9 = row_scan<false>(eerr), t10 = row_scan<false>(relax);
+                if (lane == 15) {
+#define AC_ACC(K, T_) accs[K] = (c == 0) ? T_ : accs[K] + T_;
+                    AC_ACC(1, t1) AC_ACC(2, t2) AC_ACC(3, t3) AC_ACC(4, t4) AC_ACC(5, t5) AC_ACC(6, t6) AC_ACC(7, t7) AC_ACC(8, t8) AC_ACC(9, t9) AC_ACC(10, t10)
 #undef AC_ACC
+                }
+            }
             AC_TICK(6)
             if (g == 0) {
                 const size_t si = (size_t)ray * T + i;
-                if (a.out.z_vals) a.out.z_vals[si] = zi;
-                if (a.out.weights) a.out.weights[si] = wgt;
-                if (a.out.alpha) a.out.alpha[si] = alpha;
-                if (a.out.sdf) a.out.sdf[si] = sdf0;
-                if (a.out.color) { a.out.color[3 * si] = rgb[0]; a.out.color[3 * si + 1] = rgb[1]; a.out.color[3 * si + 2] = rgb[2]; }
-                if (a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
-                if (a.out.pts) { a.out.pts[3 * si] = px; a.out.pts[3 * si + 1] = py; a.out.pts[3 * si + 2] = pz; }
+                if (EX && a.out.z_vals) a.out.z_vals[si] = zi;
+                if (EX && a.out.weights) a.out.weights[si] = wgt;
+                if (EX && a.out.alpha) a.out.alpha[si] = alpha;
+                if (EX && a.out.sdf) a.out.sdf[si] = sdf0;
+                if (EX && a.out.color) { a.out.color[3 * si] = rgb[0]; a.out.color[3 * si + 1] = rgb[1]; a.out.color[3 * si + 2] = rgb[2]; }
+                if (EX && a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
+                if (EX && a.out.pts) { a.out.pts[3 * si] = px; a.out.pts[3 * si + 1] = py; a.out.pts[3 * si + 2] = pz; }
             }
-            if (a.out.sdf_out16) *reinterpret_cast<f32x4 *>(a.out.sdf_out16 + ((size_t)ray * T + i) * 16 + 4 * g) = oc;     // lane (n, g) holds outputs 4g..4g+3
+            if (EX && a.out.sdf_out16) *reinterpret_cast<f32x4 *>(a.out.sdf_out16 + ((size_t)ray * T + i) * 16 + 4 * g) = oc;     // lane (n, g) holds outputs 4g..4g+3
         }
         if (!seg_last) {
             // hand the ray to its next segment: z values (once), the running sums, then the flag -- in that order (the stores are complete in L2
@@ -517,9 +525,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             uint32_t *st = reinterpret_cast<uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
             if (MODE != MODE_FINAL && seg_first)
                 for (int i = lane; i < T; i += 64) __hip_atomic_store(st + i, __float_as_uint(zf[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_sync();
             if (lane < 11) {
-                const float cv = lane == 0 ? cT : lane == 1 ? s_w : lane == 2 ? s_r : lane == 3 ? s_g : lane == 4 ? s_b : lane == 5 ? s_nx : lane == 6 ? s_ny :
-                                 lane == 7 ? s_nz : lane == 8 ? s_d : lane == 9 ? s_en : s_ed;
+                const float cv = lane == 0 ? cT : accs[lane];
                 __hip_atomic_store(st + MAXT + lane, __float_as_uint(cv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -528,7 +536,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             wave_sync();
             continue;
         }
+        wave_sync();
         if (lane == 0) {
+            const float s_w = accs[1], s_r = accs[2], s_g = accs[3], s_b = accs[4], s_nx = accs[5], s_ny = accs[6], s_nz = accs[7], s_d = accs[8], s_en = accs[9], s_ed = accs[10];
             const float b0 = a.bg ? a.bg[3 * ray] : 1.0f, b1 = a.bg ? a.bg[3 * ray + 1] : 1.0f, b2 = a.bg ? a.bg[3 * ray + 2] : 1.0f;
             a.out.image[3 * ray] = s_r + (1.0f - s_w) * b0;
             a.out.image[3 * ray + 1] = s_g + (1.0f - s_w) * b1;
@@ -699,7 +709,7 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
 // 16 rotating slots per device, each grown to the largest batch it has served and kept for the life of the process (launches of one stream run in
 // order; 16 launches in flight across streams would be needed for two of them to share a slot).  Counters and flags are zeroed before every launch.
 #ifndef AC_RAY_SEGMENTS
-#define AC_RAY_SEGMENTS 4           // segments a ray is cut into (1 = whole rays as work items, rounds 1 - 2)
+#define AC_RAY_SEGMENTS 4           // segments a ray is cut into (1 = whole rays as work items, rounds 1 - 2; at most 8)
 #endif
 struct SegSlot { char *p; size_t bytes; };
 static char *seg_scratch(size_t need)
@@ -722,22 +732,23 @@ static char *seg_scratch(size_t need)
     return sl.p;
 }
 
-template <int MODE, bool FAST>
+template <int MODE, bool FAST, bool EX>
 static void launch_render_p(const RenderArgs &a, hipStream_t stream)
 {
     int blocks = (a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     static uint64_t seen = 0;                       // one flag per instantiation
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(render_rays_kernel<MODE, FAST>), lds_bytes);
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(render_rays_kernel<MODE, FAST, EX>), lds_bytes);
 #if AC_DYNAMIC_RAYS
     RenderArgs b = a;
     {
         // segments: the tiles of a ray in seg_n nearly equal runs; the sampling stage (about 1.6 tiles' worth of time) rides with the first
         const int nt = (a.T0 + 16 * a.nup) / 16;
-        int sn = (MODE == MODE_UPSAMPLE) ? 1 : (nt < AC_RAY_SEGMENTS ? nt : AC_RAY_SEGMENTS);
+        // (posed space: the final pass stays with whole rays -- with skip_masked most of its tiles are skipped anyway, and segments measured 8 % slower there)
+        int sn = (MODE != MODE_FULL) ? 1 : (nt < AC_RAY_SEGMENTS ? nt : AC_RAY_SEGMENTS);
         if (sn < 1) sn = 1;
         b.seg_n = sn; b.seg_cb = 0;
-        for (int q = 0; q <= sn; ++q) b.seg_cb |= (uint32_t)((nt * q) / sn) << (4 * q);
+        for (int q = 0; q <= sn; ++q) b.seg_cb |= (uint64_t)((nt * q) / sn) << (4 * q);
         const size_t N = (size_t)a.n_rays, head = 256, flags = (N * 4 + 255) & ~(size_t)255;
         const size_t need = head + (sn > 1 ? flags + N * SEG_STATE * sizeof(float) : 0);
         char *sc = seg_scratch(need);
@@ -750,18 +761,26 @@ static void launch_render_p(const RenderArgs &a, hipStream_t stream)
         blocks = (blocks + 7) & ~7;                                      // every XCD gets the same number of workgroups
         if (!sc) blocks = 0;                                             // (the scratch could not be allocated: an empty grid is a launch error the caller reports)
     }
-    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, b);
+    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST, EX>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, b);
 #else
-    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST, EX>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
 #endif
+}
+static bool wants_samples(const ac_render_out &o)
+{
+    return o.z_vals || o.weights || o.alpha || o.color || o.sdf || o.gradient || o.ss_inds || o.sort_index || o.sdf_out16 || o.pts || o.feat7;
 }
 template <int MODE>
 static void launch_render(const RenderArgs &a, hipStream_t stream)
 {
+    const bool ex = wants_samples(a.out);
     if constexpr (MODE != MODE_UPSAMPLE) {          // (the sampling-only launch has no finite-difference stage)
-        if (a.fast) { launch_render_p<MODE, true>(a, stream); return; }
+        if (a.fast) { if (ex) launch_render_p<MODE, true, true>(a, stream); else launch_render_p<MODE, true, false>(a, stream); return; }
+        if (ex) launch_render_p<MODE, false, true>(a, stream); else launch_render_p<MODE, false, false>(a, stream);
+        return;
     }
-    launch_render_p<MODE, false>(a, stream);
+    if (a.out.ss_inds || a.out.sort_index) launch_render_p<MODE, false, true>(a, stream);      // (the sampling-only launch can export the sample indices)
+    else launch_render_p<MODE, false, false>(a, stream);
 }
 
 AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,

@@ -201,6 +201,7 @@ class NeRFRenderer(nn.Module):
     # which no inference driver reads, covers the evaluated samples only).  False (default): every output as the reference computes it.
     # drivers.render_animation (render_warp.py's loop, which keeps rgb only) switches it on.
     skip_masked_samples = False
+    supports_lean_render = True        # render(..., per_sample=False) exists (render_utils.render_instantnsr_naive asks before passing it)
 
     def _offsets_host(self):
         oh = getattr(self, "_offsets_cache", None)
@@ -239,7 +240,10 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ run == reference :133-299
     def run(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0,
-            render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True):
+            render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True, per_sample: bool = True):
+        """per_sample = False (not in the reference's signature; what render_instantnsr_naive passes for its no-grad renders): the per-sample
+        results (weights, pts_color, pts_alpha, z_vals) are not produced -- None in the returned tuple -- and the launch runs the renderer's
+        lean instantiation (no optional outputs compiled in: no register spills, 12.6 MB less to write per 4096 rays)."""
         if not self._sdf_supported():
             raise NotImplementedError("the MI355X renderer needs the default SDF side of NeRFNetwork (16-level hash grid, include_input, "
                                       "SDF network 35-64-16); other widths / depths have no sampling kernel")
@@ -298,10 +302,10 @@ class NeRFRenderer(nn.Module):
             return self._render_core_autograd(ro, rd, z_vals, num_steps, upsample_steps, bound, bg, cos_anneal_ratio, normal_epsilon_ratio, B, N,
                                               near_far=near_far)
         out = nsr_ops.render_rays(self._field(), ro, rd, num_steps, upsample_steps, bound, inv_s_t, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
-                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=True, warp=warp, near_far=near_far, precision=self.render_precision,
-                                  skip_masked=self.skip_masked_samples)
-        return (out["depth"].reshape(B, N), out["weights"], out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
-                out["normal_map"], out["gradient_error"], 0.0, out["color"], out["alpha"], out["z_vals"])
+                                  normal_epsilon_ratio=normal_epsilon_ratio, extras=bool(per_sample), warp=warp, near_far=near_far,
+                                  precision=self.render_precision, skip_masked=self.skip_masked_samples)
+        return (out["depth"].reshape(B, N), out.get("weights"), out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
+                out["normal_map"], out["gradient_error"], 0.0, out.get("color"), out.get("alpha"), out.get("z_vals"))
 
     def _render_core_autograd(self, rays_o, rays_d, z_vals, num_steps0, upsample_steps, bound, bg_color, cos_anneal_ratio,
                               normal_epsilon_ratio, B, N, near_far=None):
@@ -380,7 +384,7 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ render == reference :358-408
     def render(self, rays_o, rays_d, num_steps, bound, upsample_steps, staged=False, max_ray_batch=4096, bg_color=None,
                cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0, render_can=True, verts=None, faces=None, Ts=None, perturb: bool = False,
-               use_mesh_guide: bool = True, **kwargs):
+               use_mesh_guide: bool = True, per_sample: bool = True, **kwargs):
         B, N = rays_o.shape[:2]
         device = rays_o.device
         if staged and not self.cuda_ray:
@@ -400,7 +404,7 @@ class NeRFRenderer(nn.Module):
         else:
             (depth, weights, weight_sum, image, normal, gradient_error, curvature_error, pts_color, pts_alpha, z_vals) = self.run(
                 rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio, normal_epsilon_ratio, render_can=render_can,
-                verts=verts, faces=faces, Ts=Ts, perturb_overwrite=perturb, use_mesh_guide=use_mesh_guide)
+                verts=verts, faces=faces, Ts=Ts, perturb_overwrite=perturb, use_mesh_guide=use_mesh_guide, per_sample=per_sample)
         return {'depth': depth, 'weights': weights, 'weight_sum': weight_sum, 'rgb': image, 'normal': normal,
                 'gradient_error': gradient_error, 'curvature_error': curvature_error, 'pts_color': pts_color, 'pts_alpha': pts_alpha,
                 'z_vals': z_vals}

@@ -80,13 +80,15 @@ def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_g
     total_eikonal = 0.0
     if not render_can and verts is not None and not isinstance(verts, nsr_ops.WarpMesh):
         verts = nsr_ops.WarpMesh(verts, faces, Ts, device)       # upload the frame's mesh once, not once per ray batch
+    # the harness keeps rgb / depth / weight_sum / normal only: a no-grad render of this package's NeRFNetwork skips the per-sample outputs
+    lean = {"per_sample": False} if (not requires_grad and getattr(net, "supports_lean_render", False)) else {}
     with torch.set_grad_enabled(requires_grad):
         for i in range(0, total, rays_per_batch):
             ro, rd = rays_o[i:i + rays_per_batch], rays_d[i:i + rays_per_batch]
             background_rgb = _background_on(device, ro.shape, bkg_key)
             out = net.render(ro.unsqueeze(0), rd.unsqueeze(0), num_steps=num_steps, upsample_steps=upsample_steps, bound=bound, staged=False,
                              bg_color=background_rgb, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=render_can, verts=verts,
-                             faces=faces, Ts=Ts, perturb=perturb)
+                             faces=faces, Ts=Ts, perturb=perturb, **lean)
             total_eikonal = total_eikonal + out["gradient_error"]
             rgbs.append(out['rgb']); wsums.append(out['weight_sum']); depths.append(out['depth']); normals.append(out['normal'])
         cat = lambda ts, dim=0: ts[0] if len(ts) == 1 else torch.cat(ts, dim=dim)      # one batch (every training patch): nothing to copy

@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r02"
+rnd = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 short = lambda n: re.sub(r"\(anonymous namespace\)::|void ", "", n).split("(")[0]
@@ -40,14 +40,20 @@ def main():
     rows = list(csv.DictReader(open(glob.glob(src + "/kt/**/p_kernel_trace.csv", recursive=True)[0])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    fast = [dur(r) for r in rows if "render_rays_kernel<0, true>" in r["Kernel_Name"]]
-    exact = [dur(r) for r in rows if "render_rays_kernel<0, false>" in r["Kernel_Name"]]
-    # bench.py (default precision fast): W + K fast launches, then the other mode (min(W, 2) + K exact launches), WHOLE_VIEW fast launches of 65 536
-    # rays, then the SDS steps (three fast renders each)
-    split = {"render_rays_kernel<0, fast> main bench, timed launches": fast[W:W + K], "render_rays_kernel<0, fast> main bench, warm-up": fast[:W],
-             "render_rays_kernel<0, exact> the other arithmetic mode, same launches (roofline.other_precision)": exact[min(W, 2):min(W, 2) + K],
-             "render_rays_kernel<0, fast> whole view (65 536 rays) in one launch": fast[W + K:W + K + WHOLE_VIEW],
-             "render_rays_kernel<0, fast> SDS step (training view: every ray hits the body)": fast[W + K + WHOLE_VIEW:]}
+    # render_rays_kernel<MODE, FAST, EX>: <0, false, false> = exact, no per-sample outputs (the bench, render_val, the frozen net's render);
+    # <0, false, true> = exact with per-sample outputs (the training forward); <0, true, *> = the fast arithmetic mode
+    lean = [dur(r) for r in rows if "render_rays_kernel<0, false, false>" in r["Kernel_Name"]]
+    fast = [dur(r) for r in rows if "render_rays_kernel<0, true, false>" in r["Kernel_Name"]]
+    train = [dur(r) for r in rows if "render_rays_kernel<0, false, true>" in r["Kernel_Name"]]
+    R = int(bench.get("repeat", 1))
+    nm = W + R * K
+    # bench.py (default precision exact): W + repeat x K exact launches, then the other mode (min(W, 2) + K fast launches), WHOLE_VIEW exact launches of
+    # 65 536 rays, then the SDS steps (two lean renders + one training forward each)
+    split = {"render_rays_kernel<0, exact, lean> main bench, timed launches": lean[W:nm], "render_rays_kernel<0, exact, lean> main bench, warm-up": lean[:W],
+             "render_rays_kernel<0, fast, lean> the other arithmetic mode, same launches (roofline.other_precision)": fast[min(W, 2):min(W, 2) + K],
+             "render_rays_kernel<0, exact, lean> whole view (65 536 rays) in one launch": lean[nm:nm + WHOLE_VIEW],
+             "render_rays_kernel<0, exact, lean> SDS step: render_val + frozen-net render (training view: every ray hits the body)": lean[nm + WHOLE_VIEW:],
+             "render_rays_kernel<0, exact, per-sample outputs> SDS step: the training forward": train}
     byw = {k: dict(calls=len(v), avg_us=sum(v) / len(v), min_us=min(v), max_us=max(v)) for k, v in split.items() if v}
     byw["bench_line"] = dict(kernel_ms_hip_events=bench["roofline"]["kernel_ms"], ms_per_step=bench["ms_per_step"])
     json.dump(byw, open(f"{dst}/{rnd}_kernel_stats_by_workload.json", "w"), indent=1)
@@ -64,13 +70,14 @@ def main():
     log = open(glob.glob(src + "/g1.log")[0]).read()
     pb = json.loads([l for l in log.splitlines() if l.startswith("{")][-1])
     n_main = pb["warmup"] + pb["steps"]
-    rk = [k for k in fetch if k.startswith("render_rays_kernel<0")][0]
+    rk = [k for k in fetch if k.startswith("render_rays_kernel<0, false, false")][0]
+    rkt = [k for k in fetch if k.startswith("render_rays_kernel<0, false, true")]
     main_f = fetch[rk][:n_main]
     sds_f, sds_w = fetch[rk][n_main + WHOLE_VIEW:], write[rk][n_main + WHOLE_VIEW:]
+    trn_f, trn_w = (fetch[rkt[0]], write[rkt[0]]) if rkt else ([0.0], [0.0])
     KB = 1024
     mean = lambda v: sum(v) / len(v)
-    step = 3 * (mean(sds_f) + mean(sds_w))
-    parts = {"3 x render_rays_kernel": step * KB}
+    parts = {"2 x render_rays_kernel (lean)": 2 * (mean(sds_f) + mean(sds_w)) * KB, "render_rays_kernel (training forward)": (mean(trn_f) + mean(trn_w)) * KB}
     for k in fetch:
         if any(s in k for s in ("hash_stencil_bwd", "bucket_acc", "sdf_stencil_bwd", "color_bwd", "composite_bwd", "core_mid", "core_normals")):
             parts[k] = (mean(fetch[k]) + mean(write[k])) * KB
@@ -79,20 +86,39 @@ def main():
     byc = {}
     for f in glob.glob(src + "/g*/p_counter_collection.csv"):
         vals = collections.defaultdict(dict)
+        valt = collections.defaultdict(dict)
         for r in csv.DictReader(open(f)):
             if short(r["Kernel_Name"]) == rk:
                 vals[r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
+            elif rkt and short(r["Kernel_Name"]) == rkt[0]:
+                valt[r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
         for c, v in vals.items():
             seq = [v[i] for i in sorted(v)]
             byc[c] = {"main bench (4096 rays)": mean(seq[:n_main]), "whole view (65 536 rays)": mean(seq[n_main:n_main + WHOLE_VIEW]),
-                      "SDS renders (4096 rays, training view)": mean(seq[n_main + WHOLE_VIEW:])}
+                      "SDS renders without per-sample outputs (4096 rays, training view)": mean(seq[n_main + WHOLE_VIEW:])}
+            if c in valt:
+                byc[c]["SDS training forward (per-sample outputs + stencil features kept)"] = mean(list(valt[c].values()))
     json.dump({"kernel": rk, "per_launch_mean_by_workload": byc}, open(f"{dst}/{rnd}_pmc_render_by_workload.json", "w"), indent=1)
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    # matrix-pipe occupancy of the render kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel clocks); clocks from the trace's mean duration x the
+    # sustained shader clock (2.1 GHz, tools/phase_profile.py)
+    mfma_busy = {}
+    for prec, key, durs in (("exact", rk, lean[W:nm]), ("fast", "render_rays_kernel<0, true, false>", fast[min(W, 2):min(W, 2) + K])):
+        for f in glob.glob(src + "/g*/p_counter_collection.csv"):
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES" and short(r["Kernel_Name"]).startswith(key)]
+            if v and durs:
+                n = n_main if prec == "exact" else len(v)
+                mfma_busy[prec] = round(mean(v[:n]) / 1024.0 / (mean(durs) * 1e-6 * 2.1e9), 4)
     traffic = {
         "render_rays_kernel_hbm_bytes_per_launch": int(mean(main_f) * KB),
         "sds_step_hbm_bytes_per_step": int(sum(parts.values())),
         "sds_step_by_kernel": {k: int(v) for k, v in parts.items()},
-        "commit": head, "profile": f"tools/prof_r02.sh {tag} -> profiles/{rnd}_pmc_summary.json",
+        "commit": head, "profile": f"tools/prof_r03.sh {tag} -> profiles/{rnd}_pmc_summary.json",
+        "command": f"bench.py --steps {pb['steps']} --warmup {pb['warmup']} --sds-steps 2 --posed-frames 1 --repeat 1 under rocprofv3 --pmc (one pass per counter group)",
+        "render_rays_kernel_mfma_busy_frac": mfma_busy,
+        "fetch_size_note": ("FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950; calibrated for THIS access pattern (8-byte gathers, one 64-byte sector per L2 miss: "
+                            "profiles/r01_fetch_calibration.txt) -> factor 1.0 used; the guide's x2 correction applies to wide coalesced streaming reads "
+                            "(128-byte requests tallied at 64 B), which this kernel does not issue -- with x2 the figure would still be below the algorithmic bytes"),
         "_note": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) on `bench.py --steps {pb['steps']} --warmup {pb['warmup']} --sds-steps 2 "
                   f"--posed-frames 1`. render: mean FETCH_SIZE of the {n_main} main-bench dispatches of {rk} (KB x 1024; WRITE_SIZE "
                   f"{mean(write[rk][:n_main]):.0f} KB). sds_step: FETCH_SIZE + WRITE_SIZE of the HIP kernels of one step (three renders of the training "
