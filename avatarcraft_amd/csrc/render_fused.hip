@@ -101,7 +101,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 #ifndef AC_START_STAGGER
 #define AC_START_STAGGER 3
 #endif
-    for (int k_ = 0; k_ < AC_START_STAGGER * wave; ++k_) __builtin_amdgcn_s_sleep(64);
+    // (only launches that fill the device: a small batch -- a posed frame's tail, a unit test -- has no lock-step to break and would only pay the delay)
+    if (a.n_rays >= 2048)
+        for (int k_ = 0; k_ < AC_START_STAGGER * wave; ++k_) __builtin_amdgcn_s_sleep(64);
 #if AC_DYNAMIC_RAYS
     // Work items are (ray, segment) pairs fetched one at a time from per-XCD counters.  A ray is cut into seg_n segments of the tile loop (segment 0 =
     // the sampling stage + the first tiles); a wave that finishes a segment leaves the ray's z values and running sums in seg_state and raises the ray's
