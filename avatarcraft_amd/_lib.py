@@ -79,6 +79,7 @@ _SIGS = {
     "ac_compact_rays": ([u32, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_field_prepare": ([C.POINTER(ac_field), vp, vp], C.c_int),
     "ac_render_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_render_out), vp], C.c_int),
+    "ac_render_rays_pair": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_render_out), vp], C.c_int),
     "ac_sample_rays": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_eikonal_reduce": ([vp, i32, vp, vp], C.c_int),
     "ac_eikonal_reduce2": ([vp, i32, vp, vp], C.c_int),

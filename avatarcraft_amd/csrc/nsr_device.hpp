@@ -127,6 +127,11 @@ struct RenderArgs {
     float *seg_state;              // [N][SEG_STATE] what a ray's next segment continues from: z values + running sums (library scratch)
     uint64_t seg_cb;               // first tile of segment s in bits 4s .. 4s+3, s = 0 .. seg_n
     int seg_n;                     // segments per ray (1 .. 8)
+    // pair launches (ac_render_rays_pair): the same pair_n rays twice, n_rays = 2 * pair_n work items handed out as a0 b0 a1 b1 ...; copy a = rows
+    // [0, pair_n), copy b = rows [pair_n, 2 pair_n) of noise, bg and the per-ray outputs; rays_o / rays_d / near_m / far_m have pair_n rows.  0 = off.
+    int pair_n;
+    int ex_from;                   // the per-sample outputs (EX kernels) are kept for rays >= ex_from only, at row ray - ex_from of arrays with ex_rows rows
+    int ex_rows;
     const uint8_t *ray_dead;       // MODE_UPSAMPLE, skip_masked: [N] rays that cannot hold an unmasked sample (no field evaluation, coarse z only)
     float *zbuf;                   // [N,T] final z values: written by MODE_UPSAMPLE, read by MODE_FINAL
     float *mid_pts;                // MODE_UPSAMPLE: posed-space mid points [N,T,3]

@@ -130,20 +130,25 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             ray = base + (ray - k * xchunk);
             if (ray >= a.n_rays) continue;
         }
+        int rin = ray;                                               // row of this ray in rays_o / rays_d / near_m / far_m
+        if (a.pair_n) { rin = ray >> 1; ray = rin + ((ray & 1) ? a.pair_n : 0); }      // a0 b0 a1 b1 ...: the two copies of a ray meet in their XCD's L2
         (void)bid;
 #else
     const int seg_n = 1, seg = 0, c_begin = 0, c_end = MAXT / 16;
     const bool seg_first = true, seg_last = true;
     {
     for (int ray = bid * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
+        const int rin = ray;
 #endif
+        const int exr = ray - a.ex_from;                             // row in the per-sample outputs (pair launches keep them for copy b only)
+        const bool ex_on = exr >= 0;
         AC_T0();
-        const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
-        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+        const float ox = a.rays_o[3 * rin], oy = a.rays_o[3 * rin + 1], oz = a.rays_o[3 * rin + 2];
+        const float dx = a.rays_d[3 * rin], dy = a.rays_d[3 * rin + 1], dz = a.rays_d[3 * rin + 2];
         float near, far;
         cube_near_far(ox, oy, oz, dx, dy, dz, bound, near, far);
         if (a.near_m) {                                          // :148-153 mesh-guided range where the ray passes the body
-            const float nm = a.near_m[ray], fm = a.far_m[ray];
+            const float nm = a.near_m[rin], fm = a.far_m[rin];
             if (!is_inf(nm)) near = nm;
             if (!is_inf(fm)) far = fm;
         }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             if (g == 0) {
                 znl[n] = znew;
-                if (EX && a.out.ss_inds) a.out.ss_inds[((size_t)ray * nup + it) * 16 + n] = ind;
+                if (EX && ex_on && a.out.ss_inds) a.out.ss_inds[((size_t)exr * nup + it) * 16 + n] = ind;
             }
             AC_TICK(1)
             const bool last_it = (it + 1 == nup);
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             // stable merge == torch.sort(cat([z, znew])) :466-473.  The old z are sorted except in the first iteration of a ray whose slab
             // test gave far < near (it misses the cube: its coarse z run from near DOWN to far): there the old elements are ranked too
             const bool old_sorted = !(it == 0 && span < 0.0f);         // wave-uniform
-            int32_t *sidx = (EX && a.out.sort_index) ? a.out.sort_index + ((size_t)ray * nup + it) * 128 : nullptr;
+            int32_t *sidx = (EX && ex_on && a.out.sort_index) ? a.out.sort_index + ((size_t)exr * nup + it) * 128 : nullptr;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const int i = 64 * ch + lane;
@@ -399,14 +404,18 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             if (!skip) {
             float fe0[4][2];
             encode_stencil<(FAST && AC_FACE_VALUE) ? 1 : 0>(lds, fsl, fc, lane, px, py, pz, bxe, fe0);
-            if (EX && a.out.feat7) {                                     // training render: keep the 7 x 8 features of this lane (the backward streams them back)
-                const size_t nt4 = (size_t)a.n_rays * T * 4, at = ((size_t)ray * T + i) * 4 + g;
-#pragma unroll
-                for (int q_ = 0; q_ < 8; ++q_) a.out.feat7[q_ * nt4 + at] = fe0[q_ >> 1][q_ & 1];
+            if (EX && ex_on && a.out.feat7) {                                     // training render: keep the 7 x 8 features of this lane (the backward streams them back)
+                // layout [tile of 16 samples][14][lane][4]: float k = 8 e + q (evaluation e, slot q = 2 j + channel) of lane (n, g) sits in group k / 4,
+                // component k % 4 -- every store (and every load of the backward) is one 16-byte access per lane, 1 KB contiguous per wave
+                f32x4 *dst = reinterpret_cast<f32x4 *>(a.out.feat7) + (((size_t)exr * (T / 16) + (i >> 4)) * 14) * 64 + lane;
+                dst[0] = f32x4{ fe0[0][0], fe0[0][1], fe0[1][0], fe0[1][1] };
+                dst[64] = f32x4{ fe0[2][0], fe0[2][1], fe0[3][0], fe0[3][1] };
 #pragma unroll 1
-                for (int e = 0; e < 6; ++e)
-#pragma unroll
-                    for (int q_ = 0; q_ < 8; ++q_) a.out.feat7[((e + 1) * 8 + q_) * nt4 + at] = fsl[(e * 8 + q_) * 64 + lane];
+                for (int e = 0; e < 6; ++e) {
+                    const float *sp = fsl + (e * 8) * 64 + lane;
+                    dst[(2 * e + 2) * 64] = f32x4{ sp[0], sp[64], sp[128], sp[192] };
+                    dst[(2 * e + 3) * 64] = f32x4{ sp[256], sp[320], sp[384], sp[448] };
+                }
             }
             AC_TICK(3)
             const float pc0 = sel4(g, px, py, pz, 0.0f);
@@ -510,16 +519,16 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             AC_TICK(6)
             if (g == 0) {
-                const size_t si = (size_t)ray * T + i;
-                if (EX && a.out.z_vals) a.out.z_vals[si] = zi;
-                if (EX && a.out.weights) a.out.weights[si] = wgt;
-                if (EX && a.out.alpha) a.out.alpha[si] = alpha;
-                if (EX && a.out.sdf) a.out.sdf[si] = sdf0;
-                if (EX && a.out.color) { a.out.color[3 * si] = rgb[0]; a.out.color[3 * si + 1] = rgb[1]; a.out.color[3 * si + 2] = rgb[2]; }
-                if (EX && a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
-                if (EX && a.out.pts) { a.out.pts[3 * si] = px; a.out.pts[3 * si + 1] = py; a.out.pts[3 * si + 2] = pz; }
+                const size_t si = (size_t)exr * T + i;
+                if (EX && ex_on && a.out.z_vals) a.out.z_vals[si] = zi;
+                if (EX && ex_on && a.out.weights) a.out.weights[si] = wgt;
+                if (EX && ex_on && a.out.alpha) a.out.alpha[si] = alpha;
+                if (EX && ex_on && a.out.sdf) a.out.sdf[si] = sdf0;
+                if (EX && ex_on && a.out.color) { a.out.color[3 * si] = rgb[0]; a.out.color[3 * si + 1] = rgb[1]; a.out.color[3 * si + 2] = rgb[2]; }
+                if (EX && ex_on && a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
+                if (EX && ex_on && a.out.pts) { a.out.pts[3 * si] = px; a.out.pts[3 * si + 1] = py; a.out.pts[3 * si + 2] = pz; }
             }
-            if (EX && a.out.sdf_out16) *reinterpret_cast<f32x4 *>(a.out.sdf_out16 + ((size_t)ray * T + i) * 16 + 4 * g) = oc;     // lane (n, g) holds outputs 4g..4g+3
+            if (EX && ex_on && a.out.sdf_out16) *reinterpret_cast<f32x4 *>(a.out.sdf_out16 + ((size_t)exr * T + i) * 16 + 4 * g) = oc;     // lane (n, g) holds outputs 4g..4g+3
         }
         if (!seg_last) {
             // hand the ray to its next segment: z values (once), the running sums, then the flag -- in that order (the stores are complete in L2
@@ -689,6 +698,7 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     a.rays_o = rays_o; a.rays_d = rays_d; a.bg = bg; a.noise = noise; a.lin_z = lin_z; a.lin_u = lin_u;
     a.out = *out;
     a.n_rays = op->n_rays; a.T0 = op->num_steps; a.nup = op->upsample_steps / 16;
+    a.pair_n = 0; a.ex_from = 0; a.ex_rows = op->n_rays;
     a.inv_s = op->inv_s; a.inv_s_dev = op->inv_s_dev; a.car = op->cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)op->cos_anneal_ratio);
     a.eps = op->fd_eps; a.perturb = op->perturb;
     if (op->precision != 0 && op->precision != 1) { ac::set_error("ac_render_opts: precision %d unknown (0 = exact, 1 = fast)", op->precision); return AC_ERR_BAD_ARG; }
@@ -799,6 +809,31 @@ AC_API int ac_render_rays(const ac_field *field, const ac_render_opts *op, const
 #endif
     launch_render<MODE_FULL>(a, (hipStream_t)stream);
     return ac::check_launch("render_rays");
+}
+
+// The same N rays rendered twice in one launch, with two draws of the jitter noise and two backgrounds: what one stylisation step does with net_style
+// (stylize.py:98-116 render_val under no_grad, then :143-152 the differentiable render of the same rays) -- two calls of run() in the reference, two launches
+// of ac_render_rays before round 3.  The 2N work items are handed out as a0 b0 a1 b1 ...: the two copies of a ray walk through (nearly) the same grid
+// cells at (nearly) the same time on the same XCD, so the second finds most table sectors in L2 (-11 % on the stride-4 training view, where neighbouring
+// rays share little: profiles/r03_experiments.txt).  Every result is bit-identical to two separate launches (the rays are independent).
+// noise [2][N][num_steps], bg [2][N][3] (or NULL); out: the per-ray arrays hold 2N rows ([0, N) copy a, [N, 2N) copy b); the optional per-sample
+// arrays are written for copy b only and hold N rows.
+AC_API int ac_render_rays_pair(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
+                               const float *bg2, const float *noise2, const float *lin_z, const float *lin_u,
+                               const ac_render_out *out, ac_stream_t stream)
+{
+    if (!op || !out) { ac::set_error("render_rays_pair: NULL opts/out"); return AC_ERR_BAD_ARG; }
+    if (int rc = check_render_args("render_rays_pair", op, rays_o, rays_d, noise2, lin_z, lin_u, out)) return rc;
+    if (op->n_rays <= 0) return AC_OK;
+    if (op->n_rays > (1 << 29)) { ac::set_error("render_rays_pair: too many rays"); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = fill_render_args(a, field, op, rays_o, rays_d, bg2, noise2, lin_z, lin_u, out)) return rc;
+    a.pair_n = op->n_rays; a.n_rays = 2 * op->n_rays; a.ex_from = op->n_rays; a.ex_rows = op->n_rays;
+#ifdef AC_PROFILE
+    a.prof = nullptr;
+#endif
+    launch_render<MODE_FULL>(a, (hipStream_t)stream);
+    return ac::check_launch("render_rays_pair");
 }
 
 // the sampling stage alone (coarse z, coarse sdf, NeuS up-sampling): what the reference computes under no_grad before the

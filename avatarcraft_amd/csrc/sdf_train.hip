@@ -180,8 +180,8 @@ __device__ __forceinline__ void fill_lds_bwd(float *lds, const RenderArgs &a)
     fill_lds_fast<OFF_BW1H, OFF_BW1L, OFF_BW1C>(lds, a);
 }
 
-// SAVED: the features of the seven stencil points come from the forward launch (ac_render_out.feat7, [7][8][B][4] in this kernel's lane order) as 56
-// coalesced loads per lane instead of being gathered from the table again (index arithmetic + ~100 scattered 8-byte loads per lane and tile)
+// SAVED: the features of the seven stencil points come from the forward launch (ac_render_out.feat7, [B / 16][14][64 lanes][4] in this kernel's lane order) as 14
+// coalesced 16-byte loads per lane instead of being gathered from the table again (index arithmetic + ~100 scattered 8-byte loads per lane and tile)
 template <bool SAVED>
 __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ g_out,
                                                                  const float *__restrict__ g_grad, uint32_t B, float eps,
@@ -225,14 +225,15 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
         if (!live) { go = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; gg[0] = gg[1] = gg[2] = 0.0f; }
         float fe0[4][2];
         if constexpr (SAVED) {
-            const size_t b4 = (size_t)B * 4, at = (size_t)bb * 4 + g;
-            float v[56];
+            // [tile][14][lane][4] (see render_rays_kernel): 14 16-byte loads per lane, each 1 KB contiguous per wave
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(feat7) + ((size_t)tile * 14) * 64 + lane;
+            f32x4 v[14];
 #pragma unroll
-            for (int k = 0; k < 56; ++k) v[k] = feat7[k * b4 + at];
+            for (int k = 0; k < 14; ++k) v[k] = src[k * 64];
 #pragma unroll
-            for (int q_ = 0; q_ < 8; ++q_) fe0[q_ >> 1][q_ & 1] = v[q_];
+            for (int q_ = 0; q_ < 8; ++q_) fe0[q_ >> 1][q_ & 1] = v[q_ >> 2][q_ & 3];
 #pragma unroll
-            for (int k = 8; k < 56; ++k) fsl[(k - 8) * 64 + lane] = v[k];
+            for (int k = 8; k < 56; ++k) fsl[(k - 8) * 64 + lane] = v[k >> 2][k & 3];
         } else {
             encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
         }

@@ -161,6 +161,35 @@ class NeRFRenderer(nn.Module):
     def manual_backward_supported(self):
         return self.fused_training == "core" and self._fused_supported() and self.encoder.embeddings.is_cuda
 
+    def render_step_pair(self, rays_o, rays_d, num_steps, upsample_steps, bound, bkg_fn, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0):
+        """The two renders of net_style in one stylisation step (stylize.py:98-116 render_val, :143-152 the differentiable render of the same rays) as
+        ONE launch (ac_render_rays_pair): the two copies of a ray share most table sectors and meet in L2.  Random draws in the reference's order:
+        bkg_fn() -> background of render_val, jitter noise of render_val, bkg_fn() -> background of the training render, its jitter noise.
+        Returns (rgb_val [N,3], rgb [N,3], gradient_error, weight_sum [N,1]) of which the last three belong to the training render, whose
+        per-sample outputs are kept for backward_last().  Every value equals what the two separate renders give, bit for bit."""
+        if not (self.training and self.manual_backward_supported()):
+            raise RuntimeError("render_step_pair: needs the default model in train mode on the GPU")
+        ro = rays_o.reshape(-1, 3).float().contiguous()
+        rd = rays_d.reshape(-1, 3).float().contiguous()
+        N, device = ro.shape[0], ro.device
+
+        def as_bg(b):
+            if b is None:
+                return torch.ones((N, 3), dtype=torch.float32, device=device)
+            b = torch.as_tensor(b, dtype=torch.float32, device=device)
+            b = b.reshape(-1, 3) if b.numel() >= 3 else b.reshape(1, 1).expand(1, 3)
+            return b.expand(N, 3) if b.shape[0] == 1 else b
+        bg_a = as_bg(bkg_fn()); noise_a = torch.rand((N, num_steps), device=device)
+        bg_b = as_bg(bkg_fn()); noise_b = torch.rand((N, num_steps), device=device)
+        with torch.no_grad():
+            field, inv_s = self._field(), self.forward_variance()
+            bg2 = torch.cat([bg_a, bg_b]).contiguous()
+            ra, rb = nsr_ops.render_rays_pair(field, ro, rd, torch.cat([noise_a, noise_b]), num_steps, upsample_steps, bound, inv_s, bg2=bg2,
+                                              cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, precision=self.render_precision)
+        self._last_train = (rb, ro, rd, bg2[N:], field)
+        self._guard_finite(rb["eik_res"][0])
+        return ra["image"], rb["image"], rb["eik_res"][0], rb["weights_sum"][:, None]
+
     def backward_last(self, g_image=None, g_weights_sum=None, g_eik=None):
         out, ro, rd, bg, field = self._last_train
         self._last_train = None

@@ -146,7 +146,7 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
         o.sdf_out16 = buf("sdf_out16", (N, T, 16)).data_ptr()
         o.pts = buf("pts", (N, T, 3)).data_ptr()
         if SAVE_STENCIL_FEATURES:
-            o.feat7 = buf("feat7", (7, 8, N * T, 4)).data_ptr()
+            o.feat7 = buf("feat7", (N * T // 16, 14, 64, 4)).data_ptr()
     if debug_indices:
         o.ss_inds = buf("ss_inds", (N, max(nup, 1), 16), torch.int32).data_ptr()
         o.sort_index = buf("sort_index", (N, max(nup, 1), 128), torch.int32).data_ptr()
@@ -189,6 +189,67 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
         ge = buf("gradient_error", ())
         L.check(L.lib().ac_eikonal_reduce(res["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
     return res
+
+
+def render_rays_pair(field, rays_o, rays_d, noise2, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg2=None, cos_anneal_ratio=1.0,
+                     normal_epsilon_ratio=0.0, precision="exact", out=None, events=None, keep_weights=False):
+    """ac_render_rays_pair: the same N rays rendered twice in ONE launch -- copy a with noise2[0] / bg2[0] (per-ray outputs only), copy b with
+    noise2[1] / bg2[1] (+ everything the render-core backward needs: the training forward).  Returns (a, b): two RenderResult dicts whose tensors are
+    the two halves of shared [2N, ...] buffers; b.opts is the N-ray ac_render_opts the backward takes.  Bit-identical to
+    render_rays(..., noise=noise2[0]) and render_rays(..., noise=noise2[1], extras=True, train_extras=True)."""
+    rays_o = _chk(rays_o.reshape(-1, 3), "rays_o")
+    rays_d = _chk(rays_d.reshape(-1, 3), "rays_d")
+    N, dev, T = rays_o.shape[0], rays_o.device, num_steps + upsample_steps
+    lin_z, lin_u = linspace_tables(num_steps, dev)
+    res = out if out is not None else RenderResult()
+
+    def buf(name, shape, dtype=_F32):
+        t = res.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            res[name] = t
+        return t
+    o = L.ac_render_out()
+    per_ray = {"image": (2 * N, 3), "weights_sum": (2 * N,), "depth": (2 * N,), "normal_map": (2 * N, 3), "eik": (2 * N, 2)}
+    for k, shp in per_ray.items():
+        setattr(o, k, buf("pair_" + k, shp).data_ptr())
+    per_sample = {"z_vals": (N, T), "color": (N, T, 3), "sdf": (N, T), "gradient": (N, T, 3), "sdf_out16": (N, T, 16), "pts": (N, T, 3)}      # what the backward reads
+    if keep_weights:
+        per_sample.update({"weights": (N, T), "alpha": (N, T)})
+    if SAVE_STENCIL_FEATURES:
+        per_sample["feat7"] = (N * T // 16, 14, 64, 4)
+    for k, shp in per_sample.items():
+        setattr(o, k, buf(k, shp).data_ptr())
+    noise2 = _chk(noise2.reshape(2 * N, num_steps), "noise2")
+    if bg2 is not None:
+        bg2 = _chk(bg2.reshape(-1, 3), "bg2", (2 * N, 3))
+    import numpy as np
+    inv_s_f, inv_s_t = _inv_s_arg(inv_s)
+    op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), inv_s_f, float(cos_anneal_ratio),
+                          float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), 1, L.ptr(inv_s_t), None, None, PRECISIONS[precision], 0)
+    st = L.current_stream(dev)
+    if events is not None:
+        events[0].record()
+    L.check(L.lib().ac_render_rays_pair(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg2), noise2.data_ptr(),
+                                        lin_z.data_ptr(), lin_u.data_ptr(), C.byref(o), st), "render_rays_pair")
+    if events is not None:
+        events[1].record()
+    ra, rb = RenderResult(), RenderResult()
+    for k in per_ray:
+        t = res["pair_" + k]
+        ra[k], rb[k] = t[:N], t[N:]
+    for k in per_sample:
+        rb[k] = res[k]
+    ge = buf("pair_gradient_error", ())
+    L.check(L.lib().ac_eikonal_reduce(ra["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
+    ra["gradient_error"] = ge
+    er = buf("eik_res", (2,))
+    L.check(L.lib().ac_eikonal_reduce2(rb["eik"].data_ptr(), N, er.data_ptr(), st), "eikonal_reduce")
+    rb["eik_res"] = er
+    rb["gradient_error"] = er[0]
+    rb.opts = ra.opts = (op, inv_s_t, None, None)
+    rb._keep = ra._keep = (noise2, bg2, res)
+    return ra, rb
 
 
 def sample_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, noise=None, near_far=None):

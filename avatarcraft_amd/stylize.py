@@ -18,7 +18,7 @@ import torch
 from . import nsr_ops
 import torch.nn.functional as F
 
-from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG
+from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG, _background_on
 
 
 class SyntheticGuidance:
@@ -48,6 +48,8 @@ def flat_grad_view(params):
 
 
 _CONSTS = {}
+# sds_step renders render_val and the training forward of a one-patch view in one launch (ac_render_rays_pair); False = two launches (same values)
+PAIR_STEP_RENDERS = True
 
 
 def _const_scalar(v, device):
@@ -68,11 +70,22 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
         if timers is not None:
             ev = torch.cuda.Event(enable_timing=True); ev.record(); timers.append((name, ev))
     mark("start")
-    # (A) render_val: net_style stays in train mode (stylize.py never calls eval()), no grad
-    rgb_val, _ = render_instantnsr_naive(net_style, rays_o, rays_d, rays_per_batch=batch_size, requires_grad=False, bkg_key=bkg_key,
-                                         render_can=True, perturb=True, num_steps=num_steps, upsample_steps=upsample_steps, bound=NSR_BOUND)
+    manual = rays_o.is_cuda and getattr(net_style, "manual_backward_supported", lambda: False)()
+    # One patch covers the view (the coarse stage: 64 x 64 rays): render_val and the training render of the patch are the same rays with two
+    # noise draws -- one launch renders both (NeRFNetwork.render_step_pair); the training render does not depend on the guidance, only its
+    # backward does.  Larger views keep the reference's order (render_val of the whole view first, then patch by patch).
+    paired = None
+    if manual and PAIR_STEP_RENDERS and n_rays <= batch_size and net_style.training and hasattr(net_style, "render_step_pair"):
+        rgb_val, rgb_p, eik_p, ws_p = net_style.render_step_pair(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND,
+                                                                 lambda: _background_on(rays_o.device, rays_o.shape, bkg_key))
+        paired = (rgb_p, eik_p, {"weight_sum": ws_p})
+        mark("render_val_and_grad_forward")
+    else:
+        # (A) render_val: net_style stays in train mode (stylize.py never calls eval()), no grad
+        rgb_val, _ = render_instantnsr_naive(net_style, rays_o, rays_d, rays_per_batch=batch_size, requires_grad=False, bkg_key=bkg_key,
+                                             render_can=True, perturb=True, num_steps=num_steps, upsample_steps=upsample_steps, bound=NSR_BOUND)
+        mark("render_val")
     img = rgb_val.reshape(h, w, 3).permute(2, 0, 1).unsqueeze(0)             # "(h w) c -> 1 c h w"
-    mark("render_val")
     # (B) gradient of the guidance loss w.r.t. the whole image
     grad_img = guidance(img.detach())
     grad_rays = grad_img.squeeze(0).permute(1, 2, 0).reshape(n_rays, 3).detach()
@@ -84,20 +97,22 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
         optimizer.zero_grad()
     bs = min(batch_size, n_rays)
     eik_vals, opa_vals = [], []
-    manual = rays_o.is_cuda and getattr(net_style, "manual_backward_supported", lambda: False)()
     for i in range(0, n_rays, bs) if manual else ():
         # The same three terms WITHOUT autograd (avatarcraft_amd.NeRFNetwork): the training render keeps its per-sample outputs, the upstream
         # gradients of (image, weights_sum, gradient_error) are written down directly (d sum(rgb * g) = g; d (eik * w) = w; the opacity term through
         # ac_sds_upstream) and go through ac_render_core_backward + ac_param_grads into .grad -- ~15 launches instead of ~80 per patch.
         ro, rd = rays_o[i:i + bs], rays_d[i:i + bs]
-        net_style._manual_backward = True
-        try:
-            rgb, eik, extra = render_instantnsr_naive(net_style, ro, rd, requires_grad=True, bkg_key=bkg_key, rays_per_batch=bs, perturb=1.0,
-                                                      return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
-                                                      upsample_steps=upsample_steps)
-        finally:
-            net_style._manual_backward = False
-        mark("render_grad_forward")
+        if paired is not None:
+            rgb, eik, extra = paired
+        else:
+            net_style._manual_backward = True
+            try:
+                rgb, eik, extra = render_instantnsr_naive(net_style, ro, rd, requires_grad=True, bkg_key=bkg_key, rays_per_batch=bs, perturb=1.0,
+                                                          return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
+                                                          upsample_steps=upsample_steps)
+            finally:
+                net_style._manual_backward = False
+            mark("render_grad_forward")
         with torch.no_grad():
             _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
                                                      return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps)

@@ -183,9 +183,11 @@ typedef struct ac_render_out {
     int32_t *sort_index;      /* [N, upsample_steps/16, 128] sort permutation of cat_z_vals, -1 pad */
     float *sdf_out16;         /* [N,T,16] forward_sdf at the mid points: sdf + the 15 geometry features   */
     float *pts;               /* [N,T,3]  the mid points themselves (clamped to the bound)                */
-    float *feat7;             /* [7,8,N*T,4] the hash features of the 7 points of every sample's finite-difference stencil, in the kernel's own
-                               * lane order (evaluation e, slot 2q + c, sample, level group g: level 4q + g, channel c): what the backward would
-                               * otherwise gather again (0.9 KB per sample; training renders only)                                               */
+    float *feat7;             /* [N*T/16,14,64,4] the hash features of the 7 points of every sample's finite-difference stencil, in the kernel's own
+                               * lane order: tile of 16 consecutive samples, then float k = 8 e + 2 j + c (evaluation e, level 4 j + g, channel c) of
+                               * lane n + 16 g (sample n of the tile, level group g) at [k / 4][lane][k % 4] -- opaque to callers, produced by the
+                               * forward and consumed by ac_render_core_backward, which would otherwise gather the table again (0.9 KB per
+                               * sample; training renders only)                                                                                */
 } ac_render_out;
 
 /* rays_o, rays_d [N,3]; bg [N,3] or NULL (= white, bg_color None -> 1); noise [N,num_steps] U[0,1)
@@ -194,6 +196,16 @@ typedef struct ac_render_out {
 int ac_render_rays(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d,
                    const float *bg, const float *noise, const float *lin_z, const float *lin_u,
                    const ac_render_out *out, ac_stream_t stream);
+
+/* The same N = opts->n_rays rays rendered TWICE in one launch, with two draws of the jitter noise and two backgrounds: the two renders of
+ * net_style in one stylisation step -- stylize.py:98-116 (render_val, no_grad) and :143-152 (the differentiable render of the same rays) are two
+ * calls of NeRFRenderer.run (instant_nsr.py:133-299) in the reference.  The two copies of a ray are neighbours in the hand-out order and meet in
+ * their XCD's L2 (-11 % against two launches on the stride-4 training view); every value is bit-identical to two ac_render_rays calls.
+ * rays_o, rays_d [N,3]; bg2 [2,N,3] or NULL; noise2 [2,N,num_steps]; out: image, weights_sum, depth, normal_map, eik hold 2N rows (rows [0,N) = the
+ * copy rendered with noise2[0] / bg2[0], rows [N,2N) = the other); the optional per-sample arrays are written for the SECOND copy only, N rows. */
+int ac_render_rays_pair(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d,
+                        const float *bg2, const float *noise2, const float *lin_z, const float *lin_u,
+                        const ac_render_out *out, ac_stream_t stream);
 
 /* gradient_error = sum(relax*err) / (sum(relax) + 1e-5) over the per-ray partials, fixed order
  * (instant_nsr.py:270-272); result: 1 float (device) */

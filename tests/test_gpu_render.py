@@ -454,3 +454,30 @@ def test_repeat_launch_soak_is_bit_identical(env, view, precision):
         out = run()
         for k, v in first.items():
             assert torch.equal(v, out[k]), f"repeat {rep}: {k} differs from the first launch ({int((v != out[k]).sum())} values)"
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("n", [4096, 777])
+def test_pair_launch_equals_two_launches(env, n, precision):
+    """ac_render_rays_pair (render_val + the training forward of one stylisation step in one launch, the two copies of a ray neighbours in the hand-out
+    order): every per-ray output of both copies and every per-sample output of the second equal two separate ac_render_rays launches bit for bit,
+    with different backgrounds and noise per copy; repeated launches are identical."""
+    from avatarcraft_amd import nsr_ops
+    import bench
+    dev = "cuda:0"
+    ro, rd = bench.sds_view(1)
+    ro, rd = torch.from_numpy(ro[:n].copy()).to(dev), torch.from_numpy(rd[:n].copy()).to(dev)
+    g = torch.Generator().manual_seed(11)
+    noise2 = torch.rand((2, n, 64), generator=g).to(dev)
+    bg2 = torch.rand((2, n, 3), generator=g).to(dev)
+    f, inv_s = env["f"], float(env["p"]["inv_s"])
+    a = nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, inv_s, bg=bg2[0], noise=noise2[0], precision=precision)
+    b = nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, inv_s, bg=bg2[1], noise=noise2[1], extras=True, train_extras=True, precision=precision)
+    for rep in range(3):
+        pa, pb = nsr_ops.render_rays_pair(f, ro, rd, noise2, 64, 64, 1.6, inv_s, bg2=bg2, precision=precision, keep_weights=True)
+        for k in ("image", "weights_sum", "depth", "normal_map", "eik", "gradient_error"):
+            assert torch.equal(pa[k], a[k]), ("copy a", k, rep)
+            assert torch.equal(pb[k], b[k]), ("copy b", k, rep)
+        for k in ("z_vals", "weights", "alpha", "color", "sdf", "gradient", "sdf_out16", "pts", "feat7", "eik_res"):
+            assert torch.equal(pb[k], b[k]), ("copy b", k, rep)
+    assert pb.opts[0].n_rays == n

@@ -43,8 +43,15 @@ def main():
     ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
     N = ro.shape[0]
     noise = torch.rand((N, 64), generator=torch.Generator().manual_seed(1)).to(dev) if a.view == "sds" else None
-    run = lambda: nsr_ops.render_rays(field, ro, rd, 64, 64, 1.6, float(p["inv_s"]), noise=noise, extras=True, train_extras=True, debug_indices=True,
+    def logical(out):
+        """feat7 as the kernels store it, [tile][14][lane = n + 16 g][4] with float k = 8 e + q at [k / 4][lane][k % 4] -> [e][q][sample][g]"""
+        f7 = out["feat7"]
+        nt = f7.shape[0]
+        out["feat7"] = f7.view(nt, 14, 4, 16, 4).permute(1, 4, 0, 3, 2).reshape(7, 8, nt * 16, 4).contiguous()
+        return out
+    run_raw = lambda: nsr_ops.render_rays(field, ro, rd, 64, 64, 1.6, float(p["inv_s"]), noise=noise, extras=True, train_extras=True, debug_indices=True,
                                       precision=a.precision)
+    run = lambda: logical(run_raw())
     first = {k: v.clone() for k, v in run().items() if isinstance(v, torch.Tensor)}
     torch.cuda.synchronize()
     report = {"lib": os.environ.get("AC_LIB_PATH", "head"), "precision": a.precision, "view": a.view, "reps": a.reps, "differing_repeats": 0, "keys": {}}
