@@ -36,7 +36,7 @@ class ac_render_out(C.Structure):
 
 
 class ac_core_saved(C.Structure):
-    _fields_ = [("z_vals", vp), ("pts", vp), ("sdf", vp), ("sdf_out16", vp), ("gradient", vp), ("color", vp), ("eik_den", vp), ("feat7", vp)]
+    _fields_ = [("z_vals", vp), ("pts", vp), ("sdf", vp), ("sdf_out16", vp), ("gradient", vp), ("color", vp), ("eik_den", vp), ("feat7", vp), ("mask", vp)]
 
 
 class ac_core_upstream(C.Structure):
@@ -131,7 +131,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
             fn.argtypes = args
             fn.restype = res
-        if handle.ac_version() != 3:
+        if handle.ac_version() != 4:
             raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
         _lib = handle
     return _lib

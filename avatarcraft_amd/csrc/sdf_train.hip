@@ -648,6 +648,9 @@ struct CompArgs {
     int n_rays, T0, T;
     float bound, inv_s, car, one_m_car;
     const float *inv_s_dev;      // non-NULL: inv_s lives in device memory (the trainable variance), read once per kernel
+    // posed space (the backward of run(render_can=False), instant_nsr.py:147-153,246-249): mesh-guided range where finite, alpha * mask; NULL = off
+    const float *near_m, *far_m;
+    const uint8_t *mask;
 };
 
 struct CompSample { float alpha, om, u, pc, nc, half, delta, tc, zn; };
@@ -688,6 +691,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompArgs a_in,
         const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
         float near, far;
         cube_near_far(ox, oy, oz, dx, dy, dz, a.bound, near, far);
+        if (a.near_m) {
+            const float nm = a.near_m[ray], fm = a.far_m[ray];
+            if (!is_inf(nm)) near = nm;
+            if (!is_inf(fm)) far = fm;
+        }
         const float span = far - near, sample_dist = span / (float)a.T0;
         for (int i = lane; i < a.T; i += 64) zr[i] = a.z[(size_t)ray * a.T + i];
         wave_sync();
@@ -696,7 +704,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompArgs a_in,
             const int i = 16 * c + n;
             const size_t si = (size_t)ray * a.T + i;
             const float nx = a.nrm[3 * si], ny = a.nrm[3 * si + 1], nz = a.nrm[3 * si + 2];
-            const CompSample s = comp_sample(spg, a, zr, i, a.sdf[si], nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            CompSample s = comp_sample(spg, a, zr, i, a.sdf[si], nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            if (a.mask && !a.mask[si]) { s.alpha = 0.0f; s.om = 1.0f + 1e-7f; }                 // alpha * 0; the factor 1 - 0 + 1e-7 stays in the product
             const float loc = row_scan<true>(s.om);
             const float sh = dpp_shr<1>(1.0f, loc);
             float Tex;
@@ -743,6 +752,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a_in,
         const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
         float near, far;
         cube_near_far(ox, oy, oz, dx, dy, dz, a.bound, near, far);
+        if (a.near_m) {
+            const float nm = a.near_m[ray], fm = a.far_m[ray];
+            if (!is_inf(nm)) near = nm;
+            if (!is_inf(fm)) far = fm;
+        }
         const float span = far - near, sample_dist = span / (float)a.T0;
         for (int i = lane; i < a.T; i += 64) zr[i] = a.z[(size_t)ray * a.T + i];
         wave_sync();
@@ -756,7 +770,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a_in,
             const int i = 16 * c + n;
             const size_t si = (size_t)ray * a.T + i;
             const float nx = a.nrm[3 * si], ny = a.nrm[3 * si + 1], nz = a.nrm[3 * si + 2];
-            const CompSample s = comp_sample(spg, a, zr, i, a.sdf[si], nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            CompSample s = comp_sample(spg, a, zr, i, a.sdf[si], nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            if (a.mask && !a.mask[si]) { s.alpha = 0.0f; s.om = 1.0f + 1e-7f; }                 // alpha * 0; the factor 1 - 0 + 1e-7 stays in the product
             const float loc = row_scan<true>(s.om);
             const float sh = dpp_shr<1>(1.0f, loc);
             float Tex;
@@ -779,11 +794,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompArgs a_in,
             const size_t si = (size_t)ray * a.T + i;
             const float nx = a.nrm[3 * si], ny = a.nrm[3 * si + 1], nz = a.nrm[3 * si + 2];
             const float sdf0 = a.sdf[si];
-            const CompSample s = comp_sample(spg, a, zr, i, sdf0, nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            CompSample s = comp_sample(spg, a, zr, i, sdf0, nx, ny, nz, dx, dy, dz, near, span, sample_dist);
+            const bool masked = a.mask && !a.mask[si];
+            if (masked) { s.alpha = 0.0f; s.om = 1.0f + 1e-7f; }
             const float Tex = tex[wave][i], dw = wq[wave][i];
             const float wgt = s.alpha * Tex;
             const float suffix = total - psum[wave][i];                         // sum over j > i of dw_j w_j
-            const float dalpha = dw * Tex - suffix / s.om;
+            const float dalpha = masked ? 0.0f : dw * Tex - suffix / s.om;      // d (alpha * mask) / d alpha = mask
             const float du = (s.u >= 0.0f && s.u <= 1.0f) ? dalpha : 0.0f;      // torch.clip passes the gradient on the closed interval
             const float den = s.pc + 1e-5f;
             const float dpc = du * s.nc / (den * den), dnc = -du / den;
@@ -1005,6 +1022,7 @@ static int comp_args(CompArgs &a, const char *who, const float *rays_o, const fl
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.sdf = sdf; a.nrm = nrm; a.col = col; a.bg = bg;
     a.n_rays = n_rays; a.T0 = T0; a.T = T; a.bound = bound; a.inv_s = inv_s; a.car = car; a.one_m_car = (float)(1.0 - (double)car);
     a.inv_s_dev = nullptr;
+    a.near_m = a.far_m = nullptr; a.mask = nullptr;
     return AC_OK;
 }
 
@@ -1089,6 +1107,8 @@ AC_API int ac_render_core_backward(const ac_field *field, const ac_render_opts *
         CompArgs a{};
         if (int rc = comp_args(a, "render_core_backward", rays_o, rays_d, sv->z_vals, sv->sdf, nrm, sv->color, bg, N, T0, T, op->bound, op->inv_s, op->cos_anneal_ratio)) return rc;
         a.inv_s_dev = op->inv_s_dev;
+        if ((op->near_m != nullptr) != (op->far_m != nullptr)) { ac::set_error("render_core_backward: near_m and far_m go together"); return AC_ERR_BAD_ARG; }
+        a.near_m = op->near_m; a.far_m = op->far_m; a.mask = sv->mask;          // posed space: the range and the alpha mask of the forward
         int blocks = (N + 3) / 4; if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks), dim3(256), 0, st, a, up->g_image, up->g_weights_sum, up->g_depth, up->g_normal_map, g_sdf,
                            g_nrm_a, g_col, gr->g_inv_s_per_ray);

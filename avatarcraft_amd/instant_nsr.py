@@ -294,8 +294,8 @@ class NeRFRenderer(nn.Module):
         warp = None
         near_far = None
         if not render_can:                                       # SMPL inverse warp :166-172,198-203 (inference path of render_warp.py)
-            if needs_grad:
-                raise NotImplementedError("posed-space rendering (render_can=False) is an inference path: call it under torch.no_grad()")
+            if needs_grad and self.fused_training != "core":
+                raise NotImplementedError("posed-space rendering under autograd runs through the fused operator only (fused_training = 'core')")
             if not full:
                 raise NotImplementedError("posed-space rendering is built for the default NeRFNetwork (use_viewdirs=False, no curvature term)")
             if verts is None or faces is None or Ts is None:
@@ -306,7 +306,7 @@ class NeRFRenderer(nn.Module):
             from .ray_utils import geometry_guided_near_far
             v = verts.verts if isinstance(verts, nsr_ops.WarpMesh) else verts
             near_far = geometry_guided_near_far(ro, rd, v, DEFAULT_GEO_THRESH)
-        if needs_grad and full and self.fused_training == "core" and near_far is None and self._manual_backward:
+        if needs_grad and full and self.fused_training == "core" and near_far is None and self._manual_backward and warp is None:
             with torch.no_grad():
                 field, inv_s_ng = self._field(), self.forward_variance()
                 out = nsr_ops.render_rays(field, ro, rd, num_steps, upsample_steps, bound, inv_s_ng, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
@@ -320,7 +320,7 @@ class NeRFRenderer(nn.Module):
             enc = self.encoder
             (image, wsum, depth, nmap, gerr, weights, alpha, color, z_vals) = nsr_ops.render_core(
                 enc.embeddings, W[0], self.sdf_net[0].bias, W[1], self.sdf_net[1].bias, W[2], W[3], W[4], inv_s_t, ro, rd, bg, noise, self._offsets_host(), enc.per_level_scale, enc.base_resolution,
-                num_steps, upsample_steps, bound, cos_anneal_ratio, normal_epsilon_ratio, precision=self.render_precision)
+                num_steps, upsample_steps, bound, cos_anneal_ratio, normal_epsilon_ratio, precision=self.render_precision, warp=warp)
             self._guard_finite(gerr)
             return depth.reshape(B, N), weights, wsum[:, None], image.reshape(B, N, 3), nmap, gerr, 0.0, color, alpha, z_vals
         if needs_grad or not full:

@@ -179,6 +179,9 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
                 "render_rays_warped")
         res["can_mid"] = scratch[offs[3]:offs[3] + N * T * 12].view(_F32).view(N, T, 3)
         res["mask"] = scratch[offs[4]:offs[4] + N * T].view(N, T)
+        if warp.use_mesh_guide:          # the mesh-guided range the launch sampled in (inf where the ray misses the body): what a backward pass needs
+            res["near_m"] = scratch[offs[0]:offs[0] + N * 4].view(_F32)
+            res["far_m"] = scratch[offs[1]:offs[1] + N * 4].view(_F32)
     if events is not None:
         events[1].record()
     if train_extras:
@@ -292,6 +295,7 @@ class WarpMesh:
             self.accel = torch.empty(nbytes, dtype=torch.uint8, device=device)
             L.check(L.lib().ac_warp_accel_build(self.verts.data_ptr(), self.faces.data_ptr(), self.verts.shape[0], self.faces.shape[0],
                                                 self.accel.data_ptr(), nbytes, L.current_stream(torch.device(device))), "warp_accel_build")
+        self.use_mesh_guide = bool(use_mesh_guide)
         self.c = L.ac_warp_mesh(self.verts.data_ptr(), self.faces.data_ptr(), self.T.data_ptr(), self.verts.shape[0], self.faces.shape[0],
                                 float(threshold), float(geo_threshold), int(bool(use_mesh_guide)), L.ptr(self.accel))
 
@@ -337,14 +341,24 @@ class _RenderCore(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, cfg):
-        offsets, pls, H, T0, up, bound, car, ner, precision = cfg
+        offsets, pls, H, T0, up, bound, car, ner, precision, warp = cfg
         ctx.set_materialize_grads(False)              # an output the loss does not use arrives as None -> a NULL upstream pointer
         d = lambda t: t.detach().contiguous()
         field = Field(d(table), offsets, pls, H, d(W1), d(b1), d(W2), d(b2), d(Wc1), d(Wc2), d(Wc3)).prepare()
+        # warp = WarpMesh: posed space (run(render_can=False), instant_nsr.py:166-172,198-207,246-249) -- the launch sequence of an inference render
+        # (sampling, SMPL inverse warp, final pass; every sample evaluated: skip_masked off) with the per-sample outputs kept.  The warped points,
+        # the mask and the mesh-guided range are constants of the differentiation, as in the reference (the warp is numpy there).
         out = render_rays(field, rays_o, rays_d, T0, up, bound, inv_s, bg=bg, noise=noise, cos_anneal_ratio=car, normal_epsilon_ratio=ner,
-                          extras=True, train_extras=True, precision=precision)
+                          extras=True, train_extras=True, precision=precision, warp=warp)
         ctx.field, ctx.cfg = field, cfg
         ctx.opts = out.opts                                        # the launch's ac_render_opts (+ the tensors its pointers refer to)
+        ctx.posed = None
+        if warp is not None:
+            op_b = type(out.opts[0]).from_buffer_copy(out.opts[0])  # the backward's options: + the range the forward computed for itself
+            if "near_m" in out:
+                op_b.near_m, op_b.far_m = out["near_m"].data_ptr(), out["far_m"].data_ptr()
+            ctx.opts = (op_b,) + tuple(out.opts[1:])
+            ctx.posed = (out["mask"], out.get("near_m"), out.get("far_m"), out["_warp_scratch"], warp)
         ctx.has_bg = bg is not None
         # outputs among the saved tensors (z_vals, color) must go through save_for_backward (no reference cycle through ctx)
         ctx.save_for_backward(out["z_vals"], out["pts"], out["sdf"], out["sdf_out16"], out["gradient"], out["color"], out["eik_res"], rays_o, rays_d,
@@ -376,7 +390,7 @@ class _RenderCore(torch.autograd.Function):
         g_col_p = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)
         g_invs = torch.empty(N, dtype=_F32, device=dev)
         sv = L.ac_core_saved(z_vals.data_ptr(), pts.data_ptr(), sdf.data_ptr(), sdf16.data_ptr(), gradient.data_ptr(), color.data_ptr(),
-                             eik_res[1:].data_ptr(), feat7.data_ptr() if ctx.has_feat else None)
+                             eik_res[1:].data_ptr(), feat7.data_ptr() if ctx.has_feat else None, ctx.posed[0].data_ptr() if ctx.posed else None)
         upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
         gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
         scratch, need = core_scratch(field, N, T, dev)
@@ -390,10 +404,11 @@ class _RenderCore(torch.autograd.Function):
 
 
 def render_core(table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, offsets, per_level_scale, base_resolution, num_steps,
-                upsample_steps, bound, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, precision="exact"):
-    """-> image [N,3], weights_sum [N], depth [N], normal_map [N,3], gradient_error [], weights [N,T], alpha [N,T], color [N,T,3], z_vals [N,T]"""
+                upsample_steps, bound, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, precision="exact", warp=None):
+    """-> image [N,3], weights_sum [N], depth [N], normal_map [N,3], gradient_error [], weights [N,T], alpha [N,T], color [N,T,3], z_vals [N,T]
+    warp = WarpMesh(...): the posed-space render (run(render_can=False)) under autograd."""
     cfg = ([int(v) for v in offsets], per_level_scale, int(base_resolution), int(num_steps), int(upsample_steps), float(bound),
-           float(cos_anneal_ratio), float(normal_epsilon_ratio), precision)
+           float(cos_anneal_ratio), float(normal_epsilon_ratio), precision, warp)
     return _RenderCore.apply(table, W1, b1, W2, b2, Wc1, Wc2, Wc3, inv_s, rays_o, rays_d, bg, noise, cfg)
 
 

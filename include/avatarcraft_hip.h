@@ -42,7 +42,7 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 3 */
+int ac_version(void);                /* ABI version, currently 4 */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
 
 /* ---- hash-grid encoder -------------------------------------------------------------------
@@ -337,6 +337,10 @@ typedef struct ac_core_saved {
     const float *z_vals, *pts, *sdf, *sdf_out16, *gradient, *color;      /* per-sample outputs of the forward launch */
     const float *eik_den;                                                 /* result2[1] of ac_eikonal_reduce2          */
     const float *feat7;                                                   /* ac_render_out.feat7 of the forward, or NULL: gather again */
+    const uint8_t *mask;                                                  /* posed space only (the forward was ac_render_rays_warped): the warp's
+                                                                           * alpha mask [N,T] (instant_nsr.py:246-249), with opts->near_m / far_m =
+                                                                           * the forward's mesh-guided range and `pts` = the warped points the
+                                                                           * forward kept; NULL = canonical space (ABI version 4)                  */
 } ac_core_saved;
 typedef struct ac_core_upstream { const float *g_image, *g_weights_sum, *g_depth, *g_normal_map, *g_eik; } ac_core_upstream;
 typedef struct ac_core_grads { float *g_table, *g_sdf_params, *g_color_params, *g_inv_s_per_ray; } ac_core_grads;

@@ -205,25 +205,39 @@ static void ray_near_far(const float *o, const float *d, float bound, float *nea
 }
 
 /* the clamped sample points of one ray and their spacing, fp32 like the forward (:190-207) */
-static void ray_points(const orc_render_opts *op, const float *o, const float *d, const float *z, float *pts, float *delta, float *zn, float *near_, float *far_)
+typedef struct { const float *ext_pts; const uint8_t *mask; const float *near_m, *far_m; } posed_args;     /* all optional, see orc_render_core_backward_posed */
+
+static void ray_points(const orc_render_opts *op, const float *o, const float *d, const float *z, float *pts, float *delta, float *zn, float *near_, float *far_,
+                       const posed_args *pa, int r)
 {
     const int T = op->num_steps + op->upsample_steps;
     float near, far;
     ray_near_far(o, d, op->bound, &near, &far);
+    if (pa && pa->near_m) {                          /* :148-153 the mesh-guided range where the ray passes the body */
+        if (!isinf(pa->near_m[r])) near = pa->near_m[r];
+        if (!isinf(pa->far_m[r])) far = pa->far_m[r];
+    }
     const float span = far - near, sample_dist = span / (float)op->num_steps;
     for (int i = 0; i < T; i++) {
         delta[i] = (i < T - 1) ? z[i + 1] - z[i] : sample_dist;
         const float zmid = (i < T - 1) ? z[i] + 0.5f * delta[i] : z[i];
         for (int k = 0; k < 3; k++) pts[3 * i + k] = clampf_(o[k] + d[k] * zmid, -op->bound, op->bound);
+        if (pa && pa->ext_pts)                       /* :198-207 posed space: the SMPL inverse warp of the mid points (numpy in the reference: constants) */
+            for (int k = 0; k < 3; k++) pts[3 * i + k] = clampf_(pa->ext_pts[((size_t)r * T + i) * 3 + k], -op->bound, op->bound);
         zn[i] = clampf_((z[i] - near) / span, 0.0f, 1.0f);
     }
     *near_ = near; *far_ = far;
 }
 
-ORC_API int orc_render_core_backward(const orc_field *f, const orc_render_opts *op, const float *rays_o, const float *rays_d, const float *bg,
-                                     const float *z_vals, const float *g_image, const float *g_wsum, const float *g_depth, const float *g_nmap,
-                                     double g_eik, const orc_core_grads *out)
+/* Posed space (run(render_can=False), instant_nsr.py:166-172,198-207,246-249): ext_pts [N,T,3] = the warped mid points the field is evaluated at
+ * (the view directions stay the rays'), mask [N,T] multiplies alpha, near_m / far_m [N] replace the cube's range where finite.  Any of them NULL =
+ * the canonical-space render. */
+ORC_API int orc_render_core_backward_posed(const orc_field *f, const orc_render_opts *op, const float *rays_o, const float *rays_d, const float *bg,
+                                           const float *z_vals, const float *ext_pts, const uint8_t *mask, const float *near_m, const float *far_m,
+                                           const float *g_image, const float *g_wsum, const float *g_depth, const float *g_nmap,
+                                           double g_eik, const orc_core_grads *out)
 {
+    const posed_args pa_ = { ext_pts, mask, near_m, far_m }, *pa = &pa_;
     const int N = op->n_rays, T = op->num_steps + op->upsample_steps;
     if (T > BWD_MAXT || T <= 0 || !(op->fd_eps > 0.0f)) return 1;
     const float bound = op->bound, eps = op->fd_eps;
@@ -233,7 +247,7 @@ ORC_API int orc_render_core_backward(const orc_field *f, const orc_render_opts *
     #pragma omp parallel for schedule(static) reduction(+ : e_den)
     for (int r = 0; r < N; r++) {
         float pts[BWD_MAXT * 3], delta[BWD_MAXT], zn[BWD_MAXT], near, far;
-        ray_points(op, rays_o + 3 * r, rays_d + 3 * r, z_vals + (size_t)r * T, pts, delta, zn, &near, &far);
+        ray_points(op, rays_o + 3 * r, rays_d + 3 * r, z_vals + (size_t)r * T, pts, delta, zn, &near, &far, pa, r);
         for (int i = 0; i < T; i++) {
             const float *p = pts + 3 * i;
             const float pn = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
@@ -251,7 +265,7 @@ ORC_API int orc_render_core_backward(const orc_field *f, const orc_render_opts *
         for (int r = 0; r < N; r++) {
             const float *o = rays_o + 3 * r, *d = rays_d + 3 * r, *z = z_vals + (size_t)r * T;
             float pts[BWD_MAXT * 3], delta[BWD_MAXT], zn[BWD_MAXT], near, far;
-            ray_points(op, o, d, z, pts, delta, zn, &near, &far);
+            ray_points(op, o, d, z, pts, delta, zn, &near, &far, pa, r);
             /* ---- forward of every sample (kept: the reverse pass needs the ray's transmittance first) ---- */
             static __thread enc_geo *geo = NULL;        /* [T][7] */
             static __thread sdf_fwd *sf = NULL;         /* [T][7] */
@@ -281,6 +295,7 @@ ORC_API int orc_render_core_backward(const orc_field *f, const orc_render_opts *
                 pc[i] = sigm((sdf - half[i]) * inv_s); nc[i] = sigm((sdf + half[i]) * inv_s);
                 raw[i] = (pc[i] - nc[i] + 1e-5) / (pc[i] + 1e-5);
                 alpha[i] = raw[i] < 0.0 ? 0.0 : (raw[i] > 1.0 ? 1.0 : raw[i]);
+                if (pa->mask && !pa->mask[(size_t)r * T + i]) alpha[i] = 0.0;                  /* :246-249 alpha * alpha_mask */
                 const float pn = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
                 relax[i] = pn < 1.2f;
                 if (relax[i]) en_local += (gn[i] - 1.0) * (gn[i] - 1.0);
@@ -306,7 +321,8 @@ ORC_API int orc_render_core_backward(const orc_field *f, const orc_render_opts *
             for (int i = T - 1; i >= 0; i--) {
                 const double dw = gi[0] * cf[i].rgb[0] + gi[1] * cf[i].rgb[1] + gi[2] * cf[i].rgb[2] - gi_bg + gw + gd * (double)zn[i]
                                   + gm[0] * nrm[i][0] + gm[1] * nrm[i][1] + gm[2] * nrm[i][2];
-                const double g_alpha = dw * Tr[i] - suffix / (1.0 - alpha[i] + 1e-7);
+                double g_alpha = dw * Tr[i] - suffix / (1.0 - alpha[i] + 1e-7);
+                if (pa->mask && !pa->mask[(size_t)r * T + i]) g_alpha = 0.0;                   /* d (alpha * 0) / d alpha */
                 suffix += dw * w[i];
                 double g_rgb[3], g_n[3], g_out16[16];
                 memset(g_out16, 0, sizeof g_out16);
@@ -354,4 +370,11 @@ ORC_API int orc_render_core_backward(const orc_field *f, const orc_render_opts *
     out->g_inv_s[0] = g_inv_s;
     if (out->gradient_error) out->gradient_error[0] = e_num / e_den;
     return 0;
+}
+
+ORC_API int orc_render_core_backward(const orc_field *f, const orc_render_opts *op, const float *rays_o, const float *rays_d, const float *bg,
+                                     const float *z_vals, const float *g_image, const float *g_wsum, const float *g_depth, const float *g_nmap,
+                                     double g_eik, const orc_core_grads *out)
+{
+    return orc_render_core_backward_posed(f, op, rays_o, rays_d, bg, z_vals, NULL, NULL, NULL, NULL, g_image, g_wsum, g_depth, g_nmap, g_eik, out);
 }

@@ -375,8 +375,10 @@ CORE_PARAM_SHAPES = (("W1", (64, 35)), ("b1", (64,)), ("W2", (16, 64)), ("b2", (
 
 
 def render_core_backward(field, rays_o, rays_d, z_vals, num_steps, upsample_steps, bound, inv_s, bg=None, g_image=None, g_weights_sum=None,
-                         g_depth=None, g_normal_map=None, g_eik=0.0, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0):
-    """d loss / d (hash table, effective MLP matrices, inv_s) for loss = <g_image, image> + <g_weights_sum, weights_sum> + <g_depth, depth> +
+                         g_depth=None, g_normal_map=None, g_eik=0.0, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, ext_pts=None, mask=None, near_far=None):
+    """ext_pts [N,T,3], mask [N,T], near_far = (near [N], far [N]): posed space (run(render_can=False)) -- the warped mid points the field is
+    evaluated at, the alpha mask, the mesh-guided sampling range (inf = the cube's); all constants of the differentiation.
+    d loss / d (hash table, effective MLP matrices, inv_s) for loss = <g_image, image> + <g_weights_sum, weights_sum> + <g_depth, depth> +
     <g_normal_map, normal_map> + g_eik * gradient_error of NeRFRenderer.run's render core at the given (constant) sample positions z_vals [N,T]
     -- float64, analytic (reference models/instant_nsr.py:190-299 under autograd).  Returns a dict: g_table [n_entries,2], g_W1 ... g_Wc3,
     g_inv_s, and the fp64 forward (image, weights_sum, depth, normal_map, gradient_error)."""
@@ -392,10 +394,14 @@ def render_core_backward(field, rays_o, rays_d, z_vals, num_steps, upsample_step
     cg = _CoreGrads(g_table.ctypes.data_as(dp), g_par.ctypes.data_as(dp), g_s.ctypes.data_as(dp), fwd.ctypes.data_as(dp), ge.ctypes.data_as(dp))
     opt = lambda a, shape: None if a is None else _f(a).reshape(shape)
     gi, gw, gd, gm, bgc = opt(g_image, (N, 3)), opt(g_weights_sum, (N,)), opt(g_depth, (N,)), opt(g_normal_map, (N, 3)), opt(bg, (N, 3))
-    fn = lib().orc_render_core_backward
+    fn = lib().orc_render_core_backward_posed
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_void_p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_double, C.c_void_p]
-    rc = fn(C.byref(field.c), C.byref(op), _p(rays_o), _p(rays_d), _p(bgc), _p(z), _p(gi), _p(gw), _p(gd), _p(gm), float(g_eik), C.byref(cg))
+    fn.argtypes = [C.c_void_p, C.c_void_p, f32p, f32p, f32p, f32p, f32p, C.c_void_p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_double, C.c_void_p]
+    ep = opt(ext_pts, (N, T, 3))
+    mk = None if mask is None else np.ascontiguousarray(np.asarray(mask).reshape(N, T) != 0, dtype=np.uint8)
+    nm, fm = (None, None) if near_far is None else (opt(near_far[0], (N,)), opt(near_far[1], (N,)))
+    rc = fn(C.byref(field.c), C.byref(op), _p(rays_o), _p(rays_d), _p(bgc), _p(z), _p(ep), None if mk is None else mk.ctypes.data, _p(nm), _p(fm),
+            _p(gi), _p(gw), _p(gd), _p(gm), float(g_eik), C.byref(cg))
     if rc:
         raise RuntimeError("render_core_backward: unsupported configuration")
     res = dict(g_table=g_table, g_inv_s=float(g_s[0]), image=fwd[:, 0:3], weights_sum=fwd[:, 3], depth=fwd[:, 4], normal_map=fwd[:, 5:8],

@@ -58,6 +58,46 @@ def test_oracle_backward_matches_reference_autograd(oracle):
     assert np.abs(r3["g_table"][g["emb_idx"]] - g["emb_grad3"]).max() <= 1e-3 * np.abs(g["emb_grad3"]).max()
 
 
+
+def _posed_inputs(O, g):
+    """the constants of a posed render's differentiation, recomputed by the oracle from the golden's z values: mesh-guided near / far, the SMPL inverse
+    warp of the mid points (instant_nsr.py:190-207) and its mask"""
+    from tests.common import make_body
+    verts, faces, Ts = make_body()
+    ro, rd, z = g["rays_o"], g["rays_d"], g["z_vals"]
+    N, T = z.shape
+    near, far = O.mesh_near_far(ro, rd, verts, 0.05)
+    delta = z[:, 1:] - z[:, :-1]
+    zmid = np.concatenate([z[:, :-1] + np.float32(0.5) * delta, z[:, -1:]], 1).astype(np.float32)
+    pts = (ro[:, None, :] + rd[:, None, :] * zmid[:, :, None]).astype(np.float32)
+    can, _, _, _, mask = O.warp_samples(pts.reshape(-1, 3), verts, faces, Ts, 0.05)
+    return (verts, faces, Ts), (near, far), can.astype(np.float32).reshape(N, T, 3), mask.reshape(N, T)
+
+
+def test_oracle_posed_backward_matches_reference_autograd(oracle):
+    """run(render_can=False, verts, faces, Ts) under autograd (tests/golden/warp_grad.npz: the reference's own backward through its posed-space render,
+    training mode, 32 + 32 samples, mesh guide): the fp64 oracle at the reference's sample positions, with the warp's outputs as constants."""
+    O = oracle
+    p, g = load_golden("nsr_params.npz"), load_golden("warp_grad.npz")
+    f = oracle_field_from_golden(p)
+    _, nf, can, mask = _posed_inputs(O, g)
+    assert abs(float((g["alpha"] > 0).mean()) - float(mask.mean())) <= 0.02
+    r = O.render_core_backward(f, g["rays_o"], g["rays_d"], g["z_vals"], 32, 32, 1.6, float(p["inv_s"]), bg=g["bg"], g_image=g["G"], g_weights_sum=g["Gw"],
+                               g_normal_map=g["Gn"], g_eik=0.01, ext_pts=can, mask=mask, near_far=nf)
+    assert np.abs(r["image"] - g["rgb"]).max() <= 1e-4 and np.abs(r["weights_sum"] - g["weight_sum"]).max() <= 1e-4
+    assert abs(r["gradient_error"] - float(g["gradient_error"])) <= 1e-4 * float(g["gradient_error"])
+    raw = _chain_to_raw(O, p, r)
+    for k, mine in raw.items():
+        ref = g["grad." + k].astype(np.float64)
+        e = float(np.abs(np.asarray(mine).reshape(ref.shape) - ref).max() / np.abs(ref).max())
+        # observed <= 8e-5 everywhere except ONE row of the first colour layer (hidden unit 20, 3.6e-3, the same 0.7 % in every column): a sample whose
+        # pre-activation is ~0 sits on the other side of the ReLU in the reference's fp32 forward.  Such a sample's input is orthogonal to the row
+        # (no bias: w . in = 0), so weight_g's gradient -- the component along the row -- agrees to 1e-5 and only weight_v's shows it.
+        assert e <= (5e-3 if k == "color_net.0.weight_v" else 3e-4), (k, e)
+    assert np.abs(r["g_table"][g["emb_idx"]] - g["emb_grad"]).max() <= 3e-4 * np.abs(g["emb_grad"]).max()
+    assert abs(np.sqrt((r["g_table"] ** 2).sum()) - float(g["emb_l2"])) <= 1e-4 * float(g["emb_l2"])
+
+
 @pytest.mark.gpu
 def test_hip_backward_matches_oracle_backward_on_the_4096_ray_patch(oracle):
     """BASELINE configuration 3's patch: 64 x 64 stride-4 rays of a 256 x 256 training camera, 64 + 64 jittered samples.  Forward = the fused
