@@ -44,7 +44,8 @@ class ac_core_upstream(C.Structure):
 
 
 class ac_core_grads(C.Structure):
-    _fields_ = [("g_table", vp), ("g_sdf_params", vp), ("g_color_params", vp), ("g_inv_s_per_ray", vp)]
+    _fields_ = [("g_table", vp), ("g_sdf_params", vp), ("g_color_params", vp), ("g_inv_s_per_ray", vp), ("side_stream", vp), ("split_level", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class ac_wn_layer(C.Structure):

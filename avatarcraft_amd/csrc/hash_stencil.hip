@@ -613,11 +613,13 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
 // |v| (collected by the queue fill) and the length n of this queue, |v| 2^k < 2^(62 - ceil(log2(n + 1))), so that no entry can
 // overflow.  Contributions keep >= 24 significant bits down to 2^-18 of the level's maximum and vanish below 2^-42 of it; in
 // exchange the result does not depend on the order of the records (deterministic), which float atomics never gave.
+// One launch covers the binned levels of rank y0 .. y0 + gridDim.y - 1 (rank = position among the set bits of binned_mask, n_binned of them).
 __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restrict__ grad_grid, ac::LevelTable lt, uint32_t binned_mask,
-                                                                 const uint32_t *__restrict__ qcount, const Rec *__restrict__ queues, uint32_t cap)
+                                                                 const uint32_t *__restrict__ qcount, const Rec *__restrict__ queues, uint32_t cap,
+                                                                 uint32_t y0, uint32_t n_binned)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];        // [entries per bucket][2]
-    const uint32_t ylev = gridDim.y - 1u - blockIdx.y;            // longest queues (finest levels) first
+    const uint32_t ylev = y0 + gridDim.y - 1u - blockIdx.y;       // longest queues (finest levels) first
     uint32_t level = 0, seen = 0;
     for (uint32_t l = 0; l < lt.L; ++l) if ((binned_mask >> l) & 1u) { if (seen == ylev) level = l; ++seen; }
     const uint32_t per = 1u << bucket_shift(lt.size[level]), bucket = blockIdx.x;
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
     const uint32_t mine = first >= lt.size[level] ? 0u : (lt.size[level] - first < per ? lt.size[level] - first : per);     // the last bucket may be short
     uint32_t n = qcount[(size_t)ylev * NBUCKET + bucket];
     n = n < cap ? n : cap;
-    const uint32_t mbits = qcount[(size_t)gridDim.y * NBUCKET + ylev];
+    const uint32_t mbits = qcount[(size_t)n_binned * NBUCKET + ylev];
     if (n == 0 || mbits == 0 || mine == 0) return;                                   // wave-uniform: nothing queued for this bucket
     const Rec *q = queues + ((size_t)ylev * NBUCKET + bucket) * cap;
     float *dst = grad_grid + ((size_t)lt.offset[level] + (size_t)first) * 2;
@@ -749,9 +751,34 @@ AC_API size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint
     return stencil_layout(lt, L, n_copies, B).total;
 }
 
+// split_level / side_stream (ac_core_grads, data-parallel training): the accumulation runs in two launches, levels >= split_level first; an event
+// recorded after that launch is waited for by side_stream, so that work the caller enqueues there (the all-reduce of that part of the table
+// gradient) starts while the second launch -- and whatever follows on `stream` -- still runs.  side_stream == NULL: one launch, no event.
+static hipEvent_t split_event()
+{
+    static hipEvent_t ev[64];
+    static bool have[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    dev &= 63;
+    if (!have[dev]) { if (hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) return nullptr; have[dev] = true; }
+    return ev[dev];
+}
+
+int hash_stencil_backward_split(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                                uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
+                                ac_stream_t stream, uint32_t split_level, ac_stream_t side_stream);
+
 AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
                                     uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
                                     ac_stream_t stream)
+{
+    return hash_stencil_backward_split(grad, x, offsets_host, grad_embeddings, B, C, L, S, H, eps, bound, scratch, scratch_bytes, stream, 0, nullptr);
+}
+
+int hash_stencil_backward_split(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                                uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
+                                ac_stream_t stream, uint32_t split_level, ac_stream_t side_stream)
 {
     if (int rc = check("hash_stencil_backward", C, L, offsets_host, eps, bound)) return rc;
     if (B == 0) return AC_OK;
@@ -797,11 +824,32 @@ AC_API int ac_hash_stencil_backward(const float *grad, const float *x, const int
         if (gx > AC_FILL_GX) gx = AC_FILL_GX;            // persistent waves: full record buffers per flush, few partial last ones
         hipLaunchKernelGGL(hash_stencil_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, x, grad_embeddings, B, lt, eps, bound,
                            two_bound, fine_mask, sc.binned_mask, qcount, queues, sc.cap);
-        hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount,
-                           queues, sc.cap);
+        // binned levels >= split_level have ranks n_lo .. n_binned - 1
+        const uint32_t n_lo = (uint32_t)__builtin_popcount(sc.binned_mask & (split_level >= 32 ? 0xffffffffu : ((1u << split_level) - 1u)));
+        const bool every_hi_binned = ((all & ~sc.binned_mask) >> (split_level >= 32 ? 31 : split_level)) == 0 && split_level < 32;
+        if (side_stream && every_hi_binned && n_lo > 0 && n_lo < sc.n_binned && !sc.n_priv) {
+            hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned - n_lo), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount,
+                               queues, sc.cap, n_lo, sc.n_binned);
+            hipEvent_t ev = split_event();
+            if (!ev || hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent((hipStream_t)side_stream, ev, 0) != hipSuccess) {
+                ac::set_error("hash_stencil_backward: cannot order the side stream behind the first level group"); return AC_ERR_BAD_ARG;
+            }
+            side_stream = nullptr;                                           // (done: the fallback below is for the cases that could not split)
+            hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, n_lo), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount,
+                               queues, sc.cap, 0u, sc.n_binned);
+        } else {
+            hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount,
+                               queues, sc.cap, 0u, sc.n_binned);
+        }
     }
     if (sc.n_priv)
         hipLaunchKernelGGL(priv_reduce_kernel, dim3((sc.entries * 2 + 255) / 256), dim3(256), 0, st, priv, sc.entries * 2, n_copies, grad_embeddings);
+    if (side_stream) {                          // no split happened (direct levels, no scratch): the side stream waits for everything
+        hipEvent_t ev = split_event();
+        if (!ev || hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent((hipStream_t)side_stream, ev, 0) != hipSuccess) {
+            ac::set_error("hash_stencil_backward: cannot order the side stream"); return AC_ERR_BAD_ARG;
+        }
+    }
     return ac::check_launch("hash_stencil_backward");
 }
 
@@ -850,6 +898,6 @@ AC_API int ac_hash_encode_backward_ws(const float *grad, const float *inputs, co
     hipLaunchKernelGGL(hash_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, inputs, grad_embeddings, B, lt, sc.binned_mask, qcount,
                        queues, sc.cap);
     hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount, queues,
-                       sc.cap);
+                       sc.cap, 0u, sc.n_binned);
     return ac::check_launch("hash_encode_backward");
 }

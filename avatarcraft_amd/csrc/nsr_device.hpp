@@ -16,6 +16,11 @@ static __device__ __forceinline__ f32x4 abl_mfma(float a, float b, f32x4 c) { c[
 #endif
 #ifdef AC_ABL_GATHER   // timing ablation: every gather reads table entry 0 (perfectly cached, fully coalesced)
 #define AC_GOFF(X) ((X) & 0u)
+#elif defined(AC_ABL_L0)   // timing ablation (round 3, "what could level 0 in LDS save at most?"): gathers below byte AC_ABL_L0 of the table -- 39304 = the
+// dense 17^3 level 0 -- go out of range (dropped by the descriptor's bounds check: free).  The threshold is a mutable device global so that the control
+// build (-DAC_ABL_L0=0) runs exactly the same instructions and drops nothing.  Results are wrong by construction; timing only.
+static __device__ uint32_t g_abl_l0_thr = AC_ABL_L0;
+#define AC_GOFF(X) (((X) < g_abl_l0_thr) ? 0xfffffff8u : (X))
 #else
 #define AC_GOFF(X) (X)
 #endif

@@ -1075,6 +1075,11 @@ CoreLayout core_layout(const ac_field *field, uint32_t B)
 }
 }  // namespace
 
+// hash_stencil.hip: ac_hash_stencil_backward with the accumulation split at a level and a side stream ordered behind the first part
+int hash_stencil_backward_split(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                                uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
+                                ac_stream_t stream, uint32_t split_level, ac_stream_t side_stream);
+
 AC_API size_t ac_render_core_backward_scratch(const ac_field *field, int32_t n_rays, int32_t T)
 {
     if (!field || n_rays <= 0 || T <= 0) return 0;
@@ -1118,7 +1123,8 @@ AC_API int ac_render_core_backward(const ac_field *field, const ac_render_opts *
     hipLaunchKernelGGL(core_mid_kernel, dim3(eb), dim3(256), 0, st, sv->gradient, sv->pts, g_sdf, g_nrm_a, g_nrm_b, up->g_eik, sv->eik_den, B, g_s16, g_grad);
     if (int rc = sdf_stencil_backward_impl(field, sv->pts, g_s16, g_grad, B, op->bound, op->fd_eps, gfeat, gr->g_sdf_params, sb + l.part_sdf,
                                            ac_sdf_stencil_backward_scratch(B), stream, sv->feat7)) return rc;
-    if (int rc = ac_hash_stencil_backward(gfeat, sv->pts, field->offsets, gr->g_table, B, 2, 16, field->S, field->H, op->fd_eps, op->bound,
-                                          l.hash_bytes ? sb + l.hash : nullptr, l.hash_bytes, stream)) return rc;
+    if (int rc = hash_stencil_backward_split(gfeat, sv->pts, field->offsets, gr->g_table, B, 2, 16, field->S, field->H, op->fd_eps, op->bound,
+                                             l.hash_bytes ? sb + l.hash : nullptr, l.hash_bytes, stream,
+                                             gr->side_stream ? (uint32_t)(gr->split_level > 0 ? gr->split_level : 0) : 0u, gr->side_stream)) return rc;
     return ac::check_launch("render_core_backward");
 }

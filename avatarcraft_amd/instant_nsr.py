@@ -190,7 +190,8 @@ class NeRFRenderer(nn.Module):
         self._guard_finite(rb["eik_res"][0])
         return ra["image"], rb["image"], rb["eik_res"][0], rb["weights_sum"][:, None]
 
-    def backward_last(self, g_image=None, g_weights_sum=None, g_eik=None):
+    def backward_last(self, g_image=None, g_weights_sum=None, g_eik=None, split=None):
+        """split = (level, side stream): see nsr_ops.render_core_backward (the gradient of table levels >= level is final when the side stream runs)"""
         out, ro, rd, bg, field = self._last_train
         self._last_train = None
         enc = self.encoder
@@ -199,7 +200,8 @@ class NeRFRenderer(nn.Module):
         for t in prm:
             if t.grad is None:
                 t.grad = torch.zeros_like(t)
-        g_sdf_p, g_col_p, g_invs = nsr_ops.render_core_backward(field, out.opts, out, ro, rd, bg, g_image, g_weights_sum, None, None, g_eik, enc.embeddings.grad)
+        g_sdf_p, g_col_p, g_invs = nsr_ops.render_core_backward(field, out.opts, out, ro, rd, bg, g_image, g_weights_sum, None, None, g_eik, enc.embeddings.grad,
+                                                                split=split)
         s0, s1, c0, c1, c2 = self.sdf_net[0], self.sdf_net[1], self.color_net[0], self.color_net[1], self.color_net[2]
         WN, ADD, VAR = nsr_ops.PG_WEIGHT_NORM, nsr_ops.PG_ADD, nsr_ops.PG_VARIANCE
         var = self.deviation_net.variance

@@ -491,9 +491,11 @@ def sds_upstream(weights_sum, weights_sum_gt, scale, want_grad=True):
     return g, loss
 
 
-def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, g_depth, g_nmap, g_eik, g_table):
+def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, g_depth, g_nmap, g_eik, g_table, split=None):
     """ac_render_core_backward on the outputs of a render_rays(..., train_extras=True) launch (`out`, its .opts): the table gradient is accumulated
-    into g_table; returns (g_sdf_params [3344], g_color_params [7168], g_inv_s_per_ray [N]) w.r.t. the EFFECTIVE matrices."""
+    into g_table; returns (g_sdf_params [3344], g_color_params [7168], g_inv_s_per_ray [N]) w.r.t. the EFFECTIVE matrices.
+    split = (level, torch.cuda.Stream): the scatter completes the table gradient of levels >= level first and orders that stream behind exactly that
+    (ac_core_grads.side_stream / split_level): work enqueued there afterwards (the all-reduce of that slice) overlaps the rest of the backward."""
     z_vals = out["z_vals"]
     N, T = z_vals.shape
     dev = rays_o.device
@@ -506,6 +508,8 @@ def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, 
                          out["color"].data_ptr(), out["eik_res"][1:].data_ptr(), L.ptr(out.get("feat7") if hasattr(out, "get") else None))
     upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
     gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
+    if split is not None:
+        gr.split_level, gr.side_stream = int(split[0]), int(split[1].cuda_stream)
     scratch, need = core_scratch(field, N, T, dev)
     L.check(L.lib().ac_render_core_backward(C.byref(field.c), C.byref(opts[0]), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), C.byref(sv), C.byref(upg),
                                             C.byref(gr), scratch.data_ptr(), need, L.current_stream(dev)), "render_core_backward")

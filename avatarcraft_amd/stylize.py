@@ -14,6 +14,8 @@ available offline, so `SyntheticGuidance` -- clamp(N(0,1), -1, 1), the statistic
 Data parallel (BASELINE config 5): one view per rank, parameters replicated, ONE all-reduce (sum,
 then / world) of the flat fp32 gradient (12 248 902 elements = 49 MB) before the optimizer step.
 """
+import os
+
 import torch
 from . import nsr_ops
 import torch.nn.functional as F
@@ -50,6 +52,19 @@ def flat_grad_view(params):
 _CONSTS = {}
 # sds_step renders render_val and the training forward of a one-patch view in one launch (ac_render_rays_pair); False = two launches (same values)
 PAIR_STEP_RENDERS = True
+# data-parallel steps: all-reduce the table gradient of levels >= ALLREDUCE_SPLIT_LEVEL (33.5 of the 49 MB) while the scatter still accumulates the
+# coarser levels and the MLP gradients are formed (ac_core_grads.side_stream / split_level).  Off by default: no multi-GPU node was available to measure it
+# (at most the ~0.15 ms the second accumulation launch + ac_param_grads take can be hidden); AC_OVERLAP_ALLREDUCE=1 or sds_step(overlap_allreduce=True).
+OVERLAP_GRAD_ALLREDUCE = os.environ.get("AC_OVERLAP_ALLREDUCE", "0") == "1"
+ALLREDUCE_SPLIT_LEVEL = 8
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    k = str(device)
+    if k not in _SIDE_STREAMS:
+        _SIDE_STREAMS[k] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[k]
 
 
 def _const_scalar(v, device):
@@ -60,7 +75,7 @@ def _const_scalar(v, device):
 
 
 def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_size=4096, w_eikonal=0.01, use_opacity=True,
-             bkg_key=WHITE_BKG, flat_grad=None, process_group=None, num_steps=64, upsample_steps=64, timers=None):
+             bkg_key=WHITE_BKG, flat_grad=None, process_group=None, num_steps=64, upsample_steps=64, timers=None, overlap_allreduce=None):
     """rays_o, rays_d: [h*w, 3] of the (sub-sampled) training view; hw = (h, w).  Returns a dict of scalars.
     timers: a list that receives (phase name, torch.cuda.Event) marks on the current stream (bench.py's per-phase times)."""
     h, w = hw
@@ -97,6 +112,9 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
         optimizer.zero_grad()
     bs = min(batch_size, n_rays)
     eik_vals, opa_vals = [], []
+    dist_on = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())
+    overlap = (OVERLAP_GRAD_ALLREDUCE if overlap_allreduce is None else bool(overlap_allreduce)) and dist_on and flat_grad is not None and manual
+    work_hi = hi_range = None
     for i in range(0, n_rays, bs) if manual else ():
         # The same three terms WITHOUT autograd (avatarcraft_amd.NeRFNetwork): the training render keeps its per-sample outputs, the upstream
         # gradients of (image, weights_sum, gradient_error) are written down directly (d sum(rgb * g) = g; d (eik * w) = w; the opacity term through
@@ -123,7 +141,21 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                 g_eik = _const_scalar(w_eikonal, ro.device)
                 eik_vals.append(eik * g_eik)
             mark("render_gt_and_losses")
-            net_style.backward_last(g_image=grad_rays[i:i + bs], g_weights_sum=g_ws, g_eik=g_eik)
+            if overlap and i + bs >= n_rays:
+                # the last patch of the step: the finer levels' share of the table gradient is final before the backward has ended -- its all-reduce
+                # starts on the side stream (ordered behind exactly that part of the scatter) while the main stream finishes the coarser levels
+                emb = net_style.encoder.embeddings
+                offs = net_style._offsets_host()
+                base = (emb.grad.data_ptr() - flat_grad.data_ptr()) // 4
+                assert 0 <= base and base + emb.grad.numel() <= flat_grad.numel(), "encoder.embeddings.grad must be a view of flat_grad"
+                hi_range = (base + 2 * int(offs[ALLREDUCE_SPLIT_LEVEL]), base + 2 * int(offs[-1]))
+                side = _side_stream(ro.device)
+                net_style.backward_last(g_image=grad_rays[i:i + bs], g_weights_sum=g_ws, g_eik=g_eik, split=(ALLREDUCE_SPLIT_LEVEL, side))
+                with torch.cuda.stream(side):
+                    work_hi = torch.distributed.all_reduce(flat_grad[hi_range[0]:hi_range[1]], op=torch.distributed.ReduceOp.SUM, group=process_group,
+                                                           async_op=True)
+            else:
+                net_style.backward_last(g_image=grad_rays[i:i + bs], g_weights_sum=g_ws, g_eik=g_eik)
         mark("backward")
     for i in range(0, n_rays, bs) if not manual else ():
         ro, rd = rays_o[i:i + bs], rays_d[i:i + bs]
@@ -157,6 +189,14 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
         if flat_grad is None:
             if world > 1:
                 raise RuntimeError("data-parallel sds_step needs flat_grad = flat_grad_view(net_style.parameters())")
+        elif work_hi is not None:
+            for lo, hi in ((0, hi_range[0]), (hi_range[1], flat_grad.numel())):      # the coarser levels (and whatever precedes the table) | the MLP gradients
+                if hi > lo:
+                    torch.distributed.all_reduce(flat_grad[lo:hi], op=torch.distributed.ReduceOp.SUM, group=process_group)
+            work_hi.wait()                                                           # the current stream waits for the early collective
+            if world > 1:
+                flat_grad.div_(world)
+            mark("grad_allreduce")
         else:
             torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
             if world > 1:

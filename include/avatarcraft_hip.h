@@ -343,7 +343,16 @@ typedef struct ac_core_saved {
                                                                            * forward kept; NULL = canonical space (ABI version 4)                  */
 } ac_core_saved;
 typedef struct ac_core_upstream { const float *g_image, *g_weights_sum, *g_depth, *g_normal_map, *g_eik; } ac_core_upstream;
-typedef struct ac_core_grads { float *g_table, *g_sdf_params, *g_color_params, *g_inv_s_per_ray; } ac_core_grads;
+typedef struct ac_core_grads {
+    float *g_table, *g_sdf_params, *g_color_params, *g_inv_s_per_ray;
+    /* data-parallel training (stylize.py under torch.distributed: one all-reduce of the flat gradient per step): with side_stream != NULL the table
+     * scatter finishes levels >= split_level first and makes side_stream wait for exactly that; the caller enqueues the all-reduce of that slice of
+     * g_table (entries [offsets[split_level], offsets[16])) on side_stream right after this call returns, and it overlaps the rest of the backward.
+     * The slice is final at that point; results are bit-identical to the unsplit call.  NULL / 0 = off (ABI version 4). */
+    ac_stream_t side_stream;
+    int32_t split_level;
+    int32_t reserved;
+} ac_core_grads;
 size_t ac_render_core_backward_scratch(const ac_field *field, int32_t n_rays, int32_t T);
 int ac_render_core_backward(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d, const float *bg,
                             const ac_core_saved *saved, const ac_core_upstream *upstream, const ac_core_grads *grads,

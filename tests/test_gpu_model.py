@@ -607,29 +607,34 @@ def test_sds_step_through_rccl_world_size_1():
     ro, rd = make_rays(16, 16, dist=1.8, f=12.0)
     ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
 
-    def one_step():
+    def one_step(overlap=False, batch=256):
         net, _ = golden_net(train=True)
         net_gt, _ = golden_net(train=False)
         opt = torch.optim.Adam(net.parameters(), lr=5e-3)
         flat = flat_grad_view(net.parameters())
         torch.manual_seed(7)
         marks = []
-        sds_step(net, net_gt, ro_t, rd_t, (16, 16), opt, SyntheticGuidance(3), batch_size=256, flat_grad=flat, timers=marks)
+        sds_step(net, net_gt, ro_t, rd_t, (16, 16), opt, SyntheticGuidance(3), batch_size=batch, flat_grad=flat, timers=marks, overlap_allreduce=overlap)
         torch.cuda.synchronize()
         return {k: v.detach().clone() for k, v in net.named_parameters()}, flat.clone(), [n for n, _ in marks]
     p0, f0, m0 = one_step()
+    p0b, f0b, _ = one_step(batch=128)                       # two patches: the table gradient accumulates across them
     assert "grad_allreduce" not in m0
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
         p1, f1, m1 = one_step()
+        # the level-group split: levels 8 - 15 of the table gradient (33.5 MB) are all-reduced from a side stream that waits for exactly the part of
+        # the scatter that completes them, the rest after the backward -- three collectives instead of one, the same bits
+        p2, f2, m2 = one_step(overlap=True)
+        p3, f3, _ = one_step(overlap=True, batch=128)      # (only the LAST patch's backward may release the early slice)
         probe = torch.ones(4, device=DEV); dist.all_reduce(probe); assert float(probe.sum()) == 4.0
     finally:
         dist.destroy_process_group()
-    assert "grad_allreduce" in m1 and f1.numel() == 12248902
-    assert torch.equal(f0, f1)
+    assert "grad_allreduce" in m1 and "grad_allreduce" in m2 and f1.numel() == 12248902
+    assert torch.equal(f0, f1) and torch.equal(f0, f2) and torch.equal(f0b, f3)
     for k in p0:
-        assert torch.equal(p0[k], p1[k]), k
+        assert torch.equal(p0[k], p1[k]) and torch.equal(p0[k], p2[k]) and torch.equal(p0b[k], p3[k]), k
 
 
 def test_sds_step_without_autograd_equals_autograd_step():
