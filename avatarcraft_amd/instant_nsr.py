@@ -61,7 +61,7 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ fused field handle
     # The prepared ac_field views (ctypes structs holding raw device pointers) and the outputs of the last training render are caches, not state:
     # they are left out of pickling / copy.deepcopy / torch.save(net) and rebuilt on the next render.
-    _CACHE_ATTRS = ("_field_cache", "_field_sdf_cache", "_last_train", "_offsets_cache", "_nan_pending")
+    _CACHE_ATTRS = ("_pair_bg_cache", "_field_cache", "_field_sdf_cache", "_last_train", "_offsets_cache", "_nan_pending")
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -179,13 +179,29 @@ class NeRFRenderer(nn.Module):
             b = torch.as_tensor(b, dtype=torch.float32, device=device)
             b = b.reshape(-1, 3) if b.numel() >= 3 else b.reshape(1, 1).expand(1, 3)
             return b.expand(N, 3) if b.shape[0] == 1 else b
-        bg_a = as_bg(bkg_fn()); noise_a = torch.rand((N, num_steps), device=device)
-        bg_b = as_bg(bkg_fn()); noise_b = torch.rand((N, num_steps), device=device)
+        # the two noise draws land in the two halves of one buffer (torch.rand(out=...): the same two calls, no concatenation kernel)
+        noise2 = torch.empty((2 * N, num_steps), dtype=torch.float32, device=device)
+
+        def draw(half):
+            dst = noise2[half * N:(half + 1) * N]
+            r = torch.rand((N, num_steps), device=device, out=dst)
+            if r.data_ptr() != dst.data_ptr():                   # (a replaced torch.rand that ignores `out`: tests replaying recorded draws)
+                dst.copy_(r)
+        bg_a = as_bg(bkg_fn()); draw(0)
+        bg_b = as_bg(bkg_fn()); draw(1)
+        ck = (bg_a.data_ptr(), bg_b.data_ptr(), N)
+        if bg_a is bg_b or (bg_a.data_ptr() == bg_b.data_ptr()):   # a constant background (cached on the device): its doubled copy is cached as well
+            cache = self.__dict__.setdefault("_pair_bg_cache", {})
+            if ck not in cache:
+                cache.clear(); cache[ck] = (torch.cat([bg_a, bg_b]).contiguous(), bg_a)      # (bg_a kept alive: the key is its address)
+            bg2 = cache[ck][0]
+        else:
+            bg2 = torch.cat([bg_a, bg_b]).contiguous()
         with torch.no_grad():
             field, inv_s = self._field(), self.forward_variance()
-            bg2 = torch.cat([bg_a, bg_b]).contiguous()
-            ra, rb = nsr_ops.render_rays_pair(field, ro, rd, torch.cat([noise_a, noise_b]), num_steps, upsample_steps, bound, inv_s, bg2=bg2,
-                                              cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, precision=self.render_precision)
+            ra, rb = nsr_ops.render_rays_pair(field, ro, rd, noise2, num_steps, upsample_steps, bound, inv_s, bg2=bg2,
+                                              cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, precision=self.render_precision,
+                                              reduce_a=False)
         self._last_train = (rb, ro, rd, bg2[N:], field)
         self._guard_finite(rb["eik_res"][0])
         return ra["image"], rb["image"], rb["eik_res"][0], rb["weights_sum"][:, None]

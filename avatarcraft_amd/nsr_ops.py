@@ -195,7 +195,7 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
 
 
 def render_rays_pair(field, rays_o, rays_d, noise2, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg2=None, cos_anneal_ratio=1.0,
-                     normal_epsilon_ratio=0.0, precision="exact", out=None, events=None, keep_weights=False):
+                     normal_epsilon_ratio=0.0, precision="exact", out=None, events=None, keep_weights=False, reduce_a=True):
     """ac_render_rays_pair: the same N rays rendered twice in ONE launch -- copy a with noise2[0] / bg2[0] (per-ray outputs only), copy b with
     noise2[1] / bg2[1] (+ everything the render-core backward needs: the training forward).  Returns (a, b): two RenderResult dicts whose tensors are
     the two halves of shared [2N, ...] buffers; b.opts is the N-ray ac_render_opts the backward takes.  Bit-identical to
@@ -243,9 +243,10 @@ def render_rays_pair(field, rays_o, rays_d, noise2, num_steps=64, upsample_steps
         ra[k], rb[k] = t[:N], t[N:]
     for k in per_sample:
         rb[k] = res[k]
-    ge = buf("pair_gradient_error", ())
-    L.check(L.lib().ac_eikonal_reduce(ra["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
-    ra["gradient_error"] = ge
+    if reduce_a:                           # (the stylisation step reads copy a's image only)
+        ge = buf("pair_gradient_error", ())
+        L.check(L.lib().ac_eikonal_reduce(ra["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
+        ra["gradient_error"] = ge
     er = buf("eik_res", (2,))
     L.check(L.lib().ac_eikonal_reduce2(rb["eik"].data_ptr(), N, er.data_ptr(), st), "eikonal_reduce")
     rb["eik_res"] = er

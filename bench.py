@@ -136,7 +136,7 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
     ms = dt / steps * 1e3
     launched = sum(SDS_BYTES_LAUNCHED.values())
     ach = launched / (ms * 1e-3) / 1e9
-    res = {"ms_per_step": ms, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad + 1 frozen",
+    res = {"ms_per_step": ms, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad (one launch: ac_render_rays_pair) + 1 frozen",
            "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)", "phase_ms": {k: round(v, 4) for k, v in phases.items()},
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_step": launched, "bytes_by_kernel": SDS_BYTES_LAUNCHED,
@@ -144,7 +144,9 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
                         "traffic": None},
            "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if dist is not None else 0,
            "grad_allreduce_ms": round(phases.get("grad_allreduce", 0.0), 4),
-           "core": "no autograd graph: forward = ac_render_rays (the inference launch, per-sample outputs and stencil features kept), upstream gradients "
+           "grad_allreduce_overlap": ("levels 8-15 of the table gradient all-reduced from a side stream during the rest of the backward (AC_OVERLAP_ALLREDUCE=1)"
+                                      if __import__("avatarcraft_amd.stylize", fromlist=["x"]).OVERLAP_GRAD_ALLREDUCE else "off (one collective after the backward)"),
+           "core": "no autograd graph: forward = ac_render_rays_pair (render_val and the training render of the same rays in one launch, per-sample outputs and stencil features of the second kept), upstream gradients "
                    "written down (ac_sds_upstream), backward = ac_render_core_backward (compositing, colour MLP, normalisation + eikonal, fused SDF "
                    "query on the kept features, binned two-pass table scatter) + ac_param_grads (weight norm, biases, variance); torch: noise, fused Adam"}
     return res, (net, net_gt)

@@ -48,12 +48,12 @@ def main():
     R = int(bench.get("repeat", 1))
     nm = W + R * K
     # bench.py (default precision exact): W + repeat x K exact launches, then the other mode (min(W, 2) + K fast launches), WHOLE_VIEW exact launches of
-    # 65 536 rays, then the SDS steps (two lean renders + one training forward each)
+    # 65 536 rays, then the SDS steps (one pair launch = render_val + the training forward, and one lean render of the frozen net, each)
     split = {"render_rays_kernel<0, exact, lean> main bench, timed launches": lean[W:nm], "render_rays_kernel<0, exact, lean> main bench, warm-up": lean[:W],
              "render_rays_kernel<0, fast, lean> the other arithmetic mode, same launches (roofline.other_precision)": fast[min(W, 2):min(W, 2) + K],
              "render_rays_kernel<0, exact, lean> whole view (65 536 rays) in one launch": lean[nm:nm + WHOLE_VIEW],
-             "render_rays_kernel<0, exact, lean> SDS step: render_val + frozen-net render (training view: every ray hits the body)": lean[nm + WHOLE_VIEW:],
-             "render_rays_kernel<0, exact, per-sample outputs> SDS step: the training forward": train}
+             "render_rays_kernel<0, exact, lean> SDS step: the frozen net's render (training view: every ray hits the body)": lean[nm + WHOLE_VIEW:],
+             "render_rays_kernel<0, exact, per-sample outputs> SDS step: render_val + the training forward in ONE launch (ac_render_rays_pair, 2 x 4096 rays)": train}
     byw = {k: dict(calls=len(v), avg_us=sum(v) / len(v), min_us=min(v), max_us=max(v)) for k, v in split.items() if v}
     byw["bench_line"] = dict(kernel_ms_hip_events=bench["roofline"]["kernel_ms"], ms_per_step=bench["ms_per_step"])
     json.dump(byw, open(f"{dst}/{rnd}_kernel_stats_by_workload.json", "w"), indent=1)
@@ -77,7 +77,8 @@ def main():
     trn_f, trn_w = (fetch[rkt[0]], write[rkt[0]]) if rkt else ([0.0], [0.0])
     KB = 1024
     mean = lambda v: sum(v) / len(v)
-    parts = {"2 x render_rays_kernel (lean)": 2 * (mean(sds_f) + mean(sds_w)) * KB, "render_rays_kernel (training forward)": (mean(trn_f) + mean(trn_w)) * KB}
+    parts = {"render_rays_kernel (lean: the frozen net's render)": (mean(sds_f) + mean(sds_w)) * KB,
+             "render_rays_kernel (pair launch: render_val + training forward)": (mean(trn_f) + mean(trn_w)) * KB}
     for k in fetch:
         if any(s in k for s in ("hash_stencil_bwd", "bucket_acc", "sdf_stencil_bwd", "color_bwd", "composite_bwd", "core_mid", "core_normals")):
             parts[k] = (mean(fetch[k]) + mean(write[k])) * KB
@@ -95,9 +96,9 @@ def main():
         for c, v in vals.items():
             seq = [v[i] for i in sorted(v)]
             byc[c] = {"main bench (4096 rays)": mean(seq[:n_main]), "whole view (65 536 rays)": mean(seq[n_main:n_main + WHOLE_VIEW]),
-                      "SDS renders without per-sample outputs (4096 rays, training view)": mean(seq[n_main + WHOLE_VIEW:])}
+                      "SDS step: the frozen net's render (4096 rays, training view, no per-sample outputs)": mean(seq[n_main + WHOLE_VIEW:])}
             if c in valt:
-                byc[c]["SDS training forward (per-sample outputs + stencil features kept)"] = mean(list(valt[c].values()))
+                byc[c]["SDS step: pair launch (render_val + training forward, 2 x 4096 rays, per-sample outputs + stencil features of the second copy kept)"] = mean(list(valt[c].values()))
     json.dump({"kernel": rk, "per_launch_mean_by_workload": byc}, open(f"{dst}/{rnd}_pmc_render_by_workload.json", "w"), indent=1)
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     # matrix-pipe occupancy of the render kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel clocks); clocks from the trace's mean duration x the
