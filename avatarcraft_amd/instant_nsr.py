@@ -14,6 +14,8 @@ Where the work happens:
   * render_can=False (SMPL inverse warp, :166-172,198-203): no-grad only (render_warp.py), ac_render_rays_warped.
 """
 import numpy as np
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -102,8 +104,8 @@ class NeRFRenderer(nn.Module):
             return
         pend = self.__dict__.setdefault("_nan_pending", [])
         self._poll_finite(wait=False)
-        host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        host.copy_(torch.isfinite(gerr.detach()).logical_not().reshape(1).to(torch.int32), non_blocking=True)
+        host = torch.zeros(1, dtype=torch.float32).pin_memory()      # the value itself travels (one 4-byte copy, no kernel); it is judged on the host
+        host.copy_(gerr.detach().reshape(1), non_blocking=True)
         ev = torch.cuda.Event(); ev.record()
         pend.append((ev, host))
 
@@ -112,7 +114,7 @@ class NeRFRenderer(nn.Module):
         while pend and (wait or pend[0][0].query()):
             ev, host = pend.pop(0)
             ev.synchronize()
-            if int(host[0]):
+            if not math.isfinite(float(host[0])):
                 pend.clear()
                 raise FloatingPointError("NaN / Inf in the finite-difference normals of a training render (reference: instant_nsr.py:274)")
 

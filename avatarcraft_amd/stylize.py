@@ -205,7 +205,8 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
     # (D)
     optimizer.step()
     mark("optimizer")
-    return {"eikonal": torch.stack(eik_vals).mean() if eik_vals else torch.zeros(()), "opacity": torch.stack(opa_vals).mean()}
+    mean = lambda v: v[0].reshape(()) if len(v) == 1 else torch.stack([t.reshape(()) for t in v]).mean()      # (one patch: no reduction kernels)
+    return {"eikonal": mean(eik_vals) if eik_vals else torch.zeros(()), "opacity": mean(opa_vals)}
 
 
 def stylize_epochs(net_style, net_gt, optimizer, guidance, hw=(256, 256), n_cap=100, coarse_epochs=1, fine_epochs=0, subsample_scale=4,

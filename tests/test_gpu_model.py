@@ -780,3 +780,20 @@ def test_density_grid_mesh_export_and_marcher(oracle):
     with torch.no_grad():
         gsd = src.gradient(cen, 1.6, 0.005).cpu().numpy()
     assert ((nrm * gsd).sum(1) > 0).mean() > 0.97                         # normals point along the SDF gradient: out of the body
+
+
+def test_nan_guard_raises_after_a_poisoned_training_render():
+    """the reference asserts `(gradient == gradient).all()` in every run() (instant_nsr.py:274); here the flag travels to the host asynchronously and
+    surfaces at the next poll: a NaN in a parameter makes check_finite() raise after a training render, and a healthy net passes."""
+    net, _ = golden_net(train=True)
+    ro, rd = make_rays(8, 8, dist=1.8, f=6.0)
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    kw = dict(num_steps=32, bound=1.6, upsample_steps=32, staged=False, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=True)
+    out = net.render(ro_t[None], rd_t[None], **kw)
+    out["rgb"].sum().backward()
+    net.check_finite()
+    with torch.no_grad():
+        net.sdf_net[1].bias[0] = float("nan")
+    net.render(ro_t[None], rd_t[None], **kw)
+    with pytest.raises(FloatingPointError):
+        net.check_finite()
