@@ -96,10 +96,11 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 #endif
     // Staggered start: wave w of a workgroup begins AC_START_STAGGER x 4096 clocks (~2 us each) x w late.  All 2048 waves of a launch would otherwise walk
     // through the same phases of their first ray together (every wave gathering, then every wave in the MLPs): rays of the first round took 350 .. 420 us
-    // against 280 .. 330 us for the ones fetched later, when the waves have drifted apart (tools/phase_profile.py).  3 = 6 us per wave index, 41 us for
-    // the last wave of a workgroup; the plateau is wide (4 .. 8 us per index), larger steps lose more at the end of the launch than they gain.
+    // against 280 .. 330 us for the ones fetched later, when the waves have drifted apart (tools/phase_profile.py).  Round 2 used 3 (6 us per wave index, 41 us
+    // for the last wave); with quarter-ray work items (round 3) 1 = 2 us per index, 14 us for the last wave, does the same (0.762 vs 0.760 ms; none: 0.776,
+    // profiles/r03_experiments.txt section 14).
 #ifndef AC_START_STAGGER
-#define AC_START_STAGGER 3
+#define AC_START_STAGGER 1
 #endif
     // (only launches that fill the device: a small batch -- a posed frame's tail, a unit test -- has no lock-step to break and would only pay the delay)
     if (a.n_rays >= 2048)
