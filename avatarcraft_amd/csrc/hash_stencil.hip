@@ -14,6 +14,7 @@
 // render core passes it); features / their gradient [7, L, B, 2] (level-major like the reference's [L,B,C] kernel output).
 // Arithmetic per point is the one of hash_fwd_kernel (fma(x, scale, 0.5), floor, trilinear weights as products in d order);
 // the normalisation to [0,1] is (clamp(x +- eps) + bound) / (2 bound) with a true division, like the fused renderer.
+#include <mutex>
 #include "ac_common.hpp"
 #include "ac_devmath.hpp"
 
@@ -756,8 +757,10 @@ AC_API size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint
 // gradient) starts while the second launch -- and whatever follows on `stream` -- still runs.  side_stream == NULL: one launch, no event.
 static hipEvent_t split_event()
 {
+    static std::mutex mu;
     static hipEvent_t ev[64];
     static bool have[64];
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     dev &= 63;
