@@ -362,12 +362,15 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         if (!seg_first) {
             // continue a ray another wave (of this XCD) started: wait until its previous segment is published, then take over z and the running sums.
             // All accesses to seg_flags / seg_state are agent-scope atomics = served by the XCD's L2, past the (incoherent) vector L1 caches.
+            int timed_out = 0;
             if (lane == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(a.seg_flags + ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)seg && spins < (1 << 21)) {
                     __builtin_amdgcn_s_sleep(8); ++spins;       // (bounded: ~1 s; a ray's previous segment takes ~100 us)
                 }
+                timed_out = spins >= (1 << 21);
             }
+            timed_out = __builtin_amdgcn_readfirstlane(timed_out);
             wave_sync();
             const uint32_t *st = reinterpret_cast<const uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
             if constexpr (MODE != MODE_FINAL)
@@ -375,6 +378,10 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float cv = __uint_as_float(__hip_atomic_load(st + MAXT + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             cT = lane_bcast(cv, 0);
             if (lane < 16) accs[lane] = cv;
+            if (timed_out) {                                     // never observed; if the previous segment was not published in ~1 s the ray's pixel must not
+                cT = __builtin_nanf("");                         // look like a result: NaN, which the callers' finite checks and every parity test catch
+                if (lane < 16) accs[lane] = cT;
+            }
             wave_sync();
         }
         const float bxe = a.eps;
