@@ -585,6 +585,9 @@ __device__ unsigned long long g_warp_prof[8];
 #define WP_END()
 #endif
 // ---- pieces shared by the search kernel and the builder of the cell grid -----------------------------------------------------------------
+#ifdef AC_WARP_SEED_DEBUG
+__device__ const double *g_warp_seed_d2 = nullptr;
+#endif
 #define SBOX(ROW, TL) sbox_raw[(ROW) * ntp + (TL)]
 __device__ __forceinline__ void load_boxes(float *sbox_raw, const AccelView &av, uint32_t ntp)
 {
@@ -928,6 +931,9 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
         }
     }
 #endif
+#ifdef AC_WARP_SEED_DEBUG   // ceiling experiment (tools/warp_seed_probe.py): start every sample from its TRUE distance^2 (taken from a previous run)
+    if (g_warp_seed_d2 && live && mycnt != CELL_OVERFLOW) { const double t = g_warp_seed_d2[ii] * (1.0 + 1e-12); myseed = t < myseed ? t : myseed; }
+#endif
     sbest[lane] = __builtin_bit_cast(unsigned long long, myseed);
     sbid[lane] = 0x7fffffffu;
 #pragma unroll
@@ -1175,6 +1181,14 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
 }
 
 }  // namespace
+
+#ifdef AC_WARP_SEED_DEBUG
+AC_API void ac_debug_warp_seed(const double *d2)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warp_seed_d2), &d2, sizeof(d2));
+}
+#endif
 
 #ifdef AC_PROFILE_WARP
 AC_API void ac_debug_warp_prof(unsigned long long *out, int reset)

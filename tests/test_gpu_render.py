@@ -238,6 +238,16 @@ def test_render_bad_arguments(env):
         nsr_ops.render_rays(env["f"], ro.cpu(), rd, 64, 64, 1.6, 1.0)
     out = nsr_ops.render_rays(env["f"], ro[:0], rd[:0], 64, 64, 1.6, 1.0)   # empty batch is fine
     assert out["image"].shape == (0, 3)
+    # the pair launch: same argument checks (sample counts, device), the noise of both copies is mandatory, an empty batch is fine
+    nz = torch.rand(2, 4, 64, device="cuda:0")
+    with pytest.raises(RuntimeError):
+        nsr_ops.render_rays_pair(env["f"], ro, rd, nz[:, :, :60].contiguous(), 60, 64, 1.6, 1.0)
+    with pytest.raises(RuntimeError):
+        nsr_ops.render_rays_pair(env["f"], ro.cpu(), rd, nz, 64, 64, 1.6, 1.0)
+    with pytest.raises(RuntimeError):
+        nsr_ops.render_rays_pair(env["f"], ro, rd, nz[:1], 64, 64, 1.6, 1.0)
+    pa, pb = nsr_ops.render_rays_pair(env["f"], ro[:0], rd[:0], nz[:, :0], 64, 64, 1.6, 1.0)
+    assert pa["image"].shape == (0, 3) and pb["z_vals"].shape == (0, 128)
 
 
 def test_field_sdf_color_bitwise(env):
