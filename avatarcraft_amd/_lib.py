@@ -32,7 +32,7 @@ class ac_render_opts(C.Structure):
 class ac_render_out(C.Structure):
     _fields_ = [("image", vp), ("weights_sum", vp), ("depth", vp), ("normal_map", vp), ("eik", vp), ("z_vals", vp),
                 ("weights", vp), ("alpha", vp), ("color", vp), ("sdf", vp), ("gradient", vp), ("ss_inds", vp),
-                ("sort_index", vp), ("sdf_out16", vp), ("pts", vp), ("feat7", vp)]
+                ("sort_index", vp), ("sdf_out16", vp), ("pts", vp), ("feat7", vp), ("eik_reduced", vp)]
 
 
 class ac_core_saved(C.Structure):

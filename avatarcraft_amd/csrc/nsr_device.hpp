@@ -135,6 +135,13 @@ struct RenderArgs {
     // pair launches (ac_render_rays_pair): the same pair_n rays twice, n_rays = 2 * pair_n work items handed out as a0 b0 a1 b1 ...; copy a = rows
     // [0, pair_n), copy b = rows [pair_n, 2 pair_n) of noise, bg and the per-ray outputs; rays_o / rays_d / near_m / far_m have pair_n rows.  0 = off.
     int pair_n;
+    // launch hygiene (round 3): the last workgroup to finish (ticket from done_counter) reduces gradient_error into eik_red -- [1 or 2 (pair)][2] floats:
+    // (sum relax * err / (sum relax + 1e-5), sum relax + 1e-5) in eikonal_reduce_kernel's fixed order, bit for bit -- and re-arms the work counters for the
+    // slot's next launch; seg_flags carry the launch generation (gen << 4 | finished segments), so they need no clearing either: no memset and no reduction
+    // launch around the render kernel.
+    uint32_t *done_counter;
+    float *eik_red;
+    uint32_t gen;
     int ex_from;                   // the per-sample outputs (EX kernels) are kept for rays >= ex_from only, at row ray - ex_from of arrays with ex_rows rows
     int ex_rows;
     const uint8_t *ray_dead;       // MODE_UPSAMPLE, skip_masked: [N] rays that cannot hold an unmasked sample (no field evaluation, coarse z only)

@@ -365,7 +365,10 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             int timed_out = 0;
             if (lane == 0) {
                 int spins = 0;
-                while (__hip_atomic_load(a.seg_flags + ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)seg && spins < (1 << 21)) {
+                // the flag of THIS launch: generation in the upper bits (a value left by an earlier launch in the same slot never matches)
+                for (;;) {
+                    const uint32_t f = __hip_atomic_load(a.seg_flags + ray, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (((f >> 4) == a.gen && (f & 15u) >= (uint32_t)seg) || spins >= (1 << 21)) break;
                     __builtin_amdgcn_s_sleep(8); ++spins;       // (bounded: ~1 s; a ray's previous segment takes ~100 us)
                 }
                 timed_out = spins >= (1 << 21);
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
-            if (lane == 0) __hip_atomic_store(a.seg_flags + ray, (uint32_t)(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(a.seg_flags + ray, (a.gen << 4) | (uint32_t)(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             wave_sync();
             continue;
         }
@@ -573,6 +576,55 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 #endif
     }
     }
+#if AC_DYNAMIC_RAYS
+    // ---- epilogue: the last workgroup to finish reduces gradient_error and re-arms the slot's work counters (RenderArgs::done_counter) --------------------
+    // (the arguments used here are read from the kernel-argument segment again, behind an opaque barrier: kept in scalar registers from the start of the kernel
+    //  they cost the work loops two spilled vector registers)
+    const __attribute__((address_space(4))) RenderArgs *ka = (const __attribute__((address_space(4))) RenderArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    uint32_t *const k_done = ka->done_counter;
+    if (k_done) {
+        __syncthreads();                                         // every wave of this workgroup has left the work loops: the weights in LDS are free
+        uint32_t *ldsu = reinterpret_cast<uint32_t *>(lds);
+        if (threadIdx.x == 0) {
+            __threadfence();                                     // this workgroup's per-ray results are visible device-wide before its ticket is
+            ldsu[0] = atomicAdd(k_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool last = ldsu[0] != 0u;
+        __syncthreads();
+        if (last) {
+            __threadfence();                                     // ... and every other workgroup's are visible here
+            float *const k_red = ka->eik_red;
+            const int k_pair = ka->pair_n, k_n = ka->n_rays;
+            const float *const k_eik = ka->out.eik;
+            uint32_t *const k_cnt = ka->ray_counter;
+            if (k_red) {
+                // gradient_error (:270-272) of the batch -- of each copy of a pair launch -- in eikonal_reduce_kernel's order (oracle: orc_eikonal_reduce):
+                // 1024 strided sequential partial sums (two per thread here), then a halving tree
+                const int nred = k_pair ? 2 : 1, nper = k_pair ? k_pair : k_n;
+                float *pn = lds, *pd = lds + 1024;
+                for (int q = 0; q < nred; ++q) {
+                    const float *e = k_eik + (size_t)q * nper * 2;
+                    for (int t = (int)threadIdx.x; t < 1024; t += BLOCK) {
+                        float sa = 0.0f, sb = 0.0f;
+                        for (int r = t; r < nper; r += 1024) { sa += e[2 * r]; sb += e[2 * r + 1]; }
+                        pn[t] = sa; pd[t] = sb;
+                    }
+                    __syncthreads();
+                    for (int st = 512; st > 0; st >>= 1) {
+                        for (int t = (int)threadIdx.x; t < st; t += BLOCK) { pn[t] += pn[t + st]; pd[t] += pd[t + st]; }
+                        __syncthreads();
+                    }
+                    if (threadIdx.x == 0) { k_red[2 * q] = pn[0] / (pd[0] + 1e-5f); k_red[2 * q + 1] = pd[0] + 1e-5f; }
+                    __syncthreads();
+                }
+            }
+            if (threadIdx.x < 64) k_cnt[threadIdx.x] = 0u;       // the slot's next launch starts from zero again
+            if (threadIdx.x == 64) *k_done = 0u;
+        }
+    }
+#endif
 #ifdef AC_PROFILE
     if (a.prof && lane == 0) { const int w_ = blockIdx.x * WAVES_PER_BLOCK + wave; for (int i = 0; i < 8; ++i) a.prof[w_ * 10 + i] = prof_acc[i];
         a.prof[w_ * 10 + 8] = __builtin_amdgcn_s_memtime() - prof_t0; a.prof[w_ * 10 + 9] = __builtin_amdgcn_s_memrealtime() - prof_r0; }   // shader clock vs 100 MHz
@@ -731,8 +783,10 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
 #ifndef AC_RAY_SEGMENTS
 #define AC_RAY_SEGMENTS 4           // segments a ray is cut into (1 = whole rays as work items, rounds 1 - 2; at most 8)
 #endif
-struct SegSlot { char *p; size_t bytes; };
-static char *seg_scratch(size_t need)
+struct SegSlot { char *p; size_t bytes; uint32_t gen; };
+// -> the slot's memory and the generation of this launch (1 .. 2^28 - 1): a slot is zeroed when it is allocated; after that every launch leaves its
+// counters at zero (the kernel's last workgroup re-arms them) and tags its per-ray flags with its generation, so nothing is cleared between launches
+static char *seg_scratch(size_t need, uint32_t &gen)
 {
     static std::mutex mu;
     static SegSlot pool[64][16];
@@ -744,11 +798,18 @@ static char *seg_scratch(size_t need)
     SegSlot &sl = pool[dev][turn[dev]++ & 15u];
     if (sl.bytes < need) {
         if (sl.p) (void)hipFree(sl.p);                                   // (synchronises the device: no launch can still be using the slot)
-        sl.p = nullptr; sl.bytes = 0;
+        sl.p = nullptr; sl.bytes = 0; sl.gen = 0;
         const size_t want = (need + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
         if (hipMalloc(reinterpret_cast<void **>(&sl.p), want) != hipSuccess) { sl.p = nullptr; return nullptr; }
+        if (hipMemset(sl.p, 0, want) != hipSuccess) { (void)hipFree(sl.p); sl.p = nullptr; return nullptr; }
         sl.bytes = want;
     }
+    sl.gen = (sl.gen + 1u) & 0x0fffffffu;
+    if (sl.gen == 0u) {                                                  // wrapped: flags of 2^28 launches ago could match again -- start over from zeroed memory
+        if (hipMemset(sl.p, 0, sl.bytes) != hipSuccess) return nullptr;
+        sl.gen = 1u;
+    }
+    gen = sl.gen;
     return sl.p;
 }
 
@@ -769,13 +830,16 @@ static void launch_render_p(const RenderArgs &a, hipStream_t stream)
         if (sn < 1) sn = 1;
         b.seg_n = sn; b.seg_cb = 0;
         for (int q = 0; q <= sn; ++q) b.seg_cb |= (uint64_t)((nt * q) / sn) << (4 * q);
-        const size_t N = (size_t)a.n_rays, head = 256, flags = (N * 4 + 255) & ~(size_t)255;
+        const size_t N = (size_t)a.n_rays, head = 512, flags = (N * 4 + 255) & ~(size_t)255;      // head: [0, 256) work counters | [256] finished workgroups
         const size_t need = head + (sn > 1 ? flags + N * SEG_STATE * sizeof(float) : 0);
-        char *sc = seg_scratch(need);
+        uint32_t gen = 0;
+        char *sc = seg_scratch(need, gen);
         b.ray_counter = reinterpret_cast<uint32_t *>(sc);
+        b.done_counter = sc ? reinterpret_cast<uint32_t *>(sc + 256) : nullptr;
+        b.gen = gen;
+        b.eik_red = (MODE == MODE_UPSAMPLE) ? nullptr : a.out.eik_reduced;
         b.seg_flags = sn > 1 ? reinterpret_cast<uint32_t *>(sc + head) : nullptr;
         b.seg_state = sn > 1 ? reinterpret_cast<float *>(sc + head + flags) : nullptr;
-        if (sc) (void)hipMemsetAsync(sc, 0, head + (sn > 1 ? N * 4 : 0), stream);
         const int cus = (int)ac::cu_count();
         if (blocks > cus) blocks = cus;
         blocks = (blocks + 7) & ~7;                                      // every XCD gets the same number of workgroups
@@ -784,6 +848,11 @@ static void launch_render_p(const RenderArgs &a, hipStream_t stream)
     hipLaunchKernelGGL((render_rays_kernel<MODE, FAST, EX>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, b);
 #else
     hipLaunchKernelGGL((render_rays_kernel<MODE, FAST, EX>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
+    if (MODE != MODE_UPSAMPLE && a.out.eik_reduced) {                 // (static ray assignment builds: the reduction as its own launch(es))
+        const int nred = a.pair_n ? 2 : 1, nper = a.pair_n ? a.pair_n : a.n_rays;
+        for (int q = 0; q < nred; ++q)
+            hipLaunchKernelGGL(eikonal_reduce_kernel, dim3(1), dim3(1024), 0, stream, a.out.eik + (size_t)q * nper * 2, nper, a.out.eik_reduced + 2 * q, 1);
+    }
 #endif
 }
 static bool wants_samples(const ac_render_out &o)

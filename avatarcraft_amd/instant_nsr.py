@@ -202,8 +202,7 @@ class NeRFRenderer(nn.Module):
         with torch.no_grad():
             field, inv_s = self._field(), self.forward_variance()
             ra, rb = nsr_ops.render_rays_pair(field, ro, rd, noise2, num_steps, upsample_steps, bound, inv_s, bg2=bg2,
-                                              cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, precision=self.render_precision,
-                                              reduce_a=False)
+                                              cos_anneal_ratio=cos_anneal_ratio, normal_epsilon_ratio=normal_epsilon_ratio, precision=self.render_precision)
         self._last_train = (rb, ro, rd, bg2[N:], field)
         self._guard_finite(rb["eik_res"][0])
         return ra["image"], rb["image"], rb["eik_res"][0], rb["weights_sum"][:, None]

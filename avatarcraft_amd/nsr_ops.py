@@ -135,6 +135,10 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     o.depth = buf("depth", (N,)).data_ptr()
     o.normal_map = buf("normal_map", (N, 3)).data_ptr()
     o.eik = buf("eik", (N, 2)).data_ptr()
+    er = buf("eik_res", (2,))              # (gradient_error, its denominator): reduced by the render launch itself (ac_render_out.eik_reduced)
+    o.eik_reduced = er.data_ptr()
+    if N == 0:
+        er.zero_()
     if extras:
         o.z_vals = buf("z_vals", (N, T)).data_ptr()
         o.weights = buf("weights", (N, T)).data_ptr()
@@ -184,18 +188,12 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
             res["far_m"] = scratch[offs[1]:offs[1] + N * 4].view(_F32)
     if events is not None:
         events[1].record()
-    if train_extras:
-        er = buf("eik_res", (2,))
-        L.check(L.lib().ac_eikonal_reduce2(res["eik"].data_ptr(), N, er.data_ptr(), st), "eikonal_reduce")
-        res["gradient_error"] = er[0]
-    else:
-        ge = buf("gradient_error", ())
-        L.check(L.lib().ac_eikonal_reduce(res["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
+    res["gradient_error"] = er[0]
     return res
 
 
 def render_rays_pair(field, rays_o, rays_d, noise2, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg2=None, cos_anneal_ratio=1.0,
-                     normal_epsilon_ratio=0.0, precision="exact", out=None, events=None, keep_weights=False, reduce_a=True):
+                     normal_epsilon_ratio=0.0, precision="exact", out=None, events=None, keep_weights=False):
     """ac_render_rays_pair: the same N rays rendered twice in ONE launch -- copy a with noise2[0] / bg2[0] (per-ray outputs only), copy b with
     noise2[1] / bg2[1] (+ everything the render-core backward needs: the training forward).  Returns (a, b): two RenderResult dicts whose tensors are
     the two halves of shared [2N, ...] buffers; b.opts is the N-ray ac_render_opts the backward takes.  Bit-identical to
@@ -216,6 +214,10 @@ def render_rays_pair(field, rays_o, rays_d, noise2, num_steps=64, upsample_steps
     per_ray = {"image": (2 * N, 3), "weights_sum": (2 * N,), "depth": (2 * N,), "normal_map": (2 * N, 3), "eik": (2 * N, 2)}
     for k, shp in per_ray.items():
         setattr(o, k, buf("pair_" + k, shp).data_ptr())
+    er2 = buf("pair_eik_res", (2, 2))      # per copy: (gradient_error, its denominator), reduced by the launch itself
+    o.eik_reduced = er2.data_ptr()
+    if N == 0:
+        er2.zero_()
     per_sample = {"z_vals": (N, T), "color": (N, T, 3), "sdf": (N, T), "gradient": (N, T, 3), "sdf_out16": (N, T, 16), "pts": (N, T, 3)}      # what the backward reads
     if keep_weights:
         per_sample.update({"weights": (N, T), "alpha": (N, T)})
@@ -243,14 +245,8 @@ def render_rays_pair(field, rays_o, rays_d, noise2, num_steps=64, upsample_steps
         ra[k], rb[k] = t[:N], t[N:]
     for k in per_sample:
         rb[k] = res[k]
-    if reduce_a:                           # (the stylisation step reads copy a's image only)
-        ge = buf("pair_gradient_error", ())
-        L.check(L.lib().ac_eikonal_reduce(ra["eik"].data_ptr(), N, ge.data_ptr(), st), "eikonal_reduce")
-        ra["gradient_error"] = ge
-    er = buf("eik_res", (2,))
-    L.check(L.lib().ac_eikonal_reduce2(rb["eik"].data_ptr(), N, er.data_ptr(), st), "eikonal_reduce")
-    rb["eik_res"] = er
-    rb["gradient_error"] = er[0]
+    ra["eik_res"], rb["eik_res"] = er2[0], er2[1]
+    ra["gradient_error"], rb["gradient_error"] = er2[0, 0], er2[1, 0]
     rb.opts = ra.opts = (op, inv_s_t, None, None)
     rb._keep = ra._keep = (noise2, bg2, res)
     return ra, rb

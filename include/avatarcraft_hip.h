@@ -188,6 +188,10 @@ typedef struct ac_render_out {
                                * lane n + 16 g (sample n of the tile, level group g) at [k / 4][lane][k % 4] -- opaque to callers, produced by the
                                * forward and consumed by ac_render_core_backward, which would otherwise gather the table again (0.9 KB per
                                * sample; training renders only)                                                                                */
+    float *eik_reduced;       /* optional [2] ([2][2] for ac_render_rays_pair: one pair per copy): (gradient_error, its denominator) =
+                               * (sum relax * err / (sum relax + 1e-5), sum relax + 1e-5) over the batch (instant_nsr.py:270-272), reduced by the
+                               * render launch itself in ac_eikonal_reduce2's fixed order (bit-identical to calling it on `eik` afterwards);
+                               * not written for an empty batch (ABI version 4)                                                               */
 } ac_render_out;
 
 /* rays_o, rays_d [N,3]; bg [N,3] or NULL (= white, bg_color None -> 1); noise [N,num_steps] U[0,1)
