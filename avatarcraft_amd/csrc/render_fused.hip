@@ -139,7 +139,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     const bool seg_first = true, seg_last = true;
     {
     for (int ray = bid * WAVES_PER_BLOCK + wave; ray < a.n_rays; ray += gridDim.x * WAVES_PER_BLOCK) {
-        const int rin = ray;
+        const int rin = (a.pair_n && ray >= a.pair_n) ? ray - a.pair_n : ray;      // (pair launch: the copies are rows [0, N) and [N, 2N))
 #endif
         const int exr = ray - a.ex_from;                             // row in the per-sample outputs (pair launches keep them for copy b only)
         const bool ex_on = exr >= 0;
