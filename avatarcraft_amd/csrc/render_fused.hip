@@ -27,6 +27,7 @@
 // Numerics contract: see ac_devmath.hpp and DESIGN.md; every value produced here is bit-identical
 // to oracle/ac_oracle.c:orc_render_rays on the same inputs.
 #include <atomic>
+#include <map>
 #include <mutex>
 #include "nsr_device.hpp"
 
@@ -777,25 +778,23 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     return AC_OK;
 }
 
-// Per-launch scratch of the dynamic hand-out: [8 XCDs][8 segments] work counters (256 B) | flags [N] u32 | state [N][SEG_STATE] f32.
-// 16 rotating slots per device, each grown to the largest batch it has served and kept for the life of the process (launches of one stream run in
-// order; 16 launches in flight across streams would be needed for two of them to share a slot).  Counters and flags are zeroed before every launch.
+// Per-launch scratch of the dynamic hand-out: [8 XCDs][8 segments] work counters (256 B) | finished-workgroup counter | flags [N] u32 | state [N][SEG_STATE] f32.
+// One slot per (device, stream), grown to the largest batch it has served and kept for the life of the process: launches of one stream run in order, so a
+// slot is never in use by two launches at once, however many streams render concurrently.
 #ifndef AC_RAY_SEGMENTS
 #define AC_RAY_SEGMENTS 4           // segments a ray is cut into (1 = whole rays as work items, rounds 1 - 2; at most 8)
 #endif
 struct SegSlot { char *p; size_t bytes; uint32_t gen; };
 // -> the slot's memory and the generation of this launch (1 .. 2^28 - 1): a slot is zeroed when it is allocated; after that every launch leaves its
 // counters at zero (the kernel's last workgroup re-arms them) and tags its per-ray flags with its generation, so nothing is cleared between launches
-static char *seg_scratch(size_t need, uint32_t &gen)
+static char *seg_scratch(size_t need, uint32_t &gen, hipStream_t stream)
 {
     static std::mutex mu;
-    static SegSlot pool[64][16];
-    static uint32_t turn[64];
+    static std::map<std::pair<int, hipStream_t>, SegSlot> pool;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
-    dev &= 63;
     std::lock_guard<std::mutex> lock(mu);
-    SegSlot &sl = pool[dev][turn[dev]++ & 15u];
+    SegSlot &sl = pool[std::make_pair(dev, stream)];
     if (sl.bytes < need) {
         if (sl.p) (void)hipFree(sl.p);                                   // (synchronises the device: no launch can still be using the slot)
         sl.p = nullptr; sl.bytes = 0; sl.gen = 0;
@@ -833,7 +832,7 @@ static void launch_render_p(const RenderArgs &a, hipStream_t stream)
         const size_t N = (size_t)a.n_rays, head = 512, flags = (N * 4 + 255) & ~(size_t)255;      // head: [0, 256) work counters | [256] finished workgroups
         const size_t need = head + (sn > 1 ? flags + N * SEG_STATE * sizeof(float) : 0);
         uint32_t gen = 0;
-        char *sc = seg_scratch(need, gen);
+        char *sc = seg_scratch(need, gen, stream);
         b.ray_counter = reinterpret_cast<uint32_t *>(sc);
         b.done_counter = sc ? reinterpret_cast<uint32_t *>(sc + 256) : nullptr;
         b.gen = gen;

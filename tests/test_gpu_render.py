@@ -491,3 +491,27 @@ def test_pair_launch_equals_two_launches(env, n, precision):
         for k in ("z_vals", "weights", "alpha", "color", "sdf", "gradient", "sdf_out16", "pts", "feat7", "eik_res"):
             assert torch.equal(pb[k], b[k]), ("copy b", k, rep)
     assert pb.opts[0].n_rays == n
+
+
+def test_render_on_concurrent_streams(env):
+    """launches issued from several streams at once: every stream owns its hand-out scratch (work counters, per-ray flags and state), so renders that
+    overlap in time do not disturb each other -- 4 streams x 6 launches of different batches, each equal to its single-stream result bit for bit"""
+    from avatarcraft_amd import nsr_ops
+    dev = "cuda:0"
+    ro, rd = make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)
+    f, inv_s = env["f"], float(env["p"]["inv_s"])
+    batches = [(torch.from_numpy(ro[k * 4096:(k + 1) * 4096].copy()).to(dev), torch.from_numpy(rd[k * 4096:(k + 1) * 4096].copy()).to(dev)) for k in (0, 5, 9, 14)]
+    ref = [nsr_ops.render_rays(f, o, d, 64, 64, 1.6, inv_s) for o, d in batches]
+    ref = [{k: r[k].clone() for k in ("image", "weights_sum", "depth", "normal_map", "gradient_error")} for r in ref]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in batches]
+    outs = [[] for _ in batches]
+    for rep in range(6):
+        for s, (o, d), acc in zip(streams, batches, outs):
+            with torch.cuda.stream(s):
+                acc.append(nsr_ops.render_rays(f, o, d, 64, 64, 1.6, inv_s))
+    torch.cuda.synchronize()
+    for r, acc in zip(ref, outs):
+        for out in acc:
+            for k, v in r.items():
+                assert torch.equal(out[k], v), k
