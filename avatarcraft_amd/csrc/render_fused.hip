@@ -800,12 +800,13 @@ static char *seg_scratch(size_t need, uint32_t &gen, hipStream_t stream)
         sl.p = nullptr; sl.bytes = 0; sl.gen = 0;
         const size_t want = (need + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
         if (hipMalloc(reinterpret_cast<void **>(&sl.p), want) != hipSuccess) { sl.p = nullptr; return nullptr; }
-        if (hipMemset(sl.p, 0, want) != hipSuccess) { (void)hipFree(sl.p); sl.p = nullptr; return nullptr; }
+        // (on the launch's own stream: ordered before the kernel that is about to use the slot -- a null-stream memset is not, for non-blocking streams)
+        if (hipMemsetAsync(sl.p, 0, want, stream) != hipSuccess) { (void)hipFree(sl.p); sl.p = nullptr; return nullptr; }
         sl.bytes = want;
     }
     sl.gen = (sl.gen + 1u) & 0x0fffffffu;
     if (sl.gen == 0u) {                                                  // wrapped: flags of 2^28 launches ago could match again -- start over from zeroed memory
-        if (hipMemset(sl.p, 0, sl.bytes) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(sl.p, 0, sl.bytes, stream) != hipSuccess) return nullptr;
         sl.gen = 1u;
     }
     gen = sl.gen;
