@@ -755,7 +755,8 @@ AC_API size_t ac_hash_stencil_backward_scratch(const int32_t *offsets_host, uint
 // split_level / side_stream (ac_core_grads, data-parallel training): the accumulation runs in two launches, levels >= split_level first; an event
 // recorded after that launch is waited for by side_stream, so that work the caller enqueues there (the all-reduce of that part of the table
 // gradient) starts while the second launch -- and whatever follows on `stream` -- still runs.  side_stream == NULL: one launch, no event.
-static hipEvent_t split_event()
+// side waits for everything enqueued on st so far (one event per device, recorded and waited for under one lock: host threads cannot interleave)
+static bool order_side_stream(hipStream_t st, hipStream_t side)
 {
     static std::mutex mu;
     static hipEvent_t ev[64];
@@ -764,8 +765,8 @@ static hipEvent_t split_event()
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     dev &= 63;
-    if (!have[dev]) { if (hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) return nullptr; have[dev] = true; }
-    return ev[dev];
+    if (!have[dev]) { if (hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) return false; have[dev] = true; }
+    return hipEventRecord(ev[dev], st) == hipSuccess && hipStreamWaitEvent(side, ev[dev], 0) == hipSuccess;
 }
 
 int hash_stencil_backward_split(const float *grad, const float *x, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
@@ -833,8 +834,7 @@ int hash_stencil_backward_split(const float *grad, const float *x, const int32_t
         if (side_stream && every_hi_binned && n_lo > 0 && n_lo < sc.n_binned && !sc.n_priv) {
             hipLaunchKernelGGL(bucket_accumulate_kernel, dim3(NBUCKET, sc.n_binned - n_lo), dim3(1024), lds2, st, grad_embeddings, lt, sc.binned_mask, qcount,
                                queues, sc.cap, n_lo, sc.n_binned);
-            hipEvent_t ev = split_event();
-            if (!ev || hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent((hipStream_t)side_stream, ev, 0) != hipSuccess) {
+            if (!order_side_stream(st, (hipStream_t)side_stream)) {
                 ac::set_error("hash_stencil_backward: cannot order the side stream behind the first level group"); return AC_ERR_BAD_ARG;
             }
             side_stream = nullptr;                                           // (done: the fallback below is for the cases that could not split)
@@ -848,10 +848,7 @@ int hash_stencil_backward_split(const float *grad, const float *x, const int32_t
     if (sc.n_priv)
         hipLaunchKernelGGL(priv_reduce_kernel, dim3((sc.entries * 2 + 255) / 256), dim3(256), 0, st, priv, sc.entries * 2, n_copies, grad_embeddings);
     if (side_stream) {                          // no split happened (direct levels, no scratch): the side stream waits for everything
-        hipEvent_t ev = split_event();
-        if (!ev || hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent((hipStream_t)side_stream, ev, 0) != hipSuccess) {
-            ac::set_error("hash_stencil_backward: cannot order the side stream"); return AC_ERR_BAD_ARG;
-        }
+        if (!order_side_stream(st, (hipStream_t)side_stream)) { ac::set_error("hash_stencil_backward: cannot order the side stream"); return AC_ERR_BAD_ARG; }
     }
     return ac::check_launch("hash_stencil_backward");
 }
