@@ -21,7 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          # no compiler-formed packed-fp32 (v_pk_*_f32) code: the one run-to-run non-determinism ever observed in the renderer (round 2: the "face-value"
          # stencil variant; round 3: reproduced and bisected) appears exactly when the SLP vectorizer packs the xy weight
          # products and the two feature channels of that variant into v_pk_mul / v_pk_fma with crossed op_sel, and disappears with this flag;
-         # measured cost of the flag on the shipped kernels: none (render 0.799 vs 0.796 ms, posed frame 8.50 vs 8.75 ms, same box)
+         # measured cost of the flag on the shipped kernels: none (render 0.799 vs 0.796 ms; per kernel on one-batch posed frames at the end of round 3, vectoriser
+         # on / off: warp search 4.86 / 4.74 ms, mesh near-far 0.33 / 0.17 ms, render passes equal -- profiles/r03_experiments.txt section 19)
          "-fno-slp-vectorize"]
 
 
