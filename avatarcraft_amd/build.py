@@ -25,6 +25,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          # on / off: warp search 4.86 / 4.74 ms, mesh near-far 0.33 / 0.17 ms, render passes equal -- profiles/r03_experiments.txt section 19)
          "-fno-slp-vectorize"]
 
+# per-source additions: the instruction scheduler LLVM's AMDGPU back end uses for that file (scheduling only -- no arithmetic changes; every kernel stays bit-identical to
+# the oracle, which the GPU tests check).  Measured same-box, profiles/r03_experiments.txt sections 20 - 21:
+#   hash_stencil.hip (table-gradient scatter): max-memory-clause -- the queue fill is a long sequence of LDS record traffic between short arithmetic sections:
+#       1.246 -> 1.188 ms per 4096-ray patch (the same strategy costs the render kernel 7 %, so it is not a global flag);
+#   render_fused.hip: iterative-maxocc -- 0.763 -> 0.752 ms per 4096-ray launch of the instantiation without per-sample outputs (+0.6 % on the training one);
+#   warp.hip: iterative-maxocc -- posed frame 8.21 -> 8.08 ms.
+PER_FILE_FLAGS = {"hash_stencil.hip": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+                  "render_fused.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"],
+                  "warp.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]}
+
 
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
@@ -55,7 +65,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

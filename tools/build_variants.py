@@ -12,18 +12,21 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from avatarcraft_amd.build import SOURCES, FLAGS, CSRC  # noqa: E402
+from avatarcraft_amd.build import SOURCES, FLAGS, CSRC, PER_FILE_FLAGS  # noqa: E402
 
 OUT = os.path.join(ROOT, "tools", "_bin")
 
 
 def build(spec):
     name, _, flags = spec.partition(":")
+    flags, _, only = flags.partition("@")            # name:"flags@file.hip": the flags go to that source file only
     os.makedirs(OUT, exist_ok=True)
     objs = []
+    all_flags = flags
     for src in SOURCES:
+        flags = all_flags if (not only or src == only) else ""
         o = os.path.join(OUT, f"{name}_{src.replace('.hip', '.o')}")
-        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + flags.split() + ["-c", os.path.join(CSRC, src), "-o", o], stdout=subprocess.PIPE,
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + PER_FILE_FLAGS.get(src, []) + flags.split() + ["-c", os.path.join(CSRC, src), "-o", o], stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True)
         if r.returncode:
             return name, r.stdout[-2000:]
