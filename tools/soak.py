@@ -1,0 +1,89 @@
+"""Long repeat-launch soak at the final build: the same inputs, many launches, every output compared with the first launch bit for bit.
+    renders   : bench batch + SDS training view, exact and fast, lean and with every per-sample output (incl. the 7 x 32 stencil features)
+    pair      : ac_render_rays_pair
+    backward  : ac_render_core_backward on fixed saved tensors / upstream gradients (table gradient through the binned scatter, MLP gradients)
+    step      : stylize.sds_step from identical parameters, noise and guidance -> identical parameters after Adam
+python tools/soak.py [scale]   (scale 1.0 ~ 3 minutes on one MI355X)"""
+import sys, os, time, copy
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+import bench
+from avatarcraft_amd import nsr_ops
+from tests.common import make_rays, load_golden, make_table
+from tests.gpu_common import device_field
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+dev = torch.device("cuda:0")
+p = load_golden("nsr_params.npz")
+f, table = device_field(p, device=dev); f.prepare()
+inv_s = float(p["inv_s"])
+t0 = time.time()
+report = []
+
+
+def same(a, b):
+    return all(torch.equal(a[k], b[k]) for k in a)
+
+
+def soak(name, fn, n):
+    first = {k: v.clone() for k, v in fn().items() if isinstance(v, torch.Tensor)}
+    bad = 0
+    for _ in range(n - 1):
+        out = fn()
+        bad += 0 if same(first, out) else 1
+    torch.cuda.synchronize()
+    report.append("%-64s %6d launches, %d differ from the first" % (name, n, bad))
+    print(report[-1], flush=True)
+    return bad
+
+
+views = {"bench batch": tuple(torch.from_numpy(a[:4096].copy()).to(dev) for a in make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)),
+         "sds view": tuple(torch.from_numpy(a).to(dev) for a in bench.sds_view(0))}
+noise = torch.rand((4096, 64), generator=torch.Generator().manual_seed(5)).to(dev)
+total_bad = 0
+for vn, (ro, rd) in views.items():
+    for prec in ("exact", "fast"):
+        total_bad += soak(f"render {vn}, {prec}, lean", lambda: nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, inv_s, noise=noise, precision=prec), int(1500 * scale))
+        total_bad += soak(f"render {vn}, {prec}, all per-sample outputs", lambda: nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, inv_s, noise=noise, precision=prec, extras=True,
+                                                                                                         train_extras=True, debug_indices=True), int(300 * scale))
+ro, rd = views["sds view"]
+n2 = torch.rand((2, 4096, 64), generator=torch.Generator().manual_seed(6)).to(dev)
+
+
+def pair():
+    a, b = nsr_ops.render_rays_pair(f, ro, rd, n2, 64, 64, 1.6, inv_s)
+    return {**{"a_" + k: v for k, v in a.items() if isinstance(v, torch.Tensor)}, **{"b_" + k: v for k, v in b.items() if isinstance(v, torch.Tensor)}}
+
+
+total_bad += soak("pair launch (render_val + training forward), sds view", pair, int(300 * scale))
+# backward on fixed saved tensors
+out = nsr_ops.render_rays(f, ro, rd, 64, 64, 1.6, inv_s, noise=noise, extras=True, train_extras=True)
+g = torch.Generator().manual_seed(9)
+gi = torch.randn((4096, 3), generator=g).clamp(-1, 1).to(dev); gw = (torch.randn(4096, generator=g) * 3).to(dev); ge = torch.tensor(0.01, device=dev)
+
+
+def backward():
+    gt = torch.zeros_like(f.t["table"])
+    a, b, c = nsr_ops.render_core_backward(f, out.opts, out, ro, rd, None, gi, gw, None, None, ge, gt)
+    return {"g_table": gt, "g_sdf": a, "g_col": b, "g_invs": c}
+
+
+total_bad += soak("render-core backward (binned scatter + MLP gradients), 4096 rays", backward, int(150 * scale))
+# whole steps from identical state
+from avatarcraft_amd.stylize import sds_step, flat_grad_view, SyntheticGuidance
+tab = make_table(int(p["offsets"][-1]), seed=int(p["table_seed"]), offsets=p["offsets"], level_amp=p["level_amp"])
+ro_h, rd_h = bench.sds_view(0)
+
+
+def step():
+    net = bench.make_net(p, tab, dev, True); net_gt = bench.make_net(p, tab, dev, False)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3, fused=True)
+    flat = flat_grad_view(net.parameters())
+    torch.manual_seed(11)
+    for _ in range(2):
+        sds_step(net, net_gt, ro, rd, (64, 64), opt, SyntheticGuidance(3), batch_size=4096, flat_grad=flat)
+    return {k: v.detach() for k, v in net.named_parameters()}
+
+
+total_bad += soak("two stylisation steps from identical state (parameters after Adam)", step, int(25 * scale))
+print("total: %d differing repeats; %.0f s" % (total_bad, time.time() - t0))
