@@ -63,11 +63,14 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ fused field handle
     # The prepared ac_field views (ctypes structs holding raw device pointers) and the outputs of the last training render are caches, not state:
     # they are left out of pickling / copy.deepcopy / torch.save(net) and rebuilt on the next render.
-    _CACHE_ATTRS = ("_pair_bg_cache", "_field_cache", "_field_sdf_cache", "_last_train", "_offsets_cache", "_nan_pending")
+    _CACHE_ATTRS = ("_pair_bg_cache", "_field_cache", "_field_sdf_cache", "_last_train", "_offsets_cache")
+    # not picklable (events, pinned words) but NOT a cache either: pending NaN flags survive invalidate_caches() and are resolved by check_finite()
+    _UNPICKLED_ATTRS = _CACHE_ATTRS + ("_nan_pending",)
 
     def __getstate__(self):
+        self.check_finite()             # a NaN recorded by an earlier training render must not vanish into a checkpoint / copy
         state = self.__dict__.copy()
-        for k in self._CACHE_ATTRS:
+        for k in self._UNPICKLED_ATTRS:
             state.pop(k, None)
         return state
 
@@ -94,7 +97,11 @@ class NeRFRenderer(nn.Module):
     # The reference stops a training render on a NaN normal (`assert (gradient == gradient).all()`, instant_nsr.py:274), which costs it a host
     # round trip per render.  Here every training render leaves a one-word "gradient_error is not finite" flag in pinned host memory behind an
     # event; the flags of earlier renders are looked at (never waited for) on the next one, and check_finite() waits for all of them.
-    # A NaN therefore surfaces at most one step late instead of flowing into the optimizer unnoticed.  nan_guard = False switches it off.
+    # The step functions (stylize.sds_step, reconstruct.reconstruct_step) call check_finite() BEFORE optimizer.step(): the event is recorded right
+    # behind the training forward, i.e. it has fired long before the host gets there (the backward is still queued), so a poisoned gradient raises
+    # before Adam's state or the weights are touched -- the reference's order (assert, then backward, then step).  A caller that drives
+    # render() + its own optimizer gets the flag on its next render, on check_finite(), or when the net is pickled / checkpointed / deep-copied.
+    # nan_guard = False switches it off.
     nan_guard = True
 
     def _guard_finite(self, gerr):

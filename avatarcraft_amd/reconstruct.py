@@ -53,6 +53,9 @@ def reconstruct_step(net, optimizer, rays_o, rays_d, rgb_gt, white_bkg=True, w_e
         torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
         if world > 1:
             flat_grad.div_(world)
+    chk = getattr(net, "check_finite", None)
+    if chk is not None:
+        chk()                           # a NaN in this step's normals raises here (reference: the assert at instant_nsr.py:274), not after Adam has consumed it
     optimizer.step()
     return loss.detach()
 

@@ -75,9 +75,12 @@ def _const_scalar(v, device):
 
 
 def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_size=4096, w_eikonal=0.01, use_opacity=True,
-             bkg_key=WHITE_BKG, flat_grad=None, process_group=None, num_steps=64, upsample_steps=64, timers=None, overlap_allreduce=None):
+             bkg_key=WHITE_BKG, flat_grad=None, process_group=None, num_steps=64, upsample_steps=64, timers=None, overlap_allreduce=None,
+             grad_divisor=None):
     """rays_o, rays_d: [h*w, 3] of the (sub-sampled) training view; hw = (h, w).  Returns a dict of scalars.
-    timers: a list that receives (phase name, torch.cuda.Event) marks on the current stream (bench.py's per-phase times)."""
+    timers: a list that receives (phase name, torch.cuda.Event) marks on the current stream (bench.py's per-phase times).
+    grad_divisor: the number of ranks that contribute a view to this step's all-reduce (default: the world size; smaller in the last round of an epoch
+    whose view count is not a multiple of the world size, see shard_views / sds_idle_step)."""
     h, w = hw
     n_rays = h * w
 
@@ -195,14 +198,15 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                     torch.distributed.all_reduce(flat_grad[lo:hi], op=torch.distributed.ReduceOp.SUM, group=process_group)
             work_hi.wait()                                                           # the current stream waits for the early collective
             if world > 1:
-                flat_grad.div_(world)
+                flat_grad.div_(world if grad_divisor is None else int(grad_divisor))
             mark("grad_allreduce")
         else:
             torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
             if world > 1:
-                flat_grad.div_(world)
+                flat_grad.div_(world if grad_divisor is None else int(grad_divisor))
             mark("grad_allreduce")
-    # (D)
+    # (D) -- a NaN recorded by this step's renders raises here, before Adam's state and the weights are touched
+    _check_finite(net_style)
     optimizer.step()
     mark("optimizer")
     mean = lambda v: v[0].reshape(()) if len(v) == 1 else torch.stack([t.reshape(()) for t in v]).mean()      # (one patch: no reduction kernels)
@@ -242,16 +246,25 @@ def stylize_epochs(net_style, net_gt, optimizer, guidance, hw=(256, 256), n_cap=
         perm = torch.randperm(len(poses), generator=gen).tolist()
         stride = subsample_scale if coarse else max(1, subsample_scale // 2)
         assert stride in (1, 2, 4, 8, 16), 'subsample scale must be 1, 2, 4, 8, or 16'
-        for k in shard_views(len(perm), rank, world):
-            i = perm[k]
+        for rnd, k in enumerate(shard_views(len(perm), rank, world)):
+            # (the random draws below are made by every rank for every round, idle or not, so that the host-side streams stay in step across ranks)
+            n_active = views_in_round(len(perm), world, rnd)
             bkg_key = random.randint(WHITE_BKG, NOISE_BKG) if augment_bkg else (WHITE_BKG if white_bkg else BLACK_BKG)
-            text = f"{desc[i]} {tgt_text}" if augment_text else tgt_text
-            ro, rd = cap2rays(pose2cap([H, W], poses[i]), device=device)
-            ro, rd = sparse_ray_sampling(ro.reshape(H, W, 3), rd.reshape(H, W, 3), stride)
-            h, w = ro.shape[0], ro.shape[1]
-            g = (lambda rgb, _t=text: guidance(rgb, text=_t)) if _accepts_text(guidance) else guidance
-            stats = sds_step(net_style, net_gt, ro.reshape(-1, 3).float().contiguous(), rd.reshape(-1, 3).float().contiguous(), (h, w), optimizer, g,
-                             batch_size=batch_size, w_eikonal=w_eikonal, use_opacity=use_opacity, bkg_key=bkg_key, flat_grad=flat_grad)
+            if k is None:
+                # the epoch's view count is not a multiple of the world size and this rank has no view in the last round (the reference's epoch is every
+                # view once, stylize.py:76-78: nothing is dropped, nothing is visited twice): zero gradient into the same collective
+                stats = sds_idle_step(net_style, optimizer, flat_grad, n_active)
+            else:
+                i = perm[k]
+                text = f"{desc[i]} {tgt_text}" if augment_text else tgt_text
+                ro, rd = cap2rays(pose2cap([H, W], poses[i]), device=device)
+                ro, rd = sparse_ray_sampling(ro.reshape(H, W, 3), rd.reshape(H, W, 3), stride)
+                h, w = ro.shape[0], ro.shape[1]
+                g = (lambda rgb, _t=text: guidance(rgb, text=_t)) if _accepts_text(guidance) else guidance
+                short = n_active < world
+                stats = sds_step(net_style, net_gt, ro.reshape(-1, 3).float().contiguous(), rd.reshape(-1, 3).float().contiguous(), (h, w), optimizer, g,
+                                 batch_size=batch_size, w_eikonal=w_eikonal, use_opacity=use_opacity, bkg_key=bkg_key, flat_grad=flat_grad,
+                                 grad_divisor=n_active if short else None, overlap_allreduce=False if short else None)
             if on_step is not None:
                 on_step(step, epoch, stats)
             step += 1
@@ -267,6 +280,35 @@ def _accepts_text(guidance):
 
 
 def shard_views(n_views, rank, world):
-    """view indices handled by `rank` in one epoch: round-robin, every rank the same count (drop the remainder)"""
-    per = n_views // world
-    return [rank + world * k for k in range(per)]
+    """Positions of one epoch's view permutation handled by `rank`: round-robin over ceil(n_views / world) ROUNDS, every rank the same number of
+    rounds (the all-reduce of a step is a collective: all ranks take part in every round).  The reference's epoch visits every view exactly once
+    (stylize.py:76-78); when n_views is not a multiple of world the LAST round has fewer views than ranks and the ranks without one get None --
+    they join that round's collective with a zero gradient (sds_idle_step) and the average is taken over the views that exist."""
+    rounds = -(-n_views // world)
+    return [(rank + world * k if rank + world * k < n_views else None) for k in range(rounds)]
+
+
+def views_in_round(n_views, world, k):
+    """number of ranks that hold a view in round k of shard_views (the divisor of that round's gradient average)"""
+    return max(0, min(world, n_views - world * k))
+
+
+def sds_idle_step(net_style, optimizer, flat_grad, n_active, process_group=None):
+    """The step of a rank that holds no view in the last round of an epoch: a zero gradient into the same collective(s) the working ranks issue,
+    the same divisor, the same optimizer step -- parameters stay replicated bit for bit."""
+    if flat_grad is None:
+        raise RuntimeError("data-parallel sds_idle_step needs flat_grad = flat_grad_view(net_style.parameters())")
+    flat_grad.zero_()
+    torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
+    flat_grad.div_(max(1, int(n_active)))
+    _check_finite(net_style)
+    optimizer.step()
+    return {"eikonal": torch.zeros(()), "opacity": torch.zeros(()), "idle": True}
+
+
+def _check_finite(net):
+    """the reference asserts on a NaN gradient_error before its backward (instant_nsr.py:274); the fused path records a device flag instead, and it is
+    resolved HERE -- before the optimizer step consumes the gradients -- at the cost of one 4-byte event wait"""
+    chk = getattr(net, "check_finite", None)
+    if chk is not None:
+        chk()

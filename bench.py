@@ -39,10 +39,15 @@ FLOP_PER_RAY = 1008 * 6528 + 128 * 11264
 HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def oracle_field(p, table):
+    """the CPU oracle's view of the same field (cpu_baseline legs only)"""
+    from oracle import oracle as O
+    return O.Field(table, p["offsets"], p["W1"], p["b1"], p["W2"], p["b2"], p["Wc1"], p["Wc2"], p["Wc3"], float(p["per_level_scale"]))
+
+
 def make_inputs(device, rank):
-    from tests.common import load_golden, make_rays
-    from tests.gpu_common import device_field
-    p = load_golden("nsr_params.npz")
+    from avatarcraft_amd.synthetic import load_field_params, make_rays, device_field
+    p = load_field_params()
     field, table = device_field(p, device=device)
     # camera on the 360-degree path of render_canonical.py (dist 1.7, f = 0.78125*256 = 200), one view per rank
     yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
@@ -53,7 +58,6 @@ def make_inputs(device, rank):
 def cpu_baseline(p, table, ro, rd, budget_s=12.0):
     """time the CPU oracle on a bounded, strided sample of the same rays"""
     from oracle import oracle as O
-    from tests.gpu_common import oracle_field
     of = oracle_field(p, table)
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
@@ -63,7 +67,7 @@ def cpu_baseline(p, table, ro, rd, budget_s=12.0):
     n = (n // 64) * 64
     idx = np.arange(0, ro.shape[0], max(1, ro.shape[0] // n))[:n]
     t0 = time.time(); O.render_rays(of, ro[idx], rd[idx], NUM_STEPS, UPSAMPLE_STEPS, 1.6, float(p["inv_s"]), extras=False); dt = time.time() - t0
-    return dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
+    return dict(value=n / dt, unit="rays/s", cores=cores, threads=int(os.environ.get("OMP_NUM_THREADS", cores)), kind="port",
                 sample=f"{n} rays (every {max(1, ro.shape[0] // n)}-th ray of the 256x256 view), 64+64 samples, {dt:.1f} s wall, OpenMP over rays",
                 note="the C restatement of the reference's algorithm (oracle/), OpenMP over rays on every host core: faster than the reference's own "
                      "torch-CPU path would be; a reported baseline, not the target")
@@ -96,7 +100,7 @@ def make_net(p, table, dev, train):
 
 def sds_view(rank):
     """the 64x64 stride-4 sub-sampled rays of a 256x256 training camera (stylize.py:98-107), one view per rank"""
-    from tests.common import make_rays
+    from avatarcraft_amd.synthetic import make_rays
     yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
     ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=yaw, pitch=0.0)
     return ro.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy(), rd.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy()
@@ -159,7 +163,6 @@ def cpu_baseline_sds(p, table, n_side=16, threads=None):
     passes folded into one like the GPU path.  kind = "port"."""
     import torch.nn as nn
     from oracle import oracle as O
-    from tests.gpu_common import oracle_field
     from avatarcraft_amd.instant_nsr import NeRFNetwork
     # threads: this leg is many medium-sized torch ops and a hash backward that is parallel over its 16 levels only; on a 256-core host the
     # full thread count is SLOWER than 32 (51 s per 256-ray step against a few seconds), so the leg runs on min(cores, 32) threads and says so
@@ -230,7 +233,9 @@ def cpu_baseline_sds(p, table, n_side=16, threads=None):
     while reps < 1 or (time.time() - t0 < 8.0 and reps < 8):
         step(); reps += 1
     dt = (time.time() - t0) / reps
-    return dict(value=n / dt, unit="rays/s (SDS steps)", ms_per_4096_ray_step_equivalent=dt * 1e3 * 4096 / n, cores=cores, kind="port",
+    return dict(value=n / dt, unit="rays/s (SDS steps)", ms_per_4096_ray_step_equivalent=dt * 1e3 * 4096 / n, cores=os.cpu_count() or 1, threads=cores,
+                threads_note="min(host cores, 32): this leg is many medium-sized torch ops and a hash backward parallel over its 16 levels only; on a 256-core "
+                             "host the full thread count is slower (51 s per 256-ray step)", kind="port",
                 sample=f"{reps} step(s) of {n} rays (every {4096 // n}-th ray of the 4096-ray training view), 64+64 samples, {dt:.2f} s each: C oracle (OpenMP) "
                        f"for the two no-grad renders and the sampling stage, torch-CPU autograd ({torch.get_num_threads()} threads) over the oracle's hash "
                        f"forward/backward for the render core, torch Adam on 12.2 M parameters")
@@ -242,7 +247,7 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     and its culling structure rebuilt once per frame.  The reference does the two warps of every batch on the CPU (libigl).
     roofline: SURVEY 8(d)'s 507 904 gather bytes per ray (496 hash evaluations) x 65 536 rays / frame time."""
     from avatarcraft_amd.render_utils import render_instantnsr_naive
-    from tests.common import make_rays, make_body
+    from avatarcraft_amd.synthetic import make_rays, make_body
     net = make_net(p, table, dev, False)
     net.skip_masked_samples = True          # what drivers.render_animation sets: masked-out tiles (alpha * 0) are not evaluated; pixels bit-identical
     verts, faces, Ts = make_body(n_lat=83, n_lon=83)
@@ -278,7 +283,6 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
            "searches_per_s": 65536 * (32 + 64) / dt}
     if cpu:
         from oracle import oracle as O
-        from tests.gpu_common import oracle_field
         of = oracle_field(p, table)
         idx = np.arange(0, 65536, 65536 // 48)[:48]
         t0 = time.time()
@@ -299,6 +303,52 @@ def _flush_c_stdio():
         pass
 
 
+def _free_port():
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    return port
+
+
+def self_launch(n, argv, script=None):
+    """`python bench.py --gpus N` without torch.distributed.run: start N ranks of this script (one per visible GPU, rendezvous on 127.0.0.1 at a free
+    port), rank 0's stdout is this process's stdout (its JSON line stays the last thing written there), the other ranks' stdout goes to stderr.
+    Returns the exit code: 0 only if every rank exited 0; a rank that dies takes the others down with it (exact PIDs, after a grace period) instead of
+    leaving them in a collective forever."""
+    import subprocess
+    backend = os.environ.get("AC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        print("bench.py needs an MI355X (torch.cuda.is_available() is False); the hot path has no CPU fallback", file=sys.stderr)
+        return 1
+    if ndev < n and backend == "nccl":
+        print(f"bench.py --gpus {n}: only {ndev} GPU(s) visible; RCCL needs one device per rank (AC_DIST_BACKEND=gloo runs the N > 1 code path with "
+              f"ranks sharing a device -- a plumbing check, not a measurement)", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   AC_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    rc, dead_since = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and dead_since is None:
+            dead_since = time.time()
+        if dead_since is not None and time.time() - dead_since > float(os.environ.get("AC_BENCH_GRACE_S", "20")):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            print(f"bench.py: rank {r} exited with {p.returncode}", file=sys.stderr)
+            rc = rc or (p.returncode if p.returncode and p.returncode > 0 else 1)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,25 +365,38 @@ def main():
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own (the form the driver uses for N = 1): this process becomes the launcher of N ranks of itself
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); the hot path has no CPU fallback")
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    dev_index = local_rank % torch.cuda.device_count()        # one rank per GPU; more ranks than GPUs only in the gloo smoke test below
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N spawns them itself; or "
+                         f"python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
+    backend = os.environ.get("AC_DIST_BACKEND", "nccl")         # "nccl" is RCCL on ROCm; "gloo" lets the N > 1 path be exercised on a 1-GPU box
+    if world > torch.cuda.device_count() and backend == "nccl":
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} visible GPU(s): RCCL needs one device per rank "
+                         f"(AC_DIST_BACKEND=gloo runs the N > 1 code path with ranks sharing a device -- a plumbing check, not a measurement)")
+    dev_index = local_rank % torch.cuda.device_count()        # one rank per GPU; more ranks than GPUs only in the gloo plumbing check
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    rccl_ranks = None
     if world > 1 or os.environ.get("AC_BENCH_FORCE_DIST") == "1":      # (forced at world size 1: the RCCL code path of an N > 1 run on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("AC_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" lets the N > 1 path be exercised on a 1-GPU box
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # an actual collective before anything is timed: the number of ranks that took part in it is what the line reports
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        rccl_ranks = int(round(float(one.item())))
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
     from avatarcraft_amd import nsr_ops
     p, field, table, ro, rd = make_inputs(dev, rank)
@@ -435,6 +498,8 @@ def main():
             "ms_per_step_spread": round((max(r[0] for r in regions) - min(r[0] for r in regions)) / a.steps * 1e3, 4),
             "ms_per_step_rank_min_max": [round(dt_rank_min / a.steps * 1e3, 4), round(dt / a.steps * 1e3, 4)],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "launcher": os.environ.get("AC_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
+            "dist_backend": (backend if dist is not None else None), "rccl_ranks": rccl_ranks,
             "config": {"workload": "render_canonical 256x256, hash-grid Instant-NSR, 64+64 samples/ray, 16 x 4096-ray batches, eval, 1 view per rank",
                        "rays_per_step": RAYS_PER_BATCH, "table_mb": round(table.nbytes / 1e6, 2), "parallelism": f"dp{world} (independent views, no collective)",
                        "precision": a.precision,

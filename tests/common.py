@@ -4,53 +4,10 @@ bit-identically, so large arrays (the 49 MB hash table) never have to be committ
 import os
 import numpy as np
 
-TABLE_SEED = 20260926
-N_TABLE_DEFAULT = 6119857            # sum of the 16 level sizes of the default model
+# the generators themselves live in the package (bench.py and smoke() use them too, and must not import the test package)
+from avatarcraft_amd.synthetic import TABLE_SEED, N_TABLE_DEFAULT, make_table, smooth_level_amp, make_rays, make_body   # noqa: F401
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-
-
-def make_table(n_entries=N_TABLE_DEFAULT, level_dim=2, seed=TABLE_SEED, amp=0.5, offsets=None, level_amp=None):
-    """embeddings ~ U(-amp, amp), float32, from the frozen numpy RandomState stream.
-    With offsets + level_amp the amplitude is per level ("smooth" field: fine levels carry little
-    energy, like a trained avatar; the SDF then has |grad| ~ 1 instead of ~5)."""
-    rs = np.random.RandomState(seed)
-    t = rs.uniform(-1.0, 1.0, size=(n_entries, level_dim))
-    if level_amp is not None:
-        a = np.repeat(np.asarray(level_amp, np.float64), np.diff(np.asarray(offsets, np.int64)))
-        t = t * a[:, None]
-    else:
-        t = t * amp
-    return t.astype(np.float32)
-
-
-def smooth_level_amp(scale):
-    """per-level table amplitude 3/scale_l (level 0: 0.2 ... level 15: 0.0015)"""
-    return 3.0 / np.asarray(scale, np.float64)
-
-
-def make_rays(h, w, dist=1.7, f=None, jitter_seed=None, yaw=0.35, pitch=-0.2):
-    """Pinhole rays: camera on a sphere of radius `dist` (yaw/pitch in rad) looking at the origin.
-    Returns (rays_o[h*w,3], rays_d[h*w,3]) float32, d normalised."""
-    f = f if f is not None else 0.78125 * w
-    jj, ii = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64), indexing="xy")
-    px = (jj + 0.5 - w / 2) / f
-    py = -(ii + 0.5 - h / 2) / f
-    if jitter_seed is not None:
-        rs = np.random.RandomState(jitter_seed)
-        px = px + rs.uniform(-0.3, 0.3, px.shape) / f
-        py = py + rs.uniform(-0.3, 0.3, py.shape) / f
-    d_cam = np.stack([px, py, -np.ones_like(px)], -1).reshape(-1, 3)
-    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
-    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
-    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
-    R = Ry @ Rx
-    d = d_cam @ R.T
-    d = d / np.linalg.norm(d, axis=1, keepdims=True)
-    o = np.tile((R @ np.array([0, 0, dist]))[None], (d.shape[0], 1))
-    o = o.astype(np.float32); d = d.astype(np.float32)
-    # one axis-aligned ray exercises the (d + 1e-15) path of near_far_from_bound
-    o[0] = [0, 0, dist]; d[0] = [0, 0, -1]
-    return o, d
 
 
 def load_golden(name):
@@ -63,41 +20,6 @@ def oracle_field_from_golden(params=None):
     table = make_table(int(p["offsets"][-1]), seed=int(p["table_seed"]), offsets=p["offsets"], level_amp=p["level_amp"])
     return O.Field(table, p["offsets"], p["W1"], p["b1"], p["W2"], p["b2"], p["Wc1"], p["Wc2"], p["Wc3"],
                    float(p["per_level_scale"]))
-
-
-def make_body(n_lat=40, n_lon=80, seed=3):
-    """Synthetic SMPL-like body for the warp tests: a closed capsule mesh (UV sphere stretched along y, scaled to the
-    avatar's size), per-vertex rigid-ish 4x4 transforms (float64, smooth in space, like blended LBS matrices).
-    Returns verts[V,3] f32, faces[F,3] i32, Ts[V,4,4] f64."""
-    th = np.linspace(0, np.pi, n_lat + 2)[1:-1]
-    ph = np.linspace(0, 2 * np.pi, n_lon, endpoint=False)
-    v = [[0, 1, 0]]
-    for t in th:
-        for p_ in ph:
-            v.append([np.sin(t) * np.cos(p_), np.cos(t), np.sin(t) * np.sin(p_)])
-    v.append([0, -1, 0])
-    v = np.array(v) * np.array([0.28, 0.85, 0.2])
-    f = []
-    for j in range(n_lon):
-        f.append([0, 1 + (j + 1) % n_lon, 1 + j])
-    for i in range(n_lat - 1):
-        for j in range(n_lon):
-            a = 1 + i * n_lon + j; b = 1 + i * n_lon + (j + 1) % n_lon; c = a + n_lon; d = b + n_lon
-            f.append([a, b, d]); f.append([a, d, c])
-    last = len(v) - 1
-    for j in range(n_lon):
-        a = 1 + (n_lat - 1) * n_lon + j; b = 1 + (n_lat - 1) * n_lon + (j + 1) % n_lon
-        f.append([a, b, last])
-    verts = v.astype(np.float32)
-    faces = np.array(f, dtype=np.int32)
-    rs = np.random.RandomState(seed)
-    # smooth transform field: rotation about z by an angle that varies with height + small translation, scaled by 1/0.9
-    ang = 0.35 * np.sin(2.0 * verts[:, 1].astype(np.float64)) + 0.05 * rs.normal(size=verts.shape[0])
-    Ts = np.tile(np.eye(4)[None], (verts.shape[0], 1, 1))
-    Ts[:, 0, 0] = np.cos(ang); Ts[:, 0, 1] = -np.sin(ang); Ts[:, 1, 0] = np.sin(ang); Ts[:, 1, 1] = np.cos(ang)
-    Ts[:, :3, 3] = 0.03 * rs.normal(size=(verts.shape[0], 3))
-    Ts = Ts @ (np.eye(4) / 0.9)
-    return verts, faces, Ts
 
 
 def edge_case_rays():

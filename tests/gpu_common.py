@@ -5,17 +5,7 @@ import torch
 from tests.common import load_golden, make_table
 
 
-def device_field(params=None, device="cuda:0", rough=False):
-    from avatarcraft_amd import nsr_ops
-    p = params if params is not None else load_golden("nsr_params.npz")
-    if rough:
-        table = make_table(int(p["offsets"][-1]), seed=int(p["table_seed"]) + 1, amp=0.5)
-    else:
-        table = make_table(int(p["offsets"][-1]), seed=int(p["table_seed"]), offsets=p["offsets"], level_amp=p["level_amp"])
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
-    f = nsr_ops.Field(t(table), p["offsets"], float(p["per_level_scale"]), 16, t(p["W1"]), t(p["b1"]), t(p["W2"]), t(p["b2"]),
-                      t(p["Wc1"]), t(p["Wc2"]), t(p["Wc3"]))
-    return f, table
+from avatarcraft_amd.synthetic import device_field            # noqa: E402,F401  (shared with bench.py / smoke())
 
 
 def oracle_field(params, table):

@@ -90,10 +90,20 @@ def test_single_rank_equals_manual_average():
         off += p.numel()
     (net.l2(torch.tanh(net.l1(torch.ones(3, 6)))).sum()).backward()
     assert float(flat.abs().sum()) > 0 and net.l1.weight.grad.data_ptr() == flat.data_ptr()
-    assert shard_views(10, 1, 4) == [1, 5] and shard_views(100, 7, 8) == [7 + 8 * k for k in range(12)]
+    # every view of an epoch exactly once (the reference's epoch, stylize.py:76-78); ranks without a view in the last round get None
+    assert shard_views(10, 1, 4) == [1, 5, 9] and shard_views(10, 2, 4) == [2, 6, None]
+    assert shard_views(100, 7, 8) == [7 + 8 * k for k in range(12)] + [None] and shard_views(100, 3, 8) == [3 + 8 * k for k in range(13)]
+    assert shard_views(8, 0, 1) == list(range(8))
+    from avatarcraft_amd.stylize import views_in_round
+    for n, w in ((100, 8), (150, 8), (10, 4), (8, 2), (7, 1)):
+        got = sorted(k for r in range(w) for k in shard_views(n, r, w) if k is not None)
+        assert got == list(range(n))
+        rounds = len(shard_views(n, 0, w))
+        assert all(len(shard_views(n, r, w)) == rounds for r in range(w))
+        assert [views_in_round(n, w, k) for k in range(rounds)] == [sum(shard_views(n, r, w)[k] is not None for r in range(w)) for k in range(rounds)]
 
 
-def _loop_worker(rank, world, port, q):
+def _loop_worker(rank, world, port, q, n_cap=8):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from avatarcraft_amd.stylize import stylize_epochs, flat_grad_view, SyntheticGuidance
@@ -109,7 +119,7 @@ def _loop_worker(rank, world, port, q):
         def __call__(self, rgb, text=None):
             seen.append((tuple(rgb.shape), text))
             return super().__call__(rgb, text)
-    steps = stylize_epochs(net, net_gt, opt, G(1 + rank), hw=(16, 16), n_cap=8, coarse_epochs=1, fine_epochs=1, subsample_scale=4, augment_cam=True,
+    steps = stylize_epochs(net, net_gt, opt, G(1 + rank), hw=(16, 16), n_cap=n_cap, coarse_epochs=1, fine_epochs=1, subsample_scale=4, augment_cam=True,
                            stylize_head=True, coarse_head=0.5, fine_head=0.5, augment_bkg=True, augment_text=True, tgt_text="Hulk", batch_size=8,
                            device="cpu", flat_grad=flat)
     q.put((rank, steps, seen, [p.detach().numpy().copy() for p in net.parameters()]))
@@ -138,3 +148,24 @@ def test_stylize_outer_loop_two_ranks_gloo():
     assert shapes[:6] == [(1, 3, 4, 4)] * 6 and shapes[6:] == [(1, 3, 8, 8)] * 6          # fine stage: half the stride
     texts = {t for _, t in seen0 + seen1}
     assert all(t.endswith(" Hulk") for t in texts) and any("face" in t for t in texts) and any("body" in t for t in texts)
+
+
+def test_stylize_outer_loop_uneven_views_two_ranks_gloo():
+    """an epoch whose view count is not a multiple of the world size: 7 views (body + head close-ups of style_360_path(6)) on 2 ranks = 4 rounds, the last with one view; the rank
+    without a view joins the collective with a zero gradient, nothing is dropped, parameters stay replicated"""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, q, 6)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, seen0, p0), (r1, s1, seen1, p1) = res
+    assert s0 == s1 == 2 * 4                                   # optimizer steps: every rank takes part in every round
+    assert len(seen0) == 2 * 4 and len(seen1) == 2 * 3         # guidance calls = views actually rendered: 7 per epoch in total
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
