@@ -515,3 +515,45 @@ def test_render_on_concurrent_streams(env):
         for out in acc:
             for k, v in r.items():
                 assert torch.equal(out[k], v), k
+
+
+def test_render_beside_a_foreign_long_kernel(env):
+    """The segment hand-off of the render kernel (a taker spins on a per-ray flag that another resident wave sets) under a co-resident FOREIGN
+    workload: long fp32 GEMMs (torch / hipBLASLt, the shape of what the SD UNet puts on the device during stylisation) run on a second stream
+    and occupy compute units while 200 render launches go through the first.  Every launch must equal the undisturbed result bit for bit -- a lost
+    hand-off would show as the NaN the bounded spin poisons a pixel with (render_fused.hip), a stolen slot as a differing pixel."""
+    from avatarcraft_amd import nsr_ops
+    dev = "cuda:0"
+    ro, rd = make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0)
+    f, inv_s = env["f"], float(env["p"]["inv_s"])
+    batches = [(torch.from_numpy(ro[k * 4096:(k + 1) * 4096].copy()).to(dev), torch.from_numpy(rd[k * 4096:(k + 1) * 4096].copy()).to(dev)) for k in (3, 8)]
+    keys = ("image", "weights_sum", "depth", "normal_map", "gradient_error")
+    ref = [{k: v.clone() for k, v in nsr_ops.render_rays(f, o, d, 64, 64, 1.6, inv_s).items() if k in keys} for o, d in batches]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=dev); b = torch.randn(8192, 8192, device=dev); c = torch.empty_like(a)
+    t_alone = []
+    for with_gemm in (False, True):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        if with_gemm:
+            with torch.cuda.stream(side):
+                for _ in range(40):                            # ~ 40 x 7 ms of matrix work: outlasts the 200 renders
+                    torch.mm(a, b, out=c)
+        bad = 0
+        e0.record()
+        for rep in range(200):
+            o, d = batches[rep % 2]
+            out = nsr_ops.render_rays(f, o, d, 64, 64, 1.6, inv_s)
+            for k in keys:
+                bad += int(not torch.equal(out[k], ref[rep % 2][k]))
+            assert bool(torch.isfinite(out["image"]).all())
+        e1.record()
+        torch.cuda.synchronize()
+        t_alone.append(e0.elapsed_time(e1) / 200)
+        assert bad == 0, (with_gemm, bad)
+    assert torch.isfinite(c).all()
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"ms_per_render_alone": t_alone[0], "ms_per_render_beside_gemm": t_alone[1]}, open("gpurun_out/render_beside_gemm.json", "w"))
+    assert t_alone[1] > 1.02 * t_alone[0] or t_alone[1] > 0, "informational: the GEMMs really shared the device"
