@@ -154,3 +154,29 @@ class SDSGuidance:
         with torch.enable_grad():
             self.sd.mannual_backward(self._emb[text], img, self.scale)
         return img.grad.clone().detach()
+
+
+def real_sd_probe(version="1.5"):
+    """(available, reason): can StableDiffusion(device, version) load the REAL pretrained networks on this machine without a network?  Needs
+    `diffusers`, `transformers` and the four sub-models of the checkpoint in the local Hugging Face cache (models/diffusion.py:45-69 downloads them
+    with from_pretrained; this image has no egress).  bench.py --real-sd and tests/test_gpu_stylize.py record the outcome either way."""
+    key = {"1.5": "runwayml/stable-diffusion-v1-5", "2.0": "stabilityai/stable-diffusion-2-depth"}.get(version)
+    if key is None:
+        return False, f"unknown sd_version {version!r}"
+    missing = []
+    for mod in ("diffusers", "transformers"):
+        try:
+            __import__(mod)
+        except Exception as e:                                   # noqa: BLE001
+            missing.append(f"{mod} not importable ({type(e).__name__})")
+    if missing:
+        return False, "; ".join(missing)
+    try:
+        from huggingface_hub import try_to_load_from_cache
+        need = {"vae": "config.json", "unet": "config.json", "text_encoder": "config.json", "tokenizer": "vocab.json"}
+        absent = [sub for sub, fn in need.items() if not isinstance(try_to_load_from_cache(key, f"{sub}/{fn}"), str)]
+        if absent:
+            return False, f"{key} not in the local Hugging Face cache (missing: {', '.join(absent)}); no network"
+    except Exception as e:                                       # noqa: BLE001
+        return False, f"huggingface_hub cache lookup failed ({type(e).__name__}: {e})"
+    return True, key

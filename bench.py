@@ -293,6 +293,38 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     return res
 
 
+def time_real_sd_step(dev, p, table, steps=3):
+    """`--real-sd`: one stylisation step with the REAL Stable-Diffusion guidance (models/diffusion.py:28-69,92-149 -- VAE encoder with grad, UNet on a
+    batch of two 64 x 64 latents, classifier-free guidance 100) when diffusers + transformers + the runwayml/stable-diffusion-v1-5 weights are on
+    this machine; otherwise the reason they are not.  Either outcome is evidence: the SD UNet has never run in this build's environment."""
+    from avatarcraft_amd.guidance import real_sd_probe
+    ok, why = real_sd_probe("1.5")
+    if not ok:
+        return f"absent: {why}"
+    from avatarcraft_amd.guidance import StableDiffusion, SDSGuidance
+    from avatarcraft_amd.stylize import sds_step, flat_grad_view
+    net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3, fused=True)
+    flat = flat_grad_view(net.parameters())
+    guide = SDSGuidance(StableDiffusion(dev, "1.5"), "Hulk, photorealistic style", 100.0)
+    ro, rd = sds_view(0)
+    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
+    torch.cuda.synchronize()
+    marks = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat, timers=marks)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    phases = {}
+    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+        if n1 != "start":
+            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
+    return {"ms_per_step": ms, "guidance_ms": phases.get("guidance"), "render_and_backward_ms": ms - phases.get("guidance", 0.0), "steps": steps,
+            "model": why, "dtype": "f32 (the reference loads the pipelines without a dtype)", "phase_ms": {k: round(v, 3) for k, v in phases.items()}}
+
+
 def _flush_c_stdio():
     """RCCL printf()s a version banner when the first communicator is created; with stdout a pipe or a file it sits in C stdio's buffer until exit,
     i.e. it would land AFTER a line printed from Python"""
@@ -362,6 +394,8 @@ def main():
                          "positions bit-identical, pixels within 2e-4 of exact)")
     ap.add_argument("--repeat", type=int, default=5, help="number of timed regions of --steps steps each; the headline is the MEDIAN region (all of them are listed)")
     ap.add_argument("--sds-steps", type=int, default=8, help="also time this many 4096-ray SDS steps (secondary metric); 0 = skip")
+    ap.add_argument("--real-sd", action="store_true", help="time one SDS step with the real Stable-Diffusion guidance if diffusers + the weights are on this "
+                                                           "machine (the line's real_sd field says why not otherwise; the probe itself always runs)")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
 
@@ -533,6 +567,13 @@ def main():
                 res["posed_frame"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, table, ro, rd)
+        try:
+            from avatarcraft_amd.guidance import real_sd_probe
+            ok_sd, why_sd = real_sd_probe("1.5")
+            res["real_sd"] = (time_real_sd_step(dev, p, table) if (ok_sd and a.real_sd) else
+                              (f"available ({why_sd}); pass --real-sd to time it" if ok_sd else f"absent: {why_sd}"))
+        except Exception as e:                 # noqa: BLE001
+            res["real_sd"] = f"error: {type(e).__name__}: {e}"
         if world > 1 and sds is not None and "error" not in sds:
             res["sds_step"]["note"] = "N > 1: one view per rank, one all-reduce (RCCL, sum then / world) of the flat 49 MB gradient per step"
         line = json.dumps(res)
