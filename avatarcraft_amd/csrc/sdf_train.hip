@@ -467,6 +467,63 @@ __global__ __launch_bounds__(TBLOCK) void color_fwd_kernel(const RenderArgs a, c
     }
 }
 
+// ---- field evaluation on PACKED samples: what stands between the occupancy-grid marcher and the packed compositor (run_cuda) -------------------
+// One tile = 16 samples of whatever rays (the marcher lays a ray's samples out consecutively): the same stencil gather, the same seven SDF MLP
+// passes, the same colour tile and the same NeuS alpha arithmetic as the final pass of render_rays_kernel (render_fused.hip) -- a sample gets the
+// bits here that it would get there for the same point, direction and section length.
+struct SampleArgs {
+    const float *xyzs, *dirs, *deltas;          // [M,3] [M,3] [M * dstride] (march_rays_train: dstride 1; march_rays: dstride 2, column 0 = the step)
+    uint32_t dstride, M;
+    float *alpha, *rgb, *normal;                // [M] [M,3] [M,3]
+    float *sdf, *gradient;                      // optional [M] [M,3] (the raw finite-difference gradient: eikonal term)
+};
+
+__global__ __launch_bounds__(FBLOCK) void field_samples_kernel(const RenderArgs a, const SampleArgs s)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
+    const FieldCtx fc = make_ctx(a);
+    const float inv_s = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;
+    const float bound = a.bound, eps = a.eps;
+    const uint32_t ntiles = (s.M + 15) / 16;
+    for (uint32_t tile = blockIdx.x * FW + wave; tile < ntiles; tile += gridDim.x * FW) {
+        const uint32_t b = tile * 16 + n, bb = b < s.M ? b : s.M - 1;
+        const float px = clampf(s.xyzs[3 * (size_t)bb], -bound, bound), py = clampf(s.xyzs[3 * (size_t)bb + 1], -bound, bound),
+                    pz = clampf(s.xyzs[3 * (size_t)bb + 2], -bound, bound);                                          // new_pts.clamp(-bound, bound)
+        const float dx = s.dirs[3 * (size_t)bb], dy = s.dirs[3 * (size_t)bb + 1], dz = s.dirs[3 * (size_t)bb + 2];
+        const float delta = s.deltas[(size_t)bb * s.dstride];
+        float fe0[4][2];
+        encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
+        f32x4 oc; float gr[3];
+        fd_forward(lds, fsl, lane, px, py, pz, eps, bound, fe0, oc, gr);
+        const float gx = gr[0], gy = gr[1], gz = gr[2];
+        const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+        const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
+        float rgb[3];
+        color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+        // NeuS alpha, instant_nsr.py:219-243 with the marcher's step as the section length
+        const float sdf0 = oc[0];
+        const float tc = (dx * nx + dy * ny) + dz * nz;
+        const float a1 = dv_softplus100(lds + OFF_SPQ, -tc * 0.5f + 0.5f) * a.one_m_car;
+        const float a2 = dv_softplus100(lds + OFF_SPQ, -tc) * a.car;
+        const float iter_cos = -(a1 + a2);
+        const float half = iter_cos * delta * 0.5f;
+        const float pc = dv_sigmoid((sdf0 - half) * inv_s), nc = dv_sigmoid((sdf0 + half) * inv_s);
+        const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+        if (b < s.M && g == 0) {
+            s.alpha[b] = alpha;
+            s.rgb[3 * (size_t)b] = rgb[0]; s.rgb[3 * (size_t)b + 1] = rgb[1]; s.rgb[3 * (size_t)b + 2] = rgb[2];
+            s.normal[3 * (size_t)b] = nx; s.normal[3 * (size_t)b + 1] = ny; s.normal[3 * (size_t)b + 2] = nz;
+            if (s.sdf) s.sdf[b] = sdf0;
+            if (s.gradient) { s.gradient[3 * (size_t)b] = gx; s.gradient[3 * (size_t)b + 1] = gy; s.gradient[3 * (size_t)b + 2] = gz; }
+        }
+        wave_sync();
+    }
+}
+
 __device__ __forceinline__ void fill_lds_color_bwd(float *lds, const RenderArgs &a)
 {
     for (int e = threadIdx.x; e < 4 * 64; e += blockDim.x) {        // fragment to: lane (m, kk) = Wc3[o = kk][unit = 16 to + m]
@@ -935,6 +992,28 @@ AC_API int ac_sdf_stencil_forward(const ac_field *field, const float *x, uint32_
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(sdf_stencil_fwd_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, x, B, eps, out16, grad);
     return ac::check_launch("sdf_stencil_forward");
+}
+
+AC_API int ac_field_samples(const ac_field *field, const float *xyzs, const float *dirs, const float *deltas, uint32_t delta_stride, uint32_t M,
+                            float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio, float *alpha, float *rgb, float *normal,
+                            float *sdf, float *gradient, ac_stream_t stream)
+{
+    if (M == 0) return AC_OK;
+    if (!xyzs || !dirs || !deltas || !alpha || !rgb || !normal || delta_stride == 0 || !(eps > 0.0f)) {
+        ac::set_error("field_samples: NULL buffer, delta_stride == 0 or eps <= 0"); return AC_ERR_BAD_ARG;
+    }
+    RenderArgs a{};
+    if (int rc = prep_args(a, field, bound, eps)) return rc;
+    a.inv_s = inv_s; a.inv_s_dev = inv_s_dev; a.car = cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)cos_anneal_ratio);
+    SampleArgs sa{ xyzs, dirs, deltas, delta_stride, M, alpha, rgb, normal, sdf, gradient };
+    const size_t lds_bytes = FWD_LDS_FLOATS * sizeof(float);
+    static uint64_t seen = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(field_samples_kernel), lds_bytes);
+    uint32_t blocks = ((M + 15) / 16 + FW - 1) / FW;              // persistent, one workgroup per CU (140 KB of LDS), like the SDF query
+    const uint32_t cus = ac::cu_count();
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(field_samples_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, sa);
+    return ac::check_launch("field_samples");
 }
 
 AC_API size_t ac_sdf_stencil_backward_scratch(uint32_t B)

@@ -436,6 +436,114 @@ class NeRFRenderer(nn.Module):
         image = image + (1 - weights_sum) * bg_color
         return depth.reshape(B, N), weights, weights_sum, image.reshape(B, N, 3), normal_map, gradient_error, curvature_error, color, alpha, z_vals
 
+    # ------------------------------------------------------------------ occupancy-grid rendering (cuda_ray = True)
+    def run_cuda(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0, render_can=True,
+                 verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True, per_sample: bool = True, max_steps=1024):
+        """The render path the reference dispatches to when cuda_ray=True (models/instant_nsr.py:358-363) and never defines: the chain its
+        raymarching module and density grid exist for (raymarching/raymarching.py:21-188, update_extra_state :303-356), in the shape of the Instant-NSR
+        code base the module was taken from --
+
+          train():  march_rays_train (occupancy grid, perturb, align 128) -> field on the packed samples -> composite_rays_train (+ background)
+          eval():   loop { compact_rays; march_rays (n_step = clamp(N / n_alive, 1, 8)); field; composite_rays } until no ray is alive or max_steps
+
+        with the field evaluated per sample exactly like run()'s render core (:205-243): forward_sdf, finite-difference normal, forward_color and
+        the NeuS alpha with the marcher's step as the section length (ac_field_samples: one fused launch; under autograd the SDF-query / colour
+        operators with their fused backward).  composite_rays_train treats its first input as alpha (quirk C.4), so the chain is consistent.
+        num_steps / upsample_steps are unused (the marcher decides the sampling).  Returns run()'s tuple; per-sample entries are None and the
+        training depth is zero (the packed compositor has none)."""
+        from . import raymarching
+        if not self.cuda_ray:
+            raise RuntimeError("run_cuda needs NeRFNetwork(cuda_ray=True) (density grid + step counters)")
+        if not render_can:
+            raise NotImplementedError("the occupancy grid lives in canonical space: cuda_ray renders render_can=True only")
+        if not self._fused_supported():
+            raise NotImplementedError("run_cuda is built for the default NeRFNetwork (use_viewdirs=False, no curvature term)")
+        fd_eps = 0.005 * (1.0 - normal_epsilon_ratio)
+        if not fd_eps > 0.0:
+            raise RuntimeError("run_cuda: normal_epsilon_ratio must be < 1 (finite-difference step 0.005 * (1 - ratio) > 0)")
+        B, N = rays_o.shape[:2]
+        device = rays_o.device
+        ro = rays_o.reshape(-1, 3).float().contiguous()
+        rd = rays_d.reshape(-1, 3).float().contiguous()
+        n_rays = ro.shape[0]
+        bg = 1.0
+        if bg_color is not None:
+            bg = torch.as_tensor(bg_color, dtype=torch.float32, device=device)
+            bg = bg.reshape(-1, 3) if bg.numel() >= 3 else bg.reshape(1, 1)
+        inv_s_t = self.forward_variance()
+        if self.training:
+            counter = self.step_counter[self.local_step % 64]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, bound, self.density_grid, self.mean_density, self.iter_density, counter,
+                                                                    self.mean_count, bool(perturb_overwrite), 128, False)
+            M = xyzs.shape[0]
+            valid = (torch.arange(M, device=device) < counter[0]).float()          # samples past counter[0] are alignment padding (all-zero rows)
+            needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            if needs_grad:
+                enc = self.encoder
+                W = nsr_ops.weight_norm_all(list(self.sdf_net) + list(self.color_net))
+                sdf_out, gradient = nsr_ops.sdf_stencil(xyzs, enc.embeddings, W[0], self.sdf_net[0].bias, W[1], self.sdf_net[1].bias, self._offsets_host(),
+                                                        enc.per_level_scale, enc.base_resolution, bound, fd_eps)
+                normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
+                rgbs = nsr_ops.color_mlp(xyzs, normal, sdf_out, W[2], W[3], W[4])
+                true_cos = (dirs * normal).sum(-1, keepdim=True)
+                act = nn.Softplus(beta=100)
+                iter_cos = -(act(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + act(-true_cos) * cos_anneal_ratio)
+                half = iter_cos * deltas.reshape(-1, 1) * 0.5
+                sdf = sdf_out[:, :1]
+                prev_cdf, next_cdf = torch.sigmoid((sdf - half) * inv_s_t), torch.sigmoid((sdf + half) * inv_s_t)
+                alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).reshape(-1).clip(0.0, 1.0)
+            else:
+                fs = nsr_ops.field_samples(self._field(), xyzs, dirs, deltas, bound, fd_eps, inv_s_t, cos_anneal_ratio, want_gradient=True)
+                alpha, rgbs, normal, gradient = fs["alpha"], fs["rgb"], fs["normal"], fs["gradient"]
+            relax = (torch.linalg.norm(xyzs, ord=2, dim=-1) < 1.2).float() * valid
+            gerr = (torch.linalg.norm(gradient, ord=2, dim=-1) - 1.0) ** 2
+            gradient_error = (relax * gerr).sum() / (relax.sum() + 1e-5)                 # :266-272 over the packed samples
+            self._guard_finite(gradient_error)
+            weights_sum, image = raymarching.composite_rays_train(alpha, rgbs, deltas, rays, bound)
+            with torch.no_grad():
+                _, normal_map = raymarching.composite_rays_train(alpha.detach(), normal.detach().contiguous(), deltas, rays, bound)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg
+            depth = torch.zeros(n_rays, dtype=torch.float32, device=device)
+            return depth.reshape(B, N), None, weights_sum[:, None], image.reshape(B, N, 3), normal_map, gradient_error, 0.0, None, None, None
+        # ---- inference: march / evaluate / composite in rounds, dead rays compacted away between rounds (one 4-byte D2H per round, like the reference's
+        # `alive_counter.item()`: the next round's step count depends on it)
+        with torch.no_grad():
+            field = self._field()
+            f32 = dict(dtype=torch.float32, device=device)
+            weights_sum, depth = torch.zeros(n_rays, **f32), torch.zeros(n_rays, **f32)
+            image, normal_map = torch.zeros(n_rays, 3, **f32), torch.zeros(n_rays, 3, **f32)
+            near, far = near_far_from_bound(ro, rd, bound, type='cube')
+            near, far = near.reshape(-1).contiguous(), far.reshape(-1).contiguous()
+            n_alive = n_rays
+            alive_counter = torch.zeros(1, dtype=torch.int32, device=device)
+            rays_alive = torch.zeros(2, n_rays, dtype=torch.int32, device=device)
+            rays_t = torch.zeros(2, n_rays, **f32)
+            step = rnd = 0
+            while step < max_steps:
+                if step == 0:
+                    rays_alive[0] = torch.arange(n_rays, dtype=torch.int32, device=device)
+                    rays_t[0] = near
+                else:
+                    alive_counter.zero_()
+                    raymarching.compact_rays(n_alive, rays_alive[rnd % 2], rays_alive[(rnd + 1) % 2], rays_t[rnd % 2], rays_t[(rnd + 1) % 2], alive_counter)
+                    n_alive = int(alive_counter.item())
+                if n_alive <= 0:
+                    break
+                n_step = max(min(n_rays // n_alive, 8), 1)
+                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive[rnd % 2], rays_t[rnd % 2], ro, rd, bound, self.density_grid,
+                                                            self.mean_density, near, far, 128, False)
+                fs = nsr_ops.field_samples(field, xyzs, dirs, deltas, bound, fd_eps, inv_s_t, cos_anneal_ratio)
+                raymarching.composite_rays(n_alive, n_step, rays_alive[rnd % 2], rays_t[rnd % 2], fs["alpha"], fs["rgb"], fs["normal"], deltas, weights_sum,
+                                           depth, image, normal_map)
+                step += n_step
+                rnd += 1
+            self._last_cuda_rounds = rnd
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg
+            depth = torch.clamp(depth - near, min=0) / (far - near)
+            return (depth.reshape(B, N), None, weights_sum[:, None], image.reshape(B, N, 3), normal_map, torch.zeros((), **f32), 0.0, None, None, None)
+
     # ------------------------------------------------------------------ render == reference :358-408
     def render(self, rays_o, rays_d, num_steps, bound, upsample_steps, staged=False, max_ray_batch=4096, bg_color=None,
                cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0, render_can=True, verts=None, faces=None, Ts=None, perturb: bool = False,
@@ -457,7 +565,8 @@ class NeRFRenderer(nn.Module):
                     normal[b, head:tail] = r[4].detach()
                     head += max_ray_batch
         else:
-            (depth, weights, weight_sum, image, normal, gradient_error, curvature_error, pts_color, pts_alpha, z_vals) = self.run(
+            _run = self.run_cuda if self.cuda_ray else self.run           # :360-363 (the reference has no run_cuda: see there)
+            (depth, weights, weight_sum, image, normal, gradient_error, curvature_error, pts_color, pts_alpha, z_vals) = _run(
                 rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio, normal_epsilon_ratio, render_can=render_can,
                 verts=verts, faces=faces, Ts=Ts, perturb_overwrite=perturb, use_mesh_guide=use_mesh_guide, per_sample=per_sample)
         return {'depth': depth, 'weights': weights, 'weight_sum': weight_sum, 'rgb': image, 'normal': normal,

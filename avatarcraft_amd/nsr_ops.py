@@ -654,6 +654,28 @@ def sdf_stencil(x, table, W1, b1, W2, b2, offsets, per_level_scale, base_resolut
     return _SdfStencil.apply(x, table, W1, b1, W2, b2, cfg)
 
 
+def field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio=1.0, want_sdf=False, want_gradient=False):
+    """ac_field_samples: the field on packed samples (what run_cuda evaluates between the marcher and the packed compositor).
+    xyzs, dirs [M,3]; deltas [M] (march_rays_train) or [M,2] (march_rays; column 0 is the step).  inv_s: float or a CUDA tensor (read on the device).
+    -> dict(alpha [M], rgb [M,3], normal [M,3] (+ sdf [M], gradient [M,3]))"""
+    xyzs = _chk(xyzs.reshape(-1, 3), "xyzs"); dirs = _chk(dirs.reshape(-1, 3), "dirs"); deltas = _chk(deltas, "deltas")
+    M, dev = xyzs.shape[0], xyzs.device
+    if dirs.shape[0] != M or deltas.shape[0] != M or deltas.dim() not in (1, 2):
+        raise RuntimeError("field_samples: xyzs [M,3], dirs [M,3], deltas [M] or [M,k]")
+    stride = 1 if deltas.dim() == 1 else int(deltas.shape[1])
+    f = lambda *sh: torch.empty(sh, dtype=_F32, device=dev)
+    out = dict(alpha=f(M), rgb=f(M, 3), normal=f(M, 3))
+    if want_sdf:
+        out["sdf"] = f(M)
+    if want_gradient:
+        out["gradient"] = f(M, 3)
+    inv_f, inv_t = _inv_s_arg(inv_s)
+    L.check(L.lib().ac_field_samples(C.byref(field.c), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), stride, M, float(bound), float(eps), inv_f, L.ptr(inv_t),
+                                     float(cos_anneal_ratio), out["alpha"].data_ptr(), out["rgb"].data_ptr(), out["normal"].data_ptr(),
+                                     L.ptr(out.get("sdf")), L.ptr(out.get("gradient")), L.current_stream(dev)), "field_samples")
+    return out
+
+
 def field_sdf(field, x, bound):
     """forward_sdf (instant_nsr.py:627-642): x [B,3] -> [B,16] (sdf, 15 features)"""
     x = _chk(x.reshape(-1, 3), "x")

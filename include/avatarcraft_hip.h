@@ -303,6 +303,18 @@ size_t ac_sdf_stencil_backward_scratch(uint32_t B);
 int ac_sdf_stencil_backward(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
                             float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
+/* ---- field evaluation on PACKED samples: the body of NeRFRenderer.run_cuda between raymarching.march_rays[_train] and
+ * raymarching.composite_rays[_train].  The reference dispatches cuda_ray=True renders to `run_cuda` (models/instant_nsr.py:362-363) but never defines it
+ * (SURVEY 0.1); the per-sample arithmetic is run()'s render core (:205-243) with the marcher's step as the section length:
+ *   p = clamp(xyz, +-bound); out16 = forward_sdf(p) (:627-642); g = finite-difference gradient (:687-704, eps); n = g / (1e-5 + |g|);
+ *   rgb = forward_color(p, n, out16[1:]) (:644-663); alpha = NeuS alpha of (out16[0], dot(dir, n), delta, inv_s, cos_anneal_ratio) (:219-243), clipped to [0, 1].
+ * xyzs, dirs [M,3]; deltas [M * delta_stride] (column 0 is used: march_rays_train writes stride 1, march_rays stride 2).
+ * inv_s_dev (optional) = forward_variance() as one float on the device, else inv_s.  sdf [M], gradient [M,3] optional.
+ * Bit-identical, per sample, to what ac_render_rays computes for the same point / direction / section length (same tile code). */
+int ac_field_samples(const ac_field *field, const float *xyzs, const float *dirs, const float *deltas, uint32_t delta_stride, uint32_t M,
+                     float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio, float *alpha, float *rgb, float *normal,
+                     float *sdf, float *gradient, ac_stream_t stream);
+
 /* ---- colour MLP of the render core (training path): forward_color (models/instant_nsr.py:644-663, use_viewdirs = False)
  * rgb = sigmoid(Wc3 relu(Wc2 relu(Wc1 [x, normal, feat]))) with feat = sdf16[:, 1:16].
  * forward : same values as ac_field_color / ac_render_rays.   backward: recomputes the forward per tile of 16 samples and returns

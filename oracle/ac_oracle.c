@@ -409,6 +409,44 @@ ORC_API void orc_field_color(const orc_field *f, const float *x, const float *n,
     for (int64_t b = 0; b < (int64_t)B; b++)
         orc_color_mlp(f, x + 3 * b, n + 3 * b, sdfout + 16 * b, rgb + 3 * b);
 }
+/* Field evaluation on packed samples: the body of the (undefined) NeRFRenderer.run_cuda that models/instant_nsr.py:362-363 dispatches to, between
+ * raymarching.march_rays[_train] and composite_rays[_train] -- run()'s render core per sample with the marcher's step as the section length:
+ * new_pts.clamp (:205), forward_sdf (:209-211), finite-difference gradient (:213, :687-704), normal (:214), forward_color (:216), NeuS alpha (:219-243).
+ * deltas: column 0 of a [M, dstride] array.  sdf / gradient optional. */
+ORC_API void orc_field_samples(const orc_field *f, const float *xyzs, const float *dirs, const float *deltas, uint32_t dstride, uint32_t M,
+                               float bound, float eps, float inv_s, float cos_anneal_ratio, float *alpha, float *rgb, float *normal,
+                               float *sdf, float *gradient)
+{
+    const float car = cos_anneal_ratio, one_m_car = (float)(1.0 - (double)cos_anneal_ratio);
+    #pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)M; b++) {
+        float p[3], s16[16], g[3], nn[3];
+        const float *d = dirs + 3 * b;
+        for (int k = 0; k < 3; k++) p[k] = clampf(xyzs[3 * b + k], -bound, bound);
+        field_sdf(f, p, bound, s16);
+        for (int k = 0; k < 3; k++) {
+            float q[3] = { p[0], p[1], p[2] };
+            q[k] = clampf(p[k] + eps, -bound, bound);
+            const float sp = field_sdf_only(f, q, bound);
+            q[k] = clampf(p[k] + (-eps), -bound, bound);
+            const float sn = field_sdf_only(f, q, bound);
+            g[k] = 0.5f * (sp - sn) / eps;
+        }
+        const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+        for (int k = 0; k < 3; k++) nn[k] = g[k] / (1e-5f + gn);
+        orc_color_mlp(f, p, nn, s16, rgb + 3 * b);
+        const float tc = (d[0] * nn[0] + d[1] * nn[1]) + d[2] * nn[2];
+        const float a1 = orc_softplus100(-tc * 0.5f + 0.5f) * one_m_car;
+        const float a2 = orc_softplus100(-tc) * car;
+        const float iter_cos = -(a1 + a2);
+        const float half = iter_cos * deltas[(size_t)b * dstride] * 0.5f;
+        const float pc = orc_sigmoid((s16[0] - half) * inv_s), nc = orc_sigmoid((s16[0] + half) * inv_s);
+        alpha[b] = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+        for (int k = 0; k < 3; k++) normal[3 * b + k] = nn[k];
+        if (sdf) sdf[b] = s16[0];
+        if (gradient) for (int k = 0; k < 3; k++) gradient[3 * b + k] = g[k];
+    }
+}
 ORC_API float orc_test_expf(float x) { return orc_expf(x); }
 ORC_API float orc_test_log1pf(float x) { return orc_log1pf(x); }
 ORC_API float orc_test_softplus100(float x) { return orc_softplus100(x); }

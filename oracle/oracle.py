@@ -262,6 +262,83 @@ class Field:
         return out
 
 
+def field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio=1.0):
+    """per-sample (alpha, rgb, normal, sdf, gradient) of packed samples (orc_field_samples); deltas [M] or [M,2] (column 0)"""
+    xyzs = _f(xyzs).reshape(-1, 3); dirs = _f(dirs).reshape(-1, 3); deltas = _f(deltas)
+    M = xyzs.shape[0]
+    stride = 1 if deltas.ndim == 1 else deltas.shape[1]
+    out = dict(alpha=np.empty(M, np.float32), rgb=np.empty((M, 3), np.float32), normal=np.empty((M, 3), np.float32), sdf=np.empty(M, np.float32),
+               gradient=np.empty((M, 3), np.float32))
+    if M:
+        lib().orc_field_samples(C.byref(field.c), _p(xyzs), _p(dirs), _p(deltas), C.c_uint32(stride), C.c_uint32(M), C.c_float(bound), C.c_float(eps),
+                                C.c_float(inv_s), C.c_float(cos_anneal_ratio), _p(out["alpha"]), _p(out["rgb"]), _p(out["normal"]), _p(out["sdf"]),
+                                _p(out["gradient"]))
+    return out
+
+
+def _near_far_cube(rays_o, rays_d, bound):
+    """near_far_from_bound(type='cube'), models/instant_nsr.py:58-77, fp32"""
+    o, d = _f(rays_o).reshape(-1, 3), _f(rays_d).reshape(-1, 3)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tmin = (np.float32(-bound) - o) / (d + np.float32(1e-15))
+        tmax = (np.float32(bound) - o) / (d + np.float32(1e-15))
+    near = np.where(tmin < tmax, tmin, tmax).max(axis=1)
+    far = np.where(tmin > tmax, tmin, tmax).min(axis=1)
+    return np.maximum(near, np.float32(0.05)).astype(np.float32), far.astype(np.float32)
+
+
+def run_cuda_train(field, rays_o, rays_d, grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, bg=1.0, perturb=0, mean_count=-1, align=128):
+    """training form of the occupancy-grid render (NeRFRenderer.run_cuda, train()): march_rays_train -> field_samples -> composite_rays_train_forward.
+    Returns dict(image, weights_sum, normal_map, gradient_error, rays, counter, xyzs, dirs, deltas, alpha, rgb, normal, gradient)."""
+    N = _f(rays_o).reshape(-1, 3).shape[0]
+    M = None
+    if mean_count > 0:
+        M = mean_count + (align - mean_count % align) if align > 0 else mean_count
+    xyzs, dirs, deltas, rays, counter = march_rays_train(rays_o, rays_d, grid, mean_density, bound, M=M, perturb=perturb)
+    if mean_count <= 0:
+        m = int(counter[0])
+        m = m + (align - m % align) if align > 0 else m
+        xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+    fs = field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio)
+    ws, img = composite_rays_train_forward(fs["alpha"], fs["rgb"], deltas, rays, bound)
+    _, nmap = composite_rays_train_forward(fs["alpha"], fs["normal"], deltas, rays, bound)
+    valid = (np.arange(xyzs.shape[0]) < int(counter[0])).astype(np.float32)
+    relax = (np.sqrt((xyzs.astype(np.float64) ** 2).sum(1)) < 1.2).astype(np.float64) * valid
+    gerr = (np.sqrt((fs["gradient"].astype(np.float64) ** 2).sum(1)) - 1.0) ** 2
+    res = dict(fs)
+    res.update(image=(img + (1 - ws)[:, None] * np.asarray(bg, np.float32)).astype(np.float32), weights_sum=ws, normal_map=nmap,
+               gradient_error=float((relax * gerr).sum() / (relax.sum() + 1e-5)), rays=rays, counter=counter, xyzs=xyzs, dirs=dirs, deltas=deltas)
+    return res
+
+
+def run_cuda_eval(field, rays_o, rays_d, grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, bg=1.0, max_steps=1024, align=128):
+    """inference form (eval()): rounds of compact_rays / march_rays / field_samples / composite_rays with n_step = clamp(N // n_alive, 1, 8).
+    Returns dict(image, weights_sum, depth, normal_map, rounds, alive_per_round)."""
+    o, d = _f(rays_o).reshape(-1, 3), _f(rays_d).reshape(-1, 3)
+    N = o.shape[0]
+    ws, depth = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    image, nmap = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32)
+    near, far = _near_far_cube(o, d, bound)
+    rays_alive = np.arange(N, dtype=np.int32); rays_t = near.copy()
+    n_alive, step, alive_log = N, 0, []
+    while step < max_steps:
+        if step > 0:
+            rays_alive, rays_t, n_alive = compact_rays(n_alive, rays_alive, rays_t)
+        if n_alive <= 0:
+            break
+        alive_log.append(n_alive)
+        n_step = max(min(N // n_alive, 8), 1)
+        xyzs, dirs, deltas = march_rays(n_alive, n_step, rays_alive, rays_t, o, d, bound, grid, mean_density, near, far)
+        fs = field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio)
+        rays_t = np.ascontiguousarray(rays_t, np.float32)
+        composite_rays(n_alive, n_step, rays_alive, rays_t, fs["alpha"], fs["rgb"], fs["normal"], deltas, ws, depth, image, nmap)
+        step += n_step
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dn = (np.maximum(depth - near, np.float32(0)) / (far - near)).astype(np.float32)
+    return dict(image=(image + (1 - ws)[:, None] * np.asarray(bg, np.float32)).astype(np.float32), weights_sum=ws, depth=dn, normal_map=nmap,
+                rounds=len(alive_log), alive_per_round=alive_log)
+
+
 def linspace_tables(num_steps):
     """The two torch.linspace tables the renderer consumes (instant_nsr.py:155, :34), made by torch on
     the CPU exactly as the reference makes them."""

@@ -1,0 +1,170 @@
+"""-m gpu: the occupancy-grid render (NeRFRenderer.run_cuda behind render(cuda_ray=True)) on the MI355X
+against the oracle's chain (oracle.run_cuda_train / run_cuda_eval, pinned piecewise on the CPU: tests/test_oracle_run_cuda.py):
+  * ac_field_samples == orc_field_samples bit for bit on the marcher's packed samples (both delta layouts);
+  * training form through net.render: rays[N,3] exactly, pixels / opacity / normal map against the oracle chain;
+  * inference loop through net.render: the same number of rounds and alive rays per round, pixels against the oracle chain;
+  * gradients of the training form against an independent torch-autograd formulation (torch MLPs over the HIP hash encoder, six forward_sdf
+    calls for the normal, torch NeuS alpha) through the same packed compositor."""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import make_rays
+from tests.gpu_common import oracle_field as make_of, assert_bitwise
+from tests.test_gpu_model import golden_net, DEV
+
+pytestmark = pytest.mark.gpu
+INV_S_VARIANCE = float(np.log(512.0) / 10.0)        # forward_variance() = exp(10 v) = 512: the sharpness the grid is built for (instant_nsr.py:325)
+
+
+@pytest.fixture(scope="module")
+def env(oracle):
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    src, p = golden_net()
+    torch.manual_seed(0)
+    net = NeRFNetwork(cuda_ray=True)
+    net.load_state_dict(src.state_dict(), strict=False)
+    net = net.to(DEV)
+    with torch.no_grad():
+        net.deviation_net.variance.fill_(INV_S_VARIANCE)
+    of = make_of(p, src.encoder.embeddings.detach().cpu().numpy())
+    grid, mean = oracle.update_density_grid(of, np.zeros((129,) * 3, np.float32), 1.6)
+    # the ORACLE's grid on the device (the GPU's own update_extra_state agrees to 2e-4 of max -- tests/test_gpu_model.py -- which is not bit for bit,
+    # and the chain comparison below is)
+    net.density_grid.copy_(torch.from_numpy(grid)); net.mean_density = float(mean); net.iter_density = 1
+    inv_s = float(net.forward_variance().item())
+    return dict(net=net, of=of, grid=grid, mean=float(mean), inv_s=inv_s, O=oracle, p=p)
+
+
+def test_field_samples_bitwise_vs_oracle(env):
+    from avatarcraft_amd import nsr_ops, raymarching
+    O, net = env["O"], env["net"]
+    ro, rd = make_rays(24, 24, dist=1.8, f=18.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(t(ro), t(rd), 1.6, net.density_grid, net.mean_density, 1, align=128, force_all_rays=True)
+    x_o, d_o, dl_o, r_o, c_o = O.march_rays_train(ro, rd, env["grid"], env["mean"], 1.6)
+    assert np.array_equal(rays.cpu().numpy(), r_o)                                          # rays[N,3] = (id, offset, count): exactly equal
+    M = int(c_o[0])
+    assert M > 2000 and xyzs.shape[0] % 128 == 0
+    assert_bitwise(xyzs[:M], x_o[:M], "xyzs"); assert_bitwise(dirs[:M], d_o[:M], "dirs"); assert_bitwise(deltas[:M], dl_o[:M], "deltas")
+    field = net.eval()._field()
+    for car in (1.0, 0.3):
+        g = nsr_ops.field_samples(field, xyzs, dirs, deltas, 1.6, 0.005, env["inv_s"], car, want_sdf=True, want_gradient=True)
+        r = O.field_samples(env["of"], xyzs.cpu().numpy(), dirs.cpu().numpy(), deltas.cpu().numpy(), 1.6, 0.005, env["inv_s"], car)
+        for k in ("alpha", "rgb", "normal", "sdf", "gradient"):
+            assert_bitwise(g[k], r[k], f"{k} (car {car})")
+    # the [M,2] layout of march_rays, inv_s read from the device, a ragged count
+    d2 = torch.stack([deltas, torch.full_like(deltas, 3.0)], 1).contiguous()[:M - 5]
+    g2 = nsr_ops.field_samples(field, xyzs[:M - 5], dirs[:M - 5], d2, 1.6, 0.005, net.forward_variance(), 1.0)
+    r2 = O.field_samples(env["of"], x_o[:M - 5], d_o[:M - 5], d2.cpu().numpy(), 1.6, 0.005, env["inv_s"], 1.0)
+    for k in ("alpha", "rgb", "normal"):
+        assert_bitwise(g2[k], r2[k], k + " (stride 2)")
+    assert float(g["alpha"][:M].max()) > 0.05
+    with pytest.raises(RuntimeError):
+        nsr_ops.field_samples(field, xyzs.cpu(), dirs, deltas, 1.6, 0.005, 1.0)
+
+
+def test_run_cuda_training_form_vs_oracle_chain(env):
+    O, net = env["O"], env["net"].train()
+    ro, rd = make_rays(32, 32, dist=1.8, f=24.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    bg = np.random.RandomState(3).uniform(0, 1, (1024, 3)).astype(np.float32)
+    net.mean_count, net.local_step = 0, 0
+    with torch.no_grad():
+        out = net.render(t(ro)[None], t(rd)[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=t(bg), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0,
+                         perturb=False)
+    r = O.run_cuda_train(env["of"], ro, rd, env["grid"], env["mean"], 1.6, 0.005, env["inv_s"], bg=bg)
+    assert set(out) == {"depth", "weights", "weight_sum", "rgb", "normal", "gradient_error", "curvature_error", "pts_color", "pts_alpha", "z_vals"}
+    assert out["rgb"].shape == (1, 1024, 3) and out["weight_sum"].shape == (1024, 1) and out["normal"].shape == (1024, 3)
+    c = lambda v: v.detach().cpu().numpy()
+    assert tuple(c(net.step_counter[0])) == (int(r["counter"][0]), 1024) and net.local_step == 1
+    assert_bitwise(out["weight_sum"][:, 0], r["weights_sum"], "weights_sum")               # same samples, same per-sample bits, same compositor arithmetic
+    assert np.abs(c(out["rgb"])[0] - r["image"]).max() <= 1e-6                              # (+ the background blend: torch vs numpy, one rounding)
+    assert_bitwise(out["normal"], r["normal_map"], "normal_map")
+    assert abs(float(out["gradient_error"]) - r["gradient_error"]) <= 1e-5 * max(1.0, r["gradient_error"])
+    # against run() on the same field: the same integral by another quadrature
+    net_run = env["net"]
+    net_run.cuda_ray = False
+    try:
+        with torch.no_grad():
+            ref = net_run.eval().render(t(ro)[None], t(rd)[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=t(bg), cos_anneal_ratio=1.0,
+                                        normal_epsilon_ratio=0.0)
+    finally:
+        net_run.cuda_ray = True
+    assert float((ref["rgb"] - out["rgb"]).abs().max()) <= 8e-3 and float((ref["weight_sum"] - out["weight_sum"]).abs().max()) <= 1.5e-2
+    # perturbed march with the per-epoch sample budget: no host synchronisation, same pixels for the rays that fit
+    net.train(); net.mean_count = int(r["counter"][0]); net.local_step = 5
+    with torch.no_grad():
+        out2 = net.render(t(ro)[None], t(rd)[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=t(bg), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0,
+                          perturb=True)
+    r2 = O.run_cuda_train(env["of"], ro, rd, env["grid"], env["mean"], 1.6, 0.005, env["inv_s"], bg=bg, perturb=1, mean_count=int(r["counter"][0]))
+    assert_bitwise(out2["weight_sum"][:, 0], r2["weights_sum"], "weights_sum (perturbed, budgeted)")
+    assert tuple(c(net.step_counter[5])) == (int(r2["counter"][0]), 1024)
+    net.mean_count = 0
+
+
+def test_run_cuda_inference_loop_vs_oracle_chain(env):
+    O, net = env["O"], env["net"].eval()
+    ro, rd = make_rays(48, 48, dist=1.8, f=36.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    with torch.no_grad():
+        out = net.render(t(ro)[None], t(rd)[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0)
+    r = O.run_cuda_eval(env["of"], ro, rd, env["grid"], env["mean"], 1.6, 0.005, env["inv_s"])
+    assert net._last_cuda_rounds == r["rounds"]
+    assert_bitwise(out["weight_sum"][:, 0], r["weights_sum"], "weights_sum")
+    assert_bitwise(out["normal"], r["normal_map"], "normal_map")
+    c = lambda v: v.detach().cpu().numpy()
+    assert np.abs(c(out["rgb"])[0] - r["image"]).max() <= 1e-6
+    hit = r["weights_sum"] > 0.5
+    assert hit.any() and np.abs(c(out["depth"])[0][hit] - r["depth"][hit]).max() <= 1e-6
+    assert float(out["gradient_error"]) == 0.0 and out["weights"] is None and out["z_vals"] is None
+
+
+def test_run_cuda_gradients_vs_torch_formulation(env):
+    """the training form under autograd: fused SDF-query / colour operators + packed compositor, against torch MLPs over the HIP hash encoder with the
+    normal from six more forward_sdf calls (the reference's formulation of the same per-sample arithmetic), same samples, same compositor"""
+    from avatarcraft_amd import raymarching
+    import torch.nn as nn
+    net = env["net"].train()
+    ro, rd = make_rays(16, 16, dist=1.8, f=12.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    gi = torch.from_numpy(np.random.RandomState(5).normal(0, 1, (256, 3)).astype(np.float32)).to(DEV)
+    net.mean_count, net.local_step = 0, 0
+    net.zero_grad()
+    out = net.render(t(ro)[None], t(rd)[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, perturb=False)
+    loss = (out["rgb"][0] * gi).sum() + 0.1 * out["gradient_error"] + 3.0 * out["weight_sum"].sum()
+    loss.backward()
+    got = {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
+    assert set(got) >= {"encoder.embeddings", "sdf_net.0.weight_v", "color_net.2.weight_v", "deviation_net.variance"}
+    # the independent formulation
+    net.zero_grad()
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(t(ro), t(rd), 1.6, net.density_grid, net.mean_density, 1, align=128, force_all_rays=True)
+    M = int((rays[:, 2]).sum())
+    sdf_out = net.forward_sdf(xyzs, 1.6)
+    gradient = net.gradient(xyzs, 1.6, 0.005).squeeze()
+    normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
+    rgb = net.forward_color(xyzs, dirs, normal, sdf_out[:, 1:], 1.6)
+    inv_s = net.forward_variance()
+    tc = (dirs * normal).sum(-1, keepdim=True)
+    act = nn.Softplus(beta=100)
+    half = -(act(-tc * 0.5 + 0.5) * 0.0 + act(-tc) * 1.0) * deltas.reshape(-1, 1) * 0.5
+    pc, nc = torch.sigmoid((sdf_out[:, :1] - half) * inv_s), torch.sigmoid((sdf_out[:, :1] + half) * inv_s)
+    alpha = ((pc - nc + 1e-5) / (pc + 1e-5)).reshape(-1).clip(0.0, 1.0)
+    ws, img = raymarching.composite_rays_train(alpha, rgb, deltas, rays, 1.6)
+    img = img + (1 - ws).unsqueeze(-1)
+    valid = (torch.arange(xyzs.shape[0], device=DEV) < M).float()
+    relax = (torch.linalg.norm(xyzs, dim=-1) < 1.2).float() * valid
+    gerr = ((torch.linalg.norm(gradient, dim=-1) - 1.0) ** 2 * relax).sum() / (relax.sum() + 1e-5)
+    assert float((img - out["rgb"][0]).abs().max()) <= 2e-5 and abs(float(gerr) - float(out["gradient_error"])) <= 1e-5
+    ((img * gi).sum() + 0.1 * gerr + 3.0 * ws.sum()).backward()
+    worst = {}
+    for k, v in net.named_parameters():
+        if v.grad is None:
+            continue
+        a, b = got[k].double(), v.grad.double()
+        worst[k] = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(worst, open("gpurun_out/run_cuda_grad_parity.json", "w"), indent=1)
+    assert all(e <= 2e-3 for e in worst.values()), worst
+    net.zero_grad()
