@@ -88,13 +88,13 @@ SDS_BYTES_LAUNCHED = {
 SDS_BYTES_SURVEY = 3 * RAYS_PER_BATCH * BYTES_PER_RAY + (7 + 6 + 7) * RAYS_PER_BATCH * SAMPLES * 2048
 
 
-def make_net(p, table, dev, train):
+def make_net(p, table, dev, train, cuda_ray=False):
     from avatarcraft_amd.instant_nsr import NeRFNetwork
     torch.manual_seed(0)
-    net = NeRFNetwork()
+    net = NeRFNetwork(cuda_ray=cuda_ray)
     sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
     sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
-    net.load_state_dict(sd)
+    net.load_state_dict(sd, strict=not cuda_ray)       # (cuda_ray adds the density grid / step counter buffers)
     return net.to(dev).train(train)
 
 
@@ -293,6 +293,66 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     return res
 
 
+def time_occupancy_render(dev, p, table, ro, rd, reps=3):
+    """A SEPARATE figure, not the headline and not run()'s result: the occupancy-grid render (render(cuda_ray=True) -> NeRFRenderer.run_cuda, the path
+    models/instant_nsr.py:358-363 dispatches to and the reference never defines): density grid (update_extra_state) -> march -> fused per-sample field
+    (ac_field_samples) -> packed compositor, on the same 256 x 256 view.  The grid is built for a sharp variance (inv_s = 512 hard-coded at :325), so
+    this leg sets forward_variance() = 512 and reports how far its pixels are from run()'s at that variance (two quadratures of one integral)."""
+    from avatarcraft_amd.render_utils import NSR_BOUND
+    net = make_net(p, table, dev, False, cuda_ray=True)
+    with torch.no_grad():
+        net.deviation_net.variance.fill_(float(np.log(512.0) / 10.0))
+    t0 = time.perf_counter(); net.update_extra_state(NSR_BOUND); torch.cuda.synchronize(); t_grid = time.perf_counter() - t0
+    kw = dict(num_steps=64, bound=NSR_BOUND, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0)
+    n = ro.shape[0]
+
+    def view(rpb):
+        rounds = 0
+        outs = []
+        for i in range(0, n, rpb):
+            outs.append(net.render(ro[None, i:i + rpb], rd[None, i:i + rpb], **kw)["rgb"][0])
+            rounds += net._last_cuda_rounds
+        return torch.cat(outs), rounds
+
+    res = {}
+    with torch.no_grad():
+        for rpb in (RAYS_PER_BATCH, n):
+            img, rounds = view(rpb); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                img, rounds = view(rpb)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            res[f"eval_{rpb}_ray_batches"] = {"ms_per_view": dt * 1e3, "rays_per_s": n / dt, "march_rounds_per_view": rounds}
+        net.cuda_ray = False
+        ref = torch.cat([net.render(ro[None, i:i + RAYS_PER_BATCH], rd[None, i:i + RAYS_PER_BATCH], **kw)["rgb"][0] for i in range(0, n, RAYS_PER_BATCH)])
+        net.cuda_ray = True
+        res["max_abs_rgb_diff_vs_run_at_inv_s_512"] = float((img - ref).abs().max())
+        res["mean_abs_rgb_diff_vs_run_at_inv_s_512"] = float((img - ref).abs().mean())
+        # training form (march_rays_train with the per-epoch sample budget: no host synchronisation), no-grad: march + field + two composites per batch
+        net.train()
+        so, sd_ = sds_view(0)                                    # the 4096-ray training view of the SDS step (every ray aimed at the body)
+        ro, rd = torch.from_numpy(so).to(dev), torch.from_numpy(sd_).to(dev)
+        b0 = slice(0, RAYS_PER_BATCH)
+        net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
+        samples = int(net.step_counter[0, 0].item())
+        net.mean_count = samples + 4096
+        for _ in range(2):
+            net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        res["train_form_4096_ray_batch"] = {"ms_per_batch": dt * 1e3, "rays_per_s": RAYS_PER_BATCH / dt, "samples_per_ray": samples / RAYS_PER_BATCH,
+                                            "bytes_per_sample_gathered": 7 * 1024, "gather_gbs": samples * 7 * 1024 / dt / 1e9}
+    res["density_grid_update_ms"] = t_grid * 1e3
+    res["note"] = ("occupancy-grid path (cuda_ray=True): a separate renderer from the headline's run(); the reference ships its operators but no caller "
+                   "(run_cuda is undefined there), so there is no reference number for it")
+    return res
+
+
 def time_real_sd_step(dev, p, table, steps=3):
     """`--real-sd`: one stylisation step with the REAL Stable-Diffusion guidance (models/diffusion.py:28-69,92-149 -- VAE encoder with grad, UNet on a
     batch of two 64 x 64 latents, classifier-free guidance 100) when diffusers + transformers + the runwayml/stable-diffusion-v1-5 weights are on
@@ -396,6 +456,7 @@ def main():
     ap.add_argument("--sds-steps", type=int, default=8, help="also time this many 4096-ray SDS steps (secondary metric); 0 = skip")
     ap.add_argument("--real-sd", action="store_true", help="time one SDS step with the real Stable-Diffusion guidance if diffusers + the weights are on this "
                                                            "machine (the line's real_sd field says why not otherwise; the probe itself always runs)")
+    ap.add_argument("--no-occupancy", action="store_true", help="skip the occupancy-grid render leg (render(cuda_ray=True): a separate figure beside the headline)")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
 
@@ -567,6 +628,12 @@ def main():
                 res["posed_frame"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, table, ro, rd)
+        if world == 1 and not a.no_occupancy:
+            try:
+                res["occupancy_render"] = time_occupancy_render(dev, p, table, ro_t, rd_t)
+            except Exception as e:             # noqa: BLE001
+                import traceback
+                res["occupancy_render"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-500:]}
         try:
             from avatarcraft_amd.guidance import real_sd_probe
             ok_sd, why_sd = real_sd_probe("1.5")
