@@ -952,6 +952,28 @@ static int warp_any(const ac_warp_mesh *m, const float *pts, uint32_t P, float *
     return ac_warp_samples(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, nullptr, can, nullptr, nullptr, nullptr, mask, stream);
 }
 
+// Measurement hook (bench.py's posed-frame roofline): with ac_debug_warped_phases(1) every ac_render_rays_warped call records HIP events on its stream
+// at the phase boundaries -- [0] start, [1] near / far + coarse points + ray cull, [2] first warp search, [3] up-sampling pass, [4] second warp search,
+// [5] final pass -- and ac_debug_warped_phase_ms() returns the five intervals of the LAST call in ms (it waits for that call).  Off by default.
+namespace {
+hipEvent_t g_phase_ev[6];
+int g_phase_on = 0, g_phase_have = 0;
+void phase_mark(int k, hipStream_t st) { if (g_phase_on) { (void)hipEventRecord(g_phase_ev[k], st); if (k == 5) g_phase_have = 1; } }
+}
+AC_API void ac_debug_warped_phases(int enable)
+{
+    if (enable && !g_phase_on) for (auto &e : g_phase_ev) (void)hipEventCreate(&e);
+    if (!enable && g_phase_on) { for (auto &e : g_phase_ev) (void)hipEventDestroy(e); g_phase_have = 0; }
+    g_phase_on = enable ? 1 : 0;
+}
+AC_API int ac_debug_warped_phase_ms(float out[5])
+{
+    if (!g_phase_on || !g_phase_have) { ac::set_error("ac_debug_warped_phase_ms: no instrumented ac_render_rays_warped call yet"); return AC_ERR_BAD_ARG; }
+    if (hipEventSynchronize(g_phase_ev[5]) != hipSuccess) { ac::set_error("ac_debug_warped_phase_ms: event wait failed"); return AC_ERR_LAUNCH; }
+    for (int k = 0; k < 5; ++k) { out[k] = 0.0f; (void)hipEventElapsedTime(out + k, g_phase_ev[k], g_phase_ev[k + 1]); }
+    return AC_OK;
+}
+
 AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op, const float *rays_o, const float *rays_d,
                                  const float *bg, const float *noise, const float *lin_z, const float *lin_u,
                                  const ac_warp_mesh *mesh, void *scratch, size_t scratch_bytes, const ac_render_out *out,
@@ -978,6 +1000,7 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
     hipStream_t st = (hipStream_t)stream;
     RenderArgs a{};
     if (int rc = fill_render_args(a, field, op, rays_o, rays_d, bg, noise, lin_z, lin_u, out)) return rc;
+    phase_mark(0, st);
     if (mesh->use_mesh_guide) {
         if (int rc = ac_mesh_near_far(rays_o, rays_d, mesh->verts, (uint32_t)N, mesh->V, mesh->geo_threshold, near_m, far_m, stream)) return rc;
         a.near_m = near_m; a.far_m = far_m;
@@ -992,16 +1015,21 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
             if (int rc = ac::warp_ray_cull(pts, (uint32_t)N, (uint32_t)T0, mesh->threshold, mesh->accel, rdead, stream)) return rc;
             ray_dead = rdead;
         }
+        phase_mark(1, st);
         if (int rc = warp_any(mesh, pts, (uint32_t)(N * T0), can, mask, stream, 0, ray_dead, (uint32_t)T0)) return rc;
-    }
+    } else phase_mark(1, st);
+    phase_mark(2, st);
     a.ext_pts = can;
     a.ray_dead = ray_dead;
     launch_render<MODE_UPSAMPLE>(a, st);                          // coarse sdf, up-sampling, mid points (posed space)
     if (int rc = ac::check_launch("render_rays_warped (up-sampling)")) return rc;
+    phase_mark(3, st);
     // (skip_masked: the final pass does not evaluate masked-out samples, so the search may leave out those the cell grids prove masked)
     if (int rc = warp_any(mesh, pts, (uint32_t)(N * T), can, mask, stream, op->skip_masked, ray_dead, (uint32_t)T)) return rc;     // :198-203
+    phase_mark(4, st);
     a.mask = mask;
     launch_render<MODE_FINAL>(a, st);
+    phase_mark(5, st);
     return ac::check_launch("render_rays_warped");
 }
 

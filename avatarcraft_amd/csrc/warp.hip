@@ -296,19 +296,25 @@ constexpr int GRID_LEVELS = 2;
 #define AC_LVL1_LOG2 16
 #endif
 constexpr uint32_t LVL_CELLS[GRID_LEVELS] = { 1u << AC_LVL0_LOG2, 1u << AC_LVL1_LOG2 };     // capacity in cells
-constexpr uint32_t LVL_K[GRID_LEVELS] = { 64, 192 };                    // listed tiles per cell
+#ifndef AC_LVL0_K
+#define AC_LVL0_K 128
+#endif
+constexpr uint32_t LVL_K[GRID_LEVELS] = { AC_LVL0_K, 192 };             // listed tiles per cell
 constexpr uint32_t LVL_CELL0[GRID_LEVELS] = { 0, LVL_CELLS[0] };        // first cell of the level in AccelView::cell
 constexpr uint32_t LVL_CTL0[GRID_LEVELS] = { 0, LVL_CELLS[0] * LVL_K[0] };   // first entry of the level in AccelView::ctl
 constexpr uint32_t CTL_ENTRIES = LVL_CELLS[0] * LVL_K[0] + LVL_CELLS[1] * LVL_K[1];
 constexpr uint32_t CELL_OVERFLOW = 0xffffu;      // count field of a cell without a list
 #ifndef AC_GRID_MARGIN0
-#define AC_GRID_MARGIN0 0.15f                    // metres of fine grid around the mesh's bounding box
+#define AC_GRID_MARGIN0 0.25f                    // metres of fine grid around the mesh's bounding box (round 4: wider than sqrt(0.05) = 0.224, the reach of the
+                                                 // warp mask, so that every sample that can be unmasked lies in a fine cell with a face list)
 #endif
 #ifndef AC_GRID_MARGIN1
 #define AC_GRID_MARGIN1 1.25f                    // ... of coarse grid
 #endif
 constexpr int HDR_WORDS = 64;
 constexpr int HDR_LVL = 8, HDR_LVL_STRIDE = 12;
+constexpr int HDR_WORK = 40;                     // hdr[40..47]: four 64-bit work counters of the searches since the build: exact point-triangle tests,
+                                                 // bounding-disc tests, sub-box tests, tile-box tests (zeroed by accel_grid_setup_kernel)
 // hdr words: [0] tiles, [1] F, [4..7] debug counters (64-bit x 2), level l at [8 + 12 l]: grid origin (3 floats), 1 / cell size, 2 x padded half
 // diagonal of a cell (float), nx, ny, nz, cells
 struct AccelView {                   // pointers into the caller's accel buffer
@@ -322,15 +328,25 @@ struct AccelView {                   // pointers into the caller's accel buffer
     uint16_t *ctl;                   // [CTL_ENTRIES] the cells' candidate tiles
     float *sub;                      // [MAX_TILES * SUBS][6] lo (3), hi (3) of each group of TILE_F / SUBS consecutive faces of a tile, in the tile's frame
     float *cfar;                     // [cells of all levels] a conservative LOWER bound of dist(q, mesh)^2 over the points q of the cell
+    // round 4: per FINE cell the faces (slots) that can hold the closest face -- or one at equal distance -- of any point of the cell
+    uint32_t *fl_off;                // [LVL_CELLS[0]] first entry of the cell's list in fl_pool (a multiple of 8)
+    uint32_t *fl_cnt;                // [LVL_CELLS[0]] entries (0: the cell has no face list: too far, tile-list overflow, pool exhausted, degenerate seed)
+    uint16_t *fl_pool;               // [FL_POOL] slots; hdr[2] = entries handed out, hdr[3] = cells that did not fit
 };
 constexpr int SUBS = 4, SUB_F = TILE_F / SUBS;   // sub-boxes per tile, faces per sub-box
-constexpr int ACCEL_SEGS = 10;
+constexpr uint32_t FL_POOL = 48u << 20;          // 48 M entries (96 MB): ~ 80 K listed cells x 250 faces for an SMPL-sized body, twice over
+#ifndef AC_FLIST_MAXD
+#define AC_FLIST_MAXD 0.25f                      // fine cells whose every point is provably farther than this from the mesh get no face list
+#endif
+constexpr uint8_t FL_TODO = 2;                   // mask value of a sample the face-list kernel leaves to the tile-walk kernel (fixup pass)
+constexpr int ACCEL_SEGS = 13;
 __host__ __device__ inline size_t accel_offsets(size_t (&o)[ACCEL_SEGS])
 {
     size_t off = 0;
     const size_t sz[ACCEL_SEGS] = { HDR_WORDS * 4, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)NB * MAX_TILES * 4,
                                     (size_t)MAX_ACCEL_FACES * 32, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4, (size_t)CTL_ENTRIES * 2,
-                                    (size_t)MAX_TILES * SUBS * 6 * 4, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4 };
+                                    (size_t)MAX_TILES * SUBS * 6 * 4, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4,
+                                    (size_t)LVL_CELLS[0] * 4, (size_t)LVL_CELLS[0] * 4, (size_t)FL_POOL * 2 };
     for (int i = 0; i < ACCEL_SEGS; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
     return off;
 }
@@ -343,6 +359,7 @@ __host__ __device__ inline AccelView accel_view(void *base)
     v.tri = reinterpret_cast<float *>(b + o[2]); v.oid = reinterpret_cast<int32_t *>(b + o[3]); v.box = reinterpret_cast<float *>(b + o[4]);
     v.sph = reinterpret_cast<float4 *>(b + o[5]);
     v.cell = reinterpret_cast<uint32_t *>(b + o[6]); v.ctl = reinterpret_cast<uint16_t *>(b + o[7]); v.sub = reinterpret_cast<float *>(b + o[8]); v.cfar = reinterpret_cast<float *>(b + o[9]);
+    v.fl_off = reinterpret_cast<uint32_t *>(b + o[10]); v.fl_cnt = reinterpret_cast<uint32_t *>(b + o[11]); v.fl_pool = reinterpret_cast<uint16_t *>(b + o[12]);
     return v;
 }
 
@@ -682,6 +699,8 @@ __global__ __launch_bounds__(1024) void accel_grid_setup_kernel(const float *__r
         __syncthreads();
     }
     if (t < 6) av.hdr[HDR_BBOX + t] = __builtin_bit_cast(uint32_t, red[t][0]);
+    if (t == 6) { av.hdr[2] = 0u; av.hdr[3] = 0u; }                  // face-list pool: nothing handed out yet
+    if (t >= 8 && t < 16) av.hdr[HDR_WORK + t - 8] = 0u;             // work counters of the searches on this structure
     if (t < (uint32_t)GRID_LEVELS) {
         const int l = (int)t;
         const float margin = l == 0 ? AC_GRID_MARGIN0 : AC_GRID_MARGIN1;
@@ -736,19 +755,39 @@ __device__ __forceinline__ uint32_t grid_cell(const GridParams &g, const float (
     return inside ? ((uint32_t)gz * g.n[1] + (uint32_t)gy) * g.n[0] + (uint32_t)gx : ~0u;
 }
 
+// Lower-bound test of one face against a bound: false only if the face's bounding disc (accel_tiles_kernel) proves dist(q, face)^2 > limf.
+// fp32 with every rounding padded towards "pass" (a face that passes wrongly only costs an exact test) -- the arithmetic of disc_trip below.
+__device__ __forceinline__ bool disc_pass(float q0, float q1, float q2, const float4 &sp, const float4 &sn, float limf)
+{
+    const float ex = q0 - sp.x, ey = q1 - sp.y, ez = q2 - sp.z;
+    const float e1 = (__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez);
+    const float e2 = (ex * ex + ey * ey) + ez * ez;
+    const float apd = __builtin_fabsf((ex * sn.x + ey * sn.y) + ez * sn.z);
+    const float err = 1e-6f * e1 + 1e-6f;
+    const float pdl = apd > err ? apd - err : 0.0f, pdh = apd + err;
+    const float rem = (limf - pdl * pdl) + 1e-6f * (limf + pdl * pdl);
+    const float rho2 = (e2 - pdh * pdh) - 2e-6f * (e2 + pdh * pdh);
+    const float rr = (sp.w + __builtin_sqrtf(rem > 0.0f ? rem : 0.0f) * 1.000001f) + 1e-12f;
+    return rem >= 0.0f && rho2 <= rr * rr * 1.000001f;
+}
+
 // one wave per cell (strided): the full bounding pass + seed test at the cell centre c, then the list of tiles t with
 //   sqrt(lb_t(c)) <= sqrt(d2(c, seed face)) + 2 h:   for q in the cell, boxdist(q, t) >= boxdist(c, t) - h and dist(q, mesh) <= dist(c, seed face) + h,
 // so a tile outside the list cannot hold the closest face (nor one at equal distance) of any q of the cell.
-__global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
+__global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av, int build_flists)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t nt = av.hdr[0];
     const uint32_t nit = (nt + 63) >> 6;
     extern __shared__ __attribute__((aligned(16))) float sbox_raw[];
+    __shared__ uint16_t s_tl[4][LVL_K[0]];                       // per wave: the cell's listed tiles (fine level: face-list build)
+    __shared__ unsigned long long s_pm[4][LVL_K[0] / 2];         // ... and which faces of each pair of tiles are candidates
     const uint32_t ntp = nit * 64;
     load_boxes(sbox_raw, av, ntp);
     __syncthreads();
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    static_assert(TILE_F == 32, "two tiles per wave step in the face-list build");
 #pragma unroll 1
     for (int l = 0; l < GRID_LEVELS; ++l) {
         const GridParams g = grid_params(av, l);
@@ -760,6 +799,7 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
             const double q[3] = { (double)qf[0], (double)qf[1], (double)qf[2] };
             float lb[NIT];
             int tA, tB;
+            float cfar_cell = 0.0f;
             (void)bounding_pass(sbox_raw, ntp, nit, lane, qf, lb, tA, tB);
             {   // every face lies in its tile's box: dist(q, mesh) >= min_t boxdist(c, t) - h for all q of the cell
                 float mn = lb[0];
@@ -767,7 +807,8 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
                 for (int it = 1; it < NIT; ++it) mn = lb[it] < mn ? lb[it] : mn;
                 mn = wave_min_f32(mn);
                 const float dl = __builtin_sqrtf(mn) * (1.0f - 1e-6f) - 0.5f * g.h2;
-                if (lane == 0) av.cfar[LVL_CELL0[l] + cell] = dl > 0.0f ? dl * dl * (1.0f - 1e-6f) : 0.0f;
+                cfar_cell = dl > 0.0f ? dl * dl * (1.0f - 1e-6f) : 0.0f;
+                if (lane == 0) av.cfar[LVL_CELL0[l] + cell] = cfar_cell;
             }
             double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
             int bid = 0x7fffffff;
@@ -775,6 +816,7 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
             seed_test(av, q, tA, tB, lane, best, bid, bc, myslot);
             const double seed = wave_min_f64(best);
             uint32_t info = CELL_OVERFLOW << 16;
+            uint32_t fcnt = 0, foff = 0;
             if (seed < 1e30) {                                           // false for inf / NaN: a cell next to nothing but degenerate faces
                 const uint32_t sslot = (uint32_t)__builtin_amdgcn_readlane((int)myslot, __builtin_ctzll(__ballot(best == seed)));
                 const float su = __builtin_sqrtf((float)seed * (1.0f + 1e-6f)) * (1.0f + 1e-6f) + g.h2 * (1.0f + 1e-6f);      // >= sqrt(seed) + 2 h
@@ -793,13 +835,60 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av)
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         if ((uint32_t)it >= nit) continue;
-                        if ((cand[it] >> lane) & 1ull) dst[at + (uint32_t)__builtin_popcountll(cand[it] & ((1ull << lane) - 1ull))] = (uint16_t)(it * 64 + lane);
+                        if ((cand[it] >> lane) & 1ull) {
+                            const uint32_t at_l = at + (uint32_t)__builtin_popcountll(cand[it] & ((1ull << lane) - 1ull));
+                            dst[at_l] = (uint16_t)(it * 64 + lane);
+                            if (l == 0) s_tl[wv][at_l] = (uint16_t)(it * 64 + lane);
+                        }
                         at += (uint32_t)__builtin_popcountll(cand[it]);
                     }
                     info = (cnt << 16) | sslot;
+                    // round 4, fine level: the FACES of the listed tiles that can hold the closest face (or one at equal distance) of a point of the cell:
+                    //   lb_f(c) <= sqrt(d2(c, seed face)) + 2 h   with lb_f the face's bounding-disc lower bound (disc_pass against su^2) --
+                    // dist(q, f) >= dist(c, f) - h >= lb_f(c) - h and dist(q, mesh) <= dist(c, seed face) + h for every q of the cell.  Lane = (tile of a
+                    // pair, face); candidate masks are kept per pair, the list is reserved with one atomic and written in a second sweep.
+                    if (l == 0 && build_flists && cfar_cell < AC_FLIST_MAXD * AC_FLIST_MAXD) {
+                        wave_sync_lds();
+                        const float limf = su * su * (1.0f + 1e-6f);
+                        const uint32_t steps = (cnt + 1u) >> 1;
+                        for (uint32_t st = 0; st < steps; ++st) {
+                            const uint32_t ti = 2u * st + (uint32_t)(lane >> 5);
+                            const bool have = ti < cnt;
+                            const uint32_t slot = (uint32_t)s_tl[wv][have ? ti : 0u] * TILE_F + (uint32_t)(lane & 31);
+                            const float4 sp = av.sph[2 * (size_t)slot], sn = av.sph[2 * (size_t)slot + 1];
+                            const unsigned long long pm = __ballot(have && disc_pass(qf[0], qf[1], qf[2], sp, sn, limf));
+                            if (lane == 0) s_pm[wv][st] = pm;
+                            fcnt += (uint32_t)__builtin_popcountll(pm);
+                        }
+                        wave_sync_lds();
+                        if (fcnt > 0xffffu) fcnt = 0;                                                     // (cannot happen: <= 128 tiles x 32 faces)
+                        if (fcnt) {
+                            uint32_t o = 0;
+                            if (lane == 0) o = atomicAdd(av.hdr + 2, (fcnt + 7u) & ~7u);                  // lists start on 16-byte boundaries
+                            foff = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+                            if (foff + ((fcnt + 7u) & ~7u) > FL_POOL) { if (lane == 0) atomicAdd(av.hdr + 3, 1u); fcnt = 0; foff = 0; }
+                        }
+                        if (fcnt) {
+                            uint32_t at2 = 0;
+                            for (uint32_t st = 0; st < steps; ++st) {
+                                const unsigned long long pm = s_pm[wv][st];
+                                const uint32_t ti = 2u * st + (uint32_t)(lane >> 5);
+                                if ((pm >> lane) & 1ull)
+                                    av.fl_pool[(size_t)foff + at2 + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull))] =
+                                        (uint16_t)((uint32_t)s_tl[wv][ti] * TILE_F + (uint32_t)(lane & 31));
+                                at2 += (uint32_t)__builtin_popcountll(pm);
+                            }
+                            const uint32_t padn = ((fcnt + 7u) & ~7u) - fcnt;                              // the tail of the last 8-entry group: never read as entries
+                            if ((uint32_t)lane < padn) av.fl_pool[(size_t)foff + fcnt + (uint32_t)lane] = 0;
+                        }
+                        wave_sync_lds();
+                    }
                 }
             }
-            if (lane == 0) av.cell[LVL_CELL0[l] + cell] = info;
+            if (lane == 0) {
+                av.cell[LVL_CELL0[l] + cell] = info;
+                if (l == 0) { av.fl_off[cell] = foff; av.fl_cnt[cell] = fcnt; }
+            }
         }
     }
 }
@@ -861,9 +950,17 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
                                                                  float *__restrict__ can_pts_f32, double *__restrict__ closest,
                                                                  double *__restrict__ dist2, int32_t *__restrict__ face_id,
                                                                  uint8_t *__restrict__ mask, float skip_thr,
-                                                                 const uint8_t *__restrict__ ray_dead, uint32_t spr, uint32_t perm_mul)
+                                                                 const uint8_t *__restrict__ ray_dead, uint32_t spr, uint32_t perm_mul, int fixup)
 {
     const int lane = threadIdx.x & 63;
+    // fixup != 0 (round 4): warp_samples_flist_kernel ran first and left mask[i] == FL_TODO on the samples it could not resolve (no fine cell / no
+    // face list); only those are searched here, every other lane is idle and writes nothing, and a workgroup without any returns at once
+    bool todo_lane = true;
+    if (fixup) {
+        const uint32_t i0 = (uint32_t)(((unsigned long long)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * perm_mul) % ((P + 63u) >> 6)) * 64u + (uint32_t)lane;
+        todo_lane = i0 < P && ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) < ((P + 63u) >> 6) && mask[i0] == FL_TODO;
+        if (!__syncthreads_or(todo_lane ? 1 : 0)) return;
+    }
     // which 64 samples this wave owns: consecutive waves take chunks perm_mul apart (a bijection: gcd(perm_mul, chunks) = 1, chosen by the host), so
     // that the eight waves of a workgroup -- and the two workgroups of a compute unit -- hold a mix of cheap chunks (rays far from the body, samples the
     // caller lets the search skip) and expensive ones instead of 16 neighbouring rays of the same kind
@@ -896,6 +993,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     // skip_thr >= 0 (the caller only wants mask and the canonical points of UNMASKED samples): a sample whose cell proves dist^2 >= threshold is
     // masked out whatever its closest face is -- it is not searched at all (dead).  Outside both grids the mesh is >= the coarse margin away.
     bool dead = ray_dead ? ray_dead[ii / spr] != 0 : false;              // skip_masked: the sample's whole ray is provably masked out (ray_cull_kernel)
+    if (!todo_lane) dead = true;                                         // fixup mode: already resolved (nothing is written for it below)
 #ifndef AC_ABL_NOGRID
     if (dead) mycnt = 0;
     else if (skip_thr >= 0.0f) {
@@ -941,6 +1039,8 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     wave_sync_lds();
     WP_TICK(7)
     uint32_t th = 0, tt = 0, gh = 0, gt = 0, fh = 0, ft = 0;             // wave-uniform ring positions: tile pairs, group triples, face pairs
+    // work counters of this wave (wave-uniform; one atomic each at the end -> hdr[HDR_WORK..]: what bench.py prices the search with)
+    uint32_t n_exact = 0, n_disc = 0, n_sub = 0, n_box = 0;
 
     // exact distances of n queued (sample, face) pairs, folded into the samples' running minima
     auto exact_batch = [&](uint32_t n) {
@@ -965,6 +1065,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             act = d2 == d2;                                              // a degenerate face (0 / 0 in an edge region) is never accepted
             d2b = __builtin_bit_cast(unsigned long long, d2);             // d2 >= +0: the bit patterns order like the values
         }
+        n_exact += n;
         const unsigned long long prev = sbest[s];
         wave_sync_lds();
         if (act) atomicMin(&sbest[s], d2b);
@@ -1009,6 +1110,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             gt += (uint32_t)__builtin_popcountll(pm);
         }
         th += np;
+        n_sub += 4u * np;
         WP_TICK(3)
     };
     // up to DSTEPS x 8 queued (sample, tile, group) triples: the group's 8 faces against their bounding discs (a lower bound of a face's distance)
@@ -1028,6 +1130,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             sp[u] = av.sph[2 * (size_t)slot[u]]; sn[u] = av.sph[2 * (size_t)slot[u] + 1];
         }
         gh += ne;
+        n_disc += 8u * ne;
 #pragma unroll
         for (int u = 0; u < DSTEPS; ++u) {
             if ((uint32_t)(8 * u) >= ne) break;                          // wave-uniform
@@ -1095,6 +1198,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             const float padq = 4e-7f * ((__builtin_fabsf(qf[0]) + __builtin_fabsf(qf[1])) + __builtin_fabsf(qf[2]));
             const double lim0 = lane_f64(myseed, (int)j) * (1.0 + 1e-9);
             const float lim0f = (float)lim0 * 1.000001f;
+            n_box += cnt;
             for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {                  // one step for the fine grid, up to three for the coarse one
                 if (c0) tl_mine = c0 == 64u ? tl_c1 : tl_c2;
                 const bool mine = c0 + (uint32_t)lane < cnt;
@@ -1117,6 +1221,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             uint32_t myslot;
             seed_test(av, q, tA, tB, lane, best, bid, bc, myslot);
             const double seed = wave_min_f64(best);                      // +inf if every seed face is degenerate
+            n_box += nt; n_exact += 2u * TILE_F;
             if (lane == 0) sbest[j] = __builtin_bit_cast(unsigned long long, seed);
             WP_TICK(2)
             const float lim0f = (float)(seed * (1.0 + 1e-9)) * 1.000001f;
@@ -1151,7 +1256,8 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     }
 #undef SBOX
     WP_TICK(5)
-    if (live && dead) {                                                  // certainly masked out: no closest face was looked for
+    if (live && !todo_lane) {
+    } else if (live && dead) {                                           // certainly masked out: no closest face was looked for
         mask[i] = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1176,8 +1282,130 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
         }
         finish_sample(i, p, rbc, rbest, (int)rb, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
     }
+    const uint32_t seeds = (uint32_t)__builtin_popcountll(__ballot(myseed < 1e30));          // exact tests of the cells' seed faces (stage 0)
+    if (lane == 0) {
+        unsigned long long *wk = reinterpret_cast<unsigned long long *>(av.hdr + HDR_WORK);
+        atomicAdd(wk, (unsigned long long)(n_exact + seeds)); atomicAdd(wk + 1, (unsigned long long)n_disc);
+        atomicAdd(wk + 2, (unsigned long long)n_sub); atomicAdd(wk + 3, (unsigned long long)n_box);
+    }
     WP_TICK(6)
     WP_END()
+}
+
+// ---- round 4: the search over per-cell FACE lists, lane = sample -------------------------------------------------------------------------------
+// A sample in a fine cell with a face list (accel_cells_kernel) needs no tile walk, no queues and no cross-lane traffic: its first bound is the exact
+// distance to the cell's seed face, its candidates are the cell's listed faces.  Per 8 list entries (one 16-byte load) the lane tests the bounding
+// discs against its running bound and remembers the survivors in a bit mask; the survivors of all 64 lanes then go through the fp64 Ericson routine
+// together, one per lane and trip (re-tested against the lane's bound of the moment first), so a trip is as full as the lanes' survivor counts allow.
+// (d2, face id) is a lexicographic minimum over a superset of the possible winners: the exhaustive kernel's answer bit for bit, ties -> lowest id.
+// Samples that have no list are marked FL_TODO in `mask` and resolved by warp_samples_accel_kernel's fixup pass.
+__device__ __forceinline__ uint32_t fl_entry(const uint4 &e, int k)      // k = 0..7: the k-th 16-bit entry
+{
+    const uint32_t w = k < 4 ? (k < 2 ? e.x : e.y) : (k < 6 ? e.z : e.w);
+    return (k & 1) ? (w >> 16) : (w & 0xffffu);
+}
+__global__ __launch_bounds__(256) void warp_samples_flist_kernel(const float *__restrict__ pts, const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                                 const double *__restrict__ T, uint32_t P, double threshold, AccelView av,
+                                                                 double *__restrict__ can_pts, float *__restrict__ can_pts_f32, double *__restrict__ closest,
+                                                                 double *__restrict__ dist2, int32_t *__restrict__ face_id, uint8_t *__restrict__ mask,
+                                                                 float skip_thr, const uint8_t *__restrict__ ray_dead, uint32_t spr)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < P;
+    const uint32_t ii = live ? i : P - 1;
+    const float pf[3] = { pts[3 * (size_t)ii], pts[3 * (size_t)ii + 1], pts[3 * (size_t)ii + 2] };
+    const double p[3] = { (double)pf[0], (double)pf[1], (double)pf[2] };
+    bool dead = ray_dead ? ray_dead[ii / spr] != 0 : false;
+    if (!dead && skip_thr >= 0.0f) {                                     // as in the tile-walk kernel: the cell grids may prove the sample masked out
+        bool in_any = false;
+#pragma unroll
+        for (int l = 0; l < GRID_LEVELS; ++l) {
+            const uint32_t cell = grid_cell(grid_params(av, l), pf);
+            if (cell != ~0u && !in_any) { in_any = true; dead = av.cfar[LVL_CELL0[l] + cell] >= skip_thr; }
+        }
+        if (!in_any && av.hdr[HDR_LVL + HDR_LVL_STRIDE * (GRID_LEVELS - 1) + 8] != 0u)
+            dead = AC_GRID_MARGIN1 * AC_GRID_MARGIN1 * (1.0f - 1e-5f) >= skip_thr;
+    }
+    uint32_t off = 0, cnt = 0;
+    double best = __builtin_inf();
+    if (live && !dead) {
+        const uint32_t cell = grid_cell(grid_params(av, 0), pf);
+        if (cell != ~0u) {
+            cnt = av.fl_cnt[cell];
+            if (cnt) {
+                off = av.fl_off[cell];
+                const uint32_t slot = av.cell[cell] & 0xffffu;           // the seed face: a real face, its exact distance is the first bound
+                const float *tp = av.tri + (size_t)slot * 9;
+                const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
+                             c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
+                double cq[3];
+                closest_pt_tri(p, a, b, c, cq);
+                const double ex = p[0] - cq[0], ey = p[1] - cq[1], ez = p[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
+                if (d2 < 1e30) best = d2; else cnt = 0;                  // a degenerate seed for this sample: the tile walk handles it
+            }
+        }
+    }
+    const bool scan = cnt != 0;
+    uint32_t bid = 0x7fffffffu;
+    for (uint32_t k0 = 0; __ballot(scan && k0 < cnt) != 0ull; k0 += 8) {
+        const bool mine = scan && k0 < cnt;
+        uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+        if (mine) ent = *reinterpret_cast<const uint4 *>(av.fl_pool + (size_t)off + k0);
+        const uint32_t left = mine ? cnt - k0 : 0u;
+        float limf = (float)(best * (1.0 + 1e-9)) * 1.000001f;
+        uint32_t pass = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t slot = fl_entry(ent, e);
+            const float4 sp = av.sph[2 * (size_t)slot], sn = av.sph[2 * (size_t)slot + 1];
+            if ((uint32_t)e < left && disc_pass(pf[0], pf[1], pf[2], sp, sn, limf)) pass |= 1u << e;
+        }
+        while (__ballot(pass != 0u) != 0ull) {
+            if (pass) {
+                const int e = __builtin_ctz(pass);
+                pass &= pass - 1u;
+                const uint32_t slot = fl_entry(ent, e);
+                limf = (float)(best * (1.0 + 1e-9)) * 1.000001f;         // the bound may have dropped since the disc test
+                const float4 sp = av.sph[2 * (size_t)slot], sn = av.sph[2 * (size_t)slot + 1];
+                if (disc_pass(pf[0], pf[1], pf[2], sp, sn, limf)) {
+                    const float *tp = av.tri + (size_t)slot * 9;
+                    const double a[3] = { (double)tp[0], (double)tp[1], (double)tp[2] }, b[3] = { (double)tp[3], (double)tp[4], (double)tp[5] },
+                                 c[3] = { (double)tp[6], (double)tp[7], (double)tp[8] };
+                    double cq[3];
+                    closest_pt_tri(p, a, b, c, cq);
+                    const double ex = p[0] - cq[0], ey = p[1] - cq[1], ez = p[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
+                    const uint32_t id = (uint32_t)av.oid[slot];
+                    if (d2 < best || (d2 == best && id < bid)) { best = d2; bid = id; }      // NaN (degenerate face) compares false: never accepted
+                }
+            }
+        }
+    }
+    if (!live) return;
+    if (dead) {                                                          // certainly masked out: no closest face was looked for
+        mask[i] = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (can_pts) can_pts[3 * (size_t)i + r] = p[r];
+            if (can_pts_f32) can_pts_f32[3 * (size_t)i + r] = pf[r];
+            if (closest) closest[3 * (size_t)i + r] = p[r];
+        }
+        if (dist2) dist2[i] = __builtin_inf();
+        if (face_id) face_id[i] = 0;
+    } else if (!scan) {
+        mask[i] = FL_TODO;
+    } else {
+        uint32_t rb = bid;
+        double rbc[3] = { 0.0, 0.0, 0.0 };
+        if (rb == 0x7fffffffu) rb = 0;
+        else {
+            const int32_t f0v = faces[3 * (size_t)rb], f1v = faces[3 * (size_t)rb + 1], f2v = faces[3 * (size_t)rb + 2];
+            double a[3], b[3], c[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { a[k] = (double)verts[3 * (size_t)f0v + k]; b[k] = (double)verts[3 * (size_t)f1v + k]; c[k] = (double)verts[3 * (size_t)f2v + k]; }
+            closest_pt_tri(p, a, b, c, rbc);
+        }
+        finish_sample(i, p, rbc, best, (int)rb, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
+    }
 }
 
 }  // namespace
@@ -1227,11 +1455,29 @@ AC_API int ac_warp_samples(const float *pts, const float *verts, const int32_t *
     return ac::check_launch("warp_samples");
 }
 
+// The face-list search (warp_samples_flist_kernel + the lists accel_cells_kernel builds for it) is an opt-in experiment: AC_WARP_FLIST=1 in the
+// environment of the process, read once.  Measured on the bench frame (profiles/r04_experiments.txt): same bits, slower -- see DESIGN.md 5.3.
+static int warp_flist_enabled()
+{
+    static const int on = []() { const char *e = getenv("AC_WARP_FLIST"); return (e && e[0] == '1') ? 1 : 0; }();
+    return on;
+}
+
+AC_API int ac_warp_accel_work(const void *accel, unsigned long long out[4], ac_stream_t stream)
+{
+    if (!accel || !out) { ac::set_error("warp_accel_work: NULL argument"); return AC_ERR_BAD_ARG; }
+    const AccelView av = accel_view(const_cast<void *>(accel));
+    if (hipMemcpyAsync(out, av.hdr + HDR_WORK, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { ac::set_error("warp_accel_work: copy failed"); return AC_ERR_LAUNCH; }
+    return AC_OK;
+}
+
 AC_API size_t ac_warp_accel_bytes(uint32_t F)
 {
     if (F == 0 || F > MAX_ACCEL_FACES) return 0;
     size_t o[ACCEL_SEGS];
-    return accel_offsets(o);
+    const size_t all = accel_offsets(o);
+    return warp_flist_enabled() ? all : o[ACCEL_SEGS - 1];          // the face-list pool (the last segment, 96 MB) only when the experiment is on
 }
 
 AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_t V, uint32_t F, void *accel, size_t accel_bytes,
@@ -1251,7 +1497,7 @@ AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_
     const size_t lds_c = (size_t)NB * ntp * sizeof(float);
     static uint64_t seen_c = 0;
     ac::allow_dynamic_lds(seen_c, reinterpret_cast<const void *>(accel_cells_kernel), (size_t)NB * MAX_TILES * sizeof(float));
-    hipLaunchKernelGGL(accel_cells_kernel, dim3(4 * (unsigned)ac::cu_count()), dim3(256), lds_c, (hipStream_t)stream, av);
+    hipLaunchKernelGGL(accel_cells_kernel, dim3(4 * (unsigned)ac::cu_count()), dim3(256), lds_c, (hipStream_t)stream, av, warp_flist_enabled());
     return ac::check_launch("warp_accel_build");
 }
 
@@ -1279,9 +1525,16 @@ int ac::warp_samples_accel_impl(const float *pts, const float *verts, const int3
         while (b) { const uint32_t t = a % b; a = b; b = t; }
         if (a == 1u) { perm_mul = m; break; }
     }
+    // round 4: samples in fine cells with a face list are resolved by the lane-per-sample kernel; the tile-walk kernel follows as a fixup pass over
+    // the samples it marked (AC_WARP_FLIST=0 in the environment: the tile walk alone, as in rounds 2 - 3 -- same results, for A/B timing)
+    const int use_flist = warp_flist_enabled();
+    const float skip_thr = skip_far ? (float)threshold * (1.0f + 1e-6f) : -1.0f;
+    const uint32_t spr = samples_per_ray ? samples_per_ray : 1u;
+    if (use_flist)
+        hipLaunchKernelGGL(warp_samples_flist_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av, can_pts,
+                           can_pts_f32, closest, dist2, face_id, mask, skip_thr, ray_dead, spr);
     hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + PK_WAVES - 1) / PK_WAVES), dim3(PK_WAVES * 64), lds, (hipStream_t)stream, pts, verts, faces, T, P,
-                       threshold, av, can_pts, can_pts_f32, closest, dist2, face_id, mask,
-                       skip_far ? (float)threshold * (1.0f + 1e-6f) : -1.0f, ray_dead, samples_per_ray ? samples_per_ray : 1u, perm_mul);
+                       threshold, av, can_pts, can_pts_f32, closest, dist2, face_id, mask, skip_thr, ray_dead, spr, perm_mul, use_flist);
     return ac::check_launch("warp_samples_accel");
 }
 

@@ -183,6 +183,9 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
                 "render_rays_warped")
         res["can_mid"] = scratch[offs[3]:offs[3] + N * T * 12].view(_F32).view(N, T, 3)
         res["mask"] = scratch[offs[4]:offs[4] + N * T].view(N, T)
+        if skip_masked and warp.accel is not None and upsample_steps > 0:      # rays the cell grids proved masked out (never sampled): the scratch's last segment
+            tail = (N + 255) & ~255
+            res["ray_dead"] = scratch[int(nbytes) - tail:int(nbytes) - tail + N]
         if warp.use_mesh_guide:          # the mesh-guided range the launch sampled in (inf where the ray misses the body): what a backward pass needs
             res["near_m"] = scratch[offs[0]:offs[0] + N * 4].view(_F32)
             res["far_m"] = scratch[offs[1]:offs[1] + N * 4].view(_F32)
@@ -295,6 +298,15 @@ class WarpMesh:
         self.use_mesh_guide = bool(use_mesh_guide)
         self.c = L.ac_warp_mesh(self.verts.data_ptr(), self.faces.data_ptr(), self.T.data_ptr(), self.verts.shape[0], self.faces.shape[0],
                                 float(threshold), float(geo_threshold), int(bool(use_mesh_guide)), L.ptr(self.accel))
+
+
+    def work_counters(self):
+        """what the closest-face searches have done on this frame's structure since it was built (ac_warp_accel_work): dict of counts"""
+        if self.accel is None:
+            return None
+        out = (C.c_ulonglong * 4)()
+        L.check(L.lib().ac_warp_accel_work(self.accel.data_ptr(), C.addressof(out), L.current_stream(self.accel.device)), "warp_accel_work")
+        return dict(exact_tests=int(out[0]), disc_tests=int(out[1]), subbox_tests=int(out[2]), box_tests=int(out[3]))
 
 
 _CORE_SCRATCH = {}

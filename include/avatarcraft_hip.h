@@ -246,6 +246,14 @@ int ac_warp_samples(const float *pts, const float *verts, const int32_t *faces, 
  * bounding boxes; ac_warp_samples_accel then tests only the tiles whose box can contain the closest face (exact culling).
  * F <= 16384 (SMPL: 13776); ac_warp_accel_bytes returns 0 for meshes outside that range. */
 size_t ac_warp_accel_bytes(uint32_t F);
+/* Measurement accessors (bench.py's posed-frame roofline; no effect on results):
+ * ac_warp_accel_work: the work the searches have done on this structure since its last build -- out[0] exact fp64 point-triangle tests,
+ *   out[1] bounding-disc tests, out[2] sub-box tests, out[3] tile-box tests (counted per wave, one atomic each; waits for `stream`).
+ * ac_debug_warped_phases(1): ac_render_rays_warped records HIP events at its phase boundaries; ac_debug_warped_phase_ms returns the five intervals of
+ *   the last call in ms: near / far + coarse points + ray cull | first search | up-sampling pass | second search | final pass. */
+int ac_warp_accel_work(const void *accel, unsigned long long out[4], ac_stream_t stream);
+void ac_debug_warped_phases(int enable);
+int ac_debug_warped_phase_ms(float out[5]);
 int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_t V, uint32_t F, void *accel, size_t accel_bytes,
                         ac_stream_t stream);
 int ac_warp_samples_accel(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V, uint32_t F,
