@@ -103,6 +103,7 @@ _SIGS = {
     "ac_sdf_stencil_backward_scratch": ([u32], C.c_size_t),
     "ac_sdf_stencil_backward": ([C.POINTER(ac_field), vp, vp, vp, u32, f32, f32, vp, vp, vp, C.c_size_t, vp], C.c_int),
     "ac_color_forward": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),
+    "ac_render_handoff_timeouts": ([vp, vp], C.c_int),
     "ac_warp_accel_work": ([vp, vp, vp], C.c_int),
     "ac_debug_warped_phases": ([C.c_int], None),
     "ac_debug_warped_phase_ms": ([vp], C.c_int),

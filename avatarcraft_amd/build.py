@@ -43,6 +43,29 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+_PROBED = {}
+
+
+def _supported(hipcc, flags):
+    """the per-file scheduler strategies are internal LLVM options (-mllvm ...): an older or newer ROCm may not know them.  They change instruction
+    ORDER only (every kernel stays bit-identical), so a toolchain that rejects them builds without them, with a warning -- instead of not at all."""
+    key = tuple(flags)
+    if not flags:
+        return True
+    if key not in _PROBED:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "probe.hip")
+            with open(src, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n__global__ void k(float *p) { p[0] = 1.0f; }\n")
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-c", src, "-o", os.path.join(td, "probe.o")] + list(flags),
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        _PROBED[key] = r.returncode == 0
+        if not _PROBED[key]:
+            print(f"avatarcraft_amd.build: this hipcc rejects {' '.join(flags)} (scheduling only): building without it", file=sys.stderr)
+    return _PROBED[key]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -65,7 +88,8 @@ def build(force=False, verbose=False):
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        extra = PER_FILE_FLAGS.get(os.path.basename(s), [])
+        cmd = [hipcc] + FLAGS + (extra if _supported(hipcc, extra) else []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -784,9 +784,12 @@ int hash_stencil_backward_split(const float *grad, const float *x, const int32_t
                                 uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
                                 ac_stream_t stream, uint32_t split_level, ac_stream_t side_stream)
 {
-    if (int rc = check("hash_stencil_backward", C, L, offsets_host, eps, bound)) return rc;
-    if (B == 0) return AC_OK;
-    if (!grad || !x || !grad_embeddings) { ac::set_error("hash_stencil_backward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    // whatever happens below, a caller that passed a side stream will enqueue work on it that reads the table gradient: on every early return the side
+    // stream is ordered behind what `stream` holds so far (the accumulations of earlier patches), like the normal path orders it behind the split launch
+    auto leave = [&](int rc) { if (side_stream) (void)order_side_stream((hipStream_t)stream, (hipStream_t)side_stream); return rc; };
+    if (int rc = check("hash_stencil_backward", C, L, offsets_host, eps, bound)) return leave(rc);
+    if (B == 0) return leave(AC_OK);
+    if (!grad || !x || !grad_embeddings) { ac::set_error("hash_stencil_backward: NULL buffer"); return leave(AC_ERR_BAD_ARG); }
     ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
     const float two_bound = (float)(2.0 * (double)bound);
     hipStream_t st = (hipStream_t)stream;

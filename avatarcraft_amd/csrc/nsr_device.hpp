@@ -140,6 +140,7 @@ struct RenderArgs {
     // slot's next launch; seg_flags carry the launch generation (gen << 4 | finished segments), so they need no clearing either: no memset and no reduction
     // launch around the render kernel.
     uint32_t *done_counter;
+    uint32_t *handoff_timeouts;    // device word counting segment hand-offs that timed out (ac_render_handoff_timeouts), or NULL
     float *eik_red;
     uint32_t gen;
     int ex_from;                   // the per-sample outputs (EX kernels) are kept for rays >= ex_from only, at row ray - ex_from of arrays with ex_rows rows

@@ -373,8 +373,13 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                     __builtin_amdgcn_s_sleep(8); ++spins;       // (bounded: ~1 s; a ray's previous segment takes ~100 us)
                 }
                 timed_out = spins >= (1 << 21);
+                if (timed_out && a.handoff_timeouts) atomicAdd(a.handoff_timeouts, 1u);     // the host can ask (ac_render_handoff_timeouts): a lost hand-off is an ERROR, not only a NaN pixel
             }
             timed_out = __builtin_amdgcn_readfirstlane(timed_out);
+            // acquire, pairing with the publisher's release: everything the publishing wave stored before its flag is visible to the loads below.  (The
+            // state itself is read with agent-scope atomic loads = from L2, so on this hardware the fence costs one L1 invalidate per segment; it is
+            // here so that correctness does not rest on "same XCD" or on how workgroups happen to be dispatched.)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             wave_sync();
             const uint32_t *st = reinterpret_cast<const uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
             if constexpr (MODE != MODE_FINAL)
@@ -553,9 +558,10 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 const float cv = lane == 0 ? cT : accs[lane];
                 __hip_atomic_store(st + MAXT + lane, __float_as_uint(cv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every lane's state stores have left the wave ...
             wave_sync();
-            if (lane == 0) __hip_atomic_store(a.seg_flags + ray, (a.gen << 4) | (uint32_t)(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ... and the flag is a RELEASE store at agent scope: ordered behind them for any wave of the device that acquires it
+            if (lane == 0) __hip_atomic_store(a.seg_flags + ray, (a.gen << 4) | (uint32_t)(seg + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             wave_sync();
             continue;
         }
@@ -784,17 +790,29 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
 #ifndef AC_RAY_SEGMENTS
 #define AC_RAY_SEGMENTS 4           // segments a ray is cut into (1 = whole rays as work items, rounds 1 - 2; at most 8)
 #endif
-struct SegSlot { char *p; size_t bytes; uint32_t gen; };
+struct SegSlot { char *p; size_t bytes; uint32_t gen; uint64_t last_use; };
+constexpr size_t SEG_POOL_MAX = 32;        // (device, stream) slots kept; beyond that the least recently used one is freed (stream churn must not grow device memory without bound)
+static std::mutex g_seg_mu;
+static std::map<std::pair<int, hipStream_t>, SegSlot> g_seg_pool;
+static uint64_t g_seg_clock = 0;
 // -> the slot's memory and the generation of this launch (1 .. 2^28 - 1): a slot is zeroed when it is allocated; after that every launch leaves its
 // counters at zero (the kernel's last workgroup re-arms them) and tags its per-ray flags with its generation, so nothing is cleared between launches
 static char *seg_scratch(size_t need, uint32_t &gen, hipStream_t stream)
 {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, SegSlot> pool;
+    std::mutex &mu = g_seg_mu;
+    auto &pool = g_seg_pool;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     std::lock_guard<std::mutex> lock(mu);
-    SegSlot &sl = pool[std::make_pair(dev, stream)];
+    const auto key = std::make_pair(dev, stream);
+    if (pool.find(key) == pool.end() && pool.size() >= SEG_POOL_MAX) {   // evict the least recently used slot (hipFree waits for the device: nothing can still use it)
+        auto victim = pool.begin();
+        for (auto it = pool.begin(); it != pool.end(); ++it) if (it->second.last_use < victim->second.last_use) victim = it;
+        if (victim->second.p) (void)hipFree(victim->second.p);
+        pool.erase(victim);
+    }
+    SegSlot &sl = pool[key];
+    sl.last_use = ++g_seg_clock;
     if (sl.bytes < need) {
         if (sl.p) (void)hipFree(sl.p);                                   // (synchronises the device: no launch can still be using the slot)
         sl.p = nullptr; sl.bytes = 0; sl.gen = 0;
@@ -811,6 +829,26 @@ static char *seg_scratch(size_t need, uint32_t &gen, hipStream_t stream)
     }
     gen = sl.gen;
     return sl.p;
+}
+
+// hand-offs that timed out (a taker waited ~1 s for a segment that was never published: its pixel is NaN) on the slot of (current device, stream), over
+// the life of that slot; waits for the stream.  0 on a healthy run -- the GPU tier asserts it after its soak and co-residency tests.
+AC_API int ac_render_handoff_timeouts(ac_stream_t stream, uint32_t *count)
+{
+    if (!count) { ac::set_error("render_handoff_timeouts: NULL count"); return AC_ERR_BAD_ARG; }
+    *count = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    char *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_seg_mu);
+        auto it = g_seg_pool.find(std::make_pair(dev, (hipStream_t)stream));
+        if (it != g_seg_pool.end()) p = it->second.p;
+    }
+    if (!p) return AC_OK;                                                // no render has run on this stream
+    if (hipMemcpyAsync(count, p + 260, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { ac::set_error("render_handoff_timeouts: copy failed"); return AC_ERR_LAUNCH; }
+    return AC_OK;
 }
 
 template <int MODE, bool FAST, bool EX>
@@ -836,6 +874,7 @@ static void launch_render_p(const RenderArgs &a, hipStream_t stream)
         char *sc = seg_scratch(need, gen, stream);
         b.ray_counter = reinterpret_cast<uint32_t *>(sc);
         b.done_counter = sc ? reinterpret_cast<uint32_t *>(sc + 256) : nullptr;
+        b.handoff_timeouts = sc ? reinterpret_cast<uint32_t *>(sc + 260) : nullptr;      // (never re-armed: counts over the life of the slot)
         b.gen = gen;
         b.eik_red = (MODE == MODE_UPSAMPLE) ? nullptr : a.out.eik_reduced;
         b.seg_flags = sn > 1 ? reinterpret_cast<uint32_t *>(sc + head) : nullptr;

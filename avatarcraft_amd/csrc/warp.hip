@@ -313,8 +313,9 @@ constexpr uint32_t CELL_OVERFLOW = 0xffffu;      // count field of a cell withou
 #endif
 constexpr int HDR_WORDS = 64;
 constexpr int HDR_LVL = 8, HDR_LVL_STRIDE = 12;
-constexpr int HDR_WORK = 40;                     // hdr[40..47]: four 64-bit work counters of the searches since the build: exact point-triangle tests,
-                                                 // bounding-disc tests, sub-box tests, tile-box tests (zeroed by accel_grid_setup_kernel)
+constexpr int WORK_SLOTS = 256;                  // AccelView::work: [WORK_SLOTS][4] 64-bit work counters of the searches since the build (exact point-triangle
+                                                 // tests, bounding-disc tests, sub-box tests, tile-box tests), a wave adds to slot (its index % WORK_SLOTS): spread
+                                                 // over slots because ~10^5 waves adding to ONE address cost the frame 1.4 ms (round 4, measured); zeroed by the build
 // hdr words: [0] tiles, [1] F, [4..7] debug counters (64-bit x 2), level l at [8 + 12 l]: grid origin (3 floats), 1 / cell size, 2 x padded half
 // diagonal of a cell (float), nx, ny, nz, cells
 struct AccelView {                   // pointers into the caller's accel buffer
@@ -332,6 +333,7 @@ struct AccelView {                   // pointers into the caller's accel buffer
     uint32_t *fl_off;                // [LVL_CELLS[0]] first entry of the cell's list in fl_pool (a multiple of 8)
     uint32_t *fl_cnt;                // [LVL_CELLS[0]] entries (0: the cell has no face list: too far, tile-list overflow, pool exhausted, degenerate seed)
     uint16_t *fl_pool;               // [FL_POOL] slots; hdr[2] = entries handed out, hdr[3] = cells that did not fit
+    unsigned long long *work;        // [WORK_SLOTS][4] work counters (see WORK_SLOTS)
 };
 constexpr int SUBS = 4, SUB_F = TILE_F / SUBS;   // sub-boxes per tile, faces per sub-box
 constexpr uint32_t FL_POOL = 48u << 20;          // 48 M entries (96 MB): ~ 80 K listed cells x 250 faces for an SMPL-sized body, twice over
@@ -339,14 +341,14 @@ constexpr uint32_t FL_POOL = 48u << 20;          // 48 M entries (96 MB): ~ 80 K
 #define AC_FLIST_MAXD 0.25f                      // fine cells whose every point is provably farther than this from the mesh get no face list
 #endif
 constexpr uint8_t FL_TODO = 2;                   // mask value of a sample the face-list kernel leaves to the tile-walk kernel (fixup pass)
-constexpr int ACCEL_SEGS = 13;
+constexpr int ACCEL_SEGS = 14;
 __host__ __device__ inline size_t accel_offsets(size_t (&o)[ACCEL_SEGS])
 {
     size_t off = 0;
     const size_t sz[ACCEL_SEGS] = { HDR_WORDS * 4, MAX_ACCEL_FACES * 4, (size_t)MAX_ACCEL_FACES * 36, (size_t)MAX_ACCEL_FACES * 4, (size_t)NB * MAX_TILES * 4,
                                     (size_t)MAX_ACCEL_FACES * 32, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4, (size_t)CTL_ENTRIES * 2,
                                     (size_t)MAX_TILES * SUBS * 6 * 4, ((size_t)LVL_CELLS[0] + LVL_CELLS[1]) * 4,
-                                    (size_t)LVL_CELLS[0] * 4, (size_t)LVL_CELLS[0] * 4, (size_t)FL_POOL * 2 };
+                                    (size_t)LVL_CELLS[0] * 4, (size_t)LVL_CELLS[0] * 4, (size_t)WORK_SLOTS * 4 * 8, (size_t)FL_POOL * 2 };
     for (int i = 0; i < ACCEL_SEGS; ++i) { o[i] = off; off += (sz[i] + 255) & ~(size_t)255; }
     return off;
 }
@@ -359,7 +361,8 @@ __host__ __device__ inline AccelView accel_view(void *base)
     v.tri = reinterpret_cast<float *>(b + o[2]); v.oid = reinterpret_cast<int32_t *>(b + o[3]); v.box = reinterpret_cast<float *>(b + o[4]);
     v.sph = reinterpret_cast<float4 *>(b + o[5]);
     v.cell = reinterpret_cast<uint32_t *>(b + o[6]); v.ctl = reinterpret_cast<uint16_t *>(b + o[7]); v.sub = reinterpret_cast<float *>(b + o[8]); v.cfar = reinterpret_cast<float *>(b + o[9]);
-    v.fl_off = reinterpret_cast<uint32_t *>(b + o[10]); v.fl_cnt = reinterpret_cast<uint32_t *>(b + o[11]); v.fl_pool = reinterpret_cast<uint16_t *>(b + o[12]);
+    v.fl_off = reinterpret_cast<uint32_t *>(b + o[10]); v.fl_cnt = reinterpret_cast<uint32_t *>(b + o[11]);
+    v.work = reinterpret_cast<unsigned long long *>(b + o[12]); v.fl_pool = reinterpret_cast<uint16_t *>(b + o[13]);
     return v;
 }
 
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(1024) void accel_grid_setup_kernel(const float *__r
     }
     if (t < 6) av.hdr[HDR_BBOX + t] = __builtin_bit_cast(uint32_t, red[t][0]);
     if (t == 6) { av.hdr[2] = 0u; av.hdr[3] = 0u; }                  // face-list pool: nothing handed out yet
-    if (t >= 8 && t < 16) av.hdr[HDR_WORK + t - 8] = 0u;             // work counters of the searches on this structure
+    for (uint32_t e = t; e < (uint32_t)WORK_SLOTS * 4u; e += 1024) av.work[e] = 0ull;      // work counters of the searches on this structure
     if (t < (uint32_t)GRID_LEVELS) {
         const int l = (int)t;
         const float margin = l == 0 ? AC_GRID_MARGIN0 : AC_GRID_MARGIN1;
@@ -1039,7 +1042,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     wave_sync_lds();
     WP_TICK(7)
     uint32_t th = 0, tt = 0, gh = 0, gt = 0, fh = 0, ft = 0;             // wave-uniform ring positions: tile pairs, group triples, face pairs
-    // work counters of this wave (wave-uniform; one atomic each at the end -> hdr[HDR_WORK..]: what bench.py prices the search with)
+    // work counters of this wave (wave-uniform; one atomic each at the end -> AccelView::work: what bench.py prices the search with)
     uint32_t n_exact = 0, n_disc = 0, n_sub = 0, n_box = 0;
 
     // exact distances of n queued (sample, face) pairs, folded into the samples' running minima
@@ -1284,7 +1287,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     }
     const uint32_t seeds = (uint32_t)__builtin_popcountll(__ballot(myseed < 1e30));          // exact tests of the cells' seed faces (stage 0)
     if (lane == 0) {
-        unsigned long long *wk = reinterpret_cast<unsigned long long *>(av.hdr + HDR_WORK);
+        unsigned long long *wk = av.work + 4 * (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % (uint32_t)WORK_SLOTS);
         atomicAdd(wk, (unsigned long long)(n_exact + seeds)); atomicAdd(wk + 1, (unsigned long long)n_disc);
         atomicAdd(wk + 2, (unsigned long long)n_sub); atomicAdd(wk + 3, (unsigned long long)n_box);
     }
@@ -1467,8 +1470,10 @@ AC_API int ac_warp_accel_work(const void *accel, unsigned long long out[4], ac_s
 {
     if (!accel || !out) { ac::set_error("warp_accel_work: NULL argument"); return AC_ERR_BAD_ARG; }
     const AccelView av = accel_view(const_cast<void *>(accel));
-    if (hipMemcpyAsync(out, av.hdr + HDR_WORK, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+    static unsigned long long host[WORK_SLOTS * 4];
+    if (hipMemcpyAsync(host, av.work, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { ac::set_error("warp_accel_work: copy failed"); return AC_ERR_LAUNCH; }
+    for (int k = 0; k < 4; ++k) { out[k] = 0; for (int sl = 0; sl < WORK_SLOTS; ++sl) out[k] += host[4 * sl + k]; }
     return AC_OK;
 }
 

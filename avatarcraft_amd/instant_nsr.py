@@ -76,7 +76,10 @@ class NeRFRenderer(nn.Module):
 
     def __deepcopy__(self, memo):
         # (through pickling: the caches are dropped by __getstate__, and torch's own deepcopy refuses the non-leaf `weight` attribute that the
-        # old-style weight_norm hook leaves on every layer -- the reference's networks cannot be deep-copied at all)
+        # old-style weight_norm hook leaves on every layer -- the reference's networks cannot be deep-copied at all).
+        # LIMITATION: only the module itself is registered in `memo`, not its parameters / buffers: deep-copying a CONTAINER that holds this net
+        # and an optimizer over its parameters yields an optimizer that still points at the ORIGINAL parameters.  Copy the net, then build the
+        # optimizer on the copy (what stylize.py / reconstruct.py do with their checkpoints: state_dicts, never live objects).
         import io
         buf = io.BytesIO()
         torch.save(self, buf)

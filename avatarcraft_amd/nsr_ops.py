@@ -195,6 +195,15 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     return res
 
 
+def handoff_timeouts(device=None):
+    """segment hand-offs of the render launches on the CURRENT stream of `device` that timed out (ac_render_handoff_timeouts): 0 on a healthy run"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    n = C.c_uint32(0)
+    with torch.cuda.device(dev):
+        L.check(L.lib().ac_render_handoff_timeouts(L.current_stream(dev), C.addressof(n)), "render_handoff_timeouts")
+    return int(n.value)
+
+
 def render_rays_pair(field, rays_o, rays_d, noise2, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg2=None, cos_anneal_ratio=1.0,
                      normal_epsilon_ratio=0.0, precision="exact", out=None, events=None, keep_weights=False):
     """ac_render_rays_pair: the same N rays rendered twice in ONE launch -- copy a with noise2[0] / bg2[0] (per-ray outputs only), copy b with

@@ -311,6 +311,12 @@ size_t ac_sdf_stencil_backward_scratch(uint32_t B);
 int ac_sdf_stencil_backward(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
                             float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
+/* Liveness of the renderer's segment hand-off (a ray's final pass is cut into segments that different waves may take; a taker waits, bounded to ~1 s,
+ * for the previous segment's state).  A timed-out hand-off poisons the pixel with NaN AND is counted here, per (device, stream), over the life of the
+ * launch scratch of that stream: 0 on a healthy run.  Waits for `stream`.  The render launches tag their scratch with a host-side generation number
+ * baked into the kernel arguments: they must NOT be captured into a hipGraph (a replay would match the flags of its previous run). */
+int ac_render_handoff_timeouts(ac_stream_t stream, uint32_t *count);
+
 /* ---- field evaluation on PACKED samples: the body of NeRFRenderer.run_cuda between raymarching.march_rays[_train] and
  * raymarching.composite_rays[_train].  The reference dispatches cuda_ray=True renders to `run_cuda` (models/instant_nsr.py:362-363) but never defines it
  * (SURVEY 0.1); the per-sample arithmetic is run()'s render core (:205-243) with the marcher's step as the section length:

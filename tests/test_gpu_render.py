@@ -554,6 +554,8 @@ def test_render_beside_a_foreign_long_kernel(env):
                 outs.append({k: v for k, v in nsr_ops.render_rays(f, o, d, 64, 64, 1.6, inv_s, out={}).items() if k in keys})
             e1.record()
         torch.cuda.synchronize()
+        with torch.cuda.stream(main):
+            assert nsr_ops.handoff_timeouts(dev) == 0                  # no taker ever gave up waiting for a segment (it would also be a NaN pixel)
         bad = sum(int(not torch.equal(out[k], ref[rep % 2][k])) for rep, out in enumerate(outs) for k in keys)
         assert all(bool(torch.isfinite(out["image"]).all()) for out in outs)
         assert bad == 0, (with_gemm, bad)
