@@ -426,6 +426,44 @@ def time_real_sd_step(dev, p, table, steps=3):
             "model": why, "dtype": "f32 (the reference loads the pipelines without a dtype)", "phase_ms": {k: round(v, 3) for k, v in phases.items()}}
 
 
+def time_sd_arch_step(dev, p, table, steps=2):
+    """What one stylisation step costs WITH a guidance of Stable-Diffusion 1.5's size (models/diffusion.py:92-149: VAE encoder with grad at 512 x 512, UNet
+    on two 64 x 64 latents, classifier-free guidance) when the real networks are absent: avatarcraft_amd.sd_arch restates their published architecture
+    (859.5 M + 34.2 M parameters, parameter counts equal to the checkpoint's) with RANDOM weights, fp32 like the reference loads them.  A clock, not a
+    guidance: the step's time does not depend on the weights' values, its images would."""
+    from avatarcraft_amd import sd_arch
+    from avatarcraft_amd.guidance import StableDiffusion, SDSGuidance
+    from avatarcraft_amd.stylize import sds_step, flat_grad_view
+    net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3, fused=True)
+    flat = flat_grad_view(net.parameters())
+    t0 = time.perf_counter()
+    sd = StableDiffusion(dev, "1.5", components=sd_arch.components(device=dev))
+    guide = SDSGuidance(sd, "Hulk, photorealistic style", 100.0)
+    ro, rd = sds_view(0)
+    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)              # warm-up (MIOpen / hipBLASLt pick their kernels here)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    marks = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat, timers=marks)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    phases = {}
+    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+        if n1 != "start":
+            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
+    nu, nv = sd_arch.parameter_counts()
+    g = phases.get("guidance", 0.0)
+    return {"ms_per_step": ms, "guidance_ms": g, "render_and_backward_ms": ms - g, "guidance_share": g / ms, "steps": steps, "setup_and_first_step_s": t_setup,
+            "phase_ms": {k: round(v, 3) for k, v in phases.items()},
+            "guidance": f"SD-1.5 ARCHITECTURE stand-in (avatarcraft_amd/sd_arch.py): UNet2DConditionModel {nu} + AutoencoderKL encoder {nv} parameters, random "
+                        "weights, fp32; 512 x 512 VAE encode with grad, UNet on 2 x 4 x 64 x 64 latents with [2, 77, 768] text embeddings -- the real "
+                        "guidance's clock, not its values (the pretrained weights are not on this machine: see real_sd)"}
+
+
 def _flush_c_stdio():
     """RCCL printf()s a version banner when the first communicator is created; with stdout a pipe or a file it sits in C stdio's buffer until exit,
     i.e. it would land AFTER a line printed from Python"""
@@ -497,6 +535,8 @@ def main():
     ap.add_argument("--sds-steps", type=int, default=8, help="also time this many 4096-ray SDS steps (secondary metric); 0 = skip")
     ap.add_argument("--real-sd", action="store_true", help="time one SDS step with the real Stable-Diffusion guidance if diffusers + the weights are on this "
                                                            "machine (the line's real_sd field says why not otherwise; the probe itself always runs)")
+    ap.add_argument("--sd-arch-steps", type=int, default=2, help="time this many SDS steps with a guidance of Stable-Diffusion 1.5's architecture (random weights: "
+                                                                  "what the step costs once the real UNet is in it); 0 = skip")
     ap.add_argument("--no-occupancy", action="store_true", help="skip the occupancy-grid render leg (render(cuda_ray=True): a separate figure beside the headline)")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
@@ -675,6 +715,12 @@ def main():
             except Exception as e:             # noqa: BLE001
                 import traceback
                 res["occupancy_render"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-500:]}
+        if world == 1 and a.sd_arch_steps > 0:
+            try:
+                res["sds_step_sd_arch_standin"] = time_sd_arch_step(dev, p, table, a.sd_arch_steps)
+            except Exception as e:             # noqa: BLE001
+                import traceback
+                res["sds_step_sd_arch_standin"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-500:]}
         try:
             from avatarcraft_amd.guidance import real_sd_probe
             ok_sd, why_sd = real_sd_probe("1.5")

@@ -216,3 +216,32 @@ def test_real_sd_guidance_runs_or_says_why_not():
         assert isinstance(why, str) and len(why) > 10
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rec, open("gpurun_out/real_sd.json", "w"))
+
+
+def test_sd_architecture_standin_has_the_checkpoints_shapes_and_drives_a_step():
+    """avatarcraft_amd.sd_arch: the UNet / VAE-encoder of Stable-Diffusion 1.5 restated from the published configuration (random weights; a clock for
+    bench.py's sds_step_sd_arch_standin).  Parameter counts equal the checkpoint's (UNet2DConditionModel 859 520 964, AutoencoderKL encoder + quant_conv
+    34 163 664); one SDS step through guidance.StableDiffusion over it moves the parameters and stays finite."""
+    from avatarcraft_amd import sd_arch
+    from avatarcraft_amd.guidance import StableDiffusion, SDSGuidance
+    from avatarcraft_amd.stylize import sds_step, flat_grad_view
+    from avatarcraft_amd.synthetic import make_rays
+    assert sd_arch.parameter_counts() == (859520964, 34163664)
+    net, _ = golden_net(train=True)
+    net_gt, _ = golden_net(train=False)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    flat = flat_grad_view(net.parameters())
+    guide = SDSGuidance(StableDiffusion(torch.device(DEV), "1.5", components=sd_arch.components(device=DEV)), "Hulk, photorealistic style", 100.0)
+    ro, rd = make_rays(64, 64, dist=1.8, f=50.0)
+    seen = {}
+
+    def g(rgb):
+        seen["grad"] = guide(rgb)
+        return seen["grad"]
+    before = net.encoder.embeddings.detach().clone()
+    sds_step(net, net_gt, torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV), (64, 64), opt, g, batch_size=4096, flat_grad=flat)
+    net.check_finite()
+    assert seen["grad"].shape == (1, 3, 64, 64) and torch.isfinite(seen["grad"]).all() and float(seen["grad"].abs().max()) > 0
+    assert torch.isfinite(flat).all() and float((net.encoder.embeddings.detach() - before).abs().max()) > 0
+    del guide
+    torch.cuda.empty_cache()

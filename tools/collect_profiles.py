@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r03"
+rnd = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 short = lambda n: re.sub(r"\(anonymous namespace\)::|void ", "", n).split("(")[0]
@@ -114,7 +114,7 @@ def main():
         "render_rays_kernel_hbm_bytes_per_launch": int(mean(main_f) * KB),
         "sds_step_hbm_bytes_per_step": int(sum(parts.values())),
         "sds_step_by_kernel": {k: int(v) for k, v in parts.items()},
-        "commit": head, "profile": f"tools/prof_r03.sh {tag} -> profiles/{rnd}_pmc_summary.json",
+        "commit": head, "profile": f"tools/prof_r04.sh {tag} -> profiles/{rnd}_pmc_summary.json",
         "command": f"bench.py --steps {pb['steps']} --warmup {pb['warmup']} --sds-steps 2 --posed-frames 1 --repeat 1 under rocprofv3 --pmc (one pass per counter group)",
         "render_rays_kernel_mfma_busy_frac": mfma_busy,
         "fetch_size_note": ("FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950; calibrated for THIS access pattern (8-byte gathers, one 64-byte sector per L2 miss: "
