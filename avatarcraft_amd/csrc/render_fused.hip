@@ -376,10 +376,13 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 if (timed_out && a.handoff_timeouts) atomicAdd(a.handoff_timeouts, 1u);     // the host can ask (ac_render_handoff_timeouts): a lost hand-off is an ERROR, not only a NaN pixel
             }
             timed_out = __builtin_amdgcn_readfirstlane(timed_out);
-            // acquire, pairing with the publisher's release: everything the publishing wave stored before its flag is visible to the loads below.  (The
-            // state itself is read with agent-scope atomic loads = from L2, so on this hardware the fence costs one L1 invalidate per segment; it is
-            // here so that correctness does not rest on "same XCD" or on how workgroups happen to be dispatched.)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // NO acquire fence here, on purpose and measured (round 4): `fence acquire, agent` is `buffer_inv sc1` on gfx950 -- it empties the compute
+            // unit's vector L1, i.e. the table lines all eight resident waves are gathering from, three times per ray: the 4096-ray launch went from
+            // 0.744 to 1.087 ms with the acquire / release pair in place.  What makes the hand-off correct without it: the state and the
+            // flag are written and read with agent-scope ATOMIC accesses only (they bypass the non-coherent L1 on both sides and meet at the device's
+            // coherence point, whichever XCD either wave runs on); the publisher drains its state stores (s_waitcnt vmcnt(0)) before it issues the flag
+            // store; the taker issues its state loads only after lane 0 has observed the flag (control dependence + the wave barrier below), and the
+            // memory pipeline returns a wave's loads in issue order.  No ordinary (cached) access ever touches these words.
             wave_sync();
             const uint32_t *st = reinterpret_cast<const uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
             if constexpr (MODE != MODE_FINAL)
@@ -560,8 +563,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every lane's state stores have left the wave ...
             wave_sync();
-            // ... and the flag is a RELEASE store at agent scope: ordered behind them for any wave of the device that acquires it
-            if (lane == 0) __hip_atomic_store(a.seg_flags + ray, (a.gen << 4) | (uint32_t)(seg + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // ... before the flag store is issued (relaxed, agent scope: see the taker's side for why no release / acquire pair is used)
+            if (lane == 0) __hip_atomic_store(a.seg_flags + ray, (a.gen << 4) | (uint32_t)(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             wave_sync();
             continue;
         }
