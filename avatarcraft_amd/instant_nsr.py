@@ -175,8 +175,10 @@ class NeRFRenderer(nn.Module):
 
     def render_step_pair(self, rays_o, rays_d, num_steps, upsample_steps, bound, bkg_fn, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0):
         """The two renders of net_style in one stylisation step (stylize.py:98-116 render_val, :143-152 the differentiable render of the same rays) as
-        ONE launch (ac_render_rays_pair): the two copies of a ray share most table sectors and meet in L2.  Random draws in the reference's order:
-        bkg_fn() -> background of render_val, jitter noise of render_val, bkg_fn() -> background of the training render, its jitter noise.
+        ONE launch (ac_render_rays_pair): the two copies of a ray share most table sectors and meet in L2.  Random draws, in the order the two renders
+        make them: bkg_fn() -> background of render_val, jitter noise of render_val, bkg_fn() -> background of the training render, its jitter noise --
+        i.e. the training render's draws come BEFORE whatever the guidance draws in between in the reference (stylize.py:128-152), which is why
+        stylize.sds_step pairs the renders only for a guidance with `private_rng = True`.
         Returns (rgb_val [N,3], rgb [N,3], gradient_error, weight_sum [N,1]) of which the last three belong to the training render, whose
         per-sample outputs are kept for backward_last().  Every value equals what the two separate renders give, bit for bit."""
         if not (self.training and self.manual_backward_supported()):

@@ -26,6 +26,8 @@ from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG, _backgr
 class SyntheticGuidance:
     """Stand-in for StableDiffusion.mannual_backward: a clamped Gaussian image gradient from a per-call seeded stream."""
 
+    private_rng = True          # draws from its own generator: sds_step may render the training forward before calling it (see sds_step)
+
     def __init__(self, seed=42):
         self.gen = None
         self.seed = seed
@@ -92,8 +94,13 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
     # One patch covers the view (the coarse stage: 64 x 64 rays): render_val and the training render of the patch are the same rays with two
     # noise draws -- one launch renders both (NeRFNetwork.render_step_pair); the training render does not depend on the guidance, only its
     # backward does.  Larger views keep the reference's order (render_val of the whole view first, then patch by patch).
+    # RNG order: the pair launch draws the training render's background and jitter BEFORE the guidance runs; the reference draws them after it
+    # (stylize.py:128-152), and its Stable-Diffusion guidance takes its timestep and noise from the GLOBAL generator in between.  Pairing is therefore
+    # used only with a guidance that declares `private_rng = True` (its draws do not touch the global streams: SyntheticGuidance); any other guidance --
+    # SDSGuidance over the real networks -- gets the reference's order: render_val, guidance, training render (two launches, same values per launch).
     paired = None
-    if manual and PAIR_STEP_RENDERS and n_rays <= batch_size and net_style.training and hasattr(net_style, "render_step_pair"):
+    if (manual and PAIR_STEP_RENDERS and n_rays <= batch_size and net_style.training and hasattr(net_style, "render_step_pair")
+            and getattr(guidance, "private_rng", False)):
         rgb_val, rgb_p, eik_p, ws_p = net_style.render_step_pair(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND,
                                                                  lambda: _background_on(rays_o.device, rays_o.shape, bkg_key))
         paired = (rgb_p, eik_p, {"weight_sum": ws_p})
@@ -260,7 +267,10 @@ def stylize_epochs(net_style, net_gt, optimizer, guidance, hw=(256, 256), n_cap=
                 ro, rd = cap2rays(pose2cap([H, W], poses[i]), device=device)
                 ro, rd = sparse_ray_sampling(ro.reshape(H, W, 3), rd.reshape(H, W, 3), stride)
                 h, w = ro.shape[0], ro.shape[1]
-                g = (lambda rgb, _t=text: guidance(rgb, text=_t)) if _accepts_text(guidance) else guidance
+                g = guidance
+                if _accepts_text(guidance):
+                    g = lambda rgb, _t=text: guidance(rgb, text=_t)                       # noqa: E731
+                    g.private_rng = getattr(guidance, "private_rng", False)
                 short = n_active < world
                 stats = sds_step(net_style, net_gt, ro.reshape(-1, 3).float().contiguous(), rd.reshape(-1, 3).float().contiguous(), (h, w), optimizer, g,
                                  batch_size=batch_size, w_eikonal=w_eikonal, use_opacity=use_opacity, bkg_key=bkg_key, flat_grad=flat_grad,

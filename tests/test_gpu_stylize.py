@@ -245,3 +245,42 @@ def test_sd_architecture_standin_has_the_checkpoints_shapes_and_drives_a_step():
     assert torch.isfinite(flat).all() and float((net.encoder.embeddings.detach() - before).abs().max()) > 0
     del guide
     torch.cuda.empty_cache()
+
+
+def test_pair_launch_only_with_a_guidance_that_keeps_off_the_global_rng():
+    """the pair launch draws the training render's jitter before the guidance runs; a guidance that draws from the GLOBAL generator
+    (the real SD guidance: timestep, noise) must therefore get the reference's order render_val -> guidance -> training render.  With such a guidance
+    the step is the same whether pairing is allowed or not; forcing the pair on it changes the draws (which is why it is gated)."""
+    from avatarcraft_amd import stylize as S
+    from avatarcraft_amd.synthetic import make_rays
+    ro, rd = make_rays(16, 16, dist=1.8, f=12.0)
+    ro, rd = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+
+    class GlobalRngGuidance:
+        def __call__(self, rgb, text=None):
+            return torch.randn(rgb.shape, device=rgb.device).clamp_(-1, 1)      # the global CUDA generator, like StableDiffusion.mannual_backward
+
+    def step(pair_allowed, private=None):
+        net, _ = golden_net(train=True)
+        net_gt, _ = golden_net(train=False)
+        opt = torch.optim.SGD(net.parameters(), lr=0.0)
+        flat = S.flat_grad_view(net.parameters())
+        g = GlobalRngGuidance()
+        if private is not None:
+            g.private_rng = private
+        old = S.PAIR_STEP_RENDERS
+        S.PAIR_STEP_RENDERS = pair_allowed
+        try:
+            torch.manual_seed(1234)
+            marks = []
+            S.sds_step(net, net_gt, ro, rd, (16, 16), opt, g, batch_size=4096, flat_grad=flat, timers=marks)
+        finally:
+            S.PAIR_STEP_RENDERS = old
+        return flat.clone(), [n for n, _ in marks]
+    a, ma = step(True)
+    b, mb = step(False)
+    assert "render_val" in ma and "render_val_and_grad_forward" not in ma and ma == mb       # not paired: the reference's order
+    assert torch.equal(a, b)
+    c, mc = step(True, private=True)
+    assert "render_val_and_grad_forward" in mc
+    assert not torch.equal(a, c)                                                              # the draws really are consumed in another order
