@@ -941,7 +941,13 @@ __global__ __launch_bounds__(256) void ray_cull_kernel(const float *__restrict__
 // order of the pairs, and equals the exhaustive kernel's bit for bit.
 constexpr uint32_t TQ = 1024, GQ = 256, FQ = 256;     // pair queues (rings): a sample adds <= NIT x 64 = 512 (sample, tile) pairs to < 32 left over; a group trip
                                                        // <= 128 (sample, tile, group) triples to < 16; a disc trip <= 128 (sample, face) pairs to < 64
-constexpr int GSTEPS = 2, DSTEPS = 2;                  // steps per group trip (16 tile pairs each) and per disc trip (8 triples each)
+#ifndef AC_GSTEPS
+#define AC_GSTEPS 2
+#endif
+#ifndef AC_DSTEPS
+#define AC_DSTEPS 3
+#endif
+constexpr int GSTEPS = AC_GSTEPS, DSTEPS = AC_DSTEPS;  // steps per group trip (16 tile pairs each) and per disc trip (8 triples each)
 static_assert(TQ >= NIT * 64 + 16 * GSTEPS && GQ >= 64 * GSTEPS + 8 * DSTEPS && FQ >= 64 * DSTEPS + 64 && MAX_TILES <= 512 && SUBS == 4 && SUB_F == 8,
               "queue capacities / pair encoding");
 constexpr int PK_WAVES = 8;                     // waves per workgroup (they share the 32 KB of boxes)
