@@ -107,6 +107,7 @@ _SIGS = {
     "ac_warp_accel_work": ([vp, vp, vp], C.c_int),
     "ac_debug_warped_phases": ([C.c_int], None),
     "ac_debug_warped_phase_ms": ([vp], C.c_int),
+    "ac_render_rays_occupancy": ([C.POINTER(ac_field), vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, f32, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_field_samples": ([C.POINTER(ac_field), vp, vp, vp, u32, u32, f32, f32, f32, vp, f32, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_color_backward_scratch": ([u32], C.c_size_t),
     "ac_color_backward": ([C.POINTER(ac_field), vp, vp, vp, vp, u32, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),

@@ -17,6 +17,7 @@
 //   dW1 += d1 inp^T        48 MFMA   } accumulators live in registers for the whole kernel (a column of ones gives db1)
 // Weight-gradient partials are written per wave (no atomics) and summed by sdf_partials_reduce_kernel (deterministic).
 #include "nsr_device.hpp"
+#include "rm_device.hpp"
 
 namespace {
 
@@ -524,6 +525,124 @@ __global__ __launch_bounds__(FBLOCK) void field_samples_kernel(const RenderArgs 
     }
 }
 
+// ---- the occupancy-grid INFERENCE render as one launch (round 4): march + field + composite per ray, no host round trips -----------------------------
+// What NeRFRenderer.run_cuda's eval() loop computes in rounds of compact_rays / march_rays / ac_field_samples / composite_rays (one 4-byte D2H per round),
+// computed as if it were ONE round with n_step = 1024: lane = ray.  Per iteration every alive lane marches to its NEXT occupied sample (the body of
+// march_rays_kernel, raymarching.hip), the samples of the wave's alive rays are packed into tiles of 16 (ballot ranks through an LDS stage), the tiles go through
+// the renderer's stencil gather / MLP / colour / alpha code (the body of field_samples_kernel), and every lane composites its own sample in order (the body of
+// composite_rays_kernel: T = 1 - weights_sum, early stop at T < 1e-2).  Bit-identical to the three stand-alone operators run with n_step = 1024.
+constexpr int OC_STAGE = 8 * 64;                   // per-wave stage: 8 floats per packed sample: in x y z dx dy dz dt - | out alpha r g b nx ny nz
+constexpr int OCC_LDS_FLOATS = FWD_LDS_FLOATS + FW * OC_STAGE;
+static_assert(OCC_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+struct OccArgs {
+    const float *rays_o, *rays_d, *grid;
+    uint32_t N, H;
+    float mean_density;
+    float *weights_sum, *depth, *image, *normal_map;     // [N] [N] [N,3] [N,3]: accumulators as composite_rays leaves them (background / depth normalisation: the caller)
+    uint32_t *n_samples;                                   // optional [1]: total samples evaluated (atomic, one add per wave)
+};
+
+__global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderArgs a, const OccArgs oc)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    fill_lds(lds, a);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
+    float *stage = lds + FWD_LDS_FLOATS + wave * OC_STAGE;
+    const FieldCtx fc = make_ctx(a);
+    const float inv_s = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;
+    const float bound = a.bound, eps = a.eps;
+    const uint32_t ngroups = (oc.N + 63) / 64;
+    uint32_t evaluated = 0;
+    for (uint32_t grp = blockIdx.x * FW + wave; grp < ngroups; grp += gridDim.x * FW) {
+        const uint32_t ray = grp * 64 + (uint32_t)lane;
+        bool alive = ray < oc.N;
+        const uint32_t rr = alive ? ray : oc.N - 1;
+        RayCtx c; rm_setup(c, oc.rays_o + 3 * (size_t)rr, oc.rays_d + 3 * (size_t)rr, oc.grid, oc.mean_density, bound, oc.H);
+        float near, far;
+        cube_near_far(c.ox, c.oy, c.oz, c.dx, c.dy, c.dz, bound, near, far);      // near_far_from_bound(type='cube'), instant_nsr.py:58-77 (what run_cuda passes to march_rays)
+        float t = near, last_t = near, tc = near;                                  // marcher's t | its last_t | the compositor's t (rays_t)
+        float ws = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f;
+        while (__ballot(alive) != 0ull) {
+            // ---- march: this lane's next occupied sample (march_rays_kernel's loop body, one sample) ----
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f, dt = 0.0f, dl1 = 0.0f;
+            bool have = false;
+            if (alive) {
+                float x, y, z; int vx, vy, vz;
+                while (t < far) {
+                    const float den = rm_density(c, t, x, y, z, vx, vy, vz);
+                    if (den > c.thresh) {
+                        sx = x; sy = y; sz = z;
+                        dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+                        t += dt; dl1 = t - last_t; last_t = t;
+                        have = true;
+                        break;
+                    }
+                    t = rm_skip(c, t, x, y, z, vx, vy, vz);
+                }
+                if (!have) alive = false;                                           // t >= far: composite_rays would meet dl[0] == 0 here
+            }
+            const unsigned long long hm = __ballot(have);
+            if (hm == 0ull) break;
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(hm);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
+            if (have) {
+                float *sp = stage + 8 * rank;
+                sp[0] = sx; sp[1] = sy; sp[2] = sz; sp[3] = c.dx; sp[4] = c.dy; sp[5] = c.dz; sp[6] = dt;
+            }
+            wave_sync();
+            evaluated += cnt;
+            // ---- field on the packed samples, tiles of 16 (field_samples_kernel's body) ----
+            for (uint32_t q0 = 0; q0 < cnt; q0 += 16) {
+                const uint32_t si = q0 + (uint32_t)n, sc = si < cnt ? si : cnt - 1;
+                const float *sp = stage + 8 * sc;
+                const float px = clampf(sp[0], -bound, bound), py = clampf(sp[1], -bound, bound), pz = clampf(sp[2], -bound, bound);
+                const float dx = sp[3], dy = sp[4], dz = sp[5], delta = sp[6];
+                float fe0[4][2];
+                encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
+                f32x4 o16; float gr[3];
+                fd_forward(lds, fsl, lane, px, py, pz, eps, bound, fe0, o16, gr);
+                const float gx = gr[0], gy = gr[1], gz = gr[2];
+                const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+                const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
+                float rgb[3];
+                color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb);
+                const float tcos = (dx * nx + dy * ny) + dz * nz;
+                const float a1 = dv_softplus100(lds + OFF_SPQ, -tcos * 0.5f + 0.5f) * a.one_m_car;
+                const float a2 = dv_softplus100(lds + OFF_SPQ, -tcos) * a.car;
+                const float half = -(a1 + a2) * delta * 0.5f;
+                const float pc = dv_sigmoid((o16[0] - half) * inv_s), nc = dv_sigmoid((o16[0] + half) * inv_s);
+                const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+                wave_sync();                                                         // every lane has read its inputs: the slots become outputs
+                if (g == 0 && si < cnt) {
+                    float *so = stage + 8 * si;
+                    so[0] = alpha; so[1] = rgb[0]; so[2] = rgb[1]; so[3] = rgb[2]; so[4] = nx; so[5] = ny; so[6] = nz;
+                }
+                wave_sync();
+            }
+            // ---- composite: every lane its own sample, in order (composite_rays_kernel's loop body) ----
+            if (have) {
+                const float *so = stage + 8 * rank;
+                const float alpha = so[0], T = 1 - ws, w = alpha * T;
+                ws += w;
+                tc += dl1;
+                dep += w * tc;
+                cr += w * so[1]; cg += w * so[2]; cb += w * so[3];
+                mx += w * so[4]; my += w * so[5]; mz += w * so[6];
+                if ((double)T < 1e-2) alive = false;
+            }
+            wave_sync();
+        }
+        if (ray < oc.N) {
+            oc.weights_sum[ray] = ws; oc.depth[ray] = dep;
+            oc.image[3 * (size_t)ray] = cr; oc.image[3 * (size_t)ray + 1] = cg; oc.image[3 * (size_t)ray + 2] = cb;
+            oc.normal_map[3 * (size_t)ray] = mx; oc.normal_map[3 * (size_t)ray + 1] = my; oc.normal_map[3 * (size_t)ray + 2] = mz;
+        }
+    }
+    if (oc.n_samples && lane == 0 && evaluated) atomicAdd(oc.n_samples, evaluated);
+}
+
 __device__ __forceinline__ void fill_lds_color_bwd(float *lds, const RenderArgs &a)
 {
     for (int e = threadIdx.x; e < 4 * 64; e += blockDim.x) {        // fragment to: lane (m, kk) = Wc3[o = kk][unit = 16 to + m]
@@ -1014,6 +1133,28 @@ AC_API int ac_field_samples(const ac_field *field, const float *xyzs, const floa
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(field_samples_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, sa);
     return ac::check_launch("field_samples");
+}
+
+AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
+                                    float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
+                                    float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, ac_stream_t stream)
+{
+    if (N == 0) return AC_OK;
+    if (!rays_o || !rays_d || !grid || !weights_sum || !depth || !image || !normal_map || H < 2 || !(eps > 0.0f)) {
+        ac::set_error("render_rays_occupancy: NULL buffer, H < 2 or eps <= 0"); return AC_ERR_BAD_ARG;
+    }
+    RenderArgs a{};
+    if (int rc = prep_args(a, field, bound, eps)) return rc;
+    a.inv_s = inv_s; a.inv_s_dev = inv_s_dev; a.car = cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)cos_anneal_ratio);
+    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples };
+    const size_t lds_bytes = OCC_LDS_FLOATS * sizeof(float);
+    static uint64_t seen = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_render_kernel), lds_bytes);
+    uint32_t blocks = ((N + 63) / 64 + FW - 1) / FW;              // a wave owns 64 rays at a time; one persistent workgroup per CU
+    const uint32_t cus = ac::cu_count();
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(occupancy_render_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
+    return ac::check_launch("render_rays_occupancy");
 }
 
 AC_API size_t ac_sdf_stencil_backward_scratch(uint32_t B)

@@ -442,6 +442,8 @@ class NeRFRenderer(nn.Module):
         return depth.reshape(B, N), weights, weights_sum, image.reshape(B, N, 3), normal_map, gradient_error, curvature_error, color, alpha, z_vals
 
     # ------------------------------------------------------------------ occupancy-grid rendering (cuda_ray = True)
+    occupancy_rounds = False           # True: run_cuda's eval() as the reference-shaped loop of compact / march / field / composite rounds (same results)
+
     def run_cuda(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0, render_can=True,
                  verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True, per_sample: bool = True, max_steps=1024):
         """The render path the reference dispatches to when cuda_ray=True (models/instant_nsr.py:358-363) and never defines: the chain its
@@ -512,7 +514,19 @@ class NeRFRenderer(nn.Module):
             image = image + (1 - weights_sum).unsqueeze(-1) * bg
             depth = torch.zeros(n_rays, dtype=torch.float32, device=device)
             return depth.reshape(B, N), None, weights_sum[:, None], image.reshape(B, N, 3), normal_map, gradient_error, 0.0, None, None, None
-        # ---- inference: march / evaluate / composite in rounds, dead rays compacted away between rounds (one 4-byte D2H per round, like the reference's
+        # ---- inference.  Default: ONE launch (ac_render_rays_occupancy: march + field + composite per ray, a wave's 64 rays packed into tiles) -- the
+        # same bits as the reference-shaped loop below without its rounds and host read-backs; occupancy_rounds = True selects the loop.
+        if not self.occupancy_rounds:
+            with torch.no_grad():
+                near, far = near_far_from_bound(ro, rd, bound, type='cube')
+                near, far = near.reshape(-1), far.reshape(-1)
+                o = nsr_ops.render_rays_occupancy(self._field(), ro, rd, self.density_grid, self.mean_density, bound, fd_eps, inv_s_t, cos_anneal_ratio)
+                self._last_cuda_rounds = 0
+                image = o["image"] + (1 - o["weights_sum"]).unsqueeze(-1) * bg
+                depth = torch.clamp(o["depth"] - near, min=0) / (far - near)
+                return (depth.reshape(B, N), None, o["weights_sum"][:, None], image.reshape(B, N, 3), o["normal_map"],
+                        torch.zeros((), dtype=torch.float32, device=device), 0.0, None, None, None)
+        # ---- the loop: march / evaluate / composite in rounds, dead rays compacted away between rounds (one 4-byte D2H per round, like the reference's
         # `alive_counter.item()`: the next round's step count depends on it)
         with torch.no_grad():
             field = self._field()

@@ -697,6 +697,25 @@ def field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio
     return out
 
 
+def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, count_samples=False):
+    """ac_render_rays_occupancy: the inference form of run_cuda in one launch (march + field + composite per ray, no rounds).
+    -> dict(weights_sum [N], depth [N] (raw sum of w t), image [N,3] (no background), normal_map [N,3] (+ n_samples, a [1] int32 device tensor))"""
+    rays_o = _chk(rays_o.reshape(-1, 3), "rays_o"); rays_d = _chk(rays_d.reshape(-1, 3), "rays_d"); grid = _chk(density_grid, "density_grid")
+    N, dev = rays_o.shape[0], rays_o.device
+    if grid.dim() != 3 or grid.shape[0] != grid.shape[1] or grid.shape[0] != grid.shape[2]:
+        raise RuntimeError("render_rays_occupancy: density_grid must be [H, H, H]")
+    f = lambda *sh: torch.empty(sh, dtype=_F32, device=dev)
+    out = dict(weights_sum=f(N), depth=f(N), image=f(N, 3), normal_map=f(N, 3))
+    if count_samples:
+        out["n_samples"] = torch.zeros(1, dtype=torch.int32, device=dev)
+    inv_f, inv_t = _inv_s_arg(inv_s)
+    L.check(L.lib().ac_render_rays_occupancy(C.byref(field.c), rays_o.data_ptr(), rays_d.data_ptr(), N, grid.data_ptr(), int(grid.shape[0]), float(mean_density),
+                                             float(bound), float(eps), inv_f, L.ptr(inv_t), float(cos_anneal_ratio), out["weights_sum"].data_ptr(),
+                                             out["depth"].data_ptr(), out["image"].data_ptr(), out["normal_map"].data_ptr(), L.ptr(out.get("n_samples")),
+                                             L.current_stream(dev)), "render_rays_occupancy")
+    return out
+
+
 def field_sdf(field, x, bound):
     """forward_sdf (instant_nsr.py:627-642): x [B,3] -> [B,16] (sdf, 15 features)"""
     x = _chk(x.reshape(-1, 3), "x")

@@ -357,14 +357,22 @@ def time_occupancy_render(dev, p, table, ro, rd, reps=3):
 
     res = {}
     with torch.no_grad():
-        for rpb in (RAYS_PER_BATCH, n):
-            img, rounds = view(rpb); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                img, rounds = view(rpb)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / reps
-            res[f"eval_{rpb}_ray_batches"] = {"ms_per_view": dt * 1e3, "rays_per_s": n / dt, "march_rounds_per_view": rounds}
+        # the one-launch form (ac_render_rays_occupancy: march + field + composite per ray; run_cuda's default in eval()) and the reference-shaped loop of
+        # compact / march / field / composite rounds with one host read-back each (the same pixels bit for bit)
+        for mode, rounds_on in (("one_launch", False), ("rounds", True)):
+            net.occupancy_rounds = rounds_on
+            for rpb in (RAYS_PER_BATCH, n):
+                img, rounds = view(rpb); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps * (4 if not rounds_on else 1)):
+                    img, rounds = view(rpb)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / (reps * (4 if not rounds_on else 1))
+                res[f"eval_{mode}_{rpb}_ray_batches"] = {"ms_per_view": dt * 1e3, "rays_per_s": n / dt, "march_rounds_per_view": rounds}
+        net.occupancy_rounds = False
+        from avatarcraft_amd import nsr_ops as _ops
+        res["samples_evaluated_per_view"] = int(_ops.render_rays_occupancy(net._field(), ro, rd, net.density_grid, net.mean_density, NSR_BOUND, 0.005,
+                                                                           net.forward_variance(), 1.0, count_samples=True)["n_samples"].item())
         net.cuda_ray = False
         ref = torch.cat([net.render(ro[None, i:i + RAYS_PER_BATCH], rd[None, i:i + RAYS_PER_BATCH], **kw)["rgb"][0] for i in range(0, n, RAYS_PER_BATCH)])
         net.cuda_ray = True

@@ -329,6 +329,16 @@ int ac_field_samples(const ac_field *field, const float *xyzs, const float *dirs
                      float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio, float *alpha, float *rgb, float *normal,
                      float *sdf, float *gradient, ac_stream_t stream);
 
+/* The inference form of run_cuda as ONE launch: per ray, march through the occupancy grid (the arithmetic of ac_march_rays), evaluate the field on the
+ * samples (the arithmetic of ac_field_samples, samples of a wave's 64 rays packed into tiles of 16) and composite them in order (the arithmetic of
+ * ac_composite_rays: T = 1 - weights_sum, a ray stops at T < 1e-2 or at `far`) -- what the reference-shaped loop compact_rays / march_rays / field /
+ * composite_rays computes in rounds with one host read-back each, bit for bit, without the rounds.  near / far = near_far_from_bound(type = 'cube')
+ * (models/instant_nsr.py:58-77).  Outputs are the accumulators as composite_rays leaves them: weights_sum [N], depth [N] (sum of w * t: the caller normalises,
+ * like run_cuda's last lines), image [N,3] (no background), normal_map [N,3]; n_samples (optional, device, [1]): samples evaluated, accumulated. */
+int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
+                             float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
+                             float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, ac_stream_t stream);
+
 /* ---- colour MLP of the render core (training path): forward_color (models/instant_nsr.py:644-663, use_viewdirs = False)
  * rgb = sigmoid(Wc3 relu(Wc2 relu(Wc1 [x, normal, feat]))) with feat = sdf16[:, 1:16].
  * forward : same values as ac_field_color / ac_render_rays.   backward: recomputes the forward per tile of 16 samples and returns

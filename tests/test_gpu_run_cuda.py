@@ -115,8 +115,12 @@ def test_run_cuda_inference_loop_vs_oracle_chain(env):
     O, net = env["O"], env["net"].eval()
     ro, rd = make_rays(48, 48, dist=1.8, f=36.0)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
-    with torch.no_grad():
-        out = net.render(t(ro)[None], t(rd)[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0)
+    net.occupancy_rounds = True                     # the reference-shaped loop of rounds (the one-launch form is compared with it below)
+    try:
+        with torch.no_grad():
+            out = net.render(t(ro)[None], t(rd)[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0)
+    finally:
+        net.occupancy_rounds = False
     r = O.run_cuda_eval(env["of"], ro, rd, env["grid"], env["mean"], 1.6, 0.005, env["inv_s"])
     assert net._last_cuda_rounds == r["rounds"]
     assert_bitwise(out["weight_sum"][:, 0], r["weights_sum"], "weights_sum")
@@ -126,6 +130,23 @@ def test_run_cuda_inference_loop_vs_oracle_chain(env):
     hit = r["weights_sum"] > 0.5
     assert hit.any() and np.abs(c(out["depth"])[0][hit] - r["depth"][hit]).max() <= 1e-6
     assert float(out["gradient_error"]) == 0.0 and out["weights"] is None and out["z_vals"] is None
+    # the same render as ONE launch (ac_render_rays_occupancy, the default of run_cuda's eval()): every output bit for bit what the rounds give
+    from avatarcraft_amd import nsr_ops
+    bg = torch.from_numpy(np.random.RandomState(9).uniform(0, 1, (ro.shape[0], 3)).astype(np.float32)).to(DEV)
+    for rays in ((ro, rd), make_rays(40, 25, dist=1.7, f=30.0, yaw=1.1, pitch=0.3)):          # (a ray count that is not a multiple of 64)
+        o_, d_ = t(rays[0]), t(rays[1])
+        b_ = bg[:o_.shape[0]]
+        with torch.no_grad():
+            net.occupancy_rounds = True
+            loop = net.render(o_[None], d_[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=b_, cos_anneal_ratio=0.7, normal_epsilon_ratio=0.0)
+            net.occupancy_rounds = False
+            one = net.render(o_[None], d_[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=b_, cos_anneal_ratio=0.7, normal_epsilon_ratio=0.0)
+        assert net._last_cuda_rounds == 0
+        for k in ("weight_sum", "rgb", "normal", "depth"):
+            assert torch.equal(loop[k], one[k]), k
+        assert float(one["weight_sum"].max()) > 0.9
+    cnt = nsr_ops.render_rays_occupancy(net._field(), t(ro), t(rd), net.density_grid, net.mean_density, 1.6, 0.005, env["inv_s"], 1.0, count_samples=True)["n_samples"]
+    assert 0 < int(cnt.item()) <= sum(a * 8 for a in r["alive_per_round"])
 
 
 def test_run_cuda_gradients_vs_torch_formulation(env):
