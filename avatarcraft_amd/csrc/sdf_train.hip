@@ -540,7 +540,8 @@ struct OccArgs {
     float mean_density;
     float *weights_sum, *depth, *image, *normal_map;     // [N] [N] [N,3] [N,3]: accumulators as composite_rays leaves them (background / depth normalisation: the caller)
     uint32_t *n_samples;                                   // optional [1]: total samples evaluated (atomic, one add per wave)
-};
+    uint32_t gsz;                                          // rays a wave marches at a time (16, 32 or 64 lanes): fewer rays per wave = more waves for small batches,
+};                                                         // more rays per wave = fuller tiles (the host picks it from N)
 
 __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderArgs a, const OccArgs oc)
 {
@@ -553,11 +554,12 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
     const FieldCtx fc = make_ctx(a);
     const float inv_s = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;
     const float bound = a.bound, eps = a.eps;
-    const uint32_t ngroups = (oc.N + 63) / 64;
+    const uint32_t ngroups = (oc.N + oc.gsz - 1) / oc.gsz;
     uint32_t evaluated = 0;
-    for (uint32_t grp = blockIdx.x * FW + wave; grp < ngroups; grp += gridDim.x * FW) {
-        const uint32_t ray = grp * 64 + (uint32_t)lane;
-        bool alive = ray < oc.N;
+    // groups are dealt to the workgroups first, to the waves of a workgroup second: a small batch spreads over the compute units instead of filling few of them
+    for (uint32_t grp = (uint32_t)wave * gridDim.x + blockIdx.x; grp < ngroups; grp += gridDim.x * FW) {
+        const uint32_t ray = grp * oc.gsz + (uint32_t)lane;
+        bool alive = (uint32_t)lane < oc.gsz && ray < oc.N;
         const uint32_t rr = alive ? ray : oc.N - 1;
         RayCtx c; rm_setup(c, oc.rays_o + 3 * (size_t)rr, oc.rays_d + 3 * (size_t)rr, oc.grid, oc.mean_density, bound, oc.H);
         float near, far;
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
             }
             wave_sync();
         }
-        if (ray < oc.N) {
+        if ((uint32_t)lane < oc.gsz && ray < oc.N) {
             oc.weights_sum[ray] = ws; oc.depth[ray] = dep;
             oc.image[3 * (size_t)ray] = cr; oc.image[3 * (size_t)ray + 1] = cg; oc.image[3 * (size_t)ray + 2] = cb;
             oc.normal_map[3 * (size_t)ray] = mx; oc.normal_map[3 * (size_t)ray + 1] = my; oc.normal_map[3 * (size_t)ray + 2] = mz;
@@ -1146,12 +1148,14 @@ AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, 
     RenderArgs a{};
     if (int rc = prep_args(a, field, bound, eps)) return rc;
     a.inv_s = inv_s; a.inv_s_dev = inv_s_dev; a.car = cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)cos_anneal_ratio);
-    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples };
+    const uint32_t cus = ac::cu_count();
+    // rays per wave: 64 when there are enough rays to give every wave slot of the device (cus x FW) a group, else 32, else 16
+    const uint32_t gsz = (N >= 64u * cus * FW) ? 64u : ((N >= 32u * cus * FW) ? 32u : 16u);
+    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, gsz };
     const size_t lds_bytes = OCC_LDS_FLOATS * sizeof(float);
     static uint64_t seen = 0;
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_render_kernel), lds_bytes);
-    uint32_t blocks = ((N + 63) / 64 + FW - 1) / FW;              // a wave owns 64 rays at a time; one persistent workgroup per CU
-    const uint32_t cus = ac::cu_count();
+    uint32_t blocks = (N + gsz - 1) / gsz;                         // one group per workgroup first (see the kernel's loop), one persistent workgroup per CU at most
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(occupancy_render_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
     return ac::check_launch("render_rays_occupancy");

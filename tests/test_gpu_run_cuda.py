@@ -130,12 +130,17 @@ def test_run_cuda_inference_loop_vs_oracle_chain(env):
     hit = r["weights_sum"] > 0.5
     assert hit.any() and np.abs(c(out["depth"])[0][hit] - r["depth"][hit]).max() <= 1e-6
     assert float(out["gradient_error"]) == 0.0 and out["weights"] is None and out["z_vals"] is None
-    # the same render as ONE launch (ac_render_rays_occupancy, the default of run_cuda's eval()): every output bit for bit what the rounds give
-    from avatarcraft_amd import nsr_ops
+    # the same render as ONE launch (ac_render_rays_occupancy, the default of run_cuda's eval()).  Bit for bit what the three operators give when run as a
+    # SINGLE round (n_step = 1024): the marcher continues from its own t.  The loop of rounds restarts each round from the compositor's t = near + sum of
+    # (t_after - t_before) differences, which is t up to one rounding when a ray jumps across a long empty stretch (front and back of the body): a handful of
+    # rays then march from a position one ulp away -- so against the rounds the comparison is 1e-5, not bitwise.
+    from avatarcraft_amd import nsr_ops, raymarching
+    from avatarcraft_amd.instant_nsr import near_far_from_bound
     bg = torch.from_numpy(np.random.RandomState(9).uniform(0, 1, (ro.shape[0], 3)).astype(np.float32)).to(DEV)
-    for rays in ((ro, rd), make_rays(40, 25, dist=1.7, f=30.0, yaw=1.1, pitch=0.3)):          # (a ray count that is not a multiple of 64)
+    for rays in ((ro, rd), make_rays(40, 25, dist=1.7, f=30.0, yaw=1.1, pitch=0.3), make_rays(200, 200, dist=1.8, f=150.0)):   # 2304 | 1000 (not a multiple of 16) | 40 000 rays
         o_, d_ = t(rays[0]), t(rays[1])
-        b_ = bg[:o_.shape[0]]
+        n_ = o_.shape[0]
+        b_ = bg[:n_] if n_ <= bg.shape[0] else None
         with torch.no_grad():
             net.occupancy_rounds = True
             loop = net.render(o_[None], d_[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=b_, cos_anneal_ratio=0.7, normal_epsilon_ratio=0.0)
@@ -143,8 +148,23 @@ def test_run_cuda_inference_loop_vs_oracle_chain(env):
             one = net.render(o_[None], d_[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=b_, cos_anneal_ratio=0.7, normal_epsilon_ratio=0.0)
         assert net._last_cuda_rounds == 0
         for k in ("weight_sum", "rgb", "normal", "depth"):
-            assert torch.equal(loop[k], one[k]), k
+            dmax = float((loop[k] - one[k]).abs().max())
+            assert dmax <= 2e-5, (k, dmax)
+            assert float((loop[k] != one[k]).float().mean()) <= 0.01, k                  # (and all but a handful of rays are equal bit for bit)
         assert float(one["weight_sum"].max()) > 0.9
+        if n_ > 3000:
+            continue
+        # single round through the stand-alone operators
+        near, far = near_far_from_bound(o_, d_, 1.6, type='cube')
+        near, far = near.reshape(-1).contiguous(), far.reshape(-1).contiguous()
+        alive = torch.arange(n_, dtype=torch.int32, device=DEV); rt = near.clone()
+        xyzs, dirs, deltas = raymarching.march_rays(n_, 1024, alive, rt, o_, d_, 1.6, net.density_grid, net.mean_density, near, far, -1, False)
+        fs = nsr_ops.field_samples(net._field(), xyzs, dirs, deltas, 1.6, 0.005, net.forward_variance(), 0.7)
+        ws, dp = torch.zeros(n_, device=DEV), torch.zeros(n_, device=DEV)
+        im, nm = torch.zeros(n_, 3, device=DEV), torch.zeros(n_, 3, device=DEV)
+        raymarching.composite_rays(n_, 1024, alive, rt, fs["alpha"], fs["rgb"], fs["normal"], deltas, ws, dp, im, nm)
+        raw = nsr_ops.render_rays_occupancy(net._field(), o_, d_, net.density_grid, net.mean_density, 1.6, 0.005, net.forward_variance(), 0.7)
+        assert torch.equal(raw["weights_sum"], ws) and torch.equal(raw["depth"], dp) and torch.equal(raw["image"], im) and torch.equal(raw["normal_map"], nm)
     cnt = nsr_ops.render_rays_occupancy(net._field(), t(ro), t(rd), net.density_grid, net.mean_density, 1.6, 0.005, env["inv_s"], 1.0, count_samples=True)["n_samples"]
     assert 0 < int(cnt.item()) <= sum(a * 8 for a in r["alive_per_round"])
 
