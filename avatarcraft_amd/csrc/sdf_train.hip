@@ -531,7 +531,7 @@ __global__ __launch_bounds__(FBLOCK) void field_samples_kernel(const RenderArgs 
 // march_rays_kernel, raymarching.hip), the samples of the wave's alive rays are packed into tiles of 16 (ballot ranks through an LDS stage), the tiles go through
 // the renderer's stencil gather / MLP / colour / alpha code (the body of field_samples_kernel), and every lane composites its own sample in order (the body of
 // composite_rays_kernel: T = 1 - weights_sum, early stop at T < 1e-2).  Bit-identical to the three stand-alone operators run with n_step = 1024.
-constexpr int OC_STAGE = 8 * 64;                   // per-wave stage: 8 floats per packed sample: in x y z dx dy dz dt - | out alpha r g b nx ny nz
+constexpr int OC_STAGE = 9 * 64;                   // per-wave stage: 64 sample slots x 8 floats (in: x y z dt . . . dl1 | out: alpha r g b nx ny nz, dl1 kept) + slot map [64]
 constexpr int OCC_LDS_FLOATS = FWD_LDS_FLOATS + FW * OC_STAGE;
 static_assert(OCC_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 struct OccArgs {
@@ -540,8 +540,8 @@ struct OccArgs {
     float mean_density;
     float *weights_sum, *depth, *image, *normal_map;     // [N] [N] [N,3] [N,3]: accumulators as composite_rays leaves them (background / depth normalisation: the caller)
     uint32_t *n_samples;                                   // optional [1]: total samples evaluated (atomic, one add per wave)
-    uint32_t gsz;                                          // rays a wave marches at a time (16, 32 or 64 lanes): fewer rays per wave = more waves for small batches,
-};                                                         // more rays per wave = fuller tiles (the host picks it from N)
+    uint32_t glog;                                         // a wave marches 2^glog rays at a time (lanes 0 .. 2^glog - 1), each up to 64 >> glog samples per iteration:
+};                                                         // 64 sample slots = 4 tiles per iteration; few rays per wave = short chains of dependent iterations
 
 __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderArgs a, const OccArgs oc)
 {
@@ -551,56 +551,62 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
     float *stage = lds + FWD_LDS_FLOATS + wave * OC_STAGE;
+    uint32_t *slotmap = reinterpret_cast<uint32_t *>(stage + 8 * 64);
     const FieldCtx fc = make_ctx(a);
     const float inv_s = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;
     const float bound = a.bound, eps = a.eps;
-    const uint32_t ngroups = (oc.N + oc.gsz - 1) / oc.gsz;
+    const uint32_t gsz = 1u << oc.glog, klog = 6u - oc.glog, K = 1u << klog;
+    const uint32_t ngroups = (oc.N + gsz - 1) >> oc.glog;
     uint32_t evaluated = 0;
     // groups are dealt to the workgroups first, to the waves of a workgroup second: a small batch spreads over the compute units instead of filling few of them
     for (uint32_t grp = (uint32_t)wave * gridDim.x + blockIdx.x; grp < ngroups; grp += gridDim.x * FW) {
-        const uint32_t ray = grp * oc.gsz + (uint32_t)lane;
-        bool alive = (uint32_t)lane < oc.gsz && ray < oc.N;
-        const uint32_t rr = alive ? ray : oc.N - 1;
+        const uint32_t ray = (grp << oc.glog) + (uint32_t)lane;
+        const bool mine = (uint32_t)lane < gsz && ray < oc.N;
+        bool alive = mine;
+        const uint32_t rr = mine ? ray : oc.N - 1;
         RayCtx c; rm_setup(c, oc.rays_o + 3 * (size_t)rr, oc.rays_d + 3 * (size_t)rr, oc.grid, oc.mean_density, bound, oc.H);
         float near, far;
         cube_near_far(c.ox, c.oy, c.oz, c.dx, c.dy, c.dz, bound, near, far);      // near_far_from_bound(type='cube'), instant_nsr.py:58-77 (what run_cuda passes to march_rays)
         float t = near, last_t = near, tc = near;                                  // marcher's t | its last_t | the compositor's t (rays_t)
         float ws = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f;
         while (__ballot(alive) != 0ull) {
-            // ---- march: this lane's next occupied sample (march_rays_kernel's loop body, one sample) ----
-            float sx = 0.0f, sy = 0.0f, sz = 0.0f, dt = 0.0f, dl1 = 0.0f;
-            bool have = false;
+            // ---- march: this lane's next (up to K) occupied samples into its own slots (march_rays_kernel's loop body) ----
+            uint32_t mycnt = 0;
             if (alive) {
                 float x, y, z; int vx, vy, vz;
-                while (t < far) {
-                    const float den = rm_density(c, t, x, y, z, vx, vy, vz);
-                    if (den > c.thresh) {
-                        sx = x; sy = y; sz = z;
-                        dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
-                        t += dt; dl1 = t - last_t; last_t = t;
-                        have = true;
-                        break;
+                float *sp = stage + 8 * ((uint32_t)lane << klog);
+                while (mycnt < K) {
+                    bool have = false;
+                    while (t < far) {
+                        const float den = rm_density(c, t, x, y, z, vx, vy, vz);
+                        if (den > c.thresh) { have = true; break; }
+                        t = rm_skip(c, t, x, y, z, vx, vy, vz);
                     }
-                    t = rm_skip(c, t, x, y, z, vx, vy, vz);
+                    if (!have) { alive = false; break; }                            // t >= far: composite_rays would meet dl[0] == 0 here
+                    const float dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+                    t += dt;
+                    sp[0] = x; sp[1] = y; sp[2] = z; sp[3] = dt; sp[7] = t - last_t;
+                    last_t = t;
+                    sp += 8; ++mycnt;
                 }
-                if (!have) alive = false;                                           // t >= far: composite_rays would meet dl[0] == 0 here
             }
-            const unsigned long long hm = __ballot(have);
-            if (hm == 0ull) break;
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(hm);
-            const uint32_t rank = (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
-            if (have) {
-                float *sp = stage + 8 * rank;
-                sp[0] = sx; sp[1] = sy; sp[2] = sz; sp[3] = c.dx; sp[4] = c.dy; sp[5] = c.dz; sp[6] = dt;
-            }
+            // slot s = lane: valid if its ray (lane s >> klog) produced more than s & (K - 1) samples
+            const uint32_t owner_cnt = (uint32_t)__shfl((int)mycnt, lane >> klog);
+            const bool valid = ((uint32_t)lane & (K - 1u)) < owner_cnt;
+            const unsigned long long vm = __ballot(valid);
+            if (vm == 0ull) break;
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(vm);
+            if (valid) slotmap[__builtin_popcountll(vm & ((1ull << lane) - 1ull))] = (uint32_t)lane;
             wave_sync();
             evaluated += cnt;
             // ---- field on the packed samples, tiles of 16 (field_samples_kernel's body) ----
             for (uint32_t q0 = 0; q0 < cnt; q0 += 16) {
-                const uint32_t si = q0 + (uint32_t)n, sc = si < cnt ? si : cnt - 1;
-                const float *sp = stage + 8 * sc;
-                const float px = clampf(sp[0], -bound, bound), py = clampf(sp[1], -bound, bound), pz = clampf(sp[2], -bound, bound);
-                const float dx = sp[3], dy = sp[4], dz = sp[5], delta = sp[6];
+                const uint32_t ci = q0 + (uint32_t)n;
+                const uint32_t slot = slotmap[ci < cnt ? ci : cnt - 1];
+                const float *sp = stage + 8 * slot;
+                const float px = clampf(sp[0], -bound, bound), py = clampf(sp[1], -bound, bound), pz = clampf(sp[2], -bound, bound), delta = sp[3];
+                const int src = (int)(slot >> klog);
+                const float dx = __shfl(c.dx, src), dy = __shfl(c.dy, src), dz = __shfl(c.dz, src);
                 float fe0[4][2];
                 encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
                 f32x4 o16; float gr[3];
@@ -617,26 +623,26 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                 const float pc = dv_sigmoid((o16[0] - half) * inv_s), nc = dv_sigmoid((o16[0] + half) * inv_s);
                 const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
                 wave_sync();                                                         // every lane has read its inputs: the slots become outputs
-                if (g == 0 && si < cnt) {
-                    float *so = stage + 8 * si;
+                if (g == 0 && ci < cnt) {
+                    float *so = stage + 8 * slot;
                     so[0] = alpha; so[1] = rgb[0]; so[2] = rgb[1]; so[3] = rgb[2]; so[4] = nx; so[5] = ny; so[6] = nz;
                 }
                 wave_sync();
             }
-            // ---- composite: every lane its own sample, in order (composite_rays_kernel's loop body) ----
-            if (have) {
-                const float *so = stage + 8 * rank;
+            // ---- composite: every lane its own samples, in order (composite_rays_kernel's loop body) ----
+            for (uint32_t k = 0; k < mycnt; ++k) {
+                const float *so = stage + 8 * (((uint32_t)lane << klog) + k);
                 const float alpha = so[0], T = 1 - ws, w = alpha * T;
                 ws += w;
-                tc += dl1;
+                tc += so[7];
                 dep += w * tc;
                 cr += w * so[1]; cg += w * so[2]; cb += w * so[3];
                 mx += w * so[4]; my += w * so[5]; mz += w * so[6];
-                if ((double)T < 1e-2) alive = false;
+                if ((double)T < 1e-2) { alive = false; break; }
             }
             wave_sync();
         }
-        if ((uint32_t)lane < oc.gsz && ray < oc.N) {
+        if (mine) {
             oc.weights_sum[ray] = ws; oc.depth[ray] = dep;
             oc.image[3 * (size_t)ray] = cr; oc.image[3 * (size_t)ray + 1] = cg; oc.image[3 * (size_t)ray + 2] = cb;
             oc.normal_map[3 * (size_t)ray] = mx; oc.normal_map[3 * (size_t)ray + 1] = my; oc.normal_map[3 * (size_t)ray + 2] = mz;
@@ -1149,9 +1155,11 @@ AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, 
     if (int rc = prep_args(a, field, bound, eps)) return rc;
     a.inv_s = inv_s; a.inv_s_dev = inv_s_dev; a.car = cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)cos_anneal_ratio);
     const uint32_t cus = ac::cu_count();
-    // rays per wave: 64 when there are enough rays to give every wave slot of the device (cus x FW) a group, else 32, else 16
-    const uint32_t gsz = (N >= 64u * cus * FW) ? 64u : ((N >= 32u * cus * FW) ? 32u : 16u);
-    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, gsz };
+    // rays per wave (2^glog): 8 rays x 8 samples per iteration for whole views, 4 x 16 for small batches (more waves, shorter chains); AC_OCC_GLOG overrides (2 .. 6)
+    static const int env_glog = []() { const char *e = getenv("AC_OCC_GLOG"); return (e && e[0] >= '2' && e[0] <= '6' && !e[1]) ? e[0] - '0' : -1; }();
+    const uint32_t glog = env_glog >= 0 ? (uint32_t)env_glog : (N >= 32768u ? 3u : 2u);
+    const uint32_t gsz = 1u << glog;
+    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, glog };
     const size_t lds_bytes = OCC_LDS_FLOATS * sizeof(float);
     static uint64_t seen = 0;
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_render_kernel), lds_bytes);
