@@ -531,7 +531,7 @@ __global__ __launch_bounds__(FBLOCK) void field_samples_kernel(const RenderArgs 
 // march_rays_kernel, raymarching.hip), the samples of the wave's alive rays are packed into tiles of 16 (ballot ranks through an LDS stage), the tiles go through
 // the renderer's stencil gather / MLP / colour / alpha code (the body of field_samples_kernel), and every lane composites its own sample in order (the body of
 // composite_rays_kernel: T = 1 - weights_sum, early stop at T < 1e-2).  Bit-identical to the three stand-alone operators run with n_step = 1024.
-constexpr int OC_STAGE = 9 * 64;                   // per-wave stage: 64 sample slots x 8 floats (in: x y z dt . . . dl1 | out: alpha r g b nx ny nz, dl1 kept) + slot map [64]
+constexpr int OC_STAGE = 10 * 64;                  // per-wave stage: 64 sample slots x 8 floats (in: x y z dt . . . dl1 | out: alpha r g b nx ny nz, dl1 kept) + slot map [64] + lane map [64]
 constexpr int OCC_LDS_FLOATS = FWD_LDS_FLOATS + FW * OC_STAGE;
 static_assert(OCC_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 struct OccArgs {
@@ -540,8 +540,8 @@ struct OccArgs {
     float mean_density;
     float *weights_sum, *depth, *image, *normal_map;     // [N] [N] [N,3] [N,3]: accumulators as composite_rays leaves them (background / depth normalisation: the caller)
     uint32_t *n_samples;                                   // optional [1]: total samples evaluated (atomic, one add per wave)
-    uint32_t glog;                                         // a wave marches 2^glog rays at a time (lanes 0 .. 2^glog - 1), each up to 64 >> glog samples per iteration:
-};                                                         // 64 sample slots = 4 tiles per iteration; few rays per wave = short chains of dependent iterations
+    uint32_t glog;                                         // a wave marches 2^glog rays at a time (lanes 0 .. 2^glog - 1); the 64 sample slots of an iteration (4 tiles) are
+};                                                         // shared out among the rays still alive: 64 / alive each -- the last, long rays of a group get whole tiles
 
 __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderArgs a, const OccArgs oc)
 {
@@ -551,11 +551,11 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
     float *stage = lds + FWD_LDS_FLOATS + wave * OC_STAGE;
-    uint32_t *slotmap = reinterpret_cast<uint32_t *>(stage + 8 * 64);
+    uint32_t *slotmap = reinterpret_cast<uint32_t *>(stage + 8 * 64), *lanemap = slotmap + 64;
     const FieldCtx fc = make_ctx(a);
     const float inv_s = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;
     const float bound = a.bound, eps = a.eps;
-    const uint32_t gsz = 1u << oc.glog, klog = 6u - oc.glog, K = 1u << klog;
+    const uint32_t gsz = 1u << oc.glog;
     const uint32_t ngroups = (oc.N + gsz - 1) >> oc.glog;
     uint32_t evaluated = 0;
     // groups are dealt to the workgroups first, to the waves of a workgroup second: a small batch spreads over the compute units instead of filling few of them
@@ -570,11 +570,16 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
         float t = near, last_t = near, tc = near;                                  // marcher's t | its last_t | the compositor's t (rays_t)
         float ws = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f;
         while (__ballot(alive) != 0ull) {
-            // ---- march: this lane's next (up to K) occupied samples into its own slots (march_rays_kernel's loop body) ----
+            // ---- march: this lane's next (up to K) occupied samples into its own slots (march_rays_kernel's loop body).  K = 64 / (rays of the group still
+            // alive): a group starts with few samples per ray and iteration and ends with whole tiles for its last, longest rays ----
+            const unsigned long long am = __ballot(alive);
+            const uint32_t na = (uint32_t)__builtin_popcountll(am), K = 64u / na;
+            const uint32_t arank = (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull)), mybase = arank * K;
+            if (alive) lanemap[arank] = (uint32_t)lane;
             uint32_t mycnt = 0;
             if (alive) {
                 float x, y, z; int vx, vy, vz;
-                float *sp = stage + 8 * ((uint32_t)lane << klog);
+                float *sp = stage + 8 * mybase;
                 while (mycnt < K) {
                     bool have = false;
                     while (t < far) {
@@ -590,9 +595,11 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                     sp += 8; ++mycnt;
                 }
             }
-            // slot s = lane: valid if its ray (lane s >> klog) produced more than s & (K - 1) samples
-            const uint32_t owner_cnt = (uint32_t)__shfl((int)mycnt, lane >> klog);
-            const bool valid = ((uint32_t)lane & (K - 1u)) < owner_cnt;
+            wave_sync();
+            // slot s = lane: it belongs to the (s / K)-th alive ray and is valid if that ray produced more than s % K samples this iteration
+            const uint32_t orank = (uint32_t)lane / K, owner = orank < na ? lanemap[orank] : 0u;
+            const uint32_t owner_cnt = (uint32_t)__shfl((int)mycnt, (int)owner);
+            const bool valid = orank < na && ((uint32_t)lane - orank * K) < owner_cnt;
             const unsigned long long vm = __ballot(valid);
             if (vm == 0ull) break;
             const uint32_t cnt = (uint32_t)__builtin_popcountll(vm);
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                 const uint32_t slot = slotmap[ci < cnt ? ci : cnt - 1];
                 const float *sp = stage + 8 * slot;
                 const float px = clampf(sp[0], -bound, bound), py = clampf(sp[1], -bound, bound), pz = clampf(sp[2], -bound, bound), delta = sp[3];
-                const int src = (int)(slot >> klog);
+                const int src = (int)lanemap[slot / K];
                 const float dx = __shfl(c.dx, src), dy = __shfl(c.dy, src), dz = __shfl(c.dz, src);
                 float fe0[4][2];
                 encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
             }
             // ---- composite: every lane its own samples, in order (composite_rays_kernel's loop body) ----
             for (uint32_t k = 0; k < mycnt; ++k) {
-                const float *so = stage + 8 * (((uint32_t)lane << klog) + k);
+                const float *so = stage + 8 * (mybase + k);
                 const float alpha = so[0], T = 1 - ws, w = alpha * T;
                 ws += w;
                 tc += so[7];
