@@ -614,6 +614,10 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                 const float px = clampf(sp[0], -bound, bound), py = clampf(sp[1], -bound, bound), pz = clampf(sp[2], -bound, bound), delta = sp[3];
                 const int src = (int)lanemap[slot / K];
                 const float dx = __shfl(c.dx, src), dy = __shfl(c.dy, src), dz = __shfl(c.dz, src);
+#ifdef AC_OCC_NOFIELD      // timing ablation: no field evaluation (what the marching and the bookkeeping cost alone)
+                const float nx = dx, ny = dy, nz = dz, alpha = 0.02f * delta / (delta + 1e-3f) + 0.0f * (px + py + pz + inv_s);
+                float rgb[3] = { 0.5f, 0.5f, 0.5f };
+#else
                 float fe0[4][2];
                 encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
                 f32x4 o16; float gr[3];
@@ -629,6 +633,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                 const float half = -(a1 + a2) * delta * 0.5f;
                 const float pc = dv_sigmoid((o16[0] - half) * inv_s), nc = dv_sigmoid((o16[0] + half) * inv_s);
                 const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+#endif
                 wave_sync();                                                         // every lane has read its inputs: the slots become outputs
                 if (g == 0 && ci < cnt) {
                     float *so = stage + 8 * slot;
@@ -1162,9 +1167,11 @@ AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, 
     if (int rc = prep_args(a, field, bound, eps)) return rc;
     a.inv_s = inv_s; a.inv_s_dev = inv_s_dev; a.car = cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)cos_anneal_ratio);
     const uint32_t cus = ac::cu_count();
-    // rays per wave (2^glog): 8 rays x 8 samples per iteration for whole views, 4 x 16 for small batches (more waves, shorter chains); AC_OCC_GLOG overrides (2 .. 6)
+    // rays per wave (2^glog): 16 for whole views, 8 for small batches (more waves in flight: the march is a chain of ~200 dependent grid look-ups per ray,
+    // 0.26 ms end to end, and only concurrency hides it).  Measured on the 256 x 256 bench view (profiles/r04_experiments.txt section 11): 65 536 rays in one
+    // launch 2.67 / 2.37 / 2.92 / 3.26 ms for 8 / 16 / 32 / 64 rays per wave; in 4096-ray launches 12.1 / 15.6 / 20.0 / 23.4 ms.  AC_OCC_GLOG = 2 .. 6 overrides.
     static const int env_glog = []() { const char *e = getenv("AC_OCC_GLOG"); return (e && e[0] >= '2' && e[0] <= '6' && !e[1]) ? e[0] - '0' : -1; }();
-    const uint32_t glog = env_glog >= 0 ? (uint32_t)env_glog : (N >= 32768u ? 3u : 2u);
+    const uint32_t glog = env_glog >= 0 ? (uint32_t)env_glog : (N >= 32768u ? 4u : 3u);
     const uint32_t gsz = 1u << glog;
     OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, glog };
     const size_t lds_bytes = OCC_LDS_FLOATS * sizeof(float);
