@@ -26,7 +26,7 @@ class ac_field(C.Structure):
 
 class ac_render_opts(C.Structure):
     _fields_ = [("n_rays", i32), ("num_steps", i32), ("upsample_steps", i32), ("bound", f32), ("inv_s", f32),
-                ("cos_anneal_ratio", f32), ("fd_eps", f32), ("perturb", i32), ("inv_s_dev", vp), ("near_m", vp), ("far_m", vp), ("precision", i32), ("skip_masked", i32)]
+                ("cos_anneal_ratio", f32), ("fd_eps", f32), ("perturb", i32), ("inv_s_dev", vp), ("near_m", vp), ("far_m", vp), ("precision", i32), ("skip_masked", i32), ("opacity_only", i32)]
 
 
 class ac_render_out(C.Structure):
@@ -138,7 +138,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
             fn.argtypes = args
             fn.restype = res
-        if handle.ac_version() != 4:
+        if handle.ac_version() != 5:
             raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
         _lib = handle
     return _lib

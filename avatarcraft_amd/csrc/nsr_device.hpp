@@ -121,6 +121,7 @@ struct RenderArgs {
     const float *inv_s_dev;     // non-NULL: inv_s is read from device memory (ac_render_opts.inv_s_dev)
     int fast;                   // ac_render_opts.precision
     int skip_masked;            // ac_render_opts.skip_masked (MODE_FINAL only)
+    int opacity_only;           // ac_render_opts.opacity_only: no colour network (rgb = 0)
     int perturb;
     unsigned long long *prof;   // AC_PROFILE builds only: [n_waves][10]: 8 per-phase s_memtime counters, whole-wave s_memtime and s_memrealtime (100 MHz)
     // posed-space rendering (render_can=False) only: see ac_render_rays_warped

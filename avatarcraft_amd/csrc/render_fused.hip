@@ -496,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
             const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
             float rgb[3] = { 0.0f, 0.0f, 0.0f };
-            if (!skip) {
+            if (!skip && !a.opacity_only) {                      // (wave-uniform)
                 if constexpr (FC) color_tile_fast(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
                 else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
             }
@@ -775,6 +775,8 @@ static int fill_render_args(RenderArgs &a, const ac_field *field, const ac_rende
     a.fast = op->precision;
     if (op->skip_masked != 0 && op->skip_masked != 1) { ac::set_error("ac_render_opts: skip_masked must be 0 or 1"); return AC_ERR_BAD_ARG; }
     a.skip_masked = op->skip_masked;
+    if (op->opacity_only != 0 && op->opacity_only != 1) { ac::set_error("ac_render_opts: opacity_only must be 0 or 1"); return AC_ERR_BAD_ARG; }
+    a.opacity_only = op->opacity_only;
     if ((op->near_m != nullptr) != (op->far_m != nullptr)) { ac::set_error("ac_render_opts: near_m and far_m go together"); return AC_ERR_BAD_ARG; }
     a.near_m = op->near_m; a.far_m = op->far_m;
     for (int j = 0; j < 4; ++j) {           // finite-difference reach in cells, per gather round (see encode_stencil)

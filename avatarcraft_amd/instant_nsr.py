@@ -261,6 +261,7 @@ class NeRFRenderer(nn.Module):
     # which no inference driver reads, covers the evaluated samples only).  False (default): every output as the reference computes it.
     # drivers.render_animation (render_warp.py's loop, which keeps rgb only) switches it on.
     skip_masked_samples = False
+    supports_opacity_only = True       # render(..., opacity_only=True) exists (no colour network: the frozen avatar of the opacity loss)
     supports_lean_render = True        # render(..., per_sample=False) exists (render_utils.render_instantnsr_naive asks before passing it)
 
     def _offsets_host(self):
@@ -300,8 +301,11 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ run == reference :133-299
     def run(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0,
-            render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True, per_sample: bool = True):
-        """per_sample = False (not in the reference's signature; what render_instantnsr_naive passes for its no-grad renders): the per-sample
+            render_can=True, verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True, per_sample: bool = True,
+            opacity_only: bool = False):
+        """opacity_only = True (no-grad renders only; what stylize.sds_step asks of the frozen avatar): the colour network is skipped, `rgb` is meaningless,
+        weight_sum / depth / normal / gradient_error are unchanged bit for bit.
+        per_sample = False (not in the reference's signature; what render_instantnsr_naive passes for its no-grad renders): the per-sample
         results (weights, pts_color, pts_alpha, z_vals) are not produced -- None in the returned tuple -- and the launch runs the renderer's
         lean instantiation (no optional outputs compiled in: no register spills, 12.6 MB less to write per 4096 rays)."""
         if not self._sdf_supported():
@@ -363,7 +367,7 @@ class NeRFRenderer(nn.Module):
                                               near_far=near_far)
         out = nsr_ops.render_rays(self._field(), ro, rd, num_steps, upsample_steps, bound, inv_s_t, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
                                   normal_epsilon_ratio=normal_epsilon_ratio, extras=bool(per_sample), warp=warp, near_far=near_far,
-                                  precision=self.render_precision, skip_masked=self.skip_masked_samples)
+                                  precision=self.render_precision, skip_masked=self.skip_masked_samples, opacity_only=bool(opacity_only))
         return (out["depth"].reshape(B, N), out.get("weights"), out["weights_sum"][:, None], out["image"].reshape(B, N, 3),
                 out["normal_map"], out["gradient_error"], 0.0, out.get("color"), out.get("alpha"), out.get("z_vals"))
 
@@ -566,7 +570,7 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ render == reference :358-408
     def render(self, rays_o, rays_d, num_steps, bound, upsample_steps, staged=False, max_ray_batch=4096, bg_color=None,
                cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0, render_can=True, verts=None, faces=None, Ts=None, perturb: bool = False,
-               use_mesh_guide: bool = True, per_sample: bool = True, **kwargs):
+               use_mesh_guide: bool = True, per_sample: bool = True, opacity_only: bool = False, **kwargs):
         B, N = rays_o.shape[:2]
         device = rays_o.device
         if staged and not self.cuda_ray:
@@ -587,7 +591,8 @@ class NeRFRenderer(nn.Module):
             _run = self.run_cuda if self.cuda_ray else self.run           # :360-363 (the reference has no run_cuda: see there)
             (depth, weights, weight_sum, image, normal, gradient_error, curvature_error, pts_color, pts_alpha, z_vals) = _run(
                 rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio, normal_epsilon_ratio, render_can=render_can,
-                verts=verts, faces=faces, Ts=Ts, perturb_overwrite=perturb, use_mesh_guide=use_mesh_guide, per_sample=per_sample)
+                verts=verts, faces=faces, Ts=Ts, perturb_overwrite=perturb, use_mesh_guide=use_mesh_guide, per_sample=per_sample,
+                **({"opacity_only": True} if (opacity_only and not self.cuda_ray) else {}))
         return {'depth': depth, 'weights': weights, 'weight_sum': weight_sum, 'rgb': image, 'normal': normal,
                 'gradient_error': gradient_error, 'curvature_error': curvature_error, 'pts_color': pts_color, 'pts_alpha': pts_alpha,
                 'z_vals': z_vals}

@@ -101,7 +101,7 @@ def _inv_s_arg(inv_s):
 
 def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.6, inv_s=1.0, bg=None, noise=None,
                 cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, extras=False, debug_indices=False, out=None, events=None, warp=None,
-                train_extras=False, near_far=None, precision="exact", skip_masked=False):
+                train_extras=False, near_far=None, precision="exact", skip_masked=False, opacity_only=False):
     """One launch of the fused renderer for N rays.  Returns a dict of CUDA tensors:
     image[N,3] weights_sum[N] depth[N] normal_map[N,3] eik[N,2] gradient_error[] (+ z_vals, weights,
     alpha, color, sdf, gradient when extras; + ss_inds, sort_index when debug_indices; + sdf_out16 [N,T,16], pts [N,T,3] and
@@ -111,6 +111,7 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
     precision: "exact" (every product an fp32 fma, bit-identical to the CPU oracle) or "fast" (layer 1 of the six finite-difference
     evaluations as a split-bf16 correction of the centre's; sample positions, indices and sdf unchanged bit for bit; ac_render_opts.precision).
     warp = WarpMesh(...) renders in posed space (run(render_can=False)): + can_mid[N,T,3], mask[N,T] views of the scratch.
+    opacity_only: the colour network is not evaluated (image = background over a black body); weights_sum, depth, normal_map, gradient_error unchanged.
     skip_masked (posed space only): tiles of 16 samples that the warp masks out entirely are not evaluated (ac_render_opts.skip_masked): image,
     weights_sum, depth, normal_map, weights and alpha unchanged bit for bit; sdf / color / gradient of skipped samples 0, gradient_error over the
     evaluated samples."""
@@ -165,7 +166,7 @@ def render_rays(field, rays_o, rays_d, num_steps=64, upsample_steps=64, bound=1.
         nm, fm = _chk(near_far[0].reshape(-1), "near", (N,)), _chk(near_far[1].reshape(-1), "far", (N,))
     op = L.ac_render_opts(N, int(num_steps), int(upsample_steps), float(bound), inv_s_f, float(cos_anneal_ratio),
                           float(np.float32(0.005 * (1.0 - normal_epsilon_ratio))), int(noise is not None), L.ptr(inv_s_t), L.ptr(nm), L.ptr(fm),
-                          PRECISIONS[precision], int(bool(skip_masked) and warp is not None))
+                          PRECISIONS[precision], int(bool(skip_masked) and warp is not None), int(bool(opacity_only)))
     if isinstance(res, RenderResult):
         res.opts = (op, inv_s_t, nm, fm)
     st = L.current_stream(dev)

@@ -71,9 +71,10 @@ def _background_on(device, shape, key):
 # ------------------------------------------------------------------ the batching harness
 def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_grad=False, return_torch=True, bkg_key: int = WHITE_BKG,
                             render_can: bool = False, perturb: bool = True, return_raw: bool = False, verts=None, faces=None, Ts=None,
-                            num_steps: int = 64, upsample_steps=64, bound: float = 1.6):
+                            num_steps: int = 64, upsample_steps=64, bound: float = 1.6, opacity_only: bool = False):
     """Same signature, defaults and outputs as the reference (render_utils.py:514-600):
-    returns (rgb[Ntot,3], sum of eikonal terms[, {depth[Ntot,1], weight_sum[Ntot,1], normal[Ntot,3]}])."""
+    returns (rgb[Ntot,3], sum of eikonal terms[, {depth[Ntot,1], weight_sum[Ntot,1], normal[Ntot,3]}]).
+    opacity_only (not in the reference): the caller will only read weight_sum / depth / normal -- a no-grad render then skips the colour network."""
     device = rays_o.device
     total = rays_o.shape[0]
     rgbs, depths, wsums, normals = [], [], [], []
@@ -82,6 +83,8 @@ def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_g
         verts = nsr_ops.WarpMesh(verts, faces, Ts, device)       # upload the frame's mesh once, not once per ray batch
     # the harness keeps rgb / depth / weight_sum / normal only: a no-grad render of this package's NeRFNetwork skips the per-sample outputs
     lean = {"per_sample": False} if (not requires_grad and getattr(net, "supports_lean_render", False)) else {}
+    if opacity_only and not requires_grad and getattr(net, "supports_opacity_only", False):
+        lean["opacity_only"] = True
     with torch.set_grad_enabled(requires_grad):
         for i in range(0, total, rays_per_batch):
             ro, rd = rays_o[i:i + rays_per_batch], rays_d[i:i + rays_per_batch]

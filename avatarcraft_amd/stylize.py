@@ -143,7 +143,8 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
             mark("render_grad_forward")
         with torch.no_grad():
             _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
-                                                     return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps)
+                                                     return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps,
+                                                     opacity_only=True)           # (only its weight_sum is read: no colour network)
             g_ws, opa = nsr_ops.sds_upstream(extra["weight_sum"], extra_gt["weight_sum"], 1e5 / ro.shape[0], want_grad=use_opacity)
             opa_vals.append(opa[0])
             g_eik = None

@@ -42,7 +42,8 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 4 */
+int ac_version(void);                /* ABI version, currently 5 (round 4: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
+                                      * ac_field_samples, ac_render_rays_occupancy, the measurement / liveness accessors) */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
 
 /* ---- hash-grid encoder -------------------------------------------------------------------
@@ -164,6 +165,10 @@ typedef struct ac_render_opts {
                                  weights / alpha are unchanged bit for bit (their contribution is exactly zero; the transmittance factor
                                  1 + 1e-7 of a masked sample is kept); the per-sample sdf / color / gradient of skipped samples are 0 and
                                  gradient_error covers the evaluated samples only.  0 = evaluate everything like the reference (default). */
+    int32_t opacity_only;     /* 1 = the caller wants weights_sum / depth / normal_map / gradient_error only (the frozen avatar of the opacity loss,
+                                 stylize.py:176-190, is rendered for its weight_sum alone): the colour network is not evaluated and `image` is the
+                                 background blend of a black body.  Every other output is unchanged bit for bit (alpha does not depend on the
+                                 colour).  0 = default. */
 } ac_render_opts;
 
 typedef struct ac_render_out {

@@ -576,3 +576,18 @@ def test_render_beside_a_foreign_long_kernel(env):
     json.dump(stats, open("gpurun_out/render_beside_gemm.json", "w"))
     # the two workloads really shared the device: the renders were slowed down by the GEMMs and / or the GEMMs by the renders
     assert stats["ms_per_render_beside_gemm"] > 1.05 * stats["ms_per_render_alone"] or stats["gemm_ms_each_while_rendering"] > 1.05 * stats["gemm_ms_each_alone"], stats
+
+
+def test_opacity_only_render_changes_nothing_but_the_image(env):
+    """ac_render_opts.opacity_only (what sds_step asks of the frozen avatar, of which it reads weight_sum only): no colour network; weights_sum, depth,
+    normal_map and gradient_error bit for bit the full render's, the image is the background over a black body"""
+    from avatarcraft_amd import nsr_ops
+    ro, rd = make_rays(64, 64, dist=1.7, f=50.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to("cuda:0")
+    bg = t(np.random.RandomState(2).uniform(0, 1, (4096, 3)))
+    for prec in ("exact", "fast"):
+        full = nsr_ops.render_rays(env["f"], t(ro), t(rd), 64, 64, 1.6, float(env["p"]["inv_s"]), bg=bg, precision=prec, out={})
+        lean = nsr_ops.render_rays(env["f"], t(ro), t(rd), 64, 64, 1.6, float(env["p"]["inv_s"]), bg=bg, precision=prec, opacity_only=True, out={})
+        for k in ("weights_sum", "depth", "normal_map", "gradient_error"):
+            assert torch.equal(full[k], lean[k]), (prec, k)
+        assert torch.allclose(lean["image"], (1.0 - lean["weights_sum"])[:, None] * bg, atol=1e-6) and not torch.equal(full["image"], lean["image"])

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ac_version() == 4
+    assert lib.ac_version() == 5
     # host helper needs no GPU: level table == oracle's == SURVEY Appendix B
     scale = (ctypes.c_float * 16)(); res = (ctypes.c_uint32 * 16)()
     S = float(np.float32(np.log2(1.381912879967776)))
@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from avatarcraft_amd import _lib
-    assert ctypes.sizeof(_lib.ac_render_opts) == 64 and _lib.ac_render_opts.precision.offset == 56 and _lib.ac_render_opts.inv_s_dev.offset == 32 and _lib.ac_render_opts.far_m.offset == 48
+    assert ctypes.sizeof(_lib.ac_render_opts) == 72 and _lib.ac_render_opts.opacity_only.offset == 64 and _lib.ac_render_opts.precision.offset == 56 and _lib.ac_render_opts.inv_s_dev.offset == 32 and _lib.ac_render_opts.far_m.offset == 48
     assert ctypes.sizeof(_lib.ac_render_out) == 17 * 8 and _lib.ac_render_out.sdf_out16.offset == 13 * 8 and _lib.ac_render_out.feat7.offset == 15 * 8
     assert ctypes.sizeof(_lib.ac_core_saved) == 9 * 8 and ctypes.sizeof(_lib.ac_core_upstream) == 5 * 8 and ctypes.sizeof(_lib.ac_core_grads) == 6 * 8 and _lib.ac_core_grads.split_level.offset == 5 * 8
     assert ctypes.sizeof(_lib.ac_wn_layer) == 40 and _lib.ac_wn_layer.rows.offset == 24 and ctypes.sizeof(_lib.ac_pg_entry) == 56 and _lib.ac_pg_entry.kind.offset == 52
