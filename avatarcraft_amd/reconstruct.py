@@ -30,7 +30,7 @@ def make_optimizer(net, epochs, lr=5e-4):
 
 
 def reconstruct_step(net, optimizer, rays_o, rays_d, rgb_gt, white_bkg=True, w_eikonal=W_EIKONAL, batch_size=BATCH_SIZE, num_steps=64, upsample_steps=64,
-                     flat_grad=None, process_group=None):
+                     flat_grad=None, process_group=None, grad_divisor=None):
     """one optimisation step on one ray batch (reconstruct.py:92-112).  rays_o, rays_d, rgb_gt: [n, 3] on the net's device.
     With a process group every rank takes its own ray batch and the flat gradient is all-reduced (sum, / world) like stylize.sds_step."""
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -52,7 +52,7 @@ def reconstruct_step(net, optimizer, rays_o, rays_d, rgb_gt, white_bkg=True, w_e
         world = torch.distributed.get_world_size(process_group)
         torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
         if world > 1:
-            flat_grad.div_(world)
+            flat_grad.div_(world if grad_divisor is None else int(grad_divisor))
     chk = getattr(net, "check_finite", None)
     if chk is not None:
         chk()                           # a NaN in this step's normals raises here (reference: the assert at instant_nsr.py:274), not after Adam has consumed it
@@ -64,7 +64,8 @@ def reconstruct_epochs(net, optimizer, scheduler, all_rays_o, all_rays_d, gt_rgb
                        max_steps=None, flat_grad=None, process_group=None):
     """the training loop of main_reconstruct (reconstruct.py:80-162): per epoch one random permutation of ALL rays (every view), batches of
     1600, scheduler.step() per epoch.  all_rays_o / all_rays_d / gt_rgb: [n_views * H * W, 3].  Under torch.distributed every rank draws the
-    same permutation and takes the batches rank, rank + world, ...  Returns the number of optimizer steps taken by this rank."""
+    same permutation and takes the batches rank, rank + world, ...; every batch of an epoch is visited once also when their number is not a multiple of the
+    world size (the ranks without a batch in the last round contribute a zero gradient).  Returns the number of optimizer steps taken by this rank."""
     gen = torch.Generator(); gen.manual_seed(seed)
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     rank = torch.distributed.get_rank(process_group) if dist_on else 0
@@ -74,11 +75,19 @@ def reconstruct_epochs(net, optimizer, scheduler, all_rays_o, all_rays_d, gt_rgb
     for epoch in range(epochs):
         perm = torch.randperm(n, generator=gen).to(all_rays_o.device)
         starts = list(range(0, n, batch_size))
-        starts = starts[rank:len(starts) - (len(starts) % world) if world > 1 else len(starts):world]
-        for i in starts:
-            idx = perm[i:i + batch_size]
-            loss = reconstruct_step(net, optimizer, all_rays_o[idx].contiguous(), all_rays_d[idx].contiguous(), gt_rgb[idx], white_bkg=white_bkg,
-                                    batch_size=batch_size, flat_grad=flat_grad, process_group=process_group)
+        rounds = -(-len(starts) // world)                      # every batch of the epoch exactly once, like the reference (reconstruct.py:86-92): in the last
+        for rnd in range(rounds):                              # round the ranks without a batch join the collective with a zero gradient (stylize.sds_idle_step)
+            k = rnd * world + rank
+            n_active = min(world, len(starts) - rnd * world)
+            if k < len(starts):
+                idx = perm[starts[k]:starts[k] + batch_size]
+                loss = reconstruct_step(net, optimizer, all_rays_o[idx].contiguous(), all_rays_d[idx].contiguous(), gt_rgb[idx], white_bkg=white_bkg,
+                                        batch_size=batch_size, flat_grad=flat_grad, process_group=process_group,
+                                        grad_divisor=n_active if n_active < world else None)
+            else:
+                from .stylize import sds_idle_step
+                sds_idle_step(net, optimizer, flat_grad, n_active, process_group)
+                loss = torch.zeros((), device=all_rays_o.device)
             if on_step is not None:
                 on_step(step, epoch, loss)
             step += 1

@@ -169,3 +169,43 @@ def test_stylize_outer_loop_uneven_views_two_ranks_gloo():
     assert len(seen0) == 2 * 4 and len(seen1) == 2 * 3         # guidance calls = views actually rendered: 7 per epoch in total
     for a, b in zip(p0, p1):
         assert np.array_equal(a, b)
+
+
+def _recon_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from avatarcraft_amd.reconstruct import reconstruct_epochs, make_optimizer
+    from avatarcraft_amd.stylize import flat_grad_view
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = TinyField().train()
+    opt, sched = make_optimizer(net, epochs=2)
+    flat = flat_grad_view(net.parameters())
+    g = torch.Generator().manual_seed(5)
+    n = 5 * 8                                                  # five batches of 8 rays on two ranks: three rounds, the last with one batch
+    ro = torch.randn(n, 3, generator=g); rd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1); rgb = torch.rand(n, 3, generator=g)
+    seen = []
+    steps = reconstruct_epochs(net, opt, sched, ro, rd, rgb, epochs=2, batch_size=8, flat_grad=flat, on_step=lambda s, e, l: seen.append((s, e, float(l))))
+    q.put((rank, steps, seen, [p.detach().numpy().copy() for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_reconstruct_epochs_uneven_batches_two_ranks_gloo():
+    """reconstruct_epochs under a process group visits every batch of an epoch once (reconstruct.py:86-92), also when batches % world != 0: the rank
+    without a batch in the last round contributes a zero gradient to the same collective; parameters stay replicated"""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_recon_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, seen0, p0), (r1, s1, seen1, p1) = res
+    assert s0 == s1 == 2 * 3
+    assert [l for _, _, l in seen1][2] == 0.0 and [l for _, _, l in seen0][2] > 0.0          # round 3: rank 1 idle, rank 0 holds the fifth batch
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
