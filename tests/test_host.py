@@ -305,3 +305,36 @@ def test_sds_guidance_matches_reference_over_stub_models():
             StableDiffusion(torch.device("cpu"), "1.5")
     with pytest.raises(ValueError):
         StableDiffusion(torch.device("cpu"), "3.0", components=SD.components())
+
+
+def test_dropin_fused_route_serves_models_instant_nsr(tmp_path, monkeypatch):
+    """dropin.install(fused=True): inside the reference's own `models` package the module `instant_nsr` -- and nothing else -- comes from this package, through
+    every import form the reference's drivers use (render_canonical.py:30 `import models.instant_nsr as instant_nsr`, stylize.py:17 `from models import
+    instant_nsr, diffusion`); a stand-in `models` package plays the reference's"""
+    import sys
+    import avatarcraft_amd.dropin as d
+    pkg = tmp_path / "models"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "instant_nsr.py").write_text("WHO = 'reference'\n")
+    (pkg / "diffusion.py").write_text("WHO = 'reference'\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        monkeypatch.delitem(sys.modules, k)
+    d.install(fused=True)
+    try:
+        import models.instant_nsr as a
+        from models import instant_nsr as b, diffusion
+        import models
+        assert a is b is models.instant_nsr and a.__name__ == "avatarcraft_amd.instant_nsr" and hasattr(a, "NeRFNetwork")
+        assert diffusion.WHO == "reference"
+    finally:
+        d.uninstall()
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+            del sys.modules[k]
+    import importlib
+    importlib.invalidate_caches()
+    import models.instant_nsr as c
+    assert c.WHO == "reference"                      # after uninstall the package serves its own module again
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
