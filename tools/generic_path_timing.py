@@ -1,0 +1,40 @@
+"""What the model variants OUTSIDE the fused renderer cost (stated, untimed): use_viewdirs=True and curvature_loss=True run
+through the generic path (fused sampling launch + torch MLPs over the HIP hash / SH encoders); 64 + 64 steps other than multiples of 16 are refused.
+    python tools/generic_path_timing.py      (on the GPU box)"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from avatarcraft_amd.instant_nsr import NeRFNetwork
+from avatarcraft_amd.synthetic import make_rays
+
+dev = "cuda:0"
+ro, rd = make_rays(64, 64, dist=1.7, f=50.0)
+ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+kw = dict(num_steps=64, bound=1.6, upsample_steps=64, staged=False, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True)
+
+
+def timed(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for name, opts in (("default (fused)", {}), ("use_viewdirs=True", dict(use_viewdirs=True)), ("curvature_loss=True", dict(curvature_loss=True))):
+    torch.manual_seed(1)
+    net = NeRFNetwork(**opts).to(dev)
+    with torch.no_grad():
+        net.encoder.embeddings.uniform_(-0.05, 0.05)
+        net.sdf_net[0].weight_v[:, 3:].normal_(0, 0.05)
+
+    def infer():
+        with torch.no_grad():
+            net.eval().render(ro[None], rd[None], perturb=False, **kw)
+
+    def train():
+        net.train().zero_grad()
+        out = net.render(ro[None], rd[None], perturb=True, **kw)
+        (out["rgb"].sum() + out["gradient_error"] + (out["curvature_error"] if torch.is_tensor(out["curvature_error"]) else 0.0)).backward()
+    print(f"{name:22s} 4096 rays x (64+64): inference {timed(infer):8.3f} ms   forward + backward {timed(train):8.3f} ms")
