@@ -340,6 +340,10 @@ __device__ __forceinline__ void fill_lds_color_fast(float *lds, const RenderArgs
 // buffer descriptor (32-bit byte offsets, hardware bounds check) and are issued ROUND levels at a time.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+#ifndef AC_DENSE_PAIRS
+#define AC_DENSE_PAIRS 1    // dense levels: the corners (x, x + 1) of a cell through ONE 16-byte gather (round 4)
+#endif
 
 template <int ROUND>
 __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t table, int g, const int (&jmode)[4],
@@ -364,6 +368,16 @@ __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t ta
             const uint32_t ax0 = gx, ax1 = gx + 1u, ay0 = gy * my, ay1 = ay0 + my, az0 = gz * mz, az1 = az0 + mz;
             const int mode = jmode[j];                      // wave-uniform: one code path per gather round
             uint32_t idx[8];
+#if AC_DENSE_PAIRS
+            if (mode == 0) {                                // all four levels of this round are dense: the corners (x, x + 1) are ADJACENT entries -- one
+#pragma unroll                                              // 16-byte gather per pair (the per-CU gather path is what the kernel is short of: r04_experiments 7)
+                for (int p = 0; p < 4; ++p) {
+                    const u32q w = __builtin_amdgcn_raw_buffer_load_b128(table, AC_GOFF((offset + (ax0 + ((p & 1) ? ay1 : ay0) + ((p & 2) ? az1 : az0))) * 8u), 0, 0);
+                    v[jj][2 * p] = u32x2{ w.x, w.y }; v[jj][2 * p + 1] = u32x2{ w.z, w.w };
+                }
+                continue;
+            }
+#endif
             if (mode == 0) {                                // all four levels of this round are dense
 #pragma unroll
                 for (int c = 0; c < 8; ++c) idx[c] = ((c & 1) ? ax1 : ax0) + ((c & 2) ? ay1 : ay0) + ((c & 4) ? az1 : az0);
@@ -569,6 +583,7 @@ template <int GM>
 __device__ __forceinline__ uint32_t gidx(const LvlC &L, uint32_t tx, uint32_t ty, uint32_t tz)
 {
     if constexpr (GM == 1) return (tx ^ ty ^ tz) & L.mask;
+    else if constexpr (GM == 0) return tx + ty + tz;                       // a dense round (every lane's level): index < level size by construction
     else return (L.hashed ? (tx ^ ty ^ tz) : (tx + ty + tz)) & L.mask;
 }
 __device__ __forceinline__ void interp8(const u32x2 (&v)[8], float qx, float qy, float qz, bool oob, float &f0, float &f1)
@@ -616,6 +631,19 @@ __device__ __forceinline__ AxisGeo<K, SIGN> coarse_issue(rsrc_t table, const Lvl
     const uint32_t mk = K == 0 ? 1u : (K == 1 ? L.my : L.mz);
     const uint32_t base = K == 0 ? tx[0] : (K == 1 ? ty[0] : tz[0]);
     const uint32_t tk = SIGN == 0 ? base + 2u * mk : base - mk;   // coordinate g+2 / g-1 along K
+    if constexpr (GM == 0 && K != 0 && !AC_SENTINEL_LOADS) {      // dense round, a y- or z-face: its corners come in x-adjacent pairs
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int c = face_corner<K>(0, 2 * pp);
+            const uint32_t ay = K == 1 ? tk : ty[(c >> 1) & 1], az = K == 2 ? tk : tz[(c >> 2) & 1];
+            w[2 * pp] = u32x2{ 0u, 0u }; w[2 * pp + 1] = u32x2{ 0u, 0u };
+            if (a.need) {
+                const u32q q = __builtin_amdgcn_raw_buffer_load_b128(table, AC_GOFF((L.offset + (tx[0] + ay + az)) * 8u), 0, 0);
+                w[2 * pp] = u32x2{ q.x, q.y }; w[2 * pp + 1] = u32x2{ q.z, q.w };
+            }
+        }
+        return a;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = face_corner<K>(0, i);
@@ -724,10 +752,18 @@ __device__ __forceinline__ void stencil_levels(const float *__restrict__ lds, fl
     uint32_t tx[2], ty[2], tz[2];
     tx[0] = gc[0]; tx[1] = gc[0] + 1u; ty[0] = gc[1] * L.my; ty[1] = ty[0] + L.my; tz[0] = gc[2] * L.mz; tz[1] = tz[0] + L.mz;
     u32x2 vc[8];
+    if constexpr (GM == 0) {                                // dense round: x-adjacent corners through one 16-byte gather each
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const u32q w = __builtin_amdgcn_raw_buffer_load_b128(table, AC_GOFF((L.offset + (tx[0] + ty[p & 1] + tz[p >> 1])) * 8u), 0, 0);
+            vc[2 * p] = u32x2{ w.x, w.y }; vc[2 * p + 1] = u32x2{ w.z, w.w };
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         vc[c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((L.offset + gidx<GM>(L, tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2])) * 8u), 0, 0);
-    if (!fine) {
+    }
+    if (GM == 0 || !fine) {
         u32x2 w0[4], w1[4], w2[4], w3[4], w4[4], w5[4];
         const auto a0 = coarse_issue<0, 0, GM>(table, L, gc, tx, ty, tz, oob, xp, w0);
         const auto a1 = coarse_issue<0, 1, GM>(table, L, gc, tx, ty, tz, oob, xm, w1);
@@ -860,8 +896,9 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {                           // one copy of each code path; results go to LDS / a rotating fe0
         float c0, c1;
-        const bool fine = (jbits >> (8 + j)) & 1u, hashed4 = ((jbits >> (2 * j)) & 3u) == 1u;
+        const bool fine = (jbits >> (8 + j)) & 1u, hashed4 = ((jbits >> (2 * j)) & 3u) == 1u, dense4 = ((jbits >> (2 * j)) & 3u) == 0u;
         if (AC_STENCIL_SPECIALIZE && hashed4) stencil_levels<1, FV>(lds, fslab, table, lane, g, j, fine, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
+        else if (AC_DENSE_PAIRS && dense4 && !fine) stencil_levels<0, FV>(lds, fslab, table, lane, g, j, false, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
         else stencil_levels<2, FV>(lds, fslab, table, lane, g, j, fine, ux, uy, uz, oob, xp, xm, yp, ym, zp, zm, c0, c1);
         // rotate the centre features into place: after the 4th iteration fe0[j] holds level 4j+g
         fe0[0][0] = fe0[1][0]; fe0[0][1] = fe0[1][1]; fe0[1][0] = fe0[2][0]; fe0[1][1] = fe0[2][1];
