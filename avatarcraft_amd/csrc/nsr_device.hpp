@@ -342,7 +342,9 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32q __attribute__((ext_vector_type(4)));
 #ifndef AC_DENSE_PAIRS
-#define AC_DENSE_PAIRS 1    // dense levels: the corners (x, x + 1) of a cell through ONE 16-byte gather (round 4)
+#define AC_DENSE_PAIRS 0    // 1: on dense levels the corners (x, x + 1) of a cell come through ONE 16-byte gather (round 4 experiment: bit-identical, 8.7 % fewer
+                            // gather instructions on the all-dense round, and NO gain -- render 0.7438 vs 0.7464 ms, the frozen SDS render 0.969 vs 0.959:
+                            // the texture-address path is paced by bytes per instruction, a 64-lane dwordx4 costs it what two dwordx2 cost; r04_experiments 7b)
 #endif
 
 template <int ROUND>
