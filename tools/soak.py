@@ -86,4 +86,32 @@ def step():
 
 
 total_bad += soak("two stylisation steps from identical state (parameters after Adam)", step, int(25 * scale))
+
+# round 4: the occupancy-grid render in one launch, the per-sample field on packed samples, one posed frame (search + two render passes)
+from avatarcraft_amd import raymarching
+from avatarcraft_amd.synthetic import make_body
+occ_net = bench.make_net(p, tab, dev, False, cuda_ray=True)
+with torch.no_grad():
+    occ_net.deviation_net.variance.fill_(float(np.log(512.0) / 10.0))
+occ_net.update_extra_state(1.6)
+vro, vrd = (torch.from_numpy(a).to(dev) for a in make_rays(256, 256, dist=1.7, f=200.0, yaw=0.0, pitch=0.0))
+occ_field = occ_net._field()
+total_bad += soak("occupancy render, one launch, 65 536 rays",
+                  lambda: nsr_ops.render_rays_occupancy(occ_field, vro, vrd, occ_net.density_grid, occ_net.mean_density, 1.6, 0.005, occ_net.forward_variance(), 1.0),
+                  int(100 * scale))
+xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, 1.6, occ_net.density_grid, occ_net.mean_density, 1, align=128, force_all_rays=True)
+total_bad += soak("field on packed samples (ac_field_samples), %d samples" % xyzs.shape[0],
+                  lambda: nsr_ops.field_samples(occ_field, xyzs, dirs, deltas, 1.6, 0.005, 512.0, 1.0, want_sdf=True, want_gradient=True), int(300 * scale))
+verts, faces, Ts = make_body(n_lat=83, n_lon=83)
+wm = nsr_ops.WarpMesh(verts, faces, Ts, dev, 0.05, 0.05, True)
+pro, prd = (torch.from_numpy(a).to(dev) for a in make_rays(256, 256, dist=1.8, f=443.405 / 2, yaw=0.3, pitch=-0.1))
+
+
+def posed():
+    o = nsr_ops.render_rays(f, pro, prd, 32, 32, 1.6, inv_s, warp=wm, skip_masked=True)
+    return {k: o[k] for k in ("image", "weights_sum", "depth", "normal_map", "mask", "can_mid")}
+
+
+total_bad += soak("posed frame (65 536 rays: two closest-face searches + two render passes)", posed, int(25 * scale))
+print("hand-off timeouts on this stream:", nsr_ops.handoff_timeouts(dev))
 print("total: %d differing repeats; %.0f s" % (total_bad, time.time() - t0))
