@@ -42,8 +42,11 @@ class ScaledLinearSchedule:
 class StableDiffusion(nn.Module):
     """same constructor arguments, attributes and methods as the reference's class (models/diffusion.py:23)"""
 
-    def __init__(self, device, version="1.5", components=None, latent_size=512):
+    def __init__(self, device, version="1.5", components=None, latent_size=512, unet_autocast=None):
+        """unet_autocast (not in the reference, which runs everything in fp32): a torch dtype (torch.bfloat16) under which the no-grad UNet forward
+        runs (torch.autocast); the VAE encoder -- the only differentiable stage -- stays fp32.  Opt-in: the noise prediction moves by bf16 round-off."""
         super().__init__()
+        self.unet_autocast = unet_autocast
         self.sd_version = version
         self.device = device
         self.num_train_timesteps = 1000
@@ -120,7 +123,11 @@ class StableDiffusion(nn.Module):
             latent_model_input = torch.cat([latents_noisy] * 2)
             if self.use_depth and pred_depth is not None:
                 latent_model_input = torch.cat([latent_model_input, pred_depth], dim=1)
-            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings).sample
+            if self.unet_autocast is not None and latent_model_input.is_cuda:
+                with torch.autocast("cuda", dtype=self.unet_autocast):
+                    noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings).sample.float()
+            else:
+                noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings).sample
         noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
         noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
         w = 1 - self.alphas[t]

@@ -465,7 +465,26 @@ def time_sd_arch_step(dev, p, table, steps=2):
             phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
     nu, nv = sd_arch.parameter_counts()
     g = phases.get("guidance", 0.0)
-    return {"ms_per_step": ms, "guidance_ms": g, "render_and_backward_ms": ms - g, "guidance_share": g / ms, "steps": steps, "setup_and_first_step_s": t_setup,
+    # the same step with the (no-grad) UNet forward under bf16 autocast -- an option of this package's StableDiffusion, not the reference's precision
+    bf16 = None
+    try:
+        sd.unet_autocast = torch.bfloat16
+        sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
+        torch.cuda.synchronize()
+        marks2 = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat, timers=marks2)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0) / steps * 1e3
+        g2 = sum(e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(marks2[:-1], marks2[1:]) if n1 == "guidance") / steps
+        bf16 = {"ms_per_step": ms2, "guidance_ms": g2, "note": "UNet forward (no grad) under torch.autocast(bfloat16); VAE encoder (with grad) fp32; opt-in "
+                                                                "(StableDiffusion(unet_autocast=torch.bfloat16)), not the reference's precision"}
+    except Exception as e:                    # noqa: BLE001
+        bf16 = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        sd.unet_autocast = None
+    return {"ms_per_step": ms, "unet_bf16_autocast": bf16, "guidance_ms": g, "render_and_backward_ms": ms - g, "guidance_share": g / ms, "steps": steps, "setup_and_first_step_s": t_setup,
             "phase_ms": {k: round(v, 3) for k, v in phases.items()},
             "guidance": f"SD-1.5 ARCHITECTURE stand-in (avatarcraft_amd/sd_arch.py): UNet2DConditionModel {nu} + AutoencoderKL encoder {nv} parameters, random "
                         "weights, fp32; 512 x 512 VAE encode with grad, UNet on 2 x 4 x 64 x 64 latents with [2, 77, 768] text embeddings -- the real "
