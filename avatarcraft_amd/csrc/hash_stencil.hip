@@ -227,7 +227,39 @@ constexpr int NBUCKET = 64;
 constexpr int RCAP = AC_RCAP;              // records per wave buffer; add8 reserves room for 8 x 64 records
 constexpr int WAVE_WORDS = 3 * RCAP + 2 * NBUCKET;     // LDS words per wave: ridx, rv0, rv1 [RCAP], hist, base [64]
 static_assert(RCAP % 2 == 0 && RCAP >= 1024, "wave buffer: room for two batches of 8 x 64 records");
+#ifndef AC_REC16
+#define AC_REC16 0          // 1: queue records padded to 16 bytes (one aligned dwordx4 store / load per record instead of three dword accesses; +33 % queue bytes)
+#endif
+#ifndef AC_REC8
+#define AC_REC8 1           // 1 (round 4): 8-byte queue records -- 13 bits of entry index inside its bucket | v0 rounded to 16 explicit mantissa bits (25 bits) | v1
+#endif                      //    rounded to 17 (26 bits).  PRECISION CONTRACT of the table gradient: every (entry, v0, v1) contribution is rounded
+                            //    to nearest at 2^-17 / 2^-18 of its own magnitude before the order-independent fixed-point sum -- below the fp32 round-off of a sum
+                            //    of a few records, checked against the fp64 oracle backward at 3e-4 of max (observed 1.2e-4, unchanged).  The queue traffic is what
+                            //    the two scatter passes are short of: 16-byte records cost the step +0.21 ms, 8-byte ones gain (profiles/r04_experiments.txt 8b).
+#if AC_REC16
+struct __attribute__((aligned(16))) Rec { uint32_t idx; float v0, v1; uint32_t pad; };
+#elif AC_REC8
+struct __attribute__((aligned(8))) Rec { uint32_t lo, hi; };
+// values are rounded when they are RECORDED (add8), so that the level's max |v| -- the fixed-point scale -- is taken over what is actually summed
+__device__ __forceinline__ float rec_round(float v, int drop)        // round to nearest at bit `drop` (quiet NaN and Inf survive; FLT_MAX may round to Inf)
+{
+    return __uint_as_float((__float_as_uint(v) + (1u << (drop - 1))) & ~((1u << drop) - 1u));
+}
+__device__ __forceinline__ Rec rec_pack(uint32_t idx13, float v0, float v1)
+{
+    const uint32_t a = __float_as_uint(v0) >> 7, b = __float_as_uint(v1) >> 6;      // 25 and 26 bits (the dropped bits are zero: rec_round)
+    Rec r; r.lo = idx13 | (a << 13); r.hi = (a >> 19) | (b << 6);
+    return r;
+}
+__device__ __forceinline__ void rec_unpack(const Rec &r, uint32_t &idx13, float &v0, float &v1)
+{
+    idx13 = r.lo & 0x1fffu;
+    v0 = __uint_as_float(((r.lo >> 13) | ((r.hi & 0x3fu) << 19)) << 7);
+    v1 = __uint_as_float((r.hi >> 6) << 6);
+}
+#else
 struct Rec { uint32_t idx; float v0, v1; };
+#endif
 
 struct BinSink {
     uint32_t *ridx; float *rv0, *rv1;      // this wave's LDS record buffer [RCAP]; ridx = entry | rank inside its bucket << 19
@@ -270,8 +302,13 @@ struct BinSink {
             if (m[k] == 0ull) continue;
             if (pred[k]) {
                 const uint32_t pos = cnt + (uint32_t)__builtin_popcountll(m[k] & ((1ull << lane) - 1ull));
-                ridx[pos] = index[k] | (rank[k] << 19); rv0[pos] = v[2 * k]; rv1[pos] = v[2 * k + 1];
-                const uint32_t a0 = __float_as_uint(v[2 * k]) & 0x7fffffffu, a1 = __float_as_uint(v[2 * k + 1]) & 0x7fffffffu;
+#if AC_REC8
+                const float r0 = rec_round(v[2 * k], 7), r1 = rec_round(v[2 * k + 1], 6);
+#else
+                const float r0 = v[2 * k], r1 = v[2 * k + 1];
+#endif
+                ridx[pos] = index[k] | (rank[k] << 19); rv0[pos] = r0; rv1[pos] = r1;
+                const uint32_t a0 = __float_as_uint(r0) & 0x7fffffffu, a1 = __float_as_uint(r1) & 0x7fffffffu;
                 mx = mx > a0 ? mx : a0; mx = mx > a1 ? mx : a1;
             }
             cnt += (uint32_t)__builtin_popcountll(m[k]);
@@ -318,7 +355,14 @@ struct BinSink {
                 const uint32_t idx = packed[u] & 0x7ffffu, bucket = idx >> sh;
                 const uint32_t slot = bs[u] + (packed[u] >> 19);
                 if (slot < cap) {
+#if AC_REC8
+                    const Rec r = rec_pack(idx - (bucket << sh), v0[u], v1[u]);
+#else
                     Rec r; r.idx = idx - (bucket << sh); r.v0 = v0[u]; r.v1 = v1[u];
+#endif
+#if AC_REC16
+                    r.pad = 0u;
+#endif
 #if AC_ABL_FLUSH == 2       // timing ablation: bin the records but do not write them
                     if (v0[u] == 123456.789f)
 #endif
@@ -640,8 +684,12 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
         for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) accf[e] = 0.0f;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const Rec r = q[i];
-            atomicAdd(&accf[2 * r.idx], r.v0); atomicAdd(&accf[2 * r.idx + 1], r.v1);
+#if AC_REC8
+            uint32_t ri; float rv0, rv1; rec_unpack(q[i], ri, rv0, rv1);
+#else
+            const Rec r = q[i]; const uint32_t ri = r.idx; const float rv0 = r.v0, rv1 = r.v1;
+#endif
+            atomicAdd(&accf[2 * ri], rv0); atomicAdd(&accf[2 * ri + 1], rv1);
         }
         __syncthreads();
         for (uint32_t e = threadIdx.x; e < mine * 2; e += blockDim.x)
@@ -658,9 +706,20 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
 #endif
     constexpr int U = AC_ACC_U;                          // queue records in flight per thread
     for (uint32_t i0 = threadIdx.x; i0 < n; i0 += blockDim.x * U) {
-        Rec r[U];
+        Rec raw[U];
+        struct { uint32_t idx; float v0, v1; } r[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * blockDim.x; r[u] = q[i < n ? i : i0]; if (i >= n) { r[u].v0 = 0.0f; r[u].v1 = 0.0f; } }
+        for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * blockDim.x; raw[u] = q[i < n ? i : i0]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = i0 + u * blockDim.x;
+#if AC_REC8
+            rec_unpack(raw[u], r[u].idx, r[u].v0, r[u].v1);
+#else
+            r[u].idx = raw[u].idx; r[u].v0 = raw[u].v0; r[u].v1 = raw[u].v1;
+#endif
+            if (i >= n) { r[u].v0 = 0.0f; r[u].v1 = 0.0f; }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #ifdef AC_ABL_NOLDSATOMIC
