@@ -22,6 +22,9 @@ using namespace acdev;
 
 namespace {
 
+#ifndef AC_RUN_EARLY_OUT
+#define AC_RUN_EARLY_OUT 1     // the segmented run scan stops as soon as every lane of the wave has met the head of its run (run_reduce)
+#endif
 #ifndef AC_ABL_FLUSH
 #define AC_ABL_FLUSH 0
 #endif
@@ -182,12 +185,30 @@ __device__ __forceinline__ bool run_reduce(float (&v)[N], bool head, int lane, b
 #pragma unroll
     for (int c = 0; c < N; c += 8)
         asm volatile("" : "+v"(v[c]), "+v"(v[c + 1]), "+v"(v[c + 2]), "+v"(v[c + 3]), "+v"(v[c + 4]), "+v"(v[c + 5]), "+v"(v[c + 6]), "+v"(v[c + 7]));
-    run_step<N, 0x111, 0xf>(v, f);
-    run_step<N, 0x112, 0xf>(v, f);
-    run_step<N, 0x114, 0xf>(v, f);
-    run_step<N, 0x118, 0xf>(v, f);
-    run_step<N, 0x142, 0xa>(v, f);          // row_bcast15: rows 1 and 3 take lane 15 of rows 0 and 2
-    run_step<N, 0x143, 0xc>(v, f);          // row_bcast31: rows 2 and 3 take lane 31
+    // A step only moves values into lanes that have not met the head of their run yet (f == 0): once no such lane is left in the wave, the
+    // remaining steps would add `neighbour * 0` everywhere and are skipped (wave-uniform branch; round 4: the scan is more than half of the
+    // fill's vector instructions, and outside the densely sampled shell of the surface runs are a few lanes long on all but the coarsest levels).
+    // The skipped additions of +-0 can only turn a -0 into +0: a value that the != 0 predicate drops or the fixed-point sum reads as 0 either way.
+#if AC_RUN_EARLY_OUT
+#define AC_RUN_DONE() (__builtin_amdgcn_ballot_w64(f == 0) == 0ull)
+#else
+#define AC_RUN_DONE() false
+#endif
+    do {
+        if (AC_RUN_DONE()) break;
+        run_step<N, 0x111, 0xf>(v, f);
+        if (AC_RUN_DONE()) break;
+        run_step<N, 0x112, 0xf>(v, f);
+        if (AC_RUN_DONE()) break;
+        run_step<N, 0x114, 0xf>(v, f);
+        if (AC_RUN_DONE()) break;
+        run_step<N, 0x118, 0xf>(v, f);
+        if (AC_RUN_DONE()) break;
+        run_step<N, 0x142, 0xa>(v, f);          // row_bcast15: rows 1 and 3 take lane 15 of rows 0 and 2
+        if (AC_RUN_DONE()) break;
+        run_step<N, 0x143, 0xc>(v, f);          // row_bcast31: rows 2 and 3 take lane 31
+    } while (false);
+#undef AC_RUN_DONE
 #endif
     const int next_head = __shfl_down(head ? 1 : 0, 1);
     return lane == 63 || next_head != 0;
