@@ -70,6 +70,10 @@ _SIGS = {
     "ac_hash_encode_backward_scratch": ([vp, u32, u32, u32, f32, u32, u32], C.c_size_t),
     "ac_hash_encode_backward_ws": ([vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp, vp, C.c_size_t, vp], C.c_int),
     "ac_hash_corner_indices": ([vp, vp, vp, u32, u32, u32, f32, u32, vp], C.c_int),
+    "ac_hash_encode_forward_typed": ([C.c_int, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp], C.c_int),
+    "ac_hash_encode_backward_typed": ([C.c_int, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp, vp], C.c_int),
+    "ac_sh_encode_forward_typed": ([C.c_int, vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
+    "ac_sh_encode_backward_typed": ([C.c_int, vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),
     "ac_sh_encode_forward": ([vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
     "ac_sh_encode_backward": ([vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),
     "ac_march_rays_train": ([vp, vp, vp, f32, C.c_int, f32, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, vp], C.c_int),
@@ -159,6 +163,24 @@ def ptr(t):
 def current_stream(device=None):
     import torch
     return torch.cuda.current_stream(device).cuda_stream
+
+
+DTYPE_CODES = {}       # torch dtype -> AC_DTYPE_* (include/avatarcraft_hip.h), filled on first use (torch is imported lazily by the callers)
+
+
+def dtype_code(t, name="inputs", like=None):
+    """AC_DTYPE_F32 / _F16 / _F64 of a tensor; the reference's CHECK_IS_FLOATING (hashencoder.cu:19) for anything else.  like: tensors that must share
+    the dtype (the reference instantiates its kernels on ONE scalar_t for every pointer of the call)."""
+    import torch
+    if not DTYPE_CODES:
+        DTYPE_CODES.update({torch.float32: 0, torch.float16: 1, torch.float64: 2})
+    code = DTYPE_CODES.get(t.dtype)
+    if code is None:
+        raise RuntimeError(f"{name} must be a floating tensor")
+    for other, oname in (like or ()):
+        if other.dtype != t.dtype:
+            raise RuntimeError(f"{oname} must have the dtype of {name} ({t.dtype}), got {other.dtype}")
+    return code
 
 
 def require_cuda(*tensors):

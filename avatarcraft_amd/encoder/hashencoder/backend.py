@@ -9,7 +9,6 @@ from ... import _lib as L
 
 def _floating(t, name):
     if t.dtype != torch.float32:
-        # reference dispatches float/half/double; the MI355X path is fp32 (fp32 is the only dtype exercised)
         raise RuntimeError(f"{name} must be a float32 tensor")
 
 
@@ -62,9 +61,14 @@ class _Backend:
     @staticmethod
     def hash_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L_, S, H, calc_grad_inputs, dy_dx):
         L.require_cuda(inputs, embeddings, offsets, outputs, dy_dx)
-        for t, n in ((inputs, "inputs"), (embeddings, "embeddings"), (outputs, "outputs"), (dy_dx, "dy_dx")):
-            _floating(t, n)
+        # the reference dispatches on inputs.scalar_type() over Float / Half / Double (hashencoder.cu:352): one dtype for every tensor of the call
+        code = L.dtype_code(inputs, "inputs", ((embeddings, "embeddings"), (outputs, "outputs"), (dy_dx, "dy_dx")))
         oh = _Backend._offsets_host(offsets)
+        if code != 0:
+            L.check(L.lib().ac_hash_encode_forward_typed(code, inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(), oh.ctypes.data,
+                                                         outputs.data_ptr(), B, D, C, L_, float(np.float32(S)), H, int(bool(calc_grad_inputs)),
+                                                         dy_dx.data_ptr(), L.current_stream(inputs.device)), "hash_encode_forward")
+            return
         L.check(L.lib().ac_hash_encode_forward(inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(), oh.ctypes.data,
                                                outputs.data_ptr(), B, D, C, L_, float(np.float32(S)), H, int(bool(calc_grad_inputs)),
                                                dy_dx.data_ptr(), L.current_stream(inputs.device)), "hash_encode_forward")
@@ -73,10 +77,16 @@ class _Backend:
     def hash_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L_, S, H, calc_grad_inputs, dy_dx,
                              grad_inputs):
         L.require_cuda(grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs)
-        for t, n in ((grad, "grad"), (inputs, "inputs"), (embeddings, "embeddings"), (grad_embeddings, "grad_embeddings")):
-            _floating(t, n)
+        code = L.dtype_code(grad, "grad", ((inputs, "inputs"), (embeddings, "embeddings"), (grad_embeddings, "grad_embeddings"), (dy_dx, "dy_dx"),
+                                           (grad_inputs, "grad_inputs")))
         oh = _Backend._offsets_host(offsets)
         Sf = float(np.float32(S))
+        if code != 0:           # half / double: hardware atomics (packed half2 / fp64), no binned path
+            L.check(L.lib().ac_hash_encode_backward_typed(code, grad.data_ptr(), inputs.data_ptr(), embeddings.data_ptr(), offsets.data_ptr(),
+                                                          oh.ctypes.data, grad_embeddings.data_ptr(), B, D, C, L_, Sf, H, int(bool(calc_grad_inputs)),
+                                                          dy_dx.data_ptr(), grad_inputs.data_ptr(), L.current_stream(inputs.device)),
+                    "hash_encode_backward")
+            return
         scratch, nbytes = None, 0
         if BINNED_SCATTER and not calc_grad_inputs:
             nbytes = int(L.lib().ac_hash_encode_backward_scratch(oh.ctypes.data, D, C, L_, Sf, H, B))
@@ -91,6 +101,8 @@ class _Backend:
     @staticmethod
     def hash_stencil_forward(x, embeddings, offsets, outputs, B, C, L_, S, H, eps, bound):
         L.require_cuda(x, embeddings, offsets, outputs)
+        for t, n in ((x, "x"), (embeddings, "embeddings"), (outputs, "outputs")):
+            _floating(t, n)                 # the stencil operators are not part of the reference's surface: fp32 only
         oh = _Backend._offsets_host(offsets)
         L.check(L.lib().ac_hash_stencil_forward(x.data_ptr(), embeddings.data_ptr(), oh.ctypes.data, outputs.data_ptr(), B, C, L_,
                                                 float(np.float32(S)), H, float(eps), float(bound), L.current_stream(x.device)),

@@ -8,6 +8,7 @@ ac_hash_stencil_forward/backward)."""
 import numpy as np
 import torch
 from torch import nn
+from torch.amp import custom_bwd, custom_fwd
 
 from .backend import _backend
 
@@ -21,7 +22,11 @@ def level_layout(input_dim, num_levels, per_level_scale, base_resolution, max_en
 
 
 class GridEncodeFn(torch.autograd.Function):
+    """float32, float16 and float64 tensors alike (one dtype per call: hashencoder.cu:352 dispatches on inputs.scalar_type()); under autocast the
+    operands arrive as half, exactly like the reference's `@custom_fwd(cast_inputs=torch.half)` (hashgrid.py:13)"""
+
     @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.half)
     def forward(ctx, x01, table, offsets, per_level_scale, base_resolution, want_input_grad=False):
         x01, table, offsets = x01.contiguous(), table.contiguous(), offsets.contiguous()
         n, dim = x01.shape
@@ -35,10 +40,11 @@ class GridEncodeFn(torch.autograd.Function):
         return level_major.permute(1, 0, 2).reshape(n, levels * feats)
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         x01, table, offsets, jac = ctx.saved_tensors
         n, dim, feats, levels, log2_scale, base_resolution, want_input_grad = ctx.cfg
-        dy = dy.view(n, levels, feats).permute(1, 0, 2).contiguous()
+        dy = dy.to(x01.dtype).view(n, levels, feats).permute(1, 0, 2).contiguous()
         d_table = torch.zeros_like(table)
         d_x = torch.zeros_like(x01) if want_input_grad else torch.zeros(1, device=x01.device, dtype=x01.dtype)
         _backend.hash_encode_backward(dy, x01, table, offsets, d_table, n, dim, feats, levels, log2_scale, base_resolution, want_input_grad, jac, d_x)

@@ -3,6 +3,7 @@ encoder/shencoder/sphere_harmonics.py:11-83 (same class name, constructor, attri
 ac_sh_encode_forward / ac_sh_encode_backward, csrc/shencoder.hip)."""
 import torch
 from torch import nn
+from torch.amp import custom_bwd, custom_fwd
 
 from .backend import _backend
 
@@ -17,6 +18,7 @@ class SphericalHarmonicsFn(torch.autograd.Function):
     """y[b, :] = the degree**2 real SH basis functions at direction x[b, :]; optionally keeps dy/dx for the backward"""
 
     @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.half)         # sphere_harmonics.py:13 of the reference: half under autocast
     def forward(ctx, directions, degree, want_input_grad):
         x = directions.contiguous()
         n, d = x.shape
@@ -32,13 +34,14 @@ class SphericalHarmonicsFn(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
+    @custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         if not ctx.want_input_grad:
             return None, None, None
         x, jac = ctx.saved_tensors
         n, d, degree = ctx.shape
         dx = torch.zeros_like(x)
-        _backend.sh_encode_backward(dy.contiguous(), x, n, d, degree, jac, dx)
+        _backend.sh_encode_backward(dy.to(x.dtype).contiguous(), x, n, d, degree, jac, dx)
         return dx, None, None
 
 

@@ -106,6 +106,19 @@ def sds_view(rank):
     return ro.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy(), rd.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy()
 
 
+class _NoStep:
+    """optimizer stand-in whose step() leaves the gradients and the weights alone (bench.py inspects the gradient of one more step)"""
+
+    def __init__(self, opt):
+        self.param_groups = opt.param_groups
+
+    def zero_grad(self, set_to_none=False):
+        pass
+
+    def step(self):
+        pass
+
+
 def time_sds_step(dev, p, table, rank, world, dist, steps):
     """secondary metric: ms per 4096-ray SDS step (stylize.py coarse stage: 64x64 sub-sampled view of a 256x256 camera,
     3 renders + the backward of the three loss terms per patch, Adam, all-reduce of the 49 MB flat gradient when a process group exists).
@@ -138,6 +151,13 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
         if n1 != "start":
             phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
     ms = dt / steps * 1e3
+    # what the N > 1 all-reduce carries: one more step with the optimizer's zero_grad left out of the picture -- the share of the flat 49 MB gradient
+    # that one view actually touches (outside the timed region)
+    opt.zero_grad(set_to_none=False)
+    sds_step(net, net_gt, ro, rd, (64, 64), _NoStep(opt), guidance, batch_size=4096, flat_grad=flat)
+    emb = net.encoder.embeddings.grad
+    nz_table = float((emb != 0).any(dim=-1).float().mean().item()) if emb is not None else None
+    nz_flat = float((flat != 0).float().mean().item())
     launched = sum(SDS_BYTES_LAUNCHED.values())
     ach = launched / (ms * 1e-3) / 1e9
     res = {"ms_per_step": ms, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad (one launch: ac_render_rays_pair) + 1 frozen",
@@ -148,6 +168,8 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
                         "traffic": None},
            "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if dist is not None else 0,
            "grad_allreduce_ms": round(phases.get("grad_allreduce", 0.0), 4),
+           "grad_nonzero_frac": {"flat_gradient": round(nz_flat, 4), "table_entries": None if nz_table is None else round(nz_table, 4),
+                                 "note": "share of the flat gradient one 4096-ray view touches: what a sparse all-reduce could leave out at most"},
            "grad_allreduce_overlap": ("levels 8-15 of the table gradient all-reduced from a side stream during the rest of the backward (AC_OVERLAP_ALLREDUCE=1)"
                                       if __import__("avatarcraft_amd.stylize", fromlist=["x"]).OVERLAP_GRAD_ALLREDUCE else "off (one collective after the backward)"),
            "core": "no autograd graph: forward = ac_render_rays_pair (render_val and the training render of the same rays in one launch, per-sample outputs and stencil features of the second kept), upstream gradients "

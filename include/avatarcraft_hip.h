@@ -43,7 +43,7 @@ typedef void *ac_stream_t; /* hipStream_t */
 
 /* library identification / diagnostics */
 int ac_version(void);                /* ABI version, currently 5 (round 4: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
-                                      * ac_field_samples, ac_render_rays_occupancy, the measurement / liveness accessors) */
+                                      * ac_field_samples, ac_render_rays_occupancy, the measurement / liveness accessors, the *_typed encoder entries) */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
 
 /* ---- hash-grid encoder -------------------------------------------------------------------
@@ -84,6 +84,27 @@ int ac_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32
                          int calc_grad_inputs, float *dy_dx, ac_stream_t stream);
 int ac_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D, uint32_t C,
                           const float *dy_dx, float *grad_inputs, ac_stream_t stream);
+
+/* ---- half / double tensors of the two encoders ------------------------------------------------
+ * The reference dispatches both extensions over the dtype of their tensors (AT_DISPATCH_FLOATING_TYPES_AND_HALF: hashencoder.cu:352,391,
+ * shencoder.cu:337,380; `CHECK_IS_FLOATING` accepts Float, Half, Double).  Same arguments as the fp32 entry points above with `dtype` in front and
+ * untyped pointers: AC_DTYPE_F32 forwards to them; AC_DTYPE_F16 / AC_DTYPE_F64 are every tensor of the call (inputs, embeddings, outputs, dy_dx, grad,
+ * grad_embeddings, grad_inputs) in that type.  Arithmetic: cell positions and interpolation weights in fp32 whatever the dtype (`float pos[D]`,
+ * hashencoder.cu:125-133); half tensors are widened on load, accumulated in fp32 and rounded once on store (the table gradient: packed half2 atomics,
+ * hashencoder.cu:293-299); double tensors accumulate in double.  Any other code: AC_ERR_BAD_ARG ("... must be a floating tensor"). */
+#define AC_DTYPE_F32 0
+#define AC_DTYPE_F16 1
+#define AC_DTYPE_F64 2
+int ac_hash_encode_forward_typed(int dtype, const void *inputs, const void *embeddings, const int32_t *offsets, const int32_t *offsets_host,
+                                 void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                                 void *dy_dx, ac_stream_t stream);
+int ac_hash_encode_backward_typed(int dtype, const void *grad, const void *inputs, const void *embeddings, const int32_t *offsets,
+                                  const int32_t *offsets_host, void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                  uint32_t H, int calc_grad_inputs, const void *dy_dx, void *grad_inputs, ac_stream_t stream);
+int ac_sh_encode_forward_typed(int dtype, const void *inputs, void *outputs, uint32_t B, uint32_t D, uint32_t C, int calc_grad_inputs,
+                               void *dy_dx, ac_stream_t stream);
+int ac_sh_encode_backward_typed(int dtype, const void *grad, const void *inputs, uint32_t B, uint32_t D, uint32_t C, const void *dy_dx,
+                                void *grad_inputs, ac_stream_t stream);
 
 /* ---- raymarching operators (raymarching/src/raymarching.cu) ---------------------------------
  * Same arguments as the reference wrappers.  Slot reservation is deterministic: packed samples

@@ -34,5 +34,6 @@ typedef struct {
 } orc_render_opts;
 
 ORC_API uint32_t orc_grid_index(uint32_t D, uint32_t C, uint32_t ch, uint32_t hashmap_size, uint32_t resolution, const uint32_t *pos_grid);
+ORC_API void orc_hash_level_table(uint32_t L, float S, uint32_t H, float *scale, uint32_t *res);
 
 #endif

@@ -20,7 +20,7 @@ u32p = C.POINTER(C.c_uint32)
 def build(force=False):
     """Compile libac_oracle.so with the committed Makefile (gcc, seconds)."""
     so = os.path.join(_HERE, "libac_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_oracle_bwd.c", "ac_oracle.h", "ac_math.h", "ac_sh_table.h", "ac_sp_table.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_oracle_bwd.c", "ac_oracle_typed.c", "ac_oracle.h", "ac_math.h", "ac_sh_table.h", "ac_sp_table.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libac_oracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -149,6 +149,100 @@ def sh_encode_backward(grad, inputs, degree, dy_dx):
     gi = np.zeros_like(inputs)
     lib().orc_sh_encode_backward(_p(grad), _p(inputs), C.c_uint32(inputs.shape[0]), C.c_uint32(3), C.c_uint32(degree),
                                  _p(dy_dx), _p(gi))
+    return gi
+
+
+# ------------------------------------------------------------------ the encoders on half / double tensors
+# The reference dispatches both extensions over the dtype of their tensors (hashencoder.cu:352,391; shencoder.cu:337,380).  float64: the C restatement
+# in ac_oracle_typed.c.  float16: widen, run the fp32 routine, round ONCE -- positions and weights are fp32 in every instantiation
+# (hashencoder.cu:125-154), only the accumulation differs: the reference rounds every partial sum to half through c10::Half's operators, which cannot be
+# reproduced without its CUDA build and which nothing exercises; the single rounding is what the HIP kernels do and at least as
+# accurate.  PARITY UNPINNED for both (see ac_oracle_typed.c).
+f64p = C.POINTER(C.c_double)
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def hash_encode_forward_typed(inputs, grid, offsets, S, H, calc_grad_inputs=False):
+    """(outputs [L,B,C], dy_dx or None) in the dtype of `inputs` (float32 / float16 / float64; grid must share it)"""
+    dt = np.asarray(inputs).dtype
+    assert np.asarray(grid).dtype == dt, "one dtype per call (the reference instantiates its kernel on inputs.scalar_type())"
+    if dt == np.float32:
+        out, dy, _ = hash_encode_forward(inputs, grid, offsets, S, H, calc_grad_inputs)
+        return out, dy
+    if dt == np.float16:
+        out, dy, _ = hash_encode_forward(np.asarray(inputs, np.float32), np.asarray(grid, np.float32), offsets, S, H, calc_grad_inputs)
+        return out.astype(np.float16), (None if dy is None else dy.astype(np.float16))
+    assert dt == np.float64, "inputs must be a floating tensor"
+    inputs = _d(inputs); grid = _d(grid); offsets = np.ascontiguousarray(offsets, np.int32)
+    B, D = inputs.shape
+    L = offsets.shape[0] - 1
+    Cc = grid.shape[1]
+    out = np.empty((L, B, Cc), np.float64)
+    dy_dx = np.empty((B, L * D * Cc), np.float64) if calc_grad_inputs else np.empty(1, np.float64)
+    rc = lib().orc_hash_encode_forward_f64(_p(inputs, f64p), _p(grid, f64p), _p(offsets, i32p), _p(out, f64p), C.c_uint32(B), C.c_uint32(D),
+                                           C.c_uint32(Cc), C.c_uint32(L), C.c_float(S), C.c_uint32(H), C.c_int(int(calc_grad_inputs)), _p(dy_dx, f64p))
+    if rc:
+        raise RuntimeError("GridEncoding: unsupported D/C")
+    return out, (dy_dx if calc_grad_inputs else None)
+
+
+def hash_encode_backward_typed(grad, inputs, grid, offsets, S, H, dy_dx=None):
+    """(grad_grid, grad_inputs or None) in the dtype of `grad`.  float16: the fp32 sums rounded once (the GPU adds half2 atomics in arbitrary order:
+    compare with a tolerance that covers one half rounding per contribution)"""
+    dt = np.asarray(grad).dtype
+    if dt == np.float32:
+        return hash_encode_backward(grad, inputs, grid, offsets, S, H, dy_dx)
+    if dt == np.float16:
+        gg, gi = hash_encode_backward(np.asarray(grad, np.float32), np.asarray(inputs, np.float32), np.asarray(grid, np.float32), offsets, S, H,
+                                      None if dy_dx is None else np.asarray(dy_dx, np.float32))
+        return gg.astype(np.float16), (None if gi is None else gi.astype(np.float16))
+    assert dt == np.float64, "grad must be a floating tensor"
+    grad = _d(grad); inputs = _d(inputs); offsets = np.ascontiguousarray(offsets, np.int32)
+    B, D = inputs.shape
+    L = offsets.shape[0] - 1
+    Cc = np.asarray(grid).shape[1]
+    gg = np.zeros(np.asarray(grid).shape, np.float64)
+    gi = np.zeros_like(inputs) if dy_dx is not None else np.zeros(1, np.float64)
+    dd = _d(dy_dx) if dy_dx is not None else np.zeros(1, np.float64)
+    rc = lib().orc_hash_encode_backward_f64(_p(grad, f64p), _p(inputs, f64p), _p(offsets, i32p), _p(gg, f64p), C.c_uint32(B), C.c_uint32(D), C.c_uint32(Cc),
+                                            C.c_uint32(L), C.c_float(S), C.c_uint32(H), C.c_int(int(dy_dx is not None)), _p(dd, f64p), _p(gi, f64p))
+    if rc:
+        raise RuntimeError("GridEncoding: unsupported D/C")
+    return gg, (gi if dy_dx is not None else None)
+
+
+def sh_encode_forward_typed(inputs, degree, calc_grad_inputs=False):
+    dt = np.asarray(inputs).dtype
+    if dt == np.float32:
+        return sh_encode_forward(inputs, degree, calc_grad_inputs)
+    if dt == np.float16:
+        out, dy = sh_encode_forward(np.asarray(inputs, np.float32), degree, calc_grad_inputs)
+        return out.astype(np.float16), (None if dy is None else dy.astype(np.float16))
+    assert dt == np.float64, "inputs must be a floating tensor"
+    inputs = _d(inputs)
+    B = inputs.shape[0]
+    out = np.empty((B, degree * degree), np.float64)
+    dy_dx = np.empty((B, 3 * degree * degree), np.float64) if calc_grad_inputs else np.empty(1, np.float64)
+    rc = lib().orc_sh_encode_forward_f64(_p(inputs, f64p), _p(out, f64p), C.c_uint32(B), C.c_uint32(inputs.shape[1]), C.c_uint32(degree),
+                                         C.c_int(int(calc_grad_inputs)), _p(dy_dx, f64p))
+    if rc:
+        raise RuntimeError("SH encoder: unsupported input_dim/degree")
+    return out, (dy_dx if calc_grad_inputs else None)
+
+
+def sh_encode_backward_typed(grad, inputs, degree, dy_dx):
+    dt = np.asarray(grad).dtype
+    if dt == np.float32:
+        return sh_encode_backward(grad, inputs, degree, dy_dx)
+    if dt == np.float16:
+        return sh_encode_backward(np.asarray(grad, np.float32), np.asarray(inputs, np.float32), degree, np.asarray(dy_dx, np.float32)).astype(np.float16)
+    assert dt == np.float64, "grad must be a floating tensor"
+    grad = _d(grad); dy_dx = _d(dy_dx)
+    gi = np.zeros((grad.shape[0], 3), np.float64)
+    lib().orc_sh_encode_backward_f64(_p(grad, f64p), C.c_uint32(grad.shape[0]), C.c_uint32(3), C.c_uint32(degree), _p(dy_dx, f64p), _p(gi, f64p))
     return gi
 
 

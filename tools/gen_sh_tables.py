@@ -143,6 +143,11 @@ def emit(path, guard, qual="static const"):
             f.write(f"{qual} float AC_SH_COEF{ki}[{max(1,len(mono))}] = {{\n")
             f.write(",\n".join("  " + ", ".join(f"{float(m[0]).hex()}f" for m in mono[i:i + 4]) for i in range(0, len(mono), 4)))
             f.write("\n};\n")
+            # the same coefficients in double (the float ones above are these rounded): the double instantiation of the encoder (shencoder.cu's
+            # AT_DISPATCH_FLOATING_TYPES_AND_HALF) evaluates the basis in double like the reference's double literals
+            f.write(f"{qual} double AC_SH_COEF{ki}D[{max(1,len(mono))}] = {{\n")
+            f.write(",\n".join("  " + ", ".join(f"{float(m[0]).hex()}" for m in mono[i:i + 4]) for i in range(0, len(mono), 4)))
+            f.write("\n};\n")
             f.write(f"{qual} unsigned char AC_SH_EXP{ki}[{max(1,len(mono))}][3] = {{\n")
             f.write(",\n".join("  " + ", ".join("{%d,%d,%d}" % m[1:] for m in mono[i:i + 8]) for i in range(0, len(mono), 8)))
             f.write("\n};\n")
