@@ -25,6 +25,12 @@ namespace {
 #ifndef AC_RUN_EARLY_OUT
 #define AC_RUN_EARLY_OUT 1     // the segmented run scan stops as soon as every lane of the wave has met the head of its run (run_reduce)
 #endif
+#ifndef AC_ACC_SPLIT
+#define AC_ACC_SPLIT 0         // 1: the two channels of the bucket sums in separate halves of the LDS slice (fewer bank conflicts of the LDS atomics) -- measured: nothing
+#endif
+#ifndef AC_ACC_W
+#define AC_ACC_W 8             // bucket_accumulate_kernel: table elements per thread whose read-modify-write is issued together
+#endif
 #ifndef AC_ABL_FLUSH
 #define AC_ABL_FLUSH 0
 #endif
@@ -719,6 +725,13 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
     }
     for (uint32_t e = threadIdx.x; e < per * 2; e += blockDim.x) acc[e] = 0ull;
     __syncthreads();
+    // fixed-point sums of the bucket's entries: channel c of entry i at AC_ACC_AT(i, c).  Split (round 4): the two channels in separate halves of the slice,
+    // so that the 64 lanes of one LDS atomic spread over 32 bank pairs instead of 16 bank quads
+#if AC_ACC_SPLIT
+#define AC_ACC_AT(I, CH) ((I) + (CH) * per)
+#else
+#define AC_ACC_AT(I, CH) (2u * (I) + (CH))
+#endif
     const int emax = (int)(mbits >> 23) - 126;                                       // |v| < 2^emax for every record of the level
     const int head = 32 - __builtin_clz(n);                                          // ceil(log2(n + 1))
     const int k = 62 - head - emax;
@@ -744,17 +757,26 @@ __global__ __launch_bounds__(1024) void bucket_accumulate_kernel(float *__restri
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #ifdef AC_ABL_NOLDSATOMIC
-            if (r[u].v0 != 0.0f || r[u].v1 != 0.0f) { acc[2 * r[u].idx] = 1ull; acc[2 * r[u].idx + 1] = 1ull; }
+            if (r[u].v0 != 0.0f || r[u].v1 != 0.0f) { acc[AC_ACC_AT(r[u].idx, 0u)] = 1ull; acc[AC_ACC_AT(r[u].idx, 1u)] = 1ull; }
 #else
-            if (r[u].v0 != 0.0f) atomicAdd(&acc[2 * r[u].idx], (unsigned long long)__double2ll_rn(ldexp((double)r[u].v0, k)));
-            if (r[u].v1 != 0.0f) atomicAdd(&acc[2 * r[u].idx + 1], (unsigned long long)__double2ll_rn(ldexp((double)r[u].v1, k)));
+            if (r[u].v0 != 0.0f) atomicAdd(&acc[AC_ACC_AT(r[u].idx, 0u)], (unsigned long long)__double2ll_rn(ldexp((double)r[u].v0, k)));
+            if (r[u].v1 != 0.0f) atomicAdd(&acc[AC_ACC_AT(r[u].idx, 1u)], (unsigned long long)__double2ll_rn(ldexp((double)r[u].v1, k)));
 #endif
         }
     }
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < mine * 2; e += blockDim.x) {
-        const long long v = (long long)acc[e];
-        if (v != 0) dst[e] += (float)ldexp((double)v, -k);
+    // slice += sums, AC_ACC_W elements per thread at a time with their table loads issued together: one element per trip made every workgroup pay 16
+    // dependent global round trips here (~1 / 4 of the kernel: r04_experiments.txt 8d)
+    constexpr uint32_t W = AC_ACC_W;
+    for (uint32_t e0 = threadIdx.x; e0 < mine * 2; e0 += blockDim.x * W) {
+        long long v[W]; float old[W];
+#pragma unroll
+        for (uint32_t u = 0; u < W; ++u) { const uint32_t e = e0 + u * blockDim.x; v[u] = e < mine * 2 ? (long long)acc[AC_ACC_AT(e >> 1, e & 1u)] : 0ll; }
+#pragma unroll
+        for (uint32_t u = 0; u < W; ++u) old[u] = v[u] != 0 ? dst[e0 + u * blockDim.x] : 0.0f;
+#pragma unroll
+        for (uint32_t u = 0; u < W; ++u)
+            if (v[u] != 0) dst[e0 + u * blockDim.x] = old[u] + (float)ldexp((double)v[u], -k);
     }
 }
 
