@@ -440,10 +440,26 @@ __global__ __launch_bounds__(1024) void sdf_partials_reduce_kernel(const float *
 //   dh2 = Wc3^T do3 (4 MFMA), dh1 = Wc2^T dh2 (64), dinp = Wc1^T dh1 (32; lane (n, g) receives d sdf_out[4g..4g+3] and d normal_g:
 //   exactly the layouts sdf_stencil_bwd_kernel and the caller read), dWc3 += do3 h2^T (16), dWc2 += dh2 h1^T (64),
 //   dWc1 += dh1 inp^T (32) with K = the 16 samples of the tile through LDS transposes.
+#ifndef AC_COLORBWD_BF16
+#define AC_COLORBWD_BF16 1    // round 4: layer 3 of the forward recomputation and the two data-gradient products of color_bwd_kernel (dh1 = Wc2^T dh2, dinp = Wc1^T dh1)
+#endif                        // as three-term bf16 splits instead of fp32 MFMA.  Layers 1 and 2 of the recomputation stay fp32: they decide the ReLU masks, and a
+                              // recomputation that is only 2^-16 accurate flips enough of them to show (dWc1 3e-3 of max against the fp64 oracle, measured);
+                              // the weight gradients (K = the tile's samples, through LDS) stay fp32 as well
+#if AC_COLORBWD_BF16
+// layer 3 of the forward: its two bf16 hi and two lo fragments (k blocks 0, 1; order of color_fast_weight) take the place of the fp32 ones
+constexpr int OFF_C3H = OFF_C3F, OFF_C3LO = OFF_C3F + 2 * 64 * 4;
+constexpr int OFF_C3T = OFF_WAVE;                  // [4 tiles][64]                       fp32 A fragments of Wc3^T (4 MFMA: not worth splitting)
+constexpr int OFF_C2T = OFF_C3T + 4 * 64;          // [4 tiles][2 k blocks][64][4] hi | lo   Wc2^T, v_mfma_f32_16x16x32_bf16 order
+constexpr int OFF_C2TL = OFF_C2T + 8 * 64 * 4;
+constexpr int OFF_C1T = OFF_C2TL + 8 * 64 * 4;     // [2 tiles][2 k blocks][64][4] hi | lo   Wc1^T (rows: sdf_out[16] | normal, coordinate)
+constexpr int OFF_C1TL = OFF_C1T + 4 * 64 * 4;
+constexpr int OFF_CW = OFF_C1TL + 4 * 64 * 4;      // per-wave slabs
+#else
 constexpr int OFF_C3T = OFF_WAVE;                  // [4 tiles][64]              A fragments of Wc3^T
 constexpr int OFF_C2T = OFF_C3T + 4 * 64;          // [4 tiles][16 ksteps][64]   Wc2^T
 constexpr int OFF_C1T = OFF_C2T + 64 * 64;         // [2 tiles][16 ksteps][64]   Wc1^T (rows: sdf_out[16] | normal, coordinate)
 constexpr int OFF_CW = OFF_C1T + 32 * 64;          // per-wave slabs
+#endif
 constexpr int CS_H1 = 0, CS_H2 = 64 * TLD, CS_D1 = 128 * TLD, CS_D2 = 192 * TLD, CS_O3 = 256 * TLD, CS_IN = 272 * TLD;
 constexpr int COLOR_SLAB = ((CS_IN + 32 * TLD + 3) / 4) * 4;
 constexpr int CBWD_LDS_FLOATS = OFF_CW + TW * COLOR_SLAB;
@@ -669,6 +685,41 @@ __device__ __forceinline__ void fill_lds_color_bwd(float *lds, const RenderArgs 
         const int l = e & 63, to = e >> 6, m = l & 15, kk = l >> 4;
         lds[OFF_C3T + e] = kk < 3 ? a.Wc3[kk * 64 + 16 * to + m] : 0.0f;
     }
+#if AC_COLORBWD_BF16
+    // K order of both products = the register layout the previous product leaves its result in (slot i of lane group kk in k block s = unit
+    // 16 (2s + (i >> 2)) + 4 kk + (i & 3)): no data moves between lanes.  Weights split hi + lo by round-to-nearest like fill_lds_color_fast.
+    uint32_t *lw = reinterpret_cast<uint32_t *>(lds);
+    for (int e = threadIdx.x; e < (8 + 4) * 64 * 4; e += blockDim.x) {
+        const int q = e & 3, l = (e >> 2) & 63, f = e >> 8, m = l & 15, kk = l >> 4;
+        const bool c2 = f < 8;
+        const int t = c2 ? f >> 1 : (f - 8) >> 1, sblk = f & 1;
+        int col = -1;                                                 // Wc1^T rows: tile 0 row m = sdf_out[m] (feat m - 1; the sdf itself is no input), tile 1 row 4 g = normal component g
+        if (!c2) { if (t == 0) col = m == 0 ? -1 : 6 + (m - 1); else if ((m & 3) == 0 && (m >> 2) < 3) col = 3 + (m >> 2); }
+        uint32_t hi2 = 0, lo2 = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * q + h, unit = 16 * (2 * sblk + (i >> 2)) + 4 * kk + (i & 3);
+            const float w = c2 ? a.Wc2[unit * 64 + 16 * t + m] : (col < 0 ? 0.0f : a.Wc1[unit * 21 + col]);
+            const uint32_t hb = bf16_rne_bits(w), lb = bf16_rne_bits(w - __uint_as_float(hb << 16));
+            hi2 |= hb << (16 * h); lo2 |= lb << (16 * h);
+        }
+        if (c2) { lw[OFF_C2T + e] = hi2; lw[OFF_C2TL + e] = lo2; }
+        else { lw[OFF_C1T + (e - 8 * 256)] = hi2; lw[OFF_C1TL + (e - 8 * 256)] = lo2; }
+    }
+    for (int e = threadIdx.x; e < 2 * 64 * 4; e += blockDim.x) {      // layer 3 of the forward, k blocks 0 and 1 (rows 3 .. 15 zero)
+        const int q = e & 3, l = (e >> 2) & 63, sblk = e >> 8;
+        uint32_t hi2 = 0, lo2 = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float w = color_fast_weight(a, 12 + sblk, l, 2 * q + h);
+            const uint32_t hb = bf16_rne_bits(w), lb = bf16_rne_bits(w - __uint_as_float(hb << 16));
+            hi2 |= hb << (16 * h); lo2 |= lb << (16 * h);
+        }
+        lw[OFF_C3H + e] = hi2; lw[OFF_C3LO + e] = lo2;
+    }
+    return;
+#endif
+#if !AC_COLORBWD_BF16
     for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {       // fragment (t, ks = 4 to + r): lane (m, kk) = Wc2[i = 16 to + 4 kk + r][j = 16 t + m]
         const int l = e & 63, fs = e >> 6, t = fs >> 4, ks = fs & 15, to = ks >> 2, r = ks & 3, m = l & 15, kk = l >> 4;
         lds[OFF_C2T + e] = a.Wc2[(16 * to + 4 * kk + r) * 64 + 16 * t + m];
@@ -680,7 +731,46 @@ __device__ __forceinline__ void fill_lds_color_bwd(float *lds, const RenderArgs 
         else if ((m & 3) == 0 && (m >> 2) < 3) col = 3 + (m >> 2);   // row 4 g: normal component g
         lds[OFF_C1T + e] = col < 0 ? 0.0f : a.Wc1[(16 * t + 4 * kk + r) * 21 + col];
     }
+#endif
 }
+
+#if AC_COLORBWD_BF16
+// acc += A (bf16 hi + lo fragment pair at hi_off / lo_off, fragment f) x B (split activations): three of the four partial products
+__device__ __forceinline__ f32x4 cb_mma(const float *__restrict__ lds, int hi_off, int lo_off, int f, int lane, const u32x4 &bh, const u32x4 &bl, f32x4 acc)
+{
+    const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + hi_off + (f * 64 + lane) * 4));
+    const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds + lo_off + (f * 64 + lane) * 4));
+    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, acc, 0, 0, 0);
+}
+// 8 fp32 values -> bf16 hi and lo parts, both ROUNDED to nearest (v_cvt_pk_bf16_f32, two values per instruction): |x - hi - lo| <= 2^-17 |x| and the
+// dropped lo x lo term has either sign.  The renderer's split8_bf16 truncates both parts (2^-14, biased towards zero): good enough for an image, but
+// through the five chained products of this kernel the bias showed as 6.5e-4 of max in dWc1 against the fp64 oracle (contract 3e-4); rounded: where the
+// fp32 products were.  Same packing (value 2q in the low half of dword q), same instruction count.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8_bf16_rn(const float (&d)[8], u32x4 &bh, u32x4 &bl)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2_t v = { d[2 * q], d[2 * q + 1] };
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+        const f32x2_t r = { d[2 * q] - __uint_as_float(hb << 16), d[2 * q + 1] - __uint_as_float(hb & 0xffff0000u) };
+        bh[q] = hb;
+        bl[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
+    }
+}
+__device__ __forceinline__ void split_tiles(const f32x4 (&v)[4], u32x4 (&bh)[2], u32x4 (&bl)[2])
+{
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+        const float in[8] = { v[2 * sb][0], v[2 * sb][1], v[2 * sb][2], v[2 * sb][3], v[2 * sb + 1][0], v[2 * sb + 1][1], v[2 * sb + 1][2], v[2 * sb + 1][3] };
+        split8_bf16_rn(in, bh[sb], bl[sb]);
+    }
+}
+#endif
 
 __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ nrm,
                                                            const float *__restrict__ sdf16, const float *__restrict__ g_rgb, uint32_t B,
@@ -688,6 +778,7 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fill_lds(lds, a);
+    __syncthreads();                                  // (the bf16 fragments of layer 3 overwrite the fp32 ones fill_lds has just written)
     fill_lds_color_bwd(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     float *slab = lds + OFF_CW + wave * COLOR_SLAB;
@@ -712,7 +803,7 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
         const float nx = nrm[3 * (size_t)bb], ny = nrm[3 * (size_t)bb + 1], nz = nrm[3 * (size_t)bb + 2];
         const f32x4 so = *reinterpret_cast<const f32x4 *>(sdf16 + (size_t)bb * 16 + 4 * g);
         const float bxyz = sel4(g, px, py, pz, 0.0f), bn = sel4(g, nx, ny, nz, 0.0f);
-        // forward recompute (same instruction sequence as color_tile), activations kept
+        // forward recompute, activations kept: layers 1 and 2 with the instruction sequence of color_tile (fp32: the ReLU masks are the forward's own)
         f32x4 h1[4], h2[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -737,9 +828,18 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
             h2[to] = acc;
         }
         f32x4 o3 = { 0.0f, 0.0f, 0.0f, 0.0f };
+#if AC_COLORBWD_BF16
+        {
+            u32x4 ch[2], cl[2];
+            split_tiles(h2, ch, cl);
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) o3 = cb_mma(lds, OFF_C3H, OFF_C3LO, sb, lane, ch[sb], cl[sb], o3);
+        }
+#else
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
             o3 = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C3F + kk * 64 + lane], h2[kk >> 2][kk & 3], o3, 0, 0, 0);
+#endif
         // d o3 = d rgb * rgb (1 - rgb), held by the lanes g == 0 (o = r); broadcast to lane group kk = o as the B operand of Wc3^T
         float d3[3];
 #pragma unroll
@@ -760,23 +860,40 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
             for (int r = 0; r < 4; ++r) acc[r] = h2[to][r] > 0.0f ? acc[r] : 0.0f;
             dh2[to] = acc;
         }
+#if AC_COLORBWD_BF16
+        u32x4 gbh[2], gbl[2];
+        split_tiles(dh2, gbh, gbl);
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#if AC_COLORBWD_BF16
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) acc = cb_mma(lds, OFF_C2T, OFF_C2TL, 2 * t + sb, lane, gbh[sb], gbl[sb], acc);
+#else
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C2T + (t * 16 + ks) * 64 + lane], dh2[ks >> 2][ks & 3], acc, 0, 0, 0);
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = h1[t][r] > 0.0f ? acc[r] : 0.0f;
             dh1[t] = acc;
         }
+#if AC_COLORBWD_BF16
+        split_tiles(dh1, gbh, gbl);
+#endif
         // dinp = Wc1^T dh1: tile 0 -> d sdf_out[4g + r], tile 1 reg 0 -> d normal_g
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
             f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#if AC_COLORBWD_BF16
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) acc = cb_mma(lds, OFF_C1T, OFF_C1TL, 2 * tp + sb, lane, gbh[sb], gbl[sb], acc);
+#else
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C1T + (tp * 16 + ks) * 64 + lane], dh1[ks >> 2][ks & 3], acc, 0, 0, 0);
+#endif
             if (live) {
                 if (tp == 0) *reinterpret_cast<f32x4 *>(g_sdf16 + (size_t)b * 16 + 4 * g) = acc;
                 else if (g < 3) g_nrm[3 * (size_t)b + g] = acc[0];
