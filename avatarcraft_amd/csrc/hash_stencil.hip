@@ -25,6 +25,9 @@ namespace {
 #ifndef AC_RUN_EARLY_OUT
 #define AC_RUN_EARLY_OUT 1     // the segmented run scan stops as soon as every lane of the wave has met the head of its run (run_reduce)
 #endif
+#ifndef AC_FILL_PREFETCH
+#define AC_FILL_PREFETCH 1     // hash_stencil_bwd_binned_kernel requests the next group's inputs before it scatters the current one
+#endif
 #ifndef AC_ACC_SPLIT
 #define AC_ACC_SPLIT 0         // 1: the two channels of the bucket sums in separate halves of the LDS slice (fewer bank conflicts of the LDS atomics) -- measured: nothing
 #endif
@@ -610,18 +613,35 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
 #endif
     const bool fine = ((fine_mask >> level) & 1u) != 0;
     const uint32_t ngroups = (B + 63) / 64;
-    for (uint32_t grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+    // the next group's position and seven feature gradients are requested before this group is scattered (round 4)
+    struct GroupIn { float xc[3]; float2 gp[7]; };
+    auto request = [&](uint32_t grp, GroupIn &in) {
         const uint32_t b0 = grp * 64 + lane;
         const bool valid = b0 < B;
         const uint32_t b = valid ? b0 : B - 1;
-        const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
-        float2 gp[7];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in.xc[k] = x[3 * (size_t)b + k];
 #pragma unroll
         for (int p = 0; p < 7; ++p) {
-            gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
-            if (!valid) gp[p] = make_float2(0.0f, 0.0f);
+            in.gp[p] = reinterpret_cast<const float2 *>(grad)[((size_t)p * Lc + level) * B + b];
+            if (!valid) in.gp[p] = make_float2(0.0f, 0.0f);
         }
+    };
+    const uint32_t grp0 = blockIdx.x * 4 + wave, gstride = gridDim.x * 4;
+    GroupIn nxt;
+    if (grp0 < ngroups) request(grp0, nxt);
+    for (uint32_t grp = grp0; grp < ngroups; grp += gstride) {
+        const float xc[3] = { nxt.xc[0], nxt.xc[1], nxt.xc[2] };
+        float2 gp[7];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) gp[p] = nxt.gp[p];
+#if AC_FILL_PREFETCH
+        if (grp + gstride < ngroups) request(grp + gstride, nxt);
+#endif
         stencil_scatter(sink, L, fine, xc, gp, eps, bound, two_bound, lane);
+#if !AC_FILL_PREFETCH
+        if (grp + gstride < ngroups) request(grp + gstride, nxt);
+#endif
     }
     sink.finish();
 #ifdef AC_PROFILE_FILL

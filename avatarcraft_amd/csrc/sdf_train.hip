@@ -24,6 +24,9 @@ namespace {
 #ifndef AC_SDFBWD_RANK1
 #define AC_SDFBWD_RANK1 1     // offset evaluations of the backward: rank-1 shortcuts instead of 32 of their 148 MFMA (0: every evaluation alike)
 #endif
+#ifndef AC_SDFBWD_PREFETCH
+#define AC_SDFBWD_PREFETCH 1  // sdf_stencil_bwd_kernel requests the next tile's inputs while it computes the current one
+#endif
 constexpr int TW = 4;                              // waves per workgroup of the backward kernels (296 / 284 VGPRs: one wave per SIMD)
 constexpr int TBLOCK = TW * 64;
 constexpr int FW = 8;                              // waves per workgroup of the forward SDF query (224 VGPRs: two waves per SIMD, like the renderer)
@@ -217,27 +220,43 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
     }
     const uint32_t ntiles = (B + 15) / 16;
     const float hs = 0.5f / eps;
-    for (uint32_t tile = blockIdx.x * TW + wave; tile < ntiles; tile += gridDim.x * TW) {
+    // The inputs of tile i + 1 are requested while tile i is computed (round 4): with one wave per SIMD nothing else covers their ~2 us, and a third of
+    // the 512 registers a lone wave may use are free.  TileIn = what a lane reads per tile: its sample's position and upstream gradients and, with SAVED,
+    // the 14 x 16 bytes of stencil features the forward kept ([tile][14][lane][4], see render_rays_kernel: each load 1 KB contiguous per wave).
+    struct TileIn { float p[3], gg[3]; f32x4 go; f32x4 v[SAVED ? 14 : 1]; };
+    auto request = [&](uint32_t tile, TileIn &in) {
         const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { in.p[k] = x[3 * (size_t)bb + k]; in.gg[k] = g_grad[3 * (size_t)bb + k]; }
+        in.go = *reinterpret_cast<const f32x4 *>(g_out + (size_t)bb * 16 + 4 * g);
+        if constexpr (SAVED) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(feat7) + ((size_t)tile * 14) * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 14; ++k) in.v[k] = src[k * 64];
+        }
+    };
+    const uint32_t tile0 = blockIdx.x * TW + wave, tstride = gridDim.x * TW;
+    TileIn nxt;
+    if (tile0 < ntiles) request(tile0, nxt);
+    for (uint32_t tile = tile0; tile < ntiles; tile += tstride) {
+        const uint32_t b = tile * 16 + n;
         const bool live = b < B;
-        const float px = x[3 * (size_t)bb], py = x[3 * (size_t)bb + 1], pz = x[3 * (size_t)bb + 2];
-        f32x4 go = *reinterpret_cast<const f32x4 *>(g_out + (size_t)bb * 16 + 4 * g);
-        float gg[3] = { g_grad[3 * (size_t)bb], g_grad[3 * (size_t)bb + 1], g_grad[3 * (size_t)bb + 2] };
+        const float px = nxt.p[0], py = nxt.p[1], pz = nxt.p[2];
+        f32x4 go = nxt.go;
+        float gg[3] = { nxt.gg[0], nxt.gg[1], nxt.gg[2] };
         if (!live) { go = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; gg[0] = gg[1] = gg[2] = 0.0f; }
         float fe0[4][2];
         if constexpr (SAVED) {
-            // [tile][14][lane][4] (see render_rays_kernel): 14 16-byte loads per lane, each 1 KB contiguous per wave
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(feat7) + ((size_t)tile * 14) * 64 + lane;
-            f32x4 v[14];
 #pragma unroll
-            for (int k = 0; k < 14; ++k) v[k] = src[k * 64];
+            for (int q_ = 0; q_ < 8; ++q_) fe0[q_ >> 1][q_ & 1] = nxt.v[q_ >> 2][q_ & 3];
 #pragma unroll
-            for (int q_ = 0; q_ < 8; ++q_) fe0[q_ >> 1][q_ & 1] = v[q_ >> 2][q_ & 3];
-#pragma unroll
-            for (int k = 8; k < 56; ++k) fsl[(k - 8) * 64 + lane] = v[k >> 2][k & 3];
+            for (int k = 8; k < 56; ++k) fsl[(k - 8) * 64 + lane] = nxt.v[k >> 2][k & 3];
         } else {
             encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
         }
+#if AC_SDFBWD_PREFETCH
+        if (tile + tstride < ntiles) request(tile + tstride, nxt);
+#endif
         const float pc0 = sel4(g, px, py, pz, 0.0f);
         Acc4 h10;                                               // layer 1 of the centre evaluation (set at e == 0)
 #pragma unroll
@@ -379,6 +398,9 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
             for (int r = 0; r < 4; ++r) gb2[r] += d2[r];
             wave_sync();
         }
+#if !AC_SDFBWD_PREFETCH
+        if (tile + tstride < ntiles) request(tile + tstride, nxt);
+#endif
     }
     // per-wave partial sums: dW1 [64][36] | dW2 [16][64] | db2 [16]
     float *part = partials + (size_t)(blockIdx.x * TW + wave) * NPART;
@@ -796,12 +818,28 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
         for (int c = 0; c < 4; ++c) gW2[t][c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     }
     const uint32_t ntiles = (B + 15) / 16;
-    for (uint32_t tile = blockIdx.x * TW + wave; tile < ntiles; tile += gridDim.x * TW) {
+    // like sdf_stencil_bwd_kernel: the next tile's inputs are requested while this one is computed (one wave per SIMD: nothing else covers the loads)
+    struct TileIn { float p[3], nr[3], up[3]; f32x4 so; };
+    auto request = [&](uint32_t tile, TileIn &in) {
         const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            in.p[k] = x[3 * (size_t)bb + k]; in.nr[k] = nrm[3 * (size_t)bb + k];
+            in.up[k] = (b < B && g == 0) ? g_rgb[3 * (size_t)bb + k] : 0.0f;
+        }
+        in.so = *reinterpret_cast<const f32x4 *>(sdf16 + (size_t)bb * 16 + 4 * g);
+    };
+    const uint32_t tile0 = blockIdx.x * TW + wave, tstride = gridDim.x * TW;
+    TileIn nxt;
+    if (tile0 < ntiles) request(tile0, nxt);
+    for (uint32_t tile = tile0; tile < ntiles; tile += tstride) {
+        const uint32_t b = tile * 16 + n;
         const bool live = b < B;
-        const float px = x[3 * (size_t)bb], py = x[3 * (size_t)bb + 1], pz = x[3 * (size_t)bb + 2];
-        const float nx = nrm[3 * (size_t)bb], ny = nrm[3 * (size_t)bb + 1], nz = nrm[3 * (size_t)bb + 2];
-        const f32x4 so = *reinterpret_cast<const f32x4 *>(sdf16 + (size_t)bb * 16 + 4 * g);
+        const float px = nxt.p[0], py = nxt.p[1], pz = nxt.p[2];
+        const float nx = nxt.nr[0], ny = nxt.nr[1], nz = nxt.nr[2];
+        const float ups[3] = { nxt.up[0], nxt.up[1], nxt.up[2] };
+        const f32x4 so = nxt.so;
+        if (tile + tstride < ntiles) request(tile + tstride, nxt);
         const float bxyz = sel4(g, px, py, pz, 0.0f), bn = sel4(g, nx, ny, nz, 0.0f);
         // forward recompute, activations kept: layers 1 and 2 with the instruction sequence of color_tile (fp32: the ReLU masks are the forward's own)
         f32x4 h1[4], h2[4];
@@ -845,7 +883,7 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const float rgb = dv_sigmoid(o3[o]);
-            const float up = (live && g == 0) ? g_rgb[3 * (size_t)bb + o] : 0.0f;
+            const float up = ups[o];
             d3[o] = up * (rgb * (1.0f - rgb));
         }
         const float s0 = __shfl(d3[0], n), s1 = __shfl(d3[1], n), s2 = __shfl(d3[2], n);
