@@ -56,6 +56,13 @@ class ac_pg_entry(C.Structure):
     _fields_ = [("src", vp), ("v", vp), ("g", vp), ("dst", vp), ("dst2", vp), ("rows", u32), ("cols", u32), ("src_stride", u32), ("kind", i32)]
 
 
+class ac_adam_entry(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_uint64)]
+
+
+AC_ADAM_MAX_TENSORS = 16
+
+
 class ac_warp_mesh(C.Structure):
     _fields_ = [("verts", vp), ("faces", vp), ("T", vp), ("V", u32), ("F", u32), ("threshold", C.c_double), ("geo_threshold", f32),
                 ("use_mesh_guide", i32), ("accel", vp)]
@@ -74,6 +81,7 @@ _SIGS = {
     "ac_hash_encode_backward_typed": ([C.c_int, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp, vp], C.c_int),
     "ac_sh_encode_forward_typed": ([C.c_int, vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
     "ac_sh_encode_backward_typed": ([C.c_int, vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),
+    "ac_adam_step": ([C.POINTER(ac_adam_entry), u32, f32, f32, f32, f32, f32, f32, f32, C.c_int, vp], C.c_int),
     "ac_sh_encode_forward": ([vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
     "ac_sh_encode_backward": ([vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),
     "ac_march_rays_train": ([vp, vp, vp, f32, C.c_int, f32, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, vp], C.c_int),

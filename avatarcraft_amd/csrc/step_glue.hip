@@ -4,6 +4,8 @@
 //   ac_param_grads         : its backward for every layer + the bias gradients + d loss / d variance from the per-ray d loss / d inv_s,
 //                            ACCUMULATED into the parameters' .grad buffers, one launch
 //   ac_sds_upstream        : d / d weights_sum of smooth_l1(clamp(ws, 0, 1), clamp(ws_gt, 0, 1)) * scale (stylize.py:183-193) and the loss value
+//   ac_adam_step           : optimizer.step() of torch.optim.Adam (stylize.py:199, :355-363) for every parameter tensor in ONE launch, optionally
+//                            clearing the gradients it has just consumed (the next step's optimizer.zero_grad(), stylize.py:143)
 // All reductions are wave-local trees in a fixed order: results do not depend on the launch.
 #include "ac_common.hpp"
 
@@ -105,7 +107,81 @@ __global__ __launch_bounds__(1024) void sds_upstream_kernel(const float *__restr
     }
 }
 
+// Adam (torch.optim.Adam without amsgrad / weight decay / maximize; the arithmetic of torch's update, torch/optim/adam.py _single_tensor_adam):
+//   m = m + (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g;  p = p - step_size * m / (sqrt(v) / sqrt(bias_correction2) + eps)
+// with step_size = lr / bias_correction1, sqrt(bias_correction2), 1 - beta1 and 1 - beta2 formed on the host in double like torch does (1 - 0.999f is
+// 1.3e-5 off 0.001).  HBM-bound streaming: 4 reads + 3 writes (+ 1 with
+// zero_grad) of 4 bytes per element; 16-byte accesses, 4 x 16 bytes in flight per lane.
+struct AdamArgs { ac_adam_entry e[AC_ADAM_MAX_TENSORS]; uint32_t blk0[AC_ADAM_MAX_TENSORS + 1]; uint32_t n; float step_size, beta1, omb1, beta2, omb2, eps, bc2_sqrt; int zero_grad; };
+constexpr int ADAM_BLOCK = 256, ADAM_PER_BLOCK = ADAM_BLOCK * 16;     // elements per workgroup: four float4 per lane
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamArgs &a)
+{
+    m = m + a.omb1 * (g - m);
+    v = a.beta2 * v + a.omb2 * g * g;
+    const float denom = __builtin_sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(ADAM_BLOCK) void adam_step_kernel(const AdamArgs a)
+{
+    ac_adam_entry E = a.e[0];                          // static indexing of the by-value argument (see weight_norm_fwd_kernel)
+    uint32_t blk = blockIdx.x;
+#pragma unroll
+    for (int i = 1; i < AC_ADAM_MAX_TENSORS; ++i)
+        if ((uint32_t)i < a.n && blockIdx.x >= a.blk0[i]) { E = a.e[i]; blk = blockIdx.x - a.blk0[i]; }
+    const size_t base = (size_t)blk * ADAM_PER_BLOCK;
+    const bool vec = ((reinterpret_cast<uintptr_t>(E.param) | reinterpret_cast<uintptr_t>(E.grad) | reinterpret_cast<uintptr_t>(E.exp_avg) |
+                       reinterpret_cast<uintptr_t>(E.exp_avg_sq)) & 15u) == 0 && base + ADAM_PER_BLOCK <= E.n;
+    if (vec) {
+        float4 p[4], g[4], m[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = base / 4 + (size_t)u * ADAM_BLOCK + threadIdx.x;
+            p[u] = reinterpret_cast<const float4 *>(E.param)[i]; g[u] = reinterpret_cast<const float4 *>(E.grad)[i];
+            m[u] = reinterpret_cast<const float4 *>(E.exp_avg)[i]; v[u] = reinterpret_cast<const float4 *>(E.exp_avg_sq)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            adam_one(p[u].x, g[u].x, m[u].x, v[u].x, a); adam_one(p[u].y, g[u].y, m[u].y, v[u].y, a);
+            adam_one(p[u].z, g[u].z, m[u].z, v[u].z, a); adam_one(p[u].w, g[u].w, m[u].w, v[u].w, a);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = base / 4 + (size_t)u * ADAM_BLOCK + threadIdx.x;
+            reinterpret_cast<float4 *>(E.param)[i] = p[u]; reinterpret_cast<float4 *>(E.exp_avg)[i] = m[u]; reinterpret_cast<float4 *>(E.exp_avg_sq)[i] = v[u];
+            if (a.zero_grad) reinterpret_cast<float4 *>(E.grad)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        return;
+    }
+    for (size_t i = base + threadIdx.x; i < base + ADAM_PER_BLOCK && i < E.n; i += ADAM_BLOCK) {       // ragged tail / unaligned tensor
+        float p = E.param[i], m = E.exp_avg[i], v = E.exp_avg_sq[i];
+        adam_one(p, E.grad[i], m, v, a);
+        E.param[i] = p; E.exp_avg[i] = m; E.exp_avg_sq[i] = v;
+        if (a.zero_grad) E.grad[i] = 0.0f;
+    }
+}
+
 }  // namespace
+
+AC_API int ac_adam_step(const ac_adam_entry *tensors, uint32_t n, float step_size, float beta1, float one_minus_beta1, float beta2, float one_minus_beta2,
+                        float eps, float bias_correction2_sqrt, int zero_grad, ac_stream_t stream)
+{
+    if (n == 0) return AC_OK;
+    if (!tensors || n > AC_ADAM_MAX_TENSORS) { ac::set_error("adam_step: NULL tensors or more than %d", AC_ADAM_MAX_TENSORS); return AC_ERR_BAD_ARG; }
+    if (!(bias_correction2_sqrt > 0.0f)) { ac::set_error("adam_step: sqrt(bias_correction2) must be positive"); return AC_ERR_BAD_ARG; }
+    AdamArgs a;
+    a.n = n; a.blk0[0] = 0; a.step_size = step_size; a.beta1 = beta1; a.omb1 = one_minus_beta1; a.beta2 = beta2; a.omb2 = one_minus_beta2; a.eps = eps; a.bc2_sqrt = bias_correction2_sqrt; a.zero_grad = zero_grad;
+    for (uint32_t i = 0; i < n; ++i) {
+        const ac_adam_entry &e = tensors[i];
+        if (!e.param || !e.grad || !e.exp_avg || !e.exp_avg_sq || e.n == 0) { ac::set_error("adam_step: tensor %u: NULL buffer or empty", i); return AC_ERR_BAD_ARG; }
+        const uint64_t blocks = (e.n + ADAM_PER_BLOCK - 1) / ADAM_PER_BLOCK;
+        if (a.blk0[i] + blocks > 0x7fffffffull) { ac::set_error("adam_step: too many elements"); return AC_ERR_BAD_ARG; }
+        a.e[i] = e; a.blk0[i + 1] = a.blk0[i] + (uint32_t)blocks;
+    }
+    hipLaunchKernelGGL(adam_step_kernel, dim3(a.blk0[n]), dim3(ADAM_BLOCK), 0, (hipStream_t)stream, a);
+    return ac::check_launch("adam_step");
+}
 
 AC_API int ac_weight_norm_forward(const ac_wn_layer *layers, uint32_t n, ac_stream_t stream)
 {

@@ -126,7 +126,11 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
     HIP-event times per phase of the step."""
     from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view
     net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-3, fused=os.environ.get("AC_FUSED_ADAM", "1") == "1")     # one kernel for the 12.2 M parameters
+    # the reference's torch.optim.Adam(lr = 5e-3) as one launch over the 12.2 M parameters: stylize.Adam (ac_adam_step, also clears the gradients it consumed)
+    # by default; AC_FUSED_ADAM=1 torch's fused kernel, =0 torch's default
+    which = os.environ.get("AC_FUSED_ADAM", "2")
+    opt = (__import__("avatarcraft_amd.stylize", fromlist=["Adam"]).Adam(net.parameters(), lr=5e-3, zero_grad_in_step=True) if which == "2"
+           else torch.optim.Adam(net.parameters(), lr=5e-3, fused=which == "1"))
     flat = flat_grad_view(net.parameters())
     guidance = SyntheticGuidance(42 + rank)
     ro, rd = sds_view(rank)

@@ -439,6 +439,15 @@ int ac_weight_norm_forward(const ac_wn_layer *layers, uint32_t n_layers, ac_stre
  *                      (SingleVarianceNetwork + clip, models/instant_nsr.py:35-45, 666-667; src = g_inv_s_per_ray) */
 #define AC_PG_MAX_ENTRIES 12
 enum { AC_PG_WEIGHT_NORM = 0, AC_PG_ADD = 1, AC_PG_VARIANCE = 2 };
+/* optimizer.step() of the stylisation / reconstruction step (stylize.py:199 over torch.optim.Adam, :355-363; no amsgrad, weight decay or maximize): every
+ * parameter tensor of the network in ONE launch, m = m + (1 - beta1)(g - m), v = beta2 v + (1 - beta2) g g, p -= step_size m / (sqrt(v) / sqrt(bc2) + eps);
+ * step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t), 1 - beta1 and 1 - beta2 are formed by the caller in double.  zero_grad != 0 also clears the gradients
+ * (the next step's optimizer.zero_grad(), stylize.py:143) while they are in registers.  HBM-bound: 28 (32) bytes per element. */
+#define AC_ADAM_MAX_TENSORS 16
+typedef struct ac_adam_entry { float *param, *grad, *exp_avg, *exp_avg_sq; uint64_t n; } ac_adam_entry;
+int ac_adam_step(const ac_adam_entry *tensors, uint32_t n_tensors, float step_size, float beta1, float one_minus_beta1, float beta2,
+                 float one_minus_beta2, float eps, float bias_correction2_sqrt, int zero_grad, ac_stream_t stream);
+
 typedef struct ac_pg_entry { const float *src, *v, *g; float *dst, *dst2; uint32_t rows, cols, src_stride; int32_t kind; } ac_pg_entry;
 int ac_param_grads(const ac_pg_entry *entries, uint32_t n_entries, ac_stream_t stream);
 /* ac_sds_upstream: the opacity term of the stylisation loss (stylize.py:183-193): loss = sum_i smooth_l1(clamp(ws_i, 0, 1), clamp(ws_gt_i, 0, 1)) *

@@ -284,3 +284,80 @@ def test_pair_launch_only_with_a_guidance_that_keeps_off_the_global_rng():
     c, mc = step(True, private=True)
     assert "render_val_and_grad_forward" in mc
     assert not torch.equal(a, c)                                                              # the draws really are consumed in another order
+
+
+def test_adam_step_kernel_equals_torch_adam():
+    """stylize.Adam (ac_adam_step: every tensor in one launch) against torch.optim.Adam on the same gradients: ragged, unaligned and multi-block tensors,
+    several steps (bias corrections), state_dict interchange both ways, and the in-step clearing of the gradients"""
+    from avatarcraft_amd.stylize import Adam
+    torch.manual_seed(3)
+    shapes = [(300001, 2), (64, 35), (64,), (1,), (4099,), (16, 64), (5000, 3)]
+    flat = torch.randn(sum(int(np.prod(s)) for s in shapes) + 3, device=DEV)
+    ps_a, ps_b, off = [], [], 1                                  # offset 1: every tensor but the first is not 16-byte aligned
+    for sh in shapes:
+        n = int(np.prod(sh))
+        ps_a.append(torch.nn.Parameter(flat[off:off + n].clone().view(sh))); ps_b.append(torch.nn.Parameter(flat[off:off + n].clone().view(sh)))
+        off += n
+    gflat = torch.zeros(off + 3, device=DEV)
+    o = 1
+    for p in ps_a:
+        p.grad = gflat[o:o + p.numel()].view_as(p); o += p.numel()
+    ours, ref = Adam(ps_a, lr=5e-3, zero_grad_in_step=True), torch.optim.Adam(ps_b, lr=5e-3)
+    for step in range(5):
+        for pa, pb in zip(ps_a, ps_b):
+            g = torch.randn_like(pb) * (10.0 ** (step - 2))
+            pa.grad.copy_(g); pb.grad = g.clone()
+        ours.step(); ref.step()
+        assert ours.grads_cleared and float(gflat.abs().max()) == 0.0
+        for pa, pb in zip(ps_a, ps_b):
+            d = float((pa - pb).abs().max())
+            assert d <= 2e-6 * max(1.0, float(pb.abs().max())), (step, tuple(pa.shape), d)          # a few ulps: fma contraction and operation order differ
+            assert float((ours.state[pa]["exp_avg_sq"] - ref.state[pb]["exp_avg_sq"]).abs().max()) <= 1e-6 * float(ref.state[pb]["exp_avg_sq"].abs().max())
+    assert int(ours.state[ps_a[0]]["step"].item()) == 5
+    # state dicts are interchangeable: torch's state into ours and back
+    ours2 = Adam(ps_a, lr=5e-3); ours2.load_state_dict(ref.state_dict())
+    ref2 = torch.optim.Adam(ps_b, lr=5e-3); ref2.load_state_dict(ours.state_dict())
+    for pa, pb in zip(ps_a, ps_b):
+        g = torch.randn_like(pb)
+        pa.grad.copy_(g); pb.grad = g.clone()
+    with torch.no_grad():
+        for pa, pb in zip(ps_a, ps_b):
+            pa.copy_(pb)
+    ours2.step(); ref2.step()
+    for pa, pb in zip(ps_a, ps_b):
+        assert float((pa - pb).abs().max()) <= 2e-6 * max(1.0, float(pb.abs().max()))
+    assert not ours2.grads_cleared and float(gflat.abs().max()) > 0.0             # zero_grad_in_step off: gradients left alone
+    with pytest.raises(NotImplementedError):
+        bad = Adam(ps_a, lr=1e-3); bad.param_groups[0]["weight_decay"] = 0.1; bad.step()
+
+
+def test_sds_steps_with_the_one_launch_adam():
+    """stylisation steps from identical state.  (a) ONE step with stylize.Adam against torch.optim.Adam: the parameters agree to rounding (later steps are
+    no test of an optimizer: with lr = 5e-3 on table entries of 1e-4 the trajectory amplifies a last-bit difference to 1e-5 within two steps).  (b) three
+    steps with the gradients cleared INSIDE the optimizer's launch (sds_step then skips its own clearing) against three steps that clear them explicitly:
+    bit for bit -- a gradient left over, or cleared too early, would show."""
+    from avatarcraft_amd.stylize import sds_step, flat_grad_view, SyntheticGuidance, Adam
+    from avatarcraft_amd.synthetic import make_rays
+    ro, rd = make_rays(64, 64, dist=1.8, f=50.0)
+    ro, rd = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+
+    def run(kind, steps):
+        net, _ = golden_net(train=True)
+        net_gt, _ = golden_net(train=False)
+        opt = torch.optim.Adam(net.parameters(), lr=5e-3) if kind == "torch" else Adam(net.parameters(), lr=5e-3, zero_grad_in_step=kind == "in_step")
+        flat = flat_grad_view(net.parameters())
+        guide = SyntheticGuidance(11)
+        torch.manual_seed(5)
+        for _ in range(steps):
+            sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
+        net.check_finite()
+        if kind == "in_step":
+            assert opt.grads_cleared and float(flat.abs().max()) == 0.0
+        return {k: v.detach().clone() for k, v in net.named_parameters()}
+
+    a, b = run("in_step", 1), run("torch", 1)
+    for k in a:
+        assert float((a[k] - b[k]).abs().max()) <= 2e-8 + 1e-6 * float(b[k].abs().max()), (k, float((a[k] - b[k]).abs().max()))
+    a, b = run("in_step", 3), run("explicit", 3)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
