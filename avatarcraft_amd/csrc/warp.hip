@@ -941,6 +941,9 @@ __global__ __launch_bounds__(256) void ray_cull_kernel(const float *__restrict__
 // order of the pairs, and equals the exhaustive kernel's bit for bit.
 constexpr uint32_t TQ = 1024, GQ = 256, FQ = 256;     // pair queues (rings): a sample adds <= NIT x 64 = 512 (sample, tile) pairs to < 32 left over; a group trip
                                                        // <= 128 (sample, tile, group) triples to < 16; a disc trip <= 128 (sample, face) pairs to < 64
+#ifndef AC_WARP_LANE_LISTS
+#define AC_WARP_LANE_LISTS 1     // the search's front end as lane = sample (every lane walks its own cell's tile list); 0: one sample at a time, lane = list entry
+#endif
 #ifndef AC_GSTEPS
 #define AC_GSTEPS 2
 #endif
@@ -1176,12 +1179,55 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
 #endif
     };
 
+    // ONE inlined copy of each downstream stage; downstream first (that bounds the queues): full trips / batches while candidates are still coming, the
+    // leftovers at the end (last)
+    auto drain = [&](bool last) {
+        for (;;) {
+            const uint32_t ntq = tt - th, ngq = gt - gh, nfq = ft - fh;
+            const bool do_e = nfq >= 64u || (last && !ntq && !ngq && nfq);
+            const bool do_d = !do_e && (ngq >= (uint32_t)(8 * DSTEPS) || (last && !ntq && ngq));
+            const bool do_g = !do_e && !do_d && (ntq >= (uint32_t)(16 * GSTEPS) || (last && ntq));
+            if (do_e) { exact_batch(nfq < 64u ? nfq : 64u); WP_TICK(5) }
+            else if (do_d) disc_trip();
+            else if (do_g) group_trip();
+            else break;
+        }
+    };
+#if AC_WARP_LANE_LISTS
+    // Round 4, the front end as lane = sample: every lane walks the tile list of ITS cell, one entry per trip -- the box test of entry k against the lane's
+    // CURRENT bound (the running minimum the exact batches keep lowering, not only the seed), survivors compacted into the pair queue.  A trip costs what
+    // one sample's step cost before (15 LDS reads + ~40 vector instructions) and serves up to 64 samples; the per-sample version broadcast the sample to
+    // all lanes, waited for its list and left most lanes idle (35 listed tiles per sample on average, 64 lanes).  Trips = the longest list in the wave.
+    {
+        const bool has_list = (uint32_t)lane < npts && mycnt != CELL_OVERFLOW && mycnt != 0u;
+        const uint32_t kmax = (uint32_t)(-wave_min_i32(has_list ? -(int)mycnt : 0));
+        const float padq_l = 4e-7f * ((__builtin_fabsf(pf[0]) + __builtin_fabsf(pf[1])) + __builtin_fabsf(pf[2]));
+        constexpr int PFL = 4;                                             // list entries requested ahead
+        uint32_t tlq[PFL];
+#pragma unroll
+        for (int d = 0; d < PFL; ++d) tlq[d] = (has_list && (uint32_t)d < mycnt) ? (uint32_t)av.ctl[(size_t)mybase + (uint32_t)d] : 0u;
+        for (uint32_t k = 0; k < kmax; ++k) {
+            const bool mine = has_list && k < mycnt;
+            const uint32_t tl = tlq[0];
+#pragma unroll
+            for (int d = 0; d + 1 < PFL; ++d) tlq[d] = tlq[d + 1];
+            tlq[PFL - 1] = (has_list && k + (uint32_t)PFL < mycnt) ? (uint32_t)av.ctl[(size_t)mybase + k + (uint32_t)PFL] : 0u;
+            const float limf = (float)(__builtin_bit_cast(double, sbest[lane]) * (1.0 + 1e-9)) * 1.000001f;      // >= the bound (+inf stays +inf)
+            const float l = box_lower_bound(sbox_raw, ntp, (int)(mine ? tl : 0u), pf, padq_l);
+            n_box += (uint32_t)__builtin_popcountll(__ballot(mine));
+            const unsigned long long cand = __ballot(mine && l <= limf);
+            if (cand) push_tiles((uint32_t)lane, cand, tl);
+            WP_TICK(0)
+            drain(false);
+        }
+    }
+#endif
     // the first 64 entries of a sample's list are requested PF samples ahead (a sample's front end is ~100 instructions: one sample of distance
     // leaves the load's latency exposed); further chunks of a coarse-level list are requested together when the sample's turn comes
     constexpr int PF = 4;
     uint32_t tlq[PF];
     auto list_head = [&](uint32_t jj) -> uint32_t {
-        if (jj >= npts) return 0u;
+        if (AC_WARP_LANE_LISTS || jj >= npts) return 0u;
         const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, (int)jj);
         return cn != CELL_OVERFLOW ? (uint32_t)av.ctl[(size_t)__builtin_amdgcn_readlane((int)mybase, (int)jj) + lane] : 0u;
     };
@@ -1189,6 +1235,10 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     for (int d = 0; d < PF; ++d) tlq[d] = list_head((uint32_t)d);
     for (uint32_t j = 0; j <= npts; ++j) {                                 // j == npts: drain the queues
         const bool last = j == npts;
+#if AC_WARP_LANE_LISTS
+        // (samples with a list were served above: only the few without one -- outside both grids, an overflowing cell -- take a turn here)
+        if (!last && (uint32_t)__builtin_amdgcn_readlane((int)mycnt, (int)j) != CELL_OVERFLOW) continue;
+#endif
         if (!last) {
         const float qf[3] = { lane_f32(pf[0], (int)j), lane_f32(pf[1], (int)j), lane_f32(pf[2], (int)j) };
         const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, (int)j);          // wave-uniform
@@ -1250,18 +1300,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             WP_TICK(3)
         }
         }
-        // ONE inlined copy of each stage; downstream first (that bounds the queues): full trips / batches while samples are still coming, the
-        // leftovers at the end
-        for (;;) {
-            const uint32_t ntq = tt - th, ngq = gt - gh, nfq = ft - fh;
-            const bool do_e = nfq >= 64u || (last && !ntq && !ngq && nfq);
-            const bool do_d = !do_e && (ngq >= (uint32_t)(8 * DSTEPS) || (last && !ntq && ngq));
-            const bool do_g = !do_e && !do_d && (ntq >= (uint32_t)(16 * GSTEPS) || (last && ntq));
-            if (do_e) { exact_batch(nfq < 64u ? nfq : 64u); WP_TICK(5) }
-            else if (do_d) disc_trip();
-            else if (do_g) group_trip();
-            else break;
-        }
+        drain(last);
     }
 #undef SBOX
     WP_TICK(5)
