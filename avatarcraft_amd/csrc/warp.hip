@@ -608,20 +608,51 @@ __device__ unsigned long long g_warp_prof[8];
 #ifdef AC_WARP_SEED_DEBUG
 __device__ const double *g_warp_seed_d2 = nullptr;
 #endif
-#define SBOX(ROW, TL) sbox_raw[(ROW) * ntp + (TL)]
+// The tiles' bounds in LDS, two layouts.  Row-major [NB][ntp] (TM = false): lane = tile reads are conflict-free -- the structure build
+// (accel_cells_kernel: every cell runs the full bounding pass).  Tile-major [ntp][NBT] (TM = true, round 4): one tile's 15 numbers are four 16-byte
+// reads for a lane that looks at ITS OWN tile -- the search, whose front end is lane = sample since round 4 (15 scattered dword reads with 4 - 8-way
+// bank conflicts were a third of its time: tools/warp_profile.py).
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+constexpr int NBT = 20;            // floats per tile in the tile-major layout: axes (9) | lo (3) | hi (3) | representative vertex (3) | pad (2)
+template <bool TM> __device__ __forceinline__ float sbox_at(const float *sbox_raw, uint32_t ntp, int row, int tl)
+{
+    return TM ? sbox_raw[tl * NBT + row] : sbox_raw[(uint32_t)row * ntp + (uint32_t)tl];
+}
+#define SBOX(ROW, TL) sbox_at<TM>(sbox_raw, ntp, (ROW), (int)(TL))
+template <bool TM = false>
 __device__ __forceinline__ void load_boxes(float *sbox_raw, const AccelView &av, uint32_t ntp)
 {
-    for (uint32_t e = threadIdx.x; e < NB * ntp; e += blockDim.x) sbox_raw[e] = av.box[(e / ntp) * MAX_TILES + e % ntp];
+    if (TM) {
+        for (uint32_t e = threadIdx.x; e < (uint32_t)NBT * ntp; e += blockDim.x) {
+            const uint32_t tl = e / NBT, r = e % NBT;
+            sbox_raw[e] = r < (uint32_t)NB ? av.box[r * MAX_TILES + tl] : 0.0f;
+        }
+    } else {
+        for (uint32_t e = threadIdx.x; e < NB * ntp; e += blockDim.x) sbox_raw[e] = av.box[(e / ntp) * MAX_TILES + e % ntp];
+    }
 }
 
 // conservative fp32 lower bound of dist(q, box of tile tl)^2 (every rounding padded to the safe side; +inf for padding tiles)
+template <bool TM = false>
 __device__ __forceinline__ float box_lower_bound(const float *sbox_raw, uint32_t ntp, int tl, const float (&qf)[3], float padq)
 {
+    float ax[9], blo[3], bhi[3];
+    if (TM) {
+        const f32x4w *rec = reinterpret_cast<const f32x4w *>(sbox_raw + tl * NBT);
+        const f32x4w a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3];
+        ax[0] = a0[0]; ax[1] = a0[1]; ax[2] = a0[2]; ax[3] = a0[3]; ax[4] = a1[0]; ax[5] = a1[1]; ax[6] = a1[2]; ax[7] = a1[3]; ax[8] = a2[0];
+        blo[0] = a2[1]; blo[1] = a2[2]; blo[2] = a2[3]; bhi[0] = a3[0]; bhi[1] = a3[1]; bhi[2] = a3[2];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) ax[r] = SBOX(r, tl);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { blo[k] = SBOX(9 + k, tl); bhi[k] = SBOX(12 + k, tl); }
+    }
     float l = 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float sk = qf[0] * SBOX(3 * k, tl) + qf[1] * SBOX(3 * k + 1, tl) + qf[2] * SBOX(3 * k + 2, tl);
-        const float lo = SBOX(9 + k, tl) - sk, hi = sk - SBOX(12 + k, tl);
+        const float sk = qf[0] * ax[3 * k] + qf[1] * ax[3 * k + 1] + qf[2] * ax[3 * k + 2];
+        const float lo = blo[k] - sk, hi = sk - bhi[k];
         float d = (lo > hi ? lo : hi) - padq;                      // the box itself is padded by its builder
         d = d > 0.0f ? d : 0.0f;
         l += d * d;
@@ -631,6 +662,7 @@ __device__ __forceinline__ float box_lower_bound(const float *sbox_raw, uint32_t
 
 // 1. of the full search: lower bound of every tile (lb[], lane = tile), upper bound from the representative vertices, and the two most
 // promising tiles: tA = nearest representative vertex, tB = smallest lower bound
+template <bool TM = false>
 __device__ __forceinline__ float bounding_pass(const float *sbox_raw, uint32_t ntp, uint32_t nit, int lane, const float (&qf)[3], float (&lb)[NIT],
                                                int &tA, int &tB)
 {
@@ -645,7 +677,7 @@ __device__ __forceinline__ float bounding_pass(const float *sbox_raw, uint32_t n
         const float ex = qf[0] - SBOX(15, tl), ey = qf[1] - SBOX(16, tl), ez = qf[2] - SBOX(17, tl);
         const float u = (ex * ex + ey * ey + ez * ez) * (1.0f + 1e-6f);      // >= |q - representative vertex|^2
         if (u < ubl) { ubl = u; tbest = tl; }                      // padding tiles hold +inf
-        lb[it] = box_lower_bound(sbox_raw, ntp, tl, qf, padq);
+        lb[it] = box_lower_bound<TM>(sbox_raw, ntp, tl, qf, padq);
     }
     const float ub = wave_min_f32(ubl);
     float lmin = lb[0];
@@ -981,14 +1013,15 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     const uint32_t nit = (nt + 63) >> 6;
     extern __shared__ __attribute__((aligned(16))) float sbox_raw[];
     const uint32_t ntp = nit * 64;                                     // tiles rounded up to whole bounding-pass iterations: the LDS row length
-    char *wl = reinterpret_cast<char *>(sbox_raw + NB * ntp) + (threadIdx.x >> 6) * PK_WAVE_BYTES;
+    constexpr bool TM = true;                                          // tile-major bounds (see load_boxes)
+    char *wl = reinterpret_cast<char *>(sbox_raw + NBT * ntp) + (threadIdx.x >> 6) * PK_WAVE_BYTES;
     unsigned long long *sbest = reinterpret_cast<unsigned long long *>(wl);      // [64] bits of the running minimum distance^2 of sample s
     uint32_t *sbid = reinterpret_cast<uint32_t *>(wl + 512);                     // [64] lowest face id at that distance
     float *sq = reinterpret_cast<float *>(wl + 768);                             // [3][64] the samples
     uint32_t *fq = reinterpret_cast<uint32_t *>(wl + 1536);                      // [FQ] (sample << 14) | slot
     uint32_t *gq = reinterpret_cast<uint32_t *>(wl + 1536 + FQ * 4);             // [GQ] (sample << 11) | (tile << 2) | group
     uint16_t *tq = reinterpret_cast<uint16_t *>(wl + 1536 + FQ * 4 + GQ * 4);    // [TQ] (sample << 9) | tile
-    load_boxes(sbox_raw, av, ntp);
+    load_boxes<TM>(sbox_raw, av, ntp);
     __syncthreads();
     if (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) >= ((P + 63u) >> 6)) return;       // (after the barrier) a wave without samples
     const uint32_t i = wave * 64 + lane;
@@ -1107,10 +1140,13 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             const float padq = 4e-7f * ((__builtin_fabsf(q0) + __builtin_fabsf(q1)) + __builtin_fabsf(q2));
             const float limf = (float)(__builtin_bit_cast(double, sbest[smp]) * (1.0 + 1e-9)) * 1.000001f;      // >= the bound (+inf stays +inf)
             const float blo[3] = { b0.x, b0.y, b1.x }, bhi[3] = { b1.y, b2.x, b2.y };
+            const f32x4w *rec = reinterpret_cast<const f32x4w *>(sbox_raw + tile * NBT);     // the tile's axes: three 16-byte reads (tile-major bounds)
+            const f32x4w a0 = rec[0], a1 = rec[1], a2 = rec[2];
+            const float ax[9] = { a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], a2[0] };
             float l = 0.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float sk = q0 * SBOX(3 * k, tile) + q1 * SBOX(3 * k + 1, tile) + q2 * SBOX(3 * k + 2, tile);
+                const float sk = q0 * ax[3 * k] + q1 * ax[3 * k + 1] + q2 * ax[3 * k + 2];
                 const float lo = blo[k] - sk, hi = sk - bhi[k];
                 float d = (lo > hi ? lo : hi) - padq;
                 d = d > 0.0f ? d : 0.0f;
@@ -1213,7 +1249,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             for (int d = 0; d + 1 < PFL; ++d) tlq[d] = tlq[d + 1];
             tlq[PFL - 1] = (has_list && k + (uint32_t)PFL < mycnt) ? (uint32_t)av.ctl[(size_t)mybase + k + (uint32_t)PFL] : 0u;
             const float limf = (float)(__builtin_bit_cast(double, sbest[lane]) * (1.0 + 1e-9)) * 1.000001f;      // >= the bound (+inf stays +inf)
-            const float l = box_lower_bound(sbox_raw, ntp, (int)(mine ? tl : 0u), pf, padq_l);
+            const float l = box_lower_bound<TM>(sbox_raw, ntp, (int)(mine ? tl : 0u), pf, padq_l);
             n_box += (uint32_t)__builtin_popcountll(__ballot(mine));
             const unsigned long long cand = __ballot(mine && l <= limf);
             if (cand) push_tiles((uint32_t)lane, cand, tl);
@@ -1262,7 +1298,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
                 if (c0) tl_mine = c0 == 64u ? tl_c1 : tl_c2;
                 const bool mine = c0 + (uint32_t)lane < cnt;
                 const uint32_t tl = mine ? tl_mine : 0u;
-                const float l = box_lower_bound(sbox_raw, ntp, (int)tl, qf, padq);
+                const float l = box_lower_bound<TM>(sbox_raw, ntp, (int)tl, qf, padq);
                 const unsigned long long cand = __ballot(mine && l <= lim0f);
                 push_tiles(j, cand, tl);
             }
@@ -1272,7 +1308,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             // tiles; the best of their faces is the sample's first bound (a real face's distance)
             float lb[NIT];
             int tA, tB;
-            (void)bounding_pass(sbox_raw, ntp, nit, lane, qf, lb, tA, tB);
+            (void)bounding_pass<TM>(sbox_raw, ntp, nit, lane, qf, lb, tA, tB);
             WP_TICK(1)
             const double q[3] = { (double)qf[0], (double)qf[1], (double)qf[2] };
             double best = __builtin_inf(), bc[3] = { 0.0, 0.0, 0.0 };
@@ -1566,9 +1602,9 @@ int ac::warp_samples_accel_impl(const float *pts, const float *verts, const int3
     const AccelView av = accel_view(const_cast<void *>(accel));
     const uint32_t waves = (P + 63) / 64;
     const size_t ntp = (((size_t)F + TILE_F - 1) / TILE_F + 63) / 64 * 64;        // as in the kernel: tiles rounded up to 64
-    const size_t lds = (size_t)NB * ntp * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES;
+    const size_t lds = (size_t)NBT * ntp * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES;
     static uint64_t seen = 0;        // the limit for the largest mesh the search supports; a launch asks for what its mesh needs
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(warp_samples_accel_kernel), (size_t)NB * MAX_TILES * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES);
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(warp_samples_accel_kernel), (size_t)NBT * MAX_TILES * sizeof(float) + (size_t)PK_WAVES * PK_WAVE_BYTES);
     uint32_t perm_mul = 1;
     for (uint32_t m : { 37u, 41u, 43u, 47u, 53u }) {
         uint32_t a = waves, b = m;
