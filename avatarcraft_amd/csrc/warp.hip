@@ -270,6 +270,9 @@ __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restri
 // with lanes = 16 pairs x 4 groups, 8 triples x 8 faces and 64 pairs respectively, so the lanes never diverge and every step is full.
 // Every test before the last is a conservative lower bound; the exact routine is the brute-force kernel's; ties -> lowest face id.
 // The barycentric blend / 4x4 inverse epilogue runs lane-parallel for the 64 samples.  Bit-identical to warp_samples_kernel.
+#ifndef AC_LIST_CLASSES
+#define AC_LIST_CLASSES 3        // a cell's tile list is written in this many distance classes, nearest first (1: in tile order)
+#endif
 #ifndef AC_TILE_F
 #define AC_TILE_F 32
 #endif
@@ -867,15 +870,24 @@ __global__ __launch_bounds__(256) void accel_cells_kernel(AccelView av, int buil
                 if (cnt <= K) {
                     uint16_t *dst = av.ctl + LVL_CTL0[l] + (size_t)cell * K;
                     uint32_t at = 0;
+                    // Listed NEAR TILES FIRST (round 4): the search walks a list front to back against a bound that falls with every exact test, so
+                    // the tiles most likely to hold the closest face should come before the ones that are only in the list because of the 2 h band.
+                    // Three classes by the box distance from the cell centre: <= half, <= the whole, > the distance of the seed face.
+                    const float seedf = (float)seed;
+#pragma unroll 1
+                    for (int cls = 0; cls < AC_LIST_CLASSES; ++cls) {
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        if ((uint32_t)it >= nit) continue;
-                        if ((cand[it] >> lane) & 1ull) {
-                            const uint32_t at_l = at + (uint32_t)__builtin_popcountll(cand[it] & ((1ull << lane) - 1ull));
-                            dst[at_l] = (uint16_t)(it * 64 + lane);
-                            if (l == 0) s_tl[wv][at_l] = (uint16_t)(it * 64 + lane);
+                        for (int it = 0; it < NIT; ++it) {
+                            if ((uint32_t)it >= nit) continue;
+                            const int mycls = AC_LIST_CLASSES == 1 ? 0 : (lb[it] <= 0.25f * seedf ? 0 : (lb[it] <= seedf ? 1 : 2));
+                            const unsigned long long m = cand[it] & __ballot(mycls == cls);
+                            if ((m >> lane) & 1ull) {
+                                const uint32_t at_l = at + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                                dst[at_l] = (uint16_t)(it * 64 + lane);
+                                if (l == 0) s_tl[wv][at_l] = (uint16_t)(it * 64 + lane);
+                            }
+                            at += (uint32_t)__builtin_popcountll(m);
                         }
-                        at += (uint32_t)__builtin_popcountll(cand[it]);
                     }
                     info = (cnt << 16) | sslot;
                     // round 4, fine level: the FACES of the listed tiles that can hold the closest face (or one at equal distance) of a point of the cell:
