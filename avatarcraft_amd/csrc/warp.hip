@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
         }
     };
 #if AC_WARP_LANE_LISTS
-    // Round 4, the front end as lane = sample: every lane walks the tile list of ITS cell, one entry per trip -- the box test of entry k against the lane's
+    // Round 4, the front end as lane = sample: every lane walks the tile list of ITS cell, four entries per trip -- the box test of an entry against the lane's
     // CURRENT bound (the running minimum the exact batches keep lowering, not only the seed), survivors compacted into the pair queue.  A trip costs what
     // one sample's step cost before (15 LDS reads + ~40 vector instructions) and serves up to 64 samples; the per-sample version broadcast the sample to
     // all lanes, waited for its list and left most lanes idle (35 listed tiles per sample on average, 64 lanes).  Trips = the longest list in the wave.
@@ -1250,21 +1250,26 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
         const bool has_list = (uint32_t)lane < npts && mycnt != CELL_OVERFLOW && mycnt != 0u;
         const uint32_t kmax = (uint32_t)(-wave_min_i32(has_list ? -(int)mycnt : 0));
         const float padq_l = 4e-7f * ((__builtin_fabsf(pf[0]) + __builtin_fabsf(pf[1])) + __builtin_fabsf(pf[2]));
-        constexpr int PFL = 4;                                             // list entries requested ahead
-        uint32_t tlq[PFL];
-#pragma unroll
-        for (int d = 0; d < PFL; ++d) tlq[d] = (has_list && (uint32_t)d < mycnt) ? (uint32_t)av.ctl[(size_t)mybase + (uint32_t)d] : 0u;
-        for (uint32_t k = 0; k < kmax; ++k) {
-            const bool mine = has_list && k < mycnt;
-            const uint32_t tl = tlq[0];
-#pragma unroll
-            for (int d = 0; d + 1 < PFL; ++d) tlq[d] = tlq[d + 1];
-            tlq[PFL - 1] = (has_list && k + (uint32_t)PFL < mycnt) ? (uint32_t)av.ctl[(size_t)mybase + k + (uint32_t)PFL] : 0u;
+        // four list entries per trip (one 8-byte load: lists start on multiples of four entries), requested one trip ahead; the bound is read once per trip
+        constexpr int BU = 4;
+        static_assert(LVL_K[0] % BU == 0 && LVL_K[1] % BU == 0 && LVL_CTL0[1] % BU == 0, "8-byte aligned list chunks");
+        auto chunk = [&](uint32_t k) -> uint2 {
+            return (has_list && k < mycnt) ? *reinterpret_cast<const uint2 *>(av.ctl + (size_t)mybase + k) : make_uint2(0u, 0u);
+        };
+        uint2 nxt = chunk(0u);
+        for (uint32_t k = 0; k < kmax; k += BU) {
+            const uint2 cur = nxt;
+            nxt = chunk(k + (uint32_t)BU);
+            const uint32_t tl[BU] = { cur.x & 0xffffu, cur.x >> 16, cur.y & 0xffffu, cur.y >> 16 };
             const float limf = (float)(__builtin_bit_cast(double, sbest[lane]) * (1.0 + 1e-9)) * 1.000001f;      // >= the bound (+inf stays +inf)
-            const float l = box_lower_bound<TM>(sbox_raw, ntp, (int)(mine ? tl : 0u), pf, padq_l);
-            n_box += (uint32_t)__builtin_popcountll(__ballot(mine));
-            const unsigned long long cand = __ballot(mine && l <= limf);
-            if (cand) push_tiles((uint32_t)lane, cand, tl);
+#pragma unroll
+            for (int u = 0; u < BU; ++u) {
+                const bool mine = has_list && k + (uint32_t)u < mycnt;
+                const float l = box_lower_bound<TM>(sbox_raw, ntp, (int)(mine ? tl[u] : 0u), pf, padq_l);
+                n_box += (uint32_t)__builtin_popcountll(__ballot(mine));
+                const unsigned long long cand = __ballot(mine && l <= limf);
+                if (cand) push_tiles((uint32_t)lane, cand, tl[u]);
+            }
             WP_TICK(0)
             drain(false);
         }
