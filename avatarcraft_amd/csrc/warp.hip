@@ -264,8 +264,9 @@ __global__ __launch_bounds__(256) void warp_samples_kernel(const float *__restri
 // 16384 64-bit keys in 128 KB of LDS), cut into tiles of TILE_F faces with an oriented box (axis 0 = mean normal), four sub-boxes
 // (groups of 8 consecutive faces, in the tile's frame), a bounding disc per face and one representative vertex; then two cell
 // grids whose cells list the tiles that matter for any point inside them (below).
-// Per sample (warp_samples_accel_kernel): a wave owns 64 consecutive samples.  A sample's candidate tiles come from its cell's list
-// (or, without a cell, from a pass over all tile boxes) and the rest is a pipeline of packed LDS queues shared by the wave's samples:
+// Per sample (warp_samples_accel_kernel): a wave owns 64 consecutive samples.  A sample's candidate tiles come from its cell's list -- since round 4
+// every lane walks the list of ITS sample's cell, four entries per trip, box-testing them against the sample's current bound -- (or, without a cell,
+// from a pass over all tile boxes, one sample at a time) and the rest is a pipeline of packed LDS queues shared by the wave's samples:
 //   (sample, tile) -> sub-box test -> (sample, tile, group) -> disc test -> (sample, face) -> fp64 Ericson routine -> running minimum of the sample
 // with lanes = 16 pairs x 4 groups, 8 triples x 8 faces and 64 pairs respectively, so the lanes never diverge and every step is full.
 // Every test before the last is a conservative lower bound; the exact routine is the brute-force kernel's; ties -> lowest face id.
