@@ -339,3 +339,26 @@ def test_dropin_fused_route_serves_models_instant_nsr(tmp_path, monkeypatch):
     assert c.WHO == "reference"                      # after uninstall the package serves its own module again
     for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
         del sys.modules[k]
+
+
+def test_dtype_codes_and_adam_argument_checks():
+    """host-side checks that need no GPU: the dtype dispatch of the encoders (the reference's CHECK_IS_FLOATING / one scalar_t per call) and the one-launch
+    Adam's refusal of tensors it cannot step"""
+    from avatarcraft_amd import _lib
+    from avatarcraft_amd.stylize import Adam
+    assert _lib.dtype_code(torch.zeros(1)) == 0 and _lib.dtype_code(torch.zeros(1, dtype=torch.float16)) == 1 and _lib.dtype_code(torch.zeros(1, dtype=torch.float64)) == 2
+    with pytest.raises(RuntimeError, match="floating tensor"):
+        _lib.dtype_code(torch.zeros(1, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="floating tensor"):
+        _lib.dtype_code(torch.zeros(1, dtype=torch.int32), "grad")
+    with pytest.raises(RuntimeError, match="must have the dtype of inputs"):
+        _lib.dtype_code(torch.zeros(1, dtype=torch.float16), "inputs", ((torch.zeros(1), "embeddings"),))
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    opt = Adam([p], lr=1e-3, zero_grad_in_step=True)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        opt.step()                                           # a CPU parameter: no silent fallback to torch's update
+    assert float(p.abs().max()) == 0.0 and not opt.grads_cleared
+    opt.zero_grad()
+    assert opt.grads_cleared and p.grad is not None and float(p.grad.abs().max()) == 0.0      # cleared in place, never dropped
+    assert set(opt.state_dict()["param_groups"][0].keys()) == set(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3).state_dict()["param_groups"][0].keys())
