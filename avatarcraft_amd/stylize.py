@@ -71,9 +71,16 @@ class Adam(torch.optim.Adam):
         super().zero_grad(set_to_none=False)
         self.grads_cleared = True
 
+    def __setstate__(self, state):
+        super().__setstate__(state)                      # (torch's __getstate__ keeps defaults / state / param_groups only)
+        self.__dict__.setdefault("zero_grad_in_step", False)
+        self.__dict__.setdefault("grads_cleared", False)
+        self._entries = {}
+
     @torch.no_grad()
     def step(self, closure=None):
-        import ctypes
+        """one launch per 16 tensors of a parameter group.  The group's step count is read from its first parameter (torch keeps one per parameter; they
+        only differ when parameters are added to a running optimizer, which the reference never does)."""
         from . import _lib as L
         loss = None
         if closure is not None:
