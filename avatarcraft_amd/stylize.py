@@ -71,8 +71,13 @@ class Adam(torch.optim.Adam):
         super().zero_grad(set_to_none=False)
         self.grads_cleared = True
 
+    def __getstate__(self):
+        d = super().__getstate__()                       # (torch's keeps defaults / state / param_groups only)
+        d["zero_grad_in_step"] = self.zero_grad_in_step
+        return d
+
     def __setstate__(self, state):
-        super().__setstate__(state)                      # (torch's __getstate__ keeps defaults / state / param_groups only)
+        super().__setstate__(state)
         self.__dict__.setdefault("zero_grad_in_step", False)
         self.__dict__.setdefault("grads_cleared", False)
         self._entries = {}
