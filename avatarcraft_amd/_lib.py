@@ -81,6 +81,7 @@ _SIGS = {
     "ac_hash_encode_backward_typed": ([C.c_int, vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp, vp], C.c_int),
     "ac_sh_encode_forward_typed": ([C.c_int, vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
     "ac_sh_encode_backward_typed": ([C.c_int, vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),
+    "ac_variance_forward": ([vp, vp, vp], C.c_int),
     "ac_adam_step": ([C.POINTER(ac_adam_entry), u32, f32, f32, f32, f32, f32, f32, f32, C.c_int, vp], C.c_int),
     "ac_sh_encode_forward": ([vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
     "ac_sh_encode_backward": ([vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),

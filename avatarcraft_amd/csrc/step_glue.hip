@@ -162,6 +162,15 @@ __global__ __launch_bounds__(ADAM_BLOCK) void adam_step_kernel(const AdamArgs a)
     }
 }
 
+// inv_s = forward_variance() of the model: ones([1, 1]) * exp(variance * 10) clipped to [1e-6, 1e6] (models/instant_nsr.py:35-45, 666-667) -- five torch
+// launches of ~5 us each per parameter version, one here.  expf is the device library's exp torch's kernel calls: the same bits; NaN passes like torch.clip's.
+__global__ __launch_bounds__(64) void variance_forward_kernel(const float *__restrict__ variance, float *__restrict__ inv_s)
+{
+    if (threadIdx.x != 0) return;
+    const float e = expf(variance[0] * 10.0f);
+    inv_s[0] = e != e ? e : __builtin_fminf(__builtin_fmaxf(e, 1e-6f), 1e6f);
+}
+
 }  // namespace
 
 AC_API int ac_adam_step(const ac_adam_entry *tensors, uint32_t n, float step_size, float beta1, float one_minus_beta1, float beta2, float one_minus_beta2,
@@ -181,6 +190,13 @@ AC_API int ac_adam_step(const ac_adam_entry *tensors, uint32_t n, float step_siz
     }
     hipLaunchKernelGGL(adam_step_kernel, dim3(a.blk0[n]), dim3(ADAM_BLOCK), 0, (hipStream_t)stream, a);
     return ac::check_launch("adam_step");
+}
+
+AC_API int ac_variance_forward(const float *variance, float *inv_s, ac_stream_t stream)
+{
+    if (!variance || !inv_s) { ac::set_error("variance_forward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(variance_forward_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, variance, inv_s);
+    return ac::check_launch("variance_forward");
 }
 
 AC_API int ac_weight_norm_forward(const ac_wn_layer *layers, uint32_t n, ac_stream_t stream)

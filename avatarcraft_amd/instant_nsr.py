@@ -15,6 +15,7 @@ Where the work happens:
 """
 import numpy as np
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -36,6 +37,10 @@ def near_far_from_bound(rays_o, rays_d, bound, type='cube'):
     near = torch.where(tmin < tmax, tmin, tmax).max(dim=-1, keepdim=True)[0]
     far = torch.where(tmin > tmax, tmin, tmax).min(dim=-1, keepdim=True)[0]
     return torch.clamp(near, min=0.05), far
+
+
+# forward_variance() without a graph through ac_variance_forward (one launch instead of torch's five); AC_FUSED_VARIANCE=0: torch's
+FUSED_VARIANCE = os.environ.get("AC_FUSED_VARIANCE", "1") != "0"
 
 
 class SingleVarianceNetwork(nn.Module):
@@ -710,7 +715,10 @@ class NeRFNetwork(NeRFRenderer):
             c = getattr(self, "_inv_s_cache", None)
             if c is None or c[0] != key:
                 with torch.no_grad():
-                    c = (key, self.deviation_net(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6))
+                    if v.is_cuda and v.dtype == torch.float32 and FUSED_VARIANCE:
+                        c = (key, nsr_ops.variance_forward(v))                       # one launch, the same bits (ac_variance_forward)
+                    else:
+                        c = (key, self.deviation_net(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6))
                 self._inv_s_cache = c
             return c[1]
         return self.deviation_net(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6)

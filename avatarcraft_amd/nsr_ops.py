@@ -676,6 +676,17 @@ def sdf_stencil(x, table, W1, b1, W2, b2, offsets, per_level_scale, base_resolut
     return _SdfStencil.apply(x, table, W1, b1, W2, b2, cfg)
 
 
+def variance_forward(variance):
+    """forward_variance() without a graph: clip(exp(10 * variance), 1e-6, 1e6) as a [1, 1] tensor, one launch (ac_variance_forward)"""
+    v = variance.detach()
+    _chk(v, "variance")
+    if v.dtype != torch.float32 or v.numel() != 1:
+        raise RuntimeError("variance_forward: a single float32 value")
+    out = torch.empty((1, 1), dtype=torch.float32, device=v.device)
+    L.check(L.lib().ac_variance_forward(v.data_ptr(), out.data_ptr(), L.current_stream(v.device)), "variance_forward")
+    return out
+
+
 def field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio=1.0, want_sdf=False, want_gradient=False):
     """ac_field_samples: the field on packed samples (what run_cuda evaluates between the marcher and the packed compositor).
     xyzs, dirs [M,3]; deltas [M] (march_rays_train) or [M,2] (march_rays; column 0 is the step).  inv_s: float or a CUDA tensor (read on the device).

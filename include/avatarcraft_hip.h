@@ -448,6 +448,10 @@ typedef struct ac_adam_entry { float *param, *grad, *exp_avg, *exp_avg_sq; uint6
 int ac_adam_step(const ac_adam_entry *tensors, uint32_t n_tensors, float step_size, float beta1, float one_minus_beta1, float beta2,
                  float one_minus_beta2, float eps, float bias_correction2_sqrt, int zero_grad, ac_stream_t stream);
 
+/* forward_variance() of the model (models/instant_nsr.py:35-45, 666-667): inv_s[0] = clip(exp(10 * variance[0]), 1e-6, 1e6), the value
+ * ac_render_opts.inv_s_dev points at -- one launch instead of torch's five (ones, mul, exp, mul, clip); same bits (the device library's expf). */
+int ac_variance_forward(const float *variance, float *inv_s, ac_stream_t stream);
+
 typedef struct ac_pg_entry { const float *src, *v, *g; float *dst, *dst2; uint32_t rows, cols, src_stride; int32_t kind; } ac_pg_entry;
 int ac_param_grads(const ac_pg_entry *entries, uint32_t n_entries, ac_stream_t stream);
 /* ac_sds_upstream: the opacity term of the stylisation loss (stylize.py:183-193): loss = sum_i smooth_l1(clamp(ws_i, 0, 1), clamp(ws_gt_i, 0, 1)) *

@@ -797,3 +797,18 @@ def test_nan_guard_raises_after_a_poisoned_training_render():
     net.render(ro_t[None], rd_t[None], **kw)
     with pytest.raises(FloatingPointError):
         net.check_finite()
+
+
+def test_variance_forward_kernel_equals_torch_bit_for_bit():
+    """ac_variance_forward (forward_variance() without a graph in one launch) against the five torch launches it replaces -- the bits decide every sample
+    position of a render, so equality is exact: ordinary values, both clip limits, NaN"""
+    from avatarcraft_amd import nsr_ops
+    from avatarcraft_amd.instant_nsr import SingleVarianceNetwork
+    vals = [0.3, 0.6239, 0.05, -0.2, 1.0, 1.3815, 1.3816, 1.5, -1.3815, -1.3816, -2.0, 0.0, 8.9, -9.0, float("nan")] + list(np.random.RandomState(0).uniform(-1.5, 1.5, 200))
+    for val in vals:
+        net = SingleVarianceNetwork(float(val)).to(DEV)
+        with torch.no_grad():
+            want = net(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6)
+        got = nsr_ops.variance_forward(net.variance)
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.cpu().numpy().view(np.uint32)), (val, float(got), float(want))
