@@ -82,6 +82,13 @@ class Adam(torch.optim.Adam):
         self.__dict__.setdefault("grads_cleared", False)
         self._entries = {}
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # a state saved by torch.optim.Adam(fused=True / capturable=True) keeps its step counts on the device: reading them would synchronise every step
+        for st in self.state.values():
+            if isinstance(st.get("step"), torch.Tensor) and st["step"].is_cuda:
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+
     @torch.no_grad()
     def step(self, closure=None):
         """one launch per 16 tensors of a parameter group.  The group's step count is read from its first parameter (torch keeps one per parameter; they
