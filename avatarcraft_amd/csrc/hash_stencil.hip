@@ -418,6 +418,10 @@ __host__ __device__ __forceinline__ uint32_t bucket_shift(uint32_t size)
     while (((size + (1u << sh) - 1u) >> sh) > (uint32_t)NBUCKET) ++sh;
     return sh;
 }
+// Largest level the binned scatter takes (binned_levels): an entry's index inside its bucket must fit the 13 bits rec_pack gives it (8-byte records) and the
+// 19 bits ridx gives the entry in the wave buffer (BinSink::add8, every record layout); a bucket's slice must fit bucket_accumulate_kernel's LDS image.
+constexpr uint32_t BIN_IDX_BITS = 13, BIN_MAX_LEVEL = 1u << 19;
+static_assert((uint32_t)NBUCKET << BIN_IDX_BITS >= BIN_MAX_LEVEL, "rec_pack: the in-bucket index of the largest binned level needs more than 13 bits");
 
 
 // one point's 8 corners, combined over the run of lanes in the same cell
@@ -846,7 +850,7 @@ static uint32_t binned_levels(const ac::LevelTable &lt, uint32_t L)
 {
     uint32_t m = 0;
     for (uint32_t l = 0; l < L; ++l)
-        if (lt.size[l] >= (uint32_t)NBUCKET && lt.size[l] <= (1u << 19)) m |= 1u << l;
+        if (lt.size[l] >= (uint32_t)NBUCKET && lt.size[l] <= BIN_MAX_LEVEL && bucket_shift(lt.size[l]) <= BIN_IDX_BITS) m |= 1u << l;
     return m;
 }
 static uint32_t queue_cap(uint32_t B, uint32_t per_sample = 56u) { return (uint32_t)(((uint64_t)B * per_sample * 3u / 2u) / NBUCKET) + 4096u; }   // 1.5 x the average

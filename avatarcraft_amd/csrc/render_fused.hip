@@ -383,6 +383,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             // coherence point, whichever XCD either wave runs on); the publisher drains its state stores (s_waitcnt vmcnt(0)) before it issues the flag
             // store; the taker issues its state loads only after lane 0 has observed the flag (control dependence + the wave barrier below), and the
             // memory pipeline returns a wave's loads in issue order.  No ordinary (cached) access ever touches these words.
+            // COMPILER ordering is pinned, not assumed: wave_sync() is `fence acq_rel, wavefront` + wave barrier (nsr_device.hpp) -- a wavefront-scope fence
+            // costs no instruction (no cache maintenance) but forbids LLVM to move the relaxed state loads below above the flag load of the loop above
+            // (ADVICE round 4); the publisher's side has the same fence between its state stores and its flag store.
             wave_sync();
             const uint32_t *st = reinterpret_cast<const uint32_t *>(a.seg_state + (size_t)ray * SEG_STATE);
             if constexpr (MODE != MODE_FINAL)

@@ -581,7 +581,9 @@ struct OccArgs {
     float *weights_sum, *depth, *image, *normal_map;     // [N] [N] [N,3] [N,3]: accumulators as composite_rays leaves them (background / depth normalisation: the caller)
     uint32_t *n_samples;                                   // optional [1]: total samples evaluated (atomic, one add per wave)
     uint32_t glog;                                         // a wave marches 2^glog rays at a time (lanes 0 .. 2^glog - 1); the 64 sample slots of an iteration (4 tiles) are
-};                                                         // shared out among the rays still alive: 64 / alive each -- the last, long rays of a group get whole tiles
+                                                           // shared out among the rays still alive: 64 / alive each -- the last, long rays of a group get whole tiles
+    uint32_t max_steps;                                    // a ray stops after this many samples (run_cuda's max_steps; the loop of rounds stops at the first round that
+};                                                         // brings its step count to >= max_steps, i.e. after max_steps .. max_steps + 7 samples); 0 = no cap
 
 __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderArgs a, const OccArgs oc)
 {
@@ -609,6 +611,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
         cube_near_far(c.ox, c.oy, c.oz, c.dx, c.dy, c.dz, bound, near, far);      // near_far_from_bound(type='cube'), instant_nsr.py:58-77 (what run_cuda passes to march_rays)
         float t = near, last_t = near, tc = near;                                  // marcher's t | its last_t | the compositor's t (rays_t)
         float ws = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f;
+        uint32_t taken = 0;                                                         // samples this ray has marched so far
         while (__ballot(alive) != 0ull) {
             // ---- march: this lane's next (up to K) occupied samples into its own slots (march_rays_kernel's loop body).  K = 64 / (rays of the group still
             // alive): a group starts with few samples per ray and iteration and ends with whole tiles for its last, longest rays ----
@@ -621,6 +624,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                 float x, y, z; int vx, vy, vz;
                 float *sp = stage + 8 * mybase;
                 while (mycnt < K) {
+                    if (oc.max_steps && taken >= oc.max_steps) { alive = false; break; }   // the samples already staged this iteration are still composited below
                     bool have = false;
                     while (t < far) {
                         const float den = rm_density(c, t, x, y, z, vx, vy, vz);
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                     t += dt;
                     sp[0] = x; sp[1] = y; sp[2] = z; sp[3] = dt; sp[7] = t - last_t;
                     last_t = t;
-                    sp += 8; ++mycnt;
+                    sp += 8; ++mycnt; ++taken;
                 }
             }
             wave_sync();
@@ -1314,7 +1318,8 @@ AC_API int ac_field_samples(const ac_field *field, const float *xyzs, const floa
 
 AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
                                     float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
-                                    float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, ac_stream_t stream)
+                                    float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
+                                    ac_stream_t stream)
 {
     if (N == 0) return AC_OK;
     if (!rays_o || !rays_d || !grid || !weights_sum || !depth || !image || !normal_map || H < 2 || !(eps > 0.0f)) {
@@ -1330,7 +1335,7 @@ AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, 
     static const int env_glog = []() { const char *e = getenv("AC_OCC_GLOG"); return (e && e[0] >= '2' && e[0] <= '6' && !e[1]) ? e[0] - '0' : -1; }();
     const uint32_t glog = env_glog >= 0 ? (uint32_t)env_glog : (N >= 32768u ? 4u : 3u);
     const uint32_t gsz = 1u << glog;
-    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, glog };
+    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, glog, max_steps };
     const size_t lds_bytes = OCC_LDS_FLOATS * sizeof(float);
     static uint64_t seen = 0;
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_render_kernel), lds_bytes);

@@ -248,6 +248,14 @@ class NeRFRenderer(nn.Module):
             wn(g_sdf_p, 64 * 36, 64, s1), (ADD, (g_sdf_p, 64 * 36 + 1024), 1, 16, 1, None, None, s1.bias.grad, None),
             wn(g_col_p, 0, 32, c0), wn(g_col_p, 2048, 64, c1), wn(g_col_p, 6144, 64, c2),
             (VAR, g_invs, 1, g_invs.shape[0], 1, None, inv_s.reshape(-1), var.grad.reshape(-1), None)], ro.device)
+        # the kernels wrote the gradients through raw pointers: bump their version counters, so that anything keyed on them -- stylize.Adam.grads_cleared --
+        # sees that the buffers are no longer what they were (views of one flat buffer share a counter: one bump per distinct base is enough)
+        seen = set()
+        for t in prm:
+            key = t.grad.untyped_storage().data_ptr()
+            if key not in seen:
+                seen.add(key)
+                torch.autograd.graph.increment_version(t.grad)
 
     # How a render WITH gradients runs (stylize.py / reconstruct.py):
     #   "core": one operator -- forward = the fused renderer itself (the launch an inference render makes, bit for bit), backward =
@@ -524,12 +532,15 @@ class NeRFRenderer(nn.Module):
             depth = torch.zeros(n_rays, dtype=torch.float32, device=device)
             return depth.reshape(B, N), None, weights_sum[:, None], image.reshape(B, N, 3), normal_map, gradient_error, 0.0, None, None, None
         # ---- inference.  Default: ONE launch (ac_render_rays_occupancy: march + field + composite per ray, a wave's 64 rays packed into tiles) -- the
-        # same bits as the reference-shaped loop below without its rounds and host read-backs; occupancy_rounds = True selects the loop.
+        # same bits as the reference-shaped loop below without its rounds and host read-backs; occupancy_rounds = True selects the loop.  max_steps: the
+        # one launch stops a ray after exactly max_steps samples, the loop after max_steps .. max_steps + 7 (it stops at the first round that brings its step
+        # count to >= max_steps): the two agree bit for bit on every ray that needs fewer (tests/test_gpu_run_cuda.py checks both sides of that line).
         if not self.occupancy_rounds:
             with torch.no_grad():
                 near, far = near_far_from_bound(ro, rd, bound, type='cube')
                 near, far = near.reshape(-1), far.reshape(-1)
-                o = nsr_ops.render_rays_occupancy(self._field(), ro, rd, self.density_grid, self.mean_density, bound, fd_eps, inv_s_t, cos_anneal_ratio)
+                o = nsr_ops.render_rays_occupancy(self._field(), ro, rd, self.density_grid, self.mean_density, bound, fd_eps, inv_s_t, cos_anneal_ratio,
+                                                  max_steps=max_steps)
                 self._last_cuda_rounds = 0
                 image = o["image"] + (1 - o["weights_sum"]).unsqueeze(-1) * bg
                 depth = torch.clamp(o["depth"] - near, min=0) / (far - near)

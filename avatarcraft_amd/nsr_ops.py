@@ -709,9 +709,10 @@ def field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio
     return out
 
 
-def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, count_samples=False):
+def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, count_samples=False, max_steps=0):
     """ac_render_rays_occupancy: the inference form of run_cuda in one launch (march + field + composite per ray, no rounds).
-    -> dict(weights_sum [N], depth [N] (raw sum of w t), image [N,3] (no background), normal_map [N,3] (+ n_samples, a [1] int32 device tensor))"""
+    -> dict(weights_sum [N], depth [N] (raw sum of w t), image [N,3] (no background), normal_map [N,3] (+ n_samples, a [1] int32 device tensor))
+    max_steps: a ray stops after that many samples (0 = no cap); see include/avatarcraft_hip.h for how that relates to the loop of rounds."""
     rays_o = _chk(rays_o.reshape(-1, 3), "rays_o"); rays_d = _chk(rays_d.reshape(-1, 3), "rays_d"); grid = _chk(density_grid, "density_grid")
     N, dev = rays_o.shape[0], rays_o.device
     if grid.dim() != 3 or grid.shape[0] != grid.shape[1] or grid.shape[0] != grid.shape[2]:
@@ -724,7 +725,7 @@ def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bou
     L.check(L.lib().ac_render_rays_occupancy(C.byref(field.c), rays_o.data_ptr(), rays_d.data_ptr(), N, grid.data_ptr(), int(grid.shape[0]), float(mean_density),
                                              float(bound), float(eps), inv_f, L.ptr(inv_t), float(cos_anneal_ratio), out["weights_sum"].data_ptr(),
                                              out["depth"].data_ptr(), out["image"].data_ptr(), out["normal_map"].data_ptr(), L.ptr(out.get("n_samples")),
-                                             L.current_stream(dev)), "render_rays_occupancy")
+                                             max(0, int(max_steps)), L.current_stream(dev)), "render_rays_occupancy")
     return out
 
 

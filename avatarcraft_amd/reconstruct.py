@@ -32,7 +32,7 @@ def make_optimizer(net, epochs, lr=5e-4):
 def reconstruct_step(net, optimizer, rays_o, rays_d, rgb_gt, white_bkg=True, w_eikonal=W_EIKONAL, batch_size=BATCH_SIZE, num_steps=64, upsample_steps=64,
                      flat_grad=None, process_group=None, grad_divisor=None):
     """one optimisation step on one ray batch (reconstruct.py:92-112).  rays_o, rays_d, rgb_gt: [n, 3] on the net's device.
-    With a process group every rank takes its own ray batch and the flat gradient is all-reduced (sum, / world) like stylize.sds_step."""
+    With a process group every rank takes its own ray batch and the flat gradient is averaged in ONE collective like stylize.sds_step (stylize.reduce_gradients)."""
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     if flat_grad is None and dist_on and torch.distributed.get_world_size(process_group) > 1:
         # every rank draws its own ray batch: without the all-reduce the replicas would silently drift apart (stylize.sds_step refuses the same way)
@@ -48,14 +48,14 @@ def reconstruct_step(net, optimizer, rays_o, rays_d, rgb_gt, white_bkg=True, w_e
             optimizer.zero_grad()
         loss = F.smooth_l1_loss(rgb, rgb_gt, reduction='mean') + eikonal * w_eikonal
         loss.backward()
+    guard = None
     if flat_grad is not None and (process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())):
-        world = torch.distributed.get_world_size(process_group)
-        torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
-        if world > 1:
-            flat_grad.div_(world if grad_divisor is None else int(grad_divisor))
-    chk = getattr(net, "check_finite", None)
-    if chk is not None:
-        chk()                           # a NaN in this step's normals raises here (reference: the assert at instant_nsr.py:274), not after Adam has consumed it
+        from .stylize import reduce_gradients
+        guard = reduce_gradients(flat_grad, process_group, grad_divisor, nan_flag=eikonal.detach() if isinstance(eikonal, torch.Tensor) else None)
+    # a NaN in this step's normals -- on ANY rank, through the guard word of the collective -- raises here on every rank (reference: the assert at
+    # instant_nsr.py:274), not after Adam has consumed it
+    from .stylize import _check_finite
+    _check_finite(net, guard)
     optimizer.step()
     return loss.detach()
 

@@ -12,7 +12,7 @@ available offline, so `SyntheticGuidance` -- clamp(N(0,1), -1, 1), the statistic
 (models/diffusion.py:139-146) -- stands in for measurement and tests).
 
 Data parallel (BASELINE config 5): one view per rank, parameters replicated, ONE all-reduce (sum,
-then / world) of the flat fp32 gradient (12 248 902 elements = 49 MB) before the optimizer step.
+averaged inside the collective on RCCL) of the flat fp32 gradient (12 248 902 elements = 49 MB, plus one guard word) before the optimizer step.
 """
 import os
 
@@ -40,10 +40,14 @@ class SyntheticGuidance:
 
 def flat_grad_view(params):
     """Allocate ONE contiguous fp32 buffer and point every p.grad into it (so that the all-reduce is a single
-    collective over 49 MB instead of 15 small ones).  Returns the flat buffer."""
+    collective over 49 MB instead of 15 small ones).  Returns the flat buffer [n_params].
+    The allocation is one word longer than what is returned: the GUARD WORD behind the gradients (`flat.ac_guard`, a [n_params + 1] view of the same
+    memory) rides in the same collective and carries the step's "a render produced NaN / Inf" flag to every rank (see _reduce_gradients)."""
     params = [p for p in params if p.requires_grad]
     n = sum(p.numel() for p in params)
-    flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+    full = torch.zeros(n + 1, dtype=torch.float32, device=params[0].device)
+    flat = full[:n]
+    flat.ac_guard = full
     off = 0
     for p in params:
         p.grad = flat[off:off + p.numel()].view_as(p)
@@ -58,13 +62,29 @@ class Adam(torch.optim.Adam):
     'exp_avg_sq' per parameter), so state_dict()s are interchangeable with torch.optim.Adam's.
 
     zero_grad_in_step: the launch also clears the gradients it has consumed -- the next step's optimizer.zero_grad() (stylize.py:143) for free while the
-    values are in registers; `grads_cleared` then tells sds_step that its own clearing of the flat gradient is redundant."""
+    values are in registers; `grads_cleared` then tells sds_step that its own clearing of the flat gradient is redundant.
+
+    `grads_cleared` is a CHECKED claim, not a sticky flag: step() / zero_grad() record the version counters of the gradient tensors they have just cleared
+    and the property is true only while every counter still has that value.  Anything that writes a gradient in between -- loss.backward(), an in-place
+    op on .grad or on the flat buffer it is a view of, NeRFRenderer.backward_last (which bumps the counters of what its kernels wrote) -- makes it false,
+    and sds_step then clears the buffer itself (when in doubt, zero)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, zero_grad_in_step=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps)
         self.zero_grad_in_step = bool(zero_grad_in_step)
-        self.grads_cleared = False
+        self._cleared_token = None
         self._entries = {}
+
+    def _grad_token(self):
+        return tuple((id(p.grad), p.grad.data_ptr(), p.grad._version) for g in self.param_groups for p in g["params"] if p.grad is not None)
+
+    @property
+    def grads_cleared(self):
+        return self._cleared_token is not None and self._cleared_token == self._grad_token()
+
+    @grads_cleared.setter
+    def grads_cleared(self, value):
+        self._cleared_token = self._grad_token() if value else None
 
     def zero_grad(self, set_to_none=False):
         # the gradients live in one flat buffer other code holds views of (flat_grad_view): they are cleared in place, never dropped
@@ -79,7 +99,8 @@ class Adam(torch.optim.Adam):
     def __setstate__(self, state):
         super().__setstate__(state)
         self.__dict__.setdefault("zero_grad_in_step", False)
-        self.__dict__.setdefault("grads_cleared", False)
+        self.__dict__.pop("grads_cleared", None)             # (a pickle of the round-4 class kept a plain attribute of that name)
+        self._cleared_token = None
         self._entries = {}
 
     def load_state_dict(self, state_dict):
@@ -215,9 +236,13 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
     if hasattr(optimizer, "grads_cleared"):
         optimizer.grads_cleared = False
     bs = min(batch_size, n_rays)
-    eik_vals, opa_vals = [], []
+    eik_vals, opa_vals, nan_flags = [], [], []
     dist_on = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())
     overlap = (OVERLAP_GRAD_ALLREDUCE if overlap_allreduce is None else bool(overlap_allreduce)) and dist_on and flat_grad is not None and manual
+    if overlap and _avg_in_collective(process_group) and torch.distributed.get_world_size(process_group) > 1:
+        early_op = torch.distributed.ReduceOp.AVG          # (every slice of one step uses the same operator)
+    else:
+        early_op = torch.distributed.ReduceOp.SUM
     work_hi = hi_range = None
     for i in range(0, n_rays, bs) if manual else ():
         # The same three terms WITHOUT autograd (avatarcraft_amd.NeRFNetwork): the training render keeps its per-sample outputs, the upstream
@@ -241,6 +266,8 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                                                      opacity_only=True)           # (only its weight_sum is read: no colour network)
             g_ws, opa = nsr_ops.sds_upstream(extra["weight_sum"], extra_gt["weight_sum"], 1e5 / ro.shape[0], want_grad=use_opacity)
             opa_vals.append(opa[0])
+            if isinstance(eik, torch.Tensor):
+                nan_flags.append(eik)
             g_eik = None
             if w_eikonal > 0.0:
                 g_eik = _const_scalar(w_eikonal, ro.device)
@@ -257,8 +284,7 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                 side = _side_stream(ro.device)
                 net_style.backward_last(g_image=grad_rays[i:i + bs], g_weights_sum=g_ws, g_eik=g_eik, split=(ALLREDUCE_SPLIT_LEVEL, side))
                 with torch.cuda.stream(side):
-                    work_hi = torch.distributed.all_reduce(flat_grad[hi_range[0]:hi_range[1]], op=torch.distributed.ReduceOp.SUM, group=process_group,
-                                                           async_op=True)
+                    work_hi = torch.distributed.all_reduce(flat_grad[hi_range[0]:hi_range[1]], op=early_op, group=process_group, async_op=True)
             else:
                 net_style.backward_last(g_image=grad_rays[i:i + bs], g_weights_sum=g_ws, g_eik=g_eik)
         mark("backward")
@@ -268,6 +294,8 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                                                   return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
                                                   upsample_steps=upsample_steps)
         opacity_pred = extra["weight_sum"]
+        if isinstance(eik, torch.Tensor):
+            nan_flags.append(eik.detach())
         mark("render_grad_forward")
         # The reference back-propagates the three terms one after the other through the same retained graph
         # (stylize.py:163,169,193).  Gradients are linear in the loss, so ONE backward pass of their sum gives the same
@@ -289,26 +317,19 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
         mark("backward")
     # data parallel: one collective over the flat gradient (issued whenever a process group exists, world size 1 included: the call
     # path RCCL sees on an 8-GPU node is then the one every single-GPU run exercises)
-    if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-        world = torch.distributed.get_world_size(process_group)
+    guard = None
+    if dist_on:
         if flat_grad is None:
-            if world > 1:
+            if torch.distributed.get_world_size(process_group) > 1:
                 raise RuntimeError("data-parallel sds_step needs flat_grad = flat_grad_view(net_style.parameters())")
-        elif work_hi is not None:
-            for lo, hi in ((0, hi_range[0]), (hi_range[1], flat_grad.numel())):      # the coarser levels (and whatever precedes the table) | the MLP gradients
-                if hi > lo:
-                    torch.distributed.all_reduce(flat_grad[lo:hi], op=torch.distributed.ReduceOp.SUM, group=process_group)
-            work_hi.wait()                                                           # the current stream waits for the early collective
-            if world > 1:
-                flat_grad.div_(world if grad_divisor is None else int(grad_divisor))
-            mark("grad_allreduce")
         else:
-            torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
-            if world > 1:
-                flat_grad.div_(world if grad_divisor is None else int(grad_divisor))
+            flag = None
+            if nan_flags:
+                flag = nan_flags[0] if len(nan_flags) == 1 else torch.stack([t.detach().reshape(()) for t in nan_flags]).sum()
+            guard = reduce_gradients(flat_grad, process_group, grad_divisor, nan_flag=flag, early=(work_hi, hi_range) if work_hi is not None else None)
             mark("grad_allreduce")
-    # (D) -- a NaN recorded by this step's renders raises here, before Adam's state and the weights are touched
-    _check_finite(net_style)
+    # (D) -- a NaN recorded by this step's renders ON ANY RANK raises here on EVERY rank, before Adam's state and the weights are touched
+    _check_finite(net_style, guard)
     optimizer.step()
     mark("optimizer")
     mean = lambda v: v[0].reshape(()) if len(v) == 1 else torch.stack([t.reshape(()) for t in v]).mean()      # (one patch: no reduction kernels)
@@ -404,16 +425,92 @@ def sds_idle_step(net_style, optimizer, flat_grad, n_active, process_group=None)
     if flat_grad is None:
         raise RuntimeError("data-parallel sds_idle_step needs flat_grad = flat_grad_view(net_style.parameters())")
     flat_grad.zero_()
-    torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=process_group)
-    flat_grad.div_(max(1, int(n_active)))
-    _check_finite(net_style)
+    guard = reduce_gradients(flat_grad, process_group, max(1, int(n_active)))
+    _check_finite(net_style, guard)
     optimizer.step()
     return {"eikonal": torch.zeros(()), "opacity": torch.zeros(()), "idle": True}
 
 
-def _check_finite(net):
+def _avg_in_collective(process_group):
+    """RCCL averages inside the collective (ncclAvg: no separate pass over the 49 MB); gloo -- the CPU tests' backend -- has no AVG"""
+    try:
+        return str(torch.distributed.get_backend(process_group)).lower() == "nccl"
+    except Exception:
+        return False
+
+
+class _Guard:
+    """the guard word of one step's gradient collective, on its way to the host: finite() waits for it (4 bytes behind an event)"""
+
+    def __init__(self, word):
+        self.host = torch.zeros(1, dtype=torch.float32)
+        if word.is_cuda:
+            self.host = self.host.pin_memory()
+            self.host.copy_(word.detach().reshape(1), non_blocking=True)
+            self.event = torch.cuda.Event(); self.event.record()
+        else:
+            self.host.copy_(word.detach().reshape(1)); self.event = None
+
+    def finite(self):
+        if self.event is not None:
+            self.event.synchronize()
+        import math
+        return math.isfinite(float(self.host[0]))
+
+
+def reduce_gradients(flat_grad, process_group=None, divisor=None, nan_flag=None, early=None):
+    """The ONE collective of a data-parallel step: all-reduce of the flat fp32 gradient, averaged over `divisor` contributing ranks
+    (default: the world size; fewer in the last round of an epoch whose view count is not a multiple of the world size).
+
+      * the average is taken INSIDE the collective on RCCL (ReduceOp.AVG; a short round rescales by world / divisor afterwards, once per epoch at most);
+        backends without AVG (gloo) sum and scale in one pass afterwards.  World size 1: no scaling at all.
+      * a buffer made by flat_grad_view carries a GUARD WORD behind the gradients: this rank's "a training render produced NaN / Inf" value (nan_flag: a
+        device scalar that is non-finite in that case -- the renders' gradient_error --, or None = 0) rides in the same collective, so every rank
+        sees the same verdict and either all of them step or all of them raise (a per-rank flag leaves the healthy ranks stepping on a
+        poisoned gradient and then hanging in the next collective).  Returns a _Guard (or None without a guard word).
+      * early = (work, (lo, hi)): the slice [lo, hi) is already in flight on a side stream (sds_step's overlap option); the rest goes now."""
+    dist = torch.distributed
+    world = dist.get_world_size(process_group)
+    d = world if divisor is None else int(divisor)
+    n = flat_grad.numel()
+    buf = getattr(flat_grad, "ac_guard", None)
+    if buf is not None and (buf.data_ptr() != flat_grad.data_ptr() or buf.numel() != n + 1):
+        buf = None
+    if buf is not None:
+        if nan_flag is None:
+            buf[n:].zero_()
+        else:
+            buf[n:].copy_(nan_flag.detach().reshape(1).to(device=buf.device, dtype=buf.dtype))
+    else:
+        buf = flat_grad
+    avg = _avg_in_collective(process_group) and world > 1
+    op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    if early is None:
+        dist.all_reduce(buf, op=op, group=process_group)
+    else:
+        work, (lo, hi) = early
+        for a, b in ((0, lo), (hi, buf.numel())):                                   # the coarser levels (and whatever precedes the table) | the MLP gradients + guard
+            if b > a:
+                dist.all_reduce(buf[a:b], op=op, group=process_group)
+        work.wait()                                                                  # the current stream waits for the early collective
+    if world > 1:
+        if avg and d != world:
+            flat_grad.mul_(float(world) / float(d))
+        elif not avg and d != 1:
+            flat_grad.div_(d)
+    return _Guard(buf[n:]) if buf.numel() == n + 1 else None
+
+
+def _check_finite(net, guard=None):
     """the reference asserts on a NaN gradient_error before its backward (instant_nsr.py:274); the fused path records a device flag instead, and it is
-    resolved HERE -- before the optimizer step consumes the gradients -- at the cost of one 4-byte event wait"""
+    resolved HERE -- before the optimizer step consumes the gradients -- at the cost of one 4-byte event wait.  Under a process group the verdict is the
+    guard word of the gradient collective (reduce_gradients): the same on every rank."""
+    if guard is not None and not guard.finite():
+        pend = getattr(net, "__dict__", {}).get("_nan_pending")
+        if pend:
+            pend.clear()                                     # (this step's local flags are resolved by the collective verdict)
+        raise FloatingPointError("NaN / Inf in the finite-difference normals of a training render on at least one rank (reference: instant_nsr.py:274); "
+                                 "no rank has stepped")
     chk = getattr(net, "check_finite", None)
     if chk is not None:
         chk()

@@ -159,8 +159,6 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
     # that one view actually touches (outside the timed region)
     opt.zero_grad(set_to_none=False)
     sds_step(net, net_gt, ro, rd, (64, 64), _NoStep(opt), guidance, batch_size=4096, flat_grad=flat)
-    if hasattr(opt, "grads_cleared"):
-        opt.grads_cleared = False                      # (the stand-in stepped nothing: the gradients of this extra step are still in the buffer)
     emb = net.encoder.embeddings.grad
     nz_table = float((emb != 0).any(dim=-1).float().mean().item()) if emb is not None else None
     nz_flat = float((flat != 0).float().mean().item())

@@ -42,7 +42,8 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 5 (round 4: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
+int ac_version(void);                /* ABI version, currently 6 (round 5: ac_render_rays_occupancy's max_steps, ac_field_sdf_grid, ac_marching_cubes*,
+                                      * ac_density_grid_update, the SH colour input of ac_field; round 4 = 5: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
                                       * ac_field_samples, ac_render_rays_occupancy, the measurement / liveness accessors, the *_typed encoder entries) */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
 
@@ -360,10 +361,15 @@ int ac_field_samples(const ac_field *field, const float *xyzs, const float *dirs
  * ac_composite_rays: T = 1 - weights_sum, a ray stops at T < 1e-2 or at `far`) -- what the reference-shaped loop compact_rays / march_rays / field /
  * composite_rays computes in rounds with one host read-back each, bit for bit, without the rounds.  near / far = near_far_from_bound(type = 'cube')
  * (models/instant_nsr.py:58-77).  Outputs are the accumulators as composite_rays leaves them: weights_sum [N], depth [N] (sum of w * t: the caller normalises,
- * like run_cuda's last lines), image [N,3] (no background), normal_map [N,3]; n_samples (optional, device, [1]): samples evaluated, accumulated. */
+ * like run_cuda's last lines), image [N,3] (no background), normal_map [N,3]; n_samples (optional, device, [1]): samples evaluated, accumulated.
+ * max_steps (ABI 6): a ray stops after that many samples (0 = only at `far` / T < 1e-2).  The loop of rounds stops at the first round that brings its
+ * step count to >= max_steps -- after max_steps .. max_steps + 7 samples per ray, depending on how many rays were alive in its last rounds; this entry
+ * stops at exactly max_steps.  The two forms are bit-identical for every ray that needs fewer than max_steps samples (all of them at the default 1024
+ * unless a ray crosses > 1024 occupied cells: ~1600 steps of dt_min fit the diagonal of a bound-1.6 cube). */
 int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
                              float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
-                             float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, ac_stream_t stream);
+                             float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
+                             ac_stream_t stream);
 
 /* ---- colour MLP of the render core (training path): forward_color (models/instant_nsr.py:644-663, use_viewdirs = False)
  * rgb = sigmoid(Wc3 relu(Wc2 relu(Wc1 [x, normal, feat]))) with feat = sdf16[:, 1:16].

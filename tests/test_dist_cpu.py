@@ -209,3 +209,63 @@ def test_reconstruct_epochs_uneven_batches_two_ranks_gloo():
     assert [l for _, _, l in seen1][2] == 0.0 and [l for _, _, l in seen0][2] > 0.0          # round 3: rank 1 idle, rank 0 holds the fifth batch
     for a, b in zip(p0, p1):
         assert np.array_equal(a, b)
+
+
+class _NaNField(TinyField):
+    """a field whose training render reports a non-finite gradient_error (the reference's `assert (gradient == gradient).all()`, instant_nsr.py:274)"""
+    poison = False
+
+    def render(self, *a, **kw):
+        out = super().render(*a, **kw)
+        if self.poison and torch.is_grad_enabled():
+            out["gradient_error"] = out["gradient_error"] * float("nan")
+        return out
+
+
+def _nan_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from avatarcraft_amd.stylize import sds_step, flat_grad_view
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net, net_gt = _NaNField().train(), TinyField().eval()
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    flat = flat_grad_view(net.parameters())
+    assert flat.ac_guard.numel() == flat.numel() + 1 and flat.ac_guard.data_ptr() == flat.data_ptr()
+    g = torch.Generator().manual_seed(rank)
+    ro = torch.randn(64, 3, generator=g); rd = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+    guidance = lambda img: torch.zeros_like(img)
+    sds_step(net, net_gt, ro, rd, (8, 8), opt, guidance, batch_size=64, flat_grad=flat)          # a healthy step: both ranks step
+    before = [p.detach().clone() for p in net.parameters()]
+    net.poison = rank == 1                                                                       # the NaN happens on rank 1 ONLY
+    raised = False
+    try:
+        sds_step(net, net_gt, ro, rd, (8, 8), opt, guidance, batch_size=64, flat_grad=flat)
+    except FloatingPointError:
+        raised = True
+    stepped = any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+    # ... and the group is still usable: no rank is left behind in a collective
+    net.poison = False
+    sds_step(net, net_gt, ro, rd, (8, 8), opt, guidance, batch_size=64, flat_grad=flat)
+    q.put((rank, raised, stepped, [p.detach().numpy().copy() for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_nan_on_one_rank_stops_every_rank_gloo():
+    """the NaN flag of a training render is per rank; the verdict must be collective (the guard word of the gradient all-reduce) --
+    every rank raises before its optimizer step, none steps, and the replicas stay identical afterwards"""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, raised0, stepped0, p0), (_, raised1, stepped1, p1) = res
+    assert raised0 and raised1 and not stepped0 and not stepped1
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b) and np.isfinite(a).all()

@@ -165,6 +165,18 @@ def test_run_cuda_inference_loop_vs_oracle_chain(env):
         raymarching.composite_rays(n_, 1024, alive, rt, fs["alpha"], fs["rgb"], fs["normal"], deltas, ws, dp, im, nm)
         raw = nsr_ops.render_rays_occupancy(net._field(), o_, d_, net.density_grid, net.mean_density, 1.6, 0.005, net.forward_variance(), 0.7)
         assert torch.equal(raw["weights_sum"], ws) and torch.equal(raw["depth"], dp) and torch.equal(raw["image"], im) and torch.equal(raw["normal_map"], nm)
+        # max_steps (ABI 6): the one launch stops a ray after exactly that many samples == one round of the operators with n_step = max_steps
+        S = 6
+        alive = torch.arange(n_, dtype=torch.int32, device=DEV); rt = near.clone()
+        xyzs, dirs, deltas = raymarching.march_rays(n_, S, alive, rt, o_, d_, 1.6, net.density_grid, net.mean_density, near, far, -1, False)
+        fs = nsr_ops.field_samples(net._field(), xyzs, dirs, deltas, 1.6, 0.005, net.forward_variance(), 0.7)
+        ws, dp = torch.zeros(n_, device=DEV), torch.zeros(n_, device=DEV)
+        im, nm = torch.zeros(n_, 3, device=DEV), torch.zeros(n_, 3, device=DEV)
+        raymarching.composite_rays(n_, S, alive, rt, fs["alpha"], fs["rgb"], fs["normal"], deltas, ws, dp, im, nm)
+        cap = nsr_ops.render_rays_occupancy(net._field(), o_, d_, net.density_grid, net.mean_density, 1.6, 0.005, net.forward_variance(), 0.7, max_steps=S,
+                                            count_samples=True)
+        assert torch.equal(cap["weights_sum"], ws) and torch.equal(cap["depth"], dp) and torch.equal(cap["image"], im) and torch.equal(cap["normal_map"], nm)
+        assert 0 < int(cap["n_samples"].item()) <= n_ * S and not torch.equal(cap["weights_sum"], raw["weights_sum"])
     cnt = nsr_ops.render_rays_occupancy(net._field(), t(ro), t(rd), net.density_grid, net.mean_density, 1.6, 0.005, env["inv_s"], 1.0, count_samples=True)["n_samples"]
     assert 0 < int(cnt.item()) <= ro.shape[0] * 1024
 

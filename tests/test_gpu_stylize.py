@@ -341,7 +341,7 @@ def test_sds_steps_with_the_one_launch_adam():
     ro, rd = make_rays(64, 64, dist=1.8, f=50.0)
     ro, rd = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
 
-    def run(kind, steps):
+    def run(kind, steps, stray=False):
         net, _ = golden_net(train=True)
         net_gt, _ = golden_net(train=False)
         opt = torch.optim.Adam(net.parameters(), lr=5e-3) if kind == "torch" else Adam(net.parameters(), lr=5e-3, zero_grad_in_step=kind == "in_step")
@@ -350,8 +350,14 @@ def test_sds_steps_with_the_one_launch_adam():
         torch.manual_seed(5)
         for _ in range(steps):
             sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
+            if stray:
+                # something accumulates into the gradients between two steps (a manual backward, a wrapped optimizer, ...): `grads_cleared` is a checked
+                # claim (version counters), so the next sds_step clears the buffer itself instead of adding this to its gradient
+                assert opt.grads_cleared
+                net.sdf_net[0].bias.grad.add_(1.0)
+                assert not opt.grads_cleared
         net.check_finite()
-        if kind == "in_step":
+        if kind == "in_step" and not stray:
             assert opt.grads_cleared and float(flat.abs().max()) == 0.0
         return {k: v.detach().clone() for k, v in net.named_parameters()}
 
@@ -361,3 +367,6 @@ def test_sds_steps_with_the_one_launch_adam():
     a, b = run("in_step", 3), run("explicit", 3)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+    c = run("in_step", 3, stray=True)
+    for k in a:
+        assert torch.equal(a[k], c[k]), k

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ac_version() == 5
+    assert lib.ac_version() == 6
     # host helper needs no GPU: level table == oracle's == SURVEY Appendix B
     scale = (ctypes.c_float * 16)(); res = (ctypes.c_uint32 * 16)()
     S = float(np.float32(np.log2(1.381912879967776)))
@@ -361,4 +361,9 @@ def test_dtype_codes_and_adam_argument_checks():
     assert float(p.abs().max()) == 0.0 and not opt.grads_cleared
     opt.zero_grad()
     assert opt.grads_cleared and p.grad is not None and float(p.grad.abs().max()) == 0.0      # cleared in place, never dropped
+    p.grad.add_(1.0)                                         # anything that writes a gradient afterwards withdraws the claim (version counters, not a sticky flag)
+    assert not opt.grads_cleared
+    opt.zero_grad(); assert opt.grads_cleared
+    (p * 2.0).sum().backward()
+    assert not opt.grads_cleared and float(p.grad.min()) == 2.0
     assert set(opt.state_dict()["param_groups"][0].keys()) == set(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3).state_dict()["param_groups"][0].keys())
