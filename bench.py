@@ -538,7 +538,6 @@ def self_launch(n, argv, script=None):
     port), rank 0's stdout is this process's stdout (its JSON line stays the last thing written there), the other ranks' stdout goes to stderr.
     Returns the exit code: 0 only if every rank exited 0; a rank that dies takes the others down with it (exact PIDs, after a grace period) instead of
     leaving them in a collective forever."""
-    import subprocess
     backend = os.environ.get("AC_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if ndev == 0:
@@ -548,12 +547,36 @@ def self_launch(n, argv, script=None):
         print(f"bench.py --gpus {n}: only {ndev} GPU(s) visible; RCCL needs one device per rank (AC_DIST_BACKEND=gloo runs the N > 1 code path with "
               f"ranks sharing a device -- a plumbing check, not a measurement)", file=sys.stderr)
         return 2
+    # HSA_ENABLE_IPC_MODE_LEGACY: this pool's host driver supports dmabuf IPC only -- the image exports HSA_ENABLE_IPC_MODE_LEGACY=0 for that reason and
+    # its documentation says RCCL / cross-process device memory fails with "hipIpcGetMemHandle: invalid argument" without it (the task environment's own
+    # statement; no multi-GPU box was available to this build to observe either outcome).  So: an inherited value is passed through untouched; with none
+    # inherited the ranks get 0, and if that job dies on an RCCL job (any rank non-zero) it is started ONCE more with the variable unset -- the line
+    # records which attempt produced it (`hsa_ipc_mode_legacy`).  AC_BENCH_IPC_RETRY=0 switches the second attempt off.
+    inherited = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    attempts = [(inherited, "inherited from the environment")] if inherited is not None else [("0", "launcher default (dmabuf IPC, as the image exports it)")]
+    if inherited is None and backend == "nccl" and os.environ.get("AC_BENCH_IPC_RETRY", "1") != "0":
+        attempts.append((None, "unset (second attempt: the first, with 0, failed)"))
+    rc = 1
+    for k, (ipc, why) in enumerate(attempts):
+        rc = _launch_once(n, argv, script, ipc, f"attempt {k + 1}: {why}")
+        if rc == 0:
+            break
+        if k + 1 < len(attempts):
+            print(f"bench.py: the {n}-rank job failed (exit {rc}) with HSA_ENABLE_IPC_MODE_LEGACY={ipc}; one more attempt with it unset", file=sys.stderr)
+    return rc
+
+
+def _launch_once(n, argv, script, ipc, ipc_note):
+    import subprocess
     port = _free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   AC_BENCH_LAUNCHER="self")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+                   AC_BENCH_LAUNCHER="self", AC_BENCH_IPC_NOTE=ipc_note)
+        if ipc is None:
+            env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+        else:
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = ipc
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
     rc, dead_since = 0, None
@@ -571,6 +594,44 @@ def self_launch(n, argv, script=None):
             print(f"bench.py: rank {r} exited with {p.returncode}", file=sys.stderr)
             rc = rc or (p.returncode if p.returncode and p.returncode > 0 else 1)
     return rc
+
+
+XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0          # per GPU: 7 point-to-point xGMI links x ~153 GB/s (the task's figure for this node type)
+
+
+def measure_solo(dev, p, field, table, ro, rd, rank, a):
+    """this rank alone, no process group: rays/s of the headline launches and ms per SDS step (see main)"""
+    from avatarcraft_amd import nsr_ops
+    ro_t, rd_t = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    nb = (H * W) // RAYS_PER_BATCH
+    outs = [dict() for _ in range(nb)]
+    inv_s = float(p["inv_s"])
+
+    def step(k):
+        b = k % nb
+        sl = slice(b * RAYS_PER_BATCH, (b + 1) * RAYS_PER_BATCH)
+        nsr_ops.render_rays(field, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=outs[b], precision=a.precision)
+    for k in range(a.warmup):
+        step(k)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            step(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    out = {"rays_per_s": a.steps * RAYS_PER_BATCH / best, "ms_per_step": best / a.steps * 1e3}
+    if a.sds_steps > 0:
+        try:
+            sds, nets = time_sds_step(dev, p, table, rank, 1, None, a.sds_steps)
+            del nets
+            out["sds_ms_per_step"] = sds["ms_per_step"]
+        except Exception as e:                 # noqa: BLE001
+            out["sds_error"] = f"{type(e).__name__}: {e}"
+    torch.cuda.synchronize()
+    return out
 
 
 def main():
@@ -613,6 +674,16 @@ def main():
     dev = torch.device("cuda", dev_index)
     dist = None
     rccl_ranks = None
+    from avatarcraft_amd import nsr_ops
+    p, field, table, ro, rd = make_inputs(dev, rank)
+    if not a.no_prepared_field:
+        field.prepare()                 # the weights in LDS order, once (like NeRFRenderer does per parameter version)
+    solo = None
+    if world > 1:
+        # BEFORE the process group exists: what this very GPU does on its own in this very job (the same launches as the timed region below, the same SDS
+        # steps without a collective) -- the N = 1 reference of an N > 1 line measured on the same box, clocks and build (`same_job_solo`; the driver
+        # computes the scaling efficiency it reports from its own separate N = 1 run)
+        solo = measure_solo(dev, p, field, table, ro, rd, rank, a)
     if world > 1 or os.environ.get("AC_BENCH_FORCE_DIST") == "1":      # (forced at world size 1: the RCCL code path of an N > 1 run on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -627,10 +698,6 @@ def main():
         rccl_ranks = int(round(float(one.item())))
         assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
-    from avatarcraft_amd import nsr_ops
-    p, field, table, ro, rd = make_inputs(dev, rank)
-    if not a.no_prepared_field:
-        field.prepare()                 # the weights in LDS order, once (like NeRFRenderer does per parameter version)
     ro_t, rd_t = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
     inv_s = float(p["inv_s"])
     nb = (H * W) // RAYS_PER_BATCH
@@ -781,8 +848,25 @@ def main():
                               (f"available ({why_sd}); pass --real-sd to time it" if ok_sd else f"absent: {why_sd}"))
         except Exception as e:                 # noqa: BLE001
             res["real_sd"] = f"error: {type(e).__name__}: {e}"
+        res["hsa_ipc_mode_legacy"] = {"value": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                                      "set_by": os.environ.get("AC_BENCH_IPC_NOTE", "the environment of this process (not bench.py's launcher)")}
+        if solo is not None:
+            # informational: rank 0's own solo figures from the same job (the driver derives its efficiency from its own N = 1 run, not from this)
+            res["same_job_solo"] = dict(solo, value_over_n_times_solo=res["value"] / (world * solo["rays_per_s"]),
+                                        note="rank 0 alone on its GPU before the process group was formed: same launches, same build, same box")
         if world > 1 and sds is not None and "error" not in sds:
-            res["sds_step"]["note"] = "N > 1: one view per rank, one all-reduce (RCCL, sum then / world) of the flat 49 MB gradient per step"
+            res["sds_step"]["note"] = ("N > 1: one view per rank, ONE all-reduce of the flat 49 MB gradient (+ 1 guard word) per step, averaged inside the "
+                                       "collective on RCCL (ReduceOp.AVG)")
+            ar_ms = sds.get("grad_allreduce_ms") or 0.0
+            if ar_ms > 0:
+                nbytes = sds["grad_allreduce_mb"] * 1e6
+                busbw = 2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9
+                res["sds_step"]["allreduce_busbw_gbs"] = busbw           # the ring-equivalent bus bandwidth (nccl-tests' definition)
+                res["sds_step"]["allreduce_busbw_peak_gbs"] = XGMI_LINKS * XGMI_LINK_GBS
+                res["sds_step"]["allreduce_busbw_frac"] = busbw / (XGMI_LINKS * XGMI_LINK_GBS)
+            if solo is not None and solo.get("sds_ms_per_step"):
+                res["sds_step"]["same_job_solo_ms_per_step"] = solo["sds_ms_per_step"]
+                res["sds_step"]["solo_over_n_rank_step_time"] = solo["sds_ms_per_step"] / sds["ms_per_step"]     # 1.0 = the all-reduce is free
         line = json.dumps(res)
     else:
         line = None

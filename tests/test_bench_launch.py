@@ -100,3 +100,8 @@ def test_bench_gpus_2_self_launched_over_gloo_on_one_gpu():
     assert "error" not in sds, sds
     assert sds["grad_allreduce_mb"] == pytest.approx(48.99, abs=0.02) and sds["grad_allreduce_ms"] > 0
     assert "posed_frame" not in rec and "cpu_baseline" not in rec
+    # round 5: the N > 1 line says how the ranks were started, what one rank does alone in the same job, and the collective's bus bandwidth
+    assert rec["hsa_ipc_mode_legacy"]["value"] == "0" and "attempt 1" in rec["hsa_ipc_mode_legacy"]["set_by"]
+    solo = rec["same_job_solo"]
+    assert solo["rays_per_s"] > 0 and 0 < solo["value_over_n_times_solo"] < 1.5 and solo["sds_ms_per_step"] > 0
+    assert sds["allreduce_busbw_gbs"] > 0 and sds["allreduce_busbw_peak_gbs"] == pytest.approx(7 * 153.0) and sds["solo_over_n_rank_step_time"] > 0
