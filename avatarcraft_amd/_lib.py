@@ -130,6 +130,12 @@ _SIGS = {
     "ac_render_rays_warped": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_warp_mesh), vp, C.c_size_t,
                                C.POINTER(ac_render_out), vp], C.c_int),
     "ac_warp_samples": ([vp, vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp, vp, vp, vp, vp], C.c_int),
+    "ac_field_sdf_grid": ([C.POINTER(ac_field), vp, vp, vp, u32, u32, u32, f32, C.c_int, vp, vp], C.c_int),
+    "ac_marching_cubes_scratch": ([u32, u32, u32], C.c_size_t),
+    "ac_marching_cubes_count": ([vp, u32, u32, u32, f32, vp, C.c_size_t, vp, vp], C.c_int),
+    "ac_marching_cubes_emit": ([vp, u32, u32, u32, f32, vp, C.c_size_t, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, u32, vp, u32, vp], C.c_int),
+    "ac_density_grid_update_scratch": ([u32], C.c_size_t),
+    "ac_density_grid_update": ([C.POINTER(ac_field), vp, u32, f32, f32, f32, vp, vp, vp, C.c_size_t, vp], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
 FIELD_PREPARED_BYTES = 98304          # AC_FIELD_PREPARED_BYTES of include/avatarcraft_hip.h

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libavatarcraft_hip.so")
-SOURCES = ["ac_capi.hip", "hashgrid.hip", "hash_stencil.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "sdf_train.hip", "warp.hip", "step_glue.hip"]
+SOURCES = ["ac_capi.hip", "hashgrid.hip", "hash_stencil.hip", "shencoder.hip", "raymarching.hip", "render_fused.hip", "sdf_train.hip", "warp.hip", "step_glue.hip", "geometry.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wno-unused-result",
          # no compiler-formed packed-fp32 (v_pk_*_f32) code: the one run-to-run non-determinism ever observed in the renderer (round 2: the "face-value"

@@ -68,7 +68,7 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ fused field handle
     # The prepared ac_field views (ctypes structs holding raw device pointers) and the outputs of the last training render are caches, not state:
     # they are left out of pickling / copy.deepcopy / torch.save(net) and rebuilt on the next render.
-    _CACHE_ATTRS = ("_pair_bg_cache", "_field_cache", "_field_sdf_cache", "_last_train", "_offsets_cache")
+    _CACHE_ATTRS = ("_pair_bg_cache", "_field_cache", "_field_sdf_cache", "_last_train", "_offsets_cache", "_axis_cache")
     # not picklable (events, pinned words) but NOT a cache either: pending NaN flags survive invalidate_caches() and are resolved by check_finite()
     _UNPICKLED_ATTRS = _CACHE_ATTRS + ("_nan_pending",)
 
@@ -753,9 +753,33 @@ class NeRFNetwork(NeRFRenderer):
             outs.append(0.5 * (pos - neg) / epsilon)
         return torch.cat(outs, dim=-1)
 
+    def _grid_axis(self, bound, resolution):
+        """torch.linspace(-bound, bound, resolution) as the reference forms it (on the host, fp32: extract_fields :730-732, update_extra_state :312-314), on the
+        device.  Cached: the axis of the density grid is asked for once per epoch, the mesh export's once per export."""
+        dev = self.encoder.embeddings.device
+        key = (float(bound), int(resolution), str(dev))
+        c = self.__dict__.setdefault("_axis_cache", {})
+        if key not in c:
+            if len(c) > 8:
+                c.clear()
+            c[key] = torch.linspace(-bound, bound, resolution).to(dev)
+        return c[key]
+
+    def extract_fields_device(self, bound: float, resolution: int, negate: bool = False):
+        """the SDF (negate: -SDF) on the resolution^3 grid over [-bound, bound]^3 as a device tensor [res, res, res]: ONE launch (ac_field_sdf_grid) -- the
+        kernel forms the grid points from the axis table; no meshgrid / cat tensors, no 256^3 blocks, no host round trip"""
+        if not (self.encoder.embeddings.is_cuda and self._sdf_supported()):
+            raise RuntimeError("extract_fields_device: needs the default SDF side of NeRFNetwork on the GPU")
+        ax = self._grid_axis(bound, resolution)
+        with torch.no_grad():
+            f = self._field() if self._fused_supported() else self._field_sdf_only()
+            return nsr_ops.field_sdf_grid(f, ax, ax, ax, bound, negate=negate)
+
     def extract_fields(self, bound: float, resolution: int):
-        """the SDF on a resolution^3 grid over [-bound, bound]^3 (extract_fields, reference :728-745): blocks of 256^3 points through the
-        fused field kernel (ac_field_sdf), assembled on the device; returns a float32 numpy array [res, res, res] like the reference"""
+        """the SDF on a resolution^3 grid over [-bound, bound]^3 (extract_fields, reference :728-745); returns a float32 numpy array
+        [res, res, res] like the reference.  On the GPU: extract_fields_device + one copy to the host."""
+        if self.encoder.embeddings.is_cuda and self._sdf_supported():
+            return self.extract_fields_device(bound, resolution).cpu().numpy()
         N = 256
         dev = self.encoder.embeddings.device
         xs = torch.linspace(-bound, bound, resolution).split(N)
@@ -769,18 +793,34 @@ class NeRFNetwork(NeRFRenderer):
                         u[xi * N: xi * N + len(x), yi * N: yi * N + len(y), zi * N: zi * N + len(z)] = self.density(pts, bound).reshape(len(x), len(y), len(z))
         return u.cpu().numpy()
 
-    def extract_geometry(self, bound: float, resolution: int, threshold: int = 0.0, device=None):
-        """iso-surface of the SDF (reference :706-764): vertices [V,3] in world units, triangles [F,3].  The reference runs PyMCubes'
-        marching cubes on -sdf; PyMCubes is used when it is installed, otherwise the built-in marching tetrahedra (geometry.py) on the
-        device: the same surface (every vertex on an sdf = threshold crossing of a grid edge), a different triangulation."""
+    def extract_geometry(self, bound: float, resolution: int, threshold: int = 0.0, device=None, mesher=None, return_torch=False):
+        """iso-surface of the SDF (reference :706-764; its one call is extract_geometry(NSR_BOUND, 512), stylize.py:267): vertices [V,3] float64 in world
+        units, triangles [F,3].  The reference runs PyMCubes' marching_cubes on u = -sdf (third party, not in this image).
+        mesher: "native" (default on the GPU) = ac_field_sdf_grid + ac_marching_cubes on the device: the volume never leaves it, one shared vertex per
+                sign-changing grid edge at the linear zero crossing, the 256-case table of the definition, triangles oriented out of the body; only the
+                finished mesh is copied to the host (return_torch=True: not even that -- device tensors);
+                "mcubes" = the reference's own call when PyMCubes is installed; "tetra" = the marching-tetrahedra mesher of round 3 (geometry.py:
+                the same vertex set, a different triangulation -- kept as the cross-check of the tests)."""
+        native_ok = self.encoder.embeddings.is_cuda and self._sdf_supported()
+        if mesher is None:
+            mesher = "native" if native_ok else "tetra"
+        if mesher == "native":
+            if not native_ok:
+                raise RuntimeError("extract_geometry(mesher='native') needs the default SDF side of NeRFNetwork on the GPU")
+            u = self.extract_fields_device(bound, resolution, negate=True)
+            bmin, bmax = np.float32(-bound), np.float32(bound)                       # (the reference's bounds are float32 tensors, :712)
+            v, t = nsr_ops.marching_cubes(u, float(threshold), den=resolution - 1.0, span=[float(bmax - bmin)] * 3, lo=[float(bmin)] * 3)
+            return (v, t) if return_torch else (v.cpu().numpy(), t.cpu().numpy())
         u = -1.0 * self.extract_fields(bound, resolution)
-        try:
+        if mesher == "mcubes":
             import mcubes
             vertices, triangles = mcubes.marching_cubes(u, threshold)
-        except ImportError:
+        elif mesher == "tetra":
             from .geometry import marching_tetrahedra
             v, t = marching_tetrahedra(torch.from_numpy(u).to(self.encoder.embeddings.device), float(threshold))
             vertices, triangles = v.cpu().numpy().astype(np.float64), t.cpu().numpy()
+        else:
+            raise ValueError(f"extract_geometry: unknown mesher {mesher!r}")
         vertices = vertices / (resolution - 1.0) * (2 * bound) - bound
         return vertices, triangles
 
@@ -788,33 +828,49 @@ class NeRFNetwork(NeRFRenderer):
     def update_extra_state(self, bound, decay=0.95):
         """density grid for raymarching.march_rays_train / march_rays (only with cuda_ray=True, like the reference): the SDF on the 129^3
         grid -> a logistic density with inv_s = 512 (inv_s * sigmoid'(-|...|) written in two overflow-free branches), dilated by a 2^3 max
-        pool, merged into the running grid with max(grid * decay, new); mean density and the step-counter bookkeeping."""
+        pool, merged into the running grid with max(grid * decay, new); mean density and the step-counter bookkeeping.
+        On the GPU the grid update is ONE launch (ac_density_grid_update, csrc/geometry.hip; the grid is updated in place); the torch chain below
+        is the formulation of the reference, kept for the CPU and as the cross-check of the tests (fused_density_grid = False)."""
         if not self.cuda_ray:
             return
         resolution = self.density_grid.shape[0]
         dev = self.density_grid.device
-        axes = torch.linspace(-bound, bound, resolution).split(128)
-        tmp_grid = torch.zeros_like(self.density_grid)
         inv_s = 512.0
-        with torch.no_grad():
-            for xi, xs in enumerate(axes):
-                for yi, ys in enumerate(axes):
-                    for zi, zs in enumerate(axes):
-                        lx, ly, lz = len(xs), len(ys), len(zs)
-                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                        pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).to(dev)
-                        sdf = self.density(pts, bound).detach().float().reshape(-1)
-                        mask = sdf > 0
-                        density = torch.zeros_like(sdf)
-                        density[mask] = inv_s * torch.exp(-inv_s * sdf[mask]) / (1 + torch.exp(-inv_s * sdf[mask]))
-                        density[~mask] = inv_s * torch.exp(inv_s * sdf[~mask]) / (1 + torch.exp(inv_s * sdf[~mask]))
-                        tmp_grid[xi * 128: xi * 128 + lx, yi * 128: yi * 128 + ly, zi * 128: zi * 128 + lz] = density.reshape(lx, ly, lz)
-            tmp_grid = F.pad(tmp_grid, (0, 1, 0, 1, 0, 1))
-            tmp_grid = F.max_pool3d(tmp_grid.unsqueeze(0).unsqueeze(0), kernel_size=2, stride=1).squeeze(0).squeeze(0)
-            self.density_grid = torch.maximum(self.density_grid * decay, tmp_grid)
-        self.mean_density = torch.mean(self.density_grid).item()
-        self.iter_density += 1
+        if self.fused_density_grid and self.density_grid.is_cuda and self._sdf_supported():
+            with torch.no_grad():
+                f = self._field() if self._fused_supported() else self._field_sdf_only()
+                if not self.density_grid.is_contiguous():
+                    self.density_grid = self.density_grid.contiguous()
+                mean = nsr_ops.density_grid_update(f, self._grid_axis(bound, resolution), self.density_grid, bound, inv_s, decay)
+        else:
+            axes = torch.linspace(-bound, bound, resolution).split(128)
+            tmp_grid = torch.zeros_like(self.density_grid)
+            with torch.no_grad():
+                for xi, xs in enumerate(axes):
+                    for yi, ys in enumerate(axes):
+                        for zi, zs in enumerate(axes):
+                            lx, ly, lz = len(xs), len(ys), len(zs)
+                            xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                            pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).to(dev)
+                            sdf = self.density(pts, bound).detach().float().reshape(-1)
+                            mask = sdf > 0
+                            density = torch.zeros_like(sdf)
+                            density[mask] = inv_s * torch.exp(-inv_s * sdf[mask]) / (1 + torch.exp(-inv_s * sdf[mask]))
+                            density[~mask] = inv_s * torch.exp(inv_s * sdf[~mask]) / (1 + torch.exp(inv_s * sdf[~mask]))
+                            tmp_grid[xi * 128: xi * 128 + lx, yi * 128: yi * 128 + ly, zi * 128: zi * 128 + lz] = density.reshape(lx, ly, lz)
+                tmp_grid = F.pad(tmp_grid, (0, 1, 0, 1, 0, 1))
+                tmp_grid = F.max_pool3d(tmp_grid.unsqueeze(0).unsqueeze(0), kernel_size=2, stride=1).squeeze(0).squeeze(0)
+                self.density_grid = torch.maximum(self.density_grid * decay, tmp_grid)
+            mean = torch.mean(self.density_grid)
+        # the two scalars the marcher takes as launch constants: ONE read-back for both
         total_step = min(64, self.local_step)
         if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+            both = torch.stack([mean.reshape(()).double(), self.step_counter[:total_step, 0].sum().double()]).tolist()
+            self.mean_density = both[0]
+            self.mean_count = int(both[1] / total_step)
+        else:
+            self.mean_density = mean.item()
+        self.iter_density += 1
         self.local_step = 0
+
+    fused_density_grid = True

@@ -745,3 +745,70 @@ def field_color(field, x, n, sdfout):
     L.check(L.lib().ac_field_color(C.byref(field.c), x.data_ptr(), n.data_ptr(), sdfout.data_ptr(), x.shape[0], out.data_ptr(),
                                    L.current_stream(x.device)), "field_color")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- geometry (csrc/geometry.hip)
+def field_sdf_grid(field, axis_x, axis_y, axis_z, bound, negate=False, out=None):
+    """ac_field_sdf_grid: forward_sdf(.)[0] on the grid axis_x x axis_y x axis_z (three 1-D float32 device tensors: the coordinates
+    torch.linspace gives the reference's extract_fields, models/instant_nsr.py:728-745) -> [nx, ny, nz] float32 on the device; negate: -sdf"""
+    ax, ay, az = _chk(axis_x.reshape(-1), "axis_x"), _chk(axis_y.reshape(-1), "axis_y"), _chk(axis_z.reshape(-1), "axis_z")
+    nx, ny, nz = ax.shape[0], ay.shape[0], az.shape[0]
+    if out is None:
+        out = torch.empty((nx, ny, nz), dtype=_F32, device=ax.device)
+    elif tuple(out.shape) != (nx, ny, nz) or out.dtype != _F32 or not out.is_contiguous():
+        raise RuntimeError("field_sdf_grid: out must be a contiguous float32 [nx, ny, nz] tensor")
+    L.check(L.lib().ac_field_sdf_grid(C.byref(field.c), ax.data_ptr(), ay.data_ptr(), az.data_ptr(), nx, ny, nz, float(bound), int(bool(negate)),
+                                      out.data_ptr(), L.current_stream(ax.device)), "field_sdf_grid")
+    return out
+
+
+def marching_cubes(volume, iso=0.0, den=1.0, span=(1.0, 1.0, 1.0), lo=(0.0, 0.0, 0.0)):
+    """ac_marching_cubes_count + _emit on a device volume [nx, ny, nz] (float32): the surface u = iso, corner flagged <=> u <= iso (PyMCubes' convention),
+    one shared vertex per sign-changing grid edge.  -> (vertices [V,3] float64 = index / den * span + lo, triangles [F,3] int32), both on the device.
+    One 8-byte device-to-host read between the two calls (the caller owns the output buffers, so it has to know their size)."""
+    vol = _chk(volume, "volume")
+    if vol.dim() != 3:
+        raise RuntimeError("marching_cubes: volume must be [nx, ny, nz]")
+    nx, ny, nz = vol.shape
+    dev = vol.device
+    need = int(L.lib().ac_marching_cubes_scratch(nx, ny, nz))
+    if need == 0:
+        raise RuntimeError(f"marching_cubes: grid {nx} x {ny} x {nz} unsupported (every side >= 2, fewer than 2^31 points)")
+    scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    st = L.current_stream(dev)
+    L.check(L.lib().ac_marching_cubes_count(vol.data_ptr(), nx, ny, nz, float(iso), scratch.data_ptr(), need, counts.data_ptr(), st), "marching_cubes_count")
+    nv, nt = (int(v) for v in counts.tolist())
+    verts = torch.empty((nv, 3), dtype=torch.float64, device=dev)
+    tris = torch.empty((nt, 3), dtype=torch.int32, device=dev)
+    span_c, lo_c = (C.c_double * 3)(*[float(v) for v in span]), (C.c_double * 3)(*[float(v) for v in lo])
+    if nv or nt:
+        L.check(L.lib().ac_marching_cubes_emit(vol.data_ptr(), nx, ny, nz, float(iso), scratch.data_ptr(), need, float(den), span_c, lo_c,
+                                               L.ptr(verts) if nv else None, nv, L.ptr(tris) if nt else None, nt, st), "marching_cubes_emit")
+    return verts, tris
+
+
+_DG_SCRATCH = {}
+
+
+def density_grid_update(field, axis, grid, bound, inv_s=512.0, decay=0.95):
+    """ac_density_grid_update: the grid update of update_extra_state (models/instant_nsr.py:303-346) in one launch, IN PLACE on grid [H,H,H];
+    axis = torch.linspace(-bound, bound, H) on the device.  -> mean(grid) as a [1] float64 device tensor."""
+    axis = _chk(axis.reshape(-1), "axis"); grid = _chk(grid, "density_grid")
+    H = axis.shape[0]
+    if tuple(grid.shape) != (H, H, H):
+        raise RuntimeError("density_grid_update: grid must be [H, H, H] with H = len(axis)")
+    dev = grid.device
+    need = int(L.lib().ac_density_grid_update_scratch(H))
+    if need == 0:
+        raise RuntimeError(f"density_grid_update: H = {H} unsupported (2 <= H <= 1024)")
+    key = (str(dev), int(L.current_stream(dev) or 0), H)
+    sc = _DG_SCRATCH.get(key)
+    if sc is None:
+        if len(_DG_SCRATCH) > 16:
+            _DG_SCRATCH.clear()
+        sc = _DG_SCRATCH[key] = torch.zeros(need, dtype=torch.uint8, device=dev)        # zeroed once: the launch re-arms its ticket
+    mean = torch.empty(1, dtype=torch.float64, device=dev)
+    L.check(L.lib().ac_density_grid_update(C.byref(field.c), axis.data_ptr(), H, float(bound), float(inv_s), float(decay), grid.data_ptr(), mean.data_ptr(),
+                                           sc.data_ptr(), need, L.current_stream(dev)), "density_grid_update")
+    return mean

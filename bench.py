@@ -360,6 +360,70 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     return res
 
 
+def time_geometry(dev, p, table, reps=3):
+    """SURVEY 8(f) rank 3 at the reference's own sizes: the mesh export -- extract_geometry(NSR_BOUND, 512) (stylize.py:267: 512^3 = 134 M forward_sdf
+    queries + marching cubes) -- and the density-grid update of update_extra_state (129^3 queries -> density -> max pool -> merge -> mean), both on the
+    device (csrc/geometry.hip).  Per-launch times by HIP events on the launch stream; gather-request roofline like the headline's (1024 B per query)."""
+    from avatarcraft_amd import nsr_ops
+    from avatarcraft_amd.render_utils import NSR_BOUND
+    net = make_net(p, table, dev, False, cuda_ray=True)
+    res_ = 512
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    out = {}
+    with torch.no_grad():
+        f = net._field()
+        ax = net._grid_axis(NSR_BOUND, res_)
+        vol = torch.empty((res_,) * 3, dtype=torch.float32, device=dev)
+        nsr_ops.field_sdf_grid(f, ax, ax, ax, NSR_BOUND, negate=True, out=vol)                   # warm-up
+        t_sdf, t_mc = [], []
+        for _ in range(reps):
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            nsr_ops.field_sdf_grid(f, ax, ax, ax, NSR_BOUND, negate=True, out=vol)
+            e1.record()
+            v, t = nsr_ops.marching_cubes(vol, 0.0, den=res_ - 1.0, span=[3.2] * 3, lo=[-1.6] * 3)
+            e2.record(); torch.cuda.synchronize()
+            t_sdf.append(e0.elapsed_time(e1)); t_mc.append(e1.elapsed_time(e2))
+        t0 = time.perf_counter(); vh, th = v.cpu().numpy(), t.cpu().numpy(); t_copy = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter(); verts, tris = net.extract_geometry(NSR_BOUND, res_); t_e2e = (time.perf_counter() - t0) * 1e3
+        sdf_ms, mc_ms = float(np.median(t_sdf)), float(np.median(t_mc))
+        evals = res_ ** 3
+        gb = evals * 1024 / 1e9
+        out["mesh_export_512"] = {
+            "ms": sdf_ms + mc_ms, "sdf_grid_ms": sdf_ms, "marching_cubes_ms": mc_ms, "mesh_to_host_ms": t_copy, "extract_geometry_call_ms": t_e2e,
+            "field_evaluations": evals, "vertices": int(v.shape[0]), "triangles": int(t.shape[0]),
+            "roofline": {"bound": "hbm", "kernel": "field_sdf_grid_kernel", "algorithmic_bytes": evals * 1024, "achieved": gb / (sdf_ms * 1e-3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / (sdf_ms * 1e-3) / HBM_PEAK_GBS,
+                         "floor_ms_at_peak": gb / HBM_PEAK_GBS * 1e3},
+            "note": "reference: extract_geometry(NSR_BOUND, 512) of stylize.py:267 (512^3 forward_sdf queries in 256^3 blocks assembled on the host + PyMCubes "
+                    "on the CPU); here one ac_field_sdf_grid launch + ac_marching_cubes_count / _emit (classify, scan, emit; one 8-byte read-back between "
+                    "them), the volume never leaves the device; marching_cubes_ms includes that read-back and the allocation of the scratch"}
+        del vol, v, t
+        # density grid: the reference's call, update_extra_state(bound) once per epoch
+        ts = []
+        for _ in range(reps + 1):
+            e0, e1 = ev(), ev()
+            e0.record(); mean = nsr_ops.density_grid_update(f, net._grid_axis(NSR_BOUND, 129), net.density_grid, NSR_BOUND, 512.0, 0.95); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        t0 = time.perf_counter(); net.update_extra_state(NSR_BOUND); t_call = (time.perf_counter() - t0) * 1e3
+        net.fused_density_grid = False
+        net.update_extra_state(NSR_BOUND); torch.cuda.synchronize()
+        t0 = time.perf_counter(); net.update_extra_state(NSR_BOUND); torch.cuda.synchronize(); t_torch = (time.perf_counter() - t0) * 1e3
+        net.fused_density_grid = True
+        k_ms = float(np.median(ts[1:]))
+        halo_evals = 137 * 145 * 145               # 129^3 grid points + the +1 halo of every 16 x 8 x 8 brick that lies inside the grid
+        out["density_grid_update"] = {
+            "ms": k_ms, "update_extra_state_call_ms": t_call, "torch_chain_call_ms": t_torch, "grid": [129] * 3, "field_evaluations": halo_evals,
+            "roofline": {"bound": "hbm", "kernel": "density_grid_kernel", "algorithmic_bytes": 129 ** 3 * 1024,
+                         "achieved": 129 ** 3 * 1024 / 1e9 / (k_ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": 129 ** 3 * 1024 / 1e9 / (k_ms * 1e-3) / HBM_PEAK_GBS},
+            "note": "one launch: SDF -> logistic density -> 2^3 max pool -> max(grid * decay, new) in place -> mean; update_extra_state_call_ms = the whole "
+                    "method with its one read-back of (mean, step counts); torch_chain_call_ms = the reference-shaped torch formulation on the same fused SDF "
+                    "query (round 4's path)"}
+    return out
+
+
 def time_occupancy_render(dev, p, table, ro, rd, reps=3):
     """A SEPARATE figure, not the headline and not run()'s result: the occupancy-grid render (render(cuda_ray=True) -> NeRFRenderer.run_cuda, the path
     models/instant_nsr.py:358-363 dispatches to and the reference never defines): density grid (update_extra_state) -> march -> fused per-sample field
@@ -652,6 +716,7 @@ def main():
     ap.add_argument("--sd-arch-steps", type=int, default=2, help="time this many SDS steps with a guidance of Stable-Diffusion 1.5's architecture (random weights: "
                                                                   "what the step costs once the real UNet is in it); 0 = skip")
     ap.add_argument("--no-occupancy", action="store_true", help="skip the occupancy-grid render leg (render(cuda_ray=True): a separate figure beside the headline)")
+    ap.add_argument("--no-geometry", action="store_true", help="skip the mesh-export (512^3 + marching cubes) and density-grid-update legs")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
 
@@ -835,6 +900,12 @@ def main():
             except Exception as e:             # noqa: BLE001
                 import traceback
                 res["occupancy_render"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-500:]}
+        if world == 1 and not a.no_geometry:
+            try:
+                res.update(time_geometry(dev, p, table))
+            except Exception as e:             # noqa: BLE001
+                import traceback
+                res["mesh_export_512"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-600:]}
         if world == 1 and a.sd_arch_steps > 0:
             try:
                 res["sds_step_sd_arch_standin"] = time_sd_arch_step(dev, p, table, a.sd_arch_steps)

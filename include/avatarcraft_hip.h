@@ -371,6 +371,39 @@ int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const f
                              float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
                              ac_stream_t stream);
 
+/* ---- geometry of the learned surface: mesh export and the marcher's density grid ----------------------------------------
+ * ac_field_sdf_grid replaces extract_fields (models/instant_nsr.py:728-745): forward_sdf(x)[0] (:627-642) on the grid axis_x x axis_y x axis_z
+ * (three DEVICE arrays of nx / ny / nz coordinates: what torch.linspace(bound_min, bound_max, resolution) holds -- the kernel forms the points itself,
+ * no meshgrid / cat tensors, no 256^3 blocks, nothing goes to the host); volume [nx,ny,nz] (z fastest, like the reference's `u`), negate != 0 stores
+ * -sdf (the `u = -1.0 * u` of extract_geometry :752-753).  Values are bit-identical to ac_field_sdf at the same points. */
+int ac_field_sdf_grid(const ac_field *field, const float *axis_x, const float *axis_y, const float *axis_z, uint32_t nx, uint32_t ny, uint32_t nz,
+                      float bound, int negate, float *volume, ac_stream_t stream);
+/* Marching cubes on a device volume: replaces mcubes.marching_cubes(u, threshold) (models/instant_nsr.py:757; PyMCubes is a third-party package, not
+ * vendored in the reference and absent from this image: the algorithm is restated from its definition -- Lorensen & Cline's 256 cases, table generated
+ * by tools/gen_mc_table.py; corner flagged <=> u <= iso; one vertex per sign-changing grid edge at the linear zero crossing, formed in double; shared
+ * by every triangle that touches the edge; triangle normals point towards u <= iso).  Two calls because the caller owns the output buffers:
+ *   ac_marching_cubes_count: classify + scan; counts (DEVICE, [2]) = { vertices, triangles }.  scratch: ac_marching_cubes_scratch(nx, ny, nz) bytes
+ *                            (5 bytes per grid point), kept unchanged until the emit call.
+ *   ac_marching_cubes_emit : vertices [n_vertices,3] double = index / den * span + lo per axis (the reference's scaling to world units, :760-762, in its
+ *                            order of operations; den = resolution - 1, span / lo HOST arrays [3]; den = 1, span = 1, lo = 0 gives PyMCubes' index space),
+ *                            triangles [n_triangles,3] int32.  Deterministic order: vertices by owning grid point (linear index, z fastest) then axis
+ *                            x, y, z; triangles by cell (linear index) then table position.
+ * nx, ny, nz >= 2 and fewer than 2^31 grid points. */
+size_t ac_marching_cubes_scratch(uint32_t nx, uint32_t ny, uint32_t nz);
+int ac_marching_cubes_count(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz, float iso, void *scratch, size_t scratch_bytes,
+                            uint32_t *counts, ac_stream_t stream);
+int ac_marching_cubes_emit(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz, float iso, void *scratch, size_t scratch_bytes,
+                           double den, const double span[3], const double lo[3], double *vertices, uint32_t n_vertices, int32_t *triangles,
+                           uint32_t n_triangles, ac_stream_t stream);
+/* ac_density_grid_update replaces the grid update of NeRFRenderer.update_extra_state (models/instant_nsr.py:303-346) in ONE launch: forward_sdf on
+ * the H^3 grid axis x axis x axis (axis [H], device: torch.linspace(-bound, bound, H)) -> density = inv_s e^(-inv_s |sdf|) / (1 + e^(-inv_s |sdf|)) in the
+ * reference's two branches (:331-337; inv_s = 512) -> zero pad by one at the far ends + 2x2x2 max pool, stride 1 (:341-342) -> grid = max(grid * decay,
+ * new) IN PLACE (:345) -> mean_out (DEVICE, 1 double) = mean(grid) (:346; accumulated in double, fixed order).  grid [H,H,H].
+ * scratch: ac_density_grid_update_scratch(H) bytes, ZEROED once by the caller before its first use (the launch re-arms it).  2 <= H <= 1024. */
+size_t ac_density_grid_update_scratch(uint32_t H);
+int ac_density_grid_update(const ac_field *field, const float *axis, uint32_t H, float bound, float inv_s, float decay, float *grid,
+                           double *mean_out, void *scratch, size_t scratch_bytes, ac_stream_t stream);
+
 /* ---- colour MLP of the render core (training path): forward_color (models/instant_nsr.py:644-663, use_viewdirs = False)
  * rgb = sigmoid(Wc3 relu(Wc2 relu(Wc1 [x, normal, feat]))) with feat = sdf16[:, 1:16].
  * forward : same values as ac_field_color / ac_render_rays.   backward: recomputes the forward per tile of 16 samples and returns

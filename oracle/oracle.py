@@ -20,7 +20,8 @@ u32p = C.POINTER(C.c_uint32)
 def build(force=False):
     """Compile libac_oracle.so with the committed Makefile (gcc, seconds)."""
     so = os.path.join(_HERE, "libac_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_oracle_bwd.c", "ac_oracle_typed.c", "ac_oracle.h", "ac_math.h", "ac_sh_table.h", "ac_sp_table.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ac_oracle.c", "ac_oracle_ops.c", "ac_oracle_bwd.c", "ac_oracle_typed.c", "ac_oracle_geometry.c", "ac_oracle.h", "ac_math.h",
+                                                 "ac_sh_table.h", "ac_sp_table.h", "ac_mc_table.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libac_oracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -590,3 +591,31 @@ def weight_norm_backward(v, g, g_w):
     nrm = np.sqrt((v * v).sum(1, keepdims=True))
     dot = (g_w * v).sum(1, keepdims=True)
     return g / nrm * (g_w - v * dot / (nrm * nrm)), dot / nrm
+
+
+# ------------------------------------------------------------------ mesh export (ac_oracle_geometry.c)
+def field_sdf_grid(field, bound, resolution, negate=False):
+    """extract_fields (models/instant_nsr.py:728-745): forward_sdf on linspace(-bound, bound, resolution)^3 -> [res, res, res] fp32 (negate: -sdf)"""
+    import torch
+    ax = torch.linspace(-bound, bound, resolution).numpy()                  # the reference's own axis (host, fp32)
+    xx, yy, zz = np.meshgrid(ax, ax, ax, indexing="ij")
+    pts = np.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], 1).astype(np.float32)
+    u = field.sdf(pts, bound)[:, 0].astype(np.float32).reshape(resolution, resolution, resolution)
+    return -u if negate else u
+
+
+def marching_cubes(volume, iso=0.0, den=1.0, span=(1.0, 1.0, 1.0), lo=(0.0, 0.0, 0.0)):
+    """mcubes.marching_cubes(u, iso) restated (see ac_oracle_geometry.c): -> vertices [V,3] float64 (= index / den * span + lo), triangles [F,3] int32"""
+    vol = _f(volume)
+    nx, ny, nz = vol.shape
+    dp = C.POINTER(C.c_double)
+    span_a, lo_a = np.asarray(span, dtype=np.float64), np.asarray(lo, dtype=np.float64)
+    counts = np.zeros(2, dtype=np.uint32)
+    args = lambda v, t: (_p(vol), C.c_uint32(nx), C.c_uint32(ny), C.c_uint32(nz), C.c_float(iso), C.c_double(den), span_a.ctypes.data_as(dp),
+                         lo_a.ctypes.data_as(dp), v, t, _p(counts, u32p))
+    if lib().orc_marching_cubes(*args(None, None)) != 0:
+        raise MemoryError("orc_marching_cubes")
+    verts = np.zeros((int(counts[0]), 3), dtype=np.float64)
+    tris = np.zeros((int(counts[1]), 3), dtype=np.int32)
+    lib().orc_marching_cubes(*args(verts.ctypes.data_as(dp), _p(tris, i32p)))
+    return verts, tris
