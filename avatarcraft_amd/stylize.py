@@ -166,6 +166,8 @@ class Adam(torch.optim.Adam):
 _CONSTS = {}
 # sds_step renders render_val and the training forward of a one-patch view in one launch (ac_render_rays_pair); False = two launches (same values)
 PAIR_STEP_RENDERS = True
+# a view of several patches (fine stage): render_val and the frozen avatar's render as one launch per VIEW instead of one per patch (same values)
+WHOLE_VIEW_RENDERS = os.environ.get("AC_WHOLE_VIEW_RENDERS", "1") != "0"
 # data-parallel steps: all-reduce the table gradient of levels >= ALLREDUCE_SPLIT_LEVEL (33.5 of the 49 MB) while the scatter still accumulates the
 # coarser levels and the MLP gradients are formed (ac_core_grads.side_stream / split_level).  Off by default: no multi-GPU node was available to measure it
 # (at most the ~0.15 ms the second accumulation launch + ac_param_grads take can be hidden); AC_OVERLAP_ALLREDUCE=1 or sds_step(overlap_allreduce=True).
@@ -217,6 +219,12 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                                                                  lambda: _background_on(rays_o.device, rays_o.shape, bkg_key))
         paired = (rgb_p, eik_p, {"weight_sum": ws_p})
         mark("render_val_and_grad_forward")
+    elif manual and WHOLE_VIEW_RENDERS and n_rays > batch_size and hasattr(net_style, "render_view_nograd"):
+        # (A) a view of several patches (the fine stage: 256 x 256 = 16 patches): render_val as ONE launch instead of one per patch -- the same
+        # random draws in the same order (per patch: background, jitter noise), the same pixels bit for bit
+        rgb_val, _ = net_style.render_view_nograd(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND,
+                                                  lambda n: _background_on(rays_o.device, (n, 3), bkg_key), batch_size)
+        mark("render_val")
     else:
         # (A) render_val: net_style stays in train mode (stylize.py never calls eval()), no grad
         rgb_val, _ = render_instantnsr_naive(net_style, rays_o, rays_d, rays_per_batch=batch_size, requires_grad=False, bkg_key=bkg_key,
@@ -244,6 +252,15 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
     else:
         early_op = torch.distributed.ReduceOp.SUM
     work_hi = hi_range = None
+    # the frozen avatar of the opacity loss (stylize.py:176-190), rendered for its weight_sum alone: for a view of several patches ONE launch before the
+    # patch loop instead of one per patch.  net_gt is in eval mode (no jitter draw); its background never reaches weight_sum, but a RANDOM background
+    # would still be drawn per patch from the host generator in the reference's order -- so the hoist is taken for the constant backgrounds only.
+    ws_gt_view = None
+    if (manual and WHOLE_VIEW_RENDERS and n_rays > bs and hasattr(net_gt, "render_view_nograd") and not net_gt.training
+            and (bkg_key % 4) in (WHITE_BKG, BLACK_BKG) and getattr(net_gt, "_fused_supported", lambda: False)() and not getattr(net_gt, "cuda_ray", False)):
+        _, ws_gt_view = net_gt.render_view_nograd(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND,
+                                                  lambda n: _background_on(rays_o.device, (n, 3), bkg_key), bs, opacity_only=True)
+        mark("render_gt_view")
     for i in range(0, n_rays, bs) if manual else ():
         # The same three terms WITHOUT autograd (avatarcraft_amd.NeRFNetwork): the training render keeps its per-sample outputs, the upstream
         # gradients of (image, weights_sum, gradient_error) are written down directly (d sum(rgb * g) = g; d (eik * w) = w; the opacity term through
@@ -261,10 +278,14 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
                 net_style._manual_backward = False
             mark("render_grad_forward")
         with torch.no_grad():
-            _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
-                                                     return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps,
-                                                     opacity_only=True)           # (only its weight_sum is read: no colour network)
-            g_ws, opa = nsr_ops.sds_upstream(extra["weight_sum"], extra_gt["weight_sum"], 1e5 / ro.shape[0], want_grad=use_opacity)
+            if ws_gt_view is not None:
+                ws_gt = ws_gt_view[i:i + bs]
+            else:
+                _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
+                                                         return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps,
+                                                         opacity_only=True)           # (only its weight_sum is read: no colour network)
+                ws_gt = extra_gt["weight_sum"]
+            g_ws, opa = nsr_ops.sds_upstream(extra["weight_sum"], ws_gt, 1e5 / ro.shape[0], want_grad=use_opacity)
             opa_vals.append(opa[0])
             if isinstance(eik, torch.Tensor):
                 nan_flags.append(eik)

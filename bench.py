@@ -182,6 +182,48 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
     return res, (net, net_gt)
 
 
+def time_sds_fine_view(dev, p, table, steps=2):
+    """The fine stage of a stylisation run (stylize.py:98-107 with stride min(1, subsample_scale // 2) = 1, quirk C.8; :143-199): one optimizer step on a
+    full 256 x 256 view = 16 patches of 4096 rays -- render_val of the whole view, the guidance, then per patch the training render, the frozen avatar's
+    render and the backward of the three loss terms, gradients accumulating over the 16 patches; 20 of the default run's 25 epochs x 150 views are this.
+    Timed twice: with render_val and the frozen avatar's render as ONE launch per view each (the default, stylize.WHOLE_VIEW_RENDERS) and patch by patch
+    (the harness's own batching, round 4).  Same launched-bytes roofline as sds_step: 16 x the coarse step's bytes."""
+    import avatarcraft_amd.stylize as ST
+    from avatarcraft_amd.synthetic import make_rays
+    net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
+    opt = ST.Adam(net.parameters(), lr=5e-3, zero_grad_in_step=True)
+    flat = ST.flat_grad_view(net.parameters())
+    guidance = ST.SyntheticGuidance(42)
+    ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=0.0, pitch=0.0)
+    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    out = {}
+    for name, whole in (("patch_by_patch", False), ("whole_view_renders", True)):
+        ST.WHOLE_VIEW_RENDERS = whole
+        ST.sds_step(net, net_gt, ro, rd, (256, 256), opt, guidance, batch_size=4096, flat_grad=flat)       # warm-up
+        torch.cuda.synchronize()
+        marks = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ST.sds_step(net, net_gt, ro, rd, (256, 256), opt, guidance, batch_size=4096, flat_grad=flat, timers=marks)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        phases = {}
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            if n1 != "start":
+                phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
+        out[name] = {"ms_per_view": ms, "phase_ms": {k: round(v, 3) for k, v in phases.items()}}
+    ST.WHOLE_VIEW_RENDERS = True
+    launched = 16 * sum(SDS_BYTES_LAUNCHED.values())
+    ms = out["whole_view_renders"]["ms_per_view"]
+    ach = launched / (ms * 1e-3) / 1e9
+    return {"ms_per_view": ms, "rays_per_view": 65536, "patches": 16, "steps": steps, "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)",
+            "phase_ms": out["whole_view_renders"]["phase_ms"], "patch_by_patch": out["patch_by_patch"],
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_view": launched,
+                         "note": "16 x the coarse step's launched bytes (render_val, training forward, frozen render, stencil features, table scatter per patch)"},
+            "note": "render_val and the frozen avatar's opacity render are one launch per view (bit-identical to the 16 per-patch launches: same draws in the "
+                    "same order); the training forward + backward stay per patch (the reference's memory bound: 4096 rays x 128 samples of saved activations)"}
+
+
 def cpu_baseline_sds(p, table, n_side=16, threads=None):
     """CPU leg of the SDS step on a bounded sample (n_side^2 rays of the same training view): the no-grad renders through the C oracle
     (OpenMP), the differentiable render core as torch-CPU autograd (MKL threads) over a hash encoder served by the oracle's forward /
@@ -716,6 +758,7 @@ def main():
     ap.add_argument("--sd-arch-steps", type=int, default=2, help="time this many SDS steps with a guidance of Stable-Diffusion 1.5's architecture (random weights: "
                                                                   "what the step costs once the real UNet is in it); 0 = skip")
     ap.add_argument("--no-occupancy", action="store_true", help="skip the occupancy-grid render leg (render(cuda_ray=True): a separate figure beside the headline)")
+    ap.add_argument("--no-fine-view", action="store_true", help="skip the fine-stage leg (one optimizer step on a full 256 x 256 view = 16 patches)")
     ap.add_argument("--no-geometry", action="store_true", help="skip the mesh-export (512^3 + marching cubes) and density-grid-update legs")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
     a = ap.parse_args()
@@ -900,6 +943,12 @@ def main():
             except Exception as e:             # noqa: BLE001
                 import traceback
                 res["occupancy_render"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-500:]}
+        if world == 1 and a.sds_steps > 0 and not a.no_fine_view:
+            try:
+                res["sds_view_fine"] = time_sds_fine_view(dev, p, table)
+            except Exception as e:             # noqa: BLE001
+                import traceback
+                res["sds_view_fine"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-600:]}
         if world == 1 and not a.no_geometry:
             try:
                 res.update(time_geometry(dev, p, table))

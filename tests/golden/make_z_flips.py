@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Record, in tests/golden/warp_render.npz, WHICH rays of the posed-space goldens carry an up-sampling knife-edge flip between the reference's run()
+(the recorded z_vals) and the oracle -- instead of tolerating "<= 6 % of the rays" in the parity test.
+
+    python tests/golden/make_z_flips.py
+
+Needs no reference checkout: the reference's z_vals are already in the fixture (written by make_golden.py from run(render_can=False)); this script runs
+the CPU oracle on the same inputs and stores, per case tag, the indices of the rays whose z_vals differ by more than 1e-4 anywhere
+(`<tag>_oracle_z_flips`, int32) -- the same mechanism as `oracle_ss_flips` of the canonical goldens: a flipped searchsorted comparison moves one new
+sample into the neighbouring bin, every later sample of that ray shifts by one position.  The parity tests (CPU: oracle, GPU: HIP == oracle bit for
+bit) then require EXACTLY this set."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from oracle import oracle as O
+    from tests.common import make_body, oracle_field_from_golden, load_golden
+    path = os.path.join(HERE, "warp_render.npz")
+    g = dict(np.load(path))
+    p = load_golden("nsr_params.npz")
+    field = oracle_field_from_golden(p)
+    verts, faces, Ts = make_body()
+    for tag, guide in (("guide", True), ("noguide", False)):
+        r = O.render_rays(field, g["rays_o"], g["rays_d"], 32, 32, 1.6, float(p["inv_s"]), bg=g["bg"], warp=dict(verts=verts, faces=faces, Ts=Ts, use_mesh_guide=guide))
+        d = np.abs(np.asarray(r["z_vals"]).reshape(g[f"{tag}_z_vals"].shape) - g[f"{tag}_z_vals"])
+        flips = np.nonzero(d.max(1) > 1e-4)[0].astype(np.int32)
+        g[f"{tag}_oracle_z_flips"] = flips
+        print(tag, "rays with a z flip:", flips.tolist(), "of", d.shape[0])
+    np.savez_compressed(path, **g)
+
+
+if __name__ == "__main__":
+    main()

@@ -237,7 +237,9 @@ def test_sds_step_matches_reference_step(oracle):
     json.dump(worst, open("gpurun_out/sds_step_parity.json", "w"), indent=1)
     for k, (e_orc, e_ref) in worst.items():
         assert e_orc <= 3e-4, (k, e_orc, worst)            # (a) observed <= 1.2e-4
-        assert e_ref <= 6e-2, (k, e_ref, worst)            # (b)
+        # (b) per key: the table gradient inherits the reference's fp32 atomicAdd order and the opacity term's 1e5 scale (observed 3.5e-2; the trainer-step
+        # test splits it by loss term); every MLP / variance gradient is a plain sum and sits at <= 3.4e-3 -- a 20x regression there must not pass
+        assert e_ref <= (6e-2 if k == "encoder.embeddings" else 5e-3), (k, e_ref, worst)
     changed = int(((net.encoder.embeddings.detach() - before["encoder.embeddings"]).abs().sum(1) > 0).sum())
     assert abs(changed - int(g["adam_changed"])) <= 0.01 * int(g["adam_changed"])
 

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import load_golden
+from tests.common import load_golden, make_rays
 from tests.test_gpu_model import golden_net, DEV
 
 pytestmark = pytest.mark.gpu
@@ -370,3 +370,55 @@ def test_sds_steps_with_the_one_launch_adam():
     c = run("in_step", 3, stray=True)
     for k in a:
         assert torch.equal(a[k], c[k]), k
+
+
+@pytest.mark.parametrize("bkg", ["white", "noise"])
+def test_fine_view_whole_view_renders_equal_patch_by_patch(bkg):
+    """a fine-stage view (several patches) renders render_val and the frozen avatar ONCE per view (NeRFRenderer.render_view_nograd)
+    instead of once per patch.  Rays are independent and the random draws are made in the harness's own order, so: render_val and the frozen weight_sum
+    bit for bit, hence the guidance input, the flat gradient and the parameters after the step bit for bit -- against the patch-by-patch step (round 4) from
+    the same state and streams.  A random background (drawn per patch from the host generator) keeps the reference's order: the frozen render is then NOT
+    hoisted, render_val still is."""
+    import avatarcraft_amd.stylize as ST
+    from avatarcraft_amd.render_utils import WHITE_BKG, NOISE_BKG, render_instantnsr_naive, _background_on, NSR_BOUND
+    ro, rd = make_rays(48, 40, dist=1.8, f=36.0)                      # 1920 rays: 4 patches of 512 (the last one shorter: 384)
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    key = WHITE_BKG if bkg == "white" else NOISE_BKG
+
+    class Rec(ST.SyntheticGuidance):
+        def __call__(self, rgb, text=None):
+            self.seen = rgb.detach().clone()
+            return super().__call__(rgb, text)
+
+    def one(whole):
+        net, _ = golden_net(train=True)
+        net_gt, _ = golden_net(train=False)
+        opt = ST.Adam(net.parameters(), lr=5e-3, zero_grad_in_step=False)
+        flat = ST.flat_grad_view(net.parameters())
+        guide = Rec(3)
+        torch.manual_seed(21); random.seed(21)
+        marks = []
+        prev = ST.WHOLE_VIEW_RENDERS
+        ST.WHOLE_VIEW_RENDERS = whole
+        try:
+            st = ST.sds_step(net, net_gt, ro_t, rd_t, (48, 40), opt, guide, batch_size=512, flat_grad=flat, bkg_key=key, timers=marks)
+        finally:
+            ST.WHOLE_VIEW_RENDERS = prev
+        net.check_finite()
+        return guide.seen, flat.clone(), {k: v.detach().clone() for k, v in net.named_parameters()}, [n for n, _ in marks], st
+    img_a, g_a, p_a, m_a, s_a = one(True)
+    img_b, g_b, p_b, m_b, s_b = one(False)
+    assert ("render_gt_view" in m_a) == (bkg == "white") and "render_gt_view" not in m_b
+    assert m_a.count("backward") == m_b.count("backward") == 4
+    assert torch.equal(img_a, img_b)                                  # render_val of the view, bit for bit
+    assert torch.equal(g_a, g_b) and float(g_a.abs().max()) > 0       # the accumulated gradient of the four patches
+    for k in p_a:
+        assert torch.equal(p_a[k], p_b[k]), k
+    assert float(s_a["opacity"]) == float(s_b["opacity"]) and float(s_a["eikonal"]) == float(s_b["eikonal"])
+    # the one-launch view render against the harness on an eval net as well (no noise at all)
+    net, _ = golden_net(train=False)
+    with torch.no_grad():
+        rgb_v, ws_v = net.render_view_nograd(ro_t, rd_t, 64, 64, NSR_BOUND, lambda n: _background_on(DEV, (n, 3), WHITE_BKG), 512)
+        rgb_h, _, ex = render_instantnsr_naive(net, ro_t, rd_t, rays_per_batch=512, requires_grad=False, bkg_key=WHITE_BKG, render_can=True, perturb=True,
+                                               return_raw=True, num_steps=64, upsample_steps=64, bound=NSR_BOUND)
+    assert torch.equal(rgb_v, rgb_h) and torch.equal(ws_v, ex["weight_sum"])
