@@ -21,7 +21,7 @@ f32 = C.c_float
 
 class ac_field(C.Structure):
     _fields_ = [("table", vp), ("offsets", i32 * 17), ("S", f32), ("H", u32),
-                ("W1", vp), ("b1", vp), ("W2", vp), ("b2", vp), ("Wc1", vp), ("Wc2", vp), ("Wc3", vp), ("prepared", vp)]
+                ("W1", vp), ("b1", vp), ("W2", vp), ("b2", vp), ("Wc1", vp), ("Wc2", vp), ("Wc3", vp), ("prepared", vp), ("Wc1_sh", vp)]
 
 
 class ac_render_opts(C.Structure):

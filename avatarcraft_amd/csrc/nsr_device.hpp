@@ -6,6 +6,7 @@
 #include "ac_common.hpp"
 #include "ac_devmath.hpp"
 #include "ac_sp_table.hpp"
+#include "ac_sh_table.hpp"
 
 using namespace acdev;
 
@@ -87,7 +88,8 @@ constexpr int CF_OVERLAY = OFF_B1 - OFF_C1F;      // floats of the overlay: the 
 // buffers, cdf, new samples) until the sampling of the ray is finished and the finite-difference feature slab afterwards
 constexpr int UPS_FLOATS = MAXT + 2 * MAXT + MAXT + 32;              // zs1[128], sd[2][128], cdf[128], znew[16] + pad
 constexpr int SLAB_ACC = MAXT + (FE_SLAB > UPS_FLOATS ? FE_SLAB : UPS_FLOATS);     // the ray's ten running sums (compositing, eikonal): [16] floats, kept by lane 15
-constexpr int WAVE_SLAB = SLAB_ACC + 16;
+constexpr int SLAB_SHB = SLAB_ACC + 16;                                           // use_viewdirs: the ray's layer-1 bias of the colour network [64] + sh(d) [16]
+constexpr int WAVE_SLAB = SLAB_SHB + 80;
 constexpr int LDS_FLOATS = OFF_RWAVE + WAVES_PER_BLOCK * WAVE_SLAB;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget: one workgroup per CU");
 static_assert(OFF_WAVE % 4 == 0 && OFF_RWAVE % 4 == 0 && WAVE_SLAB % 4 == 0, "16-byte aligned slabs");
@@ -110,6 +112,7 @@ struct RenderArgs {
     const float *table;
     uint32_t table_bytes;
     const float *W1, *b1, *W2, *b2, *Wc1, *Wc2, *Wc3;
+    const float *Wsh;           // ac_field.Wc1_sh: [64,16] colour layer-1 columns of the 16 spherical harmonics of the view direction, or NULL (no view directions)
     const float *prepared;      // ac_field.prepared: the renderer's LDS image [0, OFF_RWAVE) of these parameters, or NULL
     const float *rays_o, *rays_d, *bg, *noise, *lin_z, *lin_u;
     ac_render_out out;
@@ -911,8 +914,67 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
 #undef AC_FSTORE
 
 // ---- forward_color for a tile: rgb (post-sigmoid) valid in lanes g==0 ---------------------------------
+// ---- use_viewdirs = True (models/instant_nsr.py:565-569, 644-653): h = cat[x, sh(d), n, geo_feat] ----------------------------------------
+// The 16 spherical harmonics (degree 4, encoder/shencoder) of the RAW ray direction enter layer 1 of the colour network only.  The direction is constant
+// along a ray, so Wsh sh(d) is a per-ray BIAS of that layer: bias[u] = fma chain over j = 0..15 of Wsh[u][j] * sh_j(d), and the accumulator of unit u
+// starts from bias[u] instead of 0 -- zero cost per sample.  sh_j: the value table of the stand-alone encoder (shencoder.hip), same operations.
+__device__ __forceinline__ float sh16_value(int i, float x, float y, float z)
+{
+    const float px[4] = { 1.0f, x, x * x, (x * x) * x }, py[4] = { 1.0f, y, y * y, (y * y) * y }, pz[4] = { 1.0f, z, z * z, (z * z) * z };
+    float acc = 0.0f;
+    for (int m = AC_SH_OFF0[i]; m < AC_SH_OFF0[i + 1]; ++m) {
+        const float mono = (px[AC_SH_EXP0[m][0]] * py[AC_SH_EXP0[m][1]]) * pz[AC_SH_EXP0[m][2]];
+        acc = fma_(AC_SH_COEF0[m], mono, acc);
+    }
+    return acc;
+}
+// one ray per wave: shb [80] floats of the wave's LDS slab -> shb[u] = bias of unit u (u = lane), shb[64 + j] = sh_j(d)
+__device__ __forceinline__ void ray_sh_bias(float *__restrict__ shb, const float *__restrict__ Wsh, float dx, float dy, float dz, int lane)
+{
+    if (lane < 16) shb[64 + lane] = sh16_value(lane, dx, dy, dz);
+    wave_sync();
+    const f32x4 *w = reinterpret_cast<const f32x4 *>(Wsh + lane * 16);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = w[q];
+        acc = fma_(wv[0], shb[64 + 4 * q], acc); acc = fma_(wv[1], shb[64 + 4 * q + 1], acc);
+        acc = fma_(wv[2], shb[64 + 4 * q + 2], acc); acc = fma_(wv[3], shb[64 + 4 * q + 3], acc);
+    }
+    shb[lane] = acc;
+    wave_sync();
+}
+// packed samples (a tile of 16 samples of whatever rays): lane (n, g) computes the 16 biases it needs -- units 16 t + 4 g + r of ITS sample's direction --
+// into slab[(t * 64 + lane) * 4 + r] ([4][64][4] floats of the wave's LDS: the finite-difference feature slab, free once the normals are formed)
+__device__ __forceinline__ void sample_sh_bias(float *__restrict__ slab, const float *__restrict__ Wsh, float dx, float dy, float dz, int lane)
+{
+    const int g = lane >> 4;
+    float sh[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sh[j] = sh16_value(j, dx, dy, dz);
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 *w = reinterpret_cast<const f32x4 *>(Wsh + (16 * t + 4 * g + r) * 16);
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = w[q];
+                acc = fma_(wv[0], sh[4 * q], acc); acc = fma_(wv[1], sh[4 * q + 1], acc); acc = fma_(wv[2], sh[4 * q + 2], acc); acc = fma_(wv[3], sh[4 * q + 3], acc);
+            }
+            o[r] = acc;
+        }
+        *reinterpret_cast<f32x4 *>(slab + (t * 64 + lane) * 4) = o;
+    }
+    wave_sync();
+}
+
+// shb: NULL, or this lane's first bias quadruple -- (ray slab) + 4 g with tstride 16, or (sample slab) + 4 lane with tstride 256
 __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int lane, float px, float py, float pz,
-                                           float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3])
+                                           float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3], const float *__restrict__ shb = nullptr,
+                                           int tstride = 16)
 {
     const int g = lane >> 4;
     f32x4 h1[4], h2[4];
@@ -920,6 +982,7 @@ __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int la
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (shb) acc = *reinterpret_cast<const f32x4 *>(shb + t * tstride);
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const float b = s < 4 ? sdfout[s] : (s == 4 ? bxyz : bn);
@@ -957,7 +1020,8 @@ __device__ __forceinline__ f32x4 cf_mma(const float *__restrict__ lds, int f, in
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void color_tile_fast(const float *__restrict__ lds, int lane, float px, float py, float pz,
-                                                float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3])
+                                                float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3], const float *__restrict__ shb = nullptr,
+                                                int tstride = 16)
 {
     const int g = lane >> 4;
     u32x4 bh, bl;
@@ -969,7 +1033,9 @@ __device__ __forceinline__ void color_tile_fast(const float *__restrict__ lds, i
     f32x4 h1[4], h2[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        f32x4 acc = cf_mma(lds, t, lane, bh, bl, f32x4{ 0.0f, 0.0f, 0.0f, 0.0f });
+        f32x4 acc0 = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (shb) acc0 = *reinterpret_cast<const f32x4 *>(shb + t * tstride);      // (the view-direction bias stays fp32 in either precision)
+        f32x4 acc = cf_mma(lds, t, lane, bh, bl, acc0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
         h1[t] = acc;
@@ -1059,6 +1125,7 @@ int fill_args(RenderArgs &a, const ac_field *f, float bound)
         a.jmode[j] = nh == 0 ? 0 : (nh == 4 ? 1 : 2);
     }
     a.prepared = static_cast<const float *>(f->prepared);
+    a.Wsh = f->Wc1_sh;
     a.table = f->table; a.table_bytes = (uint32_t)f->offsets[16] * 8u; a.W1 = f->W1; a.b1 = f->b1; a.W2 = f->W2; a.b2 = f->b2; a.Wc1 = f->Wc1; a.Wc2 = f->Wc2; a.Wc3 = f->Wc3;
     a.bound = bound; a.two_bound = (float)(2.0 * (double)bound);
     return AC_OK;

@@ -360,6 +360,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         // registers: they are touched once per tile by one lane (lane 15, which holds the tile totals of the row scans), and ten registers less at the
         // peak of the stencil / MLP code is the difference between ~30 and ~10 spilled registers.  Slots: 1 s_w 2..4 rgb 5..7 normal 8 depth 9 10 eikonal
         float *const accs = zs0 + SLAB_ACC;
+        float *const shb = zs0 + SLAB_SHB;                      // use_viewdirs: layer-1 bias of the colour network for THIS ray's direction (per work item: a segment
+        const bool use_sh = a.Wsh != nullptr && !a.opacity_only;      // of a ray may run on another wave than the one before it -- 16 sh values + 64 dot products, ~1 us)
+        if (use_sh) ray_sh_bias(shb, a.Wsh, dx, dy, dz, lane);
         if (!seg_first) {
             // continue a ray another wave (of this XCD) started: wait until its previous segment is published, then take over z and the running sums.
             // All accesses to seg_flags / seg_state are agent-scope atomics = served by the XCD's L2, past the (incoherent) vector L1 caches.
@@ -500,8 +503,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
             float rgb[3] = { 0.0f, 0.0f, 0.0f };
             if (!skip && !a.opacity_only) {                      // (wave-uniform)
-                if constexpr (FC) color_tile_fast(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
-                else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+                if constexpr (FC) color_tile_fast(lds, lane, px, py, pz, nx, ny, nz, oc, rgb, use_sh ? shb + 4 * g : nullptr);
+                else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb, use_sh ? shb + 4 * g : nullptr);
             }
             AC_TICK(5)
             // NeuS alpha :219-248

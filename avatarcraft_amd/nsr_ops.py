@@ -33,7 +33,9 @@ class Field:
     table [n_entries,2], offsets (17 host ints), S=log2(per_level_scale), H, and the EFFECTIVE
     (weight-normed) MLP matrices W1[64,35] b1[64] W2[16,64] b2[16] Wc1[64,21] Wc2[64,64] Wc3[3,64]."""
 
-    def __init__(self, table, offsets, per_level_scale, base_resolution, W1, b1, W2, b2, Wc1, Wc2, Wc3):
+    def __init__(self, table, offsets, per_level_scale, base_resolution, W1, b1, W2, b2, Wc1, Wc2, Wc3, Wc1_sh=None):
+        """Wc1_sh [64,16] (optional): NeRFNetwork(use_viewdirs=True) -- the columns of the effective color_net.0 weight that multiply the 16 spherical
+        harmonics of the ray direction (columns 3..18 of its [64,37] matrix; Wc1 then holds the other 21: x, normal, geo_feat).  See ac_field.Wc1_sh."""
         offsets = [int(v) for v in offsets]
         if len(offsets) != 17:
             raise RuntimeError("the fused renderer supports the 16-level hash grid only")
@@ -51,6 +53,10 @@ class Field:
         f.H = self.H
         for k in ("W1", "b1", "W2", "b2", "Wc1", "Wc2", "Wc3"):
             setattr(f, k, self.t[k].data_ptr())
+        if Wc1_sh is not None:
+            self.t["Wc1_sh"] = _chk(Wc1_sh, "Wc1_sh", (64, 16))
+            f.Wc1_sh = self.t["Wc1_sh"].data_ptr()
+        self.has_viewdirs = Wc1_sh is not None
         self.c = f
         self.device = table.device
         self.prepared = None

@@ -85,6 +85,13 @@ def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_g
     lean = {"per_sample": False} if (not requires_grad and getattr(net, "supports_lean_render", False)) else {}
     if opacity_only and not requires_grad and getattr(net, "supports_opacity_only", False):
         lean["opacity_only"] = True
+    if (getattr(net, "cuda_ray", False) and not requires_grad and not net.training and render_can and total > rays_per_batch
+            and not getattr(net, "occupancy_rounds", True) and (bkg_key % 4) in (WHITE_BKG, BLACK_BKG)):
+        # An occupancy-grid net in eval(): its render is ONE launch whatever the ray count (ac_render_rays_occupancy keeps per-ray state in registers
+        # and allocates nothing per sample), and a launch costs the latency of its longest ray -- a chain of ~200 dependent grid look-ups, 0.26 ms --
+        # however few rays it holds: sixteen 4096-ray launches per 256 x 256 view took 12.1 ms, the view in one launch 2.4 ms (round 4's figures).
+        # The reference batches to bound the memory of ITS per-sample tensors; rays are independent, so the pixels are the same bit for bit.
+        rays_per_batch = total
     with torch.set_grad_enabled(requires_grad):
         for i in range(0, total, rays_per_batch):
             ro, rd = rays_o[i:i + rays_per_batch], rays_d[i:i + rays_per_batch]

@@ -20,7 +20,7 @@ import torch
 from . import nsr_ops
 import torch.nn.functional as F
 
-from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG, _background_on
+from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG, BLACK_BKG, _background_on
 
 
 class SyntheticGuidance:

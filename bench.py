@@ -502,6 +502,18 @@ def time_occupancy_render(dev, p, table, ro, rd, reps=3):
                 dt = (time.perf_counter() - t0) / (reps * (4 if not rounds_on else 1))
                 res[f"eval_{mode}_{rpb}_ray_batches"] = {"ms_per_view": dt * 1e3, "rays_per_s": n / dt, "march_rounds_per_view": rounds}
         net.occupancy_rounds = False
+        # what a driver gets: the harness (render_instantnsr_naive, rays_per_batch = 4096 like render_canonical.py) hands an eval() occupancy net the whole view
+        from avatarcraft_amd.render_utils import render_instantnsr_naive as _harness, WHITE_BKG as _W
+        hk = dict(rays_per_batch=RAYS_PER_BATCH, requires_grad=False, bkg_key=_W, render_can=True, perturb=False, return_raw=True, num_steps=64, upsample_steps=64,
+                  bound=NSR_BOUND)
+        himg = _harness(net, ro, rd, **hk)[0]; torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps * 4):
+            himg = _harness(net, ro, rd, **hk)[0]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (reps * 4)
+        res["eval_through_the_harness_4096_ray_batches"] = {"ms_per_view": dt * 1e3, "rays_per_s": n / dt,
+                                                            "note": "render_instantnsr_naive(rays_per_batch=4096): one launch per view for an eval() occupancy net (same pixels)"}
         from avatarcraft_amd import nsr_ops as _ops
         res["samples_evaluated_per_view"] = int(_ops.render_rays_occupancy(net._field(), ro, rd, net.density_grid, net.mean_density, NSR_BOUND, 0.005,
                                                                            net.forward_variance(), 1.0, count_samples=True)["n_samples"].item())

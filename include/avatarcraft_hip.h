@@ -154,6 +154,12 @@ typedef struct ac_field {
                                  parameters (the weights in the order the renderer keeps them in LDS: its workgroups then
                                  copy 52 KB linearly instead of re-deriving the layout from the row-major matrices, 512 times
                                  per launch).  NULL = derive it in every workgroup.  Must be re-prepared when a parameter changes. */
+    const float *Wc1_sh;      /* optional (ABI 6): NeRFNetwork(use_viewdirs=True) -- the colour network's first layer reads
+                                 h = cat[x, sh(d), n, geo_feat] (models/instant_nsr.py:565-569, 644-653; sh = degree-4 real spherical harmonics of the RAW
+                                 ray direction, encoder/shencoder: 16 values).  Wc1_sh = the 16 columns of the effective color_net.0 weight that multiply
+                                 sh(d), [64,16] row-major (columns 3..18 of the [64,37] matrix); Wc1 keeps the other 21 (x, n, geo_feat).  The view
+                                 direction is constant along a ray: the renderer folds Wc1_sh sh(d) into a per-ray bias of layer 1 (fp32 fma chain over
+                                 the 16 terms in order, then the 21 inputs as without view directions) -- no per-sample cost.  NULL = no view directions. */
 } ac_field;
 #define AC_FIELD_PREPARED_BYTES 98304
 /* fills `prepared` (device, AC_FIELD_PREPARED_BYTES) from the other members of `field`; enqueue on `stream` before the launches that use it */

@@ -276,7 +276,7 @@ def test_posed_render_matches_reference_render():
                          cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=False, verts=verts, faces=faces, Ts=Ts, perturb=False)
     m = {"image": out["rgb"][0], "weights_sum": out["weight_sum"][:, 0], "depth": out["depth"][0], "normal_map": out["normal"], "weights": out["weights"],
          "alpha": out["pts_alpha"], "z_vals": out["z_vals"], "gradient_error": out["gradient_error"]}
-    check_warp_render_vs_golden(lambda k: m[k].detach().cpu().numpy(), g, "guide")
+    check_warp_render_vs_golden(lambda k: m[k].detach().cpu().numpy(), g, "guide", flips="model")      # (model path: see tests/golden/make_z_flips.py)
     # through the harness the animate driver uses
     rgb, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=100, requires_grad=False, render_can=False, perturb=False, verts=verts, faces=faces,
                                      Ts=Ts, num_steps=32, upsample_steps=32, bound=1.6)

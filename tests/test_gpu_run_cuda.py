@@ -229,3 +229,41 @@ def test_run_cuda_gradients_vs_torch_formulation(env):
     json.dump(worst, open("gpurun_out/run_cuda_grad_parity.json", "w"), indent=1)
     assert all(e <= 2e-3 for e in worst.values()), worst
     net.zero_grad()
+
+
+def test_harness_hands_an_eval_occupancy_net_the_whole_view(env):
+    """render_instantnsr_naive batches by 4096 rays (the reference bounds ITS memory that way); an eval() occupancy-grid net renders a
+    launch of any size, and a launch costs its longest ray's latency however few rays it holds -- so the harness gives it the view in one piece.  Same pixels
+    as the batches, bit for bit (rays are independent); a training net, the loop of rounds or a random background keep the batches."""
+    from avatarcraft_amd import render_utils as RU
+    net = env["net"].eval()
+    ro, rd = make_rays(96, 96, dist=1.8, f=72.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    calls = []
+    orig = net.run_cuda
+
+    def spy(rays_o, *a, **k):
+        calls.append(rays_o.shape[1]); return orig(rays_o, *a, **k)
+    net.run_cuda = spy
+    try:
+        kw = dict(requires_grad=False, bkg_key=RU.WHITE_BKG, render_can=True, perturb=False, return_raw=True, num_steps=64, upsample_steps=64, bound=1.6)
+        rgb1, _, ex1 = RU.render_instantnsr_naive(net, t(ro), t(rd), rays_per_batch=1024, **kw)
+        assert calls == [96 * 96]
+        calls.clear()
+        net.occupancy_rounds = True
+        rgb2, _, ex2 = RU.render_instantnsr_naive(net, t(ro), t(rd), rays_per_batch=1024, **kw)
+        net.occupancy_rounds = False
+        assert calls == [1024] * 9
+        calls.clear()
+        rgb3, _, ex3 = RU.render_instantnsr_naive(net, t(ro), t(rd), rays_per_batch=96 * 96, **kw)          # the same single launch, asked for explicitly
+        with torch.no_grad():
+            parts = [net.render(t(ro)[None, i:i + 1024], t(rd)[None, i:i + 1024], num_steps=64, bound=1.6, upsample_steps=64,
+                                bg_color=torch.ones(3, device=DEV), cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0) for i in range(0, 96 * 96, 1024)]
+    finally:
+        net.run_cuda = orig
+        net.occupancy_rounds = False
+    assert torch.equal(rgb1, rgb3) and torch.equal(ex1["weight_sum"], ex3["weight_sum"])
+    one = torch.cat([p["rgb"][0] for p in parts])
+    assert torch.equal(rgb1, one) and torch.equal(ex1["weight_sum"], torch.cat([p["weight_sum"] for p in parts]))
+    assert float((rgb1 - rgb2).abs().max()) <= 2e-5                  # (the loop of rounds: equal up to the one-ulp restarts documented above)
+    assert float(ex1["weight_sum"].max()) > 0.9

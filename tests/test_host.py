@@ -40,7 +40,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.ac_core_saved) == 9 * 8 and ctypes.sizeof(_lib.ac_core_upstream) == 5 * 8 and ctypes.sizeof(_lib.ac_core_grads) == 6 * 8 and _lib.ac_core_grads.split_level.offset == 5 * 8
     assert ctypes.sizeof(_lib.ac_adam_entry) == 40 and _lib.ac_adam_entry.n.offset == 32 and _lib.AC_ADAM_MAX_TENSORS == 16
     assert ctypes.sizeof(_lib.ac_wn_layer) == 40 and _lib.ac_wn_layer.rows.offset == 24 and ctypes.sizeof(_lib.ac_pg_entry) == 56 and _lib.ac_pg_entry.kind.offset == 52
-    assert _lib.ac_field.offsets.offset == 8 and _lib.ac_field.S.offset == 8 + 17 * 4 and _lib.ac_field.W1.offset == 88 and _lib.ac_field.prepared.offset == 88 + 7 * 8 and ctypes.sizeof(_lib.ac_field) == 88 + 8 * 8
+    assert _lib.ac_field.offsets.offset == 8 and _lib.ac_field.S.offset == 8 + 17 * 4 and _lib.ac_field.W1.offset == 88 and _lib.ac_field.prepared.offset == 88 + 7 * 8 and _lib.ac_field.Wc1_sh.offset == 88 + 8 * 8 and ctypes.sizeof(_lib.ac_field) == 88 + 9 * 8
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
