@@ -36,7 +36,7 @@ class ac_render_out(C.Structure):
 
 
 class ac_core_saved(C.Structure):
-    _fields_ = [("z_vals", vp), ("pts", vp), ("sdf", vp), ("sdf_out16", vp), ("gradient", vp), ("color", vp), ("eik_den", vp), ("feat7", vp), ("mask", vp)]
+    _fields_ = [("z_vals", vp), ("pts", vp), ("sdf", vp), ("sdf_out16", vp), ("gradient", vp), ("color", vp), ("eik_den", vp), ("feat7", vp), ("mask", vp), ("sh_bias", vp)]
 
 
 class ac_core_upstream(C.Structure):
@@ -45,7 +45,7 @@ class ac_core_upstream(C.Structure):
 
 class ac_core_grads(C.Structure):
     _fields_ = [("g_table", vp), ("g_sdf_params", vp), ("g_color_params", vp), ("g_inv_s_per_ray", vp), ("side_stream", vp), ("split_level", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("g_sh_tiles", vp)]
 
 
 class ac_wn_layer(C.Structure):
@@ -130,6 +130,8 @@ _SIGS = {
     "ac_render_rays_warped": ([C.POINTER(ac_field), C.POINTER(ac_render_opts), vp, vp, vp, vp, vp, vp, C.POINTER(ac_warp_mesh), vp, C.c_size_t,
                                C.POINTER(ac_render_out), vp], C.c_int),
     "ac_warp_samples": ([vp, vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp, vp, vp, vp, vp], C.c_int),
+    "ac_sh_bias": ([C.POINTER(ac_field), vp, u32, vp, vp, vp], C.c_int),
+    "ac_field_color_dirs": ([C.POINTER(ac_field), vp, vp, vp, vp, u32, vp, vp], C.c_int),
     "ac_field_sdf_grid": ([C.POINTER(ac_field), vp, vp, vp, u32, u32, u32, f32, C.c_int, vp, vp], C.c_int),
     "ac_marching_cubes_scratch": ([u32, u32, u32], C.c_size_t),
     "ac_marching_cubes_count": ([vp, u32, u32, u32, f32, vp, C.c_size_t, vp, vp], C.c_int),

@@ -665,7 +665,8 @@ __global__ __launch_bounds__(BLOCK) void field_sdf_kernel(const RenderArgs a, co
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void field_color_kernel(const RenderArgs a, const float *__restrict__ x,
+// dirs (use_viewdirs, with a.Wsh): the view direction of every point; the per-sample bias goes through a [4][64][4] slab per wave behind the weights
+__global__ __launch_bounds__(BLOCK) void field_color_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ dirs,
                                                             const float *__restrict__ nrm, const float *__restrict__ sdfout,
                                                             uint32_t B, float *__restrict__ rgb_out)
 {
@@ -674,10 +675,16 @@ __global__ __launch_bounds__(BLOCK) void field_color_kernel(const RenderArgs a, 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     const uint32_t ntiles = (B + 15) / 16;
+    float *slab = lds + OFF_WAVE + wave * 1024;
     for (uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + wave; tile < ntiles; tile += gridDim.x * WAVES_PER_BLOCK) {
         const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
         const f32x4 so = *reinterpret_cast<const f32x4 *>(sdfout + (size_t)bb * 16 + 4 * g);
         float rgb[3];
+        if (dirs) {
+            wave_sync();
+            sample_sh_bias(slab, a.Wsh, dirs[3 * bb], dirs[3 * bb + 1], dirs[3 * bb + 2], lane);
+            color_tile(lds, lane, x[3 * bb], x[3 * bb + 1], x[3 * bb + 2], nrm[3 * bb], nrm[3 * bb + 1], nrm[3 * bb + 2], so, rgb, slab + 4 * lane, 256);
+        } else
         color_tile(lds, lane, x[3 * bb], x[3 * bb + 1], x[3 * bb + 2], nrm[3 * bb], nrm[3 * bb + 1], nrm[3 * bb + 2], so, rgb);
         if (b < B && g == 0) { rgb_out[3 * b] = rgb[0]; rgb_out[3 * b + 1] = rgb[1]; rgb_out[3 * b + 2] = rgb[2]; }
     }
@@ -1126,18 +1133,28 @@ AC_API int ac_field_sdf(const ac_field *field, const float *x, uint32_t B, float
     return ac::check_launch("field_sdf");
 }
 
-AC_API int ac_field_color(const ac_field *field, const float *x, const float *n, const float *sdfout, uint32_t B, float *rgb,
-                          ac_stream_t stream)
+AC_API int ac_field_color_dirs(const ac_field *field, const float *x, const float *dirs, const float *n, const float *sdfout, uint32_t B, float *rgb,
+                               ac_stream_t stream)
 {
     if (B == 0) return AC_OK;
     if (!x || !n || !sdfout || !rgb) { ac::set_error("field_color: NULL buffer"); return AC_ERR_BAD_ARG; }
     RenderArgs a{};
     if (int rc = fill_args(a, field, 1.0f)) return rc;
+    if (a.Wsh && !dirs) { ac::set_error("field_color: the field has view-direction weights (ac_field.Wc1_sh): pass the directions (ac_field_color_dirs)"); return AC_ERR_BAD_ARG; }
+    if (!a.Wsh) dirs = nullptr;
     a.T0 = 0;
-    const size_t lds_bytes = OFF_WAVE * sizeof(float);
+    const size_t lds_bytes = (OFF_WAVE + (dirs ? WAVES_PER_BLOCK * 1024 : 0)) * sizeof(float);
+    static uint64_t seen = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(field_color_kernel), (OFF_WAVE + WAVES_PER_BLOCK * 1024) * sizeof(float));
     const uint32_t ntiles = (B + 15) / 16;
     uint32_t blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(field_color_kernel, dim3(blocks), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a, x, n, sdfout, B, rgb);
+    hipLaunchKernelGGL(field_color_kernel, dim3(blocks), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a, x, dirs, n, sdfout, B, rgb);
     return ac::check_launch("field_color");
+}
+
+AC_API int ac_field_color(const ac_field *field, const float *x, const float *n, const float *sdfout, uint32_t B, float *rgb,
+                          ac_stream_t stream)
+{
+    return ac_field_color_dirs(field, x, nullptr, n, sdfout, B, rgb, stream);
 }

@@ -544,7 +544,11 @@ __global__ __launch_bounds__(FBLOCK) void field_samples_kernel(const RenderArgs 
         const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
         const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
         float rgb[3];
-        color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
+        if (a.Wsh) {                                                 // use_viewdirs: the layer-1 bias of THIS sample's direction (wave-uniform branch)
+            wave_sync();                                             // (every lane is done with the feature slab)
+            sample_sh_bias(fsl, a.Wsh, dx, dy, dz, lane);
+            color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb, fsl + 4 * lane, 256);
+        } else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb);
         // NeuS alpha, instant_nsr.py:219-243 with the marcher's step as the section length
         const float sdf0 = oc[0];
         const float tc = (dx * nx + dy * ny) + dz * nz;
@@ -670,7 +674,11 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                 const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
                 const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
                 float rgb[3];
-                color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb);
+                if (a.Wsh) {
+                    wave_sync();
+                    sample_sh_bias(fsl, a.Wsh, dx, dy, dz, lane);
+                    color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb, fsl + 4 * lane, 256);
+                } else color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb);
                 const float tcos = (dx * nx + dy * ny) + dz * nz;
                 const float a1 = dv_softplus100(lds + OFF_SPQ, -tcos * 0.5f + 0.5f) * a.one_m_car;
                 const float a2 = dv_softplus100(lds + OFF_SPQ, -tcos) * a.car;
@@ -800,9 +808,14 @@ __device__ __forceinline__ void split_tiles(const f32x4 (&v)[4], u32x4 (&bh)[2],
 }
 #endif
 
+// use_viewdirs (sh_bias != NULL): sample b belongs to ray b / T (T a multiple of 16: a tile never straddles two rays); layer 1 of the recomputed forward
+// starts from the ray's bias sh_bias[ray][64] (ac_sh_bias: the forward's own bits, so the ReLU masks are the forward's), and the gradient of that bias --
+// the tile's sum over its 16 samples of d h1 -- goes to g_sh_tiles[tile][64]: d Wc1_sh = sum over rays of (sum of the ray's tiles) (x) sh(d_ray) is formed by
+// the caller (a [N, 64]^T x [N, 16] product: the direction is constant along a ray, there is nothing per sample to multiply).
 __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ nrm,
                                                            const float *__restrict__ sdf16, const float *__restrict__ g_rgb, uint32_t B,
-                                                           float *__restrict__ g_nrm, float *__restrict__ g_sdf16, float *__restrict__ partials)
+                                                           float *__restrict__ g_nrm, float *__restrict__ g_sdf16, float *__restrict__ partials,
+                                                           const float *__restrict__ sh_bias, uint32_t T, float *__restrict__ g_sh_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fill_lds(lds, a);
@@ -849,9 +862,11 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
         const float bxyz = sel4(g, px, py, pz, 0.0f), bn = sel4(g, nx, ny, nz, 0.0f);
         // forward recompute, activations kept: layers 1 and 2 with the instruction sequence of color_tile (fp32: the ReLU masks are the forward's own)
         f32x4 h1[4], h2[4];
+        const float *const shb = sh_bias ? sh_bias + (size_t)((tile * 16u) / T) * 64 + 4 * g : nullptr;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if (shb) acc = *reinterpret_cast<const f32x4 *>(shb + 16 * t);
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
                 const float bv = s < 4 ? so[s] : (s == 4 ? bxyz : bn);
@@ -922,6 +937,15 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = h1[t][r] > 0.0f ? acc[r] : 0.0f;
             dh1[t] = acc;
+        }
+        if (g_sh_tiles) {                                            // d bias of this tile: row sums over the 16 samples (dead samples of a ragged last tile: d h1 = 0, their upstream is 0)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 sm;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm[r] = row_scan<false>(dh1[t][r]);
+                if (n == 15) *reinterpret_cast<f32x4 *>(g_sh_tiles + (size_t)tile * 64 + 16 * t + 4 * g) = sm;
+            }
         }
 #if AC_COLORBWD_BF16
         split_tiles(dh1, gbh, gbl);
@@ -1386,6 +1410,7 @@ AC_API int ac_color_forward(const ac_field *field, const float *x, const float *
 {
     if (B == 0) return AC_OK;
     if (!x || !normal || !sdf16 || !rgb) { ac::set_error("color_forward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    if (field && field->Wc1_sh) { ac::set_error("color_forward: a field with view directions goes through ac_field_color_dirs / the fused renderer (the operator has no direction input)"); return AC_ERR_BAD_ARG; }
     RenderArgs a{};
     if (int rc = prep_color_args(a, field)) return rc;
     const size_t lds_bytes = OFF_WAVE * sizeof(float);
@@ -1401,8 +1426,45 @@ AC_API size_t ac_color_backward_scratch(uint32_t B)
     return (size_t)train_grid(B) * TW * NPART_C * sizeof(float);
 }
 
+// ---- use_viewdirs: per-ray layer-1 bias of the colour network, bias[r][u] = sum_j Wc1_sh[u][j] sh_j(rays_d[r]) -- the bits ac_render_rays forms in its prologue
+__global__ __launch_bounds__(256) void sh_bias_kernel(const float *__restrict__ Wsh, const float *__restrict__ rays_d, uint32_t N, float *__restrict__ bias,
+                                                      float *__restrict__ sh_out)
+{
+    __shared__ float slab[4][80];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t ray = blockIdx.x * 4 + wave; ray < N; ray += gridDim.x * 4) {
+        wave_sync();
+        ray_sh_bias(slab[wave], Wsh, rays_d[3 * (size_t)ray], rays_d[3 * (size_t)ray + 1], rays_d[3 * (size_t)ray + 2], lane);
+        bias[(size_t)ray * 64 + lane] = slab[wave][lane];
+        if (sh_out && lane < 16) sh_out[(size_t)ray * 16 + lane] = slab[wave][64 + lane];
+    }
+}
+
+AC_API int ac_sh_bias(const ac_field *field, const float *rays_d, uint32_t N, float *bias, float *sh, ac_stream_t stream)
+{
+    if (N == 0) return AC_OK;
+    if (!field || !field->Wc1_sh) { ac::set_error("sh_bias: the field has no view-direction weights (ac_field.Wc1_sh)"); return AC_ERR_BAD_ARG; }
+    if (!rays_d || !bias) { ac::set_error("sh_bias: NULL buffer"); return AC_ERR_BAD_ARG; }
+    uint32_t blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sh_bias_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, field->Wc1_sh, rays_d, N, bias, sh);
+    return ac::check_launch("sh_bias");
+}
+
+static int color_backward_impl(const ac_field *field, const float *x, const float *normal, const float *sdf16, const float *g_rgb, uint32_t B,
+                               float *g_normal, float *g_sdf16, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream,
+                               const float *sh_bias, uint32_t T, float *g_sh_tiles);
+
 AC_API int ac_color_backward(const ac_field *field, const float *x, const float *normal, const float *sdf16, const float *g_rgb, uint32_t B,
                              float *g_normal, float *g_sdf16, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream)
+{
+    if (field && field->Wc1_sh) { ac::set_error("color_backward: a field with view directions goes through ac_render_core_backward (the operator has no direction input)"); return AC_ERR_BAD_ARG; }
+    return color_backward_impl(field, x, normal, sdf16, g_rgb, B, g_normal, g_sdf16, gparams, scratch, scratch_bytes, stream, nullptr, 16, nullptr);
+}
+
+static int color_backward_impl(const ac_field *field, const float *x, const float *normal, const float *sdf16, const float *g_rgb, uint32_t B,
+                               float *g_normal, float *g_sdf16, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream,
+                               const float *sh_bias, uint32_t T, float *g_sh_tiles)
 {
     if (!gparams) { ac::set_error("color_backward: NULL gparams"); return AC_ERR_BAD_ARG; }
     if (B == 0) { hipMemsetAsync(gparams, 0, NPART_C * sizeof(float), (hipStream_t)stream); return AC_OK; }
@@ -1416,7 +1478,7 @@ AC_API int ac_color_backward(const ac_field *field, const float *x, const float 
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(color_bwd_kernel), lds_bytes);
     const uint32_t blocks = train_grid(B);
     hipLaunchKernelGGL(color_bwd_kernel, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, normal, sdf16, g_rgb, B, g_normal, g_sdf16,
-                       static_cast<float *>(scratch));
+                       static_cast<float *>(scratch), sh_bias, T ? T : 16u, g_sh_tiles);
     hipLaunchKernelGGL(partials_reduce_kernel, dim3((NPART_C + RED_OUT - 1) / RED_OUT), dim3(1024), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
                        blocks * TW, (uint32_t)NPART_C, gparams);
     return ac::check_launch("color_backward");
@@ -1526,8 +1588,12 @@ AC_API int ac_render_core_backward(const ac_field *field, const ac_render_opts *
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks), dim3(256), 0, st, a, up->g_image, up->g_weights_sum, up->g_depth, up->g_normal_map, g_sdf,
                            g_nrm_a, g_col, gr->g_inv_s_per_ray);
     }
-    if (int rc = ac_color_backward(field, sv->pts, nrm, sv->sdf_out16, g_col, B, g_nrm_b, g_s16, gr->g_color_params, sb + l.part_col,
-                                   ac_color_backward_scratch(B), stream)) return rc;
+    if ((field->Wc1_sh != nullptr) != (sv->sh_bias != nullptr) || (field->Wc1_sh != nullptr) != (gr->g_sh_tiles != nullptr)) {
+        ac::set_error("render_core_backward: a field with view directions (ac_field.Wc1_sh) needs ac_core_saved.sh_bias and ac_core_grads.g_sh_tiles, one without takes neither");
+        return AC_ERR_BAD_ARG;
+    }
+    if (int rc = color_backward_impl(field, sv->pts, nrm, sv->sdf_out16, g_col, B, g_nrm_b, g_s16, gr->g_color_params, sb + l.part_col,
+                                     ac_color_backward_scratch(B), stream, sv->sh_bias, (uint32_t)T, gr->g_sh_tiles)) return rc;
     hipLaunchKernelGGL(core_mid_kernel, dim3(eb), dim3(256), 0, st, sv->gradient, sv->pts, g_sdf, g_nrm_a, g_nrm_b, up->g_eik, sv->eik_den, B, g_s16, g_grad);
     if (int rc = sdf_stencil_backward_impl(field, sv->pts, g_s16, g_grad, B, op->bound, op->fd_eps, gfeat, gr->g_sdf_params, sb + l.part_sdf,
                                            ac_sdf_stencil_backward_scratch(B), stream, sv->feat7)) return rc;

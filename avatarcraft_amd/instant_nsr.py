@@ -154,8 +154,10 @@ class NeRFRenderer(nn.Module):
             return cached[1]
         with torch.no_grad():
             W = self._effective_weights()
+            Wc1, Wc1_sh = nsr_ops.split_viewdir_weight(W[2])          # use_viewdirs: [64,37] -> [x | n | feat] (21) + the 16 view-direction columns
             f = nsr_ops.Field(enc.embeddings.detach(), self._offsets_host(), enc.per_level_scale, enc.base_resolution,
-                              W[0], self.sdf_net[0].bias.detach().contiguous(), W[1], self.sdf_net[1].bias.detach().contiguous(), W[2], W[3], W[4])
+                              W[0], self.sdf_net[0].bias.detach().contiguous(), W[1], self.sdf_net[1].bias.detach().contiguous(), Wc1, W[3], W[4],
+                              Wc1_sh=Wc1_sh)
         f.prepare()                     # the weights in LDS order, once per parameter version (every render workgroup then copies them linearly)
         self._field_cache = (key, f)
         return f
@@ -272,8 +274,11 @@ class NeRFRenderer(nn.Module):
         for t in prm:
             if t.grad is None:
                 t.grad = torch.zeros_like(t)
-        g_sdf_p, g_col_p, g_invs = nsr_ops.render_core_backward(field, out.opts, out, ro, rd, bg, g_image, g_weights_sum, None, None, g_eik, enc.embeddings.grad,
-                                                                split=split)
+        g_sdf_p, g_col_p, g_invs, *g_vd = nsr_ops.render_core_backward(field, out.opts, out, ro, rd, bg, g_image, g_weights_sum, None, None, g_eik,
+                                                                       enc.embeddings.grad, split=split)
+        c0_src, c0_stride = (g_col_p, 0), 32
+        if g_vd:                                                 # use_viewdirs: the gradient of the [64,37] effective matrix, columns in the reference's order
+            c0_src, c0_stride = (nsr_ops.join_viewdir_grad(g_col_p[:2048].view(64, 32)[:, :21], g_vd[0]).contiguous(), 0), 37
         s0, s1, c0, c1, c2 = self.sdf_net[0], self.sdf_net[1], self.color_net[0], self.color_net[1], self.color_net[2]
         WN, ADD, VAR = nsr_ops.PG_WEIGHT_NORM, nsr_ops.PG_ADD, nsr_ops.PG_VARIANCE
         var = self.deviation_net.variance
@@ -281,10 +286,11 @@ class NeRFRenderer(nn.Module):
             inv_s = self.forward_variance()
         wn = lambda src, off, stride, l: (WN, (src, off), stride, l.weight_v.shape[0], l.weight_v.shape[1], l.weight_v.detach(), l.weight_g.detach(),
                                           l.weight_v.grad, l.weight_g.grad)
+        wn_c0 = (WN, c0_src, c0_stride, c0.weight_v.shape[0], c0.weight_v.shape[1], c0.weight_v.detach(), c0.weight_g.detach(), c0.weight_v.grad, c0.weight_g.grad)
         nsr_ops.param_grads([
             wn(g_sdf_p, 0, 36, s0), (ADD, (g_sdf_p, 35), 36, 64, 1, None, None, s0.bias.grad, None),
             wn(g_sdf_p, 64 * 36, 64, s1), (ADD, (g_sdf_p, 64 * 36 + 1024), 1, 16, 1, None, None, s1.bias.grad, None),
-            wn(g_col_p, 0, 32, c0), wn(g_col_p, 2048, 64, c1), wn(g_col_p, 6144, 64, c2),
+            wn_c0, wn(g_col_p, 2048, 64, c1), wn(g_col_p, 6144, 64, c2),
             (VAR, g_invs, 1, g_invs.shape[0], 1, None, inv_s.reshape(-1), var.grad.reshape(-1), None)], ro.device)
         # the kernels wrote the gradients through raw pointers: bump their version counters, so that anything keyed on them -- stylize.Adam.grads_cleared --
         # sees that the buffers are no longer what they were (views of one flat buffer share a counter: one bump per distinct base is enough)
@@ -327,10 +333,17 @@ class NeRFRenderer(nn.Module):
         return (self.include_input and self.num_layers == 2 and self.hidden_dim == 64 and self.geo_feat_dim == 15 and hasattr(enc, "embeddings")
                 and enc.num_levels == 16 and enc.level_dim == 2 and enc.input_dim == 3)
 
+    def _viewdirs_supported(self):
+        """use_viewdirs=True as the reference builds it: the degree-4 spherical-harmonics encoder of the ray direction (16 values) in front of the
+        colour network (models/instant_nsr.py:565-569: in_dim_color = 16 + 15 + 6 = 37)"""
+        e = getattr(self, "encoder_dir", None)
+        return getattr(e, "degree", None) == 4 and getattr(e, "output_dim", None) == 16 and self.in_dim_color == 37
+
     def _fused_supported(self):
-        """the whole default model: no view directions (colour net 21-64-64-3), no curvature term"""
-        return (self._sdf_supported() and not self.use_viewdirs and self.num_layers_color == 3 and self.hidden_dim_color == 64
-                and not self.curvature_loss)
+        """the default model (colour net 21-64-64-3), or the same with view directions (37-64-64-3: the renderer folds the 16 spherical harmonics of the ray
+        direction into a per-ray bias of colour layer 1, ac_field.Wc1_sh); no curvature term"""
+        return (self._sdf_supported() and (not self.use_viewdirs or self._viewdirs_supported()) and self.num_layers_color == 3
+                and self.hidden_dim_color == 64 and not self.curvature_loss)
 
     def _field_sdf_only(self):
         """ac_field with the SDF side only (zero colour matrices): the sampling stage of a model whose colour net the fused renderer does not cover"""
@@ -383,7 +396,7 @@ class NeRFRenderer(nn.Module):
             if needs_grad and self.fused_training != "core":
                 raise NotImplementedError("posed-space rendering under autograd runs through the fused operator only (fused_training = 'core')")
             if not full:
-                raise NotImplementedError("posed-space rendering is built for the default NeRFNetwork (use_viewdirs=False, no curvature term)")
+                raise NotImplementedError("posed-space rendering is built for the default NeRFNetwork (with or without view directions; no curvature term)")
             if verts is None or faces is None or Ts is None:
                 raise RuntimeError("render_can=False needs verts, faces and Ts")
             warp = verts if isinstance(verts, nsr_ops.WarpMesh) else nsr_ops.WarpMesh(verts, faces, Ts, device, DEFAULT_GEO_THRESH,
@@ -430,7 +443,8 @@ class NeRFRenderer(nn.Module):
             nm, fm = near_far[0].reshape(-1, 1), near_far[1].reshape(-1, 1)
             near = torch.where(torch.isinf(nm), near, nm)
             far = torch.where(torch.isinf(fm), far, fm)
-        fused_ops = bool(self.fused_training) and self._fused_supported() and near_far is None
+        # (the stand-alone colour operator has no direction input: a model with view directions keeps torch's colour network on this path)
+        fused_ops = bool(self.fused_training) and self._fused_supported() and near_far is None and not self.use_viewdirs
         sample_dist = (far - near) / num_steps0
         T = num_steps0 + upsample_steps
         deltas = z_vals[:, 1:] - z_vals[:, :-1]
@@ -519,7 +533,7 @@ class NeRFRenderer(nn.Module):
         if not render_can:
             raise NotImplementedError("the occupancy grid lives in canonical space: cuda_ray renders render_can=True only")
         if not self._fused_supported():
-            raise NotImplementedError("run_cuda is built for the default NeRFNetwork (use_viewdirs=False, no curvature term)")
+            raise NotImplementedError("run_cuda is built for the default NeRFNetwork (with or without view directions; no curvature term)")
         fd_eps = 0.005 * (1.0 - normal_epsilon_ratio)
         if not fd_eps > 0.0:
             raise RuntimeError("run_cuda: normal_epsilon_ratio must be < 1 (finite-difference step 0.005 * (1 - ratio) > 0)")
@@ -548,7 +562,10 @@ class NeRFRenderer(nn.Module):
                 sdf_out, gradient = nsr_ops.sdf_stencil(xyzs, enc.embeddings, W[0], self.sdf_net[0].bias, W[1], self.sdf_net[1].bias, self._offsets_host(),
                                                         enc.per_level_scale, enc.base_resolution, bound, fd_eps)
                 normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
-                rgbs = nsr_ops.color_mlp(xyzs, normal, sdf_out, W[2], W[3], W[4])
+                if self.use_viewdirs:                            # (the stand-alone colour operator has no direction input: torch's colour network here)
+                    rgbs = self.forward_color(xyzs, dirs, normal, sdf_out[:, 1:], bound)
+                else:
+                    rgbs = nsr_ops.color_mlp(xyzs, normal, sdf_out, W[2], W[3], W[4])
                 true_cos = (dirs * normal).sum(-1, keepdim=True)
                 act = nn.Softplus(beta=100)
                 iter_cos = -(act(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + act(-true_cos) * cos_anneal_ratio)

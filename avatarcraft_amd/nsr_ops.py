@@ -369,7 +369,8 @@ class _RenderCore(torch.autograd.Function):
         offsets, pls, H, T0, up, bound, car, ner, precision, warp = cfg
         ctx.set_materialize_grads(False)              # an output the loss does not use arrives as None -> a NULL upstream pointer
         d = lambda t: t.detach().contiguous()
-        field = Field(d(table), offsets, pls, H, d(W1), d(b1), d(W2), d(b2), d(Wc1), d(Wc2), d(Wc3)).prepare()
+        Wc1_21, Wc1_sh = split_viewdir_weight(d(Wc1))           # use_viewdirs: [64,37] -> the 21 per-sample columns + the 16 view-direction columns
+        field = Field(d(table), offsets, pls, H, d(W1), d(b1), d(W2), d(b2), Wc1_21, d(Wc2), d(Wc3), Wc1_sh=Wc1_sh).prepare()
         # warp = WarpMesh: posed space (run(render_can=False), instant_nsr.py:166-172,198-207,246-249) -- the launch sequence of an inference render
         # (sampling, SMPL inverse warp, final pass; every sample evaluated: skip_masked off) with the per-sample outputs kept.  The warped points,
         # the mask and the mesh-guided range are constants of the differentiation, as in the reference (the warp is numpy there).
@@ -420,11 +421,15 @@ class _RenderCore(torch.autograd.Function):
         gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
         scratch, need = core_scratch(field, N, T, dev)
         op = ctx.opts[0]
+        vd = _viewdir_args(field, rays_d, N, T, sv, gr)
         L.check(L.lib().ac_render_core_backward(C.byref(field.c), C.byref(op), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), C.byref(sv), C.byref(upg),
                                                 C.byref(gr), scratch.data_ptr(), need, L.current_stream(dev)), "render_core_backward")
         gW1b = g_sdf_p[:64 * 36].view(64, 36)
+        g_Wc1 = g_col_p[:2048].view(64, 32)[:, :21]
+        if vd is not None:
+            g_Wc1 = join_viewdir_grad(g_Wc1, _viewdir_weight_grad(vd, N, T))
         return (None if in_place else g_table, gW1b[:, :35], gW1b[:, 35], g_sdf_p[64 * 36:64 * 36 + 1024].view(16, 64), g_sdf_p[64 * 36 + 1024:],
-                g_col_p[:2048].view(64, 32)[:, :21], g_col_p[2048:6144].view(64, 64), g_col_p[6144:].view(16, 64)[:3],
+                g_Wc1, g_col_p[2048:6144].view(64, 64), g_col_p[6144:].view(16, 64)[:3],
                 g_invs.sum().reshape(ctx.inv_s_shape), None, None, None, None, None)
 
 
@@ -516,9 +521,56 @@ def sds_upstream(weights_sum, weights_sum_gt, scale, want_grad=True):
     return g, loss
 
 
+VIEWDIR_COLS = 16                      # degree-4 spherical harmonics of the ray direction: columns 3 .. 18 of a use_viewdirs color_net.0 weight [64, 37]
+
+
+def split_viewdir_weight(Wc1):
+    """the effective color_net.0 weight of NeRFNetwork(use_viewdirs=True), [64, 37] = [x(3) | sh(d)(16) | normal(3) | geo_feat(15)] (models/instant_nsr.py:648-650)
+    -> (Wc1 [64,21] = [x | normal | geo_feat] as the fused kernels keep it, Wc1_sh [64,16]); a [64,21] weight -> (Wc1, None)"""
+    if Wc1.shape[1] == 21:
+        return Wc1, None
+    if Wc1.shape[1] != 21 + VIEWDIR_COLS:
+        raise RuntimeError(f"colour layer 1 has {Wc1.shape[1]} inputs: the fused renderer takes 21 (no view directions) or 37 (degree-4 spherical harmonics)")
+    return torch.cat([Wc1[:, :3], Wc1[:, 3 + VIEWDIR_COLS:]], dim=1).contiguous(), Wc1[:, 3:3 + VIEWDIR_COLS].contiguous()
+
+
+def join_viewdir_grad(g21, g_sh):
+    """inverse of split_viewdir_weight for gradients: ([64,21], [64,16]) -> [64,37]"""
+    return torch.cat([g21[:, :3], g_sh, g21[:, 3:]], dim=1)
+
+
+def sh_bias(field, rays_d, want_sh=True):
+    """ac_sh_bias: the per-ray layer-1 bias of the colour network for the view directions rays_d [N,3] -> (bias [N,64], sh [N,16] or None)"""
+    rays_d = _chk(rays_d.reshape(-1, 3), "rays_d")
+    N, dev = rays_d.shape[0], rays_d.device
+    bias = torch.empty((N, 64), dtype=_F32, device=dev)
+    sh = torch.empty((N, VIEWDIR_COLS), dtype=_F32, device=dev) if want_sh else None
+    L.check(L.lib().ac_sh_bias(C.byref(field.c), rays_d.data_ptr(), N, bias.data_ptr(), L.ptr(sh), L.current_stream(dev)), "sh_bias")
+    return bias, sh
+
+
+def _viewdir_args(field, rays_d, N, T, sv, gr):
+    """a field with view directions: fill ac_core_saved.sh_bias / ac_core_grads.g_sh_tiles; returns what viewdir_weight_grad needs (None otherwise)"""
+    if not getattr(field, "has_viewdirs", False):
+        return None
+    bias, sh = sh_bias(field, rays_d)
+    tiles = torch.empty((N * T // 16, 64), dtype=_F32, device=rays_d.device)
+    sv.sh_bias, gr.g_sh_tiles = bias.data_ptr(), tiles.data_ptr()
+    return bias, sh, tiles
+
+
+def _viewdir_weight_grad(vd, N, T):
+    """d Wc1_sh [64,16] = sum over rays of (the ray's T / 16 tile rows of g_sh_tiles, summed) (x) sh(d_ray)"""
+    if vd is None:
+        return None
+    _, sh, tiles = vd
+    return tiles.view(N, T // 16, 64).sum(1).t().matmul(sh)
+
+
 def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, g_depth, g_nmap, g_eik, g_table, split=None):
     """ac_render_core_backward on the outputs of a render_rays(..., train_extras=True) launch (`out`, its .opts): the table gradient is accumulated
-    into g_table; returns (g_sdf_params [3344], g_color_params [7168], g_inv_s_per_ray [N]) w.r.t. the EFFECTIVE matrices.
+    into g_table; returns (g_sdf_params [3344], g_color_params [7168], g_inv_s_per_ray [N][, g_Wc1_sh [64,16] for a field with view directions]) w.r.t. the
+    EFFECTIVE matrices.
     split = (level, torch.cuda.Stream): the scatter completes the table gradient of levels >= level first and orders that stream behind exactly that
     (ac_core_grads.side_stream / split_level): work enqueued there afterwards (the all-reduce of that slice) overlaps the rest of the backward."""
     z_vals = out["z_vals"]
@@ -536,8 +588,11 @@ def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, 
     if split is not None:
         gr.split_level, gr.side_stream = int(split[0]), int(split[1].cuda_stream)
     scratch, need = core_scratch(field, N, T, dev)
+    vd = _viewdir_args(field, rays_d, N, T, sv, gr)
     L.check(L.lib().ac_render_core_backward(C.byref(field.c), C.byref(opts[0]), rays_o.data_ptr(), rays_d.data_ptr(), L.ptr(bg), C.byref(sv), C.byref(upg),
                                             C.byref(gr), scratch.data_ptr(), need, L.current_stream(dev)), "render_core_backward")
+    if vd is not None:
+        return g_sdf_p, g_col_p, g_invs, _viewdir_weight_grad(vd, N, T)            # (+ d Wc1_sh [64,16] for a field with view directions)
     return g_sdf_p, g_col_p, g_invs
 
 
@@ -744,12 +799,14 @@ def field_sdf(field, x, bound):
     return out
 
 
-def field_color(field, x, n, sdfout):
-    """forward_color (instant_nsr.py:644-663), use_viewdirs=False: -> rgb [B,3]"""
+def field_color(field, x, n, sdfout, dirs=None):
+    """forward_color (instant_nsr.py:644-663): -> rgb [B,3]; dirs [B,3] = the view direction of every point for a field with view directions"""
     x = _chk(x.reshape(-1, 3), "x"); n = _chk(n.reshape(-1, 3), "n"); sdfout = _chk(sdfout.reshape(-1, 16), "sdfout")
+    if dirs is not None:
+        dirs = _chk(dirs.reshape(-1, 3), "dirs", (x.shape[0], 3))
     out = torch.empty((x.shape[0], 3), dtype=_F32, device=x.device)
-    L.check(L.lib().ac_field_color(C.byref(field.c), x.data_ptr(), n.data_ptr(), sdfout.data_ptr(), x.shape[0], out.data_ptr(),
-                                   L.current_stream(x.device)), "field_color")
+    L.check(L.lib().ac_field_color_dirs(C.byref(field.c), x.data_ptr(), L.ptr(dirs), n.data_ptr(), sdfout.data_ptr(), x.shape[0], out.data_ptr(),
+                                        L.current_stream(x.device)), "field_color")
     return out
 
 

@@ -402,6 +402,49 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     return res
 
 
+def time_viewdirs(dev, p, table, ro_t, rd_t, steps=8):
+    """NeRFNetwork(use_viewdirs=True) (models/instant_nsr.py:565-569, 644-653: colour layer 1 reads cat[x, sh(d), n, geo_feat]) through the same fused paths as
+    the default model: the 16 spherical harmonics of the ray direction are folded into a per-ray bias of colour layer 1 in the renderer's prologue, so the
+    headline launch and the SDS step should cost what they cost without view directions (round 4: 2.1x / 2.2x through the generic path)."""
+    from avatarcraft_amd import nsr_ops
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view, Adam
+
+    def make(train):
+        torch.manual_seed(0)
+        net = NeRFNetwork(use_viewdirs=True)
+        sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net.1", "color_net.2", "deviation_net"))}
+        sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
+        net.load_state_dict(sd, strict=False)                    # (color_net.0 keeps its own [64,37] initialisation)
+        return net.to(dev).train(train)
+    net = make(False)
+    with torch.no_grad():
+        f, inv_s = net._field(), net.forward_variance()
+        out = {}
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for k in range(24):
+            b = k % 16
+            sl = slice(b * RAYS_PER_BATCH, (b + 1) * RAYS_PER_BATCH)
+            nsr_ops.render_rays(f, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=out, events=evs[k - 4] if k >= 4 else None)
+        torch.cuda.synchronize()
+        k_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs]))
+    net, net_gt = make(True), make(False)
+    opt = Adam(net.parameters(), lr=5e-3, zero_grad_in_step=True)
+    flat = flat_grad_view(net.parameters())
+    guide = SyntheticGuidance(42)
+    so, sd_ = sds_view(0)
+    so, sd_ = torch.from_numpy(so).to(dev), torch.from_numpy(sd_).to(dev)
+    for _ in range(2):
+        sds_step(net, net_gt, so, sd_, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sds_step(net, net_gt, so, sd_, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
+    torch.cuda.synchronize()
+    return {"render_kernel_ms_per_4096_rays": k_ms, "rays_per_s": RAYS_PER_BATCH / (k_ms * 1e-3), "sds_step_ms": (time.perf_counter() - t0) / steps * 1e3,
+            "note": "use_viewdirs=True: sh(d) of degree 4 folded into a per-ray bias of colour layer 1 (ac_field.Wc1_sh); compare with the headline's kernel_ms and sds_step.ms_per_step"}
+
+
 def time_geometry(dev, p, table, reps=3):
     """SURVEY 8(f) rank 3 at the reference's own sizes: the mesh export -- extract_geometry(NSR_BOUND, 512) (stylize.py:267: 512^3 = 134 M forward_sdf
     queries + marching cubes) -- and the density-grid update of update_extra_state (129^3 queries -> density -> max pool -> merge -> mean), both on the
@@ -770,6 +813,7 @@ def main():
     ap.add_argument("--sd-arch-steps", type=int, default=2, help="time this many SDS steps with a guidance of Stable-Diffusion 1.5's architecture (random weights: "
                                                                   "what the step costs once the real UNet is in it); 0 = skip")
     ap.add_argument("--no-occupancy", action="store_true", help="skip the occupancy-grid render leg (render(cuda_ray=True): a separate figure beside the headline)")
+    ap.add_argument("--no-viewdirs", action="store_true", help="skip the use_viewdirs=True leg (the same render launch and SDS step with view directions)")
     ap.add_argument("--no-fine-view", action="store_true", help="skip the fine-stage leg (one optimizer step on a full 256 x 256 view = 16 patches)")
     ap.add_argument("--no-geometry", action="store_true", help="skip the mesh-export (512^3 + marching cubes) and density-grid-update legs")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
@@ -961,6 +1005,15 @@ def main():
             except Exception as e:             # noqa: BLE001
                 import traceback
                 res["sds_view_fine"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-600:]}
+        if world == 1 and not a.no_viewdirs:
+            try:
+                res["viewdirs"] = time_viewdirs(dev, p, table, ro_t, rd_t)
+                res["viewdirs"]["render_vs_default"] = res["viewdirs"]["render_kernel_ms_per_4096_rays"] / kern_ms
+                if sds is not None and "error" not in sds:
+                    res["viewdirs"]["sds_step_vs_default"] = res["viewdirs"]["sds_step_ms"] / sds["ms_per_step"]
+            except Exception as e:             # noqa: BLE001
+                import traceback
+                res["viewdirs"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-600:]}
         if world == 1 and not a.no_geometry:
             try:
                 res.update(time_geometry(dev, p, table))

@@ -410,6 +410,14 @@ size_t ac_density_grid_update_scratch(uint32_t H);
 int ac_density_grid_update(const ac_field *field, const float *axis, uint32_t H, float bound, float inv_s, float decay, float *grid,
                            double *mean_out, void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
+/* use_viewdirs: the per-ray layer-1 bias of the colour network the renderer forms in its prologue, bias[r][u] = fma chain over j = 0..15 of
+ * Wc1_sh[u][j] sh_j(rays_d[r]) (sh = the degree-4 values of ac_sh_encode_forward on the raw direction), as its own launch: bias [N,64], sh [N,16] or NULL.
+ * What ac_render_core_backward needs beside the forward's outputs (ac_core_saved.sh_bias) and what turns its g_sh_tiles into d Wc1_sh. */
+int ac_sh_bias(const ac_field *field, const float *rays_d, uint32_t N, float *bias, float *sh, ac_stream_t stream);
+/* ac_field_color with the view direction of every point: dirs [B,3] (required when field->Wc1_sh is set, ignored otherwise) */
+int ac_field_color_dirs(const ac_field *field, const float *x, const float *dirs, const float *n, const float *sdfout, uint32_t B, float *rgb,
+                        ac_stream_t stream);
+
 /* ---- colour MLP of the render core (training path): forward_color (models/instant_nsr.py:644-663, use_viewdirs = False)
  * rgb = sigmoid(Wc3 relu(Wc2 relu(Wc1 [x, normal, feat]))) with feat = sdf16[:, 1:16].
  * forward : same values as ac_field_color / ac_render_rays.   backward: recomputes the forward per tile of 16 samples and returns
@@ -452,6 +460,8 @@ typedef struct ac_core_saved {
                                                                            * alpha mask [N,T] (instant_nsr.py:246-249), with opts->near_m / far_m =
                                                                            * the forward's mesh-guided range and `pts` = the warped points the
                                                                            * forward kept; NULL = canonical space (ABI version 4)                  */
+    const float *sh_bias;                                                 /* a field with view directions (ac_field.Wc1_sh) only: ac_sh_bias of the
+                                                                           * forward's rays, [N,64]; NULL otherwise (ABI version 6)                  */
 } ac_core_saved;
 typedef struct ac_core_upstream { const float *g_image, *g_weights_sum, *g_depth, *g_normal_map, *g_eik; } ac_core_upstream;
 typedef struct ac_core_grads {
@@ -463,6 +473,9 @@ typedef struct ac_core_grads {
     ac_stream_t side_stream;
     int32_t split_level;
     int32_t reserved;
+    float *g_sh_tiles;        /* a field with view directions only: [N * T / 16, 64], per tile of 16 samples the sum of d (layer-1 pre-activation of the colour
+                               * network) = the gradient of that tile's share of its ray's view-direction bias.  d Wc1_sh [64,16] = sum over rays r of
+                               * (sum of the ray's T / 16 rows) (x) sh(rays_d[r]) (sh from ac_sh_bias): the caller's [N,64]^T x [N,16] product (ABI version 6) */
 } ac_core_grads;
 size_t ac_render_core_backward_scratch(const ac_field *field, int32_t n_rays, int32_t T);
 int ac_render_core_backward(const ac_field *field, const ac_render_opts *opts, const float *rays_o, const float *rays_d, const float *bg,

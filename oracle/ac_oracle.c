@@ -357,13 +357,28 @@ static float field_sdf_only(const orc_field *f, const float x[3], float bound)
  *   layer 1: acc=0; for r=0..3, g=0..3: SDF-MLP output o=4g+r (o=0, the sdf itself,
  *            enters with weight 0); then (x,y,z,0); then (nx,ny,nz,0);
  *   layers 2,3: for t,r,g: hidden unit 16t+4g+r. */
-static void orc_color_mlp(const orc_field *f, const float x[3], const float n[3],
-                          const float sdfout[16], float rgb[3])
+/* use_viewdirs (f->Wsh, models/instant_nsr.py:644-653): h = cat[x, sh(d), n, feat].  The direction is constant along a ray, so its share of layer 1 is a
+ * per-ray bias: bias[u] = fma chain over j = 0..15 of Wsh[u][j] * sh_j(d) from 0, and unit u's accumulator STARTS from bias[u]; then the 21 inputs in the
+ * order above.  (versus the reference's single 37-term dot product: an fp32 re-association.)  d == NULL or f->Wsh == NULL: no view directions. */
+static void orc_color_bias(const orc_field *f, const float d[3], float bias[64])
 {
-    float h1[64], h2[64];
+    float sh[16];
+    orc_sh16(d, sh);
+    for (int u = 0; u < 64; u++) {
+        float acc = 0.0f;
+        for (int j = 0; j < 16; j++) acc = fmaf(f->Wsh[u * 16 + j], sh[j], acc);
+        bias[u] = acc;
+    }
+}
+static void orc_color_mlp_d(const orc_field *f, const float x[3], const float n[3],
+                            const float sdfout[16], const float *d, float rgb[3])
+{
+    float h1[64], h2[64], bias[64];
+    const int vd = f->Wsh != NULL && d != NULL;
+    if (vd) orc_color_bias(f, d, bias);
     for (int u = 0; u < 64; u++) {
         const float *w = f->Wc1 + u * 21;
-        float acc = 0.0f;
+        float acc = vd ? bias[u] : 0.0f;
         for (int r = 0; r < 4; r++)
             for (int g = 0; g < 4; g++) {
                 int o = 4 * g + r;
@@ -394,6 +409,11 @@ static void orc_color_mlp(const orc_field *f, const float x[3], const float n[3]
     }
 }
 
+static void orc_color_mlp(const orc_field *f, const float x[3], const float n[3], const float sdfout[16], float rgb[3])
+{
+    orc_color_mlp_d(f, x, n, sdfout, NULL, rgb);
+}
+
 static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* standalone entry points used by the unit tests */
@@ -408,6 +428,13 @@ ORC_API void orc_field_color(const orc_field *f, const float *x, const float *n,
     #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < (int64_t)B; b++)
         orc_color_mlp(f, x + 3 * b, n + 3 * b, sdfout + 16 * b, rgb + 3 * b);
+}
+ORC_API void orc_field_color_dirs(const orc_field *f, const float *x, const float *dirs, const float *n, const float *sdfout,
+                                  uint32_t B, float *rgb)
+{
+    #pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++)
+        orc_color_mlp_d(f, x + 3 * b, n + 3 * b, sdfout + 16 * b, dirs ? dirs + 3 * b : NULL, rgb + 3 * b);
 }
 /* Field evaluation on packed samples: the body of the (undefined) NeRFRenderer.run_cuda that models/instant_nsr.py:362-363 dispatches to, between
  * raymarching.march_rays[_train] and composite_rays[_train] -- run()'s render core per sample with the marcher's step as the section length:
@@ -434,7 +461,7 @@ ORC_API void orc_field_samples(const orc_field *f, const float *xyzs, const floa
         }
         const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
         for (int k = 0; k < 3; k++) nn[k] = g[k] / (1e-5f + gn);
-        orc_color_mlp(f, p, nn, s16, rgb + 3 * b);
+        orc_color_mlp_d(f, p, nn, s16, d, rgb + 3 * b);
         const float tc = (d[0] * nn[0] + d[1] * nn[1]) + d[2] * nn[2];
         const float a1 = orc_softplus100(-tc * 0.5f + 0.5f) * one_m_car;
         const float a2 = orc_softplus100(-tc) * car;
@@ -707,7 +734,7 @@ static void render_one_ray(const orc_field *f, const orc_render_opts *op, const 
         float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
         float nn[3];
         for (int k = 0; k < 3; k++) nn[k] = g[k] / (1e-5f + gn);        /* :215 */
-        orc_color_mlp(f, p, nn, s16, col[i]);                           /* :217 */
+        orc_color_mlp_d(f, p, nn, s16, d, col[i]);                      /* :217 (d: the world-space ray direction, also in posed space: quirk C.2) */
         float tc = (d[0] * nn[0] + d[1] * nn[1]) + d[2] * nn[2];        /* :222 */
         float a1 = orc_softplus100(-tc * 0.5f + 0.5f) * one_m_car;
         float a2 = orc_softplus100(-tc) * car;

@@ -19,7 +19,13 @@ typedef struct {
     const float *Wc1;          /* color_net.0: [64,21] */
     const float *Wc2;          /* color_net.1: [64,64] */
     const float *Wc3;          /* color_net.2: [3,64] */
+    const float *Wsh;          /* NeRFNetwork(use_viewdirs=True) only, else NULL: the 16 columns of color_net.0 that multiply sh(d) -- the degree-4 spherical
+                                * harmonics of the raw ray direction (models/instant_nsr.py:565-569, 644-653: h = cat[x, sh(d), n, geo_feat]) -- [64,16];
+                                * Wc1 then holds the other 21 columns (x, n, geo_feat) */
 } orc_field;
+
+/* degree-4 spherical harmonics of a raw direction: the first 16 values of orc_sh_encode_forward (encoder/shencoder/src/shencoder.cu:28-...), same operations */
+void orc_sh16(const float d[3], float sh[16]);
 
 /* NeRFRenderer.run options (models/instant_nsr.py:133-299) */
 typedef struct {

@@ -47,7 +47,8 @@
 
 typedef struct {
     double *g_table;     /* [n_entries * 2], accumulated into (caller zero-fills) */
-    double *g_params;    /* [NPAR]: W1 [64,35], b1 [64], W2 [16,64], b2 [16], Wc1 [64,21], Wc2 [64,64], Wc3 [3,64]; overwritten */
+    double *g_params;    /* [NPAR]: W1 [64,35], b1 [64], W2 [16,64], b2 [16], Wc1 [64,21], Wc2 [64,64], Wc3 [3,64]; overwritten.  A field with view
+                          * directions (orc_field.Wsh): [NPAR + 1024], the last 1024 = d Wsh [64,16] */
     double *g_inv_s;     /* [1]; overwritten */
     double *fwd;         /* optional [N, 8]: image (3), weights_sum, depth, normal_map (3) of the fp64 forward (cross-check with orc_render_rays) */
     double *gradient_error; /* optional [1]: the fp64 forward's gradient_error */
@@ -148,12 +149,14 @@ static void sdf_backward(const orc_field *f, const float x[3], const enc_geo *g,
 
 typedef struct { double in[21], p1[64], h1[64], p2[64], h2[64], o[3], rgb[3]; } col_fwd;
 
-static void color_forward(const orc_field *f, const float x[3], const double n[3], const double *sdf_out, col_fwd *c)
+/* sh: the 16 spherical harmonics of the ray direction in double (from the fp32 values of orc_sh16: constants of the differentiation), or NULL */
+static void color_forward(const orc_field *f, const float x[3], const double n[3], const double *sdf_out, const double *sh, col_fwd *c)
 {
     for (int k = 0; k < 3; k++) { c->in[k] = x[k]; c->in[3 + k] = n[k]; }
     for (int k = 0; k < 15; k++) c->in[6 + k] = sdf_out[1 + k];
     for (int u = 0; u < 64; u++) {
         double acc = 0.0;
+        if (sh) for (int j = 0; j < 16; j++) acc += (double)f->Wsh[u * 16 + j] * sh[j];
         for (int k = 0; k < 21; k++) acc += (double)f->Wc1[u * 21 + k] * c->in[k];
         c->p1[u] = acc; c->h1[u] = acc > 0.0 ? acc : 0.0;
     }
@@ -170,7 +173,8 @@ static void color_forward(const orc_field *f, const float x[3], const double n[3
 }
 
 /* g_rgb -> parameter gradients, g_n (normal, accumulated), g_feat (sdf_out[1..15], accumulated into g_sdf_out[1..]) */
-static void color_backward(const orc_field *f, const col_fwd *c, const double g_rgb[3], double *gp, double g_n[3], double *g_sdf_out)
+static void color_backward(const orc_field *f, const col_fwd *c, const double g_rgb[3], double *gp, double g_n[3], double *g_sdf_out,
+                           const double *sh, double *g_wsh)
 {
     double g_h2[64], g_h1[64], g_in[21];
     memset(g_h2, 0, sizeof g_h2); memset(g_h1, 0, sizeof g_h1); memset(g_in, 0, sizeof g_in);
@@ -185,6 +189,7 @@ static void color_backward(const orc_field *f, const col_fwd *c, const double g_
     for (int u = 0; u < 64; u++) {
         if (!(c->p1[u] > 0.0)) continue;
         for (int k = 0; k < 21; k++) { gp[OFF_C1 + u * 21 + k] += g_h1[u] * c->in[k]; g_in[k] += g_h1[u] * (double)f->Wc1[u * 21 + k]; }
+        if (sh && g_wsh) for (int j = 0; j < 16; j++) g_wsh[u * 16 + j] += g_h1[u] * sh[j];
     }
     for (int k = 0; k < 3; k++) g_n[k] += g_in[3 + k];
     for (int k = 0; k < 15; k++) g_sdf_out[1 + k] += g_in[6 + k];
@@ -255,17 +260,20 @@ ORC_API int orc_render_core_backward_posed(const orc_field *f, const orc_render_
         }
     }
     e_den += 1e-5;
-    memset(out->g_params, 0, NPAR * sizeof(double));
+    const int NPV = NPAR + (f->Wsh ? 64 * 16 : 0);
+    memset(out->g_params, 0, NPV * sizeof(double));
     double g_inv_s = 0.0, e_num = 0.0;
     #pragma omp parallel
     {
-        double *gp = (double *)calloc(NPAR, sizeof(double));
+        double *gp = (double *)calloc(NPAR + 64 * 16, sizeof(double));
         double gs_local = 0.0, en_local = 0.0;
         #pragma omp for schedule(dynamic, 1)
         for (int r = 0; r < N; r++) {
             const float *o = rays_o + 3 * r, *d = rays_d + 3 * r, *z = z_vals + (size_t)r * T;
             float pts[BWD_MAXT * 3], delta[BWD_MAXT], zn[BWD_MAXT], near, far;
             ray_points(op, o, d, z, pts, delta, zn, &near, &far, pa, r);
+            double shd[16]; const double *sh = NULL;             /* use_viewdirs: sh(d) of this ray (fp32 values, constants of the differentiation) */
+            if (f->Wsh) { float shf[16]; orc_sh16(d, shf); for (int j = 0; j < 16; j++) shd[j] = shf[j]; sh = shd; }
             /* ---- forward of every sample (kept: the reverse pass needs the ray's transmittance first) ---- */
             static __thread enc_geo *geo = NULL;        /* [T][7] */
             static __thread sdf_fwd *sf = NULL;         /* [T][7] */
@@ -287,7 +295,7 @@ ORC_API int orc_render_core_backward_posed(const orc_field *f, const orc_render_
                 for (int k = 0; k < 3; k++) grad[i][k] = 0.5 * (sf[i * 7 + 1 + 2 * k].out[0] - sf[i * 7 + 2 + 2 * k].out[0]) / (double)eps;
                 gn[i] = sqrt(grad[i][0] * grad[i][0] + grad[i][1] * grad[i][1] + grad[i][2] * grad[i][2]);
                 for (int k = 0; k < 3; k++) nrm[i][k] = grad[i][k] / (1e-5 + gn[i]);
-                color_forward(f, p, nrm[i], sf[i * 7].out, &cf[i]);
+                color_forward(f, p, nrm[i], sf[i * 7].out, sh, &cf[i]);
                 tc[i] = (double)d[0] * nrm[i][0] + (double)d[1] * nrm[i][1] + (double)d[2] * nrm[i][2];
                 const double ic = -(sp100(-tc[i] * 0.5 + 0.5) * (1.0 - car) + sp100(-tc[i]) * car);
                 half[i] = ic * (double)delta[i] * 0.5;
@@ -342,7 +350,7 @@ ORC_API int orc_render_core_backward_posed(const orc_field *f, const orc_render_
                 const double g_ic = g_half * (double)delta[i] * 0.5;
                 const double g_tc = g_ic * (0.5 * (1.0 - car) * dsp100(-tc[i] * 0.5 + 0.5) + car * dsp100(-tc[i]));
                 for (int k = 0; k < 3; k++) g_n[k] += g_tc * (double)d[k];
-                color_backward(f, &cf[i], g_rgb, gp, g_n, g_out16);
+                color_backward(f, &cf[i], g_rgb, gp, g_n, g_out16, sh, gp + NPAR);
                 /* normal = g / (1e-5 + |g|), eikonal term */
                 double g_g[3] = { 0, 0, 0 };
                 if (gn[i] > 0.0) {
@@ -362,7 +370,7 @@ ORC_API int orc_render_core_backward_posed(const orc_field *f, const orc_render_
         }
         #pragma omp critical
         {
-            for (int k = 0; k < NPAR; k++) out->g_params[k] += gp[k];
+            for (int k = 0; k < NPV; k++) out->g_params[k] += gp[k];
             g_inv_s += gs_local; e_num += en_local;
         }
         free(gp);

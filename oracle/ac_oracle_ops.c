@@ -36,6 +36,14 @@ static float sh_eval(const unsigned short *off, const float *coef, const unsigne
     return acc;
 }
 
+#include "ac_oracle.h"
+void orc_sh16(const float d[3], float sh[16])
+{
+    float p[3][8];
+    for (int a = 0; a < 3; a++) { p[a][0] = 1.0f; for (int k = 1; k < 8; k++) p[a][k] = p[a][k - 1] * d[a]; }
+    for (int i = 0; i < 16; i++) sh[i] = sh_eval(AC_SH_OFF0, AC_SH_COEF0, AC_SH_EXP0, i, p[0], p[1], p[2]);
+}
+
 /* _backend.sh_encode_forward(inputs, outputs, B, D, C=degree, calc_grad_inputs, dy_dx):
  * outputs [B, C*C]; dy_dx [B, 3, C*C] (shencoder.cu:128-130). */
 ORC_API int orc_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D, uint32_t C,

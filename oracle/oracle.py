@@ -309,7 +309,7 @@ def compact_rays(n_alive, rays_alive_old, rays_t_old):
 # ------------------------------------------------------------------ Instant-NSR field + renderer
 class _Field(C.Structure):
     _fields_ = [("table", f32p), ("offsets", i32p), ("scale", C.c_float * 16), ("res", C.c_uint32 * 16),
-                ("W1", f32p), ("b1", f32p), ("W2", f32p), ("b2", f32p), ("Wc1", f32p), ("Wc2", f32p), ("Wc3", f32p)]
+                ("W1", f32p), ("b1", f32p), ("W2", f32p), ("b2", f32p), ("Wc1", f32p), ("Wc2", f32p), ("Wc3", f32p), ("Wsh", f32p)]
 
 
 class _Opts(C.Structure):
@@ -328,7 +328,17 @@ class Field:
     hash table [6119857,2] + offsets[17], W1[64,35], b1[64], W2[16,64], b2[16], Wc1[64,21], Wc2[64,64], Wc3[3,64]."""
 
     def __init__(self, table, offsets, W1, b1, W2, b2, Wc1, Wc2, Wc3, per_level_scale, base_resolution=16):
+        """Wc1 [64,21] = [x | n | geo_feat], or the [64,37] matrix of NeRFNetwork(use_viewdirs=True) = [x | sh(d) (16) | n | geo_feat] (models/instant_nsr.py:648-650):
+        its 16 view-direction columns are then kept apart (orc_field.Wsh) and enter layer 1 as a per-ray bias"""
+        Wc1 = _f(Wc1)
+        Wsh = None
+        if Wc1.shape == (64, 37):
+            Wsh = np.ascontiguousarray(Wc1[:, 3:19])
+            Wc1 = np.ascontiguousarray(np.concatenate([Wc1[:, :3], Wc1[:, 19:]], 1))
         self.arrs = dict(table=_f(table), W1=_f(W1), b1=_f(b1), W2=_f(W2), b2=_f(b2), Wc1=_f(Wc1), Wc2=_f(Wc2), Wc3=_f(Wc3))
+        if Wsh is not None:
+            self.arrs["Wsh"] = Wsh
+        self.has_viewdirs = Wsh is not None
         self.offsets = np.ascontiguousarray(offsets, np.int32)
         assert self.offsets.shape[0] == 17 and self.arrs["table"].shape[1] == 2
         assert self.arrs["W1"].shape == (64, 35) and self.arrs["W2"].shape == (16, 64)
@@ -342,6 +352,8 @@ class Field:
             s.scale[i] = float(self.scale[i]); s.res[i] = int(self.res[i])
         for k in ("W1", "b1", "W2", "b2", "Wc1", "Wc2", "Wc3"):
             setattr(s, k, _p(self.arrs[k]))
+        if self.has_viewdirs:
+            s.Wsh = _p(self.arrs["Wsh"])
         self.c = s
 
     def sdf(self, x, bound):
@@ -350,10 +362,12 @@ class Field:
         lib().orc_field_sdf(C.byref(self.c), _p(x), C.c_uint32(x.shape[0]), C.c_float(bound), _p(out))
         return out
 
-    def color(self, x, n, sdfout):
+    def color(self, x, n, sdfout, dirs=None):
         x = _f(x).reshape(-1, 3); n = _f(n).reshape(-1, 3); sdfout = _f(sdfout).reshape(-1, 16)
         out = np.empty((x.shape[0], 3), np.float32)
-        lib().orc_field_color(C.byref(self.c), _p(x), _p(n), _p(sdfout), C.c_uint32(x.shape[0]), _p(out))
+        if dirs is not None:
+            dirs = _f(dirs).reshape(-1, 3)
+        lib().orc_field_color_dirs(C.byref(self.c), _p(x), _p(dirs), _p(n), _p(sdfout), C.c_uint32(x.shape[0]), _p(out))
         return out
 
 
@@ -562,7 +576,7 @@ def render_core_backward(field, rays_o, rays_d, z_vals, num_steps, upsample_step
     dp = C.POINTER(C.c_double)
     g_table = np.zeros(field.arrs["table"].shape, np.float64)
     npar = sum(int(np.prod(s)) for _, s in CORE_PARAM_SHAPES)
-    g_par = np.zeros(npar, np.float64); g_s = np.zeros(1, np.float64); fwd = np.zeros((N, 8), np.float64); ge = np.zeros(1, np.float64)
+    g_par = np.zeros(npar + (64 * 16 if getattr(field, "has_viewdirs", False) else 0), np.float64); g_s = np.zeros(1, np.float64); fwd = np.zeros((N, 8), np.float64); ge = np.zeros(1, np.float64)
     cg = _CoreGrads(g_table.ctypes.data_as(dp), g_par.ctypes.data_as(dp), g_s.ctypes.data_as(dp), fwd.ctypes.data_as(dp), ge.ctypes.data_as(dp))
     opt = lambda a, shape: None if a is None else _f(a).reshape(shape)
     gi, gw, gd, gm, bgc = opt(g_image, (N, 3)), opt(g_weights_sum, (N,)), opt(g_depth, (N,)), opt(g_normal_map, (N, 3)), opt(bg, (N, 3))
@@ -582,6 +596,11 @@ def render_core_backward(field, rays_o, rays_d, z_vals, num_steps, upsample_step
     for name, shape in CORE_PARAM_SHAPES:
         n = int(np.prod(shape))
         res["g_" + name] = g_par[off:off + n].reshape(shape).copy(); off += n
+    if getattr(field, "has_viewdirs", False):
+        # a field with view directions: the gradient of the reference's [64,37] color_net.0 matrix, columns in ITS order [x | sh(d) | n | geo_feat]
+        g_sh = g_par[off:off + 64 * 16].reshape(64, 16)
+        res["g_Wsh"] = g_sh.copy()
+        res["g_Wc1_37"] = np.concatenate([res["g_Wc1"][:, :3], g_sh, res["g_Wc1"][:, 3:]], 1)
     return res
 
 

@@ -1,0 +1,190 @@
+"""-m gpu: NeRFNetwork(use_viewdirs=True) through the fused paths (models/instant_nsr.py:565-569, 644-653).  The 16 spherical
+harmonics of the ray direction enter colour layer 1 as a per-ray bias formed in the renderer's prologue (ac_field.Wc1_sh): HIP == oracle bit for bit,
+<= 1e-3 of the reference's own render (tests/golden/viewdirs.npz), gradients against the reference's autograd and the fp64 oracle; canonical render,
+training step, posed render and the occupancy-grid render all take the model."""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import load_golden, make_table, make_rays
+from tests.gpu_common import assert_bitwise
+from tests.test_oracle_viewdirs import viewdirs_field, check_viewdirs_render
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def device_field_vd(g, table):
+    from avatarcraft_amd import nsr_ops
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    Wc1, Wsh = nsr_ops.split_viewdir_weight(t(g["Wc1"]))
+    return nsr_ops.Field(t(table), [int(v) for v in g["offsets"]], float(g["per_level_scale"]), 16, t(g["W1"]), t(g["b1"]), t(g["W2"]), t(g["b2"]), Wc1,
+                         t(g["Wc2"]), t(g["Wc3"]), Wc1_sh=Wsh)
+
+
+def viewdirs_net(g, train=False, cuda_ray=False):
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    torch.manual_seed(0)
+    net = NeRFNetwork(use_viewdirs=True, cuda_ray=cuda_ray)
+    sd = {k: torch.from_numpy(np.asarray(g[k])) for k in g if k.startswith(("sdf_net", "color_net", "deviation_net"))}
+    sd["encoder.embeddings"] = torch.from_numpy(make_table(int(g["offsets"][-1]), seed=int(g["table_seed"]), offsets=g["offsets"], level_amp=g["level_amp"]))
+    sd["encoder.offsets"] = torch.from_numpy(g["offsets"])
+    net.load_state_dict(sd, strict=not cuda_ray)
+    assert net.color_net[0].weight_v.shape == (64, 37) and net._fused_supported()
+    return net.to(DEV).train(train)
+
+
+def test_colour_and_bias_equal_the_oracle_bit_for_bit(oracle):
+    from avatarcraft_amd import nsr_ops
+    g = load_golden("viewdirs.npz")
+    of, table = viewdirs_field(oracle, g)
+    f = device_field_vd(g, table)
+    rs = np.random.RandomState(0)
+    B = 1000                                                       # not a multiple of 16
+    x = rs.uniform(-1, 1, (B, 3)).astype(np.float32); n = rs.normal(size=(B, 3)).astype(np.float32); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    d = rs.normal(size=(B, 3)).astype(np.float32); d[:500] /= np.linalg.norm(d[:500], axis=1, keepdims=True)      # (raw directions: not normalised either)
+    s16 = rs.normal(0, 0.3, (B, 16)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    rgb = nsr_ops.field_color(f, t(x), t(n), t(s16), dirs=t(d))
+    assert_bitwise(rgb, of.color(x, n, s16, dirs=d), "rgb with view directions")
+    with pytest.raises(RuntimeError, match="view-direction"):
+        nsr_ops.field_color(f, t(x), t(n), t(s16))
+    # the per-ray bias launch == the values the colour query used: bias = Wsh sh(d) as an fp32 fma chain over j
+    bias, sh = nsr_ops.sh_bias(f, t(d))
+    sh_o, _ = oracle.sh_encode_forward(d, 4)
+    assert_bitwise(sh, sh_o, "sh(d)")
+    acc = np.zeros((B, 64), np.float32)
+    Wsh = of.arrs["Wsh"]
+    for j in range(16):
+        acc = (acc.astype(np.float64) + Wsh[None, :, j].astype(np.float64) * sh_o[:, j:j + 1].astype(np.float64)).astype(np.float32)    # fma: one rounding per term
+    assert_bitwise(bias, acc, "bias")
+
+
+@pytest.mark.parametrize("tag,precision", [("eval", "exact"), ("train", "exact"), ("eval", "fast")])
+def test_render_equals_oracle_and_reference(oracle, tag, precision):
+    from avatarcraft_amd import nsr_ops
+    g = load_golden("viewdirs.npz")
+    of, table = viewdirs_field(oracle, g)
+    f = device_field_vd(g, table).prepare()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    noise = g["train_noise"] if tag == "train" else None
+    out = nsr_ops.render_rays(f, t(g["rays_o"]), t(g["rays_d"]), 64, 64, 1.6, float(g["inv_s"]), bg=t(g["bg"]), noise=None if noise is None else t(noise),
+                              extras=True, precision=precision)
+    r = oracle.render_rays(of, g["rays_o"], g["rays_d"], 64, 64, 1.6, float(g["inv_s"]), bg=g["bg"], noise=noise)
+    if precision == "exact":
+        for k in ("image", "weights_sum", "depth", "normal_map", "z_vals", "weights", "alpha", "color"):
+            assert_bitwise(out[k], np.asarray(r[k]).reshape(tuple(out[k].shape)), k)
+    else:
+        assert_bitwise(out["z_vals"], np.asarray(r["z_vals"]).reshape(tuple(out["z_vals"].shape)), "z_vals")
+        assert float((out["image"].cpu() - torch.from_numpy(np.asarray(r["image"]))).abs().max()) <= 2e-4
+    check_viewdirs_render(lambda k: out[k].cpu().numpy(), g, tag)
+    # pair launch and a launch without per-sample outputs give the same pixels
+    lean = nsr_ops.render_rays(f, t(g["rays_o"]), t(g["rays_d"]), 64, 64, 1.6, float(g["inv_s"]), bg=t(g["bg"]), noise=None if noise is None else t(noise),
+                               extras=False, precision=precision)
+    assert torch.equal(lean["image"], out["image"])
+    if noise is not None and precision == "exact":
+        n2 = torch.cat([t(noise), t(noise)]); bg2 = torch.cat([t(g["bg"]), t(g["bg"])])
+        ra, rb = nsr_ops.render_rays_pair(f, t(g["rays_o"]), t(g["rays_d"]), n2, 64, 64, 1.6, float(g["inv_s"]), bg2=bg2)
+        assert torch.equal(ra["image"], out["image"]) and torch.equal(rb["image"], out["image"])
+
+
+def _raw_grads(net):
+    return {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in net.named_parameters()}
+
+
+def test_model_render_and_gradients_vs_reference(oracle):
+    """the model path: state_dict of the reference's use_viewdirs net -> render (eval) vs its pixels; training render under autograd (the fused operator:
+    forward = the renderer, backward = ac_render_core_backward with the view-direction bias) vs the reference's own parameter gradients and the fp64 oracle"""
+    g = load_golden("viewdirs.npz")
+    net = viewdirs_net(g)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    with torch.no_grad():
+        out = net.render(t(g["rays_o"])[None], t(g["rays_d"])[None], num_steps=64, bound=1.6, upsample_steps=64, staged=False, bg_color=t(g["bg"]),
+                         cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=False)
+    assert float((out["rgb"][0].cpu() - torch.from_numpy(g["eval_image"])).abs().max()) <= 1e-3
+    assert float((out["pts_color"].cpu() - torch.from_numpy(g["eval_color"])).abs().max()) <= 1e-3
+    # gradients
+    net = viewdirs_net(g, train=True)
+    orig_rand = torch.rand
+    torch.rand = lambda *a, **k: t(g["g_noise"])
+    try:
+        o = net.render(t(g["g_rays_o"])[None], t(g["g_rays_d"])[None], num_steps=64, bound=1.6, upsample_steps=64, staged=False, bg_color=t(g["g_bg"]),
+                       cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=True, perturb=True)
+    finally:
+        torch.rand = orig_rand
+    assert float((o["rgb"][0].detach().cpu() - torch.from_numpy(g["g_rgb"])).abs().max()) <= 1e-3
+    (o["rgb"][0] * t(g["g_img_grad"])).sum().backward(retain_graph=True)
+    (o["gradient_error"] * 0.01).backward()
+    net.check_finite()
+    got = _raw_grads(net)
+    of, _ = viewdirs_field(oracle, g)
+    r = oracle.render_core_backward(of, g["g_rays_o"], g["g_rays_d"], o["z_vals"].detach().cpu().numpy(), 64, 64, 1.6, float(g["inv_s"]), bg=g["g_bg"],
+                                    g_image=g["g_img_grad"], g_eik=0.01)
+    r["g_Wc1"] = r["g_Wc1_37"]
+    from tests.test_oracle_backward import _chain_to_raw
+    raw = _chain_to_raw(oracle, g, r)
+    worst = {}
+    for k, ref in raw.items():
+        ref = np.asarray(ref).reshape(got[k].shape)
+        e_orc = float(np.abs(got[k] - ref).max() / np.abs(ref).max())
+        rr = g["grad." + k].astype(np.float64)
+        e_ref = float(np.abs(got[k] - rr).max() / np.abs(rr).max())
+        worst[k] = (e_orc, e_ref)
+        assert e_orc <= 3e-4, (k, worst)
+        assert e_ref <= 5e-3, (k, worst)
+    gv = got["color_net.0.weight_v"]
+    assert np.abs(gv[:, 3:19]).max() > 0.1 * np.abs(gv).max()      # the direction columns carry a real gradient
+    ge = got["encoder.embeddings"][g["emb_idx"]]
+    assert np.abs(ge - g["emb_grad"]).max() <= 2e-3 * np.abs(g["emb_grad"]).max()
+    assert abs(int((np.abs(got["encoder.embeddings"]).sum(1) > 0).sum()) - int(g["emb_nnz"])) <= 0.01 * int(g["emb_nnz"])
+
+
+def test_sds_step_posed_render_and_occupancy_render_take_the_model():
+    from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view, Adam
+    from tests.common import make_body
+    g = load_golden("viewdirs.npz")
+    ro, rd = make_rays(32, 32, dist=1.8, f=25.0)
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+
+    def step(manual):
+        net, net_gt = viewdirs_net(g, train=True), viewdirs_net(g)
+        if not manual:
+            net.manual_backward_supported = lambda: False
+        opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+        flat = flat_grad_view(net.parameters())
+        assert flat.numel() == 12248902 + 64 * 16
+        torch.manual_seed(3)
+        st = sds_step(net, net_gt, ro_t, rd_t, (32, 32), opt, SyntheticGuidance(5), batch_size=512, flat_grad=flat)
+        net.check_finite()
+        return {k: v.grad.detach().clone() for k, v in net.named_parameters()}, st
+    ga, sa = step(True)                                            # the step without autograd: pair launch / core backward / param_grads with 37 columns
+    gb, sb = step(False)                                           # the autograd formulation of the same step
+    for k in ga:
+        tol = 2e-4 if k == "encoder.embeddings" else 2e-5
+        assert float((ga[k] - gb[k]).abs().max()) <= tol * float(gb[k].abs().max()) + 1e-12, k
+    assert float(ga["color_net.0.weight_v"][:, 3:19].abs().max()) > 0
+    # posed space and the occupancy grid: no NotImplementedError (round 4: instant_nsr.py:340, :476), and the direction matters
+    net = viewdirs_net(g)
+    verts, faces, Ts = make_body()
+    with torch.no_grad():
+        a = net.render(ro_t[None], rd_t[None], num_steps=32, bound=1.6, upsample_steps=32, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0,
+                       render_can=False, verts=verts, faces=faces, Ts=Ts)
+        w = net.color_net[0].weight_v.detach().clone()
+        net.color_net[0].weight_v[:, 3:19] = 0.0
+        b = net.render(ro_t[None], rd_t[None], num_steps=32, bound=1.6, upsample_steps=32, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0,
+                       render_can=False, verts=verts, faces=faces, Ts=Ts)
+        net.color_net[0].weight_v.copy_(w)
+    assert torch.isfinite(a["rgb"]).all() and float(a["weight_sum"].max()) > 0.5 and torch.equal(a["weight_sum"], b["weight_sum"])
+    assert float((a["rgb"] - b["rgb"]).abs().max()) > 1e-3
+    occ = viewdirs_net(g, cuda_ray=True)
+    occ.update_extra_state(1.6)
+    with torch.no_grad():
+        one = occ.render(ro_t[None], rd_t[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0)
+        occ.occupancy_rounds = True
+        loop = occ.render(ro_t[None], rd_t[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0)
+        occ.occupancy_rounds = False
+    assert float(one["weight_sum"].max()) > 0.9 and float((one["rgb"] - loop["rgb"]).abs().max()) <= 2e-5
+    occ.train()
+    o = occ.render(ro_t[None], rd_t[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, perturb=True)
+    o["rgb"].sum().backward()
+    assert float(occ.color_net[0].weight_v.grad[:, 3:19].abs().max()) > 0

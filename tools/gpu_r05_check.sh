@@ -12,5 +12,5 @@ s=r.get("sds_step",{}); print("sds",s.get("ms_per_step"),s.get("phase_ms"),s.get
 f=r.get("sds_view_fine",{}); print("fine",f.get("ms_per_view"),f.get("phase_ms"),(f.get("patch_by_patch") or {}).get("ms_per_view"),(f.get("roofline") or {}).get("frac"),f.get("error"))
 p=r.get("posed_frame",{}); print("posed",p.get("ms_per_frame"),p.get("error"))
 m=r.get("mesh_export_512",{}); print("mesh",{k:m.get(k) for k in ("ms","sdf_grid_ms","marching_cubes_ms","error")}); print("dg",(r.get("density_grid_update") or {}).get("ms"))
-print("occ",json.dumps(r.get("occupancy_render"))[:800])
+print("vd",r.get("viewdirs")); print("occ",json.dumps(r.get("occupancy_render"))[:300])
 PY
