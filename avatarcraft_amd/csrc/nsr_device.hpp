@@ -6,7 +6,7 @@
 #include "ac_common.hpp"
 #include "ac_devmath.hpp"
 #include "ac_sp_table.hpp"
-#include "ac_sh_table.hpp"
+#include "ac_sh16.hpp"
 
 using namespace acdev;
 
@@ -918,30 +918,26 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
 // The 16 spherical harmonics (degree 4, encoder/shencoder) of the RAW ray direction enter layer 1 of the colour network only.  The direction is constant
 // along a ray, so Wsh sh(d) is a per-ray BIAS of that layer: bias[u] = fma chain over j = 0..15 of Wsh[u][j] * sh_j(d), and the accumulator of unit u
 // starts from bias[u] instead of 0 -- zero cost per sample.  sh_j: the value table of the stand-alone encoder (shencoder.hip), same operations.
-__device__ __forceinline__ float sh16_value(int i, float x, float y, float z)
-{
-    const float px[4] = { 1.0f, x, x * x, (x * x) * x }, py[4] = { 1.0f, y, y * y, (y * y) * y }, pz[4] = { 1.0f, z, z * z, (z * z) * z };
-    float acc = 0.0f;
-    for (int m = AC_SH_OFF0[i]; m < AC_SH_OFF0[i + 1]; ++m) {
-        const float mono = (px[AC_SH_EXP0[m][0]] * py[AC_SH_EXP0[m][1]]) * pz[AC_SH_EXP0[m][2]];
-        acc = fma_(AC_SH_COEF0[m], mono, acc);
-    }
-    return acc;
-}
-// one ray per wave: shb [80] floats of the wave's LDS slab -> shb[u] = bias of unit u (u = lane), shb[64 + j] = sh_j(d)
+// one ray per wave: shb [80] floats of the wave's LDS slab -> shb[u] = bias of unit u (u = lane); KEEP_SH: shb[64 + j] = sh_j(d) as well (ac_sh_bias)
+template <bool KEEP_SH = false>
 __device__ __forceinline__ void ray_sh_bias(float *__restrict__ shb, const float *__restrict__ Wsh, float dx, float dy, float dz, int lane)
 {
-    if (lane < 16) shb[64 + lane] = sh16_value(lane, dx, dy, dz);
-    wave_sync();
+    float sh[16];
+    ac_sh16(dx, dy, dz, sh);                                  // (ac_sh16.hpp: the stand-alone encoder's operations, written out)
     const f32x4 *w = reinterpret_cast<const f32x4 *>(Wsh + lane * 16);
     float acc = 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 wv = w[q];
-        acc = fma_(wv[0], shb[64 + 4 * q], acc); acc = fma_(wv[1], shb[64 + 4 * q + 1], acc);
-        acc = fma_(wv[2], shb[64 + 4 * q + 2], acc); acc = fma_(wv[3], shb[64 + 4 * q + 3], acc);
+        acc = fma_(wv[0], sh[4 * q], acc); acc = fma_(wv[1], sh[4 * q + 1], acc);
+        acc = fma_(wv[2], sh[4 * q + 2], acc); acc = fma_(wv[3], sh[4 * q + 3], acc);
     }
+    wave_sync();                                              // (the previous work item's readers of the slab are done)
     shb[lane] = acc;
+    if constexpr (KEEP_SH) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (lane == j) shb[64 + j] = sh[j];
+    }
     wave_sync();
 }
 // packed samples (a tile of 16 samples of whatever rays): lane (n, g) computes the 16 biases it needs -- units 16 t + 4 g + r of ITS sample's direction --
@@ -950,8 +946,7 @@ __device__ __forceinline__ void sample_sh_bias(float *__restrict__ slab, const f
 {
     const int g = lane >> 4;
     float sh[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) sh[j] = sh16_value(j, dx, dy, dz);
+    ac_sh16(dx, dy, dz, sh);
 #pragma unroll 1
     for (int t = 0; t < 4; ++t) {
         f32x4 o;
@@ -971,10 +966,14 @@ __device__ __forceinline__ void sample_sh_bias(float *__restrict__ slab, const f
     wave_sync();
 }
 
-// shb: NULL, or this lane's first bias quadruple -- (ray slab) + 4 g with tstride 16, or (sample slab) + 4 lane with tstride 256
+// The view-direction bias of layer 1 reaches the accumulators in one of two ways (both leave exactly bias[u] in unit u's accumulator before the first input):
+//   shb  (packed samples): this lane's first bias quadruple -- (sample slab) + 4 lane, tstride 256 -- loaded as the initial accumulator;
+//   shb1 (the renderer: one ray per wave): the ray's bias row [64] in the wave's slab, brought in by ONE extra MFMA per tile of units with B = 1 on the
+//        lanes of group 0 and 0 elsewhere (bias * 1 + 0 + 0 + 0 = bias, exactly): one LDS dword per lane instead of a 16-byte quadruple -- the renderer's
+//        tile loop has no register to spare.
 __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int lane, float px, float py, float pz,
                                            float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3], const float *__restrict__ shb = nullptr,
-                                           int tstride = 16)
+                                           int tstride = 16, const float *__restrict__ shb1 = nullptr)
 {
     const int g = lane >> 4;
     f32x4 h1[4], h2[4];
@@ -983,6 +982,7 @@ __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int la
     for (int t = 0; t < 4; ++t) {
         f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (shb) acc = *reinterpret_cast<const f32x4 *>(shb + t * tstride);
+        if (shb1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(shb1[16 * t + (lane & 15)], g == 0 ? 1.0f : 0.0f, acc, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const float b = s < 4 ? sdfout[s] : (s == 4 ? bxyz : bn);
@@ -1021,7 +1021,7 @@ __device__ __forceinline__ f32x4 cf_mma(const float *__restrict__ lds, int f, in
 }
 __device__ __forceinline__ void color_tile_fast(const float *__restrict__ lds, int lane, float px, float py, float pz,
                                                 float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3], const float *__restrict__ shb = nullptr,
-                                                int tstride = 16)
+                                                int tstride = 16, const float *__restrict__ shb1 = nullptr)
 {
     const int g = lane >> 4;
     u32x4 bh, bl;
@@ -1035,6 +1035,7 @@ __device__ __forceinline__ void color_tile_fast(const float *__restrict__ lds, i
     for (int t = 0; t < 4; ++t) {
         f32x4 acc0 = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (shb) acc0 = *reinterpret_cast<const f32x4 *>(shb + t * tstride);      // (the view-direction bias stays fp32 in either precision)
+        if (shb1) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(shb1[16 * t + (lane & 15)], g == 0 ? 1.0f : 0.0f, acc0, 0, 0, 0);
         f32x4 acc = cf_mma(lds, t, lane, bh, bl, acc0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;

@@ -44,7 +44,9 @@ namespace {
 #endif
 // EX = false: a launch that wants the per-ray results only (image, weights_sum, depth, normal_map, eik): none of the optional per-sample outputs is
 // compiled in, which takes their sixteen pointers (and the address arithmetic on them) out of the register budget of the tile loop
-template <int MODE, bool FAST, bool EX>
+// SH = true: a field with view directions (ac_field.Wc1_sh).  A template parameter, not a run-time branch: the tile loop runs at 256 VGPRs with a few
+// spilled registers, and the live pointer / flag of a run-time switch cost the DEFAULT model six more spills (+0.7 % on the headline launch, measured).
+template <int MODE, bool FAST, bool EX, bool SH = false>
 __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 {
     constexpr bool FC = FAST && AC_FAST_COLOR;
@@ -360,9 +362,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         // registers: they are touched once per tile by one lane (lane 15, which holds the tile totals of the row scans), and ten registers less at the
         // peak of the stencil / MLP code is the difference between ~30 and ~10 spilled registers.  Slots: 1 s_w 2..4 rgb 5..7 normal 8 depth 9 10 eikonal
         float *const accs = zs0 + SLAB_ACC;
-        float *const shb = zs0 + SLAB_SHB;                      // use_viewdirs: layer-1 bias of the colour network for THIS ray's direction (per work item: a segment
-        const bool use_sh = a.Wsh != nullptr && !a.opacity_only;      // of a ray may run on another wave than the one before it -- 16 sh values + 64 dot products, ~1 us)
-        if (use_sh) ray_sh_bias(shb, a.Wsh, dx, dy, dz, lane);
+        // use_viewdirs: layer-1 bias of the colour network for THIS ray's direction, in the wave's slab (per work item: a segment of a ray may run on another
+        // wave than the one before it -- 16 sh values + 64 dot products of 16 terms, ~1 us)
+        if constexpr (SH && MODE != MODE_UPSAMPLE) { if (!a.opacity_only) ray_sh_bias(zs0 + SLAB_SHB, a.Wsh, dx, dy, dz, lane); }
         if (!seg_first) {
             // continue a ray another wave (of this XCD) started: wait until its previous segment is published, then take over z and the running sums.
             // All accesses to seg_flags / seg_state are agent-scope atomics = served by the XCD's L2, past the (incoherent) vector L1 caches.
@@ -503,8 +505,8 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
             float rgb[3] = { 0.0f, 0.0f, 0.0f };
             if (!skip && !a.opacity_only) {                      // (wave-uniform)
-                if constexpr (FC) color_tile_fast(lds, lane, px, py, pz, nx, ny, nz, oc, rgb, use_sh ? shb + 4 * g : nullptr);
-                else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb, use_sh ? shb + 4 * g : nullptr);
+                if constexpr (FC) color_tile_fast(lds, lane, px, py, pz, nx, ny, nz, oc, rgb, nullptr, 16, SH ? zs0 + SLAB_SHB : nullptr);
+                else color_tile(lds, lane, px, py, pz, nx, ny, nz, oc, rgb, nullptr, 16, SH ? zs0 + SLAB_SHB : nullptr);
             }
             AC_TICK(5)
             // NeuS alpha :219-248
@@ -869,13 +871,13 @@ AC_API int ac_render_handoff_timeouts(ac_stream_t stream, uint32_t *count)
     return AC_OK;
 }
 
-template <int MODE, bool FAST, bool EX>
+template <int MODE, bool FAST, bool EX, bool SH = false>
 static void launch_render_p(const RenderArgs &a, hipStream_t stream)
 {
     int blocks = (a.n_rays + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     static uint64_t seen = 0;                       // one flag per instantiation
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(render_rays_kernel<MODE, FAST, EX>), lds_bytes);
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(render_rays_kernel<MODE, FAST, EX, SH>), lds_bytes);
 #if AC_DYNAMIC_RAYS
     RenderArgs b = a;
     {
@@ -902,9 +904,9 @@ static void launch_render_p(const RenderArgs &a, hipStream_t stream)
         blocks = (blocks + 7) & ~7;                                      // every XCD gets the same number of workgroups
         if (!sc) blocks = 0;                                             // (the scratch could not be allocated: an empty grid is a launch error the caller reports)
     }
-    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST, EX>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, b);
+    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST, EX, SH>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, b);
 #else
-    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST, EX>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL((render_rays_kernel<MODE, FAST, EX, SH>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, a);
     if (MODE != MODE_UPSAMPLE && a.out.eik_reduced) {                 // (static ray assignment builds: the reduction as its own launch(es))
         const int nred = a.pair_n ? 2 : 1, nper = a.pair_n ? a.pair_n : a.n_rays;
         for (int q = 0; q < nred; ++q)
@@ -921,6 +923,11 @@ static void launch_render(const RenderArgs &a, hipStream_t stream)
 {
     const bool ex = wants_samples(a.out);
     if constexpr (MODE != MODE_UPSAMPLE) {          // (the sampling-only launch has no finite-difference stage)
+        if (a.Wsh) {                                // a field with view directions: its own instantiations (see the kernel's SH parameter)
+            if (a.fast) { if (ex) launch_render_p<MODE, true, true, true>(a, stream); else launch_render_p<MODE, true, false, true>(a, stream); return; }
+            if (ex) launch_render_p<MODE, false, true, true>(a, stream); else launch_render_p<MODE, false, false, true>(a, stream);
+            return;
+        }
         if (a.fast) { if (ex) launch_render_p<MODE, true, true>(a, stream); else launch_render_p<MODE, true, false>(a, stream); return; }
         if (ex) launch_render_p<MODE, false, true>(a, stream); else launch_render_p<MODE, false, false>(a, stream);
         return;

@@ -1433,8 +1433,7 @@ __global__ __launch_bounds__(256) void sh_bias_kernel(const float *__restrict__ 
     __shared__ float slab[4][80];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t ray = blockIdx.x * 4 + wave; ray < N; ray += gridDim.x * 4) {
-        wave_sync();
-        ray_sh_bias(slab[wave], Wsh, rays_d[3 * (size_t)ray], rays_d[3 * (size_t)ray + 1], rays_d[3 * (size_t)ray + 2], lane);
+        ray_sh_bias<true>(slab[wave], Wsh, rays_d[3 * (size_t)ray], rays_d[3 * (size_t)ray + 1], rays_d[3 * (size_t)ray + 2], lane);
         bias[(size_t)ray * 64 + lane] = slab[wave][lane];
         if (sh_out && lane < 16) sh_out[(size_t)ray * 16 + lane] = slab[wave][64 + lane];
     }
