@@ -1090,6 +1090,11 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
 #ifdef AC_WARP_SEED_DEBUG   // ceiling experiment (tools/warp_seed_probe.py): start every sample from its TRUE distance^2 (taken from a previous run)
     if (g_warp_seed_d2 && live && mycnt != CELL_OVERFLOW) { const double t = g_warp_seed_d2[ii] * (1.0 + 1e-12); myseed = t < myseed ? t : myseed; }
 #endif
+    // skip_thr >= 0 (round 5): the caller reads mask and the canonical points of UNMASKED samples only, i.e. a closest face matters only if it is closer than
+    // the mask's threshold -- so the running bound never needs to start above it.  A sample whose seed face is farther away (the outer part of the
+    // shell the cell grids cannot prove masked: the samples with the LONGEST candidate lists) walks its list against threshold (1 + 1e-6) instead; if no
+    // face comes in under that, the sample is masked out and leaves like a dead one.  Unmasked samples: the same face, the same bits.
+    if (skip_thr >= 0.0f && myseed > (double)skip_thr) myseed = (double)skip_thr;
     sbest[lane] = __builtin_bit_cast(unsigned long long, myseed);
     sbid[lane] = 0x7fffffffu;
 #pragma unroll
@@ -1333,7 +1338,8 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             int bid = 0x7fffffff;
             uint32_t myslot;
             seed_test(av, q, tA, tB, lane, best, bid, bc, myslot);
-            const double seed = wave_min_f64(best);                      // +inf if every seed face is degenerate
+            double seed = wave_min_f64(best);                            // +inf if every seed face is degenerate
+            if (skip_thr >= 0.0f && seed > (double)skip_thr) seed = (double)skip_thr;       // (as above: only faces under the mask's threshold matter)
             n_box += nt; n_exact += 2u * TILE_F;
             if (lane == 0) sbest[j] = __builtin_bit_cast(unsigned long long, seed);
             WP_TICK(2)
@@ -1358,6 +1364,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
     }
 #undef SBOX
     WP_TICK(5)
+    if (live && !dead && todo_lane && skip_thr >= 0.0f && sbid[lane] == 0x7fffffffu) dead = true;      // no face under the mask's threshold: masked out
     if (live && !todo_lane) {
     } else if (live && dead) {                                           // certainly masked out: no closest face was looked for
         mask[i] = 0;

@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r04"
+rnd = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r05"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 short = lambda n: re.sub(r"\(anonymous namespace\)::|void ", "", n).split("(")[0]
@@ -40,11 +40,11 @@ def main():
     rows = list(csv.DictReader(open(glob.glob(src + "/kt/**/p_kernel_trace.csv", recursive=True)[0])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    # render_rays_kernel<MODE, FAST, EX>: <0, false, false> = exact, no per-sample outputs (the bench, render_val, the frozen net's render);
+    # render_rays_kernel<MODE, FAST, EX, SH> (SH = a field with view directions, round 5; false here): <0, false, false> = exact, no per-sample outputs (the bench, render_val, the frozen net's render);
     # <0, false, true> = exact with per-sample outputs (the training forward); <0, true, *> = the fast arithmetic mode
-    lean = [dur(r) for r in rows if "render_rays_kernel<0, false, false>" in r["Kernel_Name"]]
-    fast = [dur(r) for r in rows if "render_rays_kernel<0, true, false>" in r["Kernel_Name"]]
-    train = [dur(r) for r in rows if "render_rays_kernel<0, false, true>" in r["Kernel_Name"]]
+    lean = [dur(r) for r in rows if "render_rays_kernel<0, false, false, false>" in r["Kernel_Name"]]
+    fast = [dur(r) for r in rows if "render_rays_kernel<0, true, false, false>" in r["Kernel_Name"]]
+    train = [dur(r) for r in rows if "render_rays_kernel<0, false, true, false>" in r["Kernel_Name"]]
     R = int(bench.get("repeat", 1))
     nm = W + R * K
     # bench.py (default precision exact): W + repeat x K exact launches, then the other mode (min(W, 2) + K fast launches), WHOLE_VIEW exact launches of
@@ -104,7 +104,7 @@ def main():
     # matrix-pipe occupancy of the render kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel clocks); clocks from the trace's mean duration x the
     # sustained shader clock (2.1 GHz, tools/phase_profile.py)
     mfma_busy = {}
-    for prec, key, durs in (("exact", rk, lean[W:nm]), ("fast", "render_rays_kernel<0, true, false>", fast[min(W, 2):min(W, 2) + K])):
+    for prec, key, durs in (("exact", rk, lean[W:nm]), ("fast", "render_rays_kernel<0, true, false", fast[min(W, 2):min(W, 2) + K])):
         for f in glob.glob(src + "/g*/p_counter_collection.csv"):
             v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES" and short(r["Kernel_Name"]).startswith(key)]
             if v and durs:
@@ -114,7 +114,7 @@ def main():
         "render_rays_kernel_hbm_bytes_per_launch": int(mean(main_f) * KB),
         "sds_step_hbm_bytes_per_step": int(sum(parts.values())),
         "sds_step_by_kernel": {k: int(v) for k, v in parts.items()},
-        "commit": head, "profile": f"tools/prof_r04.sh {tag} -> profiles/{rnd}_pmc_summary.json",
+        "commit": head, "profile": f"tools/prof_{rnd}.sh {tag} -> profiles/{rnd}_pmc_summary.json",
         "command": f"bench.py --steps {pb['steps']} --warmup {pb['warmup']} --sds-steps 2 --posed-frames 1 --repeat 1 under rocprofv3 --pmc (one pass per counter group)",
         "render_rays_kernel_mfma_busy_frac": mfma_busy,
         "fetch_size_note": ("FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950; calibrated for THIS access pattern (8-byte gathers, one 64-byte sector per L2 miss: "
