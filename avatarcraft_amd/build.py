@@ -36,6 +36,17 @@ PER_FILE_FLAGS = {"hash_stencil.hip": ["-mllvm", "-amdgpu-sched-strategy=max-mem
                   "warp.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]}
 
 
+# Library variants built next to the product (in-tree, so that they travel to the GPU box; git-ignored like every .so): the same objects except the listed
+# sources, which are compiled with extra defines.  Loaded through AC_LIB_PATH by the tests that keep a compile-time alternative exercised.
+#   rec12: the table-gradient scatter with full-fp32 12-byte queue records (-DAC_REC8=0) instead of the 8-byte records whose values are rounded to 16 / 17
+#          mantissa bits (the precision reduction is a compile-time choice; the fp32 form must stay covered by the parity matrix)
+VARIANTS = {"rec12": {"hash_stencil.hip": ["-DAC_REC8=0"]}}
+
+
+def variant_path(name):
+    return os.path.join(HERE, f"libavatarcraft_hip_{name}.so")
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -105,6 +116,29 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}")
+    for name, per_src in VARIANTS.items():
+        vobjs, rebuilt = [], False
+        for src in SOURCES:
+            if src not in per_src:
+                vobjs.append(os.path.join(bdir, src.replace(".hip", ".o")))
+                continue
+            s_ = os.path.join(CSRC, src)
+            o = os.path.join(bdir, f"{name}_{src.replace('.hip', '.o')}")
+            if force or _stale(o, [s_] + headers):
+                extra = PER_FILE_FLAGS.get(src, [])
+                cmd = [hipcc] + FLAGS + (extra if _supported(hipcc, extra) else []) + per_src[src] + ["-c", s_, "-o", o]
+                if verbose:
+                    print(" ".join(cmd))
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError(f"hipcc failed for variant {name} of {src}:\n{r.stdout}")
+                rebuilt = True
+            vobjs.append(o)
+        vso = variant_path(name)
+        if force or rebuilt or _stale(vso, vobjs):
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", vso] + vobjs, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link of variant {name} failed:\n{r.stdout}")
     return OUT
 
 

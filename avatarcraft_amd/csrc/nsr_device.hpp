@@ -34,7 +34,7 @@ namespace {
 constexpr int WAVES_PER_BLOCK = AC_WPB;
 constexpr int BLOCK = WAVES_PER_BLOCK * 64;
 constexpr int MAXT = 128;
-constexpr int SEG_STATE = MAXT + 16;   // floats per ray handed from one segment of a ray to the next: z [128] | cT, 10 running sums | pad
+constexpr int SEG_STATE = MAXT + 16 + 64;   // floats per ray handed from one segment of a ray to the next: z [128] | cT, 10 running sums | pad | (view directions) the ray's layer-1 bias [64]
 #ifndef AC_FINE_BATCH
 #define AC_FINE_BATCH 3     // fine stencil levels: offset-point pairs gathered per memory round trip (1: x | y | z, 2: x+y | z, 3: all six: 221 VGPRs, -2 % time)
 #endif
@@ -966,27 +966,33 @@ __device__ __forceinline__ void sample_sh_bias(float *__restrict__ slab, const f
     wave_sync();
 }
 
-// The view-direction bias of layer 1 reaches the accumulators in one of two ways (both leave exactly bias[u] in unit u's accumulator before the first input):
-//   shb  (packed samples): this lane's first bias quadruple -- (sample slab) + 4 lane, tstride 256 -- loaded as the initial accumulator;
-//   shb1 (the renderer: one ray per wave): the ray's bias row [64] in the wave's slab, brought in by ONE extra MFMA per tile of units with B = 1 on the
-//        lanes of group 0 and 0 elsewhere (bias * 1 + 0 + 0 + 0 = bias, exactly): one LDS dword per lane instead of a 16-byte quadruple -- the renderer's
-//        tile loop has no register to spare.
+// The view-direction bias of layer 1 enters unit u's fma chain at ONE fixed position: after the three coordinates, in the k = 3 slot of the MFMA that
+// carries (x, y, z, -) -- a slot that multiplies 0 by 0 without view directions.  acc = fma(bias[u], 1, acc) there, in both forms:
+//   shb1 (the renderer: one ray per wave): the ray's bias row [64] in the wave's slab becomes that slot's A operand on the lanes of group 3 (B = 1 there):
+//        no extra instruction but a select -- the renderer's tile loop has neither registers nor issue slots to spare;
+//   shb  (packed samples, a direction per sample): this lane's bias quadruples -- (sample slab) + 4 lane, tstride 256 -- added to the accumulator right
+//        after that MFMA (acc + bias, one rounding: the same bits as the slot's fma).
 __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int lane, float px, float py, float pz,
                                            float nx, float ny, float nz, f32x4 sdfout, float (&rgb)[3], const float *__restrict__ shb = nullptr,
                                            int tstride = 16, const float *__restrict__ shb1 = nullptr)
 {
     const int g = lane >> 4;
     f32x4 h1[4], h2[4];
-    const float bxyz = sel4(g, px, py, pz, 0.0f), bn = sel4(g, nx, ny, nz, 0.0f);
+    const float bxyz = sel4(g, px, py, pz, shb1 ? 1.0f : 0.0f), bn = sel4(g, nx, ny, nz, 0.0f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
-        if (shb) acc = *reinterpret_cast<const f32x4 *>(shb + t * tstride);
-        if (shb1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(shb1[16 * t + (lane & 15)], g == 0 ? 1.0f : 0.0f, acc, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const float b = s < 4 ? sdfout[s] : (s == 4 ? bxyz : bn);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C1F + (t * 6 + s) * 64 + lane], b, acc, 0, 0, 0);
+            float wa = lds[OFF_C1F + (t * 6 + s) * 64 + lane];
+            if (s == 4 && shb1) wa = g == 3 ? shb1[16 * t + (lane & 15)] : wa;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, b, acc, 0, 0, 0);
+            if (s == 4 && shb) {
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(shb + t * tstride);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = acc[r] + bq[r];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;

@@ -362,9 +362,9 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
         // registers: they are touched once per tile by one lane (lane 15, which holds the tile totals of the row scans), and ten registers less at the
         // peak of the stencil / MLP code is the difference between ~30 and ~10 spilled registers.  Slots: 1 s_w 2..4 rgb 5..7 normal 8 depth 9 10 eikonal
         float *const accs = zs0 + SLAB_ACC;
-        // use_viewdirs: layer-1 bias of the colour network for THIS ray's direction, in the wave's slab (per work item: a segment of a ray may run on another
-        // wave than the one before it -- 16 sh values + 64 dot products of 16 terms, ~1 us)
-        if constexpr (SH && MODE != MODE_UPSAMPLE) { if (!a.opacity_only) ray_sh_bias(zs0 + SLAB_SHB, a.Wsh, dx, dy, dz, lane); }
+        // use_viewdirs: layer-1 bias of the colour network for THIS ray's direction, in the wave's slab: formed by the ray's first segment (16 sh values + 64
+        // dot products of 16 terms), handed to the later ones with the segment state (64 floats: one store / one load per lane instead of the prologue again)
+        if constexpr (SH && MODE != MODE_UPSAMPLE) { if (seg_first && !a.opacity_only) ray_sh_bias(zs0 + SLAB_SHB, a.Wsh, dx, dy, dz, lane); }
         if (!seg_first) {
             // continue a ray another wave (of this XCD) started: wait until its previous segment is published, then take over z and the running sums.
             // All accesses to seg_flags / seg_state are agent-scope atomics = served by the XCD's L2, past the (incoherent) vector L1 caches.
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             const float cv = __uint_as_float(__hip_atomic_load(st + MAXT + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             cT = lane_bcast(cv, 0);
             if (lane < 16) accs[lane] = cv;
+            if constexpr (SH) zs0[SLAB_SHB + lane] = __uint_as_float(__hip_atomic_load(st + MAXT + 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (timed_out) {                                     // never observed; if the previous segment was not published in ~1 s the ray's pixel must not
                 cT = __builtin_nanf("");                         // look like a result: NaN, which the callers' finite checks and every parity test catch
                 if (lane < 16) accs[lane] = cT;
@@ -569,6 +570,7 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 const float cv = lane == 0 ? cT : accs[lane];
                 __hip_atomic_store(st + MAXT + lane, __float_as_uint(cv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if constexpr (SH) { if (seg_first) __hip_atomic_store(st + MAXT + 16 + lane, __float_as_uint(zs0[SLAB_SHB + lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every lane's state stores have left the wave ...
             wave_sync();
             // ... before the flag store is issued (relaxed, agent scope: see the taker's side for why no release / acquire pair is used)

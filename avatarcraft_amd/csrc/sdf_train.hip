@@ -866,11 +866,15 @@ __global__ __launch_bounds__(TBLOCK) void color_bwd_kernel(const RenderArgs a, c
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if (shb) acc = *reinterpret_cast<const f32x4 *>(shb + 16 * t);
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
                 const float bv = s < 4 ? so[s] : (s == 4 ? bxyz : bn);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[OFF_C1F + (t * 6 + s) * 64 + lane], bv, acc, 0, 0, 0);
+                if (s == 4 && shb) {                             // the view-direction bias: the forward's position in the chain (color_tile)
+                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(shb + 16 * t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = acc[r] + bq[r];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;

@@ -358,8 +358,9 @@ static float field_sdf_only(const orc_field *f, const float x[3], float bound)
  *            enters with weight 0); then (x,y,z,0); then (nx,ny,nz,0);
  *   layers 2,3: for t,r,g: hidden unit 16t+4g+r. */
 /* use_viewdirs (f->Wsh, models/instant_nsr.py:644-653): h = cat[x, sh(d), n, feat].  The direction is constant along a ray, so its share of layer 1 is a
- * per-ray bias: bias[u] = fma chain over j = 0..15 of Wsh[u][j] * sh_j(d) from 0, and unit u's accumulator STARTS from bias[u]; then the 21 inputs in the
- * order above.  (versus the reference's single 37-term dot product: an fp32 re-association.)  d == NULL or f->Wsh == NULL: no view directions. */
+ * per-ray bias: bias[u] = fma chain over j = 0..15 of Wsh[u][j] * sh_j(d) from 0.  It enters unit u's chain as ONE term, acc = fma(bias[u], 1, acc), at the
+ * position that is fma(0, 0, acc) without view directions: after (x, y, z), before the normal (the fourth slot of the MFMA that carries the coordinates).
+ * (versus the reference's single 37-term dot product: an fp32 re-association.)  d == NULL or f->Wsh == NULL: no view directions. */
 static void orc_color_bias(const orc_field *f, const float d[3], float bias[64])
 {
     float sh[16];
@@ -378,7 +379,7 @@ static void orc_color_mlp_d(const orc_field *f, const float x[3], const float n[
     if (vd) orc_color_bias(f, d, bias);
     for (int u = 0; u < 64; u++) {
         const float *w = f->Wc1 + u * 21;
-        float acc = vd ? bias[u] : 0.0f;
+        float acc = 0.0f;
         for (int r = 0; r < 4; r++)
             for (int g = 0; g < 4; g++) {
                 int o = 4 * g + r;
@@ -386,7 +387,7 @@ static void orc_color_mlp_d(const orc_field *f, const float x[3], const float n[
                 acc = fmaf(wv, sdfout[o], acc);
             }
         acc = fmaf(w[0], x[0], acc); acc = fmaf(w[1], x[1], acc); acc = fmaf(w[2], x[2], acc);
-        acc = fmaf(0.0f, 0.0f, acc);
+        acc = vd ? fmaf(bias[u], 1.0f, acc) : fmaf(0.0f, 0.0f, acc);
         acc = fmaf(w[3], n[0], acc); acc = fmaf(w[4], n[1], acc); acc = fmaf(w[5], n[2], acc);
         acc = fmaf(0.0f, 0.0f, acc);
         h1[u] = acc > 0.0f ? acc : 0.0f;
