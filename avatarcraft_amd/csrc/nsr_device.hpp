@@ -985,9 +985,9 @@ __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int la
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const float b = s < 4 ? sdfout[s] : (s == 4 ? bxyz : bn);
-            float wa = lds[OFF_C1F + (t * 6 + s) * 64 + lane];
-            if (s == 4 && shb1) wa = g == 3 ? shb1[16 * t + (lane & 15)] : wa;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, b, acc, 0, 0, 0);
+            const float *wsrc = lds + OFF_C1F + (t * 6 + s) * 64 + lane;
+            if (s == 4 && shb1) wsrc = g == 3 ? shb1 + 16 * t + (lane & 15) : wsrc;      // (an address select: still one LDS read per lane)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(*wsrc, b, acc, 0, 0, 0);
             if (s == 4 && shb) {
                 const f32x4 bq = *reinterpret_cast<const f32x4 *>(shb + t * tstride);
 #pragma unroll
