@@ -113,5 +113,42 @@ def posed():
 
 
 total_bad += soak("posed frame (65 536 rays: two closest-face searches + two render passes)", posed, int(25 * scale))
+# round 5: a field with view directions (the SH instantiation of the renderer: the per-ray bias is formed by a ray's first segment and handed on with the
+# segment state), the SDF on a grid, marching cubes, the one-launch density-grid update
+from avatarcraft_amd.instant_nsr import NeRFNetwork
+torch.manual_seed(0)
+vnet = NeRFNetwork(use_viewdirs=True)
+vsd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net.1", "color_net.2", "deviation_net"))}
+vsd["encoder.embeddings"] = torch.from_numpy(tab); vsd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
+vnet.load_state_dict(vsd, strict=False)
+vnet = vnet.to(dev).eval()
+with torch.no_grad():
+    vf = vnet._field()
+bro, brd = views["bench batch"]
+total_bad += soak("render bench batch with view directions, exact, lean", lambda: nsr_ops.render_rays(vf, bro, brd, 64, 64, 1.6, inv_s, noise=noise), int(1500 * scale))
+total_bad += soak("render sds view with view directions, exact, all per-sample outputs",
+                  lambda: nsr_ops.render_rays(vf, ro, rd, 64, 64, 1.6, inv_s, noise=noise, extras=True, train_extras=True), int(300 * scale))
+ax = torch.linspace(-1.6, 1.6, 256).to(dev)
+vol = nsr_ops.field_sdf_grid(f, ax, ax, ax, 1.6, negate=True)
+total_bad += soak("SDF on a 256^3 grid (ac_field_sdf_grid)", lambda: {"vol": nsr_ops.field_sdf_grid(f, ax, ax, ax, 1.6, negate=True)}, int(40 * scale))
+
+
+def mesh():
+    v, t = nsr_ops.marching_cubes(vol, 0.0, den=255.0, span=[3.2] * 3, lo=[-1.6] * 3)
+    return {"v": v, "t": t}
+
+
+total_bad += soak("marching cubes on that volume (%d vertices)" % mesh()["v"].shape[0], mesh, int(100 * scale))
+ax129 = torch.linspace(-1.6, 1.6, 129).to(dev)
+g0 = torch.rand((129, 129, 129), generator=torch.Generator().manual_seed(4)).to(dev) * 40.0
+
+
+def grid_update():
+    g = g0.clone()
+    m = nsr_ops.density_grid_update(occ_field, ax129, g, 1.6, 512.0, 0.95)
+    return {"grid": g, "mean": m}
+
+
+total_bad += soak("density-grid update, one launch (129^3)", grid_update, int(200 * scale))
 print("hand-off timeouts on this stream:", nsr_ops.handoff_timeouts(dev))
 print("total: %d differing repeats; %.0f s" % (total_bad, time.time() - t0))
