@@ -453,7 +453,10 @@ def sds_idle_step(net_style, optimizer, flat_grad, n_active, process_group=None)
 
 
 def _avg_in_collective(process_group):
-    """RCCL averages inside the collective (ncclAvg: no separate pass over the 49 MB); gloo -- the CPU tests' backend -- has no AVG"""
+    """RCCL averages inside the collective (ncclAvg: no separate pass over the 49 MB); gloo -- the CPU tests' backend -- has no AVG.
+    AC_ALLREDUCE_AVG=0 forces sum + one scaling pass on every backend (an RCCL build without ncclAvg; A/B on a multi-GPU node)."""
+    if os.environ.get("AC_ALLREDUCE_AVG", "1") == "0":
+        return False
     try:
         return str(torch.distributed.get_backend(process_group)).lower() == "nccl"
     except Exception:
