@@ -479,7 +479,11 @@ def time_geometry(dev, p, table, reps=3):
             "field_evaluations": evals, "vertices": int(v.shape[0]), "triangles": int(t.shape[0]),
             "roofline": {"bound": "hbm", "kernel": "field_sdf_grid_kernel", "algorithmic_bytes": evals * 1024, "achieved": gb / (sdf_ms * 1e-3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / (sdf_ms * 1e-3) / HBM_PEAK_GBS,
-                         "floor_ms_at_peak": gb / HBM_PEAK_GBS * 1e3},
+                         "floor_ms_at_peak": gb / HBM_PEAK_GBS * 1e3,
+                         "note": "bytes = gather REQUESTS (SURVEY 8d: 1024 B per forward_sdf query).  A fraction above 1 is possible and means what it says: tiles of 16 "
+                                 "grid points along x -- the axis the spatial hash is linear in -- find several lanes' entries in one 64-byte sector, so fewer bytes move than "
+                                 "are requested (FETCH_SIZE 36.2 GB per 512^3 = 0.26 of the requests, profiles/r05_pmc_summary.json).  What bounds the kernel now is instruction "
+                                 "issue: 5.22 G VALU x 4 + 0.436 G MFMA x 32 clocks over 1024 SIMDs = 16.2 ms of pipe time (profiles/r05_experiments.txt section 2)"},
             "note": "reference: extract_geometry(NSR_BOUND, 512) of stylize.py:267 (512^3 forward_sdf queries in 256^3 blocks assembled on the host + PyMCubes "
                     "on the CPU); here one ac_field_sdf_grid launch + ac_marching_cubes_count / _emit (classify, scan, emit; one 8-byte read-back between "
                     "them), the volume never leaves the device; marching_cubes_ms includes that read-back and the allocation of the scratch"}
