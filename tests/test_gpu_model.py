@@ -631,6 +631,11 @@ def test_sds_step_through_rccl_world_size_1():
         p2, f2, m2 = one_step(overlap=True)
         p3, f3, _ = one_step(overlap=True, batch=128)      # (only the LAST patch's backward may release the early slice)
         probe = torch.ones(4, device=DEV); dist.all_reduce(probe); assert float(probe.sum()) == 4.0
+        # round 5: on RCCL the data-parallel step averages INSIDE the collective (stylize.reduce_gradients: ReduceOp.AVG = ncclAvg).  One rank cannot show the
+        # division, but it shows that this torch + RCCL build accepts the operator on the flat gradient's dtype -- the first multi-GPU lease must not be the first call
+        from avatarcraft_amd.stylize import _avg_in_collective
+        assert _avg_in_collective(None)
+        probe = torch.full((5,), 3.0, device=DEV); dist.all_reduce(probe, op=dist.ReduceOp.AVG); assert float(probe.sum()) == 15.0
     finally:
         dist.destroy_process_group()
     assert "grad_allreduce" in m1 and "grad_allreduce" in m2 and f1.numel() == 12248902

@@ -367,3 +367,15 @@ def test_dtype_codes_and_adam_argument_checks():
     (p * 2.0).sum().backward()
     assert not opt.grads_cleared and float(p.grad.min()) == 2.0
     assert set(opt.state_dict()["param_groups"][0].keys()) == set(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3).state_dict()["param_groups"][0].keys())
+
+
+def test_drivers_shard_views_round_robin_over_ranks():
+    """multi-GPU inference: views / frames are dealt to the ranks round robin, every index exactly once, no collective"""
+    from avatarcraft_amd.drivers import shard_indices
+    assert shard_indices(10) == list(range(10))                        # no process group: everything
+    parts = [shard_indices(10, r, 4) for r in range(4)]
+    assert parts == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+    assert sorted(i for p_ in parts for i in p_) == list(range(10))
+    assert shard_indices(3, 5, 8) == [] and shard_indices(0, 0, 1) == []
+    with pytest.raises(ValueError):
+        shard_indices(4, 2, 2)
