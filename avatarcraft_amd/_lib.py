@@ -121,6 +121,9 @@ _SIGS = {
     "ac_debug_warped_phases": ([C.c_int], None),
     "ac_debug_warped_phase_ms": ([vp], C.c_int),
     "ac_render_rays_occupancy": ([C.POINTER(ac_field), vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, f32, vp, vp, vp, vp, vp, u32, vp], C.c_int),
+    "ac_render_rays_occupancy_train_scratch": ([u32], C.c_size_t),
+    "ac_render_rays_occupancy_train": ([C.POINTER(ac_field), vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, f32, u32, u32, u32, vp, vp, u32, f32, vp, vp, vp, vp,
+                                        vp, C.c_size_t, vp], C.c_int),
     "ac_field_samples": ([C.POINTER(ac_field), vp, vp, vp, u32, u32, f32, f32, f32, vp, f32, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_color_backward_scratch": ([u32], C.c_size_t),
     "ac_color_backward": ([C.POINTER(ac_field), vp, vp, vp, vp, u32, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
@@ -159,7 +162,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
             fn.argtypes = args
             fn.restype = res
-        if handle.ac_version() != 6:
+        if handle.ac_version() != 7:
             raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
         _lib = handle
     return _lib

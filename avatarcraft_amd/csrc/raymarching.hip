@@ -14,6 +14,8 @@
 //     exclusive scan (wave64 DPP scan + LDS carry) turns counts into offsets IN RAY ORDER, pass 2
 //     writes.  rays[N,3] = (id, offset, n_steps) is therefore bit-reproducible and equal to the
 //     serial order (the order of the SURVEY A.4 known answers).  Same for compact_rays.
+//   * the walk's grid look-ups are issued RM_BATCH at a time (rm_device.hpp: rm_march_batch, round 5) -- the reference's decisions replayed over
+//     positions that are known in advance, the same samples bit for bit, a fraction of the dependent round trips to L2.
 //   * arithmetic follows the reference without fma contraction (the A.4 KATs were produced that way;
 //     build flag -ffp-contract=off), the `0.5 *` voxel conversion is evaluated in double like the
 //     reference's double literal.
@@ -25,13 +27,6 @@ using namespace acdev;
 
 namespace {
 
-__device__ __forceinline__ float ray_t0(const RayCtx &c, float near, uint32_t n, uint32_t perturb)
-{
-    float t0 = near;
-    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1);
-    return t0;
-}
-
 // pass 1: number of occupied steps per ray
 __global__ __launch_bounds__(256) void march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                           const float *__restrict__ grid, float mean_density, float bound,
@@ -41,14 +36,10 @@ __global__ __launch_bounds__(256) void march_count_kernel(const float *__restric
     if (n >= N) return;
     RayCtx c; rm_setup(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, mean_density, bound, H);
     float near, far; rm_near_far(c, near, far);
-    float t = ray_t0(c, near, n, perturb);
-    uint32_t num_steps = 0; float x, y, z; int nx, ny, nz;
-    while (t < far && num_steps < RM_MAX_STEPS) {
-        const float den = rm_density(c, t, x, y, z, nx, ny, nz);
-        if (den > c.thresh) { num_steps++; t += rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max); }
-        else t = rm_skip(c, t, x, y, z, nx, ny, nz);
-    }
-    counts[n] = (int32_t)num_steps;
+    float t = ray_t0(c, near, n, perturb), skip_tt = RM_NO_SKIP;
+    uint32_t room = RM_MAX_STEPS;                                 // the reference's walk (`while (t < far && num_steps < MAX)`), look-ups RM_BATCH at a time: rm_march_batch
+    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, [](float, float, float, float, float) {})) {}
+    counts[n] = (int32_t)(RM_MAX_STEPS - room);
 }
 
 // single-workgroup exclusive scan of vals[0..n) (in place) starting at base[0]; then base[0] += total,
@@ -93,17 +84,14 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float *__restric
     if (point_index + num_steps >= M) return;
     RayCtx c; rm_setup(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, mean_density, bound, H);
     float near, far; rm_near_far(c, near, far);
-    float t = ray_t0(c, near, n, perturb);
+    float t = ray_t0(c, near, n, perturb), skip_tt = RM_NO_SKIP;
     float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3, *pt = deltas + point_index;
-    uint32_t step = 0; float x, y, z; int nx, ny, nz;
-    while (t < far && step < num_steps) {
-        const float den = rm_density(c, t, x, y, z, nx, ny, nz);
-        if (den > c.thresh) {
-            px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
-            const float dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
-            t += dt; pt[0] = dt; px += 3; pd += 3; pt++; step++;
-        } else t = rm_skip(c, t, x, y, z, nx, ny, nz);
-    }
+    uint32_t room = num_steps;
+    auto emit = [&](float x, float y, float z, float dt, float) {
+        px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+        pt[0] = dt; px += 3; pd += 3; pt++;
+    };
+    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, emit)) {}
 }
 
 __global__ __launch_bounds__(256) void composite_train_fwd_kernel(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
@@ -173,16 +161,14 @@ __global__ __launch_bounds__(256) void march_rays_kernel(uint32_t n_alive, uint3
     const float far = fars[index];
     float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pt = deltas + (size_t)n * n_step * 2;
     if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
-    float last_t = t; uint32_t step = 0; float x, y, z; int nx, ny, nz;
-    while (t < far && step < n_step) {
-        const float den = rm_density(c, t, x, y, z, nx, ny, nz);
-        if (den > c.thresh) {
-            px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
-            const float dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
-            t += dt; pt[0] = dt; pt[1] = t - last_t; last_t = t;
-            px += 3; pd += 3; pt += 2; step++;
-        } else t = rm_skip(c, t, x, y, z, nx, ny, nz);
-    }
+    float last_t = t, skip_tt = RM_NO_SKIP;
+    uint32_t room = n_step;
+    auto emit = [&](float x, float y, float z, float dt, float t_after) {
+        px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+        pt[0] = dt; pt[1] = t_after - last_t; last_t = t_after;
+        px += 3; pd += 3; pt += 2;
+    };
+    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, emit)) {}
 }
 
 __global__ __launch_bounds__(256) void composite_rays_kernel(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,

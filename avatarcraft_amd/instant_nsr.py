@@ -511,6 +511,8 @@ class NeRFRenderer(nn.Module):
         return depth.reshape(B, N), weights, weights_sum, image.reshape(B, N, 3), normal_map, gradient_error, curvature_error, color, alpha, z_vals
 
     # ------------------------------------------------------------------ occupancy-grid rendering (cuda_ray = True)
+    occupancy_train_one_launch = True  # run_cuda's train() branch under no_grad (stylize.py's render_val of a cuda_ray net) as ONE launch (ac_render_rays_occupancy_train);
+                                       # False: the chain of operators (march_rays_train / ac_field_samples / composite_rays_train x 2 / torch) -- same pixels
     occupancy_rounds = False           # True: run_cuda's eval() as the reference-shaped loop of compact / march / field / composite rounds (same results)
 
     def run_cuda(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0, render_can=True,
@@ -551,11 +553,28 @@ class NeRFRenderer(nn.Module):
             counter = self.step_counter[self.local_step % 64]
             counter.zero_()
             self.local_step += 1
+            needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            budgeted = self.mean_count > 0
+            if not needs_grad and self.occupancy_train_one_launch:
+                # no graph wanted: count, march, field, both composites, the eikonal term and the background in one launch -- the same pixels as the chain below
+                cap = raymarching.raymarching._round_up(int(self.mean_count), 128) if budgeted else 0     # (march_rays_train's capacity: + 128 - n % 128)
+                o = nsr_ops.render_rays_occupancy_train(self._field(), ro, rd, self.density_grid, self.mean_density, bound, fd_eps, inv_s_t, cos_anneal_ratio,
+                                                        perturb=bool(perturb_overwrite), capacity=cap, composite_capacity=cap, counter=counter, bg=bg)
+                gradient_error = o["gradient_error"][0]
+                self._guard_finite(gradient_error)
+                depth = torch.zeros(n_rays, dtype=torch.float32, device=device)
+                return (depth.reshape(B, N), None, o["weights_sum"][:, None], o["image"].reshape(B, N, 3), o["normal_map"], gradient_error, 0.0, None, None, None)
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, bound, self.density_grid, self.mean_density, self.iter_density, counter,
                                                                     self.mean_count, bool(perturb_overwrite), 128, False)
             M = xyzs.shape[0]
-            valid = (torch.arange(M, device=device) < counter[0]).float()          # samples past counter[0] are alignment padding (all-zero rows)
-            needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            if budgeted:
+                # the rays the budget left out wrote nothing: the marched samples are a prefix of the layout that ends with the last ray that fitted
+                # (rows behind it are zeros -- and would otherwise count as samples AT THE ORIGIN in the eikonal term)
+                ends = rays[:, 1] + rays[:, 2]
+                n_valid = (ends * ((rays[:, 2] > 0) & (ends < M))).max()
+            else:
+                n_valid = counter[0]
+            valid = (torch.arange(M, device=device) < n_valid).float()             # rows past the marched samples are alignment padding (all-zero rows)
             if needs_grad:
                 enc = self.encoder
                 W = nsr_ops.weight_norm_all(list(self.sdf_net) + list(self.color_net))

@@ -577,16 +577,27 @@ def time_occupancy_render(dev, p, table, ro, rd, reps=3):
         net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
         samples = int(net.step_counter[0, 0].item())
         net.mean_count = samples + 4096
-        for _ in range(2):
-            net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 20
+        def train_form(one_launch):
+            net.occupancy_train_one_launch = one_launch
+            try:
+                for _ in range(3):
+                    o = net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(40):
+                    net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / 40, o["rgb"]
+            finally:
+                net.occupancy_train_one_launch = True
+        dt_chain, img_chain = train_form(False)
+        dt, img_one = train_form(True)
         res["train_form_4096_ray_batch"] = {"ms_per_batch": dt * 1e3, "rays_per_s": RAYS_PER_BATCH / dt, "samples_per_ray": samples / RAYS_PER_BATCH,
-                                            "bytes_per_sample_gathered": 7 * 1024, "gather_gbs": samples * 7 * 1024 / dt / 1e9}
+                                            "bytes_per_sample_gathered": 7 * 1024, "gather_gbs": samples * 7 * 1024 / dt / 1e9,
+                                            "chain_of_operators_ms_per_batch": dt_chain * 1e3, "pixels_identical_to_the_chain": bool(torch.equal(img_one, img_chain)),
+                                            "note": "net.train() under no_grad (stylize.py's render_val of a cuda_ray net): ONE launch (ac_render_rays_occupancy_train: "
+                                                    "count, grid barrier, march + field + both composites + eikonal term + background; grid look-ups 8 at a time) "
+                                                    "against the chain it replaces (march_rays_train, ac_field_samples, composite_rays_train x 2, torch)"}
     res["density_grid_update_ms"] = t_grid * 1e3
     res["note"] = ("occupancy-grid path (cuda_ray=True): a separate renderer from the headline's run(); the reference ships its operators but no caller "
                    "(run_cuda is undefined there), so there is no reference number for it")

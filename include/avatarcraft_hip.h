@@ -42,7 +42,7 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 6 (round 5: ac_render_rays_occupancy's max_steps, ac_field_sdf_grid, ac_marching_cubes*,
+int ac_version(void);                /* ABI version, currently 7 (round 5, second half: ac_render_rays_occupancy_train; 6, round 5: ac_render_rays_occupancy's max_steps, ac_field_sdf_grid, ac_marching_cubes*,
                                       * ac_density_grid_update, the SH colour input of ac_field; round 4 = 5: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
                                       * ac_field_samples, ac_render_rays_occupancy, the measurement / liveness accessors, the *_typed encoder entries) */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
@@ -376,6 +376,30 @@ int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const f
                              float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
                              float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
                              ac_stream_t stream);
+
+/* The training form of run_cuda WITHOUT autograd as ONE launch (ABI 7) -- stylize.py's render_val of a cuda_ray network, which never leaves train() mode
+ * (stylize.py:46-215 never calls eval()): what ac_march_rays_train (count, scan, write) -> ac_field_samples -> ac_composite_rays_train_forward twice (colour,
+ * normal) -> the eikonal term and the background in torch compute, with the samples never leaving the compute unit.  Per ray: the walk of
+ * kernel_march_rays_train (raymarching.cu:56-222; perturb: t0 = near + dt_min * pcg32(ray).next_float()), the field on its samples (the arithmetic of
+ * ac_field_samples with the marcher's step as the section length), kernel_composite_rays_train_forward's loop (:232-301: T < 1e-4 ends the sums) for image
+ * and normal map on the same weights.  The packed layout is never written, but its bookkeeping is kept, because the reference's budget rule depends on it:
+ *   capacity            M of ac_march_rays_train: a ray whose samples would end at or beyond it (offset + count >= M, offsets in ray order from counter[0])
+ *                       is not marched (:133);
+ *   composite_capacity  M of ac_composite_rays_train_forward: such a ray gets weights_sum = image = 0 (:249); 0 = n + 128 - n % 128 for n = counter[0] after the march,
+ *                       the trimmed layout of an un-budgeted march_rays_train call (raymarching.py rounds like the reference: a full 128 on an aligned n);
+ *   counter             optional [2] int32 (device): [0] += samples of all rays, [1] += N, like the stand-alone marcher.
+ * bg_mode: image += (1 - weights_sum) * bg (run_cuda's last line; torch's three operations in torch's order): 0 none, 1 the scalar bg_value, 2 bg[3],
+ * 3 bg[N][3].  gradient_error [1] (device): sum(relax * (|gradient| - 1)^2) / (sum(relax) + 1e-5) over the marched samples, relax = |x| < 1.2
+ * (models/instant_nsr.py:266-272), summed in double in a fixed order (run to run identical; torch's fp32 tree differs from it by ~1e-6 relative);
+ * NaN if the launch's grid barrier timed out (it cannot with one workgroup per compute unit; the bound exists so that a mis-sized launch fails instead of hanging).
+ * weights_sum / image / normal_map are the bits of the chain of operators.  scratch: ac_render_rays_occupancy_train_scratch(N) bytes, ZERO-FILLED by the
+ * caller before its first use (every call leaves it re-armed for calls with the SAME N: the layout depends on N), one buffer per stream and ray count. */
+size_t ac_render_rays_occupancy_train_scratch(uint32_t N);
+int ac_render_rays_occupancy_train(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
+                                   float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
+                                   uint32_t perturb, uint32_t capacity, uint32_t composite_capacity, int32_t *counter, const float *bg,
+                                   uint32_t bg_mode, float bg_value, float *weights_sum, float *image, float *normal_map, float *gradient_error,
+                                   void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
 /* ---- geometry of the learned surface: mesh export and the marcher's density grid ----------------------------------------
  * ac_field_sdf_grid replaces extract_fields (models/instant_nsr.py:728-745): forward_sdf(x)[0] (:627-642) on the grid axis_x x axis_y x axis_z

@@ -411,7 +411,12 @@ def run_cuda_train(field, rays_o, rays_d, grid, mean_density, bound, eps, inv_s,
     fs = field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio)
     ws, img = composite_rays_train_forward(fs["alpha"], fs["rgb"], deltas, rays, bound)
     _, nmap = composite_rays_train_forward(fs["alpha"], fs["normal"], deltas, rays, bound)
-    valid = (np.arange(xyzs.shape[0]) < int(counter[0])).astype(np.float32)
+    n_valid = int(counter[0])
+    if mean_count > 0:          # rays the budget left out wrote nothing: the marched samples end with the last ray that fitted (rows behind it are zeros, not samples)
+        ends = rays[:, 1].astype(np.int64) + rays[:, 2]
+        fit = (rays[:, 2] > 0) & (ends < xyzs.shape[0])
+        n_valid = int(ends[fit].max()) if fit.any() else 0
+    valid = (np.arange(xyzs.shape[0]) < n_valid).astype(np.float32)
     relax = (np.sqrt((xyzs.astype(np.float64) ** 2).sum(1)) < 1.2).astype(np.float64) * valid
     gerr = (np.sqrt((fs["gradient"].astype(np.float64) ** 2).sum(1)) - 1.0) ** 2
     res = dict(fs)

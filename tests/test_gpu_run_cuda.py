@@ -111,6 +111,58 @@ def test_run_cuda_training_form_vs_oracle_chain(env):
     net.mean_count = 0
 
 
+@pytest.mark.parametrize("n_rays,perturb,budget,bg_kind", [(1024, False, None, "rays"), (1024, True, "loose", "scalar"), (1024, True, "tight", "triple"),
+                                                         (1000, True, "tight", "none"), (37, False, None, "scalar"), (1, True, None, "triple"),
+                                                         (4096, True, "loose", "rays")])
+def test_training_form_in_one_launch_equals_the_chain_of_operators(env, n_rays, perturb, budget, bg_kind):
+    """round 5: run_cuda's train() branch under no_grad as ONE launch (ac_render_rays_occupancy_train: count, grid barrier, march + field + the packed
+    compositor twice + eikonal term + background) against the chain it replaces (march_rays_train / ac_field_samples / composite_rays_train x 2 / torch):
+    pixels, opacity and normal map bit for bit, the step counter exactly, the eikonal term to the rounding of a differently ordered sum -- with and without
+    the marcher's jitter, un-budgeted (trimmed layout), with a budget that fits and with one that leaves rays out (raymarching.cu:133, 249), ragged ray counts"""
+    net = env["net"].train()
+    side = int(np.ceil(np.sqrt(n_rays)))
+    ro, rd = make_rays(side, side, dist=1.8, f=0.75 * side)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[:n_rays])).to(DEV)
+    rs = np.random.RandomState(n_rays)
+    bg = {"rays": torch.from_numpy(rs.uniform(0, 1, (n_rays, 3)).astype(np.float32)).to(DEV), "scalar": None,
+          "triple": torch.tensor([[0.2, 0.7, 0.4]], device=DEV), "none": torch.zeros(1, 3, device=DEV)}[bg_kind]
+    kw = dict(num_steps=64, bound=1.6, upsample_steps=64, bg_color=bg, cos_anneal_ratio=0.7, normal_epsilon_ratio=0.0, perturb=perturb)
+    outs, counters = {}, {}
+    total = None
+    for one in (False, True):
+        net.occupancy_train_one_launch = one
+        if budget is None:
+            net.mean_count = 0
+        else:
+            if total is None:                                   # the batch's sample count, from an un-budgeted pass
+                net.mean_count, net.local_step = 0, 0
+                with torch.no_grad():
+                    net.render(t(ro)[None], t(rd)[None], **kw)
+                total = int(net.step_counter[0, 0].item())
+                assert total > 4 * n_rays
+            net.mean_count = total if budget == "loose" else (2 * total) // 3
+        net.local_step = 7
+        try:
+            with torch.no_grad():
+                outs[one] = net.render(t(ro)[None], t(rd)[None], **kw)
+        finally:
+            net.occupancy_train_one_launch = True
+        counters[one] = tuple(net.step_counter[7].cpu().numpy().tolist())
+    net.mean_count = 0
+    a, b = outs[False], outs[True]
+    assert counters[True] == counters[False] and counters[True][1] == n_rays
+    for k in ("weight_sum", "rgb", "normal"):
+        assert_bitwise(b[k], a[k].cpu().numpy(), k)
+    ga, gb = float(a["gradient_error"]), float(b["gradient_error"])
+    assert np.isfinite(gb) and abs(ga - gb) <= 2e-5 * max(1.0, abs(ga)), (ga, gb)
+    hit = float((a["weight_sum"] > 0).float().mean())
+    if budget == "tight":
+        assert 0.05 < hit < 0.95                                # the budget left the later rays out: zeros in both forms
+        assert float(a["weight_sum"][-max(1, n_rays // 8):].abs().max()) == 0.0
+    elif n_rays >= 37:
+        assert hit > 0.05
+
+
 def test_run_cuda_inference_loop_vs_oracle_chain(env):
     O, net = env["O"], env["net"].eval()
     ro, rd = make_rays(48, 48, dist=1.8, f=36.0)

@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05_occ2; mkdir -p $O
+timeout 600 python -m pytest tests -m gpu -q --maxfail=15 -p no:cacheprovider -k "one_launch_equals or training_form" > $O/pytest.log 2>&1; echo "pytest rc $?"
+grep -n "passed\|failed" $O/pytest.log | tail -3; grep -n "^E  " $O/pytest.log | cut -c1-300 | head -20
+python tools/occ_train_probe.py 2>/dev/null | tail -1
+for v in rm1 rm4 rm16 rm32; do AC_LIB_PATH=$PWD/tools/_bin/lib_$v.so python tools/occ_train_probe.py 2>/dev/null | tail -1; done
+for gl in 1 3 4; do AC_OCC_TRAIN_GLOG=$gl python tools/occ_train_probe.py 2>/dev/null | tail -1; done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/kt -o p -- python $GRAFT_REPO_ROOT/tools/occ_train_probe.py > /dev/null 2>&1
+python - <<PY
+import csv,glob
+for f in glob.glob("$GRAFT_REPO_ROOT/$O/kt/**/p_kernel_stats.csv", recursive=True):
+    rows=sorted(csv.DictReader(open(f)), key=lambda r:-float(r['TotalDurationNs']))
+    for r in rows[:14]: print("%-60s calls %5s avg %9.1f us" % (r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3))
+PY
