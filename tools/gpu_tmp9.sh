@@ -1,4 +1,12 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05_occ3; mkdir -p $O
-timeout 600 python -m pytest tests -m gpu -q --maxfail=15 -p no:cacheprovider -k "one_launch_equals or training_form" > $O/pytest.log 2>&1; echo "pytest rc $?"
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05_occ4; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -q --maxfail=15 -p no:cacheprovider -k "run_cuda or raymarch or occupancy or march or density or pins" > $O/pytest.log 2>&1; echo "pytest rc $?"
 grep -n "passed\|failed" $O/pytest.log | tail -3; grep -n "^E  " $O/pytest.log | cut -c1-300 | head -20
-for gl in 1 2 3; do AC_OCC_TRAIN_GLOG=$gl python tools/occ_train_probe.py 2>/dev/null | tail -1; done
+python tools/occ_train_probe.py 2>/dev/null | tail -1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/kt -o p -- python $GRAFT_REPO_ROOT/tools/occ_train_probe.py > /dev/null 2>&1
+python - <<PY
+import csv,glob
+for f in glob.glob("$GRAFT_REPO_ROOT/$O/kt/**/p_kernel_stats.csv", recursive=True):
+    rows=sorted(csv.DictReader(open(f)), key=lambda r:-float(r['TotalDurationNs']))
+    for r in rows[:8]: print("%-60s calls %5s avg %9.1f us" % (r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3))
+PY
