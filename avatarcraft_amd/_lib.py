@@ -85,6 +85,7 @@ _SIGS = {
     "ac_adam_step": ([C.POINTER(ac_adam_entry), u32, f32, f32, f32, f32, f32, f32, f32, C.c_int, vp], C.c_int),
     "ac_sh_encode_forward": ([vp, vp, u32, u32, u32, C.c_int, vp, vp], C.c_int),
     "ac_sh_encode_backward": ([vp, vp, u32, u32, u32, vp, vp, vp], C.c_int),
+    "ac_march_rays_train_scratch": ([u32], C.c_size_t),
     "ac_march_rays_train": ([vp, vp, vp, f32, C.c_int, f32, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, vp], C.c_int),
     "ac_composite_rays_train_forward": ([vp, vp, vp, vp, f32, u32, u32, vp, vp, vp], C.c_int),
     "ac_composite_rays_train_backward": ([vp, vp, vp, vp, vp, vp, vp, vp, f32, u32, u32, vp, vp, vp], C.c_int),
@@ -121,7 +122,7 @@ _SIGS = {
     "ac_debug_warped_phases": ([C.c_int], None),
     "ac_debug_warped_phase_ms": ([vp], C.c_int),
     "ac_render_rays_occupancy": ([C.POINTER(ac_field), vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, f32, vp, vp, vp, vp, vp, u32, vp], C.c_int),
-    "ac_render_rays_occupancy_train_scratch": ([u32], C.c_size_t),
+    "ac_render_rays_occupancy_train_scratch": ([u32, u32], C.c_size_t),
     "ac_render_rays_occupancy_train": ([C.POINTER(ac_field), vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, f32, u32, u32, u32, vp, vp, u32, f32, vp, vp, vp, vp,
                                         vp, C.c_size_t, vp], C.c_int),
     "ac_field_samples": ([C.POINTER(ac_field), vp, vp, vp, u32, u32, f32, f32, f32, vp, f32, vp, vp, vp, vp, vp, vp], C.c_int),

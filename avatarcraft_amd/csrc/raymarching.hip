@@ -27,19 +27,30 @@ using namespace acdev;
 
 namespace {
 
-// pass 1: number of occupied steps per ray
+// pass 1: number of occupied steps per ray -- and WHICH positions of the ray's recurrence they are (rec: RM_REC_WORDS words per ray, rm_device.hpp)
 __global__ __launch_bounds__(256) void march_count_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                           const float *__restrict__ grid, float mean_density, float bound,
-                                                          uint32_t N, uint32_t H, uint32_t perturb, int32_t *__restrict__ counts)
+                                                          uint32_t N, uint32_t H, uint32_t perturb, int32_t *__restrict__ counts,
+                                                          uint32_t *__restrict__ rec, int32_t *__restrict__ ovf, uint32_t *__restrict__ wmask)
 {
+    __shared__ float edge[RM_EDGE_MAX];                           // the voxel faces (rm_skip_target_tab): H + 1 values; a larger grid computes them per position
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        RayCtx c0{}; c0.H = H; c0.bound = bound;
+        for (uint32_t m = threadIdx.x; m <= H && m < (uint32_t)RM_EDGE_MAX; m += blockDim.x) edge[m] = rm_edge(c0, m);
+        __syncthreads();
+    }
     if (n >= N) return;
+    const float *etab = H < (uint32_t)RM_EDGE_MAX ? edge : nullptr;
     RayCtx c; rm_setup(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, mean_density, bound, H);
     float near, far; rm_near_far(c, near, far);
     float t = ray_t0(c, near, n, perturb), skip_tt = RM_NO_SKIP;
-    uint32_t room = RM_MAX_STEPS;                                 // the reference's walk (`while (t < far && num_steps < MAX)`), look-ups RM_BATCH at a time: rm_march_batch
-    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, [](float, float, float, float, float) {})) {}
+    uint32_t room = RM_MAX_STEPS, kpos = 0;                       // the reference's walk (`while (t < far && num_steps < MAX)`), look-ups RM_BATCH at a time: rm_march_batch
+    RayRecorder rr; rr.begin(rec + (size_t)n * RM_REC_WORDS);
+    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, [&](float, float, float, float, float, uint32_t k) { rr.add(k); }, etab)) {}
+    rr.end();
     counts[n] = (int32_t)(RM_MAX_STEPS - room);
+    ovf[n] = rr.ovf ? 1 : 0; wmask[n] = rr.wmask;
 }
 
 // single-workgroup exclusive scan of vals[0..n) (in place) starting at base[0]; then base[0] += total,
@@ -74,7 +85,8 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float *__restric
                                                           uint32_t N, uint32_t H, uint32_t M, uint32_t perturb,
                                                           const int32_t *__restrict__ counts, const int32_t *__restrict__ offsets,
                                                           const int32_t *__restrict__ ray_base, float *__restrict__ xyzs, float *__restrict__ dirs,
-                                                          float *__restrict__ deltas, int32_t *__restrict__ rays)
+                                                          float *__restrict__ deltas, int32_t *__restrict__ rays, const uint32_t *__restrict__ rec,
+                                                          const int32_t *__restrict__ ovf, const uint32_t *__restrict__ wmask)
 {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -84,14 +96,22 @@ __global__ __launch_bounds__(256) void march_write_kernel(const float *__restric
     if (point_index + num_steps >= M) return;
     RayCtx c; rm_setup(c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, mean_density, bound, H);
     float near, far; rm_near_far(c, near, far);
-    float t = ray_t0(c, near, n, perturb), skip_tt = RM_NO_SKIP;
     float *px = xyzs + (size_t)point_index * 3, *pd = dirs + (size_t)point_index * 3, *pt = deltas + point_index;
-    uint32_t room = num_steps;
-    auto emit = [&](float x, float y, float z, float dt, float) {
+    const float t0 = ray_t0(c, near, n, perturb);
+    if (!ovf[n]) {                                                // the counting pass recorded the samples' positions: replay the recurrence, no second walk
+        rm_replay(c, t0, rec + (size_t)n * RM_REC_WORDS, wmask[n], num_steps, [&](float x, float y, float z, float dt) {
+            px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+            pt[0] = dt; px += 3; pd += 3; pt++;
+        });
+        return;
+    }
+    float t = t0, skip_tt = RM_NO_SKIP;
+    uint32_t room = num_steps, kpos = 0;
+    auto emit = [&](float x, float y, float z, float dt, float, uint32_t) {
         px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
         pt[0] = dt; px += 3; pd += 3; pt++;
     };
-    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, emit)) {}
+    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, emit)) {}
 }
 
 __global__ __launch_bounds__(256) void composite_train_fwd_kernel(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
@@ -162,13 +182,13 @@ __global__ __launch_bounds__(256) void march_rays_kernel(uint32_t n_alive, uint3
     float *px = xyzs + (size_t)n * n_step * 3, *pd = dirs + (size_t)n * n_step * 3, *pt = deltas + (size_t)n * n_step * 2;
     if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
     float last_t = t, skip_tt = RM_NO_SKIP;
-    uint32_t room = n_step;
-    auto emit = [&](float x, float y, float z, float dt, float t_after) {
+    uint32_t room = n_step, kpos = 0;
+    auto emit = [&](float x, float y, float z, float dt, float t_after, uint32_t) {
         px[0] = x; px[1] = y; px[2] = z; pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
         pt[0] = dt; pt[1] = t_after - last_t; last_t = t_after;
         px += 3; pd += 3; pt += 2;
     };
-    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, emit)) {}
+    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, emit)) {}
 }
 
 __global__ __launch_bounds__(256) void composite_rays_kernel(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
@@ -234,16 +254,21 @@ AC_API int ac_march_rays_train(const float *rays_o, const float *rays_d, const f
     hipStream_t st = (hipStream_t)stream;
     int32_t *counts = scratch;                            // [N] occupied steps per ray
     int32_t *offsets = scratch + N;                       // [N] exclusive scan of counts (+ counter[0] on entry)
-    int32_t *ray_base = scratch + 2 * (size_t)N;          // [1] counter[1] on entry (first free ray slot)
+    int32_t *ray_base = scratch + 2 * (size_t)N;          // [1] counter[1] on entry (first free ray slot) (+ 1 pad)
+    int32_t *ovf = scratch + 2 * (size_t)N + 2;           // [N] 1: a sample beyond the record (the writer walks that ray again)
+    uint32_t *wmask = reinterpret_cast<uint32_t *>(scratch + 3 * (size_t)N + 2);    // [N] which words of a ray's record are in use
+    uint32_t *rec = reinterpret_cast<uint32_t *>(scratch + 4 * (size_t)N + 2);      // [N][RM_REC_WORDS] the samples' positions (rm_device.hpp)
     hipLaunchKernelGGL(march_count_kernel, dim3((N + 255) / 256), dim3(256), 0, st, rays_o, rays_d, grid, mean_density, bound, N, H,
-                       perturb, counts);
+                       perturb, counts, rec, ovf, wmask);
     hipMemcpyAsync(offsets, counts, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(ray_base, counter + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, offsets, N, counter, (int32_t)N);
     hipLaunchKernelGGL(march_write_kernel, dim3((N + 255) / 256), dim3(256), 0, st, rays_o, rays_d, grid, mean_density, bound, N, H, M,
-                       perturb, counts, offsets, ray_base, xyzs, dirs, deltas, rays);
+                       perturb, counts, offsets, ray_base, xyzs, dirs, deltas, rays, rec, ovf, wmask);
     return ac::check_launch("march_rays_train");
 }
+
+AC_API size_t ac_march_rays_train_scratch(uint32_t N) { return (4 + (size_t)RM_REC_WORDS) * (size_t)N + 2; }
 
 AC_API int ac_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, float bound,
                                            uint32_t M, uint32_t N, float *weights_sum, float *image, ac_stream_t stream)

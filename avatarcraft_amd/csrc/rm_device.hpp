@@ -39,10 +39,14 @@ __device__ __forceinline__ void rm_pos(const RayCtx &c, float t, float &x, float
 }
 __device__ __forceinline__ void rm_voxel(const RayCtx &c, float x, float y, float z, int &nx, int &ny, int &nz)
 {
-    const float hm1 = (float)(c.H - 1);
-    nx = (int)rm_clamp((float)(0.5 * (double)(x * c.rbound + 1) * (double)c.H), 0.0f, hm1);
-    ny = (int)rm_clamp((float)(0.5 * (double)(y * c.rbound + 1) * (double)c.H), 0.0f, hm1);
-    nz = (int)rm_clamp((float)(0.5 * (double)(z * c.rbound + 1) * (double)c.H), 0.0f, hm1);
+    // The reference's expression is (float)(0.5 * (double)(x * rbound + 1) * (double)H) (raymarching.cu: `0.5 * (x * rbound + 1) * H` with a double literal).
+    // v = x * rbound + 1 is a float in {0} u [2^-24, 2]: 0.5 v is exact in either precision, and its product with H < 2^24 is exact in double (24 + 24 < 53
+    // bits), so the reference rounds the exact product to float ONCE -- which is what the fp32 product (0.5f * v) * (float)H does.  Same bits, no fp64
+    // conversions (three v_cvt_f64_f32, six v_mul_f64, three v_cvt_f32_f64 per position on a path that is bound by its instruction count).
+    const float hm1 = (float)(c.H - 1), hf = (float)c.H;
+    nx = (int)rm_clamp((0.5f * (x * c.rbound + 1)) * hf, 0.0f, hm1);
+    ny = (int)rm_clamp((0.5f * (y * c.rbound + 1)) * hf, 0.0f, hm1);
+    nz = (int)rm_clamp((0.5f * (z * c.rbound + 1)) * hf, 0.0f, hm1);
 }
 __device__ __forceinline__ float rm_density(const RayCtx &c, float t, float &x, float &y, float &z, int &nx, int &ny, int &nz)
 {
@@ -57,6 +61,21 @@ __device__ __forceinline__ float rm_skip_target(const RayCtx &c, float t, float 
     const float tx = (((nx + 0.5f + 0.5f * rm_sign(c.dx)) / hm1 * 2 - 1) * c.bound - x) * c.rdx;
     const float ty = (((ny + 0.5f + 0.5f * rm_sign(c.dy)) / hm1 * 2 - 1) * c.bound - y) * c.rdy;
     const float tz = (((nz + 0.5f + 0.5f * rm_sign(c.dz)) / hm1 * 2 - 1) * c.bound - z) * c.rdz;
+    return t + __builtin_fmaxf(0.0f, __builtin_fminf(tx, __builtin_fminf(ty, tz)));
+}
+// The same target from a table of the voxel faces: nx + 0.5f + 0.5f * sign is the integer nx or nx + 1 (exactly), so the face coordinate
+// ((nx + 0.5 + 0.5 sign) / (H - 1) * 2 - 1) * bound takes H + 1 values per launch -- edge[m], m = 0 .. H, formed by rm_edge with the expression above, the same
+// bits -- and the three IEEE divisions per visited empty position (~30 of the walk's ~160 vector instructions per position) become three LDS reads.
+__device__ __forceinline__ float rm_edge(const RayCtx &c, uint32_t m)
+{
+    const float hm1 = (float)(c.H - 1);
+    return (((float)m) / hm1 * 2 - 1) * c.bound;
+}
+__device__ __forceinline__ float rm_skip_target_tab(const RayCtx &c, const float *edge, float t, float x, float y, float z, int nx, int ny, int nz)
+{
+    const float tx = (edge[nx + (__builtin_signbitf(c.dx) ? 0 : 1)] - x) * c.rdx;
+    const float ty = (edge[ny + (__builtin_signbitf(c.dy) ? 0 : 1)] - y) * c.rdy;
+    const float tz = (edge[nz + (__builtin_signbitf(c.dz) ? 0 : 1)] - z) * c.rdz;
     return t + __builtin_fmaxf(0.0f, __builtin_fminf(tx, __builtin_fminf(ty, tz)));
 }
 __device__ __forceinline__ float rm_skip(const RayCtx &c, float t, float x, float y, float z, int nx, int ny, int nz)
@@ -79,10 +98,13 @@ __device__ __forceinline__ float rm_skip(const RayCtx &c, float t, float x, floa
 //   t        in: a position of the recurrence the walk has not decided yet; out: the next one
 //   skip_tt  pending skip target (-inf: none); a NaN target (0 * inf in a direction component) compares false like in the reference's do-while: one step
 //   room     samples the caller still takes (the reference's `step < n_step`): at 0 the walk stops AT the next visited position without consuming it
-//   emit(x, y, z, dt, t_after)   one sample
+//   emit(x, y, z, dt, t_after, k)   one sample, k = its position's index in the recurrence
 // Returns false when the walk has ended (a visited position >= far, or NaN).
+//   kpos     index of position t in the ray's recurrence (0 = the walk's first position); emit's last argument is the sample's index
+//   edge     optional table of the voxel faces (rm_edge: H + 1 floats, LDS); nullptr: the skip target's divisions are computed
 template <int B, class Emit>
-__device__ __forceinline__ bool rm_march_batch(const RayCtx &c, float &t, float &skip_tt, float far, uint32_t &room, Emit &&emit)
+__device__ __forceinline__ bool rm_march_batch(const RayCtx &c, float &t, float &skip_tt, float far, uint32_t &room, uint32_t &kpos, Emit &&emit,
+                                               const float *edge = nullptr)
 {
     float ts[B + 1], den[B];
     ts[0] = t;
@@ -97,23 +119,23 @@ __device__ __forceinline__ bool rm_march_batch(const RayCtx &c, float &t, float 
     for (int j = 0; j < B; ++j) {
         const float tj = ts[j];
         if (open && !(tj < skip_tt)) {                             // a position the reference's loop stands on
-            if (!(tj < far)) { open = false; more = false; t = tj; }
-            else if (room == 0) { open = false; t = tj; }
+            if (!(tj < far)) { open = false; more = false; t = tj; kpos += (uint32_t)j; }
+            else if (room == 0) { open = false; t = tj; kpos += (uint32_t)j; }
             else {
                 float x, y, z;
                 rm_pos(c, tj, x, y, z);
                 if (den[j] > c.thresh) {
-                    emit(x, y, z, rm_clamp(tj * c.dt_gamma, c.dt_min, c.dt_max), ts[j + 1]);
+                    emit(x, y, z, rm_clamp(tj * c.dt_gamma, c.dt_min, c.dt_max), ts[j + 1], kpos + (uint32_t)j);
                     --room;
                 } else {
                     int nx, ny, nz;
                     rm_voxel(c, x, y, z, nx, ny, nz);
-                    skip_tt = rm_skip_target(c, tj, x, y, z, nx, ny, nz);
+                    skip_tt = edge ? rm_skip_target_tab(c, edge, tj, x, y, z, nx, ny, nz) : rm_skip_target(c, tj, x, y, z, nx, ny, nz);
                 }
             }
         }
     }
-    if (open) t = ts[B];
+    if (open) { t = ts[B]; kpos += (uint32_t)B; }
     return more;
 }
 #ifndef AC_RM_BATCH
@@ -146,6 +168,50 @@ __device__ __forceinline__ float pcg_first_float(uint64_t initstate, uint64_t in
     uint64_t state = 0u; const uint64_t inc = (initseq << 1u) | 1u;
     pcg_next(state, inc); state += initstate; pcg_next(state, inc);
     return __uint_as_float((pcg_next(state, inc) >> 9) | 0x3f800000u) - 1.0f;
+}
+
+// ---- a ray's samples as a bit mask over the positions of its recurrence (round 5) ---------------------------------------------------------------------
+// The training marcher walks every ray twice: once to count (the packed layout needs every ray's offset first), once to write.  The walk is the expensive
+// part (see above); the samples are a handful of positions out of ~400.  So the counting pass RECORDS them -- bit k of RM_REC_WORDS words per ray (+ a mask of
+// the words in use, so that neither pass touches the empty ones) = position k
+// of t' = t + clamp(t dt_gamma, dt_min, dt_max) is a sample; far - near <= the cube's diagonal = 1024 dt_min bounds k -- and the writing pass replays the
+// recurrence (four instructions per position, no voxel, no look-up) and emits at the set bits: the same positions by construction, the same bits.
+// A sample at k >= 1024 (never seen: it needs a ray along the exact diagonal) raises the ray's overflow flag and the writer walks that ray again.
+constexpr int RM_REC_WORDS = 32;
+constexpr int RM_EDGE_MAX = 1026;            // the face table serves grids up to H = 1024
+struct RayRecorder {                       // one lane = one ray.  Only the words that hold a sample are written (and later read): wmask names them
+    uint32_t *rec; uint32_t w, bits, wmask; bool ovf;
+    __device__ __forceinline__ void begin(uint32_t *r) { rec = r; w = 0; bits = 0; wmask = 0; ovf = false; }
+    __device__ __forceinline__ void add(uint32_t k)
+    {
+        const uint32_t kw = k >> 5;
+        if (kw >= (uint32_t)RM_REC_WORDS) { ovf = true; return; }
+        if (kw != w) { if (bits) rec[w] = bits; w = kw; bits = 0u; }
+        bits |= 1u << (k & 31u);
+        wmask |= 1u << kw;
+    }
+    __device__ __forceinline__ void end() { if (bits) rec[w] = bits; }
+};
+// emit(x, y, z, dt) for the first `count` recorded samples of the ray whose walk starts at t0
+template <class Emit>
+__device__ __forceinline__ void rm_replay(const RayCtx &c, float t0, const uint32_t *rec, uint32_t wmask, uint32_t count, Emit &&emit)
+{
+    float t = t0;
+    uint32_t k = 0, done = 0;
+    while (wmask && done < count) {
+        const uint32_t w = (uint32_t)__builtin_ctz(wmask);
+        wmask &= wmask - 1u;
+        uint32_t bits = rec[w];
+        while (bits && done < count) {
+            const uint32_t kk = (w << 5) + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            for (; k < kk; ++k) t += rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+            float x, y, z;
+            rm_pos(c, t, x, y, z);
+            emit(x, y, z, rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max));
+            ++done;
+        }
+    }
 }
 
 // first position of the training walk (kernel_march_rays_train: t0 = near + dt_min * rng.next_float(), the generator seeded per ray)

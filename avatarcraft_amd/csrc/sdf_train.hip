@@ -587,12 +587,20 @@ struct OccArgs {
     uint32_t glog;                                         // a wave marches 2^glog rays at a time (lanes 0 .. 2^glog - 1); the 64 sample slots of an iteration (4 tiles) are
                                                            // shared out among the rays still alive: 64 / alive each -- the last, long rays of a group get whole tiles
     uint32_t max_steps;                                    // a ray stops after this many samples (run_cuda's max_steps; the loop of rounds stops at the first round that
-};                                                         // brings its step count to >= max_steps, i.e. after max_steps .. max_steps + 7 samples); 0 = no cap
+                                                           // brings its step count to >= max_steps, i.e. after max_steps .. max_steps + 7 samples); 0 = no cap
+    uint32_t edge_tab;                                     // 1: H + 1 floats of LDS behind the stages hold the voxel faces (rm_skip_target_tab)
+};
 
 __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderArgs a, const OccArgs oc)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fill_lds(lds, a);
+    const float *etab = nullptr;
+    if (oc.edge_tab) {
+        RayCtx c0{}; c0.H = oc.H; c0.bound = a.bound;
+        for (uint32_t m = threadIdx.x; m <= oc.H; m += FBLOCK) lds[OCC_LDS_FLOATS + m] = rm_edge(c0, m);
+        etab = lds + OCC_LDS_FLOATS;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
@@ -630,13 +638,14 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
                 uint32_t room = K;
                 if (oc.max_steps && oc.max_steps - taken < room) room = oc.max_steps - taken;     // (taken < max_steps while the ray is alive)
                 const uint32_t room0 = room;
-                auto emit = [&](float x, float y, float z, float dt, float t_after) {
+                auto emit = [&](float x, float y, float z, float dt, float t_after, uint32_t) {
                     sp[0] = x; sp[1] = y; sp[2] = z; sp[3] = dt; sp[7] = t_after - last_t;
                     last_t = t_after;
                     sp += 8;
                 };
                 bool more = true;                                                   // grid look-ups RM_BATCH at a time (rm_march_batch): the reference's walk, fewer round trips
-                while (room > 0 && more) more = rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, emit);
+                uint32_t kpos = 0;
+                while (room > 0 && more) more = rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, emit, etab);
                 mycnt = room0 - room; taken += mycnt;
                 if (!more) alive = false;                                           // t >= far: composite_rays would meet dl[0] == 0 here
                 if (oc.max_steps && taken >= oc.max_steps) alive = false;           // the samples staged this iteration are still composited below
@@ -715,212 +724,212 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
 
 // ---- the occupancy-grid TRAINING render without autograd as one launch (round 5) -------------------------------------------------------------------
 // What NeRFRenderer.run_cuda's train() branch computes under torch.no_grad() -- stylize.py's render_val of a cuda_ray network, which never leaves train mode --
-// as march_rays_train (count, scan, write) / ac_field_samples / two composite_rays_train / a dozen torch kernels for the eikonal term and the background:
-//   phase A  every ray's number of occupied steps (march_count_kernel's walk), one lane per ray; per 1024 rays a total (integer atomics: order-free);
-//   grid barrier (the launch is one persistent workgroup per compute unit at most, so every workgroup is resident; bounded spin, failure -> NaN);
-//   phase B  lane = ray in groups of 2^glog like the inference kernel: a ray's offset in the packed layout the stand-alone operators would have produced =
-//            counter[0] + totals of the chunks before + counts before it in its chunk -- only needed for the reference's budget rule (a ray whose samples
-//            would end at or beyond M is left out: raymarching.cu:133, 249); the samples themselves never leave the compute unit: march (same walk,
-//            emitting), the renderer's field code on tiles of 16 packed samples, composite_rays_train's loop per lane (T < 1e-4 stops the sums, not the
-//            evaluation: the eikonal term counts every sample), background.
+// as march_rays_train (count, scan, write) / ac_field_samples / two composite_rays_train / a dozen torch kernels for the eikonal term and the background.
+// One persistent workgroup per compute unit at most (so that every workgroup is resident), four phases separated by grid barriers:
+//   A  lane = ray: the walk (march_count_kernel's), counting the occupied steps and recording their positions in the ray's recurrence (RayRecorder); per
+//      256 rays a total (integer atomics: order-free);
+//   B  lane = ray: the ray's offset in the packed layout = counter[0] + totals of the chunks before + counts before it in its chunk, the reference's budget
+//      rule (a ray whose samples would end at or beyond M is left out: raymarching.cu:133), and the samples written by REPLAYING the recurrence at the
+//      recorded positions (no second walk);
+//   C  tile = 16 consecutive packed samples, dealt to ALL waves (a tile through the field code is ~45 us of latency: a wave that kept its own rays' tiles to
+//      itself -- the first form of this kernel, r05_experiments.txt section 8c -- ran three or four in a row while most of the device idled): the body of
+//      field_samples_kernel, plus the eikonal term's partial sums;
+//   D  lane = ray: composite_train_fwd_kernel's loop for image and normal map on the same weights, background.
 // weights_sum / image / normal_map: the bits of the chain of operators (tests/test_gpu_run_cuda.py).  gradient_error: the same terms summed in double
 // in a fixed order (per lane, per wave, per workgroup; the last workgroup to leave adds the partials) instead of torch's fp32 tree: equal to ~1e-6 relative.
 constexpr uint32_t OT_CHUNK_LOG = 8;                     // 2^8 rays per chunk total (a multiple of the wave's 64)
 constexpr uint32_t OT_SPIN_MAX = 1u << 22;               // x s_sleep(10): about a second
 struct OccTrainArgs {
     const float *rays_o, *rays_d, *grid;
-    uint32_t N, H, M_write, M_comp, perturb;             // M_write: capacity of the packed layout (march_write's budget); M_comp: the compositor's (0: total + 128 - total % 128, the trimmed layout)
+    uint32_t N, H, M_write, M_comp, perturb;             // M_write: capacity of the packed layout (march_write's budget, > 0); M_comp: the compositor's
     float mean_density;
     int32_t *counter;                                    // optional [2]: += samples of all rays, += N (march_rays_train's step counter)
     float *weights_sum, *image, *normal_map, *gradient_error;
     const float *bg; uint32_t bg_mode; float bg_value;   // image += (1 - weights_sum) * bg:  0 none, 1 bg_value, 2 bg[3], 3 bg[N][3]
-    uint32_t *sync;                                      // [4] zero on entry and on exit: arrivals, departures, barrier failure, -
-    int32_t *chunk_tot, *counts;                         // [chunks] zero on entry and on exit | [N]
+    uint32_t *sync;                                      // [4] zero on entry and on exit: arrivals, departures, barrier failure, samples written
+    int32_t *chunk_tot, *counts, *offs, *ovf;            // [chunks] zero on entry and on exit | [N] | [N] offset of a written ray, else -1 | [N]
+    uint32_t *wmask, *rec;                               // [N] | [N][RM_REC_WORDS]: the samples' positions (RayRecorder)
     double *partials;                                    // [gridDim.x][2]
-    uint32_t glog;
+    int32_t *p_ray; float *p_in, *p_out;                 // packed samples: ray [M] | x y z dt [M][4] | alpha r g b nx ny nz - [M][8]
 };
 
 __device__ __forceinline__ int32_t ot_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// every workgroup has arrived `phase` + 1 times (false: timed out -- a launch larger than the device; the caller gives up instead of hanging)
+__device__ __forceinline__ bool ot_barrier(uint32_t *sync, uint32_t phase, uint32_t *flag)
+{
+    __syncthreads();                                     // (the workgroup's stores are in its XCD's L2)
+    if (threadIdx.x == 0) {
+        __threadfence();                                 // release at agent scope: that L2's dirty lines go where the other XCDs see them -- once per workgroup,
+                                                         // not once per thread (512 x 256 write-backs and invalidations per barrier were a fifth of the launch)
+        atomicAdd(&sync[0], 1u);
+        const uint32_t want = (phase + 1u) * gridDim.x;
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < OT_SPIN_MAX) { __builtin_amdgcn_s_sleep(10); ++spins; }
+        *flag = spins < OT_SPIN_MAX ? 1u : 0u;
+        if (!*flag) atomicExch(&sync[2], 1u);
+        __threadfence();                                 // acquire: the compute unit's L1 and the L2's copies of other XCDs' lines are dropped
+    }
+    __syncthreads();
+    return *flag != 0u;
+}
+
 __global__ __launch_bounds__(FBLOCK) void occupancy_train_kernel(const RenderArgs a, const OccTrainArgs oc)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ uint32_t bar_flag, last;
+    __shared__ double red[2 * FW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     const float bound = a.bound, eps = a.eps;
-    const int32_t base = oc.counter ? oc.counter[0] : 0;                  // (read before the barrier: the last workgroup to leave updates it)
-    // ---- phase A: counts ----
-    {
-        // (64-ray pieces are dealt to the workgroups first, to the waves of a workgroup second, like the groups below: a 4096-ray batch is one counting wave
-        //  on each of 64 compute units, not eight on each of eight -- the walk is a dependent chain, two of them on one SIMD take turns)
-        for (uint32_t r0 = ((uint32_t)wave * gridDim.x + blockIdx.x) * 64u; r0 < oc.N; r0 += gridDim.x * FW * 64u) {      // a wave's 64 consecutive rays lie in one chunk
-            const uint32_t ray = r0 + (uint32_t)lane;
-            int32_t cnt = 0;
-            if (ray < oc.N) {
-                RayCtx c; rm_setup(c, oc.rays_o + 3 * (size_t)ray, oc.rays_d + 3 * (size_t)ray, oc.grid, oc.mean_density, bound, oc.H);
-                float near, far; rm_near_far(c, near, far);
-                float t = ray_t0(c, near, ray, oc.perturb), skip_tt = RM_NO_SKIP;
-                uint32_t room = RM_MAX_STEPS;
-                while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, [](float, float, float, float, float) {})) {}
-                cnt = (int32_t)(RM_MAX_STEPS - room);
-                oc.counts[ray] = cnt;
-            }
-            int32_t tot = cnt;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
-            if (lane == 0 && tot) atomicAdd(&oc.chunk_tot[r0 >> OT_CHUNK_LOG], tot);
-        }
-    }
-    fill_lds(lds, a);
-    __threadfence();
-    __syncthreads();
-    // ---- grid barrier ----
-    __shared__ uint32_t bar_ok;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(&oc.sync[0], 1u);
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&oc.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && spins < OT_SPIN_MAX) { __builtin_amdgcn_s_sleep(10); ++spins; }
-        bar_ok = spins < OT_SPIN_MAX ? 1u : 0u;
-        if (!bar_ok) atomicExch(&oc.sync[2], 1u);
-        __threadfence();
-    }
-    __syncthreads();
-    float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
-    float *stage = lds + FWD_LDS_FLOATS + wave * OC_STAGE;
-    uint32_t *slotmap = reinterpret_cast<uint32_t *>(stage + 8 * 64), *lanemap = slotmap + 64;
-    const FieldCtx fc = make_ctx(a);
-    const float inv_s = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;
-    const uint32_t gsz = 1u << oc.glog;
-    const uint32_t ngroups = (oc.N + gsz - 1) >> oc.glog;
+    const int32_t base = oc.counter ? oc.counter[0] : 0;                  // (read before the first barrier: the last workgroup to leave updates it)
     const uint32_t nchunks = (oc.N + (1u << OT_CHUNK_LOG) - 1) >> OT_CHUNK_LOG;
-    double e_num = 0.0, e_den = 0.0;                                       // this lane's share of sum(relax * gerr), sum(relax)
-    uint32_t m_comp = oc.M_comp;
-    if (m_comp == 0u && bar_ok) {                                          // the trimmed layout of an un-budgeted call: round_up(counter[0] after the march, 128)
-        int32_t tot = 0;
-        for (uint32_t cix = (uint32_t)lane; cix < nchunks; cix += 64) tot += ot_load(oc.chunk_tot + cix);
+    const uint32_t wid = (uint32_t)wave * gridDim.x + blockIdx.x, nwaves = gridDim.x * FW;   // work is dealt to the workgroups first, to a workgroup's waves second:
+                                                                                             // a 4096-ray batch is one walking wave on each of 64 compute units, not eight on eight
+    bool ok = true;
+    // ---- A: counts and records ----
+    const float *etab = nullptr;                                            // the voxel faces (rm_skip_target_tab) where the weights will be: H + 1 floats
+    if (oc.H < (uint32_t)RM_EDGE_MAX) {
+        RayCtx c0{}; c0.H = oc.H; c0.bound = bound;
+        for (uint32_t m = threadIdx.x; m <= oc.H; m += FBLOCK) lds[m] = rm_edge(c0, m);
+        etab = lds;
+    }
+    __syncthreads();
+    for (uint32_t r0 = wid * 64u; r0 < oc.N; r0 += nwaves * 64u) {         // (a wave's 64 consecutive rays lie in one chunk)
+        const uint32_t ray = r0 + (uint32_t)lane;
+        int32_t cnt = 0;
+        if (ray < oc.N) {
+            RayCtx c; rm_setup(c, oc.rays_o + 3 * (size_t)ray, oc.rays_d + 3 * (size_t)ray, oc.grid, oc.mean_density, bound, oc.H);
+            float near, far; rm_near_far(c, near, far);
+            float t = ray_t0(c, near, ray, oc.perturb), skip_tt = RM_NO_SKIP;
+            uint32_t room = RM_MAX_STEPS, kpos = 0;
+            RayRecorder rr; rr.begin(oc.rec + (size_t)ray * RM_REC_WORDS);
+            while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, [&](float, float, float, float, float, uint32_t k) { rr.add(k); }, etab)) {}
+            rr.end();
+            cnt = (int32_t)(RM_MAX_STEPS - room);
+            oc.counts[ray] = cnt; oc.ovf[ray] = rr.ovf ? 1 : 0; oc.wmask[ray] = rr.wmask;
+        }
+        int32_t tot = cnt;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
-        m_comp = (uint32_t)(base + tot); m_comp += 128u - m_comp % 128u;       // (raymarching.py's _round_up: a full 128 on top of an aligned count)
+        if (lane == 0 && tot) atomicAdd(&oc.chunk_tot[r0 >> OT_CHUNK_LOG], tot);
     }
-    for (uint32_t grp = (uint32_t)wave * gridDim.x + blockIdx.x; grp < ngroups && bar_ok; grp += gridDim.x * FW) {
-        const uint32_t r0 = grp << oc.glog, ray = r0 + (uint32_t)lane;
-        const bool mine = (uint32_t)lane < gsz && ray < oc.N;
-        const uint32_t rr = mine ? ray : oc.N - 1;
-        // offset of the group's first ray in the packed layout: chunks before its chunk + counts before it inside the chunk
+    __syncthreads();                                                        // (the face table is done with: the weights take its place)
+    fill_lds(lds, a);
+    ok = ot_barrier(oc.sync, 0, &bar_flag);
+    // ---- B: offsets, the budget rule, the packed samples ----
+    for (uint32_t r0 = wid * 64u; r0 < oc.N && ok; r0 += nwaves * 64u) {
+        const uint32_t ray = r0 + (uint32_t)lane;
+        const bool mine = ray < oc.N;
         int32_t pre = 0;
         {
             const uint32_t c0 = r0 >> OT_CHUNK_LOG, s0 = c0 << OT_CHUNK_LOG;
-            for (uint32_t cix = (uint32_t)lane; cix < c0; cix += 64) pre += ot_load(oc.chunk_tot + cix);
-            for (uint32_t i = s0 + (uint32_t)lane; i < r0; i += 64) pre += ot_load(oc.counts + i);
+            for (uint32_t cix = (uint32_t)lane; cix < c0; cix += 64) pre += oc.chunk_tot[cix];
+            for (uint32_t i = s0 + (uint32_t)lane; i < r0; i += 64) pre += oc.counts[i];
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) pre += __shfl_xor(pre, d);
         }
-        const int32_t cnt = mine ? ot_load(oc.counts + ray) : 0;
-        int32_t inc = cnt;                                                  // inclusive scan over the group's lanes
+        const int32_t cnt = mine ? oc.counts[ray] : 0;
+        int32_t inc = cnt;                                                  // inclusive scan over the wave's rays
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int32_t v = __shfl_up(inc, d); if (lane >= d) inc += v; }
         const uint32_t offset = (uint32_t)(base + pre + (inc - cnt)), end = offset + (uint32_t)cnt;
         const bool written = mine && cnt > 0 && end < oc.M_write;           // march_write_kernel: `point_index + num_steps >= M -> return`
-        const bool composited = written && end < m_comp;                    // composite_train_fwd_kernel: `offset + num_steps >= M -> zeros`
-        RayCtx c; rm_setup(c, oc.rays_o + 3 * (size_t)rr, oc.rays_d + 3 * (size_t)rr, oc.grid, oc.mean_density, bound, oc.H);
-        float near, far; rm_near_far(c, near, far);
-        float t = ray_t0(c, near, rr, oc.perturb), skip_tt = RM_NO_SKIP;
-        float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f;
-        bool stopped = !composited;                                         // the compositor's `T < 1e-4 -> break` (the sums stop, the evaluation goes on)
-        uint32_t left = written ? (uint32_t)cnt : 0u;                       // samples this ray still has to march
-        bool alive = left > 0u;
-        while (__ballot(alive) != 0ull) {
-            const unsigned long long am = __ballot(alive);
-            const uint32_t na = (uint32_t)__builtin_popcountll(am), K = 64u / na;
-            const uint32_t arank = (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull)), mybase = arank * K;
-            if (alive) lanemap[arank] = (uint32_t)lane;
-            uint32_t mycnt = 0;
-            if (alive) {
-                float *sp = stage + 8 * mybase;
-                uint32_t room = K < left ? K : left;
-                const uint32_t room0 = room;
-                auto emit = [&](float x, float y, float z, float dt, float) { sp[0] = x; sp[1] = y; sp[2] = z; sp[3] = dt; sp += 8; };
-                bool more = true;
-                while (room > 0 && more) more = rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, emit);
-                mycnt = room0 - room; left -= mycnt;
-                if (!more || left == 0u) alive = false;                     // (the count pass walked the same positions: `more` stays true until left == 0)
+        if (mine) oc.offs[ray] = written ? (int32_t)offset : -1;
+        uint32_t wend = written ? end : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)wend, d); wend = v > wend ? v : wend; }
+        if (lane == 0 && wend) atomicMax(&oc.sync[3], wend);
+        if (written) {
+            RayCtx c; rm_setup(c, oc.rays_o + 3 * (size_t)ray, oc.rays_d + 3 * (size_t)ray, oc.grid, oc.mean_density, bound, oc.H);
+            float near, far; rm_near_far(c, near, far);
+            const float t0 = ray_t0(c, near, ray, oc.perturb);
+            float *pi = oc.p_in + 4 * (size_t)offset; int32_t *pr = oc.p_ray + offset;
+            auto put = [&](float x, float y, float z, float dt) { pi[0] = x; pi[1] = y; pi[2] = z; pi[3] = dt; pi += 4; *pr++ = (int32_t)ray; };
+            if (!oc.ovf[ray]) rm_replay(c, t0, oc.rec + (size_t)ray * RM_REC_WORDS, oc.wmask[ray], (uint32_t)cnt, put);
+            else {
+                float t = t0, skip_tt = RM_NO_SKIP; uint32_t room = (uint32_t)cnt, kpos = 0;
+                while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, [&](float x, float y, float z, float dt, float, uint32_t) { put(x, y, z, dt); })) {}
             }
-            wave_sync();
-            const uint32_t orank = (uint32_t)lane / K, owner = orank < na ? lanemap[orank] : 0u;
-            const uint32_t owner_cnt = (uint32_t)__shfl((int)mycnt, (int)owner);
-            const bool valid = orank < na && ((uint32_t)lane - orank * K) < owner_cnt;
-            const unsigned long long vm = __ballot(valid);
-            if (vm == 0ull) break;
-            const uint32_t nv = (uint32_t)__builtin_popcountll(vm);
-            if (valid) slotmap[__builtin_popcountll(vm & ((1ull << lane) - 1ull))] = (uint32_t)lane;
-            wave_sync();
-            for (uint32_t q0 = 0; q0 < nv; q0 += 16) {
-                const uint32_t ci = q0 + (uint32_t)n;
-                const uint32_t slot = slotmap[ci < nv ? ci : nv - 1];
-                const float *sp = stage + 8 * slot;
-                const float sx = sp[0], sy = sp[1], sz = sp[2], delta = sp[3];
-                const float px = clampf(sx, -bound, bound), py = clampf(sy, -bound, bound), pz = clampf(sz, -bound, bound);
-                const int src = (int)lanemap[slot / K];
-                const float dx = __shfl(c.dx, src), dy = __shfl(c.dy, src), dz = __shfl(c.dz, src);
-                float fe0[4][2];
-                encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
-                f32x4 o16; float gr[3];
-                fd_forward(lds, fsl, lane, px, py, pz, eps, bound, fe0, o16, gr);
-                const float gx = gr[0], gy = gr[1], gz = gr[2];
-                const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
-                const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
-                float rgb[3];
-                if (a.Wsh) {
-                    wave_sync();
-                    sample_sh_bias(fsl, a.Wsh, dx, dy, dz, lane);
-                    color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb, fsl + 4 * lane, 256);
-                } else color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb);
-                const float tcos = (dx * nx + dy * ny) + dz * nz;
-                const float a1 = dv_softplus100(lds + OFF_SPQ, -tcos * 0.5f + 0.5f) * a.one_m_car;
-                const float a2 = dv_softplus100(lds + OFF_SPQ, -tcos) * a.car;
-                const float half = -(a1 + a2) * delta * 0.5f;
-                const float pc = dv_sigmoid((o16[0] - half) * inv_s), nc = dv_sigmoid((o16[0] + half) * inv_s);
-                const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
-                if (g == 0 && ci < nv) {
-                    // eikonal term over the packed samples (instant_nsr.py:266-272): relax = |x| < 1.2 on the marcher's point, (|gradient| - 1)^2
-                    if (__builtin_sqrtf((sx * sx + sy * sy) + sz * sz) < 1.2f) { const float d1 = gn - 1.0f; e_num += (double)(d1 * d1); e_den += 1.0; }
-                }
-                wave_sync();
-                if (g == 0 && ci < nv) {
-                    float *so = stage + 8 * slot;
-                    so[0] = alpha; so[1] = rgb[0]; so[2] = rgb[1]; so[3] = rgb[2]; so[4] = nx; so[5] = ny; so[6] = nz;
-                }
-                wave_sync();
-            }
-            for (uint32_t k = 0; k < mycnt && !stopped; ++k) {             // composite_train_fwd_kernel's loop body, image and normal map on the same weights
-                if (T < 1e-4f) { stopped = true; break; }
-                const float *so = stage + 8 * (mybase + k);
-                const float alpha = so[0], w = alpha * T;
-                cr += w * so[1]; cg += w * so[2]; cb += w * so[3];
-                mx += w * so[4]; my += w * so[5]; mz += w * so[6];
-                T *= 1.0f - alpha;
-            }
-            wave_sync();
-        }
-        if (mine) {
-            const float ws = composited ? 1.0f - T : 0.0f;
-            if (oc.bg_mode) {                                               // image + (1 - weights_sum) * bg, torch's three operations in torch's order
-                const float om = 1.0f - ws;
-                const float b0 = oc.bg_mode == 1 ? oc.bg_value : oc.bg[oc.bg_mode == 3 ? 3 * (size_t)ray : 0];
-                const float b1 = oc.bg_mode == 1 ? oc.bg_value : oc.bg[(oc.bg_mode == 3 ? 3 * (size_t)ray : 0) + 1];
-                const float b2 = oc.bg_mode == 1 ? oc.bg_value : oc.bg[(oc.bg_mode == 3 ? 3 * (size_t)ray : 0) + 2];
-                cr = cr + om * b0; cg = cg + om * b1; cb = cb + om * b2;
-            }
-            oc.weights_sum[ray] = ws;
-            oc.image[3 * (size_t)ray] = cr; oc.image[3 * (size_t)ray + 1] = cg; oc.image[3 * (size_t)ray + 2] = cb;
-            oc.normal_map[3 * (size_t)ray] = mx; oc.normal_map[3 * (size_t)ray + 1] = my; oc.normal_map[3 * (size_t)ray + 2] = mz;
         }
     }
-    // ---- eikonal partials: lane -> wave -> workgroup (fixed order); the last workgroup to leave adds the workgroups' and restores the scratch ----
+    ok = ok && ot_barrier(oc.sync, 1, &bar_flag);
+    // ---- C: the field on the packed samples, tiles dealt to all waves ----
+    double e_num = 0.0, e_den = 0.0;                                       // this lane's share of sum(relax * gerr), sum(relax)
+    {
+        float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
+        const FieldCtx fc = make_ctx(a);
+        const float inv_s = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;
+        const uint32_t W = ok ? __hip_atomic_load(&oc.sync[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t ntiles = (W + 15u) / 16u;
+        for (uint32_t tile = wid; tile < ntiles; tile += nwaves) {
+            const uint32_t b = tile * 16 + (uint32_t)n, bb = b < W ? b : W - 1;
+            const float4 in = *reinterpret_cast<const float4 *>(oc.p_in + 4 * (size_t)bb);
+            const int32_t ray = oc.p_ray[bb];
+            const float sx = in.x, sy = in.y, sz = in.z, delta = in.w;
+            const float px = clampf(sx, -bound, bound), py = clampf(sy, -bound, bound), pz = clampf(sz, -bound, bound);
+            const float dx = oc.rays_d[3 * (size_t)ray], dy = oc.rays_d[3 * (size_t)ray + 1], dz = oc.rays_d[3 * (size_t)ray + 2];
+            float fe0[4][2];
+            encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
+            f32x4 o16; float gr[3];
+            fd_forward(lds, fsl, lane, px, py, pz, eps, bound, fe0, o16, gr);
+            const float gx = gr[0], gy = gr[1], gz = gr[2];
+            const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+            const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
+            float rgb[3];
+            if (a.Wsh) {
+                wave_sync();
+                sample_sh_bias(fsl, a.Wsh, dx, dy, dz, lane);
+                color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb, fsl + 4 * lane, 256);
+            } else color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb);
+            const float tcos = (dx * nx + dy * ny) + dz * nz;
+            const float a1 = dv_softplus100(lds + OFF_SPQ, -tcos * 0.5f + 0.5f) * a.one_m_car;
+            const float a2 = dv_softplus100(lds + OFF_SPQ, -tcos) * a.car;
+            const float half = -(a1 + a2) * delta * 0.5f;
+            const float pc = dv_sigmoid((o16[0] - half) * inv_s), nc = dv_sigmoid((o16[0] + half) * inv_s);
+            const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+            if (g == 0 && b < W) {
+                // eikonal term over the packed samples (instant_nsr.py:266-272): relax = |x| < 1.2 on the marcher's point, (|gradient| - 1)^2
+                if (__builtin_sqrtf((sx * sx + sy * sy) + sz * sz) < 1.2f) { const float d1 = gn - 1.0f; e_num += (double)(d1 * d1); e_den += 1.0; }
+                float *po = oc.p_out + 8 * (size_t)b;
+                *reinterpret_cast<float4 *>(po) = make_float4(alpha, rgb[0], rgb[1], rgb[2]);
+                *reinterpret_cast<float4 *>(po + 4) = make_float4(nx, ny, nz, 0.0f);
+            }
+            wave_sync();
+        }
+    }
+    ok = ok && ot_barrier(oc.sync, 2, &bar_flag);
+    // ---- D: the packed compositor per ray (composite_train_fwd_kernel's loop), image and normal map on the same weights; background ----
+    for (uint32_t r0 = wid * 64u; r0 < oc.N && ok; r0 += nwaves * 64u) {
+        const uint32_t ray = r0 + (uint32_t)lane;
+        if (ray >= oc.N) continue;
+        const int32_t off = oc.offs[ray], cnt = oc.counts[ray];
+        const bool composited = off >= 0 && (uint32_t)off + (uint32_t)cnt < oc.M_comp;      // `offset + num_steps >= M -> zeros`
+        float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f;
+        if (composited) {
+            const float *po = oc.p_out + 8 * (size_t)off;
+            for (int32_t k = 0; k < cnt; ++k, po += 8) {
+                if (T < 1e-4f) break;
+                const float4 u = *reinterpret_cast<const float4 *>(po), v = *reinterpret_cast<const float4 *>(po + 4);
+                const float alpha = u.x, w = alpha * T;
+                cr += w * u.y; cg += w * u.z; cb += w * u.w;
+                mx += w * v.x; my += w * v.y; mz += w * v.z;
+                T *= 1.0f - alpha;
+            }
+        }
+        const float ws = composited ? 1.0f - T : 0.0f;
+        if (oc.bg_mode) {                                                   // image + (1 - weights_sum) * bg, torch's three operations in torch's order
+            const float om = 1.0f - ws;
+            const size_t bo = oc.bg_mode == 3 ? 3 * (size_t)ray : 0;
+            const float b0 = oc.bg_mode == 1 ? oc.bg_value : oc.bg[bo], b1 = oc.bg_mode == 1 ? oc.bg_value : oc.bg[bo + 1], b2 = oc.bg_mode == 1 ? oc.bg_value : oc.bg[bo + 2];
+            cr = cr + om * b0; cg = cg + om * b1; cb = cb + om * b2;
+        }
+        oc.weights_sum[ray] = ws;
+        oc.image[3 * (size_t)ray] = cr; oc.image[3 * (size_t)ray + 1] = cg; oc.image[3 * (size_t)ray + 2] = cb;
+        oc.normal_map[3 * (size_t)ray] = mx; oc.normal_map[3 * (size_t)ray + 1] = my; oc.normal_map[3 * (size_t)ray + 2] = mz;
+    }
+    // ---- eikonal partials: lane -> wave -> workgroup (fixed order); the last workgroup to leave adds the workgroups' and re-arms the scratch ----
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { e_num += __shfl_xor(e_num, d); e_den += __shfl_xor(e_den, d); }
-    __shared__ double red[2 * FW];
-    __shared__ uint32_t last;
     if (lane == 0) { red[2 * wave] = e_num; red[2 * wave + 1] = e_den; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -949,7 +958,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_train_kernel(const RenderArg
             const bool failed = __hip_atomic_load(&oc.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             oc.gradient_error[0] = failed ? __builtin_nanf("") : (float)sn / ((float)sd + 1e-5f);
             if (oc.counter) { oc.counter[0] = base + tot; oc.counter[1] += (int32_t)oc.N; }
-            oc.sync[0] = 0u; oc.sync[1] = 0u; oc.sync[2] = 0u;
+            oc.sync[0] = 0u; oc.sync[1] = 0u; oc.sync[2] = 0u; oc.sync[3] = 0u;
         }
     }
 }
@@ -1602,32 +1611,43 @@ AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, 
     static const int env_glog = []() { const char *e = getenv("AC_OCC_GLOG"); return (e && e[0] >= '2' && e[0] <= '6' && !e[1]) ? e[0] - '0' : -1; }();
     const uint32_t glog = env_glog >= 0 ? (uint32_t)env_glog : (N >= 32768u ? 4u : 3u);
     const uint32_t gsz = 1u << glog;
-    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, glog, max_steps };
-    const size_t lds_bytes = OCC_LDS_FLOATS * sizeof(float);
+    // the voxel faces as a table behind the stages when H + 1 floats still fit the compute unit's LDS (H = 128: 516 of the 1.9 KB left)
+    const bool tab = (OCC_LDS_FLOATS + (size_t)H + 1) * sizeof(float) + 64 <= 160 * 1024;
+    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, glog, max_steps, tab ? 1u : 0u };
+    const size_t lds_bytes = (OCC_LDS_FLOATS + (tab ? (size_t)H + 1 : 0)) * sizeof(float);
     static uint64_t seen = 0;
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_render_kernel), lds_bytes);
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_render_kernel), 160 * 1024 - 64);      // (a ceiling, set once: lds_bytes depends on H)
     uint32_t blocks = (N + gsz - 1) / gsz;                         // one group per workgroup first (see the kernel's loop), one persistent workgroup per CU at most
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(occupancy_render_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
     return ac::check_launch("render_rays_occupancy");
 }
 
-// scratch of ac_render_rays_occupancy_train: [4] sync words | [chunks] totals | [N] counts | [CUs][2] doubles.  ZERO-FILLED by the caller once (the sync words and
-// the totals; every call leaves them zero again), reusable for calls with the SAME N on the same stream (the layout depends on N).
-static size_t occ_train_layout(uint32_t N, size_t *o_tot, size_t *o_cnt, size_t *o_part)
+// scratch of ac_render_rays_occupancy_train: [4] sync words | [chunks] totals | counts, offsets, overflow flags, word masks [N] each | records [N][32] | [CUs][2] doubles |
+// packed samples: ray [M], x y z dt [M][4], alpha r g b nx ny nz - [M][8].  ZERO-FILLED by the caller once (the sync words and the totals; every call leaves
+// them zero again), reusable for calls with the SAME N and capacity on the same stream (the layout depends on both).
+struct OccTrainLayout { size_t tot, cnt, offs, ovf, wmask, rec, part, p_ray, p_in, p_out, total; };
+static OccTrainLayout occ_train_layout(uint32_t N, uint32_t M)
 {
+    OccTrainLayout l{};
     const size_t chunks = ((size_t)N + (1u << OT_CHUNK_LOG) - 1) >> OT_CHUNK_LOG;
     size_t o = 4 * sizeof(uint32_t);
-    if (o_tot) *o_tot = o;
-    o += chunks * sizeof(int32_t);
-    if (o_cnt) *o_cnt = o;
-    o += (size_t)N * sizeof(int32_t);
-    o = (o + 7) & ~(size_t)7;
-    if (o_part) *o_part = o;
-    o += (size_t)ac::cu_count() * 2 * sizeof(double);
-    return o;
+    l.tot = o; o += chunks * sizeof(int32_t);
+    l.cnt = o; o += (size_t)N * sizeof(int32_t);
+    l.offs = o; o += (size_t)N * sizeof(int32_t);
+    l.ovf = o; o += (size_t)N * sizeof(int32_t);
+    l.wmask = o; o += (size_t)N * sizeof(uint32_t);
+    l.rec = o; o += (size_t)N * RM_REC_WORDS * sizeof(uint32_t);
+    o = (o + 15) & ~(size_t)15;
+    l.part = o; o += (size_t)ac::cu_count() * 2 * sizeof(double);
+    l.p_ray = o; o += (size_t)M * sizeof(int32_t);
+    o = (o + 15) & ~(size_t)15;
+    l.p_in = o; o += (size_t)M * 4 * sizeof(float);
+    l.p_out = o; o += (size_t)M * 8 * sizeof(float);
+    l.total = o;
+    return l;
 }
-AC_API size_t ac_render_rays_occupancy_train_scratch(uint32_t N) { return occ_train_layout(N, nullptr, nullptr, nullptr); }
+AC_API size_t ac_render_rays_occupancy_train_scratch(uint32_t N, uint32_t capacity) { return occ_train_layout(N, capacity).total; }
 
 AC_API int ac_render_rays_occupancy_train(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
                                           float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
@@ -1640,28 +1660,30 @@ AC_API int ac_render_rays_occupancy_train(const ac_field *field, const float *ra
     if (!rays_o || !rays_d || !grid || !weights_sum || !image || !normal_map || !scratch || H < 2 || !(eps > 0.0f) || bg_mode > 3u || (bg_mode >= 2u && !bg)) {
         ac::set_error("render_rays_occupancy_train: NULL buffer, H < 2, eps <= 0 or bad background mode"); return AC_ERR_BAD_ARG;
     }
-    size_t o_tot, o_cnt, o_part;
-    const size_t need = occ_train_layout(N, &o_tot, &o_cnt, &o_part);
-    if (scratch_bytes < need) { ac::set_error("render_rays_occupancy_train: scratch of %zu bytes needed, %zu given", need, scratch_bytes); return AC_ERR_BAD_ARG; }
+    if (capacity == 0u || composite_capacity == 0u) {
+        ac::set_error("render_rays_occupancy_train: capacity / composite_capacity must be > 0 (the packed layout lives in the scratch: a budgeted call)"); return AC_ERR_BAD_ARG;
+    }
+    const OccTrainLayout l = occ_train_layout(N, capacity);
+    if (scratch_bytes < l.total) { ac::set_error("render_rays_occupancy_train: scratch of %zu bytes needed, %zu given", l.total, scratch_bytes); return AC_ERR_BAD_ARG; }
     RenderArgs a{};
     if (int rc = prep_args(a, field, bound, eps)) return rc;
     a.inv_s = inv_s; a.inv_s_dev = inv_s_dev; a.car = cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)cos_anneal_ratio);
-    // rays per wave and trip (2^glog): a training ray holds a handful of samples (the walk stops at the surface's shell), so small groups -- more waves in flight --
-    // and the 64 sample slots of a trip still fill; AC_OCC_TRAIN_GLOG = 1 .. 6 overrides
-    static const int env_glog = []() { const char *e = getenv("AC_OCC_TRAIN_GLOG"); return (e && e[0] >= '1' && e[0] <= '6' && !e[1]) ? e[0] - '0' : -1; }();
-    const uint32_t glog = env_glog >= 0 ? (uint32_t)env_glog : (N >= 32768u ? 4u : (N > 8192u ? 3u : 2u));
     char *sc = static_cast<char *>(scratch);
     OccTrainArgs oc{ rays_o, rays_d, grid, N, H, capacity, composite_capacity, perturb, mean_density, counter, weights_sum, image, normal_map, gradient_error,
-                     bg, bg_mode, bg_value, reinterpret_cast<uint32_t *>(sc), reinterpret_cast<int32_t *>(sc + o_tot), reinterpret_cast<int32_t *>(sc + o_cnt),
-                     reinterpret_cast<double *>(sc + o_part), glog };
-    const size_t lds_bytes = OCC_LDS_FLOATS * sizeof(float);
+                     bg, bg_mode, bg_value, reinterpret_cast<uint32_t *>(sc), reinterpret_cast<int32_t *>(sc + l.tot), reinterpret_cast<int32_t *>(sc + l.cnt),
+                     reinterpret_cast<int32_t *>(sc + l.offs), reinterpret_cast<int32_t *>(sc + l.ovf), reinterpret_cast<uint32_t *>(sc + l.wmask),
+                     reinterpret_cast<uint32_t *>(sc + l.rec),
+                     reinterpret_cast<double *>(sc + l.part), reinterpret_cast<int32_t *>(sc + l.p_ray), reinterpret_cast<float *>(sc + l.p_in),
+                     reinterpret_cast<float *>(sc + l.p_out) };
+    const size_t lds_bytes = FWD_LDS_FLOATS * sizeof(float);
     static uint64_t seen = 0;
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_train_kernel), lds_bytes);
-    // one persistent workgroup per compute unit AT MOST: the kernel's grid barrier needs every workgroup resident (FBLOCK threads at two waves per SIMD and
-    // the LDS image make it one per CU)
-    const uint32_t cus = ac::cu_count(), gsz = 1u << glog;
-    uint32_t blocks = (N + gsz - 1) / gsz;
+    // one persistent workgroup per compute unit AT MOST: the kernel's grid barriers need every workgroup resident (FBLOCK threads at two waves per SIMD and
+    // the LDS image make it one per CU); fewer when the batch has less than one 64-ray wave of walking per workgroup
+    const uint32_t cus = ac::cu_count();
+    uint32_t blocks = (N + 63u) / 64u;
     if (blocks > cus) blocks = cus;
+    if (blocks < cus && capacity / 16u > blocks * FW) blocks = cus;         // (the tiles of phase C want every wave)
     hipLaunchKernelGGL(occupancy_train_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
     return ac::check_launch("render_rays_occupancy_train");
 }

@@ -555,9 +555,10 @@ class NeRFRenderer(nn.Module):
             self.local_step += 1
             needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
             budgeted = self.mean_count > 0
-            if not needs_grad and self.occupancy_train_one_launch:
-                # no graph wanted: count, march, field, both composites, the eikonal term and the background in one launch -- the same pixels as the chain below
-                cap = raymarching.raymarching._round_up(int(self.mean_count), 128) if budgeted else 0     # (march_rays_train's capacity: + 128 - n % 128)
+            if not needs_grad and budgeted and self.occupancy_train_one_launch:
+                # no graph wanted (and a budget, so that the packed layout has a size before anything is counted): walk, packed samples, field, both composites,
+                # the eikonal term and the background in one launch -- the same pixels as the chain below
+                cap = raymarching.raymarching._round_up(int(self.mean_count), 128)                        # (march_rays_train's capacity: + 128 - n % 128)
                 o = nsr_ops.render_rays_occupancy_train(self._field(), ro, rd, self.density_grid, self.mean_density, bound, fd_eps, inv_s_t, cos_anneal_ratio,
                                                         perturb=bool(perturb_overwrite), capacity=cap, composite_capacity=cap, counter=counter, bg=bg)
                 gradient_error = o["gradient_error"][0]

@@ -795,10 +795,10 @@ _OT_SCRATCH = {}
 
 def render_rays_occupancy_train(field, rays_o, rays_d, density_grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, perturb=False, capacity=0,
                                 composite_capacity=0, counter=None, bg=None):
-    """ac_render_rays_occupancy_train: the training form of run_cuda without autograd in one launch (count, grid barrier, march + field + the packed
-    compositor per ray).  capacity / composite_capacity: the M of march_rays_train / composite_rays_train (0 for capacity: N * 1024, an un-budgeted call;
-    0 for composite_capacity: round_up(samples, 128), its trimmed layout); counter: the [2] int32 step counter (+= samples, += N); bg: None (raw sums), a
-    number, a [3] / [1,3] or an [N,3] tensor -- image + (1 - weights_sum) * bg.
+    """ac_render_rays_occupancy_train: the training form of run_cuda without autograd in one launch (walk + record, offsets + packed samples, field on
+    tiles dealt to all waves, the packed compositor per ray; grid barriers between the phases).  capacity / composite_capacity: the M of march_rays_train /
+    composite_rays_train, both > 0 (a budgeted call: the packed layout lives in the launch's scratch); counter: the [2] int32 step counter (+= samples,
+    += N); bg: None (raw sums), a number, a [3] / [1,3] or an [N,3] tensor -- image + (1 - weights_sum) * bg.
     -> dict(weights_sum [N], image [N,3], normal_map [N,3], gradient_error [1])"""
     rays_o = _chk(rays_o.reshape(-1, 3), "rays_o"); rays_d = _chk(rays_d.reshape(-1, 3), "rays_d"); grid = _chk(density_grid, "density_grid")
     N, dev = rays_o.shape[0], rays_o.device
@@ -806,6 +806,9 @@ def render_rays_occupancy_train(field, rays_o, rays_d, density_grid, mean_densit
         raise RuntimeError("render_rays_occupancy_train: density_grid must be [H, H, H]")
     if counter is not None and (counter.dtype != torch.int32 or counter.numel() < 2 or not counter.is_cuda or not counter.is_contiguous()):
         raise RuntimeError("render_rays_occupancy_train: counter must be a contiguous [2] int32 device tensor")
+    cap, ccap = int(capacity), int(composite_capacity) or int(capacity)
+    if cap <= 0:
+        raise RuntimeError("render_rays_occupancy_train: capacity must be > 0 (the un-budgeted form of march_rays_train sizes its layout after counting: use the operators)")
     bg_mode, bg_value, bg_t = 0, 0.0, None
     if bg is not None:
         if isinstance(bg, torch.Tensor):
@@ -823,18 +826,17 @@ def render_rays_occupancy_train(field, rays_o, rays_d, density_grid, mean_densit
             bg_mode, bg_value = 1, float(bg)
     f = lambda *sh: torch.empty(sh, dtype=_F32, device=dev)
     out = dict(weights_sum=f(N), image=f(N, 3), normal_map=f(N, 3), gradient_error=f(1))
-    need = int(L.lib().ac_render_rays_occupancy_train_scratch(N))
-    key = (str(dev), int(L.current_stream(dev) or 0), N)          # (the layout depends on N: a buffer is re-armed for calls of ITS ray count)
+    need = int(L.lib().ac_render_rays_occupancy_train_scratch(N, cap))
+    key = (str(dev), int(L.current_stream(dev) or 0), N, cap)      # (the layout depends on N and the capacity: a buffer is re-armed for calls of ITS shape)
     sc = _OT_SCRATCH.get(key)
     if sc is None:
-        if len(_OT_SCRATCH) > 16:
+        if len(_OT_SCRATCH) > 8:
             _OT_SCRATCH.clear()
         sc = _OT_SCRATCH[key] = torch.zeros(need, dtype=torch.uint8, device=dev)      # zeroed once: every launch re-arms it
     inv_f, inv_t = _inv_s_arg(inv_s)
-    cap = int(capacity) if capacity else min(N * 1024, 0xffffffff)
     L.check(L.lib().ac_render_rays_occupancy_train(C.byref(field.c), rays_o.data_ptr(), rays_d.data_ptr(), N, grid.data_ptr(), int(grid.shape[0]),
                                                    float(mean_density), float(bound), float(eps), inv_f, L.ptr(inv_t), float(cos_anneal_ratio),
-                                                   1 if perturb else 0, cap, int(composite_capacity), L.ptr(counter), L.ptr(bg_t), bg_mode, float(bg_value),
+                                                   1 if perturb else 0, cap, ccap, L.ptr(counter), L.ptr(bg_t), bg_mode, float(bg_value),
                                                    out["weights_sum"].data_ptr(), out["image"].data_ptr(), out["normal_map"].data_ptr(),
                                                    out["gradient_error"].data_ptr(), sc.data_ptr(), sc.numel(), L.current_stream(dev)),
             "render_rays_occupancy_train")

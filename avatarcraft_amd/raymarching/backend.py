@@ -14,7 +14,7 @@ class _Backend:
     @staticmethod
     def march_rays_train(rays_o, rays_d, grid, mean_density, iter_density, bound, N, H, M, xyzs, dirs, deltas, rays, counter, perturb):
         L.require_cuda(rays_o, rays_d, grid)
-        scratch = _scratch(2 * N + 2, rays_o.device)
+        scratch = _scratch(int(L.lib().ac_march_rays_train_scratch(N)), rays_o.device)
         L.check(L.lib().ac_march_rays_train(rays_o.data_ptr(), rays_d.data_ptr(), grid.data_ptr(), float(mean_density),
                                             int(iter_density), float(bound), N, H, M, xyzs.data_ptr(), dirs.data_ptr(),
                                             deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(), int(perturb),

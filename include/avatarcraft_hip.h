@@ -111,7 +111,11 @@ int ac_sh_encode_backward_typed(int dtype, const void *grad, const void *inputs,
  * Same arguments as the reference wrappers.  Slot reservation is deterministic: packed samples
  * are laid out in ray order (an exclusive prefix sum replaces the reference's atomicAdd), so
  * rays[N,3] = (ray id, offset, n_steps) is reproducible.  counter[2] (device) is incremented by
- * (total steps, N) as in the reference.  scratch: device int32 buffer of >= 2N+2 elements. */
+ * (total steps, N) as in the reference.  scratch: device int32 buffer of ac_march_rays_train_scratch(N)
+ * elements (ABI 7: 36 N + 2 -- counts, offsets and, new, the positions of every ray's samples as a bit mask over its
+ * step recurrence, which the counting pass records and the writing pass replays instead of walking the grid a second
+ * time; before: 2N+2). */
+size_t ac_march_rays_train_scratch(uint32_t N);
 int ac_march_rays_train(const float *rays_o, const float *rays_d, const float *grid, float mean_density,
                         int iter_density, float bound, uint32_t N, uint32_t H, uint32_t M, float *xyzs,
                         float *dirs, float *deltas, int32_t *rays, int32_t *counter, uint32_t perturb,
@@ -379,22 +383,22 @@ int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const f
 
 /* The training form of run_cuda WITHOUT autograd as ONE launch (ABI 7) -- stylize.py's render_val of a cuda_ray network, which never leaves train() mode
  * (stylize.py:46-215 never calls eval()): what ac_march_rays_train (count, scan, write) -> ac_field_samples -> ac_composite_rays_train_forward twice (colour,
- * normal) -> the eikonal term and the background in torch compute, with the samples never leaving the compute unit.  Per ray: the walk of
- * kernel_march_rays_train (raymarching.cu:56-222; perturb: t0 = near + dt_min * pcg32(ray).next_float()), the field on its samples (the arithmetic of
- * ac_field_samples with the marcher's step as the section length), kernel_composite_rays_train_forward's loop (:232-301: T < 1e-4 ends the sums) for image
- * and normal map on the same weights.  The packed layout is never written, but its bookkeeping is kept, because the reference's budget rule depends on it:
- *   capacity            M of ac_march_rays_train: a ray whose samples would end at or beyond it (offset + count >= M, offsets in ray order from counter[0])
- *                       is not marched (:133);
- *   composite_capacity  M of ac_composite_rays_train_forward: such a ray gets weights_sum = image = 0 (:249); 0 = n + 128 - n % 128 for n = counter[0] after the march,
- *                       the trimmed layout of an un-budgeted march_rays_train call (raymarching.py rounds like the reference: a full 128 on an aligned n);
+ * normal) -> the eikonal term and the background in torch compute, as four phases of one persistent launch separated by grid barriers: the walk of
+ * kernel_march_rays_train per ray (raymarching.cu:56-222; perturb: t0 = near + dt_min * pcg32(ray).next_float()), counting and recording the samples'
+ * positions; offsets in ray order, the reference's budget rule and the packed samples (replayed from the records, no second walk); the field on tiles of
+ * 16 packed samples dealt to all waves (the arithmetic of ac_field_samples with the marcher's step as the section length); kernel_composite_rays_train_forward's
+ * loop per ray (:232-301: T < 1e-4 ends the sums) for image and normal map on the same weights.  A BUDGETED call only -- the packed layout lives in the scratch:
+ *   capacity            M of ac_march_rays_train (> 0): a ray whose samples would end at or beyond it (offset + count >= M, offsets in ray order from
+ *                       counter[0]) is not marched (:133);
+ *   composite_capacity  M of ac_composite_rays_train_forward (> 0; the same number in run_cuda): such a ray gets weights_sum = image = 0 (:249);
  *   counter             optional [2] int32 (device): [0] += samples of all rays, [1] += N, like the stand-alone marcher.
  * bg_mode: image += (1 - weights_sum) * bg (run_cuda's last line; torch's three operations in torch's order): 0 none, 1 the scalar bg_value, 2 bg[3],
  * 3 bg[N][3].  gradient_error [1] (device): sum(relax * (|gradient| - 1)^2) / (sum(relax) + 1e-5) over the marched samples, relax = |x| < 1.2
  * (models/instant_nsr.py:266-272), summed in double in a fixed order (run to run identical; torch's fp32 tree differs from it by ~1e-6 relative);
- * NaN if the launch's grid barrier timed out (it cannot with one workgroup per compute unit; the bound exists so that a mis-sized launch fails instead of hanging).
- * weights_sum / image / normal_map are the bits of the chain of operators.  scratch: ac_render_rays_occupancy_train_scratch(N) bytes, ZERO-FILLED by the
- * caller before its first use (every call leaves it re-armed for calls with the SAME N: the layout depends on N), one buffer per stream and ray count. */
-size_t ac_render_rays_occupancy_train_scratch(uint32_t N);
+ * NaN if a grid barrier timed out (it cannot with one workgroup per compute unit; the bound exists so that a mis-sized launch fails instead of hanging).
+ * weights_sum / image / normal_map are the bits of the chain of operators.  scratch: ac_render_rays_occupancy_train_scratch(N, capacity) bytes, ZERO-FILLED
+ * by the caller before its first use (every call leaves it re-armed for calls with the SAME N and capacity: the layout depends on both), one buffer per stream. */
+size_t ac_render_rays_occupancy_train_scratch(uint32_t N, uint32_t capacity);
 int ac_render_rays_occupancy_train(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
                                    float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
                                    uint32_t perturb, uint32_t capacity, uint32_t composite_capacity, int32_t *counter, const float *bg,

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05_occ4; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05_occ5; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q --maxfail=15 -p no:cacheprovider -k "run_cuda or raymarch or occupancy or march or density or pins" > $O/pytest.log 2>&1; echo "pytest rc $?"
 grep -n "passed\|failed" $O/pytest.log | tail -3; grep -n "^E  " $O/pytest.log | cut -c1-300 | head -20
 python tools/occ_train_probe.py 2>/dev/null | tail -1
