@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void march_count_kernel(const float *__restric
     float t = ray_t0(c, near, n, perturb), skip_tt = RM_NO_SKIP;
     uint32_t room = RM_MAX_STEPS, kpos = 0;                       // the reference's walk (`while (t < far && num_steps < MAX)`), look-ups RM_BATCH at a time: rm_march_batch
     RayRecorder rr; rr.begin(rec + (size_t)n * RM_REC_WORDS);
-    while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, [&](float, float, float, float, float, uint32_t k) { rr.add(k); }, etab)) {}
+    while (room > 0 && rm_march_batch<RM_BATCH, true>(c, t, skip_tt, far, room, kpos, [&](float, float, float, float, float, uint32_t k) { rr.add(k); }, etab)) {}
     rr.end();
     counts[n] = (int32_t)(RM_MAX_STEPS - room);
     ovf[n] = rr.ovf ? 1 : 0; wmask[n] = rr.wmask;

@@ -102,16 +102,21 @@ __device__ __forceinline__ float rm_skip(const RayCtx &c, float t, float x, floa
 // Returns false when the walk has ended (a visited position >= far, or NaN).
 //   kpos     index of position t in the ray's recurrence (0 = the walk's first position); emit's last argument is the sample's index
 //   edge     optional table of the voxel faces (rm_edge: H + 1 floats, LDS); nullptr: the skip target's divisions are computed
-template <int B, class Emit>
+//   KEEP     the look-up's point and voxel stay in registers (6 B of them) for the decisions instead of being formed again: a quarter fewer instructions where
+//            registers are free (the counting kernels); the fused inference kernel, at its register limit, recomputes
+template <int B, bool KEEP = false, class Emit>
 __device__ __forceinline__ bool rm_march_batch(const RayCtx &c, float &t, float &skip_tt, float far, uint32_t &room, uint32_t &kpos, Emit &&emit,
                                                const float *edge = nullptr)
 {
     float ts[B + 1], den[B];
+    float kx[KEEP ? B : 1], ky[KEEP ? B : 1], kz[KEEP ? B : 1];
+    int kn[KEEP ? 3 * B : 1];
     ts[0] = t;
 #pragma unroll
     for (int j = 0; j < B; ++j) {
         float x, y, z; int nx, ny, nz;
         den[j] = rm_density(c, ts[j], x, y, z, nx, ny, nz);       // (positions are clamped into the volume: any t addresses a voxel)
+        if (KEEP) { kx[j] = x; ky[j] = y; kz[j] = z; kn[3 * j] = nx; kn[3 * j + 1] = ny; kn[3 * j + 2] = nz; }
         ts[j + 1] = ts[j] + rm_clamp(ts[j] * c.dt_gamma, c.dt_min, c.dt_max);
     }
     bool open = true, more = true;
@@ -123,13 +128,13 @@ __device__ __forceinline__ bool rm_march_batch(const RayCtx &c, float &t, float 
             else if (room == 0) { open = false; t = tj; kpos += (uint32_t)j; }
             else {
                 float x, y, z;
-                rm_pos(c, tj, x, y, z);
+                if (KEEP) { x = kx[j]; y = ky[j]; z = kz[j]; } else rm_pos(c, tj, x, y, z);
                 if (den[j] > c.thresh) {
                     emit(x, y, z, rm_clamp(tj * c.dt_gamma, c.dt_min, c.dt_max), ts[j + 1], kpos + (uint32_t)j);
                     --room;
                 } else {
                     int nx, ny, nz;
-                    rm_voxel(c, x, y, z, nx, ny, nz);
+                    if (KEEP) { nx = kn[3 * j]; ny = kn[3 * j + 1]; nz = kn[3 * j + 2]; } else rm_voxel(c, x, y, z, nx, ny, nz);
                     skip_tt = edge ? rm_skip_target_tab(c, edge, tj, x, y, z, nx, ny, nz) : rm_skip_target(c, tj, x, y, z, nx, ny, nz);
                 }
             }

@@ -803,7 +803,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_train_kernel(const RenderArg
             float t = ray_t0(c, near, ray, oc.perturb), skip_tt = RM_NO_SKIP;
             uint32_t room = RM_MAX_STEPS, kpos = 0;
             RayRecorder rr; rr.begin(oc.rec + (size_t)ray * RM_REC_WORDS);
-            while (room > 0 && rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, [&](float, float, float, float, float, uint32_t k) { rr.add(k); }, etab)) {}
+            while (room > 0 && rm_march_batch<RM_BATCH, true>(c, t, skip_tt, far, room, kpos, [&](float, float, float, float, float, uint32_t k) { rr.add(k); }, etab)) {}
             rr.end();
             cnt = (int32_t)(RM_MAX_STEPS - room);
             oc.counts[ray] = cnt; oc.ovf[ray] = rr.ovf ? 1 : 0; oc.wmask[ray] = rr.wmask;
