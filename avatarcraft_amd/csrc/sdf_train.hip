@@ -738,7 +738,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
 // weights_sum / image / normal_map: the bits of the chain of operators (tests/test_gpu_run_cuda.py).  gradient_error: the same terms summed in double
 // in a fixed order (per lane, per wave, per workgroup; the last workgroup to leave adds the partials) instead of torch's fp32 tree: equal to ~1e-6 relative.
 constexpr uint32_t OT_CHUNK_LOG = 8;                     // 2^8 rays per chunk total (a multiple of the wave's 64)
-constexpr uint32_t OT_SPIN_MAX = 1u << 22;               // x s_sleep(10): about a second
+constexpr unsigned long long OT_SPIN_TICKS = 200000000ull;   // of the 100 MHz wall clock: two seconds
 struct OccTrainArgs {
     const float *rays_o, *rays_d, *grid;
     uint32_t N, H, M_write, M_comp, perturb;             // M_write: capacity of the packed layout (march_write's budget, > 0); M_comp: the compositor's
@@ -764,9 +764,10 @@ __device__ __forceinline__ bool ot_barrier(uint32_t *sync, uint32_t phase, uint3
                                                          // not once per thread (512 x 256 write-backs and invalidations per barrier were a fifth of the launch)
         atomicAdd(&sync[0], 1u);
         const uint32_t want = (phase + 1u) * gridDim.x;
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < OT_SPIN_MAX) { __builtin_amdgcn_s_sleep(10); ++spins; }
-        *flag = spins < OT_SPIN_MAX ? 1u : 0u;
+        const unsigned long long t0 = wall_clock64();
+        bool all = false;
+        while (!(all = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) && wall_clock64() - t0 < OT_SPIN_TICKS) __builtin_amdgcn_s_sleep(10);
+        *flag = all ? 1u : 0u;
         if (!*flag) atomicExch(&sync[2], 1u);
         __threadfence();                                 // acquire: the compute unit's L1 and the L2's copies of other XCDs' lines are dropped
     }

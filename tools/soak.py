@@ -150,5 +150,22 @@ def grid_update():
 
 
 total_bad += soak("density-grid update, one launch (129^3)", grid_update, int(200 * scale))
+# the occupancy-grid training form in one launch (four phases, three grid barriers) on the SDS view, on a grid this field's own update produced
+og = torch.zeros((129, 129, 129), device=dev)
+for _ in range(3):
+    og_mean = nsr_ops.density_grid_update(occ_field, ax129, og, 1.6, 512.0, 0.95)
+og_mean = float(og_mean.item())
+ctr = torch.zeros(2, dtype=torch.int32, device=dev)
+sro, srd = views["sds view"]
+
+
+def occ_train():
+    ctr.zero_()
+    o = nsr_ops.render_rays_occupancy_train(occ_field, sro, srd, og, og_mean, 1.6, 0.005, 512.0, 1.0, perturb=True, capacity=1 << 17, counter=ctr, bg=1.0)
+    o["counter"] = ctr.clone()
+    return o
+
+
+total_bad += soak("occupancy training form, one launch (%d samples)" % int(occ_train()["counter"][0].item()), occ_train, int(2000 * scale))
 print("hand-off timeouts on this stream:", nsr_ops.handoff_timeouts(dev))
 print("total: %d differing repeats; %.0f s" % (total_bad, time.time() - t0))
