@@ -189,6 +189,20 @@ def test_sds_step_posed_render_and_occupancy_render_take_the_model():
         occ.occupancy_rounds = False
     assert float(one["weight_sum"].max()) > 0.9 and float((one["rgb"] - loop["rgb"]).abs().max()) <= 2e-5
     occ.train()
+    # the training form without autograd (round 5): one launch == the chain of operators, with view directions too
+    kwt = dict(num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, perturb=True)
+    with torch.no_grad():
+        occ.render(ro_t[None], rd_t[None], **kwt)
+        occ.mean_count = int(occ.step_counter[(occ.local_step - 1) % 64, 0].item()) + 64
+        assert occ.mean_count > 64
+        t_one = occ.render(ro_t[None], rd_t[None], **kwt)
+        occ.occupancy_train_one_launch = False
+        t_ops = occ.render(ro_t[None], rd_t[None], **kwt)
+        occ.occupancy_train_one_launch = True
+    for k in ("rgb", "weight_sum", "normal"):
+        assert torch.equal(t_one[k], t_ops[k]), k
+    assert float(t_one["weight_sum"].max()) > 0.9
+    occ.mean_count = 0
     o = occ.render(ro_t[None], rd_t[None], num_steps=64, bound=1.6, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, perturb=True)
     o["rgb"].sum().backward()
     assert float(occ.color_net[0].weight_v.grad[:, 3:19].abs().max()) > 0
