@@ -122,6 +122,8 @@ _SIGS = {
     "ac_debug_warped_phases": ([C.c_int], None),
     "ac_debug_warped_phase_ms": ([vp], C.c_int),
     "ac_render_rays_occupancy": ([C.POINTER(ac_field), vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, f32, vp, vp, vp, vp, vp, u32, vp], C.c_int),
+    "ac_render_rays_occupancy_phased_scratch": ([u32], C.c_size_t),
+    "ac_render_rays_occupancy_phased": ([C.POINTER(ac_field), vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, f32, vp, vp, vp, vp, vp, u32, vp, C.c_size_t, vp], C.c_int),
     "ac_render_rays_occupancy_train_scratch": ([u32, u32], C.c_size_t),
     "ac_render_rays_occupancy_train": ([C.POINTER(ac_field), vp, vp, u32, vp, u32, f32, f32, f32, f32, vp, f32, u32, u32, u32, vp, vp, u32, f32, vp, vp, vp, vp,
                                         vp, C.c_size_t, vp], C.c_int),

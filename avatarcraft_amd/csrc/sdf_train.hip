@@ -964,6 +964,201 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_train_kernel(const RenderArg
     }
 }
 
+// ---- the occupancy-grid INFERENCE render in phases (round 5): rounds of march | field | composite inside ONE launch, grid barriers between them --------------
+// occupancy_render_kernel above gives every wave 8 - 16 rays and lets it march (a quarter of its lanes), evaluate (its own tiles, one after the other: ~45 us of
+// latency each) and composite them.  What the training kernel taught -- walk with every lane, deal the tiles to ALL waves -- applies here too, except that a ray's
+// march depends on its composite (it stops at T < 1e-2): so the reference's loop of rounds comes back, inside the launch, without its host read-backs:
+//   M  lane = alive ray (64 per wave, waves dealt over the device): up to n_step samples into the ray's slots, the slot ids appended to the round's tile list
+//      (one integer atomic per wave: the order of the list does not reach any result);
+//   F  the field on tiles of 16 listed samples, dealt to all waves (field_samples_kernel's body);
+//   C  lane = alive ray: composite_rays_kernel's loop over the ray's samples of this round; rays that go on are appended to the next round's list.
+// A ray's samples, their order and every operation on them are those of occupancy_render_kernel (and of the three stand-alone operators run as one round):
+// the same bits for any n_step (tests/test_gpu_run_cuda.py); n_step only decides how many samples past a ray's last one are evaluated in vain.
+struct OccPhArgs {
+    const float *rays_o, *rays_d, *grid;
+    uint32_t N, H, max_steps, nlog;                        // n_step = 1 << nlog samples per ray and round
+    float mean_density;
+    float *weights_sum, *depth, *image, *normal_map;       // accumulators, as composite_rays leaves them
+    uint32_t *n_samples;                                   // optional [1]
+    uint32_t *sync;                                        // [16] zero on entry and on exit: 0 arrivals, 1 departures, 2 failure, 4 - 5 rays alive, 6 - 7 samples listed
+    int32_t *alive;                                        // [2][N]
+    float *st;                                             // [N][4] per ray: marcher's t, its last_t, the compositor's t, samples taken (bits)
+    uint32_t *cnt;                                         // [N] per alive entry: samples of this round | bit 31: the walk ended
+    uint32_t *list;                                        // [N << nlog] slot ids
+    float *s_in, *s_out;                                   // [N << nlog][8]: x y z dt dl1 - - - | alpha r g b nx ny nz -
+};
+
+__global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderArgs a, const OccPhArgs oc)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ uint32_t bar_flag, last;
+    fill_lds(lds, a);
+    const float *etab = nullptr;
+    if ((FWD_LDS_FLOATS + (size_t)oc.H + 1) * sizeof(float) + 64 <= 160 * 1024) {
+        RayCtx c0{}; c0.H = oc.H; c0.bound = a.bound;
+        for (uint32_t m = threadIdx.x; m <= oc.H; m += FBLOCK) lds[FWD_LDS_FLOATS + m] = rm_edge(c0, m);
+        etab = lds + FWD_LDS_FLOATS;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    float *fsl = lds + OFF_WAVE + wave * FE_SLAB;
+    const FieldCtx fc = make_ctx(a);
+    const float inv_s = a.inv_s_dev ? *a.inv_s_dev : a.inv_s;
+    const float bound = a.bound, eps = a.eps;
+    const uint32_t wid = (uint32_t)wave * gridDim.x + blockIdx.x, nwaves = gridDim.x * FW;
+    uint32_t n_al = oc.N, round = 0, phase = 0, evaluated = 0;
+    bool ok = true;
+    for (;;) {
+        const uint32_t cur = round & 1u, nxt = cur ^ 1u;
+        // samples per ray in this round: 2^oc.nlog while most rays are alive, up to 64 once the slots allow it (like the reference's n_step = N / n_alive: the
+        // stragglers -- rays along a limb -- finish in a round or two instead of one round per 16 samples, and a round costs three barriers whatever its size)
+        uint32_t nlog = oc.nlog;
+        while (nlog < 6u && ((uint64_t)n_al << (nlog + 1u)) <= ((uint64_t)oc.N << oc.nlog)) ++nlog;
+        const uint32_t nstep = 1u << nlog;
+        const int32_t *L = oc.alive + (size_t)cur * oc.N;
+        // ---- M: march ----
+        if (blockIdx.x == 0 && threadIdx.x == 0) oc.sync[4 + nxt] = 0u;                 // (the next round's ray counter: idle until this round's phase C)
+        for (uint32_t a0 = wid * 64u; a0 < n_al; a0 += nwaves * 64u) {
+            const uint32_t e = a0 + (uint32_t)lane;
+            const bool mine = e < n_al;
+            const uint32_t ray = mine ? (round ? (uint32_t)L[e] : e) : 0u;
+            RayCtx c; rm_setup(c, oc.rays_o + 3 * (size_t)ray, oc.rays_d + 3 * (size_t)ray, oc.grid, oc.mean_density, bound, oc.H);
+            float near, far;
+            cube_near_far(c.ox, c.oy, c.oz, c.dx, c.dy, c.dz, bound, near, far);
+            float t = near, last_t = near, skip_tt = RM_NO_SKIP;
+            uint32_t taken = 0;
+            float4 *stp = reinterpret_cast<float4 *>(oc.st) + ray;
+            if (mine) {
+                if (round) { const float4 v = *stp; t = v.x; last_t = v.y; taken = __float_as_uint(v.w); }
+                else {
+                    oc.weights_sum[ray] = 0.0f; oc.depth[ray] = 0.0f;
+                    for (int k = 0; k < 3; ++k) { oc.image[3 * (size_t)ray + k] = 0.0f; oc.normal_map[3 * (size_t)ray + k] = 0.0f; }
+                }
+            }
+            uint32_t room = nstep, mycnt = 0;
+            bool ended = false;
+            if (mine) {
+                if (oc.max_steps && oc.max_steps - taken < room) room = oc.max_steps - taken;
+                const uint32_t room0 = room;
+                float *sp = oc.s_in + 8 * ((size_t)e << nlog);
+                auto emit = [&](float x, float y, float z, float dt, float t_after, uint32_t) {
+                    *reinterpret_cast<float4 *>(sp) = make_float4(x, y, z, dt); sp[4] = t_after - last_t;
+                    last_t = t_after; sp += 8;
+                };
+                bool more = true;
+                uint32_t kpos = 0;
+                while (room > 0 && more) more = rm_march_batch<RM_BATCH>(c, t, skip_tt, far, room, kpos, emit, etab);
+                mycnt = room0 - room; taken += mycnt;
+                ended = !more || (oc.max_steps && taken >= oc.max_steps);
+                const float tc0 = round ? (*stp).z : near;
+                *stp = make_float4(t, last_t, tc0, __uint_as_float(taken));
+                oc.cnt[e] = mycnt | (ended ? 0x80000000u : 0u);
+            }
+            // the round's tile list: a wave reserves room for its samples with one atomic
+            uint32_t inc = mycnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += v; }
+            const uint32_t tot = (uint32_t)__shfl((int)inc, 63);
+            uint32_t base = 0;
+            if (lane == 0 && tot) base = atomicAdd(&oc.sync[6 + cur], tot);
+            base = (uint32_t)__shfl((int)base, 0) + (inc - mycnt);
+            for (uint32_t k = 0; k < mycnt; ++k) oc.list[base + k] = (e << nlog) + k;
+        }
+        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag);
+        // ---- F: field on the listed samples ----
+        if (blockIdx.x == 0 && threadIdx.x == 0) oc.sync[6 + nxt] = 0u;                 // (the next round's list counter)
+        const uint32_t nl = ok ? __hip_atomic_load(&oc.sync[6 + cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (uint32_t tile = wid; tile * 16u < nl; tile += nwaves) {
+            const uint32_t q = tile * 16u + (uint32_t)n, slot = oc.list[q < nl ? q : nl - 1];
+            const uint32_t e = slot >> nlog, ray = round ? (uint32_t)L[e] : e;
+            const float4 in = *reinterpret_cast<const float4 *>(oc.s_in + 8 * (size_t)slot);
+            const float px = clampf(in.x, -bound, bound), py = clampf(in.y, -bound, bound), pz = clampf(in.z, -bound, bound), delta = in.w;
+            const float dx = oc.rays_d[3 * (size_t)ray], dy = oc.rays_d[3 * (size_t)ray + 1], dz = oc.rays_d[3 * (size_t)ray + 2];
+            float fe0[4][2];
+            encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
+            f32x4 o16; float gr[3];
+            fd_forward(lds, fsl, lane, px, py, pz, eps, bound, fe0, o16, gr);
+            const float gx = gr[0], gy = gr[1], gz = gr[2];
+            const float gn = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+            const float nx = gx / (1e-5f + gn), ny = gy / (1e-5f + gn), nz = gz / (1e-5f + gn);
+            float rgb[3];
+            if (a.Wsh) {
+                wave_sync();
+                sample_sh_bias(fsl, a.Wsh, dx, dy, dz, lane);
+                color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb, fsl + 4 * lane, 256);
+            } else color_tile(lds, lane, px, py, pz, nx, ny, nz, o16, rgb);
+            const float tcos = (dx * nx + dy * ny) + dz * nz;
+            const float a1 = dv_softplus100(lds + OFF_SPQ, -tcos * 0.5f + 0.5f) * a.one_m_car;
+            const float a2 = dv_softplus100(lds + OFF_SPQ, -tcos) * a.car;
+            const float half = -(a1 + a2) * delta * 0.5f;
+            const float pc = dv_sigmoid((o16[0] - half) * inv_s), nc = dv_sigmoid((o16[0] + half) * inv_s);
+            const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+            if (g == 0 && q < nl) {
+                float *po = oc.s_out + 8 * (size_t)slot;
+                *reinterpret_cast<float4 *>(po) = make_float4(alpha, rgb[0], rgb[1], rgb[2]);
+                *reinterpret_cast<float4 *>(po + 4) = make_float4(nx, ny, nz, 0.0f);
+            }
+            wave_sync();
+        }
+        if (wid == 0 && lane == 0) evaluated += nl;
+        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag);
+        // ---- C: composite, and who goes on ----
+        for (uint32_t a0 = wid * 64u; a0 < n_al && ok; a0 += nwaves * 64u) {
+            const uint32_t e = a0 + (uint32_t)lane;
+            const bool mine = e < n_al;
+            bool goes = false;
+            uint32_t ray = 0;
+            if (mine) {
+                ray = round ? (uint32_t)L[e] : e;
+                const uint32_t cw = oc.cnt[e], mycnt = cw & 0x7fffffffu;
+                bool alive = !(cw >> 31);
+                float4 *stp = reinterpret_cast<float4 *>(oc.st) + ray;
+                float tc = (*stp).z;
+                float ws = oc.weights_sum[ray], dep = oc.depth[ray];
+                float cr = oc.image[3 * (size_t)ray], cg = oc.image[3 * (size_t)ray + 1], cb = oc.image[3 * (size_t)ray + 2];
+                float mx = oc.normal_map[3 * (size_t)ray], my = oc.normal_map[3 * (size_t)ray + 1], mz = oc.normal_map[3 * (size_t)ray + 2];
+                const float *pi = oc.s_in + 8 * ((size_t)e << nlog), *po = oc.s_out + 8 * ((size_t)e << nlog);
+                for (uint32_t k = 0; k < mycnt; ++k, pi += 8, po += 8) {            // composite_rays_kernel's loop body
+                    const float4 u = *reinterpret_cast<const float4 *>(po), v = *reinterpret_cast<const float4 *>(po + 4);
+                    const float alpha = u.x, T = 1 - ws, w = alpha * T;
+                    ws += w;
+                    tc += pi[4];
+                    dep += w * tc;
+                    cr += w * u.y; cg += w * u.z; cb += w * u.w;
+                    mx += w * v.x; my += w * v.y; mz += w * v.z;
+                    if ((double)T < 1e-2) { alive = false; break; }
+                }
+                (*stp).z = tc;
+                oc.weights_sum[ray] = ws; oc.depth[ray] = dep;
+                oc.image[3 * (size_t)ray] = cr; oc.image[3 * (size_t)ray + 1] = cg; oc.image[3 * (size_t)ray + 2] = cb;
+                oc.normal_map[3 * (size_t)ray] = mx; oc.normal_map[3 * (size_t)ray + 1] = my; oc.normal_map[3 * (size_t)ray + 2] = mz;
+                goes = alive;
+            }
+            const unsigned long long gm = __ballot(goes);
+            if (gm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&oc.sync[4 + nxt], (uint32_t)__builtin_popcountll(gm));
+                base = (uint32_t)__shfl((int)base, 0);
+                if (goes) oc.alive[(size_t)nxt * oc.N + base + (uint32_t)__builtin_popcountll(gm & ((1ull << lane) - 1ull))] = (int32_t)ray;
+            }
+        }
+        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag);
+        n_al = ok ? __hip_atomic_load(&oc.sync[4 + nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (n_al == 0u) break;
+        ++round;
+    }
+    if (oc.n_samples && wid == 0 && lane == 0 && evaluated) atomicAdd(oc.n_samples, evaluated);
+    // the last workgroup to leave re-arms the scratch
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(&oc.sync[1], 1u) == gridDim.x - 1u ? 1u : 0u; }
+    __syncthreads();
+    if (last && threadIdx.x < 16) {
+        if (threadIdx.x == 2 && oc.sync[2]) { oc.weights_sum[0] = __builtin_nanf(""); }                 // a barrier timed out: make the failure visible
+        __threadfence();
+        oc.sync[threadIdx.x] = 0u;
+    }
+}
+
 __device__ __forceinline__ void fill_lds_color_bwd(float *lds, const RenderArgs &a)
 {
     for (int e = threadIdx.x; e < 4 * 64; e += blockDim.x) {        // fragment to: lane (m, kk) = Wc3[o = kk][unit = 16 to + m]
@@ -1687,6 +1882,66 @@ AC_API int ac_render_rays_occupancy_train(const ac_field *field, const float *ra
     if (blocks < cus && capacity / 16u > blocks * FW) blocks = cus;         // (the tiles of phase C want every wave)
     hipLaunchKernelGGL(occupancy_train_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
     return ac::check_launch("render_rays_occupancy_train");
+}
+
+// scratch of ac_render_rays_occupancy_phased: [16] sync words | alive lists [2][N] | per-ray state [N][4] | per-entry counts [N] | tile list [N << nlog] |
+// sample slots in / out [N << nlog][8] each.  ZERO-FILLED by the caller once (the sync words; every call leaves them zero again); any call with the same or a
+// smaller N (and the same n_step) may reuse it on the same stream.
+struct OccPhLayout { size_t alive, st, cnt, list, s_in, s_out, total; };
+static uint32_t occ_phased_nlog()
+{
+    static const int env = []() { const char *e = getenv("AC_OCC_NLOG"); return (e && e[0] >= '1' && e[0] <= '6' && !e[1]) ? e[0] - '0' : -1; }();
+    return env >= 0 ? (uint32_t)env : 4u;
+}
+static OccPhLayout occ_phased_layout(uint32_t N, uint32_t nlog)
+{
+    OccPhLayout l{};
+    size_t o = 16 * sizeof(uint32_t);
+    l.alive = o; o += 2 * (size_t)N * sizeof(int32_t);
+    o = (o + 15) & ~(size_t)15;
+    l.st = o; o += (size_t)N * 4 * sizeof(float);
+    l.cnt = o; o += (size_t)N * sizeof(uint32_t);
+    l.list = o; o += ((size_t)N << nlog) * sizeof(uint32_t);
+    o = (o + 15) & ~(size_t)15;
+    l.s_in = o; o += ((size_t)N << nlog) * 8 * sizeof(float);
+    l.s_out = o; o += ((size_t)N << nlog) * 8 * sizeof(float);
+    l.total = o;
+    return l;
+}
+AC_API size_t ac_render_rays_occupancy_phased_scratch(uint32_t N) { return occ_phased_layout(N, occ_phased_nlog()).total; }
+
+AC_API int ac_render_rays_occupancy_phased(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
+                                           float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
+                                           float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
+                                           void *scratch, size_t scratch_bytes, ac_stream_t stream)
+{
+    if (N == 0) return AC_OK;
+    if (!rays_o || !rays_d || !grid || !weights_sum || !depth || !image || !normal_map || !scratch || H < 2 || !(eps > 0.0f)) {
+        ac::set_error("render_rays_occupancy_phased: NULL buffer, H < 2 or eps <= 0"); return AC_ERR_BAD_ARG;
+    }
+    const uint32_t nlog = occ_phased_nlog();
+    if (((uint64_t)N << nlog) >= (1ull << 31)) { ac::set_error("render_rays_occupancy_phased: too many rays for 32-bit slot ids"); return AC_ERR_BAD_ARG; }
+    const OccPhLayout l = occ_phased_layout(N, nlog);
+    if (scratch_bytes < l.total) { ac::set_error("render_rays_occupancy_phased: scratch of %zu bytes needed, %zu given", l.total, scratch_bytes); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = prep_args(a, field, bound, eps)) return rc;
+    a.inv_s = inv_s; a.inv_s_dev = inv_s_dev; a.car = cos_anneal_ratio; a.one_m_car = (float)(1.0 - (double)cos_anneal_ratio);
+    char *sc = static_cast<char *>(scratch);
+    OccPhArgs oc{ rays_o, rays_d, grid, N, H, max_steps, nlog, mean_density, weights_sum, depth, image, normal_map, n_samples,
+                  reinterpret_cast<uint32_t *>(sc), reinterpret_cast<int32_t *>(sc + l.alive), reinterpret_cast<float *>(sc + l.st),
+                  reinterpret_cast<uint32_t *>(sc + l.cnt), reinterpret_cast<uint32_t *>(sc + l.list), reinterpret_cast<float *>(sc + l.s_in),
+                  reinterpret_cast<float *>(sc + l.s_out) };
+    const bool tab = (FWD_LDS_FLOATS + (size_t)H + 1) * sizeof(float) + 64 <= 160 * 1024;
+    const size_t lds_bytes = (FWD_LDS_FLOATS + (tab ? (size_t)H + 1 : 0)) * sizeof(float);
+    static uint64_t seen = 0;
+    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_phased_kernel), 160 * 1024 - 64);
+    // one persistent workgroup per compute unit AT MOST (grid barriers: every workgroup must be resident)
+    const uint32_t cus = ac::cu_count();
+    uint32_t blocks = (N + 63u) / 64u;
+    if (blocks > cus) blocks = cus;
+    if (blocks < cus && N / 4u > blocks * FW) blocks = cus;              // (the tiles of phase F want every wave)
+    hipLaunchKernelGGL(occupancy_phased_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
+    return ac::check_launch("render_rays_occupancy_phased");
 }
 
 AC_API size_t ac_sdf_stencil_backward_scratch(uint32_t B)

@@ -770,10 +770,18 @@ def field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio
     return out
 
 
-def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, count_samples=False, max_steps=0):
-    """ac_render_rays_occupancy: the inference form of run_cuda in one launch (march + field + composite per ray, no rounds).
+# from this ray count on the inference launch runs in phases (same bits): 1.01 against 1.94 ms on a 256 x 256 view, 0.54 against 0.87 ms on a 4096-ray batch of
+# its middle rows; a few dozen rays are quicker through the one-wave-per-group kernel (no grid barriers)
+OCCUPANCY_PHASED_MIN_RAYS = int(os.environ.get("AC_OCC_PHASED_MIN_RAYS", "2048"))
+_OP_SCRATCH = {}
+
+
+def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, count_samples=False, max_steps=0,
+                          phased=None):
+    """ac_render_rays_occupancy / ac_render_rays_occupancy_phased: the inference form of run_cuda in one launch (no host round trips).
     -> dict(weights_sum [N], depth [N] (raw sum of w t), image [N,3] (no background), normal_map [N,3] (+ n_samples, a [1] int32 device tensor))
-    max_steps: a ray stops after that many samples (0 = no cap); see include/avatarcraft_hip.h for how that relates to the loop of rounds."""
+    max_steps: a ray stops after that many samples (0 = no cap); see include/avatarcraft_hip.h for how that relates to the loop of rounds.
+    phased: None = by ray count (OCCUPANCY_PHASED_MIN_RAYS); the two kernels give the same bits."""
     rays_o = _chk(rays_o.reshape(-1, 3), "rays_o"); rays_d = _chk(rays_d.reshape(-1, 3), "rays_d"); grid = _chk(density_grid, "density_grid")
     N, dev = rays_o.shape[0], rays_o.device
     if grid.dim() != 3 or grid.shape[0] != grid.shape[1] or grid.shape[0] != grid.shape[2]:
@@ -783,6 +791,20 @@ def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bou
     if count_samples:
         out["n_samples"] = torch.zeros(1, dtype=torch.int32, device=dev)
     inv_f, inv_t = _inv_s_arg(inv_s)
+    if phased is None:
+        phased = N >= OCCUPANCY_PHASED_MIN_RAYS
+    if phased and N > 0:
+        need = int(L.lib().ac_render_rays_occupancy_phased_scratch(N))
+        key = (str(dev), int(L.current_stream(dev) or 0))
+        sc = _OP_SCRATCH.get(key)
+        if sc is None or sc.numel() < need:
+            sc = _OP_SCRATCH[key] = torch.zeros(need, dtype=torch.uint8, device=dev)          # zeroed once: every launch re-arms its sync words
+        L.check(L.lib().ac_render_rays_occupancy_phased(C.byref(field.c), rays_o.data_ptr(), rays_d.data_ptr(), N, grid.data_ptr(), int(grid.shape[0]),
+                                                        float(mean_density), float(bound), float(eps), inv_f, L.ptr(inv_t), float(cos_anneal_ratio),
+                                                        out["weights_sum"].data_ptr(), out["depth"].data_ptr(), out["image"].data_ptr(),
+                                                        out["normal_map"].data_ptr(), L.ptr(out.get("n_samples")), max(0, int(max_steps)), sc.data_ptr(),
+                                                        sc.numel(), L.current_stream(dev)), "render_rays_occupancy_phased")
+        return out
     L.check(L.lib().ac_render_rays_occupancy(C.byref(field.c), rays_o.data_ptr(), rays_d.data_ptr(), N, grid.data_ptr(), int(grid.shape[0]), float(mean_density),
                                              float(bound), float(eps), inv_f, L.ptr(inv_t), float(cos_anneal_ratio), out["weights_sum"].data_ptr(),
                                              out["depth"].data_ptr(), out["image"].data_ptr(), out["normal_map"].data_ptr(), L.ptr(out.get("n_samples")),

@@ -549,6 +549,19 @@ def time_occupancy_render(dev, p, table, ro, rd, reps=3):
                 dt = (time.perf_counter() - t0) / (reps * (4 if not rounds_on else 1))
                 res[f"eval_{mode}_{rpb}_ray_batches"] = {"ms_per_view": dt * 1e3, "rays_per_s": n / dt, "march_rounds_per_view": rounds}
         net.occupancy_rounds = False
+        # the two one-launch kernels side by side on the whole view (run_cuda picks the phased one from 2048 rays on: same pixels)
+        from avatarcraft_amd import nsr_ops as _o
+        fa = (net._field(), ro, rd, net.density_grid, net.mean_density, NSR_BOUND, 0.005, net.forward_variance(), 1.0)
+        for nm, ph in (("phases_rounds_inside_the_launch", True), ("one_wave_per_ray_group", False)):
+            a_img = _o.render_rays_occupancy(*fa, phased=ph)["image"]; torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(12):
+                _o.render_rays_occupancy(*fa, phased=ph)
+            torch.cuda.synchronize()
+            res.setdefault("eval_kernels_65536_rays", {})[nm] = {"ms_per_view": (time.perf_counter() - t0) / 12 * 1e3}
+            res["eval_kernels_65536_rays"].setdefault("_img", []).append(a_img)
+        _imgs = res["eval_kernels_65536_rays"].pop("_img")
+        res["eval_kernels_65536_rays"]["pixels_identical"] = bool(torch.equal(_imgs[0], _imgs[1]))
         # what a driver gets: the harness (render_instantnsr_naive, rays_per_batch = 4096 like render_canonical.py) hands an eval() occupancy net the whole view
         from avatarcraft_amd.render_utils import render_instantnsr_naive as _harness, WHITE_BKG as _W
         hk = dict(rays_per_batch=RAYS_PER_BATCH, requires_grad=False, bkg_key=_W, render_can=True, perturb=False, return_raw=True, num_steps=64, upsample_steps=64,

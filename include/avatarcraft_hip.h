@@ -381,6 +381,18 @@ int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const f
                              float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
                              ac_stream_t stream);
 
+/* The same inference render, the same bits, as rounds of march | field | composite INSIDE one launch with grid barriers between the phases (ABI 7): every lane
+ * walks a ray, the samples of a round are evaluated on tiles dealt to all waves, and the rays that go on (not at `far`, T >= 1e-2, below max_steps) form the
+ * next round's list -- the reference's loop without its host read-backs; faster than ac_render_rays_occupancy on whole views, where that kernel keeps a
+ * quarter of a wave's lanes walking and every wave evaluating its own tiles one after the other.  n_step = 16 samples per ray and round (AC_OCC_NLOG = 1 .. 6
+ * overrides its log2); results do not depend on it.  scratch: ac_render_rays_occupancy_phased_scratch(N) bytes (64 B per ray and round sample: 67 MB for a
+ * 256 x 256 view), ZERO-FILLED by the caller before its first use, re-armed by every call, one buffer per stream; a call with fewer rays may reuse it. */
+size_t ac_render_rays_occupancy_phased_scratch(uint32_t N);
+int ac_render_rays_occupancy_phased(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
+                                    float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
+                                    float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
+                                    void *scratch, size_t scratch_bytes, ac_stream_t stream);
+
 /* The training form of run_cuda WITHOUT autograd as ONE launch (ABI 7) -- stylize.py's render_val of a cuda_ray network, which never leaves train() mode
  * (stylize.py:46-215 never calls eval()): what ac_march_rays_train (count, scan, write) -> ac_field_samples -> ac_composite_rays_train_forward twice (colour,
  * normal) -> the eikonal term and the background in torch compute, as four phases of one persistent launch separated by grid barriers: the walk of

@@ -234,6 +234,27 @@ def test_run_cuda_inference_loop_vs_oracle_chain(env):
     assert 0 < int(cnt.item()) <= ro.shape[0] * 1024
 
 
+@pytest.mark.parametrize("side,n_rays,max_steps", [(7, 37, 0), (32, 1000, 0), (64, 4096, 0), (64, 4096, 5), (256, 65536, 0), (256, 65536, 23)])
+def test_inference_in_phases_equals_the_one_wave_per_group_launch(env, side, n_rays, max_steps):
+    """round 5: ac_render_rays_occupancy_phased (rounds of march | field | composite inside one launch, grid barriers, tiles dealt to all waves) gives the
+    bits of ac_render_rays_occupancy -- any ray count, with and without the step cap, the sample count too"""
+    from avatarcraft_amd import nsr_ops
+    net = env["net"].eval()
+    ro, rd = make_rays(side, side, dist=1.8, f=0.75 * side)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[:n_rays])).to(DEV)
+    args = (net._field(), t(ro), t(rd), net.density_grid, net.mean_density, 1.6, 0.005, env["inv_s"], 0.7)
+    a = nsr_ops.render_rays_occupancy(*args, count_samples=True, max_steps=max_steps, phased=False)
+    for rep in range(2):                                     # (twice: the second call runs on the scratch the first one re-armed)
+        b = nsr_ops.render_rays_occupancy(*args, count_samples=True, max_steps=max_steps, phased=True)
+        for k in ("weights_sum", "depth", "image", "normal_map"):
+            assert torch.equal(a[k], b[k]), (k, rep)
+        assert int(b["n_samples"]) > 0 and int(a["n_samples"]) > 0        # (samples EVALUATED: each kernel evaluates some past a ray's last composited one)
+    assert float(a["weights_sum"].max()) > (0.5 if max_steps else 0.9)
+    if n_rays >= 2048:                                       # what run_cuda picks by itself from that many rays on
+        c = nsr_ops.render_rays_occupancy(*args, max_steps=max_steps)
+        assert torch.equal(c["image"], a["image"])
+
+
 def test_run_cuda_gradients_vs_torch_formulation(env):
     """the training form under autograd: fused SDF-query / colour operators + packed compositor, against torch MLPs over the HIP hash encoder with the
     normal from six more forward_sdf calls (the reference's formulation of the same per-sample arithmetic), same samples, same compositor"""

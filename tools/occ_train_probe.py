@@ -43,6 +43,17 @@ def main():
         net.eval()
         res["eval_4096"] = timed(lambda: net.render(ro_t[None, :4096], rd_t[None, :4096], **kw), 20)
         res["eval_view"] = timed(lambda: net.render(ro_t[None], rd_t[None], **kw), 10)
+        from avatarcraft_amd import nsr_ops
+        fa = (net._field(), ro_t, rd_t, net.density_grid, net.mean_density, NSR_BOUND, 0.005, net.forward_variance(), 1.0)
+        res["eval_view_groups"] = timed(lambda: nsr_ops.render_rays_occupancy(*fa, phased=False), 10)
+        res["eval_view_phased"] = timed(lambda: nsr_ops.render_rays_occupancy(*fa, phased=True), 10)
+        fb = (net._field(), ro_t[:4096], rd_t[:4096], net.density_grid, net.mean_density, NSR_BOUND, 0.005, net.forward_variance(), 1.0)
+        res["eval_4096_phased"] = timed(lambda: nsr_ops.render_rays_occupancy(*fb, phased=True), 20)
+        mid = slice(30000, 34096)
+        fc = (net._field(), ro_t[mid], rd_t[mid], net.density_grid, net.mean_density, NSR_BOUND, 0.005, net.forward_variance(), 1.0)
+        res["eval_mid4096_groups"] = timed(lambda: nsr_ops.render_rays_occupancy(*fc, phased=False), 20)
+        res["eval_mid4096_phased"] = timed(lambda: nsr_ops.render_rays_occupancy(*fc, phased=True), 20)
+        res["view_samples"] = {k: int(nsr_ops.render_rays_occupancy(*fa, phased=ph, count_samples=True)["n_samples"]) for k, ph in (("groups", False), ("phased", True))}
         net.train()
         net.mean_count = 0
         net.render(so[None, :4096], sd[None, :4096], perturb=True, **kw)
