@@ -1074,6 +1074,10 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderAr
             const float4 in = *reinterpret_cast<const float4 *>(oc.s_in + 8 * (size_t)slot);
             const float px = clampf(in.x, -bound, bound), py = clampf(in.y, -bound, bound), pz = clampf(in.z, -bound, bound), delta = in.w;
             const float dx = oc.rays_d[3 * (size_t)ray], dy = oc.rays_d[3 * (size_t)ray + 1], dz = oc.rays_d[3 * (size_t)ray + 2];
+#ifdef AC_OCC_NOFIELD      // timing ablation: no field evaluation (what the walk, the barriers and the bookkeeping cost alone)
+            const float nx = dx, ny = dy, nz = dz, alpha = 0.02f * delta / (delta + 1e-3f) + 0.0f * (px + py + pz + inv_s);
+            float rgb[3] = { 0.5f, 0.5f, 0.5f };
+#else
             float fe0[4][2];
             encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
             f32x4 o16; float gr[3];
@@ -1093,6 +1097,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderAr
             const float half = -(a1 + a2) * delta * 0.5f;
             const float pc = dv_sigmoid((o16[0] - half) * inv_s), nc = dv_sigmoid((o16[0] + half) * inv_s);
             const float alpha = clampf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f, 1.0f);
+#endif
             if (g == 0 && q < nl) {
                 float *po = oc.s_out + 8 * (size_t)slot;
                 *reinterpret_cast<float4 *>(po) = make_float4(alpha, rgb[0], rgb[1], rgb[2]);
