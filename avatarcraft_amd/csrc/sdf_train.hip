@@ -746,7 +746,7 @@ struct OccTrainArgs {
     int32_t *counter;                                    // optional [2]: += samples of all rays, += N (march_rays_train's step counter)
     float *weights_sum, *image, *normal_map, *gradient_error;
     const float *bg; uint32_t bg_mode; float bg_value;   // image += (1 - weights_sum) * bg:  0 none, 1 bg_value, 2 bg[3], 3 bg[N][3]
-    uint32_t *sync;                                      // [4] zero on entry and on exit: arrivals, departures, barrier failure, samples written
+    uint32_t *sync;                                      // [16]; 0 - 3 zero on entry and on exit: arrivals, departures, barrier failure, samples written; 8: failed launches (sticky)
     int32_t *chunk_tot, *counts, *offs, *ovf;            // [chunks] zero on entry and on exit | [N] | [N] offset of a written ray, else -1 | [N]
     uint32_t *wmask, *rec;                               // [N] | [N][RM_REC_WORDS]: the samples' positions (RayRecorder)
     double *partials;                                    // [gridDim.x][2]
@@ -959,6 +959,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_train_kernel(const RenderArg
             const bool failed = __hip_atomic_load(&oc.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             oc.gradient_error[0] = failed ? __builtin_nanf("") : (float)sn / ((float)sd + 1e-5f);
             if (oc.counter) { oc.counter[0] = base + tot; oc.counter[1] += (int32_t)oc.N; }
+            if (failed) oc.sync[8] += 1u;                                   // (sticky: launches of this scratch whose barrier timed out -- never reset)
             oc.sync[0] = 0u; oc.sync[1] = 0u; oc.sync[2] = 0u; oc.sync[3] = 0u;
         }
     }
@@ -980,7 +981,7 @@ struct OccPhArgs {
     float mean_density;
     float *weights_sum, *depth, *image, *normal_map;       // accumulators, as composite_rays leaves them
     uint32_t *n_samples;                                   // optional [1]
-    uint32_t *sync;                                        // [16] zero on entry and on exit: 0 arrivals, 1 departures, 2 failure, 4 - 5 rays alive, 6 - 7 samples listed
+    uint32_t *sync;                                        // [16]; 0 - 7 zero on entry and on exit: 0 arrivals, 1 departures, 2 failure, 4 - 5 rays alive, 6 - 7 samples listed; 8: failed launches (sticky)
     int32_t *alive;                                        // [2][N]
     float *st;                                             // [N][4] per ray: marcher's t, its last_t, the compositor's t, samples taken (bits)
     uint32_t *cnt;                                         // [N] per alive entry: samples of this round | bit 31: the walk ended
@@ -1157,8 +1158,8 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderAr
     __syncthreads();
     if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(&oc.sync[1], 1u) == gridDim.x - 1u ? 1u : 0u; }
     __syncthreads();
-    if (last && threadIdx.x < 16) {
-        if (threadIdx.x == 2 && oc.sync[2]) { oc.weights_sum[0] = __builtin_nanf(""); }                 // a barrier timed out: make the failure visible
+    if (last && threadIdx.x < 8) {
+        if (threadIdx.x == 2 && oc.sync[2]) { oc.weights_sum[0] = __builtin_nanf(""); oc.sync[8] += 1u; }      // a barrier timed out: a NaN pixel and the sticky count (word 8)
         __threadfence();
         oc.sync[threadIdx.x] = 0u;
     }
@@ -1824,7 +1825,7 @@ AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, 
     return ac::check_launch("render_rays_occupancy");
 }
 
-// scratch of ac_render_rays_occupancy_train: [4] sync words | [chunks] totals | counts, offsets, overflow flags, word masks [N] each | records [N][32] | [CUs][2] doubles |
+// scratch of ac_render_rays_occupancy_train: [16] sync words (word 8: launches whose grid barrier timed out, sticky) | [chunks] totals | counts, offsets, overflow flags, word masks [N] each | records [N][32] | [CUs][2] doubles |
 // packed samples: ray [M], x y z dt [M][4], alpha r g b nx ny nz - [M][8].  ZERO-FILLED by the caller once (the sync words and the totals; every call leaves
 // them zero again), reusable for calls with the SAME N and capacity on the same stream (the layout depends on both).
 struct OccTrainLayout { size_t tot, cnt, offs, ovf, wmask, rec, part, p_ray, p_in, p_out, total; };
@@ -1832,7 +1833,7 @@ static OccTrainLayout occ_train_layout(uint32_t N, uint32_t M)
 {
     OccTrainLayout l{};
     const size_t chunks = ((size_t)N + (1u << OT_CHUNK_LOG) - 1) >> OT_CHUNK_LOG;
-    size_t o = 4 * sizeof(uint32_t);
+    size_t o = 16 * sizeof(uint32_t);
     l.tot = o; o += chunks * sizeof(int32_t);
     l.cnt = o; o += (size_t)N * sizeof(int32_t);
     l.offs = o; o += (size_t)N * sizeof(int32_t);

@@ -865,6 +865,15 @@ def render_rays_occupancy_train(field, rays_o, rays_d, density_grid, mean_densit
     return out
 
 
+def occupancy_launch_failures():
+    """launches of the phased occupancy kernels (inference and training form) whose grid barrier timed out, over every scratch buffer this process holds
+    (word 8 of a buffer: sticky).  0 on a healthy run; such a launch leaves NaN in gradient_error / weights_sum[0].  Synchronises."""
+    n = 0
+    for sc in list(_OT_SCRATCH.values()) + list(_OP_SCRATCH.values()):
+        n += int(sc[32:36].view(torch.int32).item())
+    return n
+
+
 def field_sdf(field, x, bound):
     """forward_sdf (instant_nsr.py:627-642): x [B,3] -> [B,16] (sdf, 15 features)"""
     x = _chk(x.reshape(-1, 3), "x")

@@ -386,7 +386,9 @@ int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const f
  * next round's list -- the reference's loop without its host read-backs; faster than ac_render_rays_occupancy on whole views, where that kernel keeps a
  * quarter of a wave's lanes walking and every wave evaluating its own tiles one after the other.  n_step = 16 samples per ray and round (AC_OCC_NLOG = 1 .. 6
  * overrides its log2); results do not depend on it.  scratch: ac_render_rays_occupancy_phased_scratch(N) bytes (64 B per ray and round sample: 67 MB for a
- * 256 x 256 view), ZERO-FILLED by the caller before its first use, re-armed by every call, one buffer per stream; a call with fewer rays may reuse it. */
+ * 256 x 256 view), ZERO-FILLED by the caller before its first use, re-armed by every call, one buffer per stream; a call with fewer rays may reuse it.
+ * A launch needs every workgroup resident (one per compute unit at most): if a grid barrier is not met within two seconds (the device shared with a kernel
+ * that holds compute units that long) the launch gives up, leaves NaN in weights_sum[0] and counts itself in the scratch's 32-bit word 8 (sticky). */
 size_t ac_render_rays_occupancy_phased_scratch(uint32_t N);
 int ac_render_rays_occupancy_phased(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
                                     float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,

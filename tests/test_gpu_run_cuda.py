@@ -250,6 +250,7 @@ def test_inference_in_phases_equals_the_one_wave_per_group_launch(env, side, n_r
             assert torch.equal(a[k], b[k]), (k, rep)
         assert int(b["n_samples"]) > 0 and int(a["n_samples"]) > 0        # (samples EVALUATED: each kernel evaluates some past a ray's last composited one)
     assert float(a["weights_sum"].max()) > (0.5 if max_steps else 0.9)
+    assert nsr_ops.occupancy_launch_failures() == 0
     if n_rays >= 2048:                                       # what run_cuda picks by itself from that many rays on
         c = nsr_ops.render_rays_occupancy(*args, max_steps=max_steps)
         assert torch.equal(c["image"], a["image"])

@@ -167,5 +167,5 @@ def occ_train():
 
 
 total_bad += soak("occupancy training form, one launch (%d samples)" % int(occ_train()["counter"][0].item()), occ_train, int(2000 * scale))
-print("hand-off timeouts on this stream:", nsr_ops.handoff_timeouts(dev))
+print("hand-off timeouts on this stream:", nsr_ops.handoff_timeouts(dev), "| occupancy launches with a timed-out grid barrier:", nsr_ops.occupancy_launch_failures())
 print("total: %d differing repeats; %.0f s" % (total_bad, time.time() - t0))
