@@ -42,7 +42,8 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 7 (round 5, second half: ac_render_rays_occupancy_train; 6, round 5: ac_render_rays_occupancy's max_steps, ac_field_sdf_grid, ac_marching_cubes*,
+int ac_version(void);                /* ABI version, currently 7 (round 5, second half: ac_render_rays_occupancy_phased, ac_render_rays_occupancy_train, ac_march_rays_train_scratch -- the
+                                      * marcher's scratch grew --; 6, round 5: ac_render_rays_occupancy's max_steps, ac_field_sdf_grid, ac_marching_cubes*,
                                       * ac_density_grid_update, the SH colour input of ac_field; round 4 = 5: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
                                       * ac_field_samples, ac_render_rays_occupancy, the measurement / liveness accessors, the *_typed encoder entries) */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
