@@ -132,6 +132,19 @@ def test_sh_forward_backward(oracle, degree):
     assert_bitwise(gi, gi_o, "sh grad_inputs")
 
 
+def test_sh_kernel_vs_reference_polynomials():
+    """the HIP kernel itself (not via the oracle) against the reference's polynomial lines: tests/golden/kat_sh.npz (make_kat_sh.py), all 64 channels and
+    their 192 derivatives -- same tolerances as tests/test_oracle_golden.py::test_sh_table_vs_reference_polynomials"""
+    from avatarcraft_amd.encoder.shencoder.backend import _backend
+    from tests.common import load_golden
+    g = load_golden("kat_sh.npz")
+    xt = T(g["dirs"]); out = torch.empty(256, 64, device=DEV); dd = torch.empty(256, 3 * 64, device=DEV)
+    _backend.sh_encode_forward(xt, out, 256, 3, 8, True, dd)
+    assert np.abs(out.cpu().numpy() - g["values"]).max() <= 1e-5
+    jac = g["jacobian"]
+    assert (np.abs(dd.cpu().numpy().reshape(256, 3, 64) - jac) / np.maximum(1.0, np.abs(jac))).max() <= 2e-5
+
+
 def test_sh_module(oracle):
     from avatarcraft_amd.encoder import get_encoder
     enc, dim = get_encoder("sphere_harmonics", dict(in_dim=3))
