@@ -71,6 +71,8 @@ class ac_warp_mesh(C.Structure):
 _SIGS = {
     "ac_version": ([], C.c_int),
     "ac_last_error": ([], C.c_char_p),
+    "ac_debug_hold_cus": ([u32, u32, u32, vp], C.c_int),
+    "ac_set_occupancy_barrier_ms": ([u32], u32),
     "ac_hash_level_table": ([u32, f32, u32, vp, vp], None),
     "ac_hash_encode_forward": ([vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp], C.c_int),
     "ac_hash_encode_backward": ([vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp, vp], C.c_int),
@@ -165,7 +167,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
             fn.argtypes = args
             fn.restype = res
-        if handle.ac_version() != 7:
+        if handle.ac_version() != 8:
             raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -16,6 +16,7 @@
 //   dW2 += d2 a^T          16 MFMA   } K = the 16 samples of the tile: operands transposed through a per-wave LDS slab,
 //   dW1 += d1 inp^T        48 MFMA   } accumulators live in registers for the whole kernel (a column of ones gives db1)
 // Weight-gradient partials are written per wave (no atomics) and summed by sdf_partials_reduce_kernel (deterministic).
+#include <atomic>
 #include "nsr_device.hpp"
 #include "rm_device.hpp"
 
@@ -589,11 +590,14 @@ struct OccArgs {
     uint32_t max_steps;                                    // a ray stops after this many samples (run_cuda's max_steps; the loop of rounds stops at the first round that
                                                            // brings its step count to >= max_steps, i.e. after max_steps .. max_steps + 7 samples); 0 = no cap
     uint32_t edge_tab;                                     // 1: H + 1 floats of LDS behind the stages hold the voxel faces (rm_skip_target_tab)
+    const uint32_t *run_if;                                // NULL, or a device word: the launch does nothing unless it is non-zero (the barrier-free answer to a phased
+                                                           // launch whose grid barrier timed out: queued behind it unconditionally, a few microseconds when not needed)
 };
 
 __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderArgs a, const OccArgs oc)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (oc.run_if && __hip_atomic_load(oc.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // (uniform over the grid: written before this launch started)
     fill_lds(lds, a);
     const float *etab = nullptr;
     if (oc.edge_tab) {
@@ -738,7 +742,18 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_render_kernel(const RenderAr
 // weights_sum / image / normal_map: the bits of the chain of operators (tests/test_gpu_run_cuda.py).  gradient_error: the same terms summed in double
 // in a fixed order (per lane, per wave, per workgroup; the last workgroup to leave adds the partials) instead of torch's fp32 tree: equal to ~1e-6 relative.
 constexpr uint32_t OT_CHUNK_LOG = 8;                     // 2^8 rays per chunk total (a multiple of the wave's 64)
-constexpr unsigned long long OT_SPIN_TICKS = 200000000ull;   // of the 100 MHz wall clock: two seconds
+// bound of a grid barrier's spin, in ticks of the 100 MHz wall clock: two seconds unless AC_OCC_BARRIER_MS or ac_set_occupancy_barrier_ms says otherwise
+static std::atomic<uint32_t> g_barrier_ms{0};            // 0 = the default
+static uint32_t ot_default_ms()
+{
+    static const uint32_t d = []() { const char *e = getenv("AC_OCC_BARRIER_MS"); const long ms = e ? atol(e) : 0; return (uint32_t)(ms > 0 ? ms : 2000); }();
+    return d;
+}
+static unsigned long long ot_spin_ticks()
+{
+    const uint32_t ms = g_barrier_ms.load(std::memory_order_relaxed);
+    return (unsigned long long)(ms ? ms : ot_default_ms()) * 100000ull;
+}
 struct OccTrainArgs {
     const float *rays_o, *rays_d, *grid;
     uint32_t N, H, M_write, M_comp, perturb;             // M_write: capacity of the packed layout (march_write's budget, > 0); M_comp: the compositor's
@@ -751,25 +766,31 @@ struct OccTrainArgs {
     uint32_t *wmask, *rec;                               // [N] | [N][RM_REC_WORDS]: the samples' positions (RayRecorder)
     double *partials;                                    // [gridDim.x][2]
     int32_t *p_ray; float *p_in, *p_out;                 // packed samples: ray [M] | x y z dt [M][4] | alpha r g b nx ny nz - [M][8]
+    unsigned long long spin_ticks;                       // bound of a grid barrier's spin (ot_spin_ticks)
 };
 
 __device__ __forceinline__ int32_t ot_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// every workgroup has arrived `phase` + 1 times (false: timed out -- a launch larger than the device; the caller gives up instead of hanging)
-__device__ __forceinline__ bool ot_barrier(uint32_t *sync, uint32_t phase, uint32_t *flag)
+// every workgroup has arrived `phase` + 1 times (false: timed out after `ticks` of the 100 MHz wall clock -- a foreign kernel held compute units for that long:
+// the launch itself cannot be too large, ac::launch_resident sized it -- the caller gives up instead of hanging; the host re-renders, see the launch sites)
+__device__ __forceinline__ bool ot_barrier(uint32_t *sync, uint32_t phase, uint32_t *flag, unsigned long long ticks)
 {
-    __syncthreads();                                     // (the workgroup's stores are in its XCD's L2)
+    // every wave first waits until ITS OWN stores have been written to its XCD's L2 (s_waitcnt vmcnt(0): ADVICE round 5 -- outside tgsplit mode the
+    // workgroup-scope release inside __syncthreads() need not wait for them), then ONE thread writes that L2's dirty lines back to where the other XCDs see them
+    // (agent-scope release) -- once per workgroup.  Measured: that fence by lane 0 of every wave instead costs the 65 536-ray inference launch 1.08 -> 1.39 ms
+    // and the training form 0.335 -> 0.449 (eight L2 write-backs + invalidations per workgroup and barrier); by every thread 0.537 (round 5).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __threadfence();
     if (threadIdx.x == 0) {
-        __threadfence();                                 // release at agent scope: that L2's dirty lines go where the other XCDs see them -- once per workgroup,
-                                                         // not once per thread (512 x 256 write-backs and invalidations per barrier were a fifth of the launch)
         atomicAdd(&sync[0], 1u);
         const uint32_t want = (phase + 1u) * gridDim.x;
         const unsigned long long t0 = wall_clock64();
         bool all = false;
-        while (!(all = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) && wall_clock64() - t0 < OT_SPIN_TICKS) __builtin_amdgcn_s_sleep(10);
+        while (!(all = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(10);
         *flag = all ? 1u : 0u;
         if (!*flag) atomicExch(&sync[2], 1u);
-        __threadfence();                                 // acquire: the compute unit's L1 and the L2's copies of other XCDs' lines are dropped
+        __threadfence();                                 // acquire: the compute unit's L1 (shared by the workgroup's waves) and the L2's copies of other XCDs' lines are dropped
     }
     __syncthreads();
     return *flag != 0u;
@@ -816,7 +837,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_train_kernel(const RenderArg
     }
     __syncthreads();                                                        // (the face table is done with: the weights take its place)
     fill_lds(lds, a);
-    ok = ot_barrier(oc.sync, 0, &bar_flag);
+    ok = ot_barrier(oc.sync, 0, &bar_flag, oc.spin_ticks);
     // ---- B: offsets, the budget rule, the packed samples ----
     for (uint32_t r0 = wid * 64u; r0 < oc.N && ok; r0 += nwaves * 64u) {
         const uint32_t ray = r0 + (uint32_t)lane;
@@ -853,7 +874,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_train_kernel(const RenderArg
             }
         }
     }
-    ok = ok && ot_barrier(oc.sync, 1, &bar_flag);
+    ok = ok && ot_barrier(oc.sync, 1, &bar_flag, oc.spin_ticks);
     // ---- C: the field on the packed samples, tiles dealt to all waves ----
     double e_num = 0.0, e_den = 0.0;                                       // this lane's share of sum(relax * gerr), sum(relax)
     {
@@ -898,7 +919,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_train_kernel(const RenderArg
             wave_sync();
         }
     }
-    ok = ok && ot_barrier(oc.sync, 2, &bar_flag);
+    ok = ok && ot_barrier(oc.sync, 2, &bar_flag, oc.spin_ticks);
     // ---- D: the packed compositor per ray (composite_train_fwd_kernel's loop), image and normal map on the same weights; background ----
     for (uint32_t r0 = wid * 64u; r0 < oc.N && ok; r0 += nwaves * 64u) {
         const uint32_t ray = r0 + (uint32_t)lane;
@@ -987,6 +1008,7 @@ struct OccPhArgs {
     uint32_t *cnt;                                         // [N] per alive entry: samples of this round | bit 31: the walk ended
     uint32_t *list;                                        // [N << nlog] slot ids
     float *s_in, *s_out;                                   // [N << nlog][8]: x y z dt dl1 - - - | alpha r g b nx ny nz -
+    unsigned long long spin_ticks;                         // bound of a grid barrier's spin (ot_spin_ticks)
 };
 
 __global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderArgs a, const OccPhArgs oc)
@@ -1065,7 +1087,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderAr
             base = (uint32_t)__shfl((int)base, 0) + (inc - mycnt);
             for (uint32_t k = 0; k < mycnt; ++k) oc.list[base + k] = (e << nlog) + k;
         }
-        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag);
+        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag, oc.spin_ticks);
         // ---- F: field on the listed samples ----
         if (blockIdx.x == 0 && threadIdx.x == 0) oc.sync[6 + nxt] = 0u;                 // (the next round's list counter)
         const uint32_t nl = ok ? __hip_atomic_load(&oc.sync[6 + cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -1107,7 +1129,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderAr
             wave_sync();
         }
         if (wid == 0 && lane == 0) evaluated += nl;
-        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag);
+        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag, oc.spin_ticks);
         // ---- C: composite, and who goes on ----
         for (uint32_t a0 = wid * 64u; a0 < n_al && ok; a0 += nwaves * 64u) {
             const uint32_t e = a0 + (uint32_t)lane;
@@ -1148,7 +1170,7 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderAr
                 if (goes) oc.alive[(size_t)nxt * oc.N + base + (uint32_t)__builtin_popcountll(gm & ((1ull << lane) - 1ull))] = (int32_t)ray;
             }
         }
-        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag);
+        ok = ok && ot_barrier(oc.sync, phase++, &bar_flag, oc.spin_ticks);
         n_al = ok ? __hip_atomic_load(&oc.sync[4 + nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (n_al == 0u) break;
         ++round;
@@ -1159,7 +1181,13 @@ __global__ __launch_bounds__(FBLOCK) void occupancy_phased_kernel(const RenderAr
     if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(&oc.sync[1], 1u) == gridDim.x - 1u ? 1u : 0u; }
     __syncthreads();
     if (last && threadIdx.x < 8) {
-        if (threadIdx.x == 2 && oc.sync[2]) { oc.weights_sum[0] = __builtin_nanf(""); oc.sync[8] += 1u; }      // a barrier timed out: a NaN pixel and the sticky count (word 8)
+        // a barrier timed out: a NaN pixel, the sticky count (word 8) and THIS launch's verdict (word 9, rewritten by every launch): the barrier-free launch the
+        // host has queued behind this one (ac_render_rays_occupancy_phased) runs if and only if it is set, and overwrites every output
+        if (threadIdx.x == 2) {
+            const bool failed = oc.sync[2] != 0u;
+            if (failed) { oc.weights_sum[0] = __builtin_nanf(""); oc.sync[8] += 1u; if (oc.n_samples) *oc.n_samples = 0u; }
+            __hip_atomic_store(&oc.sync[9], failed ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __threadfence();
         oc.sync[threadIdx.x] = 0u;
     }
@@ -1794,10 +1822,10 @@ AC_API int ac_field_samples(const ac_field *field, const float *xyzs, const floa
     return ac::check_launch("field_samples");
 }
 
-AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
-                                    float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
-                                    float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
-                                    ac_stream_t stream)
+static int render_rays_occupancy_impl(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
+                                      float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
+                                      float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
+                                      ac_stream_t stream, const uint32_t *run_if)
 {
     if (N == 0) return AC_OK;
     if (!rays_o || !rays_d || !grid || !weights_sum || !depth || !image || !normal_map || H < 2 || !(eps > 0.0f)) {
@@ -1815,7 +1843,7 @@ AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, 
     const uint32_t gsz = 1u << glog;
     // the voxel faces as a table behind the stages when H + 1 floats still fit the compute unit's LDS (H = 128: 516 of the 1.9 KB left)
     const bool tab = (OCC_LDS_FLOATS + (size_t)H + 1) * sizeof(float) + 64 <= 160 * 1024;
-    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, glog, max_steps, tab ? 1u : 0u };
+    OccArgs oc{ rays_o, rays_d, grid, N, H, mean_density, weights_sum, depth, image, normal_map, n_samples, glog, max_steps, tab ? 1u : 0u, run_if };
     const size_t lds_bytes = (OCC_LDS_FLOATS + (tab ? (size_t)H + 1 : 0)) * sizeof(float);
     static uint64_t seen = 0;
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_render_kernel), 160 * 1024 - 64);      // (a ceiling, set once: lds_bytes depends on H)
@@ -1823,6 +1851,15 @@ AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, 
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(occupancy_render_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
     return ac::check_launch("render_rays_occupancy");
+}
+
+AC_API int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
+                                    float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
+                                    float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,
+                                    ac_stream_t stream)
+{
+    return render_rays_occupancy_impl(field, rays_o, rays_d, N, grid, H, mean_density, bound, eps, inv_s, inv_s_dev, cos_anneal_ratio, weights_sum, depth, image,
+                                      normal_map, n_samples, max_steps, stream, nullptr);
 }
 
 // scratch of ac_render_rays_occupancy_train: [16] sync words (word 8: launches whose grid barrier timed out, sticky) | [chunks] totals | counts, offsets, overflow flags, word masks [N] each | records [N][32] | [CUs][2] doubles |
@@ -1876,7 +1913,7 @@ AC_API int ac_render_rays_occupancy_train(const ac_field *field, const float *ra
                      reinterpret_cast<int32_t *>(sc + l.offs), reinterpret_cast<int32_t *>(sc + l.ovf), reinterpret_cast<uint32_t *>(sc + l.wmask),
                      reinterpret_cast<uint32_t *>(sc + l.rec),
                      reinterpret_cast<double *>(sc + l.part), reinterpret_cast<int32_t *>(sc + l.p_ray), reinterpret_cast<float *>(sc + l.p_in),
-                     reinterpret_cast<float *>(sc + l.p_out) };
+                     reinterpret_cast<float *>(sc + l.p_out), ot_spin_ticks() };
     const size_t lds_bytes = FWD_LDS_FLOATS * sizeof(float);
     static uint64_t seen = 0;
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(occupancy_train_kernel), lds_bytes);
@@ -1886,8 +1923,14 @@ AC_API int ac_render_rays_occupancy_train(const ac_field *field, const float *ra
     uint32_t blocks = (N + 63u) / 64u;
     if (blocks > cus) blocks = cus;
     if (blocks < cus && capacity / 16u > blocks * FW) blocks = cus;         // (the tiles of phase C want every wave)
-    hipLaunchKernelGGL(occupancy_train_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
-    return ac::check_launch("render_rays_occupancy_train");
+    void *params[2] = { &a, &oc };
+    return ac::launch_resident("render_rays_occupancy_train", reinterpret_cast<const void *>(occupancy_train_kernel), blocks, FBLOCK, lds_bytes, (hipStream_t)stream, params);
+}
+
+AC_API uint32_t ac_set_occupancy_barrier_ms(uint32_t ms)
+{
+    const uint32_t prev = g_barrier_ms.exchange(ms, std::memory_order_relaxed);
+    return prev ? prev : ot_default_ms();
 }
 
 // scratch of ac_render_rays_occupancy_phased: [16] sync words | alive lists [2][N] | per-ray state [N][4] | per-entry counts [N] | tile list [N << nlog] |
@@ -1936,7 +1979,7 @@ AC_API int ac_render_rays_occupancy_phased(const ac_field *field, const float *r
     OccPhArgs oc{ rays_o, rays_d, grid, N, H, max_steps, nlog, mean_density, weights_sum, depth, image, normal_map, n_samples,
                   reinterpret_cast<uint32_t *>(sc), reinterpret_cast<int32_t *>(sc + l.alive), reinterpret_cast<float *>(sc + l.st),
                   reinterpret_cast<uint32_t *>(sc + l.cnt), reinterpret_cast<uint32_t *>(sc + l.list), reinterpret_cast<float *>(sc + l.s_in),
-                  reinterpret_cast<float *>(sc + l.s_out) };
+                  reinterpret_cast<float *>(sc + l.s_out), ot_spin_ticks() };
     const bool tab = (FWD_LDS_FLOATS + (size_t)H + 1) * sizeof(float) + 64 <= 160 * 1024;
     const size_t lds_bytes = (FWD_LDS_FLOATS + (tab ? (size_t)H + 1 : 0)) * sizeof(float);
     static uint64_t seen = 0;
@@ -1946,8 +1989,12 @@ AC_API int ac_render_rays_occupancy_phased(const ac_field *field, const float *r
     uint32_t blocks = (N + 63u) / 64u;
     if (blocks > cus) blocks = cus;
     if (blocks < cus && N / 4u > blocks * FW) blocks = cus;              // (the tiles of phase F want every wave)
-    hipLaunchKernelGGL(occupancy_phased_kernel, dim3(blocks), dim3(FBLOCK), lds_bytes, (hipStream_t)stream, a, oc);
-    return ac::check_launch("render_rays_occupancy_phased");
+    void *params[2] = { &a, &oc };
+    if (int rc = ac::launch_resident("render_rays_occupancy_phased", reinterpret_cast<const void *>(occupancy_phased_kernel), blocks, FBLOCK, lds_bytes, (hipStream_t)stream, params)) return rc;
+    // never a partial result (the reference's loop, raymarching/raymarching.py:136-188, cannot produce one): the barrier-free kernel is queued behind the
+    // phased one and does nothing unless that launch's verdict word says a grid barrier timed out -- then it renders every ray again (the same bits: tests)
+    return render_rays_occupancy_impl(field, rays_o, rays_d, N, grid, H, mean_density, bound, eps, inv_s, inv_s_dev, cos_anneal_ratio, weights_sum, depth, image,
+                                      normal_map, n_samples, max_steps, stream, reinterpret_cast<const uint32_t *>(sc) + 9);
 }
 
 AC_API size_t ac_sdf_stencil_backward_scratch(uint32_t B)

@@ -559,12 +559,19 @@ class NeRFRenderer(nn.Module):
                 # no graph wanted (and a budget, so that the packed layout has a size before anything is counted): walk, packed samples, field, both composites,
                 # the eikonal term and the background in one launch -- the same pixels as the chain below
                 cap = raymarching.raymarching._round_up(int(self.mean_count), 128)                        # (march_rays_train's capacity: + 128 - n % 128)
-                o = nsr_ops.render_rays_occupancy_train(self._field(), ro, rd, self.density_grid, self.mean_density, bound, fd_eps, inv_s_t, cos_anneal_ratio,
-                                                        perturb=bool(perturb_overwrite), capacity=cap, composite_capacity=cap, counter=counter, bg=bg)
-                gradient_error = o["gradient_error"][0]
-                self._guard_finite(gradient_error)
-                depth = torch.zeros(n_rays, dtype=torch.float32, device=device)
-                return (depth.reshape(B, N), None, o["weights_sum"][:, None], o["image"].reshape(B, N, 3), o["normal_map"], gradient_error, 0.0, None, None, None)
+                try:
+                    o = nsr_ops.render_rays_occupancy_train(self._field(), ro, rd, self.density_grid, self.mean_density, bound, fd_eps, inv_s_t, cos_anneal_ratio,
+                                                            perturb=bool(perturb_overwrite), capacity=cap, composite_capacity=cap, counter=counter, bg=bg)
+                except nsr_ops.OccupancyBarrierTimeout:
+                    # a grid barrier of the one launch timed out (compute units held by a foreign kernel for seconds): nothing was returned; the chain of
+                    # operators below has no barriers and gives the same pixels.  The step counter may hold the failed launch's partial update.
+                    o = None
+                    counter.zero_()
+                if o is not None:
+                    gradient_error = o["gradient_error"][0]
+                    self._guard_finite(gradient_error)
+                    depth = torch.zeros(n_rays, dtype=torch.float32, device=device)
+                    return (depth.reshape(B, N), None, o["weights_sum"][:, None], o["image"].reshape(B, N, 3), o["normal_map"], gradient_error, 0.0, None, None, None)
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, bound, self.density_grid, self.mean_density, self.iter_density, counter,
                                                                     self.mean_count, bool(perturb_overwrite), 128, False)
             M = xyzs.shape[0]

@@ -775,6 +775,33 @@ def field_samples(field, xyzs, dirs, deltas, bound, eps, inv_s, cos_anneal_ratio
 OCCUPANCY_PHASED_MIN_RAYS = int(os.environ.get("AC_OCC_PHASED_MIN_RAYS", "2048"))
 _OP_SCRATCH = {}
 
+# The phased kernels (inference and training form) synchronise their grid with barriers in global memory.  The launch is sized and checked for co-residency
+# (csrc/ac_common.hpp: launch_resident); what is left is a FOREIGN kernel holding compute units for longer than a barrier's bounded spin -- then the launch
+# gives up and counts itself in its scratch's sticky word.  Neither form hands out the partial result (the reference's loop, raymarching/raymarching.py:136-188,
+# cannot produce one):
+#   inference -- on the device: ac_render_rays_occupancy_phased queues the barrier-free kernel behind the phased one, conditional on that launch's verdict
+#       word (a few microseconds when it is not needed, no host round trip); it renders every ray again, the same bits;
+#   training form -- OCCUPANCY_VERIFY (default on; AC_OCC_VERIFY=0 for callers that poll occupancy_launch_failures() themselves): the wrapper reads the
+#       sticky word behind the launch (one 4-byte read-back, +0.08 ms on a 0.34 ms launch) and raises OccupancyBarrierTimeout, which instant_nsr.run_cuda
+#       answers with the chain of operators (the same pixels).
+OCCUPANCY_VERIFY = os.environ.get("AC_OCC_VERIFY", "1") != "0"
+_OCC_FAILURES = {"dropped": 0, "fallbacks": 0}        # sticky words of scratch buffers that were dropped or replaced | launches answered by the fallback
+
+
+class OccupancyBarrierTimeout(RuntimeError):
+    """a grid barrier of a phased occupancy launch timed out (compute units held by a foreign kernel): its outputs are partial and were NOT returned"""
+
+
+def _sticky_word(sc):
+    return int(sc[32:36].view(torch.int32).item())
+
+
+def _retire_scratch(cache, key):
+    """drop a scratch buffer, keeping its failure count in the process total (clearing or re-allocating a buffer lost its sticky word)"""
+    sc = cache.pop(key, None)
+    if sc is not None:
+        _OCC_FAILURES["dropped"] += _sticky_word(sc)
+
 
 def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bound, eps, inv_s, cos_anneal_ratio=1.0, count_samples=False, max_steps=0,
                           phased=None):
@@ -798,12 +825,16 @@ def render_rays_occupancy(field, rays_o, rays_d, density_grid, mean_density, bou
         key = (str(dev), int(L.current_stream(dev) or 0))
         sc = _OP_SCRATCH.get(key)
         if sc is None or sc.numel() < need:
+            _retire_scratch(_OP_SCRATCH, key)
             sc = _OP_SCRATCH[key] = torch.zeros(need, dtype=torch.uint8, device=dev)          # zeroed once: every launch re-arms its sync words
+            sc._ac_seen_failures = 0
         L.check(L.lib().ac_render_rays_occupancy_phased(C.byref(field.c), rays_o.data_ptr(), rays_d.data_ptr(), N, grid.data_ptr(), int(grid.shape[0]),
                                                         float(mean_density), float(bound), float(eps), inv_f, L.ptr(inv_t), float(cos_anneal_ratio),
                                                         out["weights_sum"].data_ptr(), out["depth"].data_ptr(), out["image"].data_ptr(),
                                                         out["normal_map"].data_ptr(), L.ptr(out.get("n_samples")), max(0, int(max_steps)), sc.data_ptr(),
                                                         sc.numel(), L.current_stream(dev)), "render_rays_occupancy_phased")
+        # (a launch whose grid barrier timed out is answered ON THE DEVICE: the library queues the barrier-free kernel behind the phased one, conditional on that
+        #  launch's verdict word -- no read-back here, never a partial result; occupancy_launch_failures() counts such launches)
         return out
     L.check(L.lib().ac_render_rays_occupancy(C.byref(field.c), rays_o.data_ptr(), rays_d.data_ptr(), N, grid.data_ptr(), int(grid.shape[0]), float(mean_density),
                                              float(bound), float(eps), inv_f, L.ptr(inv_t), float(cos_anneal_ratio), out["weights_sum"].data_ptr(),
@@ -853,8 +884,10 @@ def render_rays_occupancy_train(field, rays_o, rays_d, density_grid, mean_densit
     sc = _OT_SCRATCH.get(key)
     if sc is None:
         if len(_OT_SCRATCH) > 8:
-            _OT_SCRATCH.clear()
+            for k in list(_OT_SCRATCH):
+                _retire_scratch(_OT_SCRATCH, k)
         sc = _OT_SCRATCH[key] = torch.zeros(need, dtype=torch.uint8, device=dev)      # zeroed once: every launch re-arms it
+        sc._ac_seen_failures = 0
     inv_f, inv_t = _inv_s_arg(inv_s)
     L.check(L.lib().ac_render_rays_occupancy_train(C.byref(field.c), rays_o.data_ptr(), rays_d.data_ptr(), N, grid.data_ptr(), int(grid.shape[0]),
                                                    float(mean_density), float(bound), float(eps), inv_f, L.ptr(inv_t), float(cos_anneal_ratio),
@@ -862,16 +895,34 @@ def render_rays_occupancy_train(field, rays_o, rays_d, density_grid, mean_densit
                                                    out["weights_sum"].data_ptr(), out["image"].data_ptr(), out["normal_map"].data_ptr(),
                                                    out["gradient_error"].data_ptr(), sc.data_ptr(), sc.numel(), L.current_stream(dev)),
             "render_rays_occupancy_train")
+    if OCCUPANCY_VERIFY and N > 0 and _sticky_word(sc) != getattr(sc, "_ac_seen_failures", 0):
+        _retire_scratch(_OT_SCRATCH, key)                 # (phases after the failed barrier were skipped: the buffer is not re-armed)
+        _OCC_FAILURES["fallbacks"] += 1
+        raise OccupancyBarrierTimeout("render_rays_occupancy_train: a grid barrier timed out (compute units held by a foreign kernel); no outputs were returned -- "
+                                      "render through the operators (instant_nsr.run_cuda does)")
     return out
 
 
 def occupancy_launch_failures():
-    """launches of the phased occupancy kernels (inference and training form) whose grid barrier timed out, over every scratch buffer this process holds
-    (word 8 of a buffer: sticky).  0 on a healthy run; such a launch leaves NaN in gradient_error / weights_sum[0].  Synchronises."""
-    n = 0
+    """launches of the phased occupancy kernels (inference and training form) whose grid barrier timed out, over the life of this process: the sticky word 8
+    of every scratch buffer held now + the words of the buffers dropped or replaced since (kept in _OCC_FAILURES).  0 on a healthy run.  With
+    OCCUPANCY_VERIFY (default) every one of them was answered by the barrier-free path and no partial result left the wrappers; without it such a launch leaves
+    NaN in gradient_error / weights_sum[0].  Synchronises."""
+    n = _OCC_FAILURES["dropped"]
     for sc in list(_OT_SCRATCH.values()) + list(_OP_SCRATCH.values()):
-        n += int(sc[32:36].view(torch.int32).item())
+        n += _sticky_word(sc)
     return n
+
+
+def occupancy_fallbacks():
+    """phased launches whose outputs were withheld and rendered again / raised (OCCUPANCY_VERIFY)"""
+    return _OCC_FAILURES["fallbacks"]
+
+
+def debug_hold_cus(blocks, lds_bytes, millis, stream=None):
+    """test utility: ac_debug_hold_cus on `stream` (a torch.cuda.Stream; default: the current one)"""
+    st = stream.cuda_stream if stream is not None else L.current_stream(None)
+    L.check(L.lib().ac_debug_hold_cus(int(blocks), int(lds_bytes), int(millis), st), "debug_hold_cus")
 
 
 def field_sdf(field, x, bound):

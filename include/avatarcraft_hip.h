@@ -42,11 +42,15 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 7 (round 5, second half: ac_render_rays_occupancy_phased, ac_render_rays_occupancy_train, ac_march_rays_train_scratch -- the
+int ac_version(void);                /* ABI version, currently 8 (round 6: ac_debug_hold_cus; the phased occupancy launches are cooperative launches sized by the runtime's
+                                      * occupancy figure; 7, round 5, second half: ac_render_rays_occupancy_phased, ac_render_rays_occupancy_train, ac_march_rays_train_scratch -- the
                                       * marcher's scratch grew --; 6, round 5: ac_render_rays_occupancy's max_steps, ac_field_sdf_grid, ac_marching_cubes*,
                                       * ac_density_grid_update, the SH colour input of ac_field; round 4 = 5: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
                                       * ac_field_samples, ac_render_rays_occupancy, the measurement / liveness accessors, the *_typed encoder entries) */
 const char *ac_last_error(void);     /* message of the last failing call on this thread */
+/* test utility: `blocks` workgroups of 1024 threads + lds_bytes of LDS each spin for `millis` ms of wall clock on `stream` -- a FOREIGN workload that holds
+ * compute units (no memory traffic), for the liveness tests of the kernels that wait for each other (tests/test_gpu_run_cuda.py, tests/test_gpu_render.py) */
+int ac_debug_hold_cus(uint32_t blocks, uint32_t lds_bytes, uint32_t millis, ac_stream_t stream);
 
 /* ---- hash-grid encoder -------------------------------------------------------------------
  * replaces hash_encode_forward (encoder/hashencoder/src/hashencoder.cu:413-436)
@@ -388,9 +392,17 @@ int ac_render_rays_occupancy(const ac_field *field, const float *rays_o, const f
  * quarter of a wave's lanes walking and every wave evaluating its own tiles one after the other.  n_step = 16 samples per ray and round (AC_OCC_NLOG = 1 .. 6
  * overrides its log2); results do not depend on it.  scratch: ac_render_rays_occupancy_phased_scratch(N) bytes (64 B per ray and round sample: 67 MB for a
  * 256 x 256 view), ZERO-FILLED by the caller before its first use, re-armed by every call, one buffer per stream; a call with fewer rays may reuse it.
- * A launch needs every workgroup resident (one per compute unit at most): if a grid barrier is not met within two seconds (the device shared with a kernel
- * that holds compute units that long) the launch gives up, leaves NaN in weights_sum[0] and counts itself in the scratch's 32-bit word 8 (sticky). */
+ * A launch needs every workgroup resident: the grid is min(what the rays want, hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units) and goes
+ * through hipLaunchCooperativeKernel where the device supports it (AC_COOP_LAUNCH=0: a plain launch of the same grid) -- a grid that cannot be co-resident is
+ * refused AT LAUNCH (AC_ERR_LAUNCH).  What remains: a foreign kernel holding compute units for longer than a barrier's bounded spin (two seconds;
+ * ac_set_occupancy_barrier_ms / AC_OCC_BARRIER_MS override) -- then the phased kernel gives up, counts itself in the scratch's 32-bit word 8 (sticky) and sets
+ * the launch's verdict word 9; the call has ALREADY queued the barrier-free kernel of ac_render_rays_occupancy behind it, conditional on that word: it
+ * renders every ray again (the same bits) -- a few microseconds when not needed, no host round trip, and the outputs are complete whenever the stream
+ * reaches the caller's next operation.  The reference's loop (raymarching/raymarching.py:136-188) never returns partial results either. */
 size_t ac_render_rays_occupancy_phased_scratch(uint32_t N);
+/* bound of a grid barrier's spin in the phased launches (inference and training form), milliseconds; 0 = back to the default (2000, or AC_OCC_BARRIER_MS).
+ * Returns the value in force before the call.  Process-wide. */
+uint32_t ac_set_occupancy_barrier_ms(uint32_t ms);
 int ac_render_rays_occupancy_phased(const ac_field *field, const float *rays_o, const float *rays_d, uint32_t N, const float *grid, uint32_t H,
                                     float mean_density, float bound, float eps, float inv_s, const float *inv_s_dev, float cos_anneal_ratio,
                                     float *weights_sum, float *depth, float *image, float *normal_map, uint32_t *n_samples, uint32_t max_steps,

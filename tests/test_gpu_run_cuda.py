@@ -342,3 +342,94 @@ def test_harness_hands_an_eval_occupancy_net_the_whole_view(env):
     assert torch.equal(rgb1, one) and torch.equal(ex1["weight_sum"], torch.cat([p["weight_sum"] for p in parts]))
     assert float((rgb1 - rgb2).abs().max()) <= 2e-5                  # (the loop of rounds: equal up to the one-ulp restarts documented above)
     assert float(ex1["weight_sum"].max()) > 0.9
+
+
+# ---- residency of the phased launches: never a partial result ------------------------------------------------
+def _hold_half_the_device(ms):
+    """a foreign workload on a stream of its own that HOLDS half of the compute units for `ms` milliseconds: one 1024-thread workgroup with 100 KB of LDS per
+    unit -- no phased workgroup (145 KB of LDS) fits beside it"""
+    from avatarcraft_amd import nsr_ops
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    side = torch.cuda.Stream()
+    nsr_ops.debug_hold_cus(cus // 2, 100 * 1024, ms, side)
+    return side
+
+
+def test_phased_inference_beside_a_kernel_that_holds_half_the_device(env):
+    """The phased inference launch next to a foreign kernel that holds half of the compute units for 1.5 s, with the barriers' spin bounded to 0.2 s: the
+    launch's workgroups cannot all be resident, a barrier times out -- and render_rays_occupancy must return the pixels of the barrier-free kernel bit for bit
+    (the library queues that kernel behind the phased one, conditional on the launch's verdict word), never the partial ones (NaN in weights_sum[0], stale rays elsewhere).  Then, with the default
+    bound (2 s > the hold): the launch simply waits for the units and succeeds.  The reference's loop (raymarching.py:136-188) cannot return partial results."""
+    from avatarcraft_amd import nsr_ops, _lib as L
+    net = env["net"].eval()
+    ro, rd = make_rays(64, 64, dist=1.8, f=48.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    args = (net._field(), t(ro), t(rd), net.density_grid, net.mean_density, 1.6, 0.005, env["inv_s"], 0.7)
+    ref = nsr_ops.render_rays_occupancy(*args, phased=False)
+    nsr_ops.render_rays_occupancy(*args, phased=True)                 # (scratch allocated, library warm)
+    torch.cuda.synchronize()
+    f0, b0 = nsr_ops.occupancy_launch_failures(), nsr_ops.occupancy_fallbacks()
+    main = torch.cuda.Stream()
+    prev = L.lib().ac_set_occupancy_barrier_ms(200)
+    try:
+        side = _hold_half_the_device(1500)
+        with torch.cuda.stream(main):
+            out = nsr_ops.render_rays_occupancy(*args, phased=True)
+        torch.cuda.synchronize()
+    finally:
+        L.lib().ac_set_occupancy_barrier_ms(0 if prev == 2000 else prev)
+    for k in ("weights_sum", "depth", "image", "normal_map"):
+        assert bool(torch.isfinite(out[k]).all()), k
+        assert torch.equal(out[k], ref[k]), k
+    timed_out = nsr_ops.occupancy_launch_failures() - f0                    # (answered on the device: the conditional barrier-free launch queued behind it)
+    assert nsr_ops.occupancy_fallbacks() == b0                              # the inference form needs no host-side answer
+    # (whether the barrier timed out depends on the dispatcher: if the foreign kernel's workgroups had not started yet the launch may have won the units;
+    #  both outcomes are correct -- what must never happen is a partial result)
+    # default bound: the launch outlasts the hold
+    side = _hold_half_the_device(300)
+    with torch.cuda.stream(main):
+        out2 = nsr_ops.render_rays_occupancy(*args, phased=True)
+    torch.cuda.synchronize()
+    for k in ("weights_sum", "depth", "image", "normal_map"):
+        assert torch.equal(out2[k], ref[k]), k
+    print(f"phased inference beside a half-device hold: barriers timed out in {timed_out} launch(es), answered by the barrier-free kernel")
+
+
+def test_training_form_beside_a_kernel_that_holds_half_the_device(env):
+    """the same for run_cuda's one-launch training form under no_grad: on a timed-out barrier the wrapper raises OccupancyBarrierTimeout, run_cuda renders
+    through the chain of operators -- the same pixels bit for bit as an undisturbed one-launch render, the step counter too"""
+    from avatarcraft_amd import nsr_ops, _lib as L
+    net = env["net"].train()
+    ro, rd = make_rays(64, 64, dist=1.8, f=48.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    kw = dict(num_steps=64, bound=1.6, upsample_steps=64, bg_color=torch.tensor([[0.2, 0.7, 0.4]], device=DEV), cos_anneal_ratio=0.7, normal_epsilon_ratio=0.0, perturb=True)
+    net.mean_count, net.local_step = 0, 0
+    with torch.no_grad():
+        net.render(t(ro)[None], t(rd)[None], **kw)
+    net.mean_count = int(net.step_counter[0, 0].item())
+    assert net.mean_count > 0
+    try:
+        net.local_step = 3
+        with torch.no_grad():
+            ref = net.render(t(ro)[None], t(rd)[None], **kw)
+        ref_counter = net.step_counter[3].cpu().numpy().tolist()
+        torch.cuda.synchronize()
+        b0 = nsr_ops.occupancy_fallbacks()
+        main = torch.cuda.Stream()
+        prev = L.lib().ac_set_occupancy_barrier_ms(200)
+        try:
+            side = _hold_half_the_device(1500)
+            net.local_step = 5
+            with torch.cuda.stream(main), torch.no_grad():
+                out = net.render(t(ro)[None], t(rd)[None], **kw)
+            torch.cuda.synchronize()
+        finally:
+            L.lib().ac_set_occupancy_barrier_ms(0 if prev == 2000 else prev)
+        for k in ("weight_sum", "rgb", "normal"):
+            assert bool(torch.isfinite(out[k]).all()), k
+            assert torch.equal(out[k], ref[k]), k
+        assert np.isfinite(float(out["gradient_error"]))
+        assert net.step_counter[5].cpu().numpy().tolist() == ref_counter
+        print(f"training form beside a half-device hold: {nsr_ops.occupancy_fallbacks() - b0} launch(es) answered by the chain of operators")
+    finally:
+        net.mean_count = 0
