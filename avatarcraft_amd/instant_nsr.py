@@ -113,6 +113,14 @@ class NeRFRenderer(nn.Module):
     nan_guard = True
 
     def _guard_finite(self, gerr):
+        # a data-parallel step is collecting (stylize._collective_verdict): the flag is NOT judged on this rank -- neither now nor by a later render's
+        # non-waiting poll (a rank whose patch k produced NaN raised inside patch k + 1's render, before the gradient collective, and the
+        # healthy ranks hung in the all-reduce) -- it is folded into the guard word of the step's collective, whose verdict every rank sees
+        defer = self.__dict__.get("_nan_deferred")
+        if defer is not None:
+            if self.nan_guard and isinstance(gerr, torch.Tensor):
+                defer.append(gerr.detach().reshape(-1)[:1].float())
+            return
         if not self.nan_guard or not isinstance(gerr, torch.Tensor) or not gerr.is_cuda:
             if self.nan_guard and isinstance(gerr, torch.Tensor) and not bool(torch.isfinite(gerr).all()):
                 raise FloatingPointError("NaN / Inf in the finite-difference normals of a training render (reference: instant_nsr.py:274)")
@@ -178,7 +186,9 @@ class NeRFRenderer(nn.Module):
     _manual_backward = False
 
     def manual_backward_supported(self):
-        return self.fused_training == "core" and self._fused_supported() and self.encoder.embeddings.is_cuda
+        # (not for cuda_ray nets: their render() is run_cuda's occupancy march -- the fixed-step pair / whole-view launches and backward_last() would render
+        #  different samples than render_instantnsr_naive does for the same net; ADVICE round 5.  They train through run_cuda under autograd.)
+        return self.fused_training == "core" and self._fused_supported() and self.encoder.embeddings.is_cuda and not getattr(self, "cuda_ray", False)
 
     def render_step_pair(self, rays_o, rays_d, num_steps, upsample_steps, bound, bkg_fn, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0):
         """The two renders of net_style in one stylisation step (stylize.py:98-116 render_val, :143-152 the differentiable render of the same rays) as

@@ -38,23 +38,25 @@ def reconstruct_step(net, optimizer, rays_o, rays_d, rgb_gt, white_bkg=True, w_e
         # every rank draws its own ray batch: without the all-reduce the replicas would silently drift apart (stylize.sds_step refuses the same way)
         raise RuntimeError("reconstruct_step under torch.distributed (world size > 1) needs flat_grad = stylize.flat_grad_view(net.parameters()): "
                            "the gradients of the ranks are averaged through that buffer")
-    with torch.enable_grad():
-        rgb, eikonal, _ = render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=batch_size, requires_grad=True, bkg_key=WHITE_BKG if white_bkg else BLACK_BKG,
-                                                  return_torch=True, perturb=1.0, return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
-                                                  upsample_steps=upsample_steps)
-        if flat_grad is not None:
-            flat_grad.zero_()
-        else:
-            optimizer.zero_grad()
-        loss = F.smooth_l1_loss(rgb, rgb_gt, reduction='mean') + eikonal * w_eikonal
-        loss.backward()
+    from .stylize import reduce_gradients, _check_finite, _collective_verdict
+    collective = flat_grad is not None and (process_group is not None or dist_on)
     guard = None
-    if flat_grad is not None and (process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())):
-        from .stylize import reduce_gradients
-        guard = reduce_gradients(flat_grad, process_group, grad_divisor, nan_flag=eikonal.detach() if isinstance(eikonal, torch.Tensor) else None)
+    # (under a process group the render's NaN flag is not judged on this rank alone: it rides in the guard word of the collective -- stylize._collective_verdict)
+    with _collective_verdict(collective, net) as verdict:
+        with torch.enable_grad():
+            rgb, eikonal, _ = render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=batch_size, requires_grad=True, bkg_key=WHITE_BKG if white_bkg else BLACK_BKG,
+                                                      return_torch=True, perturb=1.0, return_raw=True, render_can=True, bound=NSR_BOUND, num_steps=num_steps,
+                                                      upsample_steps=upsample_steps)
+            if flat_grad is not None:
+                flat_grad.zero_()
+            else:
+                optimizer.zero_grad()
+            loss = F.smooth_l1_loss(rgb, rgb_gt, reduction='mean') + eikonal * w_eikonal
+            loss.backward()
+        if collective:
+            guard = reduce_gradients(flat_grad, process_group, grad_divisor, nan_flag=verdict.flag(extra=[eikonal] if isinstance(eikonal, torch.Tensor) else ()))
     # a NaN in this step's normals -- on ANY rank, through the guard word of the collective -- raises here on every rank (reference: the assert at
     # instant_nsr.py:274), not after Adam has consumed it
-    from .stylize import _check_finite
     _check_finite(net, guard)
     optimizer.step()
     return loss.detach()

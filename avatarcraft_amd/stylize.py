@@ -197,6 +197,15 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
     timers: a list that receives (phase name, torch.cuda.Event) marks on the current stream (bench.py's per-phase times).
     grad_divisor: the number of ranks that contribute a view to this step's all-reduce (default: the world size; smaller in the last round of an epoch
     whose view count is not a multiple of the world size, see shard_views / sds_idle_step)."""
+    dist_on = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())
+    # under a process group no render of this step judges its NaN flag on this rank alone: they all ride in the guard word of the gradient collective
+    with _collective_verdict(dist_on and flat_grad is not None, net_style, net_gt) as verdict:
+        return _sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_size, w_eikonal, use_opacity, bkg_key, flat_grad, process_group,
+                         num_steps, upsample_steps, timers, overlap_allreduce, grad_divisor, verdict)
+
+
+def _sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_size, w_eikonal, use_opacity, bkg_key, flat_grad, process_group, num_steps,
+              upsample_steps, timers, overlap_allreduce, grad_divisor, verdict):
     h, w = hw
     n_rays = h * w
 
@@ -344,9 +353,7 @@ def sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_s
             if torch.distributed.get_world_size(process_group) > 1:
                 raise RuntimeError("data-parallel sds_step needs flat_grad = flat_grad_view(net_style.parameters())")
         else:
-            flag = None
-            if nan_flags:
-                flag = nan_flags[0] if len(nan_flags) == 1 else torch.stack([t.detach().reshape(()) for t in nan_flags]).sum()
+            flag = verdict.flag(extra=nan_flags)                # every NaN flag of this step's renders (both nets, grad and no-grad) + the patches' eikonal terms
             guard = reduce_gradients(flat_grad, process_group, grad_divisor, nan_flag=flag, early=(work_hi, hi_range) if work_hi is not None else None)
             mark("grad_allreduce")
     # (D) -- a NaN recorded by this step's renders ON ANY RANK raises here on EVERY rank, before Adam's state and the weights are touched
@@ -525,16 +532,53 @@ def reduce_gradients(flat_grad, process_group=None, divisor=None, nan_flag=None,
     return _Guard(buf[n:]) if buf.numel() == n + 1 else None
 
 
+class _collective_verdict:
+    """While a data-parallel step runs, the NaN flags of EVERY render of the given nets (training renders, the no-grad render_val of a cuda_ray net, ...)
+    are collected instead of judged per rank (NeRFRenderer._guard_finite): `flag()` folds them into one device scalar for the guard word of the step's
+    gradient collective, so that all ranks raise or all ranks step.  Outside a process group the nets keep their own event-based guard."""
+
+    def __init__(self, active, *nets):
+        self.nets = [n for n in nets if active and hasattr(n, "_guard_finite")]
+
+    def __enter__(self):
+        for n in self.nets:
+            n.__dict__["_nan_deferred"] = []
+        return self
+
+    def __exit__(self, *exc):
+        for n in self.nets:
+            n.__dict__.pop("_nan_deferred", None)
+        return False
+
+    def flag(self, extra=()):
+        """sum of every collected flag (+ extra device scalars): non-finite iff one of them is; None if there is none"""
+        parts = [t.reshape(-1)[:1].float() for n in self.nets for t in n.__dict__.get("_nan_deferred", ())]
+        dev = parts[0].device if parts else None
+        for t in extra:
+            if isinstance(t, torch.Tensor):
+                t = t.detach().reshape(-1)[:1].float()
+                if dev is None:
+                    dev = t.device
+                parts.append(t.to(dev))
+        if not parts:
+            return None
+        return parts[0] if len(parts) == 1 else torch.cat(parts).sum()
+
+
 def _check_finite(net, guard=None):
     """the reference asserts on a NaN gradient_error before its backward (instant_nsr.py:274); the fused path records a device flag instead, and it is
     resolved HERE -- before the optimizer step consumes the gradients -- at the cost of one 4-byte event wait.  Under a process group the verdict is the
     guard word of the gradient collective (reduce_gradients): the same on every rank."""
-    if guard is not None and not guard.finite():
+    if guard is not None:
+        # the collective's verdict is the ONLY one under a process group: a rank-local check behind a finite guard could still raise on one rank alone
+        # (a flag that never reached the guard word) and leave the others in the next collective (ADVICE round 5)
         pend = getattr(net, "__dict__", {}).get("_nan_pending")
         if pend:
             pend.clear()                                     # (this step's local flags are resolved by the collective verdict)
-        raise FloatingPointError("NaN / Inf in the finite-difference normals of a training render on at least one rank (reference: instant_nsr.py:274); "
-                                 "no rank has stepped")
+        if not guard.finite():
+            raise FloatingPointError("NaN / Inf in the finite-difference normals of a training render on at least one rank (reference: instant_nsr.py:274); "
+                                     "no rank has stepped")
+        return
     chk = getattr(net, "check_finite", None)
     if chk is not None:
         chk()

@@ -269,3 +269,86 @@ def test_nan_on_one_rank_stops_every_rank_gloo():
     assert raised0 and raised1 and not stepped0 and not stepped1
     for a, b in zip(p0, p1):
         assert np.array_equal(a, b) and np.isfinite(a).all()
+
+
+class _GuardedNaNField(TinyField):
+    """a field that guards its renders the way NeRFRenderer does (instant_nsr.py: _guard_finite behind every render, the no-grad ones included) and
+    poisons the FIRST patch of a view only: without the collective verdict the guard of that patch raises on this rank alone -- on a CPU tensor at once, on the
+    device in the next patch's non-waiting poll -- before the gradient collective, and the healthy ranks hang in the all-reduce"""
+    from avatarcraft_amd.instant_nsr import NeRFRenderer as _R
+    nan_guard = True
+    _guard_finite = _R._guard_finite
+    _poll_finite = _R._poll_finite
+    check_finite = _R.check_finite
+    poison = False
+    poison_nograd = False
+    calls = 0
+
+    def render(self, *a, **kw):
+        out = super().render(*a, **kw)
+        grad = torch.is_grad_enabled()
+        if grad:
+            self.calls += 1
+        if (self.poison and grad and self.calls == 1) or (self.poison_nograd and not grad):
+            out["gradient_error"] = out["gradient_error"] * float("nan")
+        self._guard_finite(out["gradient_error"])
+        return out
+
+
+def _guarded_nan_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from avatarcraft_amd.stylize import sds_step, flat_grad_view
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net, net_gt = _GuardedNaNField().train(), TinyField().eval()
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    flat = flat_grad_view(net.parameters())
+    g = torch.Generator().manual_seed(rank)
+    ro = torch.randn(128, 3, generator=g); rd = torch.nn.functional.normalize(torch.randn(128, 3, generator=g), dim=-1)
+    guidance = lambda img: torch.zeros_like(img)
+    step = lambda: sds_step(net, net_gt, ro, rd, (8, 16), opt, guidance, batch_size=32, flat_grad=flat)      # a view of FOUR patches
+    step()
+    out = []
+    for mode in ("patch0", "nograd"):
+        before = [p.detach().clone() for p in net.parameters()]
+        net.calls = 0
+        net.poison, net.poison_nograd = (rank == 1 and mode == "patch0"), (rank == 1 and mode == "nograd")
+        raised = False
+        try:
+            step()
+        except FloatingPointError:
+            raised = True
+        stepped = any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+        out.append((raised, stepped))
+        net.poison = net.poison_nograd = False
+        net.calls = 0
+        step()                                             # the group is still usable, no rank was left behind in a collective
+    # outside a step the net's own guard is back in force (nothing stays deferred)
+    assert "_nan_deferred" not in net.__dict__
+    q.put((rank, out, [p.detach().numpy().copy() for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_nan_in_one_patch_or_in_a_nograd_render_on_one_rank_is_a_collective_verdict_gloo():
+    """(a) NaN in patch 0 of a four-patch view on rank 1 only; (b) NaN in the no-grad render_val on rank 1 only.  With per-rank guards rank 1
+    raises before the gradient collective and rank 0 hangs in it (this test then times out); with the collective verdict both ranks raise after the
+    collective, none steps, and the replicas stay bit-identical through the healthy steps that follow"""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guarded_nan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    (_, out0, p0), (_, out1, p1) = res
+    assert out0 == out1 == [(True, False), (True, False)], (out0, out1)
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b) and np.isfinite(a).all()

@@ -422,3 +422,50 @@ def test_fine_view_whole_view_renders_equal_patch_by_patch(bkg):
         rgb_h, _, ex = render_instantnsr_naive(net, ro_t, rd_t, rays_per_batch=512, requires_grad=False, bkg_key=WHITE_BKG, render_can=True, perturb=True,
                                                return_raw=True, num_steps=64, upsample_steps=64, bound=NSR_BOUND)
     assert torch.equal(rgb_v, rgb_h) and torch.equal(ws_v, ex["weight_sum"])
+
+
+def test_a_cuda_ray_style_net_trains_through_its_own_render():
+    """a cuda_ray style net's render() is run_cuda's occupancy march; the fixed-step fused launches (pair, whole-view render_val,
+    backward_last) would render DIFFERENT samples for it.  manual_backward_supported() is False for such a net, so sds_step takes the harness path
+    (render_instantnsr_naive -> net.render -> run_cuda, autograd): render_val in one step == what render_instantnsr_naive gives for the same net and
+    draws, and a step moves the parameters and keeps them finite."""
+    from avatarcraft_amd.instant_nsr import NeRFNetwork
+    from avatarcraft_amd.render_utils import render_instantnsr_naive, WHITE_BKG
+    from avatarcraft_amd.stylize import sds_step, flat_grad_view, SyntheticGuidance
+    from avatarcraft_amd.synthetic import make_rays
+    src, _ = golden_net(train=True)
+    net = NeRFNetwork(cuda_ray=True)
+    net.load_state_dict(src.state_dict(), strict=False)
+    net = net.to(DEV).train()
+    assert not net.manual_backward_supported() and src.manual_backward_supported()
+    net.update_extra_state(1.6)
+    net_gt, _ = golden_net(train=False)
+    ro, rd = make_rays(32, 32, dist=1.8, f=25.0)
+    ro, rd = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    seen = {}
+
+    class Guide(SyntheticGuidance):
+        def __call__(self, rgb, text=None):
+            seen["img"] = rgb.detach().clone()
+            return super().__call__(rgb, text)
+
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    ls = net.local_step
+    torch.manual_seed(3)
+    sds_step(net, net_gt, ro, rd, (32, 32), opt, Guide(11), batch_size=4096, flat_grad=None)
+    net.check_finite()
+    after = dict(net.named_parameters())
+    assert all(bool(torch.isfinite(v).all()) for v in after.values())
+    assert any(not torch.equal(before[k], after[k].detach()) for k in before)
+    # render_val of that step == the harness on the same net state and draws (parameters restored, RNG re-seeded, step counter rewound)
+    with torch.no_grad():
+        for k, v in net.named_parameters():
+            v.copy_(before[k])
+    net.invalidate_caches()
+    net.local_step = ls
+    torch.manual_seed(3)
+    rgb_val, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=4096, requires_grad=False, bkg_key=WHITE_BKG, render_can=True, perturb=True,
+                                         num_steps=64, upsample_steps=64, bound=1.6)
+    img = rgb_val.reshape(32, 32, 3).permute(2, 0, 1).unsqueeze(0)
+    assert torch.equal(img, seen["img"])
