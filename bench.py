@@ -88,6 +88,39 @@ SDS_BYTES_LAUNCHED = {
 SDS_BYTES_SURVEY = 3 * RAYS_PER_BATCH * BYTES_PER_RAY + (7 + 6 + 7) * RAYS_PER_BATCH * SAMPLES * 2048
 
 
+def _binding(kernel):
+    """busy fractions of a kernel from the committed PMC pass (profiles/traffic.json `binding`, tools/collect_profiles.py) or None"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        b = (tj.get("binding") or {}).get(kernel)
+        return (b, tj.get("binding_source") or tj.get("profile")) if b else (None, None)
+    except Exception:
+        return None, None
+
+
+def _grid_roofline(kernel, evals, ms):
+    """roofline object of the regular-grid SDF kernels (mesh export, density grid).  Their x-tiles make several lanes of a gather share one 64-byte
+    sector (the spatial hash is linear in x), so the REQUEST bytes of SURVEY 8(d) -- 1024 B per query -- are not what moves: `frac` is taken against the
+    sector bytes the L1s actually asked of L2 (TCP_TCC_READ_REQ x 64 B per query, committed PMC pass), which cannot exceed the peak; the request-byte rate
+    stays in the object as `request_gbs` / `request_rate_vs_hbm_peak` (it can exceed 1 and did: 1.09), and `issue` names what binds the kernel."""
+    b, src = _binding(kernel)
+    req = evals * 1024 / 1e9
+    out = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s", "request_bytes": evals * 1024, "request_gbs": req / (ms * 1e-3),
+           "request_rate_vs_hbm_peak": req / (ms * 1e-3) / HBM_PEAK_GBS, "request_floor_ms_at_peak": req / HBM_PEAK_GBS * 1e3}
+    if b and b.get("l2_sector_bytes_per_launch"):
+        sec = b["l2_sector_bytes_per_launch"] / 1e9
+        out.update(algorithmic_bytes=int(b["l2_sector_bytes_per_launch"]), achieved=sec / (ms * 1e-3), frac=sec / (ms * 1e-3) / HBM_PEAK_GBS,
+                   bytes_basis="64-byte sectors requested of L2 per launch (TCP_TCC_READ_REQ x 64 B, " + str(src) + "); timed live")
+    else:
+        out.update(algorithmic_bytes=evals * 1024, achieved=req / (ms * 1e-3), frac=min(1.0, req / (ms * 1e-3) / HBM_PEAK_GBS),
+                   bytes_basis="request bytes (no committed sector counter for this kernel): capped at 1")
+    if b and "issue" in b:
+        out["issue"] = dict(b["issue"], source=src)
+    if b and "gather" in b:
+        out["gather"] = dict(b["gather"], source=src)
+    return out
+
+
 def make_net(p, table, dev, train, cuda_ray=False):
     from avatarcraft_amd.instant_nsr import NeRFNetwork
     torch.manual_seed(0)
@@ -477,13 +510,7 @@ def time_geometry(dev, p, table, reps=3):
         out["mesh_export_512"] = {
             "ms": sdf_ms + mc_ms, "sdf_grid_ms": sdf_ms, "marching_cubes_ms": mc_ms, "mesh_to_host_ms": t_copy, "extract_geometry_call_ms": t_e2e,
             "field_evaluations": evals, "vertices": int(v.shape[0]), "triangles": int(t.shape[0]),
-            "roofline": {"bound": "hbm", "kernel": "field_sdf_grid_kernel", "algorithmic_bytes": evals * 1024, "achieved": gb / (sdf_ms * 1e-3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / (sdf_ms * 1e-3) / HBM_PEAK_GBS,
-                         "floor_ms_at_peak": gb / HBM_PEAK_GBS * 1e3,
-                         "note": "bytes = gather REQUESTS (SURVEY 8d: 1024 B per forward_sdf query).  A fraction above 1 is possible and means what it says: tiles of 16 "
-                                 "grid points along x -- the axis the spatial hash is linear in -- find several lanes' entries in one 64-byte sector, so fewer bytes move than "
-                                 "are requested (FETCH_SIZE 36.2 GB per 512^3 = 0.26 of the requests, profiles/r05_pmc_summary.json).  What bounds the kernel now is instruction "
-                                 "issue: 5.22 G VALU x 4 + 0.436 G MFMA x 32 clocks over 1024 SIMDs = 16.2 ms of pipe time (profiles/r05_experiments.txt section 2)"},
+            "roofline": _grid_roofline("field_sdf_grid_kernel", evals, sdf_ms),
             "note": "reference: extract_geometry(NSR_BOUND, 512) of stylize.py:267 (512^3 forward_sdf queries in 256^3 blocks assembled on the host + PyMCubes "
                     "on the CPU); here one ac_field_sdf_grid launch + ac_marching_cubes_count / _emit (classify, scan, emit; one 8-byte read-back between "
                     "them), the volume never leaves the device; marching_cubes_ms includes that read-back and the allocation of the scratch"}
@@ -504,9 +531,7 @@ def time_geometry(dev, p, table, reps=3):
         halo_evals = 137 * 145 * 145               # 129^3 grid points + the +1 halo of every 16 x 8 x 8 brick that lies inside the grid
         out["density_grid_update"] = {
             "ms": k_ms, "update_extra_state_call_ms": t_call, "torch_chain_call_ms": t_torch, "grid": [129] * 3, "field_evaluations": halo_evals,
-            "roofline": {"bound": "hbm", "kernel": "density_grid_kernel", "algorithmic_bytes": 129 ** 3 * 1024,
-                         "achieved": 129 ** 3 * 1024 / 1e9 / (k_ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": 129 ** 3 * 1024 / 1e9 / (k_ms * 1e-3) / HBM_PEAK_GBS},
+            "roofline": _grid_roofline("density_grid_kernel", 129 ** 3, k_ms),
             "note": "one launch: SDF -> logistic density -> 2^3 max pool -> max(grid * decay, new) in place -> mean; update_extra_state_call_ms = the whole "
                     "method with its one read-back of (mean, step counts); torch_chain_call_ms = the reference-shaped torch formulation on the same fused SDF "
                     "query (round 4's path)"}
@@ -968,7 +993,7 @@ def main():
     if rank == 0:
         total_rays = world * a.steps * RAYS_PER_BATCH
         achieved = BYTES_PER_RAY * RAYS_PER_BATCH / (kern_ms * 1e-3) / 1e9
-        traffic = mfma_busy = mfma_src = traffic_note = None
+        traffic = mfma_busy = mfma_src = traffic_note = binding = binding_src = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
@@ -977,6 +1002,8 @@ def main():
                 mfma_busy = (tj.get("render_rays_kernel_mfma_busy_frac") or {}).get(a.precision)
                 mfma_src = f"profiles/traffic.json (commit {tj.get('commit')}, {tj.get('command')})"
                 traffic_note = tj.get("fetch_size_note")
+                binding = (tj.get("binding") or {}).get("render_rays_kernel (main bench, 4096 rays)")
+                binding_src = tj.get("binding_source") or tj.get("profile")
             except Exception:
                 traffic = None
         res = {
@@ -1006,6 +1033,12 @@ def main():
                          # the committed PMC pass of this workload: profiles/traffic.json)
                          "algorithmic_tflops": FLOP_PER_RAY * RAYS_PER_BATCH / (kern_ms * 1e-3) / 1e12, "fp32_peak_tflops": 157.3,
                          "mfma_busy_frac": mfma_busy, "mfma_busy_frac_source": mfma_src,
+                         # the BINDING resources, counter-derived: `frac` above is a request-byte fraction -- the table lives in L2 / MALL,
+                         # HBM itself is at ~0.2 of peak -- what the kernel runs out of is instruction issue and the per-CU gather path; busy fractions of the
+                         # committed PMC pass of this workload (tools/collect_profiles.py: busy_objects), not re-measured in this run
+                         "issue": (dict(binding["issue"], source=binding_src) if binding and "issue" in binding else None),
+                         "gather": (dict(binding["gather"], l2_sector_bytes_per_launch=binding.get("l2_sector_bytes_per_launch"), source=binding_src)
+                                    if binding and "gather" in binding else None),
                          "other_precision": {"precision": other, "kernel_ms": other_ms, "rays_per_s_per_gpu": RAYS_PER_BATCH / (other_ms * 1e-3),
                                              "frac": BYTES_PER_RAY * RAYS_PER_BATCH / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "whole_view_in_one_launch": {"rays": H * W, "kernel_ms": view_ms, "rays_per_s_per_gpu": H * W / (view_ms * 1e-3),

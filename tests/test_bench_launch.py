@@ -105,3 +105,34 @@ def test_bench_gpus_2_self_launched_over_gloo_on_one_gpu():
     solo = rec["same_job_solo"]
     assert solo["rays_per_s"] > 0 and 0 < solo["value_over_n_times_solo"] < 1.5 and solo["sds_ms_per_step"] > 0
     assert sds["allreduce_busbw_gbs"] > 0 and sds["allreduce_busbw_peak_gbs"] == pytest.approx(7 * 153.0) and sds["solo_over_n_rank_step_time"] > 0
+
+
+def _fracs(o, path=""):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            if k == "frac" and isinstance(v, (int, float)):
+                yield path, v
+            else:
+                yield from _fracs(v, f"{path}.{k}")
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            yield from _fracs(v, f"{path}[{i}]")
+
+
+@pytest.mark.gpu
+def test_bench_line_names_its_binding_resources_and_no_frac_exceeds_one():
+    """the driver's line carries roofline.issue (VALU + fp32-MFMA issue busy fraction) and roofline.gather (per-CU texture-address
+    path) from the committed counter pass, the regular-grid kernels' fraction is taken against the 64-byte sectors actually requested of L2, and no `frac`
+    anywhere in the record exceeds 1"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--repeat", "1", "--sds-steps", "1", "--posed-frames", "0",
+                        "--no-cpu-baseline", "--no-occupancy", "--no-viewdirs", "--no-fine-view", "--sd-arch-steps", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    roof = rec["roofline"]
+    assert roof["issue"]["bound"] == "valu+mfma issue" and 0 < roof["issue"]["busy_frac"] and roof["issue"]["valu_insts_per_launch"] > 1e8
+    assert roof["gather"]["bound"].startswith("L1 gather") and 0 < roof["gather"]["busy_frac"] <= 1
+    over = [(p, v) for p, v in _fracs(rec) if v > 1.0]
+    assert not over, over
+    m = rec["mesh_export_512"]["roofline"]
+    assert m["frac"] <= 1.0 and m["request_rate_vs_hbm_peak"] > 0 and "issue" in m

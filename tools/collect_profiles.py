@@ -26,6 +26,49 @@ short = lambda n: re.sub(r"\(anonymous namespace\)::|void ", "", n).split("(")[0
 
 
 WHOLE_VIEW = 4          # bench.py's informational whole-view launches of the same kernel, between the main bench and the SDS steps
+SIMDS, XCDS = 1024, 8   # MI355X: 256 CUs x 4 SIMDs in 8 XCDs (GRBM_GUI_ACTIVE is summed over the XCDs)
+
+
+def busy_objects(c):
+    """The two counter-derived resources that bind the gather kernels, from one kernel's per-launch counter means `c`:
+    issue  = (SQ_INSTS_VALU x 4 + SQ_INSTS_MFMA x 32 clocks) / (1024 SIMDs x kernel clocks): the share of the SIMDs' issue time the vector and fp32-matrix
+             instructions need (a 64-lane VALU instruction occupies its SIMD for 4 clocks, v_mfma_f32_16x16x4_f32 for 32; the few quarter-rate
+             instructions -- v_mul_lo_u32, v_rcp_f32 -- make this a lower bound);
+    gather = TA_BUSY_avr / kernel clocks: the per-CU texture-address path every table gather goes through.
+    Kernel clocks = GRBM_GUI_ACTIVE / 8 XCDs (the counter is summed over the XCDs; it reproduces the kernel time at 2.4 GHz)."""
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")
+    if any(k not in c or not c[k] for k in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
+        return None
+    clk = c["GRBM_GUI_ACTIVE"] / XCDS
+    valu, mfma = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_MFMA", 0.0)
+    out = {"issue": {"bound": "valu+mfma issue", "busy_frac": round((valu * 4 + mfma * 32) / SIMDS / clk, 4), "valu_insts_per_launch": int(valu),
+                     "mfma_insts_per_launch": int(mfma), "kernel_clocks": int(clk),
+                     "formula": "(SQ_INSTS_VALU x 4 + SQ_INSTS_MFMA x 32) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}}
+    if c.get("TA_BUSY_avr"):
+        out["gather"] = {"bound": "L1 gather (texture addresser)", "busy_frac": round(c["TA_BUSY_avr"] / clk, 4), "formula": "TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8 XCDs)"}
+    if c.get("TCP_TCC_READ_REQ_sum"):
+        out["l2_sector_bytes_per_launch"] = int(c["TCP_TCC_READ_REQ_sum"] * 64)          # what the L1s actually asked of L2: 64-byte sectors
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        out["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / clk, 4)
+    return out
+
+
+def roofline_objects(summary, byc):
+    """-> the `binding` block of traffic.json: per kernel of a bench leg, busy_objects of its counters"""
+    out = {}
+    main = {k: v.get("main bench (4096 rays)") for k, v in byc.items() if isinstance(v, dict)}
+    o = busy_objects(main)
+    if o:
+        out["render_rays_kernel (main bench, 4096 rays)"] = o
+    for name, key in (("field_sdf_grid_kernel", "field_sdf_grid_kernel"), ("density_grid_kernel", "density_grid_kernel"), ("warp_samples_accel_kernel", "warp_samples_accel_kernel"),
+                      ("sdf_stencil_bwd_kernel", "sdf_stencil_bwd_kernel"), ("hash_stencil_bwd_binned_kernel", "hash_stencil_bwd_binned_kernel"),
+                      ("bucket_accumulate_kernel", "bucket_accumulate_kernel"), ("color_bwd_kernel", "color_bwd_kernel")):
+        ks = [k for k in summary if k.startswith(key)]
+        if ks:
+            o = busy_objects(summary[ks[0]])
+            if o:
+                out[name] = o
+    return out
 
 
 def main():
@@ -111,6 +154,7 @@ def main():
                 n = n_main if prec == "exact" else len(v)
                 mfma_busy[prec] = round(mean(v[:n]) / 1024.0 / (mean(durs) * 1e-6 * 2.1e9), 4)
     traffic = {
+        "binding": roofline_objects(json.load(open(src + "/summary.json")), byc),
         "render_rays_kernel_hbm_bytes_per_launch": int(mean(main_f) * KB),
         "sds_step_hbm_bytes_per_step": int(sum(parts.values())),
         "sds_step_by_kernel": {k: int(v) for k, v in parts.items()},
@@ -137,4 +181,12 @@ def main():
     print(json.dumps({k: v for k, v in traffic.items() if k != "_note"}, indent=1))
 
 
-main()
+if tag == "--refresh-binding":
+    # python tools/collect_profiles.py --refresh-binding --round r05: rebuild traffic.json's `binding` block from the committed summaries of that round
+    tj = json.load(open(f"{dst}/traffic.json"))
+    tj["binding"] = roofline_objects(json.load(open(f"{dst}/{rnd}_pmc_summary.json")), json.load(open(f"{dst}/{rnd}_pmc_render_by_workload.json"))["per_launch_mean_by_workload"])
+    tj["binding_source"] = f"profiles/{rnd}_pmc_summary.json, profiles/{rnd}_pmc_render_by_workload.json"
+    json.dump(tj, open(f"{dst}/traffic.json", "w"), indent=1)
+    print(json.dumps(tj["binding"], indent=1))
+else:
+    main()
