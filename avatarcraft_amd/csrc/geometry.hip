@@ -6,9 +6,8 @@
 //                 Here: ac_field_sdf_grid (grid coordinates formed in the kernel from the three axis tables, the volume stays on the device) and
 //                 ac_marching_cubes_count / _emit (classify -> scan -> emit, shared-edge vertex indexing, no atomics: a deterministic mesh).
 //   density grid  NeRFRenderer.update_extra_state (:303-356): forward_sdf on the 129^3 grid -> logistic density -> zero pad + 2^3 max pool ->
-//                 maximum(grid * decay, new) -> mean.  Here ONE launch (ac_density_grid_update): a workgroup evaluates a brick of grid points plus the
-//                 one-point halo the pool needs into LDS, pools, merges into the running grid in place and leaves its partial sum; the last workgroup
-//                 to finish forms the mean.
+//                 maximum(grid * decay, new) -> mean.  Here two launches (ac_density_grid_update): the density of every grid point on the x-tiles of
+//                 ac_field_sdf_grid into a scratch volume, then one streaming pass that pools, merges into the running grid in place and forms the mean.
 //
 // The SDF itself is the renderer's own tile code (nsr_device.hpp: sdf_tile = hash gather + MFMA SDF network), so every value is bit-identical to
 // ac_field_sdf / density() and therefore to the CPU oracle's orc_field_sdf.
@@ -46,6 +45,14 @@ __device__ __forceinline__ f32x4 sdf_tile_r(const float *__restrict__ lds, const
     return sdf_mlp(lds, lane, sel4(g, px, py, pz, 0.0f), f);
 }
 
+// update_extra_state's density (:331-337): inv_s e^(-inv_s sdf) / (1 + e^(-inv_s sdf)) for sdf > 0, the mirrored form for sdf <= 0 -- the two
+// overflow-free branches, every operation in the reference's order (mul, exp, mul | add, div) in fp32
+__device__ __forceinline__ float dg_density(float sdf, float inv_s)
+{
+    const float e = expf(sdf > 0.0f ? -inv_s * sdf : inv_s * sdf);
+    return (inv_s * e) / (1.0f + e);
+}
+
 constexpr uint32_t GB_X = 16, GB_Y = 4, GB_Z = 16;           // a brick of grid points: 64 tiles of 16 points along X
 
 // BRICK = false: tiles of 16 consecutive points in the volume's linear order (z fastest), dealt to the waves round robin (round 5's first version).
@@ -58,9 +65,11 @@ constexpr uint32_t GB_X = 16, GB_Y = 4, GB_Z = 16;           // a brick of grid 
 //   Every XCD (workgroup index mod 8) walks through its own contiguous eighth of the bricks: coarse and middle levels are re-used from its L2.
 template <int ROUND, bool BRICK>
 __global__ __launch_bounds__(BLOCK) void field_sdf_grid_kernel(const RenderArgs a, const float *__restrict__ ax, const float *__restrict__ ay,
-                                                               const float *__restrict__ az, uint32_t nx, uint32_t ny, uint32_t nz, int negate,
+                                                               const float *__restrict__ az, uint32_t nx, uint32_t ny, uint32_t nz, int mode, float inv_s,
                                                                float *__restrict__ vol)
 {
+    // mode: what is stored per grid point -- 0 the sdf, 1 its negative (the mesh export's u), 2 update_extra_state's logistic density of it (dg_density)
+    auto value = [&](float sdf) { return mode == 2 ? dg_density(sdf, inv_s) : (mode == 1 ? -sdf : sdf); };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fill_lds_sdf(lds, a);
     __syncthreads();
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(BLOCK) void field_sdf_grid_kernel(const RenderArgs 
             const uint32_t b = tile * 16u + (uint32_t)n, bb = b < B ? b : B - 1u;
             const uint32_t iz = bb % nz, t = bb / nz, iy = t % ny, ix = t / ny;
             const f32x4 o = sdf_tile_r<ROUND>(lds, fc, lane, ax[ix], ay[iy], az[iz]);
-            if (b < B && g == 0) vol[b] = negate ? -o[0] : o[0];
+            if (b < B && g == 0) vol[b] = value(o[0]);
         }
     } else {
         float *stage = lds + OFF_WAVE;                                                               // [GB_X][GB_Y][GB_Z]
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(BLOCK) void field_sdf_grid_kernel(const RenderArgs 
                 if (iy >= ny || iz >= nz) continue;                                                  // (wave-uniform)
                 const uint32_t cx = ix < nx ? ix : nx - 1u;
                 const f32x4 o = sdf_tile_r<ROUND>(lds, fc, lane, ax[cx], ay[iy], az[iz]);
-                if (g == 0) stage[((uint32_t)n * GB_Y + ly) * GB_Z + lz] = negate ? -o[0] : o[0];
+                if (g == 0) stage[((uint32_t)n * GB_Y + ly) * GB_Z + lz] = value(o[0]);
             }
             __syncthreads();
             for (uint32_t o = threadIdx.x; o < GB_X * GB_Y * GB_Z; o += BLOCK) {
@@ -303,82 +312,55 @@ __global__ __launch_bounds__(256) void mc_triangles_kernel(const uint32_t *__res
 }
 
 // ---------------------------------------------------------------------------------------------------------------- density grid of the ray marcher
-constexpr int DG_BX = 16, DG_BY = 8, DG_BZ = 8;                       // outputs of a workgroup: a brick of grid points, longest along x (see field_sdf_grid_kernel: tiles along x
-                                                                      // find their table entries in few sectors)
-constexpr int DG_EX = DG_BX + 1, DG_EY = DG_BY + 1, DG_EZ = DG_BZ + 1; // + the one-point halo towards +x, +y, +z that the 2^3 max pool reads
-constexpr int DG_EVALS = DG_EX * DG_EY * DG_EZ;                        // 1377 SDF evaluations = 87 tiles of 16
-constexpr int DG_OUT = DG_BX * DG_BY * DG_BZ;                          // 1024 outputs
-constexpr int DG_LDS_FLOATS = OFF_WAVE + ((DG_EVALS + 3) / 4) * 4 + 2 * BLOCK / 64 * 2;
+// Round 6: two launches instead of one.  Round 5 gave every workgroup a brick of 16 x 8 x 8 outputs PLUS the one-point halo the 2^3 max pool reads
+// (17 x 9 x 9 = 1377 evaluations for 1024 outputs, 3.58 M for the 2.15 M points of the 129^3 grid) and cut them into tiles of 16 consecutive evaluations of
+// a 17-wide row -- tiles that straddle two rows, i.e. none of what makes field_sdf_grid_kernel fast (16 points along x = 2 .. 9 sectors per gather).
+//   1. field_sdf_grid_kernel<.., true> in mode 2: the density of every grid point ONCE, on x-tiles, into a scratch volume (8.6 MB at 129^3: L2-resident);
+//   2. density_pool_kernel: zero pad + 2^3 max pool of that volume, maximum(grid * decay, new) in place, the mean -- one short streaming pass.
+// 0.94 -> 0.3x ms per update (bench.py: density_grid_update); the same values (sdf bits, expf / divide, max).
 struct DgArgs {
-    const float *axis;        // [H] torch.linspace(-bound, bound, H)
-    uint32_t H, nbx, nby, nbz;
-    float inv_s, decay;
+    const float *dens;        // [H,H,H] the densities of pass 1
+    uint32_t H;
+    float decay;
     float *grid;              // [H,H,H] in / out
     double *partials;         // [number of workgroups]
     uint32_t *ticket;         // [1], zero between launches (the last workgroup re-arms it)
     double *mean_out;         // [1]
 };
+constexpr int DP_BLOCK = 256;
 
-// update_extra_state's density (:331-337): inv_s e^(-inv_s sdf) / (1 + e^(-inv_s sdf)) for sdf > 0, the mirrored form for sdf <= 0 -- the two
-// overflow-free branches, every operation in the reference's order (mul, exp, mul | add, div) in fp32
-__device__ __forceinline__ float dg_density(float sdf, float inv_s)
+__global__ __launch_bounds__(DP_BLOCK) void density_pool_kernel(const DgArgs g_)
 {
-    const float e = expf(sdf > 0.0f ? -inv_s * sdf : inv_s * sdf);
-    return (inv_s * e) / (1.0f + e);
-}
-
-__global__ __launch_bounds__(BLOCK) void density_grid_kernel(const RenderArgs a, const DgArgs g_)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *dens = lds + OFF_WAVE;
-    double *red = reinterpret_cast<double *>(lds + OFF_WAVE + ((DG_EVALS + 3) / 4) * 4);
-    fill_lds_sdf(lds, a);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-    const FieldCtx fc = make_ctx(a);
-    const uint32_t H = g_.H;
-    const uint32_t bz = blockIdx.x % g_.nbz, bt = blockIdx.x / g_.nbz, by = bt % g_.nby, bx = bt / g_.nby;
-    const uint32_t ox = bx * DG_BX, oy = by * DG_BY, oz = bz * DG_BZ;
-    for (int tile = wave; tile < (DG_EVALS + 15) / 16; tile += WAVES_PER_BLOCK) {
-        const int q = tile * 16 + n, qq = q < DG_EVALS ? q : DG_EVALS - 1;                   // evaluation q of the brick: x fastest
-        const uint32_t lx = (uint32_t)qq % DG_EX, lt = (uint32_t)qq / DG_EX, ly = lt % DG_EY, lz = lt / DG_EY;
-        const uint32_t gx = ox + lx, gy = oy + ly, gz = oz + lz;
-        const bool valid = q < DG_EVALS && gx < H && gy < H && gz < H;      // beyond the grid: the zero padding of F.pad (:341)
-        if (__ballot(valid) == 0ull) {                                       // (wave-uniform)
-            if (g == 0 && q < DG_EVALS) dens[q] = 0.0f;
-            continue;
-        }
-        const uint32_t cx = gx < H ? gx : H - 1u, cy = gy < H ? gy : H - 1u, cz = gz < H ? gz : H - 1u;
-        const f32x4 o = sdf_tile(lds, fc, lane, g_.axis[cx], g_.axis[cy], g_.axis[cz]);
-        if (g == 0 && q < DG_EVALS) dens[q] = valid ? dg_density(o[0], g_.inv_s) : 0.0f;
-    }
-    __syncthreads();
+    __shared__ double red[DP_BLOCK / 64];
+    __shared__ uint32_t last;
+    const uint32_t H = g_.H, N = H * H * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double part = 0.0;
-    for (int o = threadIdx.x; o < DG_OUT; o += BLOCK) {
-        const uint32_t lz = (uint32_t)o % DG_BZ, lt = (uint32_t)o / DG_BZ, ly = lt % DG_BY, lx = lt / DG_BY;      // z fastest: the grid's own order
-        const uint32_t gx = ox + lx, gy = oy + ly, gz = oz + lz;
-        if (gx >= H || gy >= H || gz >= H) continue;
-        float m = 0.0f;                                                      // (F.max_pool3d over the zero-padded tmp_grid; densities are >= 0)
+#pragma unroll 4
+    for (uint32_t p = blockIdx.x * DP_BLOCK + threadIdx.x; p < N; p += gridDim.x * DP_BLOCK) {       // z fastest: the grid's own order
+        const uint32_t gz = p % H, t = p / H, gy = t % H, gx = t / H;
+        float m = 0.0f;                                                      // (F.max_pool3d over the zero-padded tmp_grid (:341); densities are >= 0)
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx)
+        for (uint32_t dx = 0; dx < 2; ++dx)
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
+            for (uint32_t dy = 0; dy < 2; ++dy)
 #pragma unroll
-                for (int dz = 0; dz < 2; ++dz) m = fmaxf(m, dens[((lz + dz) * DG_EY + (ly + dy)) * DG_EX + (lx + dx)]);
-        const size_t idx = ((size_t)gx * H + gy) * H + gz;
-        const float v = fmaxf(g_.grid[idx] * g_.decay, m);                    // torch.maximum(density_grid * decay, tmp_grid)  (:345)
-        g_.grid[idx] = v;
+                for (uint32_t dz = 0; dz < 2; ++dz)
+                    if (gx + dx < H && gy + dy < H && gz + dz < H) m = fmaxf(m, g_.dens[((size_t)(gx + dx) * H + (gy + dy)) * H + (gz + dz)]);
+        const float v = fmaxf(g_.grid[p] * g_.decay, m);                     // torch.maximum(density_grid * decay, tmp_grid)  (:345)
+        g_.grid[p] = v;
         part += (double)v;
     }
-    // mean: per-wave shuffle tree -> per-workgroup sum (fixed order) -> the last workgroup adds the workgroups' partials (fixed order)
+    // mean: per-wave shuffle tree -> per-workgroup sum (fixed order) -> the last workgroup adds the workgroups' partials (fixed order); in double, where the
+    // reference's torch.mean reduces in fp32 -- the two agree to ~1e-7 relative (tests: <= 1e-6), not bit for bit: mean_density is a threshold of the marcher
+    // (density > min(mean, 0.01 ...)), compared against values that differ from it by orders of magnitude
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
     if (lane == 0) red[wave] = part;
     __syncthreads();
-    __shared__ uint32_t last;
     if (threadIdx.x == 0) {
         double s = 0.0;
-        for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += red[w];
+        for (int w = 0; w < DP_BLOCK / 64; ++w) s += red[w];
         g_.partials[blockIdx.x] = s;
         __threadfence();
         last = atomicAdd(g_.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
@@ -387,7 +369,7 @@ __global__ __launch_bounds__(BLOCK) void density_grid_kernel(const RenderArgs a,
     if (!last) return;
     __threadfence();
     double s = 0.0;
-    for (uint32_t b = threadIdx.x; b < gridDim.x; b += BLOCK)             // (agent-scope loads: served by L2, never by a stale vector-L1 line)
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += DP_BLOCK)             // (agent-scope loads: served by L2, never by a stale vector-L1 line)
         s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(g_.partials) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
@@ -396,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void density_grid_kernel(const RenderArgs a,
     __syncthreads();
     if (threadIdx.x == 0) {
         double tot = 0.0;
-        for (int w = 0; w < WAVES_PER_BLOCK; ++w) tot += red[w];
+        for (int w = 0; w < DP_BLOCK / 64; ++w) tot += red[w];
         g_.mean_out[0] = tot / ((double)H * (double)H * (double)H);
         *g_.ticket = 0u;
     }
@@ -435,22 +417,16 @@ int mc_check(const char *who, const float *vol, uint32_t nx, uint32_t ny, uint32
     return AC_OK;
 }
 
-}  // namespace
-
-AC_API int ac_field_sdf_grid(const ac_field *field, const float *axis_x, const float *axis_y, const float *axis_z, uint32_t nx, uint32_t ny, uint32_t nz,
-                             float bound, int negate, float *volume, ac_stream_t stream)
+// the regular-grid launch shared by ac_field_sdf_grid and ac_density_grid_update (mode: see field_sdf_grid_kernel)
+int launch_grid(const RenderArgs &a, const float *axis_x, const float *axis_y, const float *axis_z, uint32_t nx, uint32_t ny, uint32_t nz, int mode, float inv_s,
+                float *volume, hipStream_t stream, const char *what)
 {
-    if (nx == 0 || ny == 0 || nz == 0) return AC_OK;
-    if (!axis_x || !axis_y || !axis_z || !volume) { ac::set_error("field_sdf_grid: NULL buffer"); return AC_ERR_BAD_ARG; }
-    if ((uint64_t)nx * ny * nz >= (1ull << 32) - 16) { ac::set_error("field_sdf_grid: more than 2^32 grid points"); return AC_ERR_BAD_ARG; }
-    RenderArgs a{};
-    if (int rc = geo_args(a, field, bound)) return rc;
     const size_t lds_bytes = (OFF_WAVE + GB_X * GB_Y * GB_Z) * sizeof(float);
     const uint32_t B = nx * ny * nz, ntiles = (B + 15u) / 16u;
     // experiment switches (same values whatever they say): AC_GRID_ORDER = 0 linear tiles | 1 bricks per XCD; AC_GRID_ROUND = 2 | 4 levels per gather round
     static const int order = []() { const char *e = getenv("AC_GRID_ORDER"); return e ? atoi(e) : AC_GRID_ORDER_DEFAULT; }();
     static const int round_ = []() { const char *e = getenv("AC_GRID_ROUND"); return (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 2 ? 2 : AC_GRID_ROUND_DEFAULT); }();
-    using kern_t = void (*)(const RenderArgs, const float *, const float *, const float *, uint32_t, uint32_t, uint32_t, int, float *);
+    using kern_t = void (*)(const RenderArgs, const float *, const float *, const float *, uint32_t, uint32_t, uint32_t, int, float, float *);
     const kern_t kern = order ? (round_ == 4 ? (kern_t)field_sdf_grid_kernel<4, true> : (kern_t)field_sdf_grid_kernel<2, true>)
                               : (round_ == 4 ? (kern_t)field_sdf_grid_kernel<4, false> : (kern_t)field_sdf_grid_kernel<2, false>);
     uint32_t blocks = order ? ((nx + GB_X - 1) / GB_X) * ((ny + GB_Y - 1) / GB_Y) * ((nz + GB_Z - 1) / GB_Z) : (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -466,8 +442,21 @@ AC_API int ac_field_sdf_grid(const ac_field *field, const float *axis_x, const f
     const uint32_t cap = (uint32_t)pc * ac::cu_count();
     if (blocks > cap) blocks = cap;
     if (order) blocks = (blocks + 7u) & ~7u;                          // every XCD the same number of workgroups
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a, axis_x, axis_y, axis_z, nx, ny, nz, negate ? 1 : 0, volume);
-    return ac::check_launch("field_sdf_grid");
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), lds_bytes, stream, a, axis_x, axis_y, axis_z, nx, ny, nz, mode, inv_s, volume);
+    return ac::check_launch(what);
+}
+
+}  // namespace
+
+AC_API int ac_field_sdf_grid(const ac_field *field, const float *axis_x, const float *axis_y, const float *axis_z, uint32_t nx, uint32_t ny, uint32_t nz,
+                             float bound, int negate, float *volume, ac_stream_t stream)
+{
+    if (nx == 0 || ny == 0 || nz == 0) return AC_OK;
+    if (!axis_x || !axis_y || !axis_z || !volume) { ac::set_error("field_sdf_grid: NULL buffer"); return AC_ERR_BAD_ARG; }
+    if ((uint64_t)nx * ny * nz >= (1ull << 32) - 16) { ac::set_error("field_sdf_grid: more than 2^32 grid points"); return AC_ERR_BAD_ARG; }
+    RenderArgs a{};
+    if (int rc = geo_args(a, field, bound)) return rc;
+    return launch_grid(a, axis_x, axis_y, axis_z, nx, ny, nz, negate ? 1 : 0, 0.0f, volume, (hipStream_t)stream, "field_sdf_grid");
 }
 
 AC_API size_t ac_marching_cubes_scratch(uint32_t nx, uint32_t ny, uint32_t nz)
@@ -519,16 +508,20 @@ AC_API int ac_marching_cubes_emit(const float *volume, uint32_t nx, uint32_t ny,
     return ac::check_launch("marching_cubes_emit");
 }
 
-static void dg_bricks(uint32_t H, uint32_t &nbx, uint32_t &nby, uint32_t &nbz)
+static uint32_t dp_blocks(uint32_t H)
 {
-    nbx = (H + DG_BX - 1) / DG_BX; nby = (H + DG_BY - 1) / DG_BY; nbz = (H + DG_BZ - 1) / DG_BZ;
+    // few workgroups, several points per thread: every workgroup ends with a device-scope fence + a ticket (the mean's fixed-order reduction), and with one
+    // point per thread (8403 workgroups at 129^3) those epilogues were the pass: 223 us against 65 us with 2048 workgroups
+    const uint64_t n = ((uint64_t)H * H * H + DP_BLOCK - 1) / DP_BLOCK;
+    const uint32_t cap = 4u * ac::cu_count();
+    return (uint32_t)(n < cap ? n : cap);
 }
+static size_t dg_dens_offset(uint32_t H) { return (256 + (size_t)dp_blocks(H) * sizeof(double) + 255) & ~(size_t)255; }
 
 AC_API size_t ac_density_grid_update_scratch(uint32_t H)
 {
     if (H < 2 || H > 1024) return 0;
-    uint32_t nbx, nby, nbz; dg_bricks(H, nbx, nby, nbz);
-    return 256 + (size_t)nbx * nby * nbz * sizeof(double);
+    return dg_dens_offset(H) + (size_t)H * H * H * sizeof(float);           // ticket | per-workgroup partial sums | the densities of pass 1
 }
 
 AC_API int ac_density_grid_update(const ac_field *field, const float *axis, uint32_t H, float bound, float inv_s, float decay, float *grid,
@@ -539,15 +532,13 @@ AC_API int ac_density_grid_update(const ac_field *field, const float *axis, uint
     if (!need || scratch_bytes < need) { ac::set_error("density_grid_update: H = %u unsupported or scratch of %zu bytes needed, %zu given", H, need, scratch_bytes); return AC_ERR_BAD_ARG; }
     RenderArgs a{};
     if (int rc = geo_args(a, field, bound)) return rc;
+    float *dens = reinterpret_cast<float *>(static_cast<char *>(scratch) + dg_dens_offset(H));
+    if (int rc = launch_grid(a, axis, axis, axis, H, H, H, 2, inv_s, dens, (hipStream_t)stream, "density_grid_update")) return rc;
     DgArgs g{};
-    g.axis = axis; g.H = H; dg_bricks(H, g.nbx, g.nby, g.nbz);
-    g.inv_s = inv_s; g.decay = decay; g.grid = grid;
+    g.dens = dens; g.H = H; g.decay = decay; g.grid = grid;
     g.ticket = static_cast<uint32_t *>(scratch);
     g.partials = reinterpret_cast<double *>(static_cast<char *>(scratch) + 256);
     g.mean_out = mean_out;
-    const size_t lds_bytes = DG_LDS_FLOATS * sizeof(float);
-    static uint64_t seen = 0;
-    ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(density_grid_kernel), lds_bytes);
-    hipLaunchKernelGGL(density_grid_kernel, dim3(g.nbx * g.nby * g.nbz), dim3(BLOCK), lds_bytes, (hipStream_t)stream, a, g);
+    hipLaunchKernelGGL(density_pool_kernel, dim3(dp_blocks(H)), dim3(DP_BLOCK), 0, (hipStream_t)stream, g);
     return ac::check_launch("density_grid_update");
 }

@@ -456,11 +456,13 @@ int ac_marching_cubes_count(const float *volume, uint32_t nx, uint32_t ny, uint3
 int ac_marching_cubes_emit(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz, float iso, void *scratch, size_t scratch_bytes,
                            double den, const double span[3], const double lo[3], double *vertices, uint32_t n_vertices, int32_t *triangles,
                            uint32_t n_triangles, ac_stream_t stream);
-/* ac_density_grid_update replaces the grid update of NeRFRenderer.update_extra_state (models/instant_nsr.py:303-346) in ONE launch: forward_sdf on
+/* ac_density_grid_update replaces the grid update of NeRFRenderer.update_extra_state (models/instant_nsr.py:303-346) in two launches (round 6: the densities on
+ * ac_field_sdf_grid's x-tiles into the scratch, then one pooling / merging pass; round 5's single launch evaluated a halo per brick and was 3 x slower): forward_sdf on
  * the H^3 grid axis x axis x axis (axis [H], device: torch.linspace(-bound, bound, H)) -> density = inv_s e^(-inv_s |sdf|) / (1 + e^(-inv_s |sdf|)) in the
  * reference's two branches (:331-337; inv_s = 512) -> zero pad by one at the far ends + 2x2x2 max pool, stride 1 (:341-342) -> grid = max(grid * decay,
  * new) IN PLACE (:345) -> mean_out (DEVICE, 1 double) = mean(grid) (:346; accumulated in double, fixed order).  grid [H,H,H].
- * scratch: ac_density_grid_update_scratch(H) bytes, ZEROED once by the caller before its first use (the launch re-arms it).  2 <= H <= 1024. */
+ * mean: in double where torch.mean reduces in fp32 -- equal to ~1e-7 relative, not bit for bit (a marcher threshold: values it is compared with differ by orders of magnitude).
+ * scratch: ac_density_grid_update_scratch(H) bytes (4 H^3 + a few KB), ZEROED once by the caller before its first use (the launch re-arms it).  2 <= H <= 1024. */
 size_t ac_density_grid_update_scratch(uint32_t H);
 int ac_density_grid_update(const ac_field *field, const float *axis, uint32_t H, float bound, float inv_s, float decay, float *grid,
                            double *mean_out, void *scratch, size_t scratch_bytes, ac_stream_t stream);
