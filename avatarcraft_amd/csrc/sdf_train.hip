@@ -55,6 +55,30 @@ constexpr int FWD_LDS_FLOATS = OFF_WAVE + FW * FE_SLAB;
 static_assert(FWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 constexpr int BWD_LDS_FLOATS = OFF_TW + TW * TRAIN_SLAB;
 static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+// Round 6: the SDF-query backward on SAVED stencil features (the render core's backward) at TWO waves per SIMD.  Round 4 / 5 ran it at one (296 registers: 66 of
+// them the next tile's prefetched inputs, 56 of those the 14 x 16 bytes of saved features, which then also occupied a 12 KB slab per wave): every LDS round
+// trip, every matrix-to-vector dependency of the serial chain was exposed (0.635 ms per 4096-ray patch, VALU + MFMA pipe time ~0.4 of that).  Now an evaluation's
+// eight features are requested from the forward's buffer one evaluation ahead (2 x 16 bytes per lane): no feature slab.  What that buys:
+//   * NOT a second wave per SIMD (AC_SDFBWD_WAVES=8: 256 registers, occupancy 2 -- and 148 spilled registers, 368 bytes of scratch per lane: the kernel's
+//     natural live set is ~370 registers; backward of the SDS step 2.24 -> 3.10 ms);
+//   * room for a second buffer of the d1 / input transposes, so that the weight-gradient products of evaluation e (48 fp32 MFMA of 32 clocks, a quarter of
+//     the evaluation's time, with nothing beside them on the wave's only instruction stream) are issued INSIDE evaluation e + 1's recomputation
+//     (softplus, splits: vector work) instead of behind a barrier at the end of their own evaluation.
+#ifndef AC_SDFBWD_WAVES
+#define AC_SDFBWD_WAVES 4
+#endif
+#ifndef AC_SDFBWD_PIPE
+#define AC_SDFBWD_PIPE 1      // 1: the weight-gradient products of evaluation e run inside evaluation e + 1 on the bf16 matrix pipe (SAVED variant); 0: fp32, behind their own evaluation
+#endif
+constexpr int TW_S = AC_SDFBWD_WAVES;                                  // waves per workgroup of sdf_stencil_bwd_kernel<SAVED = true>
+// PIPE: the transposes of d1 [64 units][16 samples] and inp [48 columns][16 samples] as bf16 hi | lo parts, rows of 16 samples = 32 bytes padded to 48
+// (conflict-free 16-byte reads, 16-byte aligned): one buffer = d1 hi 3072 | d1 lo 3072 | inp hi 2304 | inp lo 2304 bytes, two buffers per wave
+constexpr int BF_ROW = 48, BF_D1H = 0, BF_D1L = 64 * BF_ROW, BF_INH = 2 * 64 * BF_ROW, BF_INL = BF_INH + 48 * BF_ROW, BF_BYTES = BF_INL + 48 * BF_ROW;
+constexpr int TRAIN_SLAB_PIPE = ((TS_TD - FE_SLAB) + 2 * BF_BYTES / 4 + 3) / 4 * 4;       // T2 | TA | two bf16 buffers
+constexpr int TRAIN_SLAB_NOPIPE = TRAIN_SLAB - FE_SLAB;
+constexpr int TRAIN_SLAB_S = TRAIN_SLAB_PIPE > TRAIN_SLAB_NOPIPE ? TRAIN_SLAB_PIPE : TRAIN_SLAB_NOPIPE;    // the SAVED variant's per-wave slab: no feature region
+constexpr int BWD_LDS_FLOATS_S = OFF_TW + TW_S * TRAIN_SLAB_S;
+static_assert(BWD_LDS_FLOATS_S * 4 <= 160 * 1024, "LDS budget");
 constexpr int NPART = 64 * 36 + 16 * 64 + 16;      // dW1 [64][36] (column 35 = db1), dW2 [16][64], db2 [16]
 
 // softplus_100 and its derivative from the same table row: d/dx [max(x,0) + q(fract(|400 x|))] = [x > 0] + sign(x) 400 q'(v)
@@ -188,7 +212,7 @@ __device__ __forceinline__ void fill_lds_bwd(float *lds, const RenderArgs &a)
 // SAVED: the features of the seven stencil points come from the forward launch (ac_render_out.feat7, [B / 16][14][64 lanes][4] in this kernel's lane order) as 14
 // coalesced 16-byte loads per lane instead of being gathered from the table again (index arithmetic + ~100 scattered 8-byte loads per lane and tile)
 template <bool SAVED>
-__global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ g_out,
+__global__ __launch_bounds__(SAVED ? TW_S * 64 : TBLOCK) void sdf_stencil_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ g_out,
                                                                  const float *__restrict__ g_grad, uint32_t B, float eps,
                                                                  float *__restrict__ gfeat, float *__restrict__ partials,
                                                                  const float *__restrict__ feat7)
@@ -197,9 +221,22 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
     fill_lds_sdf(lds, a);
     fill_lds_bwd(lds, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-    float *slab = lds + OFF_TW + wave * TRAIN_SLAB;
-    float *fsl = slab, *T2 = slab + TS_T2, *TA = slab + TS_TA, *TD = slab + TS_TD, *TI = slab + TS_TI;
-    for (int e = lane; e < 48 * TLD; e += 64) TI[e] = (e >= 35 * TLD && e < 36 * TLD) ? 1.0f : 0.0f;       // bias column, zero padding rows
+    constexpr int KW = SAVED ? TW_S : TW, SFE = SAVED ? FE_SLAB : 0;   // waves per workgroup | floats the slab does not hold (SAVED: no feature region)
+    float *slab = lds + OFF_TW + wave * (SAVED ? TRAIN_SLAB_S : TRAIN_SLAB);
+    float *fsl = slab, *T2 = slab + TS_T2 - SFE, *TA = slab + TS_TA - SFE, *TD0 = slab + TS_TD - SFE, *TI0 = slab + TS_TI - SFE;
+    // PIPE: two buffers of (d1, inp) transposes -- evaluation `step` writes buffer step & 1 while the weight-gradient products of the evaluation before it read
+    // the other one.  The very first step's "previous evaluation" is a buffer of zeros (products of 0: the accumulators keep their +0).
+    constexpr bool PIPE = SAVED && AC_SDFBWD_PIPE && AC_SDFBWD_RANK1;
+    unsigned char *const BF = reinterpret_cast<unsigned char *>(TD0);      // PIPE: the two bf16 buffers take the place of the fp32 transposes
+    if constexpr (PIPE) {
+        uint32_t *bw = reinterpret_cast<uint32_t *>(BF);
+        for (int e = lane; e < 2 * BF_BYTES / 4; e += 64) {                 // zeros; the bias column (input row 35) = bf16 1.0 in the hi part, for all 16 samples
+            const int o = (4 * e) % BF_BYTES;
+            bw[e] = (o >= BF_INH + 35 * BF_ROW && o < BF_INH + 35 * BF_ROW + 32) ? 0x3f803f80u : 0u;
+        }
+    } else {
+        for (int e = lane; e < 48 * TLD; e += 64) TI0[e] = (e >= 35 * TLD && e < 36 * TLD) ? 1.0f : 0.0f;       // bias column, zero padding rows
+    }
     __syncthreads();
     const FieldCtx fc = make_ctx(a);
     const float bound = a.bound;
@@ -219,26 +256,55 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
 #pragma unroll
         for (int c = 0; c < 3; ++c) gW1[t][c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     }
+    uint32_t step = 0;                                          // evaluations this wave has been through (PIPE: selects the buffer)
+    // the weight-gradient products of ONE evaluation from its transposes: dW2 += d2 a^T (16 MFMA, centre evaluations only: the offset evaluations' share is
+    // the rank-1 running sum a6) and dW1 += d1 inp^T (48 MFMA)
+    auto w2_grads = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a2 = T2[n * TLD + 4 * s + g];                         // A: d2[o = lane & 15][sample 4s + kk]
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                gW2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, TA[(16 * c + n) * TLD + 4 * s + g], gW2[c], 0, 0, 0);
+        }
+    };
+    auto w1_grads = [&](const float *__restrict__ TDr, const float *__restrict__ TIr) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float bi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bi[c] = TIr[(16 * c + n) * TLD + 4 * s + g];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float a1 = TDr[(16 * t + n) * TLD + 4 * s + g];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gW1[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bi[c], gW1[t][c], 0, 0, 0);
+            }
+        }
+    };
     const uint32_t ntiles = (B + 15) / 16;
     const float hs = 0.5f / eps;
     // The inputs of tile i + 1 are requested while tile i is computed (round 4): with one wave per SIMD nothing else covers their ~2 us, and a third of
     // the 512 registers a lone wave may use are free.  TileIn = what a lane reads per tile: its sample's position and upstream gradients and, with SAVED,
     // the 14 x 16 bytes of stencil features the forward kept ([tile][14][lane][4], see render_rays_kernel: each load 1 KB contiguous per wave).
-    struct TileIn { float p[3], gg[3]; f32x4 go; f32x4 v[SAVED ? 14 : 1]; };
+    struct TileIn { float p[3], gg[3]; f32x4 go; };
     auto request = [&](uint32_t tile, TileIn &in) {
         const uint32_t b = tile * 16 + n, bb = b < B ? b : B - 1;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { in.p[k] = x[3 * (size_t)bb + k]; in.gg[k] = g_grad[3 * (size_t)bb + k]; }
         in.go = *reinterpret_cast<const f32x4 *>(g_out + (size_t)bb * 16 + 4 * g);
-        if constexpr (SAVED) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(feat7) + ((size_t)tile * 14) * 64 + lane;
-#pragma unroll
-            for (int k = 0; k < 14; ++k) in.v[k] = src[k * 64];
-        }
     };
-    const uint32_t tile0 = blockIdx.x * TW + wave, tstride = gridDim.x * TW;
+    // SAVED: the eight features of evaluation e of a tile = floats 8 e .. 8 e + 7 of this lane = two 16-byte loads ([tile][14][lane][4]), requested one
+    // evaluation ahead
+    struct Feat2 { f32x4 a, b; };
+    auto request_feat = [&](uint32_t tile, int e, Feat2 &f) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(feat7) + ((size_t)tile * 14 + 2 * (size_t)e) * 64 + lane;
+        f.a = src[0]; f.b = src[64];
+    };
+    const uint32_t tile0 = blockIdx.x * KW + wave, tstride = gridDim.x * KW;
     TileIn nxt;
-    if (tile0 < ntiles) request(tile0, nxt);
+    Feat2 fnx{};
+    if (tile0 < ntiles) { request(tile0, nxt); if constexpr (SAVED) request_feat(tile0, 0, fnx); }
     for (uint32_t tile = tile0; tile < ntiles; tile += tstride) {
         const uint32_t b = tile * 16 + n;
         const bool live = b < B;
@@ -249,9 +315,7 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
         float fe0[4][2];
         if constexpr (SAVED) {
 #pragma unroll
-            for (int q_ = 0; q_ < 8; ++q_) fe0[q_ >> 1][q_ & 1] = nxt.v[q_ >> 2][q_ & 3];
-#pragma unroll
-            for (int k = 8; k < 56; ++k) fsl[(k - 8) * 64 + lane] = nxt.v[k >> 2][k & 3];
+            for (int q_ = 0; q_ < 4; ++q_) { fe0[q_ >> 1][q_ & 1] = fnx.a[q_]; fe0[2 + (q_ >> 1)][q_ & 1] = fnx.b[q_]; }
         } else {
             encode_stencil(lds, fsl, fc, lane, px, py, pz, eps, fe0);
         }
@@ -265,8 +329,16 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
 #pragma unroll 1
         for (int e = 0; e < 7; ++e) {
             const int k = e > 0 ? (e - 1) >> 1 : 3;
+            float *const TD = TD0, *const TI = TI0;                                                      // (!PIPE) this evaluation's fp32 transposes
+            if constexpr (PIPE) { if (e == 1) w2_grads(); }                    // (the evaluation before this one was the tile's centre)
             float fe[4][2];
-            if (e == 0) {
+            if constexpr (SAVED) {
+#pragma unroll
+                for (int q_ = 0; q_ < 4; ++q_) { fe[q_ >> 1][q_ & 1] = fnx.a[q_]; fe[2 + (q_ >> 1)][q_ & 1] = fnx.b[q_]; }
+                // the next evaluation's features (the next tile's centre after the last one) leave now: a whole evaluation of arithmetic covers them
+                if (e < 6) request_feat(tile, e + 1, fnx);
+                else if (tile + tstride < ntiles) request_feat(tile + tstride, 0, fnx);
+            } else if (e == 0) {
 #pragma unroll
                 for (int q_ = 0; q_ < 8; ++q_) fe[q_ >> 1][q_ & 1] = fe0[q_ >> 1][q_ & 1];
             } else {
@@ -291,8 +363,73 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
             if (e == 0) { h1 = sdf_l1(lds, lane, bx, fe); h10 = h1; }
             else h1 = sdf_l1_delta<OFF_BW1H, OFF_BW1L, OFF_BW1C>(lds, lane, h10, fe, fe0, k, poff - pk);
             Acc4 av, dv;
+            if constexpr (PIPE) {
+                // The PREVIOUS evaluation's weight-gradient products dW1 += d1 inp^T, issued inside this evaluation's 16 softplus values + derivatives (the
+                // largest stretch of vector work of an evaluation: no LDS stores, no branches), the order pinned by scheduling fences.
+                // On the bf16 matrix pipe, K = 32 = [hi parts of the tile's 16 samples | lo parts]: per 16 x 16 output tile
+                //   gW1 += [d1 hi | d1 lo] x [inp hi | inp hi]   (hi hi + lo hi)      gW1 += [d1 hi | d1 lo] x [inp lo | 0]   (hi lo)
+                // -- 24 instructions of 16 clocks that CO-EXECUTE with vector instructions, instead of 48 fp32 ones of 32 clocks that do not (the fp32 matrix
+                // instructions run on the vector pipe's multipliers, SQ_VALU_MFMA_COEXEC_CYCLES = 0: interleaving THOSE with the softplus work was built
+                // and measured first and bought nothing -- backward 2.244 -> 2.300 ms, profiles/r06_experiments.txt).  The dropped lo x lo term is 2^-16 of
+                // a product; the sums stay fp32.  Lane (m, kk) reads 8 consecutive samples of row m: kk = 0, 1 from the hi part, kk = 2, 3 from the lo
+                // part (d1) / the hi part again (inp, first product) / a row of zeros (inp, second product).
+                const unsigned char *const Br = BF + ((step & 1u) ? 0 : BF_BYTES);
+                const float *__restrict__ spg = lds + OFF_SPQ;
+                const int kk_ = lane >> 4, m_ = lane & 15;
+                const unsigned char *const pa = Br + (kk_ >= 2 ? BF_D1L : BF_D1H) + m_ * BF_ROW + (kk_ & 1) * 16;
+                const unsigned char *const pb1 = Br + BF_INH + m_ * BF_ROW + (kk_ & 1) * 16;
+                const unsigned char *const pb2 = kk_ >= 2 ? Br + BF_INL + 40 * BF_ROW : Br + BF_INL + m_ * BF_ROW + (kk_ & 1) * 16;    // (input rows 36 .. 47 are zero padding)
+                const int pb2s = kk_ >= 2 ? 0 : 16 * BF_ROW;
+                bf16x8 opA[4], opB1[3], opB2[3];
+                auto rdA = [&](int t_) { opA[t_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(pa + 16 * t_ * BF_ROW)); };
+                auto rdB = [&](int c_) {
+                    opB1[c_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(pb1 + 16 * c_ * BF_ROW));
+                    opB2[c_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(pb2 + c_ * pb2s));
+                };
+                rdA(0); rdA(1); rdB(0); rdB(1); rdB(2);
+                float xs[16], vv[16], qq[16], dq[16];
+                float4 cc[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) xs[i] = h1.a[i >> 2][i & 3];
+                auto P1 = [&](int i) {                                       // row request of value i
+                    const float a4 = __builtin_fminf(__builtin_fabsf(xs[i] * 400.0f), 128.0f);
+                    const uint32_t idx = (uint32_t)a4;
+                    vv[i] = __builtin_amdgcn_fractf(a4);
+                    cc[i] = *reinterpret_cast<const float4 *>(spg + idx * 4);
+                };
+                auto P2 = [&](int i) {                                       // the cubic and its derivative
+                    float q = cc[i].w;
+                    q = fma_(q, vv[i], cc[i].z); q = fma_(q, vv[i], cc[i].y); q = fma_(q, vv[i], cc[i].x);
+                    float d = 3.0f * cc[i].w;
+                    d = fma_(d, vv[i], 2.0f * cc[i].z); d = fma_(d, vv[i], cc[i].y);
+                    qq[i] = q; dq[i] = d;
+                };
+                auto P3 = [&](int i) {                                       // value and derivative of softplus_100
+                    const bool pos = xs[i] > 0.0f;
+                    av.a[i >> 2][i & 3] = fma_(0.5f, __builtin_fabsf(xs[i]), fma_(0.5f, xs[i], qq[i]));
+                    dv.a[i >> 2][i & 3] = (pos ? 1.0f : 0.0f) + (pos ? 400.0f : -400.0f) * dq[i];
+                };
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kq = 0; kq < 24; ++kq) {
+                    const int t_ = kq / 6, c_ = (kq % 6) >> 1, second = kq & 1;
+                    gW1[t_][c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(opA[t_], second ? opB2[c_] : opB1[c_], gW1[t_][c_], 0, 0, 0);
+                    if (kq == 0) rdA(2);
+                    if (kq == 2) rdA(3);
+                    // two slices of the softplus work per group: P1(0) P1(1) P1(2) | P2(i) P3(i) P1(i + 3) for i = 0 .. 12 | P2(13) P3(13) .. P2(15) P3(15)
+#pragma unroll
+                    for (int h_ = 0; h_ < 2; ++h_) {
+                        const int ks = 2 * kq + h_;
+                        if (ks < 3) P1(ks);
+                        else if (ks < 42) { const int i = (ks - 3) / 3, ph = (ks - 3) % 3; if (ph == 0) P2(i); else if (ph == 1) P3(i); else P1(i + 3); }
+                        else { const int i = 13 + (ks - 42) / 2, ph = (ks - 42) % 2; if (ph == 0) P2(i); else P3(i); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) softplus100_vg4(lds + OFF_SPQ, h1.a[t], av.a[t], dv.a[t]);
+            }
             Acc4 d1;
 #if AC_SDFBWD_RANK1
             // The six offset evaluations feed the finite-difference gradient through their sdf alone: d2 = (s, 0, ..., 0).  Then
@@ -363,6 +500,24 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
 #pragma unroll
                     for (int r = 0; r < 4; ++r) TA[(16 * t + 4 * g + r) * TLD + n] = av.a[t][r];
             }
+            if constexpr (PIPE) {
+                // hi = the value's top 16 bits, lo = the top 16 bits of (value - hi) (split8_bf16's truncation split), each a 2-byte store of a register's
+                // HIGH half (ds_write_b16_d16_hi: no shift) at [row][sample n]
+                unsigned char *const Bw = BF + ((step & 1u) ? BF_BYTES : 0);
+                auto put = [&](int part_hi, int part_lo, int row, float v) {
+                    const uint32_t u = __float_as_uint(v);
+                    const uint32_t rl = __float_as_uint(v - __uint_as_float(u & 0xffff0000u));
+                    *reinterpret_cast<uint16_t *>(Bw + part_hi + row * BF_ROW + 2 * n) = (uint16_t)(u >> 16);
+                    *reinterpret_cast<uint16_t *>(Bw + part_lo + row * BF_ROW + 2 * n) = (uint16_t)(rl >> 16);
+                };
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) put(BF_D1H, BF_D1L, 16 * t + 4 * g + r, d1.a[t][r]);
+                if (g < 3) put(BF_INH, BF_INL, g, bx);
+#pragma unroll
+                for (int s1 = 0; s1 < 8; ++s1) put(BF_INH, BF_INL, 3 + 2 * (4 * (s1 >> 1) + g) + (s1 & 1), fe[s1 >> 1][s1 & 1]);
+            } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -370,41 +525,44 @@ __global__ __launch_bounds__(TBLOCK) void sdf_stencil_bwd_kernel(const RenderArg
             if (g < 3) TI[g * TLD + n] = bx;
 #pragma unroll
             for (int s1 = 0; s1 < 8; ++s1) TI[(3 + 2 * (4 * (s1 >> 1) + g) + (s1 & 1)) * TLD + n] = fe[s1 >> 1][s1 & 1];
-            wave_sync();
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#if AC_SDFBWD_RANK1
-                if (!rank1)
-#endif
-                {
-                    const float a2 = T2[n * TLD + 4 * s + g];                     // A: d2[o = lane & 15][sample 4s + kk]
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        gW2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, TA[(16 * c + n) * TLD + 4 * s + g], gW2[c], 0, 0, 0);
-                }
-                float bi[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) bi[c] = TI[(16 * c + n) * TLD + 4 * s + g];
-#ifdef AC_ABL_NODW1           // timing ablation: the weight-gradient products of the six offset evaluations are skipped
-                if (e == 0)
-#endif
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float a1 = TD[(16 * t + n) * TLD + 4 * s + g];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) gW1[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bi[c], gW1[t][c], 0, 0, 0);
-                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) gb2[r] += d2[r];
             wave_sync();
+            ++step;
+            if constexpr (!PIPE) {
+#if AC_SDFBWD_RANK1
+                if (!rank1)
+#endif
+                    w2_grads();
+#ifdef AC_ABL_NODW1           // timing ablation: the weight-gradient products of the six offset evaluations are skipped
+                if (e == 0)
+#endif
+                w1_grads(TD, TI);
+                wave_sync();
+            }
         }
 #if !AC_SDFBWD_PREFETCH
         if (tile + tstride < ntiles) request(tile + tstride, nxt);
 #endif
     }
+    if constexpr (PIPE) {                                       // the last evaluation's products (an offset evaluation; a wave without a tile: the zero buffer)
+        const unsigned char *const Br = BF + ((step & 1u) ? 0 : BF_BYTES);
+        const int kk_ = lane >> 4, m_ = lane & 15;
+#pragma unroll
+        for (int t_ = 0; t_ < 4; ++t_) {
+            const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(Br + (kk_ >= 2 ? BF_D1L : BF_D1H) + (16 * t_ + m_) * BF_ROW + (kk_ & 1) * 16));
+#pragma unroll
+            for (int c_ = 0; c_ < 3; ++c_) {
+                const bf16x8 B1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(Br + BF_INH + (16 * c_ + m_) * BF_ROW + (kk_ & 1) * 16));
+                const bf16x8 B2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(Br + BF_INL + (kk_ >= 2 ? 40 : 16 * c_ + m_) * BF_ROW + (kk_ >= 2 ? 0 : (kk_ & 1) * 16)));
+                gW1[t_][c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B1, gW1[t_][c_], 0, 0, 0);
+                gW1[t_][c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B2, gW1[t_][c_], 0, 0, 0);
+            }
+        }
+    }
     // per-wave partial sums: dW1 [64][36] | dW2 [16][64] | db2 [16]
-    float *part = partials + (size_t)(blockIdx.x * TW + wave) * NPART;
+    float *part = partials + (size_t)(blockIdx.x * KW + wave) * NPART;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1999,7 +2157,7 @@ AC_API int ac_render_rays_occupancy_phased(const ac_field *field, const float *r
 
 AC_API size_t ac_sdf_stencil_backward_scratch(uint32_t B)
 {
-    return (size_t)train_grid(B) * TW * NPART * sizeof(float);
+    return (size_t)train_grid(B) * (TW_S > TW ? TW_S : TW) * NPART * sizeof(float);
 }
 
 static int sdf_stencil_backward_impl(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
@@ -2012,19 +2170,21 @@ static int sdf_stencil_backward_impl(const ac_field *field, const float *x, cons
     if (scratch_bytes < need) { ac::set_error("sdf_stencil_backward: scratch of %zu bytes needed, %zu given", need, scratch_bytes); return AC_ERR_BAD_ARG; }
     RenderArgs a{};
     if (int rc = prep_args(a, field, bound, eps)) return rc;
-    const size_t lds_bytes = BWD_LDS_FLOATS * sizeof(float);
+    const size_t lds_bytes = BWD_LDS_FLOATS * sizeof(float), lds_bytes_s = BWD_LDS_FLOATS_S * sizeof(float);
     static uint64_t seen = 0, seen_s = 0;
     ac::allow_dynamic_lds(seen, reinterpret_cast<const void *>(sdf_stencil_bwd_kernel<false>), lds_bytes);
-    ac::allow_dynamic_lds(seen_s, reinterpret_cast<const void *>(sdf_stencil_bwd_kernel<true>), lds_bytes);
-    const uint32_t blocks = train_grid(B);
-    if (feat7)
-        hipLaunchKernelGGL(sdf_stencil_bwd_kernel<true>, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
+    ac::allow_dynamic_lds(seen_s, reinterpret_cast<const void *>(sdf_stencil_bwd_kernel<true>), lds_bytes_s);
+    uint32_t blocks = train_grid(B);
+    if (feat7) {
+        const uint32_t need_blocks = ((B + 15) / 16 + TW_S - 1) / TW_S;           // (persistent: one workgroup of TW_S waves per compute unit)
+        if (blocks > need_blocks) blocks = need_blocks ? need_blocks : 1;
+        hipLaunchKernelGGL(sdf_stencil_bwd_kernel<true>, dim3(blocks), dim3(TW_S * 64), lds_bytes_s, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
                            static_cast<float *>(scratch), feat7);
-    else
+    } else
         hipLaunchKernelGGL(sdf_stencil_bwd_kernel<false>, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
                            static_cast<float *>(scratch), feat7);
     hipLaunchKernelGGL(sdf_partials_reduce_kernel, dim3((NPART + RED_OUT - 1) / RED_OUT), dim3(1024), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
-                       blocks * TW, gparams);
+                       blocks * (feat7 ? TW_S : TW), gparams);
     return ac::check_launch("sdf_stencil_backward");
 }
 
