@@ -39,6 +39,10 @@ namespace {
 #ifndef AC_XCD_CHUNK
 #define AC_XCD_CHUNK 512
 #endif
+#ifndef AC_WG_TICKETS
+#define AC_WG_TICKETS 0            // 1 (round 6 experiment): a workgroup's waves draw their work items from blocks of 8 CONSECUTIVE rays (one global ticket per
+#endif                             // block, handed out inside the workgroup through LDS) instead of one global ticket per wave: the 8 rays a compute unit
+                                   // works on at a time are neighbouring pixels, whose coarse / middle level cells share L1 lines
 #ifndef AC_FAST_COLOR
 #define AC_FAST_COLOR 1            // fast precision: the colour network in split bf16 too (0: only layer 1 of the finite-difference evaluations)
 #endif
@@ -51,6 +55,11 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
 {
     constexpr bool FC = FAST && AC_FAST_COLOR;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#if AC_WG_TICKETS && AC_DYNAMIC_RAYS
+    __shared__ uint32_t wg_cnt[8], wg_tag[8][16], wg_base[8][16];          // per segment: tickets drawn inside this workgroup | block k's (k + 1, global base)
+    if (threadIdx.x < 8) wg_cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 128) wg_tag[threadIdx.x >> 4][threadIdx.x & 15] = 0u;
+#endif
     if (a.prepared) {
         // the weights arrive in LDS order (ac_field_prepare): a linear copy, 16 bytes per lane and trip, instead of ~27 dependent
         // gather-and-place trips per thread in each of the 512 workgroups of a launch; only the per-launch sampling tables are added
@@ -126,7 +135,21 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
     const bool seg_first = seg == 0, seg_last = seg + 1 == seg_n;
     for (;;) {
         int ray = 0;
+#if AC_WG_TICKETS
+        if (lane == 0) {
+            const uint32_t t = atomicAdd(&wg_cnt[seg], 1u), blk = t >> 3, slot = t & 7u, idx = blk & 15u;
+            if (slot == 0u) {                                            // this wave opens block blk: 8 consecutive tickets of the XCD's counter
+                const uint32_t b = atomicAdd(a.ray_counter + xcd * 8 + seg, 8u);
+                __hip_atomic_store(&wg_base[seg][idx], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&wg_tag[seg][idx], blk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                while (__hip_atomic_load(&wg_tag[seg][idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != blk + 1u) __builtin_amdgcn_s_sleep(1);
+            }
+            ray = (int)(__hip_atomic_load(&wg_base[seg][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + slot);
+        }
+#else
         if (lane == 0) ray = (int)atomicAdd(a.ray_counter + xcd * 8 + seg, 1u);
+#endif
         ray = __builtin_amdgcn_readfirstlane(ray);
         {
             const int k = ray / xchunk, base = (k * 8 + xcd) * xchunk;
