@@ -65,7 +65,7 @@ AC_ADAM_MAX_TENSORS = 16
 
 class ac_warp_mesh(C.Structure):
     _fields_ = [("verts", vp), ("faces", vp), ("T", vp), ("V", u32), ("F", u32), ("threshold", C.c_double), ("geo_threshold", f32),
-                ("use_mesh_guide", i32), ("accel", vp)]
+                ("use_mesh_guide", i32), ("accel", vp), ("seed_faces", vp), ("seed_stride", u32)]
 
 
 _SIGS = {
@@ -167,7 +167,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
             fn.argtypes = args
             fn.restype = res
-        if handle.ac_version() != 8:
+        if handle.ac_version() != 9:
             raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -16,7 +16,8 @@ void set_error(const char *fmt, ...);   // defined in ac_capi.hip
 // ac_warp_samples_accel with one more switch (warp.hip; used by ac_render_rays_warped): skip_far = do not search samples that are provably masked out
 int warp_samples_accel_impl(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V, uint32_t F,
                             double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest, double *dist2, int32_t *face_id,
-                            uint8_t *mask, ac_stream_t stream, int skip_far, const uint8_t *ray_dead, uint32_t samples_per_ray);
+                            uint8_t *mask, ac_stream_t stream, int skip_far, const uint8_t *ray_dead, uint32_t samples_per_ray,
+                            int32_t *tseeds = nullptr, uint32_t tseed_stride = 0, uint32_t tseed_off = 0);     // tseeds: see ac_warp_mesh.seed_faces
 // skip_masked rendering: ray_dead[r] = 1 if no sample of ray r (coarse samples coarse_pts [N, T0, 3] and everything between them) can be unmasked
 int warp_ray_cull(const float *coarse_pts, uint32_t N, uint32_t T0, double threshold, const void *accel, uint8_t *ray_dead, ac_stream_t stream);
 

@@ -1033,11 +1033,14 @@ AC_API size_t ac_render_rays_warped_scratch(int32_t n_rays, int32_t T, size_t of
 }
 
 static int warp_any(const ac_warp_mesh *m, const float *pts, uint32_t P, float *can, uint8_t *mask, ac_stream_t stream, int skip_far = 0,
-                    const uint8_t *ray_dead = nullptr, uint32_t spr = 1)
+                    const uint8_t *ray_dead = nullptr, uint32_t spr = 1, uint32_t seed_off = 0)
 {
-    if (m->accel)
+    if (m->accel) {
+        // temporal seeds (ac_warp_mesh.seed_faces): this search's columns [seed_off, seed_off + spr) of the caller's per-ray rows
+        int32_t *ts = (m->seed_faces && m->seed_stride >= seed_off + spr && spr > 0) ? m->seed_faces : nullptr;
         return ac::warp_samples_accel_impl(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, m->accel, nullptr, can, nullptr, nullptr, nullptr,
-                                           mask, stream, skip_far, ray_dead, spr);
+                                           mask, stream, skip_far, ray_dead, spr, ts, m->seed_stride, seed_off);
+    }
     return ac_warp_samples(pts, m->verts, m->faces, m->T, P, m->V, m->F, m->threshold, nullptr, can, nullptr, nullptr, nullptr, mask, stream);
 }
 
@@ -1105,7 +1108,7 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
             ray_dead = rdead;
         }
         phase_mark(1, st);
-        if (int rc = warp_any(mesh, pts, (uint32_t)(N * T0), can, mask, stream, 0, ray_dead, (uint32_t)T0)) return rc;
+        if (int rc = warp_any(mesh, pts, (uint32_t)(N * T0), can, mask, stream, 0, ray_dead, (uint32_t)T0, 0u)) return rc;
     } else phase_mark(1, st);
     phase_mark(2, st);
     a.ext_pts = can;
@@ -1114,7 +1117,7 @@ AC_API int ac_render_rays_warped(const ac_field *field, const ac_render_opts *op
     if (int rc = ac::check_launch("render_rays_warped (up-sampling)")) return rc;
     phase_mark(3, st);
     // (skip_masked: the final pass does not evaluate masked-out samples, so the search may leave out those the cell grids prove masked)
-    if (int rc = warp_any(mesh, pts, (uint32_t)(N * T), can, mask, stream, op->skip_masked, ray_dead, (uint32_t)T)) return rc;     // :198-203
+    if (int rc = warp_any(mesh, pts, (uint32_t)(N * T), can, mask, stream, op->skip_masked, ray_dead, (uint32_t)T, (uint32_t)T0)) return rc;     // :198-203
     phase_mark(4, st);
     a.mask = mask;
     launch_render<MODE_FINAL>(a, st);

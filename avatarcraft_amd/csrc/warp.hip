@@ -1007,7 +1007,8 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
                                                                  float *__restrict__ can_pts_f32, double *__restrict__ closest,
                                                                  double *__restrict__ dist2, int32_t *__restrict__ face_id,
                                                                  uint8_t *__restrict__ mask, float skip_thr,
-                                                                 const uint8_t *__restrict__ ray_dead, uint32_t spr, uint32_t perm_mul, int fixup)
+                                                                 const uint8_t *__restrict__ ray_dead, uint32_t spr, uint32_t perm_mul, int fixup,
+                                                                 int32_t *__restrict__ tseeds, uint32_t tseed_stride, uint32_t tseed_off, uint32_t n_faces)
 {
     const int lane = threadIdx.x & 63;
     // fixup != 0 (round 4): warp_samples_flist_kernel ran first and left mask[i] == FL_TODO on the samples it could not resolve (no fine cell / no
@@ -1087,6 +1088,25 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
         }
     }
 #endif
+    // TEMPORAL SEED (round 6): the caller keeps, per (ray, sample slot), the face the PREVIOUS frame's search found (tseeds; -1 = none) -- an animation's
+    // body moves little between frames, so that face is usually the closest one again or next to it.  Its exact distance in THIS frame's pose is a real
+    // face's distance, i.e. a valid first bound like the cell's seed face, and usually a much tighter one: the walk prunes against it from the first
+    // tile on.  Results: the same face, the same bits (the bound only removes candidates that are provably farther).
+    double tseed = __builtin_inf();
+    const size_t tsi = tseeds ? (size_t)(ii / spr) * tseed_stride + tseed_off + (ii % spr) : 0;
+    if (tseeds && live && !dead) {
+        const int32_t tf = tseeds[tsi];
+        if (tf >= 0 && (uint32_t)tf < n_faces) {
+            const int32_t f0v = faces[3 * (size_t)tf], f1v = faces[3 * (size_t)tf + 1], f2v = faces[3 * (size_t)tf + 2];
+            double a[3], b[3], c[3], cq[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { a[k] = (double)verts[3 * (size_t)f0v + k]; b[k] = (double)verts[3 * (size_t)f1v + k]; c[k] = (double)verts[3 * (size_t)f2v + k]; }
+            closest_pt_tri(p, a, b, c, cq);
+            const double ex = p[0] - cq[0], ey = p[1] - cq[1], ez = p[2] - cq[2], d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 < 1e30) tseed = d2;
+        }
+    }
+    if (tseed < myseed && mycnt != CELL_OVERFLOW) myseed = tseed;
 #ifdef AC_WARP_SEED_DEBUG   // ceiling experiment (tools/warp_seed_probe.py): start every sample from its TRUE distance^2 (taken from a previous run)
     if (g_warp_seed_d2 && live && mycnt != CELL_OVERFLOW) { const double t = g_warp_seed_d2[ii] * (1.0 + 1e-12); myseed = t < myseed ? t : myseed; }
 #endif
@@ -1339,6 +1359,7 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             uint32_t myslot;
             seed_test(av, q, tA, tB, lane, best, bid, bc, myslot);
             double seed = wave_min_f64(best);                            // +inf if every seed face is degenerate
+            { const double ts = lane_f64(tseed, (int)j); if (ts < seed) seed = ts; }        // (the previous frame's face, see stage 0)
             if (skip_thr >= 0.0f && seed > (double)skip_thr) seed = (double)skip_thr;       // (as above: only faces under the mask's threshold matter)
             n_box += nt; n_exact += 2u * TILE_F;
             if (lane == 0) sbest[j] = __builtin_bit_cast(unsigned long long, seed);
@@ -1390,8 +1411,9 @@ __global__ __launch_bounds__(PK_WAVES * 64, AC_WARP_WAVES) void warp_samples_acc
             closest_pt_tri(p, a, b, c, rbc);
         }
         finish_sample(i, p, rbc, rbest, (int)rb, verts, faces, T, threshold, can_pts, can_pts_f32, closest, dist2, face_id, mask);
+        if (tseeds && sbid[lane] != 0x7fffffffu) tseeds[tsi] = (int32_t)rb;                  // the next frame's seed of this (ray, slot)
     }
-    const uint32_t seeds = (uint32_t)__builtin_popcountll(__ballot(myseed < 1e30));          // exact tests of the cells' seed faces (stage 0)
+    const uint32_t seeds = (uint32_t)__builtin_popcountll(__ballot(myseed < 1e30)) + (uint32_t)__builtin_popcountll(__ballot(tseed < 1e30));   // exact tests of the seed faces (stage 0)
     if (lane == 0) {
         unsigned long long *wk = av.work + 4 * (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % (uint32_t)WORK_SLOTS);
         atomicAdd(wk, (unsigned long long)(n_exact + seeds)); atomicAdd(wk + 1, (unsigned long long)n_disc);
@@ -1617,7 +1639,7 @@ AC_API int ac_warp_accel_build(const float *verts, const int32_t *faces, uint32_
 int ac::warp_samples_accel_impl(const float *pts, const float *verts, const int32_t *faces, const double *T, uint32_t P, uint32_t V,
                                 uint32_t F, double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest,
                                 double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream, int skip_far, const uint8_t *ray_dead,
-                                uint32_t samples_per_ray)
+                                uint32_t samples_per_ray, int32_t *tseeds, uint32_t tseed_stride, uint32_t tseed_off)
 {
     (void)V;
     if (P == 0) return AC_OK;
@@ -1645,7 +1667,8 @@ int ac::warp_samples_accel_impl(const float *pts, const float *verts, const int3
         hipLaunchKernelGGL(warp_samples_flist_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts, verts, faces, T, P, threshold, av, can_pts,
                            can_pts_f32, closest, dist2, face_id, mask, skip_thr, ray_dead, spr);
     hipLaunchKernelGGL(warp_samples_accel_kernel, dim3((waves + PK_WAVES - 1) / PK_WAVES), dim3(PK_WAVES * 64), lds, (hipStream_t)stream, pts, verts, faces, T, P,
-                       threshold, av, can_pts, can_pts_f32, closest, dist2, face_id, mask, skip_thr, ray_dead, spr, perm_mul, use_flist);
+                       threshold, av, can_pts, can_pts_f32, closest, dist2, face_id, mask, skip_thr, ray_dead, spr, perm_mul, use_flist,
+                       use_flist ? nullptr : tseeds, tseed_stride, tseed_off, F);
     return ac::check_launch("warp_samples_accel");
 }
 
@@ -1661,5 +1684,6 @@ AC_API int ac_warp_samples_accel(const float *pts, const float *verts, const int
                                  uint32_t F, double threshold, const void *accel, double *can_pts, float *can_pts_f32, double *closest,
                                  double *dist2, int32_t *face_id, uint8_t *mask, ac_stream_t stream)
 {
-    return ac::warp_samples_accel_impl(pts, verts, faces, T, P, V, F, threshold, accel, can_pts, can_pts_f32, closest, dist2, face_id, mask, stream, 0, nullptr, 1);
+    return ac::warp_samples_accel_impl(pts, verts, faces, T, P, V, F, threshold, accel, can_pts, can_pts_f32, closest, dist2, face_id, mask, stream, 0, nullptr, 1,
+                                       nullptr, 0, 0);
 }

@@ -328,6 +328,9 @@ class NeRFRenderer(nn.Module):
     # which no inference driver reads, covers the evaluated samples only).  False (default): every output as the reference computes it.
     # drivers.render_animation (render_warp.py's loop, which keeps rgb only) switches it on.
     skip_masked_samples = False
+    # posed-space inference through the harness (render_utils.render_instantnsr_naive): the closest-face searches of a frame start from the faces the previous
+    # frame found for the same (ray, sample slot) -- an upper bound from a real face, so the same pixels bit for bit, with tighter culling (ac_warp_mesh.seed_faces)
+    warp_temporal_seeds = True
     supports_opacity_only = True       # render(..., opacity_only=True) exists (no colour network: the frozen avatar of the opacity loss)
     supports_lean_render = True        # render(..., per_sample=False) exists (render_utils.render_instantnsr_naive asks before passing it)
 

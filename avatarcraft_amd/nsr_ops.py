@@ -313,7 +313,24 @@ class WarpMesh:
                                                 self.accel.data_ptr(), nbytes, L.current_stream(torch.device(device))), "warp_accel_build")
         self.use_mesh_guide = bool(use_mesh_guide)
         self.c = L.ac_warp_mesh(self.verts.data_ptr(), self.faces.data_ptr(), self.T.data_ptr(), self.verts.shape[0], self.faces.shape[0],
-                                float(threshold), float(geo_threshold), int(bool(use_mesh_guide)), L.ptr(self.accel))
+                                float(threshold), float(geo_threshold), int(bool(use_mesh_guide)), L.ptr(self.accel), None, 0)
+        self._seeds = None
+
+    def bind_seeds(self, seeds):
+        """temporal seeds of the closest-face searches for the NEXT render call(s) with this mesh (ac_warp_mesh.seed_faces): an int32 [n_rays, >= T0 + T]
+        device tensor the caller keeps across frames (new_seed_buffer), row r = ray r of the render call; None = off.  Pixels are unchanged bit for bit."""
+        if seeds is None or self.accel is None:
+            self._seeds = None
+            self.c.seed_faces, self.c.seed_stride = None, 0
+            return
+        if seeds.dtype != torch.int32 or seeds.dim() != 2 or seeds.stride(1) != 1 or not seeds.is_cuda:
+            raise RuntimeError("WarpMesh.bind_seeds: an int32 [n_rays, columns] device tensor with contiguous rows")
+        self._seeds = seeds                                 # (kept alive)
+        self.c.seed_faces, self.c.seed_stride = seeds.data_ptr(), int(seeds.stride(0))
+
+    @staticmethod
+    def new_seed_buffer(n_rays, columns, device):
+        return torch.full((int(n_rays), int(columns)), -1, dtype=torch.int32, device=device)
 
 
     def work_counters(self):

@@ -81,6 +81,18 @@ def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_g
     total_eikonal = 0.0
     if not render_can and verts is not None and not isinstance(verts, nsr_ops.WarpMesh):
         verts = nsr_ops.WarpMesh(verts, faces, Ts, device)       # upload the frame's mesh once, not once per ray batch
+    # temporal seeds of the closest-face searches (round 6): the net keeps, per ray and sample slot of a VIEW, the face the previous frame's search found;
+    # each batch of this frame starts its searches from those faces' distances and leaves its own answers for the next frame.  Same pixels bit for bit
+    # (ac_warp_mesh.seed_faces); what it buys is in bench.py's posed_frame leg.  net.warp_temporal_seeds = False switches it off.
+    seed_rows = None
+    if (not render_can and isinstance(verts, nsr_ops.WarpMesh) and not requires_grad and getattr(net, "warp_temporal_seeds", False)
+            and verts.accel is not None and rays_o.is_cuda):
+        cache = net.__dict__.setdefault("_warp_seed_rows", {})
+        key = (str(device), int(total), int(num_steps), int(upsample_steps), int(verts.faces.shape[0]))
+        seed_rows = cache.get(key)
+        if seed_rows is None:
+            cache.clear()                                        # (one view shape at a time: 25 MB per 256 x 256 view of 32 + 64 slots)
+            seed_rows = cache[key] = nsr_ops.WarpMesh.new_seed_buffer(total, 2 * num_steps + upsample_steps, device)
     # the harness keeps rgb / depth / weight_sum / normal only: a no-grad render of this package's NeRFNetwork skips the per-sample outputs
     lean = {"per_sample": False} if (not requires_grad and getattr(net, "supports_lean_render", False)) else {}
     if opacity_only and not requires_grad and getattr(net, "supports_opacity_only", False):
@@ -96,11 +108,15 @@ def render_instantnsr_naive(net, rays_o, rays_d, rays_per_batch=6400, requires_g
         for i in range(0, total, rays_per_batch):
             ro, rd = rays_o[i:i + rays_per_batch], rays_d[i:i + rays_per_batch]
             background_rgb = _background_on(device, ro.shape, bkg_key)
+            if seed_rows is not None:
+                verts.bind_seeds(seed_rows[i:i + rays_per_batch])
             out = net.render(ro.unsqueeze(0), rd.unsqueeze(0), num_steps=num_steps, upsample_steps=upsample_steps, bound=bound, staged=False,
                              bg_color=background_rgb, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0, render_can=render_can, verts=verts,
                              faces=faces, Ts=Ts, perturb=perturb, **lean)
             total_eikonal = total_eikonal + out["gradient_error"]
             rgbs.append(out['rgb']); wsums.append(out['weight_sum']); depths.append(out['depth']); normals.append(out['normal'])
+        if seed_rows is not None:
+            verts.bind_seeds(None)
         cat = lambda ts, dim=0: ts[0] if len(ts) == 1 else torch.cat(ts, dim=dim)      # one batch (every training patch): nothing to copy
         rgb = cat(rgbs, 1).squeeze(0).reshape(-1, 3)
         extra = {"depth": cat(depths, 1).squeeze(0).reshape(-1, 1), "weight_sum": cat(wsums).reshape(-1, 1), "normal": cat(normals).reshape(-1, 3)}

@@ -90,6 +90,31 @@ def make_body(n_lat=40, n_lon=80, seed=3):
     return verts, faces, Ts
 
 
+def make_body_sequence(n_frames=20, n_lat=83, n_lon=83, seed=7):
+    """A synthetic ANIMATION of make_body's capsule for the posed-frame bench (BASELINE config 4 stands on an AMASS pose sequence, which is not in this
+    image): the rest mesh bent by two smooth "joints" -- a rotation about z whose angle grows with height above the hip and one about x below it -- with
+    angles that swing sinusoidally over the sequence (extremities move up to ~8 cm per frame, the size of a limb's motion between AMASS frames at 12 fps).
+    Per frame: verts [V,3] f32 (the posed mesh) and Ts [V,4,4] f64 = bend(frame) @ make_body's rest transforms (rest -> scene, like blended LBS matrices).
+    -> (list of verts, faces, list of Ts)"""
+    verts0, faces, T0 = make_body(n_lat=n_lat, n_lon=n_lon)
+    rs = np.random.RandomState(seed)
+    ph = rs.uniform(0, 2 * np.pi, 2)
+    y = verts0[:, 1].astype(np.float64)
+    up, dn = np.clip(y / 0.85, 0.0, 1.0) ** 2, np.clip(-y / 0.85, 0.0, 1.0) ** 2          # smooth joint weights: 0 at the hip, 1 at the ends
+    out_v, out_T = [], []
+    for t in range(n_frames):
+        a = 0.5 * np.sin(2 * np.pi * t / 20.0 + ph[0]) * up                              # about z, pivot at the origin
+        b = 0.4 * np.sin(2 * np.pi * t / 20.0 + ph[1]) * dn                              # about x
+        B = np.tile(np.eye(4)[None], (verts0.shape[0], 1, 1))
+        ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+        Rz = np.zeros((verts0.shape[0], 3, 3)); Rz[:, 0, 0] = ca; Rz[:, 0, 1] = -sa; Rz[:, 1, 0] = sa; Rz[:, 1, 1] = ca; Rz[:, 2, 2] = 1
+        Rx = np.zeros((verts0.shape[0], 3, 3)); Rx[:, 0, 0] = 1; Rx[:, 1, 1] = cb; Rx[:, 1, 2] = -sb; Rx[:, 2, 1] = sb; Rx[:, 2, 2] = cb
+        B[:, :3, :3] = Rz @ Rx
+        out_v.append(np.einsum("vij,vj->vi", B[:, :3, :3], verts0.astype(np.float64)).astype(np.float32))
+        out_T.append(B @ T0)
+    return out_v, faces, out_T
+
+
 def load_field_params():
     """the synthetic field of BASELINE configs 2 - 5 (W1, b1, W2, b2, Wc1..3, offsets, level amplitudes, inv_s, state-dict entries)"""
     return dict(np.load(os.path.join(DATA, "synthetic_field.npz"), allow_pickle=False))

@@ -42,7 +42,7 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 8 (round 6: ac_debug_hold_cus; the phased occupancy launches are cooperative launches sized by the runtime's
+int ac_version(void);                /* ABI version, currently 9 (round 6: ac_warp_mesh.seed_faces / seed_stride -- the struct grew --, ac_set_occupancy_barrier_ms, ac_debug_hold_cus; the phased occupancy launches are cooperative launches sized by the runtime's
                                       * occupancy figure; 7, round 5, second half: ac_render_rays_occupancy_phased, ac_render_rays_occupancy_train, ac_march_rays_train_scratch -- the
                                       * marcher's scratch grew --; 6, round 5: ac_render_rays_occupancy's max_steps, ac_field_sdf_grid, ac_marching_cubes*,
                                       * ac_density_grid_update, the SH colour input of ac_field; round 4 = 5: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
@@ -588,6 +588,13 @@ typedef struct ac_warp_mesh {
     float geo_threshold;       /* radius of the vertex spheres of the near/far guide (DEFAULT_GEO_THRESH) */
     int32_t use_mesh_guide;
     const void *accel;         /* ac_warp_accel_build output for (verts, faces), or NULL = brute-force search */
+    /* ABI 9 (round 6) -- temporal seeds of the closest-face searches, or NULL: [n_rays][seed_stride] int32 owned by the caller and kept ACROSS FRAMES, row r =
+     * ray r of the launch, columns [0, num_steps) the faces the first search found for the ray's coarse samples, [num_steps, num_steps + T) those of the
+     * second search; -1 = none (fill a new buffer with -1).  A search starts every sample from the exact distance of the face stored for its (ray, slot)
+     * -- the previous frame's answer, a real face of THIS frame's mesh and therefore a valid bound -- and stores what it finds.  Results are unchanged
+     * bit for bit; only the culling gets tighter (an animation's body moves little between frames).  seed_stride >= num_steps + T.  Needs accel. */
+    int32_t *seed_faces;
+    uint32_t seed_stride;
 } ac_warp_mesh;
 
 /* bytes of device scratch ac_render_rays_warped needs for n_rays rays of T = num_steps + upsample_steps samples; if offs is not

@@ -591,3 +591,50 @@ def test_opacity_only_render_changes_nothing_but_the_image(env):
         for k in ("weights_sum", "depth", "normal_map", "gradient_error"):
             assert torch.equal(full[k], lean[k]), (prec, k)
         assert torch.allclose(lean["image"], (1.0 - lean["weights_sum"])[:, None] * bg, atol=1e-6) and not torch.equal(full["image"], lean["image"])
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_temporal_seeds_of_the_closest_face_search_change_no_bit(env, skip):
+    """round 6: ac_warp_mesh.seed_faces -- every (ray, sample slot) starts its closest-face search from the face the PREVIOUS frame found
+    for it.  A five-frame animation of the SMPL-sized body (synthetic.make_body_sequence), 96 x 96 rays: every output of the posed-space renderer, the warp
+    mask and the warped mid points of every frame equal the seedless render bit for bit -- with garbage seeds (face ids of another topology, out of range,
+    -1), with the previous frame's, and with a view change in between; the searches do less work with the previous frame's seeds than without"""
+    from avatarcraft_amd import nsr_ops
+    from avatarcraft_amd.synthetic import make_body_sequence
+    seq_v, faces, seq_T = make_body_sequence(5, 83, 83)
+    ro, rd = make_rays(96, 96, dist=1.8, f=0.78125 * 96)
+    ro2, rd2 = make_rays(96, 96, dist=1.8, f=0.78125 * 96, yaw=0.9)
+    d = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(d)
+    N = ro.shape[0]
+    keys = ("image", "weights_sum", "depth", "normal_map", "mask", "can_mid")
+
+    def render(wm, o, dd):
+        g = nsr_ops.render_rays(env["f"], t(o), t(dd), 32, 32, 1.6, float(env["p"]["inv_s"]), extras=True, warp=wm, skip_masked=skip)
+        torch.cuda.synchronize()
+        return {k: g[k].clone() for k in keys}
+    seeds = nsr_ops.WarpMesh.new_seed_buffer(N, 32 + 64, d)
+    rs = np.random.RandomState(5)
+    seeds.copy_(torch.from_numpy(rs.randint(-3, 40000, (N, 96)).astype(np.int32)))       # garbage: valid ids, ids >= F, negatives
+    work = {True: 0, False: 0}
+    for fi, (v, T_) in enumerate(zip(seq_v, seq_T)):
+        o, dd = (ro2, rd2) if fi == 3 else (ro, rd)                  # (frame 3 from another camera: the seeds are still real faces, just worse ones)
+        wm_a = nsr_ops.WarpMesh(v, faces, T_, d, use_mesh_guide=True)
+        ref = render(wm_a, o, dd)
+        work[False] += wm_a.work_counters()["exact_tests"]
+        wm_b = nsr_ops.WarpMesh(v, faces, T_, d, use_mesh_guide=True)
+        wm_b.bind_seeds(seeds)
+        got = render(wm_b, o, dd)
+        if fi > 0:
+            work[True] += wm_b.work_counters()["exact_tests"]
+        else:
+            work[False] -= wm_a.work_counters()["exact_tests"]       # (frame 0 ran on garbage seeds: not part of the comparison of work)
+        for k in keys:
+            assert torch.equal(got[k], ref[k]), (fi, k)
+        live = ref["mask"].bool()
+        assert 0.02 < float(live.float().mean()) < 0.9
+        assert int((seeds >= 0).sum()) > 0 and int(seeds.max()) < faces.shape[0] + 40000
+    assert work[True] < work[False], work                            # tighter first bounds: fewer exact point-triangle tests over frames 1 .. 4
+    with pytest.raises(RuntimeError):
+        nsr_ops.WarpMesh(seq_v[0], faces, seq_T[0], d).bind_seeds(torch.zeros(N, 96, device=d))          # (not int32)
+    print(f"temporal seeds (skip_masked={skip}): exact tests over 4 frames {work[False]} -> {work[True]}")
