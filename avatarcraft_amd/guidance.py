@@ -116,7 +116,11 @@ class StableDiffusion(nn.Module):
             pred_depth = 2.0 * (pred_depth - pred_depth.min()) / (pred_depth.max() - pred_depth.min()) - 1.0
             pred_depth = torch.cat([pred_depth] * 2)
         t = torch.randint(self.min_step, self.max_step + 1, [1], dtype=torch.long, device=self.device)
+        self._mark("start")
+        if self.channels_last and pred_rgb_512.is_cuda:
+            pred_rgb_512 = pred_rgb_512.contiguous(memory_format=torch.channels_last)
         latents = self.encode_imgs(pred_rgb_512)                    # WITH grad: the only differentiable stage
+        self._mark("vae_encode_fwd")
         with torch.no_grad():
             noise = torch.randn_like(latents)
             latents_noisy = self.scheduler.add_noise(latents, noise, t)
@@ -128,11 +132,46 @@ class StableDiffusion(nn.Module):
                     noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings).sample.float()
             else:
                 noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings).sample
+        self._mark("unet_fwd")
         noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
         noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
         w = 1 - self.alphas[t]
         grad = (w * (noise_pred - noise)).clamp(-1, 1)
         latents.backward(gradient=grad, retain_graph=True)
+        self._mark("vae_bwd")
+
+    # measurement / tuning hooks (not in the reference).  phase_marks: a list that receives (name, torch.cuda.Event) at the phase boundaries of
+    # mannual_backward (bench.py: vae_encode_fwd | unet_fwd | vae_bwd).  channels_last: see tune().
+    phase_marks = None
+    channels_last = False
+
+    def _mark(self, name):
+        if self.phase_marks is not None and torch.cuda.is_available():
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); self.phase_marks.append((name, ev))
+
+    def tune(self, channels_last="unet", miopen_find=True):
+        """PyTorch-level settings for the two networks that keep the reference's precision (fp32 everywhere, no autocast: SURVEY 0.5): NHWC memory format for
+        the convolution stacks of the VAE encoder and the UNet (MIOpen's fp32 kernels for these shapes are NHWC-native: no layout transposes around every
+        convolution), MIOpen's find mode (torch.backends.cudnn.benchmark: the fastest solver per shape, picked once), SDPA attention where the modules
+        allow it (the sd_arch stand-ins call F.scaled_dot_product_attention; diffusers' modules select it through their attention processor)."""
+        if miopen_find:
+            torch.backends.cudnn.benchmark = True
+        # channels_last: "unet" (default) | "vae" | "both" / True | None.  Measured on the SD-1.5-sized stand-in (tools/guidance_tune_probe.py,
+        # profiles/r06_experiments.txt section 8): NHWC helps the UNet's 64 x 64 .. 8 x 8 stages and HURTS the VAE encoder's 512 x 512 ones
+        which = {True: "both", False: None}.get(channels_last, channels_last)
+        self.channels_last = which in ("vae", "both")                # (the image handed to the VAE encoder follows the encoder's format)
+        for name, m in (("vae", self.vae), ("unet", self.unet)):
+            if isinstance(m, torch.nn.Module) and which in (name, "both"):
+                m.to(memory_format=torch.channels_last)
+        for m in (self.vae, self.unet):
+            f = getattr(m, "set_attn_processor", None)
+            if callable(f):
+                try:
+                    from diffusers.models.attention_processor import AttnProcessor2_0
+                    f(AttnProcessor2_0())
+                except Exception:                                # noqa: BLE001 -- an older diffusers: its default stays
+                    pass
+        return self
 
     def calc_grad(self, text_embeddings, pred_rgb, guidance_scale=100):
         """:150-206: the same, returning pred_rgb.grad"""
