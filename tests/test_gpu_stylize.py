@@ -8,6 +8,7 @@
   the loss values and the accumulated gradient of every parameter at the first optimizer.step().
 * the loop itself: one coarse + one fine epoch (head views, background / prompt augmentation) and one fine step of a 256 x 256 view
   (16 patches of 4096 rays through the shared backward scratch), parameters finite and moving."""
+import os
 import random
 
 import numpy as np
@@ -96,6 +97,42 @@ def test_stylize_step0_matches_reference_trainer():
             net._last_train = saved
             combined_backward(**kw)
             terms[name] = net.encoder.embeddings.grad.detach().clone()
+        # ... and the opacity term once more with the REFERENCE's upstream gradient (from its recorded opacities: d = clip(ws) - clip(ws_gt), SmoothL1'(d) 1e5 / n,
+        # stylize.py:187-190) through OUR saved forward: what is left of that term's error when the upstream is taken out of it (the attribution below)
+        pred, gt = g["weight_sum"].reshape(-1).astype(np.float64), g["weight_sum_gt"].reshape(-1).astype(np.float64)
+        dref = np.clip(pred, 0, 1) - np.clip(gt, 0, 1)
+        gws_ref = np.where(np.abs(dref) < 1.0, dref, np.sign(dref)) * (1e5 / pred.shape[0]) * ((pred >= 0) & (pred <= 1))
+        terms["_upstream_mine"] = g_weights_sum.detach().reshape(-1).double().cpu().numpy()
+        terms["_upstream_ref"] = gws_ref
+        flat.zero_()
+        net._last_train = saved
+        combined_backward(g_weights_sum=torch.from_numpy(gws_ref).to(g_weights_sum).reshape(g_weights_sum.shape))
+        terms["opacity_ref_upstream"] = net.encoder.embeddings.grad.detach().clone()
+        # ... and the share of the rays whose opacity the two forwards render most differently (a sample placed on the other side of a near-tie of the
+        # inverse-CDF sampler moves a ray's fine-level cells): their own opacity-term gradient, alone
+        ws_mine = saved[0]["weights_sum"].detach().reshape(-1).double().cpu().numpy()
+        dws = np.abs(ws_mine - pred) + np.abs(saved[0]["image"].detach().double().cpu().numpy() - g["rgb_grad_render"]).max(axis=1)
+        terms["_dws"] = dws
+        suspects = np.argsort(-dws)[:3]
+        terms["_suspects"] = suspects
+        only = torch.zeros_like(g_weights_sum).reshape(-1)
+        only[torch.from_numpy(suspects).to(only.device)] = g_weights_sum.reshape(-1)[torch.from_numpy(suspects).to(only.device)]
+        flat.zero_()
+        net._last_train = saved
+        combined_backward(g_weights_sum=only.reshape(g_weights_sum.shape))
+        terms["opacity_suspects_only"] = net.encoder.embeddings.grad.detach().clone()
+        if __import__("os").environ.get("AC_DIAG_OPACITY_ENTRIES"):           # diagnosis (profiles/r06_experiments.txt section 9): which rays feed the entries above 3e-3
+            ref_o_ = g["emb_grad_terms"][2]
+            e_ = np.abs(terms["opacity"][emb_idx].cpu().numpy() - ref_o_).max(axis=1) / np.abs(ref_o_).max()
+            ab_ = np.nonzero(e_ > 3e-3)[0]
+            rows = emb_idx[torch.from_numpy(ab_).to(emb_idx.device)]
+            per_ray = np.zeros((g_weights_sum.numel(), ab_.size, 2))
+            for r in range(g_weights_sum.numel()):
+                one = torch.zeros_like(g_weights_sum).reshape(-1); one[r] = g_weights_sum.reshape(-1)[r]
+                flat.zero_(); net._last_train = saved
+                combined_backward(g_weights_sum=one.reshape(g_weights_sum.shape))
+                per_ray[r] = net.encoder.embeddings.grad.detach()[rows].cpu().numpy()
+            terms["_per_ray"] = (ab_, per_ray, terms["opacity"][rows].cpu().numpy(), ref_o_[ab_], rows.cpu().numpy())
         flat.copy_(total)
     net.backward_last = backward_per_term
     with _Replay(g) as rp:
@@ -129,7 +166,55 @@ def test_stylize_step0_matches_reference_trainer():
     # (|d| ~ 1e-3) that the two forwards reproduce to ~1e-5 each, and a sample placed differently on one ray moves single table entries -- it alone
     # carries the loose bound, and the bound is on ITS scale, not on the sum's
     net.backward_last = combined_backward
-    assert set(terms) == {"rgb", "eikonal", "opacity"}
+    assert {"rgb", "eikonal", "opacity", "opacity_ref_upstream"} <= set(terms)
+    # ---- the loosest margin of the repository, diagnosed (What's weak 1c; profiles/r06_experiments.txt section 9).  4 of the 4096 sampled
+    # entries of the opacity term exceed 3e-3 of the term's max (worst 1.0e-2).  What they are NOT: the upstream d = clip(weight_sum) - clip(weight_sum_gt)
+    # (fed with the REFERENCE's upstream through our forward and backward they keep their error: 9.97e-3), the 8-byte queue records (the full-fp32 library
+    # gives the same four numbers), the rays whose opacity the two forwards render most differently (they do not touch these entries).  What they ARE
+    # (per-ray decomposition, AC_DIAG_OPACITY_ENTRIES=1): entries of the two finest levels (13, 14: cells of 2.2 / 1.6 mm) that receive ONE sample of ONE
+    # ray (at most three), at a corner FAR from that sample -- a trilinear weight of ~1e-2 .. 1e-3 -- times the 1e5-weighted upstream: e.g. entry 4733259,
+    # mine (-0.2977, -1.7123), reference (-0.3440, -1.9778): both channels scaled by 0.866, i.e. the corner's WEIGHT differs by 13 %, which is a 1.5e-6
+    # difference in the sample's position (the two fp32 forwards' inverse-CDF lerps: the same roundings that cause the recorded index flip of the goldens).
+    # They are small entries (<= 5 % of the term's max).  Recorded here: their number, level, size; every OTHER sampled entry is held to 3e-3.
+    ref_o = g["emb_grad_terms"][2]
+    mx_o = float(np.abs(ref_o).max())
+    err_mine = np.abs(terms["opacity"][emb_idx].cpu().numpy() - ref_o).max(axis=1) / mx_o
+    err_refup = np.abs(terms["opacity_ref_upstream"][emb_idx].cpu().numpy() - ref_o).max(axis=1) / mx_o
+    above = np.nonzero(err_mine > 3e-3)[0]
+    up_m, up_r = terms["_upstream_mine"], terms["_upstream_ref"]
+    rel_up = np.abs(up_m - up_r) / np.maximum(np.abs(up_r), 1e-30)
+    opacity_attribution = {"entries_sampled": int(err_mine.shape[0]), "entries_above_3e-3_with_own_upstream": int(above.size),
+                           "worst_with_own_upstream": float(err_mine.max()), "worst_with_reference_upstream": float(err_refup.max()),
+                           "worst_of_those_entries_with_reference_upstream": float(err_refup[above].max()) if above.size else 0.0,
+                           "upstream_rel_diff_median_and_max_over_rays": [float(np.median(rel_up)), float(rel_up.max())],
+                           "upstream_abs_diff_max_over_rays_in_units_of_1e5_over_n": float(np.abs(up_m - up_r).max() / (1e5 / up_r.shape[0]))}
+    sus = np.abs(terms["opacity_suspects_only"][emb_idx].cpu().numpy()).max(axis=1) / mx_o
+    opacity_attribution.update({"suspect_rays": [int(r) for r in terms["_suspects"]], "suspect_rays_abs_opacity_diff": [float(terms["_dws"][r]) for r in terms["_suspects"]],
+                                "median_abs_opacity_diff": float(np.median(terms["_dws"])),
+                                "entries_above": [int(i) for i in above[:16]], "their_error": [float(err_mine[i]) for i in above[:16]],
+                                "their_error_with_reference_upstream": [float(err_refup[i]) for i in above[:16]],
+                                "suspect_rays_own_gradient_at_those_entries_of_max": [float(sus[i]) for i in above[:16]],
+                                "entries_touched_by_suspect_rays": int((sus > 0).sum()),
+                                "worst_error_outside_suspect_rays_entries": float(err_mine[sus == 0].max())})
+    print("opacity attribution:", json.dumps(opacity_attribution))
+    if "_per_ray" in terms:
+        ab_, per_ray, mine_, ref_, rows_ = terms["_per_ray"]
+        offs = np.asarray(net.encoder.offsets.cpu().numpy())
+        for j in range(ab_.size):
+            c = np.abs(per_ray[:, j]).max(axis=1)
+            top = np.argsort(-c)[:5]
+            lvl = int(np.searchsorted(offs, rows_[j], side="right") - 1)
+            print(f"  entry {int(rows_[j])} (level {lvl}): mine {mine_[j]}, reference {ref_[j]}, sum over rays {per_ray[:, j].sum(0)}; contributing rays {int((c > 0).sum())}; "
+                  f"top rays {[(int(r), [float(x) for x in per_ray[r, j]]) for r in top]}; |dws| of those {[float(terms['_dws'][r]) for r in top]}")
+    offs_h = np.asarray(net.encoder.offsets.cpu().numpy())
+    lv_above = [int(np.searchsorted(offs_h, int(emb_idx[i]), side="right") - 1) for i in above]
+    size_above = [float(np.abs(ref_o[i]).max() / mx_o) for i in above]
+    opacity_attribution.update({"levels_of_entries_above": lv_above, "their_size_of_max": size_above})
+    worst["opacity_term_attribution"] = opacity_attribution
+    json.dump(worst, open("gpurun_out/trainer_step0_parity.json", "w"), indent=1)
+    assert above.size <= 8, opacity_attribution                              # observed 4 of 4096
+    assert all(l >= 12 for l in lv_above) and all(z <= 0.1 for z in size_above), opacity_attribution      # fine levels, small entries (see above)
+    assert float(err_mine[np.setdiff1d(np.arange(err_mine.shape[0]), above)].max(initial=0.0)) <= 3e-3   # the tightened bound on everything else
     tsum = terms["rgb"].double() + terms["eikonal"].double() + terms["opacity"].double()
     tot = net.encoder.embeddings.grad.detach().double()
     lin = float((tsum - tot).abs().max() / tot.abs().max())
@@ -141,6 +226,7 @@ def test_stylize_step0_matches_reference_trainer():
         l2 = float(torch.sqrt((terms[name].double() ** 2).sum()))
         term_err[name + "_l2_rel"] = abs(l2 - float(g["emb_terms_l2"][j])) / float(g["emb_terms_l2"][j])
     worst.update({"table_term." + k: v for k, v in term_err.items()}); worst["table_terms_sum_vs_combined"] = lin
+    worst["opacity_term_attribution"] = opacity_attribution
     json.dump(worst, open("gpurun_out/trainer_step0_parity.json", "w"), indent=1)
     # (the binned scatter sums in a fixed-point scale chosen from the level's largest |v| of THAT launch, so a term alone and the sum are rounded on
     #  different grids: 1.5e-5 of max observed)
@@ -149,7 +235,7 @@ def test_stylize_step0_matches_reference_trainer():
     assert term_err["rgb"] <= 3e-3 and term_err["eikonal"] <= 1e-2 and term_err["opacity"] <= 2e-2, term_err
     assert term_err["rgb_l2_rel"] <= 1e-3 and term_err["eikonal_l2_rel"] <= 1e-3 and term_err["opacity_l2_rel"] <= 3e-3, term_err
     for k, e in worst.items():
-        if not k.startswith("table_term"):
+        if not k.startswith("table_term") and not isinstance(e, dict):
             assert e <= (2e-2 if k == "encoder.embeddings" else 1e-3), (k, e, worst)           # total: the opacity term dominates it (1.0e-2 observed)
     nnz = int((net.encoder.embeddings.grad.abs().sum(1) > 0).sum())
     assert abs(nnz - int(g["emb_nnz"])) <= 0.01 * int(g["emb_nnz"])
