@@ -40,7 +40,7 @@ class ac_core_saved(C.Structure):
 
 
 class ac_core_upstream(C.Structure):
-    _fields_ = [("g_image", vp), ("g_weights_sum", vp), ("g_depth", vp), ("g_normal_map", vp), ("g_eik", vp)]
+    _fields_ = [("g_image", vp), ("g_weights_sum", vp), ("g_depth", vp), ("g_normal_map", vp), ("g_eik", vp), ("eik_group_rays", i32), ("eik_den_stride", i32)]
 
 
 class ac_core_grads(C.Structure):

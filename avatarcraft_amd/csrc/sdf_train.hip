@@ -501,14 +501,17 @@ __global__ __launch_bounds__(SAVED ? TW_S * 64 : TBLOCK) void sdf_stencil_bwd_ke
                     for (int r = 0; r < 4; ++r) TA[(16 * t + 4 * g + r) * TLD + n] = av.a[t][r];
             }
             if constexpr (PIPE) {
-                // hi = the value's top 16 bits, lo = the top 16 bits of (value - hi) (split8_bf16's truncation split), each a 2-byte store of a register's
-                // HIGH half (ds_write_b16_d16_hi: no shift) at [row][sample n]
+                // hi = the value ROUNDED TO NEAREST bf16 (v_cvt_pk_bf16_f32), lo = (value - hi) rounded likewise, 2-byte stores at [row][sample n].  Not
+                // split8_bf16's truncation: a weight gradient is a sum of ~3.7 M such products per entry, and truncation errors all point towards zero -- they
+                // add up coherently.  dW1 vs the fp64 oracle, of max (tests/test_oracle_backward.py; fp32 products before: 1.9e-4; bound 3e-4):
+                //   hi and lo truncated 3.1e-4 | hi truncated (a free d16_hi store), lo rounded 2.2e-4 (the dropped lo x lo term keeps the product's sign, and the
+                //   three separately back-propagated loss terms add up to the joint pass only to 2.1e-4) | both rounded 1.2e-4  <- shipped (+0.03 ms per patch)
                 unsigned char *const Bw = BF + ((step & 1u) ? BF_BYTES : 0);
                 auto put = [&](int part_hi, int part_lo, int row, float v) {
-                    const uint32_t u = __float_as_uint(v);
-                    const uint32_t rl = __float_as_uint(v - __uint_as_float(u & 0xffff0000u));
-                    *reinterpret_cast<uint16_t *>(Bw + part_hi + row * BF_ROW + 2 * n) = (uint16_t)(u >> 16);
-                    *reinterpret_cast<uint16_t *>(Bw + part_lo + row * BF_ROW + 2 * n) = (uint16_t)(rl >> 16);
+                    const __bf16 hb = (__bf16)v;
+                    const __bf16 lb = (__bf16)(v - (float)hb);
+                    *reinterpret_cast<__bf16 *>(Bw + part_hi + row * BF_ROW + 2 * n) = hb;
+                    *reinterpret_cast<__bf16 *>(Bw + part_lo + row * BF_ROW + 2 * n) = lb;
                 };
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -1883,7 +1886,8 @@ __global__ __launch_bounds__(256) void core_normals_kernel(const float *__restri
 // torch.linalg.norm's backward)
 __global__ __launch_bounds__(256) void core_mid_kernel(const float *__restrict__ grad, const float *__restrict__ pts, const float *__restrict__ g_sdf,
                                                        const float *__restrict__ g_nrm_a, const float *__restrict__ g_nrm_b, const float *__restrict__ g_eik,
-                                                       const float *__restrict__ eik_den, uint32_t B, float *__restrict__ g_s16, float *__restrict__ g_grad)
+                                                       const float *__restrict__ eik_den, uint32_t B, float *__restrict__ g_s16, float *__restrict__ g_grad,
+                                                       uint32_t group_samples, uint32_t den_stride)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -1896,7 +1900,8 @@ __global__ __launch_bounds__(256) void core_mid_kernel(const float *__restrict__
     if (g_eik) {
         const float px = pts[b3], py = pts[b3 + 1], pz = pts[b3 + 2];
         const float relax = __builtin_sqrtf((px * px + py * py) + pz * pz) < 1.2f ? 1.0f : 0.0f;
-        if (r > 0.0f) k += g_eik[0] * relax * 2.0f * (r - 1.0f) / (eik_den[0] * r);
+        const uint32_t grp = group_samples ? b / group_samples : 0u;      // (several patches in one launch: ac_core_upstream.eik_group_rays)
+        if (r > 0.0f) k += g_eik[grp] * relax * 2.0f * (r - 1.0f) / (eik_den[(size_t)grp * den_stride] * r);
     }
     g_grad[b3] = ux / c + k * gx; g_grad[b3 + 1] = uy / c + k * gy; g_grad[b3 + 2] = uz / c + k * gz;
     g_s16[(size_t)b * 16] += g_sdf[b];
@@ -2381,7 +2386,9 @@ AC_API int ac_render_core_backward(const ac_field *field, const ac_render_opts *
     }
     if (int rc = color_backward_impl(field, sv->pts, nrm, sv->sdf_out16, g_col, B, g_nrm_b, g_s16, gr->g_color_params, sb + l.part_col,
                                      ac_color_backward_scratch(B), stream, sv->sh_bias, (uint32_t)T, gr->g_sh_tiles)) return rc;
-    hipLaunchKernelGGL(core_mid_kernel, dim3(eb), dim3(256), 0, st, sv->gradient, sv->pts, g_sdf, g_nrm_a, g_nrm_b, up->g_eik, sv->eik_den, B, g_s16, g_grad);
+    if (up->eik_group_rays < 0 || (up->eik_group_rays > 0 && up->eik_den_stride < 1)) { ac::set_error("render_core_backward: eik_group_rays < 0 or eik_den_stride < 1"); return AC_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(core_mid_kernel, dim3(eb), dim3(256), 0, st, sv->gradient, sv->pts, g_sdf, g_nrm_a, g_nrm_b, up->g_eik, sv->eik_den, B, g_s16, g_grad,
+                       (uint32_t)up->eik_group_rays * (uint32_t)T, (uint32_t)(up->eik_group_rays > 0 ? up->eik_den_stride : 0));
     if (int rc = sdf_stencil_backward_impl(field, sv->pts, g_s16, g_grad, B, op->bound, op->fd_eps, gfeat, gr->g_sdf_params, sb + l.part_sdf,
                                            ac_sdf_stencil_backward_scratch(B), stream, sv->feat7)) return rc;
     if (int rc = hash_stencil_backward_split(gfeat, sv->pts, field->offsets, gr->g_table, B, 2, 16, field->S, field->H, op->fd_eps, op->bound,

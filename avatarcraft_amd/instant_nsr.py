@@ -274,10 +274,46 @@ class NeRFRenderer(nn.Module):
                                       precision=self.render_precision, opacity_only=bool(opacity_only))
         return out["image"], out["weights_sum"][:, None]
 
+    def render_view_train(self, rays_o, rays_d, num_steps, upsample_steps, bound, draw_fn, batch_size, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0):
+        """The TRAINING render of a whole view (stylize.py:143-152 renders it patch by patch: 256 x 256 = 16 patches of 4096 rays) as ONE launch that keeps
+        its per-sample outputs for ONE backward_last() over all patches -- the patches' gradients add up before the single optimizer.step() anyway
+        (stylize.py:199).  Random draws exactly as the patch loop makes them, patch by patch: draw_fn(k, n) -> the background of patch k's n rays (it may make
+        further draws of its own there, e.g. the frozen avatar's background), then the jitter noise of those rays.  The eikonal term stays a ratio PER PATCH
+        (instant_nsr.py:266-272): eik [P] are the patches' gradient_errors (the bits a launch of the patch alone reports), and backward_last takes one g_eik
+        per patch.  -> (rgb [N,3], eik [P], weight_sum [N,1]); pixels equal the patch-by-patch renders bit for bit."""
+        if not (self.training and self.manual_backward_supported()):
+            raise RuntimeError("render_view_train: needs the default model in train mode on the GPU")
+        ro = rays_o.reshape(-1, 3).float().contiguous()
+        rd = rays_d.reshape(-1, 3).float().contiguous()
+        N, device = ro.shape[0], ro.device
+        noise = torch.empty((N, num_steps), dtype=torch.float32, device=device)
+        bgs = []
+        for k, i in enumerate(range(0, N, batch_size)):
+            n = min(batch_size, N - i)
+            b = draw_fn(k, n)
+            b = torch.ones((n, 3), dtype=torch.float32, device=device) if b is None else torch.as_tensor(b, dtype=torch.float32, device=device)
+            b = b.reshape(-1, 3) if b.numel() >= 3 else b.reshape(1, 1).expand(1, 3)
+            bgs.append(b.expand(n, 3) if b.shape[0] == 1 else b)
+            dst = noise[i:i + n]
+            r = torch.rand((n, num_steps), device=device, out=dst)
+            if r.data_ptr() != dst.data_ptr():                   # (a replaced torch.rand that ignores `out`: tests replaying recorded draws)
+                dst.copy_(r)
+        bg = torch.cat(bgs).contiguous() if len(bgs) > 1 else bgs[0].contiguous()
+        with torch.no_grad():
+            field, inv_s = self._field(), self.forward_variance()
+            out = nsr_ops.render_rays(field, ro, rd, num_steps, upsample_steps, bound, inv_s, bg=bg, noise=noise, cos_anneal_ratio=cos_anneal_ratio,
+                                      normal_epsilon_ratio=normal_epsilon_ratio, extras=True, train_extras=True, precision=self.render_precision)
+            groups = nsr_ops.eikonal_groups(out["eik"], int(batch_size))
+        self._last_train = (out, ro, rd, bg, field)
+        self._last_train_groups = (int(batch_size), groups)
+        self._guard_finite(groups[:, 0].sum())
+        return out["image"], groups[:, 0], out["weights_sum"][:, None]
+
     def backward_last(self, g_image=None, g_weights_sum=None, g_eik=None, split=None):
         """split = (level, side stream): see nsr_ops.render_core_backward (the gradient of table levels >= level is final when the side stream runs)"""
         out, ro, rd, bg, field = self._last_train
         self._last_train = None
+        eik_groups = self.__dict__.pop("_last_train_groups", None)
         enc = self.encoder
         prm = [enc.embeddings, self.deviation_net.variance] + [t for l in self.sdf_net for t in (l.weight_v, l.weight_g, l.bias)] + \
               [t for l in self.color_net for t in (l.weight_v, l.weight_g)]
@@ -285,7 +321,7 @@ class NeRFRenderer(nn.Module):
             if t.grad is None:
                 t.grad = torch.zeros_like(t)
         g_sdf_p, g_col_p, g_invs, *g_vd = nsr_ops.render_core_backward(field, out.opts, out, ro, rd, bg, g_image, g_weights_sum, None, None, g_eik,
-                                                                       enc.embeddings.grad, split=split)
+                                                                       enc.embeddings.grad, split=split, eik_groups=eik_groups)
         c0_src, c0_stride = (g_col_p, 0), 32
         if g_vd:                                                 # use_viewdirs: the gradient of the [64,37] effective matrix, columns in the reference's order
             c0_src, c0_stride = (nsr_ops.join_viewdir_grad(g_col_p[:2048].view(64, 32)[:, :21], g_vd[0]).contiguous(), 0), 37

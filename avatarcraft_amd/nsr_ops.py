@@ -434,7 +434,7 @@ class _RenderCore(torch.autograd.Function):
         g_invs = torch.empty(N, dtype=_F32, device=dev)
         sv = L.ac_core_saved(z_vals.data_ptr(), pts.data_ptr(), sdf.data_ptr(), sdf16.data_ptr(), gradient.data_ptr(), color.data_ptr(),
                              eik_res[1:].data_ptr(), feat7.data_ptr() if ctx.has_feat else None, ctx.posed[0].data_ptr() if ctx.posed else None)
-        upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
+        upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik), 0, 0)
         gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
         scratch, need = core_scratch(field, N, T, dev)
         op = ctx.opts[0]
@@ -584,7 +584,20 @@ def _viewdir_weight_grad(vd, N, T):
     return tiles.view(N, T // 16, 64).sum(1).t().matmul(sh)
 
 
-def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, g_depth, g_nmap, g_eik, g_table, split=None):
+def eikonal_groups(eik, group_rays):
+    """gradient_error (instant_nsr.py:266-272) per group of `group_rays` consecutive rays of a launch, from its per-ray partial sums eik [N,2]
+    (ac_render_out.eik): [groups, 2] = (error, denominator), each by ac_eikonal_reduce2 -- the bits a launch of that group alone reports as eik_res"""
+    N = eik.shape[0]
+    G = (N + group_rays - 1) // group_rays
+    res = torch.empty((G, 2), dtype=_F32, device=eik.device)
+    st = L.current_stream(eik.device)
+    for k in range(G):
+        sl = eik[k * group_rays:(k + 1) * group_rays]
+        L.check(L.lib().ac_eikonal_reduce2(sl.data_ptr(), sl.shape[0], res[k].data_ptr(), st), "eikonal_reduce2")
+    return res
+
+
+def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, g_depth, g_nmap, g_eik, g_table, split=None, eik_groups=None):
     """ac_render_core_backward on the outputs of a render_rays(..., train_extras=True) launch (`out`, its .opts): the table gradient is accumulated
     into g_table; returns (g_sdf_params [3344], g_color_params [7168], g_inv_s_per_ray [N][, g_Wc1_sh [64,16] for a field with view directions]) w.r.t. the
     EFFECTIVE matrices.
@@ -598,9 +611,15 @@ def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, 
     g_sdf_p = torch.empty(64 * 36 + 16 * 64 + 16, dtype=_F32, device=dev)
     g_col_p = torch.empty(64 * 32 + 64 * 64 + 16 * 64, dtype=_F32, device=dev)
     g_invs = torch.empty(N, dtype=_F32, device=dev)
+    # eik_groups = (group_rays, res [G,2] from eikonal_groups): the launch holds G patches whose eikonal terms are separate ratios; g_eik is then [G]
+    den_ptr = out["eik_res"][1:].data_ptr() if eik_groups is None else eik_groups[1][:, 1:].data_ptr()
     sv = L.ac_core_saved(z_vals.data_ptr(), out["pts"].data_ptr(), out["sdf"].data_ptr(), out["sdf_out16"].data_ptr(), out["gradient"].data_ptr(),
-                         out["color"].data_ptr(), out["eik_res"][1:].data_ptr(), L.ptr(out.get("feat7") if hasattr(out, "get") else None))
-    upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik))
+                         out["color"].data_ptr(), den_ptr, L.ptr(out.get("feat7") if hasattr(out, "get") else None))
+    upg = L.ac_core_upstream(L.ptr(g_image), L.ptr(g_wsum), L.ptr(g_depth), L.ptr(g_nmap), L.ptr(g_eik), 0, 0)
+    if eik_groups is not None:
+        if g_eik is not None and g_eik.numel() != eik_groups[1].shape[0]:
+            raise RuntimeError("render_core_backward: one g_eik per group of rays")
+        upg.eik_group_rays, upg.eik_den_stride = int(eik_groups[0]), 2
     gr = L.ac_core_grads(g_table.data_ptr(), g_sdf_p.data_ptr(), g_col_p.data_ptr(), g_invs.data_ptr())
     if split is not None:
         gr.split_level, gr.side_stream = int(split[0]), int(split[1].cuda_stream)

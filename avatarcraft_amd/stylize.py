@@ -168,6 +168,14 @@ _CONSTS = {}
 PAIR_STEP_RENDERS = True
 # a view of several patches (fine stage): render_val and the frozen avatar's render as one launch per VIEW instead of one per patch (same values)
 WHOLE_VIEW_RENDERS = os.environ.get("AC_WHOLE_VIEW_RENDERS", "1") != "0"
+# Round 6, built, measured, OFF by default: the TRAINING render and its backward of a view of several patches (the fine stage) as
+# ONE forward launch + ONE ac_render_core_backward over all patches instead of one pair per patch (NeRFNetwork.render_view_train): the patches' gradients
+# add up before the single optimizer.step() (stylize.py:199), the random draws are made patch by patch in the reference's order, the eikonal term stays a
+# ratio per patch.  256 x 256 view, same box (bench.py sds_view_fine): training forward 14.65 -> 13.67 ms, backward 34.8 -> 36.5 ms, view 73.7 -> 74.4 ms.
+# The 16 x smaller per-patch intermediates (470 MB of feature gradients, ~1 GB of scatter queues, 117 MB of saved stencil features) are written and read
+# back within a patch's backward and largely stay in the 256 MB Infinity Cache; the whole view's 7.5 GB + 16 GB stream through HBM -- that costs more than
+# the 15 saved fixed parts of bucket_accumulate and ~450 small launches return.  Scratch: ~75 GB.  AC_WHOLE_VIEW_BACKWARD=1 switches it on.
+WHOLE_VIEW_BACKWARD = os.environ.get("AC_WHOLE_VIEW_BACKWARD", "0") == "1"
 # data-parallel steps: all-reduce the table gradient of levels >= ALLREDUCE_SPLIT_LEVEL (33.5 of the 49 MB) while the scatter still accumulates the
 # coarser levels and the MLP gradients are formed (ac_core_grads.side_stream / split_level).  Off by default: no multi-GPU node was available to measure it
 # (at most the ~0.15 ms the second accumulation launch + ac_param_grads take can be hidden); AC_OVERLAP_ALLREDUCE=1 or sds_step(overlap_allreduce=True).
@@ -270,7 +278,48 @@ def _sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_
         _, ws_gt_view = net_gt.render_view_nograd(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND,
                                                   lambda n: _background_on(rays_o.device, (n, 3), bkg_key), bs, opacity_only=True)
         mark("render_gt_view")
-    for i in range(0, n_rays, bs) if manual else ():
+    whole_bwd = (manual and WHOLE_VIEW_BACKWARD and paired is None and n_rays > bs and n_rays % bs == 0 and hasattr(net_style, "render_view_train")
+                 and hasattr(net_gt, "render_view_nograd") and not net_gt.training and getattr(net_gt, "_fused_supported", lambda: False)()
+                 and not getattr(net_gt, "cuda_ray", False))
+    if whole_bwd:
+        # one training launch + one backward for the whole view (see WHOLE_VIEW_BACKWARD).  Draw order per patch as in the loop below: the training render's
+        # background, its jitter noise (device generator), the frozen avatar's background (host generator, after the training render's) -- kept by stashing
+        # the frozen avatar's backgrounds when they are random (constant ones were rendered above already: ws_gt_view)
+        P = n_rays // bs
+        gt_bgs = []
+
+        def draw(k, n):
+            b = _background_on(rays_o.device, (n, 3), bkg_key)
+            if ws_gt_view is None:
+                gt_bgs.append(_background_on(rays_o.device, (n, 3), bkg_key))
+            return b
+        rgb, eik_p, ws_all = net_style.render_view_train(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND, draw, bs)
+        mark("render_grad_forward")
+        with torch.no_grad():
+            if ws_gt_view is None:
+                _, ws_gt_view = net_gt.render_view_nograd(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND, lambda n: gt_bgs.pop(0), bs, opacity_only=True)
+            g_ws, opa = nsr_ops.sds_upstream(ws_all, ws_gt_view, 1e5 / bs, want_grad=use_opacity)          # (each patch's mean: 1e5 / its ray count)
+            opa_vals.append(opa[0] / P)
+            nan_flags.append(eik_p.sum())
+            g_eik = None
+            if w_eikonal > 0.0:
+                g_eik = torch.full((P,), float(w_eikonal), dtype=torch.float32, device=rays_o.device)
+                eik_vals.append((eik_p * w_eikonal).mean())
+            mark("render_gt_and_losses")
+            if overlap:
+                emb = net_style.encoder.embeddings
+                offs = net_style._offsets_host()
+                base = (emb.grad.data_ptr() - flat_grad.data_ptr()) // 4
+                assert 0 <= base and base + emb.grad.numel() <= flat_grad.numel(), "encoder.embeddings.grad must be a view of flat_grad"
+                hi_range = (base + 2 * int(offs[ALLREDUCE_SPLIT_LEVEL]), base + 2 * int(offs[-1]))
+                side = _side_stream(rays_o.device)
+                net_style.backward_last(g_image=grad_rays, g_weights_sum=g_ws, g_eik=g_eik, split=(ALLREDUCE_SPLIT_LEVEL, side))
+                with torch.cuda.stream(side):
+                    work_hi = torch.distributed.all_reduce(flat_grad[hi_range[0]:hi_range[1]], op=early_op, group=process_group, async_op=True)
+            else:
+                net_style.backward_last(g_image=grad_rays, g_weights_sum=g_ws, g_eik=g_eik)
+        mark("backward")
+    for i in range(0, n_rays, bs) if (manual and not whole_bwd) else ():
         # The same three terms WITHOUT autograd (avatarcraft_amd.NeRFNetwork): the training render keeps its per-sample outputs, the upstream
         # gradients of (image, weights_sum, gradient_error) are written down directly (d sum(rgb * g) = g; d (eik * w) = w; the opacity term through
         # ac_sds_upstream) and go through ac_render_core_backward + ac_param_grads into .grad -- ~15 launches instead of ~80 per patch.

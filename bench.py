@@ -230,8 +230,8 @@ def time_sds_fine_view(dev, p, table, steps=2):
     ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=0.0, pitch=0.0)
     ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
     out = {}
-    for name, whole in (("patch_by_patch", False), ("whole_view_renders", True)):
-        ST.WHOLE_VIEW_RENDERS = whole
+    for name, whole, whole_b in (("patch_by_patch", False, False), ("whole_view_renders", True, False), ("whole_view_backward", True, True)):
+        ST.WHOLE_VIEW_RENDERS, ST.WHOLE_VIEW_BACKWARD = whole, whole_b
         ST.sds_step(net, net_gt, ro, rd, (256, 256), opt, guidance, batch_size=4096, flat_grad=flat)       # warm-up
         torch.cuda.synchronize()
         marks = []
@@ -245,12 +245,16 @@ def time_sds_fine_view(dev, p, table, steps=2):
             if n1 != "start":
                 phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
         out[name] = {"ms_per_view": ms, "phase_ms": {k: round(v, 3) for k, v in phases.items()}}
-    ST.WHOLE_VIEW_RENDERS = True
+    ST.WHOLE_VIEW_RENDERS, ST.WHOLE_VIEW_BACKWARD = True, False
+    from avatarcraft_amd import nsr_ops as _ops
+    _ops.free_scratch()                                      # (the whole-view backward's ~75 GB of scratch)
     launched = 16 * sum(SDS_BYTES_LAUNCHED.values())
     ms = out["whole_view_renders"]["ms_per_view"]
     ach = launched / (ms * 1e-3) / 1e9
     return {"ms_per_view": ms, "rays_per_view": 65536, "patches": 16, "steps": steps, "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)",
             "phase_ms": out["whole_view_renders"]["phase_ms"], "patch_by_patch": out["patch_by_patch"],
+            "whole_view_backward": dict(out["whole_view_backward"], note="the training forward and the backward of all 16 patches as one launch each (stylize.WHOLE_VIEW_BACKWARD, "
+                                        "off by default: its 16 x larger intermediates leave the Infinity Cache; gradients equal to 2e-6 of max)"),
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_view": launched,
                          "note": "16 x the coarse step's launched bytes (render_val, training forward, frozen render, stencil features, table scatter per patch)"},
             "note": "render_val and the frozen avatar's opacity render are one launch per view (bit-identical to the 16 per-patch launches: same draws in the "

@@ -520,7 +520,14 @@ typedef struct ac_core_saved {
     const float *sh_bias;                                                 /* a field with view directions (ac_field.Wc1_sh) only: ac_sh_bias of the
                                                                            * forward's rays, [N,64]; NULL otherwise (ABI version 6)                  */
 } ac_core_saved;
-typedef struct ac_core_upstream { const float *g_image, *g_weights_sum, *g_depth, *g_normal_map, *g_eik; } ac_core_upstream;
+typedef struct ac_core_upstream {
+    const float *g_image, *g_weights_sum, *g_depth, *g_normal_map, *g_eik;
+    /* ABI 9 (round 6): SEVERAL patches of a view in one backward (stylize.py:143-199 back-propagates a 256 x 256 view as 16 patches of 4096 rays whose
+     * gradients add up before the one optimizer.step()).  The eikonal term is a RATIO per patch (instant_nsr.py:266-272), so with eik_group_rays > 0 the
+     * rays [k * eik_group_rays, (k + 1) * eik_group_rays) form patch k, whose upstream is g_eik[k] and whose denominator is
+     * saved->eik_den[k * eik_den_stride]; 0 = the whole launch is one patch (g_eik[0], eik_den[0]). */
+    int32_t eik_group_rays, eik_den_stride;
+} ac_core_upstream;
 typedef struct ac_core_grads {
     float *g_table, *g_sdf_params, *g_color_params, *g_inv_s_per_ray;
     /* data-parallel training (stylize.py under torch.distributed: one all-reduce of the flat gradient per step): with side_stream != NULL the table

@@ -555,3 +555,53 @@ def test_a_cuda_ray_style_net_trains_through_its_own_render():
                                          num_steps=64, upsample_steps=64, bound=1.6)
     img = rgb_val.reshape(32, 32, 3).permute(2, 0, 1).unsqueeze(0)
     assert torch.equal(img, seen["img"])
+
+
+@pytest.mark.parametrize("bkg", ["white", "noise"])
+def test_fine_view_whole_view_backward_equals_patch_by_patch(bkg):
+    """round 6: the training render of a view of several patches as ONE launch and its backward as ONE ac_render_core_backward over all
+    patches (NeRFNetwork.render_view_train, stylize.WHOLE_VIEW_BACKWARD) against the patch-by-patch step from the same state and random streams.
+    Forward: the image handed to the guidance and both loss values bit for bit / to a last-bit mean (same draws in the same order, the eikonal term a ratio per
+    patch).  Backward: the accumulated gradient of every parameter within 2e-6 of its largest entry -- NOT bit for bit, by construction: the table gradient is
+    summed per bucket in a fixed-point scale chosen from the launch's record count and largest value and rounded to fp32 once instead of once per patch; the MLP
+    gradients join one set of per-wave partial sums instead of four."""
+    import avatarcraft_amd.stylize as ST
+    from avatarcraft_amd.render_utils import WHITE_BKG, NOISE_BKG
+    ro, rd = make_rays(64, 32, dist=1.8, f=40.0)                      # 2048 rays: 4 patches of 512
+    ro_t, rd_t = torch.from_numpy(ro).to(DEV), torch.from_numpy(rd).to(DEV)
+    key = WHITE_BKG if bkg == "white" else NOISE_BKG
+
+    class Rec(ST.SyntheticGuidance):
+        def __call__(self, rgb, text=None):
+            self.seen = rgb.detach().clone()
+            return super().__call__(rgb, text)
+
+    def one(whole):
+        net, _ = golden_net(train=True)
+        net_gt, _ = golden_net(train=False)
+        opt = torch.optim.SGD(net.parameters(), lr=0.0)
+        flat = ST.flat_grad_view(net.parameters())
+        guide = Rec(3)
+        torch.manual_seed(21); random.seed(21)
+        marks = []
+        prev = ST.WHOLE_VIEW_BACKWARD
+        ST.WHOLE_VIEW_BACKWARD = whole
+        try:
+            st = ST.sds_step(net, net_gt, ro_t, rd_t, (64, 32), opt, guide, batch_size=512, flat_grad=flat, bkg_key=key, timers=marks)
+        finally:
+            ST.WHOLE_VIEW_BACKWARD = prev
+        net.check_finite()
+        return guide.seen, {k: v.grad.detach().clone() for k, v in net.named_parameters()}, [n for n, _ in marks], st
+    img_a, g_a, m_a, s_a = one(True)
+    img_b, g_b, m_b, s_b = one(False)
+    assert m_a.count("backward") == 1 and m_b.count("backward") == 4 and m_a.count("render_grad_forward") == 1
+    assert torch.equal(img_a, img_b)
+    assert abs(float(s_a["opacity"]) - float(s_b["opacity"])) <= 1e-6 * abs(float(s_b["opacity"]))
+    assert abs(float(s_a["eikonal"]) - float(s_b["eikonal"])) <= 1e-6 * abs(float(s_b["eikonal"]))
+    worst = {}
+    for k in g_a:
+        scale = float(g_b[k].abs().max())
+        assert scale > 0, k
+        worst[k] = float((g_a[k] - g_b[k]).abs().max()) / scale
+        assert worst[k] <= 5e-6, (k, worst)                          # observed <= 2.4e-6
+    print("whole-view backward vs patch by patch, worst |d grad| / max:", max(worst.values()))

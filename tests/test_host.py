@@ -37,7 +37,7 @@ def test_struct_layout_matches_header():
     from avatarcraft_amd import _lib
     assert ctypes.sizeof(_lib.ac_render_opts) == 72 and _lib.ac_render_opts.opacity_only.offset == 64 and _lib.ac_render_opts.precision.offset == 56 and _lib.ac_render_opts.inv_s_dev.offset == 32 and _lib.ac_render_opts.far_m.offset == 48
     assert ctypes.sizeof(_lib.ac_render_out) == 17 * 8 and _lib.ac_render_out.sdf_out16.offset == 13 * 8 and _lib.ac_render_out.feat7.offset == 15 * 8
-    assert ctypes.sizeof(_lib.ac_core_saved) == 10 * 8 and ctypes.sizeof(_lib.ac_core_upstream) == 5 * 8 and ctypes.sizeof(_lib.ac_core_grads) == 7 * 8 and _lib.ac_core_grads.split_level.offset == 5 * 8 and _lib.ac_core_grads.g_sh_tiles.offset == 6 * 8
+    assert ctypes.sizeof(_lib.ac_core_saved) == 10 * 8 and ctypes.sizeof(_lib.ac_core_upstream) == 6 * 8 and ctypes.sizeof(_lib.ac_core_grads) == 7 * 8 and _lib.ac_core_grads.split_level.offset == 5 * 8 and _lib.ac_core_grads.g_sh_tiles.offset == 6 * 8
     assert ctypes.sizeof(_lib.ac_adam_entry) == 40 and _lib.ac_adam_entry.n.offset == 32 and _lib.AC_ADAM_MAX_TENSORS == 16
     assert ctypes.sizeof(_lib.ac_wn_layer) == 40 and _lib.ac_wn_layer.rows.offset == 24 and ctypes.sizeof(_lib.ac_pg_entry) == 56 and _lib.ac_pg_entry.kind.offset == 52
     assert _lib.ac_field.offsets.offset == 8 and _lib.ac_field.S.offset == 8 + 17 * 4 and _lib.ac_field.W1.offset == 88 and _lib.ac_field.prepared.offset == 88 + 7 * 8 and _lib.ac_field.Wc1_sh.offset == 88 + 8 * 8 and ctypes.sizeof(_lib.ac_field) == 88 + 9 * 8
