@@ -53,9 +53,36 @@ def busy_objects(c):
     return out
 
 
-def roofline_objects(summary, byc):
+def grid_kernel_split(src):
+    """field_sdf_grid_kernel serves two bench legs (the 512^3 mesh export and, since round 6, the 129^3 density grid): its dispatches come in the same order in
+    every pass, the kernel trace's durations say which is which (> 5 ms = the export) -> {label: {counter: mean}}"""
+    tr = glob.glob(src + "/kt/**/p_kernel_trace.csv", recursive=True)
+    if not tr:
+        return {}
+    rows = sorted((r for r in csv.DictReader(open(tr[0])) if "field_sdf_grid_kernel" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    labels = ["mesh" if (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) > 5e6 else "density" for r in rows]
+    out = {"mesh": collections.defaultdict(list), "density": collections.defaultdict(list)}
+    for f in glob.glob(src + "/g*/p_counter_collection.csv"):
+        per = collections.defaultdict(dict)
+        for r in csv.DictReader(open(f)):
+            if "field_sdf_grid_kernel" in r["Kernel_Name"]:
+                per[r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
+        for c, v in per.items():
+            seq = [v[i] for i in sorted(v)]
+            if len(seq) == len(labels):
+                for lab, x in zip(labels, seq):
+                    out[lab][c].append(x)
+    return {lab: {c: sum(v) / len(v) for c, v in d.items()} for lab, d in out.items() if d}
+
+
+def roofline_objects(summary, byc, grid_split=None):
     """-> the `binding` block of traffic.json: per kernel of a bench leg, busy_objects of its counters"""
     out = {}
+    for lab, name in (("mesh", "field_sdf_grid_kernel"), ("density", "density_grid_kernel")):
+        if grid_split and lab in grid_split:
+            o = busy_objects(grid_split[lab])
+            if o:
+                out[name] = o
     main = {k: v.get("main bench (4096 rays)") for k, v in byc.items() if isinstance(v, dict)}
     o = busy_objects(main)
     if o:
@@ -64,7 +91,7 @@ def roofline_objects(summary, byc):
                       ("sdf_stencil_bwd_kernel", "sdf_stencil_bwd_kernel"), ("hash_stencil_bwd_binned_kernel", "hash_stencil_bwd_binned_kernel"),
                       ("bucket_accumulate_kernel", "bucket_accumulate_kernel"), ("color_bwd_kernel", "color_bwd_kernel")):
         ks = [k for k in summary if k.startswith(key)]
-        if ks:
+        if ks and name not in out:
             o = busy_objects(summary[ks[0]])
             if o:
                 out[name] = o
@@ -154,7 +181,9 @@ def main():
                 n = n_main if prec == "exact" else len(v)
                 mfma_busy[prec] = round(mean(v[:n]) / 1024.0 / (mean(durs) * 1e-6 * 2.1e9), 4)
     traffic = {
-        "binding": roofline_objects(json.load(open(src + "/summary.json")), byc),
+        "binding": roofline_objects(json.load(open(src + "/summary.json")), byc, grid_kernel_split(src)),
+        "binding_source": f"profiles/{rnd}_pmc_summary.json, profiles/{rnd}_pmc_render_by_workload.json (field_sdf_grid_kernel split by workload: mesh export 512^3 | density grid 129^3, "
+                          "whose `density_grid_kernel` entry is that kernel in its density mode)",
         "render_rays_kernel_hbm_bytes_per_launch": int(mean(main_f) * KB),
         "sds_step_hbm_bytes_per_step": int(sum(parts.values())),
         "sds_step_by_kernel": {k: int(v) for k, v in parts.items()},
