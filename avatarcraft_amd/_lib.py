@@ -72,6 +72,8 @@ _SIGS = {
     "ac_version": ([], C.c_int),
     "ac_last_error": ([], C.c_char_p),
     "ac_debug_hold_cus": ([u32, u32, u32, vp], C.c_int),
+    "ac_packed_shading_forward": ([vp, vp, vp, vp, vp, u32, u32, vp, f32, vp, f32, vp, vp, vp, vp], C.c_int),
+    "ac_packed_shading_backward": ([vp, vp, vp, vp, vp, u32, u32, vp, f32, vp, f32, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "ac_set_occupancy_barrier_ms": ([u32], u32),
     "ac_hash_level_table": ([u32, f32, u32, vp, vp], None),
     "ac_hash_encode_forward": ([vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, C.c_int, vp, vp], C.c_int),

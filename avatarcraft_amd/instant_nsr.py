@@ -563,6 +563,8 @@ class NeRFRenderer(nn.Module):
     occupancy_train_one_launch = True  # run_cuda's train() branch under no_grad (stylize.py's render_val of a cuda_ray net) as ONE launch (ac_render_rays_occupancy_train);
                                        # False: the chain of operators (march_rays_train / ac_field_samples / composite_rays_train x 2 / torch) -- same pixels
     occupancy_rounds = False           # True: run_cuda's eval() as the reference-shaped loop of compact / march / field / composite rounds (same results)
+    occupancy_fused_shading = True     # run_cuda's train() branch UNDER AUTOGRAD: normal / NeuS alpha / eikonal terms of the packed samples as one launch each way
+                                       # (nsr_ops.packed_shading); False: the torch formulation (kept as the cross-check of the tests)
 
     def run_cuda(self, rays_o, rays_d, num_steps, bound, upsample_steps, bg_color, cos_anneal_ratio=1.0, normal_epsilon_ratio=1.0, render_can=True,
                  verts=None, faces=None, Ts=None, perturb_overwrite: bool = False, use_mesh_guide: bool = True, per_sample: bool = True, max_steps=1024):
@@ -637,24 +639,35 @@ class NeRFRenderer(nn.Module):
                 W = nsr_ops.weight_norm_all(list(self.sdf_net) + list(self.color_net))
                 sdf_out, gradient = nsr_ops.sdf_stencil(xyzs, enc.embeddings, W[0], self.sdf_net[0].bias, W[1], self.sdf_net[1].bias, self._offsets_host(),
                                                         enc.per_level_scale, enc.base_resolution, bound, fd_eps)
-                normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
+                if self.occupancy_fused_shading:
+                    # normal, the cos-annealed NeuS alpha and the per-sample eikonal terms as ONE launch each way (round 6: the ~40 torch kernels of the
+                    # formulation in the else branch were 2.5 ms of forward + backward per 4096-ray batch against 0.5 ms for the no-grad launch)
+                    nv = n_valid if isinstance(n_valid, torch.Tensor) else torch.tensor(int(n_valid), dtype=torch.int32, device=device)
+                    alpha, normal, eik2 = nsr_ops.packed_shading(sdf_out, gradient, inv_s_t, xyzs, dirs, deltas, nv, cos_anneal_ratio)
+                else:
+                    normal = gradient / (1e-5 + torch.linalg.norm(gradient, ord=2, dim=-1, keepdim=True))
                 if self.use_viewdirs:                            # (the stand-alone colour operator has no direction input: torch's colour network here)
                     rgbs = self.forward_color(xyzs, dirs, normal, sdf_out[:, 1:], bound)
                 else:
                     rgbs = nsr_ops.color_mlp(xyzs, normal, sdf_out, W[2], W[3], W[4])
-                true_cos = (dirs * normal).sum(-1, keepdim=True)
-                act = nn.Softplus(beta=100)
-                iter_cos = -(act(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + act(-true_cos) * cos_anneal_ratio)
-                half = iter_cos * deltas.reshape(-1, 1) * 0.5
-                sdf = sdf_out[:, :1]
-                prev_cdf, next_cdf = torch.sigmoid((sdf - half) * inv_s_t), torch.sigmoid((sdf + half) * inv_s_t)
-                alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).reshape(-1).clip(0.0, 1.0)
+                if not self.occupancy_fused_shading:
+                    true_cos = (dirs * normal).sum(-1, keepdim=True)
+                    act = nn.Softplus(beta=100)
+                    iter_cos = -(act(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + act(-true_cos) * cos_anneal_ratio)
+                    half = iter_cos * deltas.reshape(-1, 1) * 0.5
+                    sdf = sdf_out[:, :1]
+                    prev_cdf, next_cdf = torch.sigmoid((sdf - half) * inv_s_t), torch.sigmoid((sdf + half) * inv_s_t)
+                    alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).reshape(-1).clip(0.0, 1.0)
             else:
                 fs = nsr_ops.field_samples(self._field(), xyzs, dirs, deltas, bound, fd_eps, inv_s_t, cos_anneal_ratio, want_gradient=True)
                 alpha, rgbs, normal, gradient = fs["alpha"], fs["rgb"], fs["normal"], fs["gradient"]
-            relax = (torch.linalg.norm(xyzs, ord=2, dim=-1) < 1.2).float() * valid
-            gerr = (torch.linalg.norm(gradient, ord=2, dim=-1) - 1.0) ** 2
-            gradient_error = (relax * gerr).sum() / (relax.sum() + 1e-5)                 # :266-272 over the packed samples
+            if needs_grad and self.occupancy_fused_shading:
+                es = eik2.sum(0)
+                gradient_error = es[0] / (es[1] + 1e-5)                                   # :266-272 over the packed samples
+            else:
+                relax = (torch.linalg.norm(xyzs, ord=2, dim=-1) < 1.2).float() * valid
+                gerr = (torch.linalg.norm(gradient, ord=2, dim=-1) - 1.0) ** 2
+                gradient_error = (relax * gerr).sum() / (relax.sum() + 1e-5)             # :266-272 over the packed samples
             self._guard_finite(gradient_error)
             weights_sum, image = raymarching.composite_rays_train(alpha, rgbs, deltas, rays, bound)
             with torch.no_grad():

@@ -632,6 +632,49 @@ def render_core_backward(field, opts, out, rays_o, rays_d, bg, g_image, g_wsum, 
     return g_sdf_p, g_col_p, g_invs
 
 
+class _PackedShading(torch.autograd.Function):
+    """normal, cos-annealed NeuS alpha and the two per-sample eikonal terms of PACKED samples (ac_packed_shading_forward / _backward): the glue of
+    NeRFRenderer.run_cuda's train() branch between the fused SDF query and the packed compositor, one launch each way.
+    (sdf_out16 [M,16], gradient [M,3], inv_s) carry gradients; xyzs, dirs, deltas, n_valid (device int32) do not."""
+
+    @staticmethod
+    def forward(ctx, sdf16, gradient, inv_s, xyzs, dirs, deltas, n_valid, car):
+        sdf16, gradient, xyzs, dirs, deltas = (t.contiguous() for t in (sdf16, gradient, xyzs, dirs, deltas))
+        M, dev = sdf16.shape[0], sdf16.device
+        stride = 1 if deltas.dim() == 1 else int(deltas.shape[1])
+        inv_t = inv_s.detach().reshape(1).to(_F32).contiguous()
+        nv = n_valid.detach().reshape(1).to(torch.int32).contiguous()
+        alpha = torch.empty(M, dtype=_F32, device=dev)
+        normal = torch.empty((M, 3), dtype=_F32, device=dev)
+        eik = torch.empty((M, 2), dtype=_F32, device=dev)
+        L.check(L.lib().ac_packed_shading_forward(sdf16.data_ptr(), gradient.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), stride, M, nv.data_ptr(),
+                                                  0.0, inv_t.data_ptr(), float(car), alpha.data_ptr(), normal.data_ptr(), eik.data_ptr(), L.current_stream(dev)),
+                "packed_shading_forward")
+        ctx.save_for_backward(sdf16, gradient, xyzs, dirs, deltas, inv_t, nv)
+        ctx.meta = (stride, float(car), inv_s.shape)
+        return alpha, normal, eik
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_normal, g_eik):
+        sdf16, gradient, xyzs, dirs, deltas, inv_t, nv = ctx.saved_tensors
+        stride, car, inv_shape = ctx.meta
+        M, dev = sdf16.shape[0], sdf16.device
+        c = lambda g: None if g is None else g.contiguous().to(_F32)
+        g_alpha, g_normal, g_eik = c(g_alpha), c(g_normal), c(g_eik)
+        g_sdf16 = torch.zeros((M, 16), dtype=_F32, device=dev)
+        g_grad = torch.empty((M, 3), dtype=_F32, device=dev)
+        g_rows = torch.empty(M, dtype=_F32, device=dev)
+        L.check(L.lib().ac_packed_shading_backward(sdf16.data_ptr(), gradient.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), stride, M, nv.data_ptr(),
+                                                   0.0, inv_t.data_ptr(), car, L.ptr(g_alpha), L.ptr(g_normal), L.ptr(g_eik), g_sdf16.data_ptr(), g_grad.data_ptr(),
+                                                   g_rows.data_ptr(), L.current_stream(dev)), "packed_shading_backward")
+        return g_sdf16, g_grad, g_rows.sum().reshape(inv_shape), None, None, None, None, None
+
+
+def packed_shading(sdf16, gradient, inv_s, xyzs, dirs, deltas, n_valid, cos_anneal_ratio=1.0):
+    """-> (alpha [M], normal [M,3], eik [M,2] = (relax (|g| - 1)^2, relax)); see _PackedShading"""
+    return _PackedShading.apply(sdf16, gradient, inv_s, xyzs, dirs, deltas, n_valid, float(cos_anneal_ratio))
+
+
 class _SdfStencil(torch.autograd.Function):
     """forward_sdf(x) + finite_difference_normals_approximator(x) of the render core as one fused op with a fused backward
     (csrc/sdf_train.hip).  Inputs: x [B,3] (no grad), the hash table, the EFFECTIVE sdf_net matrices (weight norm stays in torch)."""

@@ -672,9 +672,32 @@ def time_occupancy_render(dev, p, table, ro, rd, reps=3):
                 net.occupancy_train_one_launch = True
         dt_chain, img_chain = train_form(False)
         dt, img_one = train_form(True)
+    # ... and UNDER AUTOGRAD (forward + backward of the same batch): the fused SDF-query / colour operators + the packed compositor,
+    # with the shading glue between them as one launch each way (nsr_ops.packed_shading, round 6) and as the torch formulation it replaced
+    def train_autograd(fused):
+        net.occupancy_fused_shading = fused
+        try:
+            def step():
+                net.zero_grad(set_to_none=True)
+                o = net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
+                (o["rgb"].sum() + o["weight_sum"].sum() + 0.1 * o["gradient_error"]).backward()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / 20
+        finally:
+            net.occupancy_fused_shading = True
+            net.zero_grad(set_to_none=True)
+    dt_ag_torch, dt_ag = train_autograd(False), train_autograd(True)
+    with torch.no_grad():                                    # (bookkeeping only)
         res["train_form_4096_ray_batch"] = {"ms_per_batch": dt * 1e3, "rays_per_s": RAYS_PER_BATCH / dt, "samples_per_ray": samples / RAYS_PER_BATCH,
                                             "bytes_per_sample_gathered": 7 * 1024, "gather_gbs": samples * 7 * 1024 / dt / 1e9,
                                             "chain_of_operators_ms_per_batch": dt_chain * 1e3, "pixels_identical_to_the_chain": bool(torch.equal(img_one, img_chain)),
+                                            "under_autograd_forward_plus_backward_ms": dt_ag * 1e3, "under_autograd_with_torch_shading_glue_ms": dt_ag_torch * 1e3,
                                             "note": "net.train() under no_grad (stylize.py's render_val of a cuda_ray net): ONE launch (ac_render_rays_occupancy_train: "
                                                     "count, grid barrier, march + field + both composites + eikonal term + background; grid look-ups 8 at a time) "
                                                     "against the chain it replaces (march_rays_train, ac_field_samples, composite_rays_train x 2, torch)"}

@@ -467,6 +467,19 @@ size_t ac_density_grid_update_scratch(uint32_t H);
 int ac_density_grid_update(const ac_field *field, const float *axis, uint32_t H, float bound, float inv_s, float decay, float *grid,
                            double *mean_out, void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
+/* ---- shading of PACKED samples under autograd (ABI 9, round 6): what NeRFRenderer.run_cuda's train() branch computes between the fused SDF query
+ * (ac_sdf_stencil_forward: sdf16 [M,16], gradient [M,3]) and the packed compositor (ac_composite_rays_train_*), one launch each way instead of ~40 torch kernels:
+ *   normal = g / (1e-5 + |g|); alpha = the cos-annealed NeuS alpha of ac_field_samples with the marcher's step (deltas, stride 1 | 2) as section length;
+ *   eik [M,2] = (relax (|g| - 1)^2, relax), relax = [|xyz| < 1.2][row < *n_valid] -- the two sums of gradient_error (models/instant_nsr.py:266-272).
+ * backward: g_alpha [M], g_normal [M,3] (the colour network's), g_eik [M,2] (column 0 is read), any of them NULL = zero -> g_sdf16 [M,16] (column 0 WRITTEN, the
+ * caller zero-fills the rest), g_gradient [M,3], g_inv_s_rows [M] (d / d inv_s = their sum).  n_valid: a DEVICE int32. */
+int ac_packed_shading_forward(const float *sdf16, const float *gradient, const float *xyzs, const float *dirs, const float *deltas, uint32_t delta_stride,
+                              uint32_t M, const int32_t *n_valid, float inv_s, const float *inv_s_dev, float cos_anneal_ratio, float *alpha, float *normal,
+                              float *eik, ac_stream_t stream);
+int ac_packed_shading_backward(const float *sdf16, const float *gradient, const float *xyzs, const float *dirs, const float *deltas, uint32_t delta_stride,
+                               uint32_t M, const int32_t *n_valid, float inv_s, const float *inv_s_dev, float cos_anneal_ratio, const float *g_alpha,
+                               const float *g_normal, const float *g_eik, float *g_sdf16, float *g_gradient, float *g_inv_s_rows, ac_stream_t stream);
+
 /* use_viewdirs: the per-ray layer-1 bias of the colour network the renderer forms in its prologue, bias[r][u] = fma chain over j = 0..15 of
  * Wc1_sh[u][j] sh_j(rays_d[r]) (sh = the degree-4 values of ac_sh_encode_forward on the raw direction), as its own launch: bias [N,64], sh [N,16] or NULL.
  * What ac_render_core_backward needs beside the forward's outputs (ac_core_saved.sh_bias) and what turns its g_sh_tiles into d Wc1_sh. */

@@ -433,3 +433,40 @@ def test_training_form_beside_a_kernel_that_holds_half_the_device(env):
         print(f"training form beside a half-device hold: {nsr_ops.occupancy_fallbacks() - b0} launch(es) answered by the chain of operators")
     finally:
         net.mean_count = 0
+
+
+@pytest.mark.parametrize("car,budget", [(1.0, False), (0.4, True)])
+def test_fused_packed_shading_equals_the_torch_glue(env, car, budget):
+    """round 6: run_cuda's train() branch under autograd with normal / NeuS alpha / eikonal terms of the packed samples as one launch
+    each way (nsr_ops.packed_shading) against the torch formulation it replaces (occupancy_fused_shading = False): pixels, opacity and the eikonal term to
+    float rounding (torch's softplus / sigmoid against the kernels' table / polynomial: <= 2e-6), the gradient of every parameter to <= 1e-4 of its largest entry --
+    with and without cosine annealing, with and without a sample budget (rows past the marched samples are alignment padding: no eikonal share)"""
+    net = env["net"].train()
+    ro, rd = make_rays(24, 24, dist=1.8, f=18.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    gi = torch.from_numpy(np.random.RandomState(7).normal(0, 1, (576, 3)).astype(np.float32)).to(DEV)
+    kw = dict(num_steps=64, bound=1.6, upsample_steps=64, bg_color=torch.tensor([[0.3, 0.6, 0.1]], device=DEV), cos_anneal_ratio=car, normal_epsilon_ratio=0.0, perturb=True)
+    net.mean_count, net.local_step = 0, 0
+    if budget:
+        with torch.no_grad():
+            net.render(t(ro)[None], t(rd)[None], **kw)
+        net.mean_count = int(net.step_counter[0, 0].item())
+    res = {}
+    try:
+        for fused in (True, False):
+            net.occupancy_fused_shading = fused
+            net.zero_grad()
+            net.local_step = 9
+            out = net.render(t(ro)[None], t(rd)[None], **kw)
+            ((out["rgb"][0] * gi).sum() + 0.1 * out["gradient_error"] + 3.0 * out["weight_sum"].sum()).backward()
+            res[fused] = (out["rgb"].detach().clone(), out["weight_sum"].detach().clone(), float(out["gradient_error"]),
+                          {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None})
+    finally:
+        net.occupancy_fused_shading = True
+        net.mean_count = 0
+        net.zero_grad()
+    (ia, wa, ea, ga), (ib, wb, eb, gb) = res[True], res[False]
+    assert float((ia - ib).abs().max()) <= 2e-6 and float((wa - wb).abs().max()) <= 2e-6 and abs(ea - eb) <= 2e-6 * max(1.0, abs(eb))
+    assert set(ga) == set(gb) and "deviation_net.variance" in ga and "encoder.embeddings" in ga
+    worst = {k: float((ga[k] - gb[k]).abs().max() / (gb[k].abs().max() + 1e-30)) for k in ga}
+    assert all(e <= 1e-4 for e in worst.values()), worst
