@@ -215,7 +215,7 @@ def time_sds_step(dev, p, table, rank, world, dist, steps):
     return res, (net, net_gt)
 
 
-def time_sds_fine_view(dev, p, table, steps=2):
+def time_sds_fine_view(dev, p, table, steps=2, whole_view_backward=False):
     """The fine stage of a stylisation run (stylize.py:98-107 with stride min(1, subsample_scale // 2) = 1, quirk C.8; :143-199): one optimizer step on a
     full 256 x 256 view = 16 patches of 4096 rays -- render_val of the whole view, the guidance, then per patch the training render, the frozen avatar's
     render and the backward of the three loss terms, gradients accumulating over the 16 patches; 20 of the default run's 25 epochs x 150 views are this.
@@ -230,7 +230,10 @@ def time_sds_fine_view(dev, p, table, steps=2):
     ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=0.0, pitch=0.0)
     ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
     out = {}
-    for name, whole, whole_b in (("patch_by_patch", False, False), ("whole_view_renders", True, False), ("whole_view_backward", True, True)):
+    variants = [("patch_by_patch", False, False), ("whole_view_renders", True, False)]
+    if whole_view_backward:                                  # opt-in (--whole-view-backward): ~75 GB of scratch; measured in profiles/r06_experiments.txt section 10
+        variants.append(("whole_view_backward", True, True))
+    for name, whole, whole_b in variants:
         ST.WHOLE_VIEW_RENDERS, ST.WHOLE_VIEW_BACKWARD = whole, whole_b
         ST.sds_step(net, net_gt, ro, rd, (256, 256), opt, guidance, batch_size=4096, flat_grad=flat)       # warm-up
         torch.cuda.synchronize()
@@ -253,8 +256,9 @@ def time_sds_fine_view(dev, p, table, steps=2):
     ach = launched / (ms * 1e-3) / 1e9
     return {"ms_per_view": ms, "rays_per_view": 65536, "patches": 16, "steps": steps, "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)",
             "phase_ms": out["whole_view_renders"]["phase_ms"], "patch_by_patch": out["patch_by_patch"],
-            "whole_view_backward": dict(out["whole_view_backward"], note="the training forward and the backward of all 16 patches as one launch each (stylize.WHOLE_VIEW_BACKWARD, "
-                                        "off by default: its 16 x larger intermediates leave the Infinity Cache; gradients equal to 2e-6 of max)"),
+            "whole_view_backward": (dict(out["whole_view_backward"], note="the training forward and the backward of all 16 patches as one launch each (stylize.WHOLE_VIEW_BACKWARD, "
+                                         "off by default: its 16 x larger intermediates leave the Infinity Cache; gradients equal to 2e-6 of max)")
+                                    if "whole_view_backward" in out else "not timed in this run (--whole-view-backward; profiles/r06_experiments.txt section 10: 74.4 ms against 73.7)"),
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_view": launched,
                          "note": "16 x the coarse step's launched bytes (render_val, training forward, frozen render, stencil features, table scatter per patch)"},
             "note": "render_val and the frozen avatar's opacity render are one launch per view (bit-identical to the 16 per-patch launches: same draws in the "
@@ -970,6 +974,7 @@ def main():
                                                                   "what the step costs once the real UNet is in it); 0 = skip")
     ap.add_argument("--no-occupancy", action="store_true", help="skip the occupancy-grid render leg (render(cuda_ray=True): a separate figure beside the headline)")
     ap.add_argument("--no-viewdirs", action="store_true", help="skip the use_viewdirs=True leg (the same render launch and SDS step with view directions)")
+    ap.add_argument("--whole-view-backward", action="store_true", help="fine-view leg: also time the whole-view training forward + backward (stylize.WHOLE_VIEW_BACKWARD; ~75 GB of scratch)")
     ap.add_argument("--no-fine-view", action="store_true", help="skip the fine-stage leg (one optimizer step on a full 256 x 256 view = 16 patches)")
     ap.add_argument("--no-geometry", action="store_true", help="skip the mesh-export (512^3 + marching cubes) and density-grid-update legs")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
@@ -1165,7 +1170,7 @@ def main():
                 res["occupancy_render"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-500:]}
         if world == 1 and a.sds_steps > 0 and not a.no_fine_view:
             try:
-                res["sds_view_fine"] = time_sds_fine_view(dev, p, table)
+                res["sds_view_fine"] = time_sds_fine_view(dev, p, table, whole_view_backward=a.whole_view_backward)
             except Exception as e:             # noqa: BLE001
                 import traceback
                 res["sds_view_fine"] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-600:]}
