@@ -120,6 +120,8 @@ _SIGS = {
     "ac_sdf_stencil_forward": ([C.POINTER(ac_field), vp, u32, f32, f32, vp, vp, vp], C.c_int),
     "ac_sdf_stencil_backward_scratch": ([u32], C.c_size_t),
     "ac_sdf_stencil_backward": ([C.POINTER(ac_field), vp, vp, vp, u32, f32, f32, vp, vp, vp, C.c_size_t, vp], C.c_int),
+    "ac_sdf_stencil_backward_inputs": ([C.POINTER(ac_field), vp, vp, vp, u32, f32, f32, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+    "ac_hash_stencil_input_backward": ([vp, vp, vp, vp, vp, u32, u32, u32, f32, u32, f32, f32, vp], C.c_int),
     "ac_color_forward": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),
     "ac_render_handoff_timeouts": ([vp, vp], C.c_int),
     "ac_warp_accel_work": ([vp, vp, vp], C.c_int),
@@ -169,7 +171,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = ABI mismatch, also loud
             fn.argtypes = args
             fn.restype = res
-        if handle.ac_version() != 9:
+        if handle.ac_version() != 10:
             raise RuntimeError("avatarcraft_amd: libavatarcraft_hip.so ABI version mismatch")
         _lib = handle
     return _lib

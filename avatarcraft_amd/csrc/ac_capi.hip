@@ -9,7 +9,7 @@ void set_error(const char *fmt, ...)
 }
 }  // namespace ac
 
-AC_API int ac_version(void) { return 9; }
+AC_API int ac_version(void) { return 10; }
 AC_API const char *ac_last_error(void) { return ac::g_err; }
 
 AC_API void ac_hash_level_table(uint32_t L, float S, uint32_t H, float *scale_host, uint32_t *res_host)

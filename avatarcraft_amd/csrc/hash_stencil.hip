@@ -128,6 +128,64 @@ __global__ __launch_bounds__(256) void hash_stencil_fwd_kernel(const float *__re
     }
 }
 
+// ---- backward to the INPUT: d loss / d x through the seven encodings ------------------------------------------------------------------
+// What the reference does with dy_dx (kernel_grid's derivative branch, hashencoder.cu:177-220, and kernel_input_backward, :311-337) for a sample whose
+// position itself carries a gradient -- the curvature term's perturbed points (models/instant_nsr.py:276-288: they are a function of the normal).  Nothing
+// is stored: the eight corners of every stencil point are gathered again and the derivative of the trilinear weights is formed in registers.
+//   gx_part[grp][b][d] = sum over the levels of group grp (4 levels each), points p, channels c of
+//        gfeat[p][level][b][c] * scale * sum_{corners of the two other axes} w_other * (T[corner + e_d] - T[corner])[c] / (2 bound) * pass_p,d
+// pass = the derivative of the offset point's clamp (1 inside [-bound, bound], torch.clamp's inclusive rule; finite_difference_normals_approximator :690-702).
+__global__ __launch_bounds__(256) void hash_stencil_input_bwd_kernel(const float *__restrict__ gfeat, const float *__restrict__ x, const float *__restrict__ grid,
+                                                                     float *__restrict__ gx_part, uint32_t B, ac::LevelTable lt, float eps, float bound,
+                                                                     float two_bound)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t Lc = lt.L;
+    const float xc[3] = { x[3 * (size_t)b], x[3 * (size_t)b + 1], x[3 * (size_t)b + 2] };
+    float acc[3] = { 0.0f, 0.0f, 0.0f };
+    for (uint32_t level = blockIdx.y * 4; level < blockIdx.y * 4 + 4 && level < Lc; ++level) {
+        const LevelC L = level_of(lt, level);
+        const float2 *g = reinterpret_cast<const float2 *>(grid) + lt.offset[level];
+        Loc c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) c[d] = locate(xc[d], bound, two_bound, L.scale);
+#pragma unroll 1
+        for (int p = 0; p < 7; ++p) {
+            const float2 gf = reinterpret_cast<const float2 *>(gfeat)[((size_t)p * Lc + level) * B + b];
+            if (gf.x == 0.0f && gf.y == 0.0f) continue;                  // (the centre of a gradient-only use, masked samples)
+            Loc q[3] = { c[0], c[1], c[2] };
+            const int k = p > 0 ? (p - 1) >> 1 : 3;
+            float pass = 1.0f;
+            if (p > 0) {
+                const float raw = xc[k] + (((p - 1) & 1) ? -eps : eps);
+                pass = (raw >= -bound && raw <= bound) ? 1.0f : 0.0f;
+                q[k] = locate(clampf(raw, -bound, bound), bound, two_bound, L.scale);
+            }
+            if (q[0].oob | q[1].oob | q[2].oob) continue;                // (hashencoder.cu:95-119: an out-of-range input has zero output and zero dy_dx)
+            float2 f[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; ++idx)
+                f[idx] = g[gindex(L, q[0].pg + (idx & 1u), q[1].pg + ((idx >> 1) & 1u), q[2].pg + ((idx >> 2) & 1u))];
+#pragma unroll
+            for (uint32_t d = 0; d < 3; ++d) {
+                const uint32_t da = (d == 0) ? 1u : 0u, db = (d == 2) ? 1u : 2u;
+                float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                for (uint32_t jm = 0; jm < 4; ++jm) {
+                    const float w = ((jm & 1u) ? q[da].fr : 1.0f - q[da].fr) * ((jm >> 1) ? q[db].fr : 1.0f - q[db].fr);
+                    const uint32_t left = ((jm & 1u) << da) | ((jm >> 1) << db), right = left | (1u << d);
+                    s0 = fma_(w, f[right].x - f[left].x, s0); s1 = fma_(w, f[right].y - f[left].y, s1);
+                }
+                const float dd = L.scale * fma_(s0, gf.x, s1 * gf.y) / two_bound;
+                acc[d] += ((int)d == k) ? dd * pass : dd;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gx_part[((size_t)blockIdx.y * B + b) * 3 + d] = acc[d];
+}
+
 // ---- backward ----------------------------------------------------------------------------------------------------------------
 // A wave holds 64 consecutive samples of one ray (B index = ray * T + sample, sorted by depth), and the importance sampling packs
 // most of them into a few cells: neighbouring lanes that sit in the same cell address the same table entries.  Their
@@ -835,6 +893,18 @@ AC_API int ac_hash_stencil_forward(const float *x, const float *embeddings, cons
     hipLaunchKernelGGL(hash_stencil_fwd_kernel, dim3((B + 255) / 256, L), dim3(256), 0, (hipStream_t)stream, x, embeddings, outputs, B, lt, eps,
                        bound, (float)(2.0 * (double)bound));
     return ac::check_launch("hash_stencil_forward");
+}
+
+AC_API int ac_hash_stencil_input_backward(const float *gfeat, const float *x, const float *embeddings, const int32_t *offsets_host, float *gx_part,
+                                          uint32_t B, uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream)
+{
+    if (int rc = check("hash_stencil_input_backward", C, L, offsets_host, eps, bound)) return rc;
+    if (B == 0) return AC_OK;
+    if (!gfeat || !x || !embeddings || !gx_part) { ac::set_error("hash_stencil_input_backward: NULL buffer"); return AC_ERR_BAD_ARG; }
+    ac::LevelTable lt; ac::make_level_table(lt, L, 3, S, H, offsets_host);
+    hipLaunchKernelGGL(hash_stencil_input_bwd_kernel, dim3((B + 255) / 256, (L + 3) / 4), dim3(256), 0, (hipStream_t)stream, gfeat, x, embeddings, gx_part, B,
+                       lt, eps, bound, (float)(2.0 * (double)bound));
+    return ac::check_launch("hash_stencil_input_backward");
 }
 
 // entries of the leading dense levels that are worth privatising (none if the caller gives no scratch)

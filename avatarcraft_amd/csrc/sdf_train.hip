@@ -211,12 +211,16 @@ __device__ __forceinline__ void fill_lds_bwd(float *lds, const RenderArgs &a)
 
 // SAVED: the features of the seven stencil points come from the forward launch (ac_render_out.feat7, [B / 16][14][64 lanes][4] in this kernel's lane order) as 14
 // coalesced 16-byte loads per lane instead of being gathered from the table again (index arithmetic + ~100 scattered 8-byte loads per lane and tile)
-template <bool SAVED>
+// GX: the sample positions carry a gradient themselves (the curvature term's perturbed points, models/instant_nsr.py:276-288): g_x [B][3] receives the share
+// that enters through the MLP's own xyz inputs (include_input, :632-633) -- W1[:, 0:3]^T d1 summed over the seven evaluations, the offset coordinate of an
+// offset evaluation through its clamp (:690-702).  The share through the encodings is ac_hash_stencil_input_backward's.
+template <bool SAVED, bool GX = false>
 __global__ __launch_bounds__(SAVED ? TW_S * 64 : TBLOCK) void sdf_stencil_bwd_kernel(const RenderArgs a, const float *__restrict__ x, const float *__restrict__ g_out,
                                                                  const float *__restrict__ g_grad, uint32_t B, float eps,
                                                                  float *__restrict__ gfeat, float *__restrict__ partials,
-                                                                 const float *__restrict__ feat7)
+                                                                 const float *__restrict__ feat7, float *__restrict__ g_x = nullptr)
 {
+    static_assert(!(SAVED && GX), "the position gradient is built for the stand-alone operator");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fill_lds_sdf(lds, a);
     fill_lds_bwd(lds, a);
@@ -255,6 +259,15 @@ __global__ __launch_bounds__(SAVED ? TW_S * 64 : TBLOCK) void sdf_stencil_bwd_ke
         gW2[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
         for (int c = 0; c < 3; ++c) gW1[t][c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    }
+    float wxyz[GX ? 4 : 1][4][3];                               // GX: W1[unit 16t + 4g + r][0..2], this lane's 16 units
+    if constexpr (GX) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wxyz[t][r][c] = a.W1[(16 * t + 4 * g + r) * 35 + c];
     }
     uint32_t step = 0;                                          // evaluations this wave has been through (PIPE: selects the buffer)
     // the weight-gradient products of ONE evaluation from its transposes: dW2 += d2 a^T (16 MFMA, centre evaluations only: the offset evaluations' share is
@@ -326,6 +339,7 @@ __global__ __launch_bounds__(SAVED ? TW_S * 64 : TBLOCK) void sdf_stencil_bwd_ke
         Acc4 h10;                                               // layer 1 of the centre evaluation (set at e == 0)
 #pragma unroll
         for (int t = 0; t < 4; ++t) h10.a[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        float gxa[3] = { 0.0f, 0.0f, 0.0f };                    // GX: d loss / d (px, py, pz) through the xyz inputs, summed over the evaluations
 #pragma unroll 1
         for (int e = 0; e < 7; ++e) {
             const int k = e > 0 ? (e - 1) >> 1 : 3;
@@ -457,6 +471,20 @@ __global__ __launch_bounds__(SAVED ? TW_S * 64 : TBLOCK) void sdf_stencil_bwd_ke
                     for (int r = 0; r < 4; ++r) d1.a[t][r] = ga[r] * dv.a[t][r];
                 }
             }
+            if constexpr (GX) {
+                const float raw = pk + (((e - 1) & 1) ? -eps : eps);
+                const float pass = (e == 0 || (raw >= -bound && raw <= bound)) ? 1.0f : 0.0f;       // d clamp / d x (inclusive, like torch.clamp's backward)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sx = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sx = fma_(d1.a[t][r], wxyz[t][r][c], sx);
+                    sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);                                 // over the four lane groups of the sample
+                    gxa[c] += (c == k) ? sx * pass : sx;
+                }
+            }
             // dinp = W1^T d1: this lane's own features (j = 2t' + (r >> 1), c = r & 1), on the bf16 matrix pipe with both factors split
             // hi + lo (3 products, fp32 accumulate: 2^-16 relative, far below the tolerance of a gradient): 12 short MFMA instead of 32 fp32 ones
             {
@@ -544,6 +572,9 @@ __global__ __launch_bounds__(SAVED ? TW_S * 64 : TBLOCK) void sdf_stencil_bwd_ke
                 w1_grads(TD, TI);
                 wave_sync();
             }
+        }
+        if constexpr (GX) {
+            if (live && g < 3) g_x[3 * (size_t)b + g] = g == 0 ? gxa[0] : (g == 1 ? gxa[1] : gxa[2]);
         }
 #if !AC_SDFBWD_PREFETCH
         if (tile + tstride < ntiles) request(tile + tstride, nxt);
@@ -2272,9 +2303,11 @@ AC_API size_t ac_sdf_stencil_backward_scratch(uint32_t B)
 }
 
 static int sdf_stencil_backward_impl(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
-                                     float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream, const float *feat7)
+                                     float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream, const float *feat7,
+                                     float *g_x = nullptr)
 {
     if (!gparams) { ac::set_error("sdf_stencil_backward: NULL gparams"); return AC_ERR_BAD_ARG; }
+    if (g_x && feat7) { ac::set_error("sdf_stencil_backward: the position gradient is not built for the saved-feature form"); return AC_ERR_BAD_ARG; }
     if (B == 0) { hipMemsetAsync(gparams, 0, NPART * sizeof(float), (hipStream_t)stream); return AC_OK; }
     if (!x || !g_out16 || !g_grad || !gfeat || !scratch || !(eps > 0.0f)) { ac::set_error("sdf_stencil_backward: NULL buffer or eps <= 0"); return AC_ERR_BAD_ARG; }
     const size_t need = ac_sdf_stencil_backward_scratch(B);
@@ -2290,10 +2323,15 @@ static int sdf_stencil_backward_impl(const ac_field *field, const float *x, cons
         const uint32_t need_blocks = ((B + 15) / 16 + TW_S - 1) / TW_S;           // (persistent: one workgroup of TW_S waves per compute unit)
         if (blocks > need_blocks) blocks = need_blocks ? need_blocks : 1;
         hipLaunchKernelGGL(sdf_stencil_bwd_kernel<true>, dim3(blocks), dim3(TW_S * 64), lds_bytes_s, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
-                           static_cast<float *>(scratch), feat7);
+                           static_cast<float *>(scratch), feat7, (float *)nullptr);
+    } else if (g_x) {
+        static uint64_t seen_x = 0;
+        ac::allow_dynamic_lds(seen_x, reinterpret_cast<const void *>(sdf_stencil_bwd_kernel<false, true>), lds_bytes);
+        hipLaunchKernelGGL((sdf_stencil_bwd_kernel<false, true>), dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
+                           static_cast<float *>(scratch), feat7, g_x);
     } else
         hipLaunchKernelGGL(sdf_stencil_bwd_kernel<false>, dim3(blocks), dim3(TBLOCK), lds_bytes, (hipStream_t)stream, a, x, g_out16, g_grad, B, eps, gfeat,
-                           static_cast<float *>(scratch), feat7);
+                           static_cast<float *>(scratch), feat7, (float *)nullptr);
     hipLaunchKernelGGL(sdf_partials_reduce_kernel, dim3((NPART + RED_OUT - 1) / RED_OUT), dim3(1024), 0, (hipStream_t)stream, static_cast<const float *>(scratch),
                        blocks * (feat7 ? TW_S : TW), gparams);
     return ac::check_launch("sdf_stencil_backward");
@@ -2303,6 +2341,13 @@ AC_API int ac_sdf_stencil_backward(const ac_field *field, const float *x, const 
                                    float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream)
 {
     return sdf_stencil_backward_impl(field, x, g_out16, g_grad, B, bound, eps, gfeat, gparams, scratch, scratch_bytes, stream, nullptr);
+}
+
+AC_API int ac_sdf_stencil_backward_inputs(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
+                                          float eps, float *gfeat, float *gparams, float *g_x, void *scratch, size_t scratch_bytes, ac_stream_t stream)
+{
+    if (!g_x && B) { ac::set_error("sdf_stencil_backward_inputs: NULL g_x"); return AC_ERR_BAD_ARG; }
+    return sdf_stencil_backward_impl(field, x, g_out16, g_grad, B, bound, eps, gfeat, gparams, scratch, scratch_bytes, stream, nullptr, g_x);
 }
 
 AC_API int ac_color_forward(const ac_field *field, const float *x, const float *normal, const float *sdf16, uint32_t B, float *rgb, ac_stream_t stream)

@@ -388,11 +388,11 @@ class NeRFRenderer(nn.Module):
         e = getattr(self, "encoder_dir", None)
         return getattr(e, "degree", None) == 4 and getattr(e, "output_dim", None) == 16 and self.in_dim_color == 37
 
-    def _fused_supported(self):
+    def _fused_supported(self, ignore_curvature=False):
         """the default model (colour net 21-64-64-3), or the same with view directions (37-64-64-3: the renderer folds the 16 spherical harmonics of the ray
         direction into a per-ray bias of colour layer 1, ac_field.Wc1_sh); no curvature term"""
         return (self._sdf_supported() and (not self.use_viewdirs or self._viewdirs_supported()) and self.num_layers_color == 3
-                and self.hidden_dim_color == 64 and not self.curvature_loss)
+                and self.hidden_dim_color == 64 and (ignore_curvature or not self.curvature_loss))
 
     def _field_sdf_only(self):
         """ac_field with the SDF side only (zero colour matrices): the sampling stage of a model whose colour net the fused renderer does not cover"""
@@ -493,7 +493,8 @@ class NeRFRenderer(nn.Module):
             near = torch.where(torch.isinf(nm), near, nm)
             far = torch.where(torch.isinf(fm), far, fm)
         # (the stand-alone colour operator has no direction input: a model with view directions keeps torch's colour network on this path)
-        fused_ops = bool(self.fused_training) and self._fused_supported() and near_far is None and not self.use_viewdirs
+        # (the curvature term does not change the operators of the render core: it adds one more stencil query, below)
+        fused_ops = bool(self.fused_training) and self._fused_supported(ignore_curvature=True) and near_far is None and not self.use_viewdirs
         sample_dist = (far - near) / num_steps0
         T = num_steps0 + upsample_steps
         deltas = z_vals[:, 1:] - z_vals[:, :-1]
@@ -521,10 +522,16 @@ class NeRFRenderer(nn.Module):
         self._guard_finite(torch.linalg.norm(gradient.detach()) if gradient.is_cuda else gradient.detach().sum())    # :274 assert (gradient == gradient).all()
         curvature_error = 0.0
         if self.curvature_loss:                                  # :276-288
-            random_vec = 2.0 * torch.randn_like(normal) - 1.0
+            draw = getattr(self, "curvature_noise", None)        # (tests replay the reference's recorded draw: a callable (shape, device) -> N(0, 1) values)
+            random_vec = 2.0 * (draw(normal.shape, normal.device) if draw is not None else torch.randn_like(normal)) - 1.0
             random_vec_norm = random_vec / (1e-5 + torch.linalg.norm(random_vec, ord=2, dim=-1, keepdim=True))
             perturbed_pts = flat + torch.cross(normal, random_vec_norm, dim=-1) * 0.01 * (1.0 - normal_epsilon_ratio)
-            pg = self.gradient(perturbed_pts, bound, fd_eps).squeeze()
+            if fd_eps > 0.0 and flat.is_cuda and self.fused_training and self._sdf_supported():
+                # self.gradient(perturbed_pts) as ONE stencil query each way: the six offset evaluations in one launch, and in the backward the gradient w.r.t.
+                # the perturbed positions themselves (they are a function of the normal: the reference's dy_dx path) -- nsr_ops._SdfStencil
+                pg = self.forward_sdf_stencil(perturbed_pts, bound, fd_eps)[1]
+            else:
+                pg = self.gradient(perturbed_pts, bound, fd_eps).squeeze()
             pn = pg / (1e-5 + torch.linalg.norm(pg, ord=2, dim=-1, keepdim=True))
             cerr = (torch.sum(normal * pn, dim=-1) - 1.0) ** 2
             curvature_error = (relax * cerr.reshape(N, T)).sum() / (relax.sum() + 1e-5)

@@ -677,7 +677,10 @@ def packed_shading(sdf16, gradient, inv_s, xyzs, dirs, deltas, n_valid, cos_anne
 
 class _SdfStencil(torch.autograd.Function):
     """forward_sdf(x) + finite_difference_normals_approximator(x) of the render core as one fused op with a fused backward
-    (csrc/sdf_train.hip).  Inputs: x [B,3] (no grad), the hash table, the EFFECTIVE sdf_net matrices (weight norm stays in torch)."""
+    (csrc/sdf_train.hip).  Inputs: x [B,3], the hash table, the EFFECTIVE sdf_net matrices (weight norm stays in torch).
+    x may require grad (the curvature term's perturbed points, models/instant_nsr.py:276-288: positions that are a function of the normal): the backward then
+    also returns d loss / d x = the share through the MLP's own xyz inputs (ac_sdf_stencil_backward_inputs) + the share through the encodings (the
+    reference's dy_dx path, hashencoder.cu:177-220,311-337: ac_hash_stencil_input_backward)."""
 
     @staticmethod
     def forward(ctx, x, table, W1, b1, W2, b2, cfg):
@@ -712,16 +715,27 @@ class _SdfStencil(torch.autograd.Function):
         nbytes = int(L.lib().ac_sdf_stencil_backward_scratch(B))
         scratch = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
         st = L.current_stream(dev)
-        L.check(L.lib().ac_sdf_stencil_backward(C.byref(field.c), x.data_ptr(), g_out.data_ptr(), g_grad.data_ptr(), B, float(bound), float(eps),
-                                                gfeat.data_ptr(), gparams.data_ptr(), scratch.data_ptr(), nbytes, st), "sdf_stencil_backward")
-        g_table = torch.zeros_like(table)
         oh = np.asarray(offsets, dtype=np.int32)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty((B, 3), dtype=_F32, device=dev)
+            L.check(L.lib().ac_sdf_stencil_backward_inputs(C.byref(field.c), x.data_ptr(), g_out.data_ptr(), g_grad.data_ptr(), B, float(bound), float(eps),
+                                                           gfeat.data_ptr(), gparams.data_ptr(), g_x.data_ptr(), scratch.data_ptr(), nbytes, st),
+                    "sdf_stencil_backward_inputs")
+            part = torch.empty(((16 + 3) // 4, B, 3), dtype=_F32, device=dev)
+            L.check(L.lib().ac_hash_stencil_input_backward(gfeat.data_ptr(), x.data_ptr(), field.t["table"].data_ptr(), oh.ctypes.data, part.data_ptr(), B, 2, 16,
+                                                           field.S, H, float(eps), float(bound), st), "hash_stencil_input_backward")
+            g_x = g_x + part.sum(0)
+        else:
+            L.check(L.lib().ac_sdf_stencil_backward(C.byref(field.c), x.data_ptr(), g_out.data_ptr(), g_grad.data_ptr(), B, float(bound), float(eps),
+                                                    gfeat.data_ptr(), gparams.data_ptr(), scratch.data_ptr(), nbytes, st), "sdf_stencil_backward")
+        g_table = torch.zeros_like(table)
         from .encoder.hashencoder.backend import stencil_scratch
         hs, hbytes = stencil_scratch(oh, 16, field.S, H, dev, B)
         L.check(L.lib().ac_hash_stencil_backward(gfeat.data_ptr(), x.data_ptr(), oh.ctypes.data, g_table.data_ptr(), B, 2, 16, field.S, H, float(eps),
                                                  float(bound), L.ptr(hs), hbytes, st), "hash_stencil_backward")
         gW1b = gparams[:64 * 36].view(64, 36)
-        return (None, g_table, gW1b[:, :35].contiguous(), gW1b[:, 35].contiguous(), gparams[64 * 36:64 * 36 + 1024].view(16, 64),
+        return (g_x, g_table, gW1b[:, :35].contiguous(), gW1b[:, 35].contiguous(), gparams[64 * 36:64 * 36 + 1024].view(16, 64),
                 gparams[64 * 36 + 1024:], None)
 
 

@@ -42,7 +42,8 @@ typedef void *ac_stream_t; /* hipStream_t */
 #define AC_MAX_LEVELS 32
 
 /* library identification / diagnostics */
-int ac_version(void);                /* ABI version, currently 9 (round 6: ac_warp_mesh.seed_faces / seed_stride -- the struct grew --, ac_set_occupancy_barrier_ms, ac_debug_hold_cus; the phased occupancy launches are cooperative launches sized by the runtime's
+int ac_version(void);                /* ABI version, currently 10 (round 6, second half: ac_sdf_stencil_backward_inputs, ac_hash_stencil_input_backward -- the position gradient
+                                      * of the stencil query, for the curvature term; 9, round 6: ac_warp_mesh.seed_faces / seed_stride -- the struct grew --, ac_set_occupancy_barrier_ms, ac_debug_hold_cus; the phased occupancy launches are cooperative launches sized by the runtime's
                                       * occupancy figure; 7, round 5, second half: ac_render_rays_occupancy_phased, ac_render_rays_occupancy_train, ac_march_rays_train_scratch -- the
                                       * marcher's scratch grew --; 6, round 5: ac_render_rays_occupancy's max_steps, ac_field_sdf_grid, ac_marching_cubes*,
                                       * ac_density_grid_update, the SH colour input of ac_field; round 4 = 5: ac_render_opts.opacity_only -- the struct grew from 64 to 72 bytes --,
@@ -332,6 +333,14 @@ int ac_hash_stencil_backward(const float *grad, const float *x, const int32_t *o
                              uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, void *scratch, size_t scratch_bytes,
                              ac_stream_t stream);
 
+/* The stencil's gradient w.r.t. the sample POSITIONS through the encodings: what the reference obtains from dy_dx (kernel_grid's derivative branch,
+ * hashencoder.cu:177-220, + kernel_input_backward, :311-337) when the encoder's input requires grad -- the curvature term's perturbed points
+ * (models/instant_nsr.py:276-288).  gfeat [7, L, B, C] as ac_sdf_stencil_backward writes it; the corners are gathered again, nothing is stored.
+ * gx_part [(L + 3) / 4][B][3]: one partial per group of four levels (the caller sums them: a fixed order); an offset coordinate passes through its
+ * clamp to [-bound, bound] with torch.clamp's rule (inclusive), an out-of-range point contributes nothing (hashencoder.cu:95-119). */
+int ac_hash_stencil_input_backward(const float *gfeat, const float *x, const float *embeddings, const int32_t *offsets_host, float *gx_part,
+                                   uint32_t B, uint32_t C, uint32_t L, float S, uint32_t H, float eps, float bound, ac_stream_t stream);
+
 /* The sampling stage of run() alone: coarse z (+ jitter), coarse SDF, 4x NeuS up-sampling -> z_vals [N, num_steps + upsample_steps]
  * (models/instant_nsr.py:155-184; the reference runs it under no_grad before the differentiable render core).  Same z as
  * ac_render_rays bit for bit, at a fraction of its cost. */
@@ -352,6 +361,13 @@ int ac_sdf_stencil_forward(const ac_field *field, const float *x, uint32_t B, fl
 size_t ac_sdf_stencil_backward_scratch(uint32_t B);
 int ac_sdf_stencil_backward(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
                             float eps, float *gfeat, float *gparams, void *scratch, size_t scratch_bytes, ac_stream_t stream);
+
+/* The same backward for positions that carry a gradient themselves (x.requires_grad in the reference: the curvature term's perturbed points,
+ * models/instant_nsr.py:276-288): additionally g_x [B,3] = the share of d loss / d x that enters through the MLP's own xyz inputs (include_input,
+ * :632-633; the offset coordinate of an offset evaluation through its clamp, :690-702).  The share through the encodings: ac_hash_stencil_input_backward
+ * on the gfeat this call wrote; the caller adds the two. */
+int ac_sdf_stencil_backward_inputs(const ac_field *field, const float *x, const float *g_out16, const float *g_grad, uint32_t B, float bound,
+                                   float eps, float *gfeat, float *gparams, float *g_x, void *scratch, size_t scratch_bytes, ac_stream_t stream);
 
 /* Liveness of the renderer's segment hand-off (a ray's final pass is cut into segments that different waves may take; a taker waits, bounded to ~1 s,
  * for the previous segment's state).  A timed-out hand-off poisons the pixel with NaN AND is counted here, per (device, stream), over the life of the

@@ -79,11 +79,11 @@ import models.instant_nsr as ref_nsr  # noqa: E402  (the reference)
 GT_SDF_BIAS = -0.40            # sdf_net.1.bias[0] of the frozen net_gt in the training golden (net_style: -0.45)
 
 
-def build_reference_net():
-    """NeRFNetwork() with seed-0 init, then table/first-layer randomised so that all 16 levels matter
+def build_reference_net(**kw):
+    """NeRFNetwork(**kw) with seed-0 init, then table/first-layer randomised so that all 16 levels matter
     (with the stock geometric init the hash features get zero weight)."""
     torch.manual_seed(0)
-    net = ref_nsr.NeRFNetwork()
+    net = ref_nsr.NeRFNetwork(**kw)
     rs = np.random.RandomState(1234)
     with torch.no_grad():
         scale, _ = O.hash_level_table(16, np.float32(np.log2(net.encoder.per_level_scale)), 16)
