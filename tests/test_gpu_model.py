@@ -557,9 +557,8 @@ def test_render_core_operator(n_side, T0, up, perturb):
 
 
 def test_render_variants_generic_path():
-    """model variants the fused renderer does not cover run through the generic path (fused sampling + torch MLPs over the HIP hash encoder):
-    use_viewdirs=True (SH-encoded directions into the colour net, models/instant_nsr.py:564-569,652-653) and curvature_loss=True (:276-288),
-    with and without gradients; a canonical render inside the mesh-guided range (verts given, :147-153); normal_epsilon_ratio >= 1 is refused"""
+    """model variants under autograd through net.render(): use_viewdirs=True (SH-encoded directions into the colour net, models/instant_nsr.py:564-569,652-653)
+    and curvature_loss=True (:276-288; since round 6 on the fused operators, tests/test_gpu_curvature.py pins its values), with and without gradients; a canonical render inside the mesh-guided range (verts given, :147-153); normal_epsilon_ratio >= 1 is refused"""
     from avatarcraft_amd.instant_nsr import NeRFNetwork
     from tests.common import make_body
     torch.manual_seed(1)

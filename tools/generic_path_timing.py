@@ -1,5 +1,6 @@
-"""What the model variants OUTSIDE the fused renderer cost (stated, untimed): use_viewdirs=True and curvature_loss=True run
-through the generic path (fused sampling launch + torch MLPs over the HIP hash / SH encoders); 64 + 64 steps other than multiples of 16 are refused.
+"""What the model variants cost next to the default model: use_viewdirs=True (inside the fused renderer since round 5) and
+curvature_loss=True (round 6: the fused operators + one more stencil query with a position gradient; rounds 3 - 5: torch MLPs over the HIP hash encoder,
+5.3 / 93 ms); AC_VARIANT_ONLY=curvature restricts the run to one variant (for a kernel trace).
     python tools/generic_path_timing.py      (on the GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -22,7 +23,10 @@ def timed(fn, n=5):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+only = os.environ.get("AC_VARIANT_ONLY", "")
 for name, opts in (("default (fused)", {}), ("use_viewdirs=True", dict(use_viewdirs=True)), ("curvature_loss=True", dict(curvature_loss=True))):
+    if only and only not in name:
+        continue
     torch.manual_seed(1)
     net = NeRFNetwork(**opts).to(dev)
     with torch.no_grad():
