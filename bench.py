@@ -18,6 +18,10 @@ Printed JSON (rank 0, one line) carries the contract fields plus
                  divided by the mean launch duration measured with HIP events on the launch stream.
   cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm; OpenMP over rays) timed on this
                  host on a bounded sample of the same workload.  A reported baseline, not the target.
+
+This file holds the contract: arguments, the timed region of the headline metric, the JSON line.  Every further workload
+the line reports (sds_step, sds_view_fine, posed_frame, viewdirs, mesh_export_512, density_grid_update, occupancy_render,
+the guidance stand-in, the CPU baselines) and the `--gpus N` self-launcher live in bench_legs/, one module each.
 """
 import argparse
 import json
@@ -25,900 +29,21 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+ROOT_DIR = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT_DIR)
 
 import numpy as np
 import torch
 
-RAYS_PER_BATCH = 4096
-H = W = 256
-NUM_STEPS, UPSAMPLE_STEPS = 64, 64
-BYTES_PER_RAY = 1008 * 1024          # 1008 hash-grid evaluations x (16 levels x 8 corners x 2 ch x 4 B)
-FLOP_PER_RAY = 1008 * 6528 + 128 * 11264
-HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec (MI355X_MICROARCH.md)
-
-
-def oracle_field(p, table):
-    """the CPU oracle's view of the same field (cpu_baseline legs only)"""
-    from oracle import oracle as O
-    return O.Field(table, p["offsets"], p["W1"], p["b1"], p["W2"], p["b2"], p["Wc1"], p["Wc2"], p["Wc3"], float(p["per_level_scale"]))
-
-
-def make_inputs(device, rank):
-    from avatarcraft_amd.synthetic import load_field_params, make_rays, device_field
-    p = load_field_params()
-    field, table = device_field(p, device=device)
-    # camera on the 360-degree path of render_canonical.py (dist 1.7, f = 0.78125*256 = 200), one view per rank
-    yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
-    ro, rd = make_rays(H, W, dist=1.7, f=200.0, yaw=yaw, pitch=0.0)
-    return p, field, table, ro, rd
-
-
-def cpu_baseline(p, table, ro, rd, budget_s=12.0):
-    """time the CPU oracle on a bounded, strided sample of the same rays"""
-    from oracle import oracle as O
-    of = oracle_field(p, table)
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    idx = np.arange(0, ro.shape[0], ro.shape[0] // 64)[:64]
-    t0 = time.time(); O.render_rays(of, ro[idx], rd[idx], NUM_STEPS, UPSAMPLE_STEPS, 1.6, float(p["inv_s"]), extras=False); dt = time.time() - t0
-    n = int(min(ro.shape[0], max(64, (budget_s / max(dt, 1e-3)) * 64)))
-    n = (n // 64) * 64
-    idx = np.arange(0, ro.shape[0], max(1, ro.shape[0] // n))[:n]
-    t0 = time.time(); O.render_rays(of, ro[idx], rd[idx], NUM_STEPS, UPSAMPLE_STEPS, 1.6, float(p["inv_s"]), extras=False); dt = time.time() - t0
-    return dict(value=n / dt, unit="rays/s", cores=cores, threads=int(os.environ.get("OMP_NUM_THREADS", cores)), kind="port",
-                sample=f"{n} rays (every {max(1, ro.shape[0] // n)}-th ray of the 256x256 view), 64+64 samples, {dt:.1f} s wall, OpenMP over rays",
-                note="the C restatement of the reference's algorithm (oracle/), OpenMP over rays on every host core: faster than the reference's own "
-                     "torch-CPU path would be; a reported baseline, not the target")
-
-
-SAMPLES = NUM_STEPS + UPSAMPLE_STEPS
-# ALGORITHMIC bytes of one 4096-ray SDS step (SURVEY 8d per-unit figures: 1024 B gathered per hash evaluation forward, 2048 B
-# read-modify-write per evaluation backward), for the work this implementation actually launches ...
-SDS_BYTES_LAUNCHED = {
-    "render_val (no-grad render of net_style)": RAYS_PER_BATCH * BYTES_PER_RAY,
-    "grad render forward (the same fused launch, per-sample outputs kept)": RAYS_PER_BATCH * BYTES_PER_RAY,
-    "net_gt render (frozen avatar, opacity target)": RAYS_PER_BATCH * BYTES_PER_RAY,
-    "stencil features of the grad render: written once by the forward, streamed back by sdf_stencil_bwd (7 points x 32 floats per sample, each way) "
-    "-- the re-gather they replace would be 3.758 GB": 2 * RAYS_PER_BATCH * SAMPLES * 7 * 32 * 4,
-    "table-gradient scatter (hash_stencil_bwd_binned + bucket_accumulate)": RAYS_PER_BATCH * SAMPLES * 7 * 2048,
-}
-# ... and SURVEY 8(d)'s contract figure for the reference's schedule (3 forward renders + 3 backward passes of 7, 6 and 7 evaluations per sample)
-SDS_BYTES_SURVEY = 3 * RAYS_PER_BATCH * BYTES_PER_RAY + (7 + 6 + 7) * RAYS_PER_BATCH * SAMPLES * 2048
-
-
-def _binding(kernel):
-    """busy fractions of a kernel from the committed PMC pass (profiles/traffic.json `binding`, tools/collect_profiles.py) or None"""
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        b = (tj.get("binding") or {}).get(kernel)
-        return (b, tj.get("binding_source") or tj.get("profile")) if b else (None, None)
-    except Exception:
-        return None, None
-
-
-def _grid_roofline(kernel, evals, ms):
-    """roofline object of the regular-grid SDF kernels (mesh export, density grid).  Their x-tiles make several lanes of a gather share one 64-byte
-    sector (the spatial hash is linear in x), so the REQUEST bytes of SURVEY 8(d) -- 1024 B per query -- are not what moves: `frac` is taken against the
-    sector bytes the L1s actually asked of L2 (TCP_TCC_READ_REQ x 64 B per query, committed PMC pass), which cannot exceed the peak; the request-byte rate
-    stays in the object as `request_gbs` / `request_rate_vs_hbm_peak` (it can exceed 1 and did: 1.09), and `issue` names what binds the kernel."""
-    b, src = _binding(kernel)
-    req = evals * 1024 / 1e9
-    out = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s", "request_bytes": evals * 1024, "request_gbs": req / (ms * 1e-3),
-           "request_rate_vs_hbm_peak": req / (ms * 1e-3) / HBM_PEAK_GBS, "request_floor_ms_at_peak": req / HBM_PEAK_GBS * 1e3}
-    if b and b.get("l2_sector_bytes_per_launch"):
-        sec = b["l2_sector_bytes_per_launch"] / 1e9
-        out.update(algorithmic_bytes=int(b["l2_sector_bytes_per_launch"]), achieved=sec / (ms * 1e-3), frac=sec / (ms * 1e-3) / HBM_PEAK_GBS,
-                   bytes_basis="64-byte sectors requested of L2 per launch (TCP_TCC_READ_REQ x 64 B, " + str(src) + "); timed live")
-    else:
-        out.update(algorithmic_bytes=evals * 1024, achieved=req / (ms * 1e-3), frac=min(1.0, req / (ms * 1e-3) / HBM_PEAK_GBS),
-                   bytes_basis="request bytes (no committed sector counter for this kernel): capped at 1")
-    if b and "issue" in b:
-        out["issue"] = dict(b["issue"], source=src)
-    if b and "gather" in b:
-        out["gather"] = dict(b["gather"], source=src)
-    return out
-
-
-def make_net(p, table, dev, train, cuda_ray=False):
-    from avatarcraft_amd.instant_nsr import NeRFNetwork
-    torch.manual_seed(0)
-    net = NeRFNetwork(cuda_ray=cuda_ray)
-    sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
-    sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
-    net.load_state_dict(sd, strict=not cuda_ray)       # (cuda_ray adds the density grid / step counter buffers)
-    return net.to(dev).train(train)
-
-
-def sds_view(rank):
-    """the 64x64 stride-4 sub-sampled rays of a 256x256 training camera (stylize.py:98-107), one view per rank"""
-    from avatarcraft_amd.synthetic import make_rays
-    yaw = 2 * np.pi * ((rank * 12) % 100) / 100.0
-    ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=yaw, pitch=0.0)
-    return ro.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy(), rd.reshape(256, 256, 3)[1::4, 2::4].reshape(-1, 3).copy()
-
-
-class _NoStep:
-    """optimizer stand-in whose step() leaves the gradients and the weights alone (bench.py inspects the gradient of one more step)"""
-
-    def __init__(self, opt):
-        self.param_groups = opt.param_groups
-
-    def zero_grad(self, set_to_none=False):
-        pass
-
-    def step(self):
-        pass
-
-
-def time_sds_step(dev, p, table, rank, world, dist, steps):
-    """secondary metric: ms per 4096-ray SDS step (stylize.py coarse stage: 64x64 sub-sampled view of a 256x256 camera,
-    3 renders + the backward of the three loss terms per patch, Adam, all-reduce of the 49 MB flat gradient when a process group exists).
-    Synthetic guidance (the SD UNet is out of scope).  Carries its own roofline (algorithmic bytes of the launched work / step time) and
-    HIP-event times per phase of the step."""
-    from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view
-    net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
-    # the reference's torch.optim.Adam(lr = 5e-3) as one launch over the 12.2 M parameters: stylize.Adam (ac_adam_step, also clears the gradients it consumed)
-    # by default; AC_FUSED_ADAM=1 torch's fused kernel, =0 torch's default
-    which = os.environ.get("AC_FUSED_ADAM", "2")
-    opt = (__import__("avatarcraft_amd.stylize", fromlist=["Adam"]).Adam(net.parameters(), lr=5e-3, zero_grad_in_step=True) if which == "2"
-           else torch.optim.Adam(net.parameters(), lr=5e-3, fused=which == "1"))
-    flat = flat_grad_view(net.parameters())
-    guidance = SyntheticGuidance(42 + rank)
-    ro, rd = sds_view(rank)
-    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
-    for _ in range(2):
-        sds_step(net, net_gt, ro, rd, (64, 64), opt, guidance, batch_size=4096, flat_grad=flat)        # warm-up
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier(); torch.cuda.synchronize()
-    marks = []
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        sds_step(net, net_gt, ro, rd, (64, 64), opt, guidance, batch_size=4096, flat_grad=flat, timers=marks)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
-    phases = {}
-    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-        if n1 != "start":
-            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
-    ms = dt / steps * 1e3
-    # what the N > 1 all-reduce carries: one more step with the optimizer's zero_grad left out of the picture -- the share of the flat 49 MB gradient
-    # that one view actually touches (outside the timed region)
-    opt.zero_grad(set_to_none=False)
-    sds_step(net, net_gt, ro, rd, (64, 64), _NoStep(opt), guidance, batch_size=4096, flat_grad=flat)
-    emb = net.encoder.embeddings.grad
-    nz_table = float((emb != 0).any(dim=-1).float().mean().item()) if emb is not None else None
-    nz_flat = float((flat != 0).float().mean().item())
-    launched = sum(SDS_BYTES_LAUNCHED.values())
-    ach = launched / (ms * 1e-3) / 1e9
-    res = {"ms_per_step": ms, "rays_per_step_per_gpu": 4096, "steps": steps, "renders_per_step": "1 no-grad + 1 grad (one launch: ac_render_rays_pair) + 1 frozen",
-           "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)", "phase_ms": {k: round(v, 4) for k, v in phases.items()},
-           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_step": launched, "bytes_by_kernel": SDS_BYTES_LAUNCHED,
-                        "survey_contract_bytes_per_step": SDS_BYTES_SURVEY, "frac_of_survey_contract": SDS_BYTES_SURVEY / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None},
-           "grad_allreduce_mb": round(flat.numel() * 4 / 1e6, 2) if dist is not None else 0,
-           "grad_allreduce_ms": round(phases.get("grad_allreduce", 0.0), 4),
-           "grad_nonzero_frac": {"flat_gradient": round(nz_flat, 4), "table_entries": None if nz_table is None else round(nz_table, 4),
-                                 "note": "share of the flat gradient one 4096-ray view touches: what a sparse all-reduce could leave out at most"},
-           "grad_allreduce_overlap": ("levels 8-15 of the table gradient all-reduced from a side stream during the rest of the backward (AC_OVERLAP_ALLREDUCE=1)"
-                                      if __import__("avatarcraft_amd.stylize", fromlist=["x"]).OVERLAP_GRAD_ALLREDUCE else "off (one collective after the backward)"),
-           "core": "no autograd graph: forward = ac_render_rays_pair (render_val and the training render of the same rays in one launch, per-sample outputs and stencil features of the second kept), upstream gradients "
-                   "written down (ac_sds_upstream), backward = ac_render_core_backward (compositing, colour MLP, normalisation + eikonal, fused SDF "
-                   "query on the kept features, binned two-pass table scatter) + ac_param_grads (weight norm, biases, variance); torch: noise, fused Adam"}
-    return res, (net, net_gt)
-
-
-def time_sds_fine_view(dev, p, table, steps=2, whole_view_backward=False):
-    """The fine stage of a stylisation run (stylize.py:98-107 with stride min(1, subsample_scale // 2) = 1, quirk C.8; :143-199): one optimizer step on a
-    full 256 x 256 view = 16 patches of 4096 rays -- render_val of the whole view, the guidance, then per patch the training render, the frozen avatar's
-    render and the backward of the three loss terms, gradients accumulating over the 16 patches; 20 of the default run's 25 epochs x 150 views are this.
-    Timed twice: with render_val and the frozen avatar's render as ONE launch per view each (the default, stylize.WHOLE_VIEW_RENDERS) and patch by patch
-    (the harness's own batching, round 4).  Same launched-bytes roofline as sds_step: 16 x the coarse step's bytes."""
-    import avatarcraft_amd.stylize as ST
-    from avatarcraft_amd.synthetic import make_rays
-    net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
-    opt = ST.Adam(net.parameters(), lr=5e-3, zero_grad_in_step=True)
-    flat = ST.flat_grad_view(net.parameters())
-    guidance = ST.SyntheticGuidance(42)
-    ro, rd = make_rays(256, 256, dist=1.8, f=200.0, yaw=0.0, pitch=0.0)
-    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
-    out = {}
-    variants = [("patch_by_patch", False, False), ("whole_view_renders", True, False)]
-    if whole_view_backward:                                  # opt-in (--whole-view-backward): ~75 GB of scratch; measured in profiles/r06_experiments.txt section 10
-        variants.append(("whole_view_backward", True, True))
-    for name, whole, whole_b in variants:
-        ST.WHOLE_VIEW_RENDERS, ST.WHOLE_VIEW_BACKWARD = whole, whole_b
-        ST.sds_step(net, net_gt, ro, rd, (256, 256), opt, guidance, batch_size=4096, flat_grad=flat)       # warm-up
-        torch.cuda.synchronize()
-        marks = []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            ST.sds_step(net, net_gt, ro, rd, (256, 256), opt, guidance, batch_size=4096, flat_grad=flat, timers=marks)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        phases = {}
-        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-            if n1 != "start":
-                phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
-        out[name] = {"ms_per_view": ms, "phase_ms": {k: round(v, 3) for k, v in phases.items()}}
-    ST.WHOLE_VIEW_RENDERS, ST.WHOLE_VIEW_BACKWARD = True, False
-    from avatarcraft_amd import nsr_ops as _ops
-    _ops.free_scratch()                                      # (the whole-view backward's ~75 GB of scratch)
-    launched = 16 * sum(SDS_BYTES_LAUNCHED.values())
-    ms = out["whole_view_renders"]["ms_per_view"]
-    ach = launched / (ms * 1e-3) / 1e9
-    return {"ms_per_view": ms, "rays_per_view": 65536, "patches": 16, "steps": steps, "guidance": "synthetic clamp(N(0,1)) (SD UNet out of scope)",
-            "phase_ms": out["whole_view_renders"]["phase_ms"], "patch_by_patch": out["patch_by_patch"],
-            "whole_view_backward": (dict(out["whole_view_backward"], note="the training forward and the backward of all 16 patches as one launch each (stylize.WHOLE_VIEW_BACKWARD, "
-                                         "off by default: its 16 x larger intermediates leave the Infinity Cache; gradients equal to 2e-6 of max)")
-                                    if "whole_view_backward" in out else "not timed in this run (--whole-view-backward; profiles/r06_experiments.txt section 10: 74.4 ms against 73.7)"),
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_view": launched,
-                         "note": "16 x the coarse step's launched bytes (render_val, training forward, frozen render, stencil features, table scatter per patch)"},
-            "note": "render_val and the frozen avatar's opacity render are one launch per view (bit-identical to the 16 per-patch launches: same draws in the "
-                    "same order); the training forward + backward stay per patch (the reference's memory bound: 4096 rays x 128 samples of saved activations)"}
-
-
-def cpu_baseline_sds(p, table, n_side=16, threads=None):
-    """CPU leg of the SDS step on a bounded sample (n_side^2 rays of the same training view): the no-grad renders through the C oracle
-    (OpenMP), the differentiable render core as torch-CPU autograd (MKL threads) over a hash encoder served by the oracle's forward /
-    backward -- the structure of the reference's own CPU path (pure PyTorch + its hash kernel), with the reference's three backward
-    passes folded into one like the GPU path.  kind = "port"."""
-    import torch.nn as nn
-    from oracle import oracle as O
-    from avatarcraft_amd.instant_nsr import NeRFNetwork
-    # threads: this leg is many medium-sized torch ops and a hash backward that is parallel over its 16 levels only; on a 256-core host the
-    # full thread count is SLOWER than 32 (51 s per 256-ray step against a few seconds), so the leg runs on min(cores, 32) threads and says so
-    cores = min(os.cpu_count() or 1, 32) if threads is None else int(threads)
-    torch.set_num_threads(cores)
-    try:
-        import ctypes
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
-    except OSError:
-        pass
-
-    class _Enc(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x01, emb, offsets, S):
-            out, _, _ = O.hash_encode_forward(x01.detach().numpy(), emb.detach().numpy(), offsets, S, 16)
-            ctx.save_for_backward(x01, emb); ctx.o = (offsets, S)
-            return torch.from_numpy(np.ascontiguousarray(out.transpose(1, 0, 2).reshape(x01.shape[0], -1)))
-
-        @staticmethod
-        def backward(ctx, g):
-            x01, emb = ctx.saved_tensors
-            gl = np.ascontiguousarray(g.numpy().reshape(x01.shape[0], 16, 2).transpose(1, 0, 2))
-            gg, _ = O.hash_encode_backward(gl, x01.numpy(), emb.detach().numpy(), ctx.o[0], ctx.o[1], 16, None)
-            return None, torch.from_numpy(gg), None, None
-
-    class OracleEncoder(nn.Module):               # stands where HashEncoder stands (no forward_stencil: 7 encoder calls per sample, like the reference)
-        def __init__(self, emb, offsets, pls):
-            super().__init__()
-            self.embeddings = nn.Parameter(emb); self.offsets_np = offsets; self.S = np.float32(np.log2(pls))
-            self.num_levels, self.level_dim, self.input_dim, self.per_level_scale, self.base_resolution = 16, 2, 3, pls, 16
-
-        def forward(self, x, size=1):
-            return _Enc.apply((x + size) / (2 * size), self.embeddings, self.offsets_np, self.S)
-
-    def cpu_net(train):
-        torch.manual_seed(0)
-        net = NeRFNetwork()
-        sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net", "deviation_net"))}
-        net.load_state_dict(sd, strict=False)
-        net.encoder = OracleEncoder(torch.from_numpy(table.copy()), np.asarray(p["offsets"], np.int32), float(p["per_level_scale"]))
-        net.fused_training = False
-        return net.train(train)
-    net = cpu_net(True)
-    of = oracle_field(p, table)
-    ro, rd = sds_view(0)
-    idx = np.arange(0, 4096, 4096 // (n_side * n_side))[:n_side * n_side]
-    ro, rd = ro[idx], rd[idx]
-    n = ro.shape[0]
-    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
-    rs = np.random.RandomState(0)
-    inv_s = float(p["inv_s"])
-
-    def step():
-        noise = rs.uniform(0, 1, (n, NUM_STEPS)).astype(np.float32)
-        O.render_rays(of, ro, rd, NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, noise=noise, extras=False)                       # (A) render_val
-        g_img = torch.from_numpy(np.clip(rs.normal(0, 1, (n, 3)), -1, 1).astype(np.float32))                              # (B) synthetic guidance
-        opt.zero_grad()
-        noise = rs.uniform(0, 1, (n, NUM_STEPS)).astype(np.float32)
-        z = O.render_rays(of, ro, rd, NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, noise=noise)["z_vals"]                       # (C) sampling stage (no grad)
-        tro, trd = torch.from_numpy(ro), torch.from_numpy(rd)
-        out = net._render_core_autograd(tro, trd, torch.from_numpy(z), NUM_STEPS, UPSAMPLE_STEPS, 1.6, None, 1.0, 0.0, 1, n)
-        wgt = O.render_rays(of, ro, rd, NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, extras=False)["weights_sum"]             # frozen net_gt
-        opa = torch.nn.functional.smooth_l1_loss(out[2].clamp(0, 1), torch.from_numpy(wgt).reshape(-1, 1).clamp(0, 1)) * 1e5
-        ((out[3][0] * g_img).sum() + 0.01 * out[5] + opa).backward()
-        opt.step()                                                                                                        # (D)
-    step()
-    t0 = time.time(); reps = 0
-    while reps < 1 or (time.time() - t0 < 8.0 and reps < 8):
-        step(); reps += 1
-    dt = (time.time() - t0) / reps
-    return dict(value=n / dt, unit="rays/s (SDS steps)", ms_per_4096_ray_step_equivalent=dt * 1e3 * 4096 / n, cores=os.cpu_count() or 1, threads=cores,
-                threads_note="min(host cores, 32): this leg is many medium-sized torch ops and a hash backward parallel over its 16 levels only; on a 256-core "
-                             "host the full thread count is slower (51 s per 256-ray step)", kind="port",
-                sample=f"{reps} step(s) of {n} rays (every {4096 // n}-th ray of the 4096-ray training view), 64+64 samples, {dt:.2f} s each: C oracle (OpenMP) "
-                       f"for the two no-grad renders and the sampling stage, torch-CPU autograd ({torch.get_num_threads()} threads) over the oracle's hash "
-                       f"forward/backward for the render core, torch Adam on 12.2 M parameters")
-
-
-def time_posed_frame(dev, p, table, frames, cpu=True):
-    """secondary metric: ms per 256x256 frame of render_warp.py (BASELINE config 4): posed-space rendering, 32+32 samples per ray,
-    the whole frame in one ray batch as drivers.render_animation does (the reference driver's 8192-ray batches are timed beside it), SMPL-sized synthetic body (6 891 vertices / 13 778 faces, per-vertex 4x4), mesh uploaded
-    and its culling structure rebuilt once per frame.  The reference does the two warps of every batch on the CPU (libigl).
-    roofline: SURVEY 8(d)'s 507 904 gather bytes per ray (496 hash evaluations) x 65 536 rays / frame time."""
-    from avatarcraft_amd.render_utils import render_instantnsr_naive
-    from avatarcraft_amd.synthetic import make_rays, make_body
-    net = make_net(p, table, dev, False)
-    net.skip_masked_samples = True          # what drivers.render_animation sets: masked-out tiles (alpha * 0) are not evaluated; pixels bit-identical
-    verts, faces, Ts = make_body(n_lat=83, n_lon=83)
-    ro_h, rd_h = make_rays(256, 256, dist=1.8, f=443.405 / 2, yaw=0.3, pitch=-0.1)
-    ro, rd = torch.from_numpy(ro_h).to(dev), torch.from_numpy(rd_h).to(dev)
-
-    def frame(rpb=65536, v=verts, T_=Ts):
-        rgb, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=rpb, requires_grad=False, render_can=False, perturb=False, verts=v, faces=faces,
-                                         Ts=T_, num_steps=32, upsample_steps=32, bound=1.6)
-        return rgb
-
-    # (a) ONE pose repeated (rounds 1 - 5's figure; no temporal seeds: a repeated pose would hand every search its own answer)
-    net.warp_temporal_seeds = False
-
-    def timed(rpb):
-        rgb = frame(rpb); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(frames):
-            rgb = frame(rpb)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / frames, rgb
-    dt8, rgb8 = timed(8192)
-    dt_static, rgb = timed(65536)
-    same = bool(torch.equal(rgb, rgb8))
-    # (b) a 20-frame ANIMATION (synthetic.make_body_sequence: the mesh changes every frame, like render_warp.py's pose sequence): every frame uploads its mesh,
-    # rebuilds the culling structure and renders; with the temporal seeds of the closest-face searches (the product's default) and without.  The headline
-    # posed figure is this sequence with seeds; pixels must be identical frame by frame.
-    from avatarcraft_amd.synthetic import make_body_sequence
-    seq_v, _, seq_T = make_body_sequence(20, 83, 83)
-
-    def sequence(seeds):
-        net.warp_temporal_seeds = seeds
-        net.__dict__.pop("_warp_seed_rows", None)
-        frame(65536, seq_v[-1], seq_T[-1]); torch.cuda.synchronize()          # (warm-up; with seeds: the frame before the first one of the loop)
-        out = []
-        t0 = time.perf_counter()
-        for v, T_ in zip(seq_v, seq_T):
-            out.append(frame(65536, v, T_))
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / len(seq_v), out
-    dt_noseed, fr_noseed = sequence(False)
-    dt, fr_seed = sequence(True)
-    seq_same = all(bool(torch.equal(a_, b_)) for a_, b_ in zip(fr_seed, fr_noseed))
-    dt_noseed2, _ = sequence(False)
-    dt2, _ = sequence(True)
-    dt_noseed, dt = min(dt_noseed, dt_noseed2), min(dt, dt2)
-    del fr_seed, fr_noseed
-    net.warp_temporal_seeds = False
-    # ---- what bounds the frame (one instrumented frame outside the timed ones): the two render passes against the HBM roofline on the hash-grid gather
-    # bytes of the tiles they actually evaluate (SURVEY 8d: 1024 B per evaluation), the two closest-face searches against the fp64 vector peak on the
-    # exact point-triangle tests they actually run (ac_warp_accel_work), with the phase times from HIP events inside ac_render_rays_warped
-    import ctypes
-    from avatarcraft_amd import nsr_ops, _lib as L
-    wm = nsr_ops.WarpMesh(verts, faces, Ts, dev, 0.05, 0.05, True)
-    L.lib().ac_debug_warped_phases(1)
-    try:
-        fr = nsr_ops.render_rays(net._field(), ro, rd, 32, 32, 1.6, net.forward_variance(), warp=wm, skip_masked=True)
-        ph = (ctypes.c_float * 5)()
-        L.check(L.lib().ac_debug_warped_phase_ms(ctypes.addressof(ph)), "phase_ms")
-    finally:
-        L.lib().ac_debug_warped_phases(0)
-    work = wm.work_counters()
-    n_rays = 65536
-    live_rays = int(n_rays - int(fr["ray_dead"].sum())) if "ray_dead" in fr else n_rays
-    tiles_final = int(fr["mask"].view(n_rays, 4, 16).any(-1).sum())                  # tiles of 16 samples with an unmasked sample: what the final pass evaluates
-    evals_up = live_rays * (32 + 16)                                                   # coarse sdf + the first up-sampling round's new samples (the last round's are not queried)
-    evals_final = tiles_final * 16 * 7
-    bytes_render = (evals_up + evals_final) * 1024
-    ms_setup, ms_s1, ms_up, ms_s2, ms_final = [float(x) for x in ph]
-    ms_render, ms_search = ms_up + ms_final, ms_s1 + ms_s2
-    FLOP_PER_EXACT = 80                # fp64 operations of one point-triangle test (Ericson's closest point, interior path, + the squared distance)
-    FP64_VECTOR_PEAK_TF = 78.6         # MI355X public spec (half the 157.3 TF fp32 vector rate; MI355X_MICROARCH.md lists no fp64 figure)
-    ach_r = bytes_render / (ms_render * 1e-3) / 1e9
-    ach_s = work["exact_tests"] * FLOP_PER_EXACT / (ms_search * 1e-3) / 1e12
-    bytes_frame = 65536 * 496 * 1024
-    res = {"ms_per_frame": dt * 1e3, "rays_per_s": 65536 / dt, "frames": 20, "samples_per_ray": "32+32", "mesh": "synthetic 6891 verts / 13778 faces",
-           "workload": "20-frame synthetic animation (synthetic.make_body_sequence), mesh upload + structure build + render per frame, temporal seeds of the "
-                       "closest-face searches on (the default of the harness); rounds 1 - 5 quoted ms_per_frame_static_pose",
-           "ms_per_frame_seedless": dt_noseed * 1e3, "pixels_identical": seq_same,
-           "ms_per_frame_static_pose": dt_static * 1e3, "static_pose_frames": frames,
-           "skip_masked": True, "rays_per_batch": 65536,
-           "ms_per_frame_8192_ray_batches": dt8 * 1e3, "pixels_identical_across_batch_sizes": same,
-           "covered": float((rgb < 0.999).any(dim=1).float().mean()),
-           "phase_ms": {"near_far_coarse_points_ray_cull": round(ms_setup, 4), "search_coarse": round(ms_s1, 4), "up_sampling_pass": round(ms_up, 4),
-                        "search_fine": round(ms_s2, 4), "final_pass": round(ms_final, 4),
-                        "note": "HIP events inside one ac_render_rays_warped call (65 536 rays); the per-frame mesh upload + structure build is in ms_per_frame, not here"},
-           "roofline": {"bound": "hbm", "achieved": ach_r, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_r / HBM_PEAK_GBS, "kernel": "render_rays_kernel<UPSAMPLE> + <FINAL>",
-                        "kernel_ms": ms_render, "algorithmic_bytes_per_frame": bytes_render, "live_rays": live_rays, "evaluated_tiles_final_pass": tiles_final,
-                        "hash_evaluations": {"up_sampling_pass": evals_up, "final_pass": evals_final},
-                        # the two passes apart (VERDICT round 5 item 6a: "0.53 against the headline's 0.705 on the same code"): the up-sampling pass evaluates
-                        # SINGLE points (8 gathers per level and evaluation, nothing shared), the final pass 7-point stencils (the seven evaluations of a sample
-                        # share most corners): the request-byte measure prices both at 1024 B per evaluation, so the blend sits between them
-                        "by_pass": {"up_sampling_pass": {"ms": ms_up, "frac": evals_up * 1024 / (ms_up * 1e-3) / 1e9 / HBM_PEAK_GBS, "evaluations_per_s": evals_up / (ms_up * 1e-3)},
-                                    "final_pass": {"ms": ms_final, "frac": evals_final * 1024 / (ms_final * 1e-3) / 1e9 / HBM_PEAK_GBS, "evaluations_per_s": evals_final / (ms_final * 1e-3)},
-                                    "headline_kernel_evaluations_per_s_for_comparison": 4096 * 1008 / 0.746e-3},
-                        "nominal_bytes_per_frame_every_sample_evaluated": bytes_frame,
-                        "note": "render passes only: gather-request bytes (1024 B per hash evaluation) of the rays the cull keeps and the 16-sample tiles the mask "
-                                "leaves, over the two passes' time; the table lives in L2 / MALL, so like the headline this is a request-byte fraction, not HBM traffic",
-                        "traffic": None},
-           "search_roofline": {"bound": "fp64 vector", "achieved": ach_s, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_s / FP64_VECTOR_PEAK_TF,
-                               "kernel": "warp_samples_accel_kernel (two launches: 32 coarse + 64 fine samples per ray)", "kernel_ms": ms_search,
-                               "exact_point_triangle_tests": work["exact_tests"], "flop_per_test": FLOP_PER_EXACT, "work": work,
-                               "samples_searched_nominal": 65536 * 96,
-                               "note": "the fp64 work is the exact tests only; the culling that keeps them few (tile boxes, sub-boxes, bounding discs: fp32, counted in "
-                                       "`work`) is what the time goes into -- the fraction says how far the search is from being bound by its fp64 arithmetic"},
-           "searches_per_s": 65536 * (32 + 64) / dt,
-           "phase_note": "phase_ms / roofline / search_roofline: one instrumented frame of the STATIC pose without seeds (the search's own cost)"}
-    if cpu:
-        from oracle import oracle as O
-        of = oracle_field(p, table)
-        cores = os.cpu_count() or 1
-        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-        wp = dict(verts=verts, faces=faces, Ts=Ts, use_mesh_guide=True)
-        idx = np.arange(0, 65536, 65536 // 256)[:256]            # calibrate on 256 rays, then a sample of >= 4096 rays bounded to ~20 s
-        t0 = time.time(); O.render_rays(of, ro_h[idx], rd_h[idx], 32, 32, 1.6, float(p["inv_s"]), warp=wp, extras=False); dtc = time.time() - t0
-        n = int(min(65536, max(4096, 20.0 / max(dtc, 1e-3) * 256))) // 64 * 64
-        idx = np.arange(0, 65536, max(1, 65536 // n))[:n]
-        t0 = time.time(); O.render_rays(of, ro_h[idx], rd_h[idx], 32, 32, 1.6, float(p["inv_s"]), warp=wp, extras=False); dtc = time.time() - t0
-        res["cpu_baseline"] = dict(value=n / dtc, unit="rays/s", cores=cores, threads=int(os.environ.get("OMP_NUM_THREADS", cores)), kind="port",
-                                   sample=f"{n} rays of the frame (every {max(1, 65536 // n)}-th), 32+32 samples, exhaustive fp64 closest-face search over 13 778 faces "
-                                          f"(OpenMP over rays), {dtc:.1f} s")
-    return res
-
-
-def time_viewdirs(dev, p, table, ro_t, rd_t, steps=8):
-    """NeRFNetwork(use_viewdirs=True) (models/instant_nsr.py:565-569, 644-653: colour layer 1 reads cat[x, sh(d), n, geo_feat]) through the same fused paths as
-    the default model: the 16 spherical harmonics of the ray direction are folded into a per-ray bias of colour layer 1 in the renderer's prologue, so the
-    headline launch and the SDS step should cost what they cost without view directions (round 4: 2.1x / 2.2x through the generic path)."""
-    from avatarcraft_amd import nsr_ops
-    from avatarcraft_amd.instant_nsr import NeRFNetwork
-    from avatarcraft_amd.stylize import sds_step, SyntheticGuidance, flat_grad_view, Adam
-
-    def make(train):
-        torch.manual_seed(0)
-        net = NeRFNetwork(use_viewdirs=True)
-        sd = {k: torch.from_numpy(np.asarray(p[k])) for k in p if k.startswith(("sdf_net", "color_net.1", "color_net.2", "deviation_net"))}
-        sd["encoder.embeddings"] = torch.from_numpy(table); sd["encoder.offsets"] = torch.from_numpy(np.asarray(p["offsets"]))
-        net.load_state_dict(sd, strict=False)                    # (color_net.0 keeps its own [64,37] initialisation)
-        return net.to(dev).train(train)
-    net = make(False)
-    with torch.no_grad():
-        f, inv_s = net._field(), net.forward_variance()
-        out = {}
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-        for k in range(24):
-            b = k % 16
-            sl = slice(b * RAYS_PER_BATCH, (b + 1) * RAYS_PER_BATCH)
-            nsr_ops.render_rays(f, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=out, events=evs[k - 4] if k >= 4 else None)
-        torch.cuda.synchronize()
-        k_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs]))
-    net, net_gt = make(True), make(False)
-    opt = Adam(net.parameters(), lr=5e-3, zero_grad_in_step=True)
-    flat = flat_grad_view(net.parameters())
-    guide = SyntheticGuidance(42)
-    so, sd_ = sds_view(0)
-    so, sd_ = torch.from_numpy(so).to(dev), torch.from_numpy(sd_).to(dev)
-    for _ in range(2):
-        sds_step(net, net_gt, so, sd_, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        sds_step(net, net_gt, so, sd_, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
-    torch.cuda.synchronize()
-    return {"render_kernel_ms_per_4096_rays": k_ms, "rays_per_s": RAYS_PER_BATCH / (k_ms * 1e-3), "sds_step_ms": (time.perf_counter() - t0) / steps * 1e3,
-            "note": "use_viewdirs=True: sh(d) of degree 4 folded into a per-ray bias of colour layer 1 (ac_field.Wc1_sh); compare with the headline's kernel_ms and sds_step.ms_per_step"}
-
-
-def time_geometry(dev, p, table, reps=3):
-    """SURVEY 8(f) rank 3 at the reference's own sizes: the mesh export -- extract_geometry(NSR_BOUND, 512) (stylize.py:267: 512^3 = 134 M forward_sdf
-    queries + marching cubes) -- and the density-grid update of update_extra_state (129^3 queries -> density -> max pool -> merge -> mean), both on the
-    device (csrc/geometry.hip).  Per-launch times by HIP events on the launch stream; gather-request roofline like the headline's (1024 B per query)."""
-    from avatarcraft_amd import nsr_ops
-    from avatarcraft_amd.render_utils import NSR_BOUND
-    net = make_net(p, table, dev, False, cuda_ray=True)
-    res_ = 512
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    out = {}
-    with torch.no_grad():
-        f = net._field()
-        ax = net._grid_axis(NSR_BOUND, res_)
-        vol = torch.empty((res_,) * 3, dtype=torch.float32, device=dev)
-        nsr_ops.field_sdf_grid(f, ax, ax, ax, NSR_BOUND, negate=True, out=vol)                   # warm-up
-        t_sdf, t_mc = [], []
-        for _ in range(reps):
-            e0, e1, e2 = ev(), ev(), ev()
-            e0.record()
-            nsr_ops.field_sdf_grid(f, ax, ax, ax, NSR_BOUND, negate=True, out=vol)
-            e1.record()
-            v, t = nsr_ops.marching_cubes(vol, 0.0, den=res_ - 1.0, span=[3.2] * 3, lo=[-1.6] * 3)
-            e2.record(); torch.cuda.synchronize()
-            t_sdf.append(e0.elapsed_time(e1)); t_mc.append(e1.elapsed_time(e2))
-        t0 = time.perf_counter(); vh, th = v.cpu().numpy(), t.cpu().numpy(); t_copy = (time.perf_counter() - t0) * 1e3
-        t0 = time.perf_counter(); verts, tris = net.extract_geometry(NSR_BOUND, res_); t_e2e = (time.perf_counter() - t0) * 1e3
-        sdf_ms, mc_ms = float(np.median(t_sdf)), float(np.median(t_mc))
-        evals = res_ ** 3
-        gb = evals * 1024 / 1e9
-        out["mesh_export_512"] = {
-            "ms": sdf_ms + mc_ms, "sdf_grid_ms": sdf_ms, "marching_cubes_ms": mc_ms, "mesh_to_host_ms": t_copy, "extract_geometry_call_ms": t_e2e,
-            "field_evaluations": evals, "vertices": int(v.shape[0]), "triangles": int(t.shape[0]),
-            "roofline": _grid_roofline("field_sdf_grid_kernel", evals, sdf_ms),
-            "note": "reference: extract_geometry(NSR_BOUND, 512) of stylize.py:267 (512^3 forward_sdf queries in 256^3 blocks assembled on the host + PyMCubes "
-                    "on the CPU); here one ac_field_sdf_grid launch + ac_marching_cubes_count / _emit (classify, scan, emit; one 8-byte read-back between "
-                    "them), the volume never leaves the device; marching_cubes_ms includes that read-back and the allocation of the scratch"}
-        del vol, v, t
-        # density grid: the reference's call, update_extra_state(bound) once per epoch
-        ts = []
-        for _ in range(reps + 1):
-            e0, e1 = ev(), ev()
-            e0.record(); mean = nsr_ops.density_grid_update(f, net._grid_axis(NSR_BOUND, 129), net.density_grid, NSR_BOUND, 512.0, 0.95); e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        t0 = time.perf_counter(); net.update_extra_state(NSR_BOUND); t_call = (time.perf_counter() - t0) * 1e3
-        net.fused_density_grid = False
-        net.update_extra_state(NSR_BOUND); torch.cuda.synchronize()
-        t0 = time.perf_counter(); net.update_extra_state(NSR_BOUND); torch.cuda.synchronize(); t_torch = (time.perf_counter() - t0) * 1e3
-        net.fused_density_grid = True
-        k_ms = float(np.median(ts[1:]))
-        halo_evals = 137 * 145 * 145               # 129^3 grid points + the +1 halo of every 16 x 8 x 8 brick that lies inside the grid
-        out["density_grid_update"] = {
-            "ms": k_ms, "update_extra_state_call_ms": t_call, "torch_chain_call_ms": t_torch, "grid": [129] * 3, "field_evaluations": halo_evals,
-            "roofline": _grid_roofline("density_grid_kernel", 129 ** 3, k_ms),
-            "note": "one launch: SDF -> logistic density -> 2^3 max pool -> max(grid * decay, new) in place -> mean; update_extra_state_call_ms = the whole "
-                    "method with its one read-back of (mean, step counts); torch_chain_call_ms = the reference-shaped torch formulation on the same fused SDF "
-                    "query (round 4's path)"}
-    return out
-
-
-def time_occupancy_render(dev, p, table, ro, rd, reps=3):
-    """A SEPARATE figure, not the headline and not run()'s result: the occupancy-grid render (render(cuda_ray=True) -> NeRFRenderer.run_cuda, the path
-    models/instant_nsr.py:358-363 dispatches to and the reference never defines): density grid (update_extra_state) -> march -> fused per-sample field
-    (ac_field_samples) -> packed compositor, on the same 256 x 256 view.  The grid is built for a sharp variance (inv_s = 512 hard-coded at :325), so
-    this leg sets forward_variance() = 512 and reports how far its pixels are from run()'s at that variance (two quadratures of one integral)."""
-    from avatarcraft_amd.render_utils import NSR_BOUND
-    net = make_net(p, table, dev, False, cuda_ray=True)
-    with torch.no_grad():
-        net.deviation_net.variance.fill_(float(np.log(512.0) / 10.0))
-    t0 = time.perf_counter(); net.update_extra_state(NSR_BOUND); torch.cuda.synchronize(); t_grid = time.perf_counter() - t0
-    kw = dict(num_steps=64, bound=NSR_BOUND, upsample_steps=64, bg_color=None, cos_anneal_ratio=1.0, normal_epsilon_ratio=0.0)
-    n = ro.shape[0]
-
-    def view(rpb):
-        rounds = 0
-        outs = []
-        for i in range(0, n, rpb):
-            outs.append(net.render(ro[None, i:i + rpb], rd[None, i:i + rpb], **kw)["rgb"][0])
-            rounds += net._last_cuda_rounds
-        return torch.cat(outs), rounds
-
-    res = {}
-    with torch.no_grad():
-        # the one-launch form (ac_render_rays_occupancy: march + field + composite per ray; run_cuda's default in eval()) and the reference-shaped loop of
-        # compact / march / field / composite rounds with one host read-back each (the same pixels bit for bit)
-        for mode, rounds_on in (("one_launch", False), ("rounds", True)):
-            net.occupancy_rounds = rounds_on
-            for rpb in (RAYS_PER_BATCH, n):
-                img, rounds = view(rpb); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(reps * (4 if not rounds_on else 1)):
-                    img, rounds = view(rpb)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / (reps * (4 if not rounds_on else 1))
-                res[f"eval_{mode}_{rpb}_ray_batches"] = {"ms_per_view": dt * 1e3, "rays_per_s": n / dt, "march_rounds_per_view": rounds}
-        net.occupancy_rounds = False
-        # the two one-launch kernels side by side on the whole view (run_cuda picks the phased one from 2048 rays on: same pixels)
-        from avatarcraft_amd import nsr_ops as _o
-        fa = (net._field(), ro, rd, net.density_grid, net.mean_density, NSR_BOUND, 0.005, net.forward_variance(), 1.0)
-        for nm, ph in (("phases_rounds_inside_the_launch", True), ("one_wave_per_ray_group", False)):
-            a_img = _o.render_rays_occupancy(*fa, phased=ph)["image"]; torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(12):
-                _o.render_rays_occupancy(*fa, phased=ph)
-            torch.cuda.synchronize()
-            res.setdefault("eval_kernels_65536_rays", {})[nm] = {"ms_per_view": (time.perf_counter() - t0) / 12 * 1e3}
-            res["eval_kernels_65536_rays"].setdefault("_img", []).append(a_img)
-        _imgs = res["eval_kernels_65536_rays"].pop("_img")
-        res["eval_kernels_65536_rays"]["pixels_identical"] = bool(torch.equal(_imgs[0], _imgs[1]))
-        # what a driver gets: the harness (render_instantnsr_naive, rays_per_batch = 4096 like render_canonical.py) hands an eval() occupancy net the whole view
-        from avatarcraft_amd.render_utils import render_instantnsr_naive as _harness, WHITE_BKG as _W
-        hk = dict(rays_per_batch=RAYS_PER_BATCH, requires_grad=False, bkg_key=_W, render_can=True, perturb=False, return_raw=True, num_steps=64, upsample_steps=64,
-                  bound=NSR_BOUND)
-        himg = _harness(net, ro, rd, **hk)[0]; torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps * 4):
-            himg = _harness(net, ro, rd, **hk)[0]
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / (reps * 4)
-        res["eval_through_the_harness_4096_ray_batches"] = {"ms_per_view": dt * 1e3, "rays_per_s": n / dt,
-                                                            "note": "render_instantnsr_naive(rays_per_batch=4096): one launch per view for an eval() occupancy net (same pixels)"}
-        from avatarcraft_amd import nsr_ops as _ops
-        res["samples_evaluated_per_view"] = int(_ops.render_rays_occupancy(net._field(), ro, rd, net.density_grid, net.mean_density, NSR_BOUND, 0.005,
-                                                                           net.forward_variance(), 1.0, count_samples=True)["n_samples"].item())
-        net.cuda_ray = False
-        ref = torch.cat([net.render(ro[None, i:i + RAYS_PER_BATCH], rd[None, i:i + RAYS_PER_BATCH], **kw)["rgb"][0] for i in range(0, n, RAYS_PER_BATCH)])
-        net.cuda_ray = True
-        res["max_abs_rgb_diff_vs_run_at_inv_s_512"] = float((img - ref).abs().max())
-        res["mean_abs_rgb_diff_vs_run_at_inv_s_512"] = float((img - ref).abs().mean())
-        # training form (march_rays_train with the per-epoch sample budget: no host synchronisation), no-grad: march + field + two composites per batch
-        net.train()
-        so, sd_ = sds_view(0)                                    # the 4096-ray training view of the SDS step (every ray aimed at the body)
-        ro, rd = torch.from_numpy(so).to(dev), torch.from_numpy(sd_).to(dev)
-        b0 = slice(0, RAYS_PER_BATCH)
-        net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
-        samples = int(net.step_counter[0, 0].item())
-        net.mean_count = samples + 4096
-        def train_form(one_launch):
-            net.occupancy_train_one_launch = one_launch
-            try:
-                for _ in range(3):
-                    o = net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(40):
-                    net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t0) / 40, o["rgb"]
-            finally:
-                net.occupancy_train_one_launch = True
-        dt_chain, img_chain = train_form(False)
-        dt, img_one = train_form(True)
-    # ... and UNDER AUTOGRAD (forward + backward of the same batch; VERDICT round 5 item 9): the fused SDF-query / colour operators + the packed compositor,
-    # with the shading glue between them as one launch each way (nsr_ops.packed_shading, round 6) and as the torch formulation it replaced
-    def train_autograd(fused):
-        net.occupancy_fused_shading = fused
-        try:
-            def step():
-                net.zero_grad(set_to_none=True)
-                o = net.render(ro[None, b0], rd[None, b0], perturb=True, **kw)
-                (o["rgb"].sum() + o["weight_sum"].sum() + 0.1 * o["gradient_error"]).backward()
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                step()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / 20
-        finally:
-            net.occupancy_fused_shading = True
-            net.zero_grad(set_to_none=True)
-    dt_ag_torch, dt_ag = train_autograd(False), train_autograd(True)
-    with torch.no_grad():                                    # (bookkeeping only)
-        res["train_form_4096_ray_batch"] = {"ms_per_batch": dt * 1e3, "rays_per_s": RAYS_PER_BATCH / dt, "samples_per_ray": samples / RAYS_PER_BATCH,
-                                            "bytes_per_sample_gathered": 7 * 1024, "gather_gbs": samples * 7 * 1024 / dt / 1e9,
-                                            "chain_of_operators_ms_per_batch": dt_chain * 1e3, "pixels_identical_to_the_chain": bool(torch.equal(img_one, img_chain)),
-                                            "under_autograd_forward_plus_backward_ms": dt_ag * 1e3, "under_autograd_with_torch_shading_glue_ms": dt_ag_torch * 1e3,
-                                            "note": "net.train() under no_grad (stylize.py's render_val of a cuda_ray net): ONE launch (ac_render_rays_occupancy_train: "
-                                                    "count, grid barrier, march + field + both composites + eikonal term + background; grid look-ups 8 at a time) "
-                                                    "against the chain it replaces (march_rays_train, ac_field_samples, composite_rays_train x 2, torch)"}
-    res["density_grid_update_ms"] = t_grid * 1e3
-    res["note"] = ("occupancy-grid path (cuda_ray=True): a separate renderer from the headline's run(); the reference ships its operators but no caller "
-                   "(run_cuda is undefined there), so there is no reference number for it")
-    return res
-
-
-def time_real_sd_step(dev, p, table, steps=3):
-    """`--real-sd`: one stylisation step with the REAL Stable-Diffusion guidance (models/diffusion.py:28-69,92-149 -- VAE encoder with grad, UNet on a
-    batch of two 64 x 64 latents, classifier-free guidance 100) when diffusers + transformers + the runwayml/stable-diffusion-v1-5 weights are on
-    this machine; otherwise the reason they are not.  Either outcome is evidence: the SD UNet has never run in this build's environment."""
-    from avatarcraft_amd.guidance import real_sd_probe
-    ok, why = real_sd_probe("1.5")
-    if not ok:
-        return f"absent: {why}"
-    from avatarcraft_amd.guidance import StableDiffusion, SDSGuidance
-    from avatarcraft_amd.stylize import sds_step, flat_grad_view
-    net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-3, fused=True)
-    flat = flat_grad_view(net.parameters())
-    guide = SDSGuidance(StableDiffusion(dev, "1.5"), "Hulk, photorealistic style", 100.0)
-    ro, rd = sds_view(0)
-    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
-    sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
-    torch.cuda.synchronize()
-    marks = []
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat, timers=marks)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    phases = {}
-    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-        if n1 != "start":
-            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
-    return {"ms_per_step": ms, "guidance_ms": phases.get("guidance"), "render_and_backward_ms": ms - phases.get("guidance", 0.0), "steps": steps,
-            "model": why, "dtype": "f32 (the reference loads the pipelines without a dtype)", "phase_ms": {k: round(v, 3) for k, v in phases.items()}}
-
-
-def time_sd_arch_step(dev, p, table, steps=2):
-    """What one stylisation step costs WITH a guidance of Stable-Diffusion 1.5's size (models/diffusion.py:92-149: VAE encoder with grad at 512 x 512, UNet
-    on two 64 x 64 latents, classifier-free guidance) when the real networks are absent: avatarcraft_amd.sd_arch restates their published architecture
-    (859.5 M + 34.2 M parameters, parameter counts equal to the checkpoint's) with RANDOM weights, fp32 like the reference loads them.  A clock, not a
-    guidance: the step's time does not depend on the weights' values, its images would."""
-    from avatarcraft_amd import sd_arch
-    from avatarcraft_amd.guidance import StableDiffusion, SDSGuidance
-    from avatarcraft_amd.stylize import sds_step, flat_grad_view
-    net, net_gt = make_net(p, table, dev, True), make_net(p, table, dev, False)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-3, fused=True)
-    flat = flat_grad_view(net.parameters())
-    t0 = time.perf_counter()
-    sd = StableDiffusion(dev, "1.5", components=sd_arch.components(device=dev))
-    guide = SDSGuidance(sd, "Hulk, photorealistic style", 100.0)
-    ro, rd = sds_view(0)
-    ro, rd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
-    sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)              # warm-up (MIOpen / hipBLASLt pick their kernels here)
-    torch.cuda.synchronize()
-    t_setup = time.perf_counter() - t0
-    marks = []
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat, timers=marks)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    phases = {}
-    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-        if n1 != "start":
-            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1) / steps
-    nu, nv = sd_arch.parameter_counts()
-    g = phases.get("guidance", 0.0)
-
-    def guidance_breakdown(n=3):
-        """HIP-event phases INSIDE the guidance (StableDiffusion.mannual_backward): VAE encoder forward (with grad, 512 x 512) | UNet forward on the two
-        latents (no grad) | backward through the VAE encoder -- the guidance alone on the step's image, n calls"""
-        img = torch.rand(1, 3, 64, 64, device=dev)
-        guide(img); torch.cuda.synchronize()
-        sd.phase_marks = []
-        t0_ = time.perf_counter()
-        for _ in range(n):
-            guide(img)
-        torch.cuda.synchronize()
-        tot = (time.perf_counter() - t0_) / n * 1e3
-        ph = {}
-        mk = sd.phase_marks
-        sd.phase_marks = None
-        for (n0, e0), (n1, e1) in zip(mk[:-1], mk[1:]):
-            if n1 != "start":
-                ph[n1] = ph.get(n1, 0.0) + e0.elapsed_time(e1) / n
-        return {"guidance_call_ms": round(tot, 3), **{k: round(v, 3) for k, v in ph.items()}}
-    breakdown = guidance_breakdown()
-    # the same with PyTorch-level settings that keep fp32 (StableDiffusion.tune: NHWC convolutions, MIOpen find mode, SDPA attention) -- VERDICT round 5 item 8
-    tuned = None
-    try:
-        sd.tune()
-        sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)          # (find mode picks its solvers here)
-        torch.cuda.synchronize()
-        marks3 = []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat, timers=marks3)
-        torch.cuda.synchronize()
-        ms3 = (time.perf_counter() - t0) / steps * 1e3
-        g3 = sum(e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(marks3[:-1], marks3[1:]) if n1 == "guidance") / steps
-        tuned = {"ms_per_step": ms3, "guidance_ms": g3, "phase_ms": guidance_breakdown(),
-                 "settings": "fp32 throughout; channels_last (NHWC) VAE encoder + UNet, torch.backends.cudnn.benchmark (MIOpen find mode), SDPA attention"}
-    except Exception as e:                    # noqa: BLE001
-        tuned = {"error": f"{type(e).__name__}: {e}"}
-    # the same step with the (no-grad) UNet forward under bf16 autocast -- an option of this package's StableDiffusion, not the reference's precision
-    bf16 = None
-    try:
-        sd.unet_autocast = torch.bfloat16
-        sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)
-        torch.cuda.synchronize()
-        marks2 = []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat, timers=marks2)
-        torch.cuda.synchronize()
-        ms2 = (time.perf_counter() - t0) / steps * 1e3
-        g2 = sum(e0.elapsed_time(e1) for (n0, e0), (n1, e1) in zip(marks2[:-1], marks2[1:]) if n1 == "guidance") / steps
-        bf16 = {"ms_per_step": ms2, "guidance_ms": g2, "note": "UNet forward (no grad) under torch.autocast(bfloat16); VAE encoder (with grad) fp32; opt-in "
-                                                                "(StableDiffusion(unet_autocast=torch.bfloat16)), not the reference's precision"}
-    except Exception as e:                    # noqa: BLE001
-        bf16 = {"error": f"{type(e).__name__}: {e}"}
-    finally:
-        sd.unet_autocast = None
-    return {"ms_per_step": ms, "unet_bf16_autocast": bf16, "guidance_ms": g, "guidance_phase_ms": breakdown, "fp32_tuned": tuned,
-            "render_and_backward_ms": ms - g, "guidance_share": g / ms, "steps": steps, "setup_and_first_step_s": t_setup,
-            "phase_ms": {k: round(v, 3) for k, v in phases.items()},
-            "guidance": f"SD-1.5 ARCHITECTURE stand-in (avatarcraft_amd/sd_arch.py): UNet2DConditionModel {nu} + AutoencoderKL encoder {nv} parameters, random "
-                        "weights, fp32; 512 x 512 VAE encode with grad, UNet on 2 x 4 x 64 x 64 latents with [2, 77, 768] text embeddings -- the real "
-                        "guidance's clock, not its values (the pretrained weights are not on this machine: see real_sd)"}
-
-
-def _flush_c_stdio():
-    """RCCL printf()s a version banner when the first communicator is created; with stdout a pipe or a file it sits in C stdio's buffer until exit,
-    i.e. it would land AFTER a line printed from Python"""
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:                         # noqa: BLE001
-        pass
-
-
-def _free_port():
-    import socket
-    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    return port
-
-
-def self_launch(n, argv, script=None):
-    """`python bench.py --gpus N` without torch.distributed.run: start N ranks of this script (one per visible GPU, rendezvous on 127.0.0.1 at a free
-    port), rank 0's stdout is this process's stdout (its JSON line stays the last thing written there), the other ranks' stdout goes to stderr.
-    Returns the exit code: 0 only if every rank exited 0; a rank that dies takes the others down with it (exact PIDs, after a grace period) instead of
-    leaving them in a collective forever."""
-    backend = os.environ.get("AC_DIST_BACKEND", "nccl")
-    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if ndev == 0:
-        print("bench.py needs an MI355X (torch.cuda.is_available() is False); the hot path has no CPU fallback", file=sys.stderr)
-        return 1
-    if ndev < n and backend == "nccl":
-        print(f"bench.py --gpus {n}: only {ndev} GPU(s) visible; RCCL needs one device per rank (AC_DIST_BACKEND=gloo runs the N > 1 code path with "
-              f"ranks sharing a device -- a plumbing check, not a measurement)", file=sys.stderr)
-        return 2
-    # HSA_ENABLE_IPC_MODE_LEGACY: this pool's host driver supports dmabuf IPC only -- the image exports HSA_ENABLE_IPC_MODE_LEGACY=0 for that reason and
-    # its documentation says RCCL / cross-process device memory fails with "hipIpcGetMemHandle: invalid argument" without it (the task environment's own
-    # statement; no multi-GPU box was available to this build to observe either outcome).  So: an inherited value is passed through untouched; with none
-    # inherited the ranks get 0, and if that job dies on an RCCL job (any rank non-zero) it is started ONCE more with the variable unset -- the line
-    # records which attempt produced it (`hsa_ipc_mode_legacy`).  AC_BENCH_IPC_RETRY=0 switches the second attempt off.
-    inherited = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
-    attempts = [(inherited, "inherited from the environment")] if inherited is not None else [("0", "launcher default (dmabuf IPC, as the image exports it)")]
-    if inherited is None and backend == "nccl" and os.environ.get("AC_BENCH_IPC_RETRY", "1") != "0":
-        attempts.append((None, "unset (second attempt: the first, with 0, failed)"))
-    rc = 1
-    for k, (ipc, why) in enumerate(attempts):
-        rc = _launch_once(n, argv, script, ipc, f"attempt {k + 1}: {why}")
-        if rc == 0:
-            break
-        if k + 1 < len(attempts):
-            print(f"bench.py: the {n}-rank job failed (exit {rc}) with HSA_ENABLE_IPC_MODE_LEGACY={ipc}; one more attempt with it unset", file=sys.stderr)
-    return rc
-
-
-def _launch_once(n, argv, script, ipc, ipc_note):
-    import subprocess
-    port = _free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   AC_BENCH_LAUNCHER="self", AC_BENCH_IPC_NOTE=ipc_note)
-        if ipc is None:
-            env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
-        else:
-            env["HSA_ENABLE_IPC_MODE_LEGACY"] = ipc
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
-    rc, dead_since = 0, None
-    while any(p.poll() is None for p in procs):
-        time.sleep(0.2)
-        bad = [p for p in procs if p.poll() not in (None, 0)]
-        if bad and dead_since is None:
-            dead_since = time.time()
-        if dead_since is not None and time.time() - dead_since > float(os.environ.get("AC_BENCH_GRACE_S", "20")):
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-    for r, p in enumerate(procs):
-        if p.returncode != 0:
-            print(f"bench.py: rank {r} exited with {p.returncode}", file=sys.stderr)
-            rc = rc or (p.returncode if p.returncode and p.returncode > 0 else 1)
-    return rc
-
-
-XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0          # per GPU: 7 point-to-point xGMI links x ~153 GB/s (the task's figure for this node type)
-
+from bench_legs.common import BYTES_PER_RAY, FLOP_PER_RAY, H, HBM_PEAK_GBS, NUM_STEPS, RAYS_PER_BATCH, ROOT, UPSAMPLE_STEPS, W, XGMI_LINKS, XGMI_LINK_GBS, make_inputs
+from bench_legs.cpu import cpu_baseline, cpu_baseline_sds
+from bench_legs.sds import time_sds_fine_view, time_sds_step
+from bench_legs.posed import time_posed_frame
+from bench_legs.variants import time_geometry, time_occupancy_render, time_viewdirs
+from bench_legs.guidance import time_real_sd_step, time_sd_arch_step
+from bench_legs.launch import _flush_c_stdio, self_launch
+from bench_legs.common import SAMPLES, SDS_BYTES_LAUNCHED, SDS_BYTES_SURVEY, make_net, oracle_field, sds_view, _binding, _grid_roofline  # noqa: F401  (re-exported: tools/ and tests/ read them here)
+from bench_legs.launch import _free_port, _launch_once  # noqa: F401
 
 def measure_solo(dev, p, field, table, ro, rd, rank, a):
     """this rank alone, no process group: rays/s of the headline launches and ms per SDS step (see main)"""

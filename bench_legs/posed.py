@@ -1,0 +1,138 @@
+"""bench_legs.posed -- a posed 256 x 256 frame of an animation (render_warp.py:40-124: SMPL inverse warp + render)."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from bench_legs.common import HBM_PEAK_GBS, make_net, oracle_field
+
+def time_posed_frame(dev, p, table, frames, cpu=True):
+    """secondary metric: ms per 256x256 frame of render_warp.py (BASELINE config 4): posed-space rendering, 32+32 samples per ray,
+    the whole frame in one ray batch as drivers.render_animation does (the reference driver's 8192-ray batches are timed beside it), SMPL-sized synthetic body (6 891 vertices / 13 778 faces, per-vertex 4x4), mesh uploaded
+    and its culling structure rebuilt once per frame.  The reference does the two warps of every batch on the CPU (libigl).
+    roofline: SURVEY 8(d)'s 507 904 gather bytes per ray (496 hash evaluations) x 65 536 rays / frame time."""
+    from avatarcraft_amd.render_utils import render_instantnsr_naive
+    from avatarcraft_amd.synthetic import make_rays, make_body
+    net = make_net(p, table, dev, False)
+    net.skip_masked_samples = True          # what drivers.render_animation sets: masked-out tiles (alpha * 0) are not evaluated; pixels bit-identical
+    verts, faces, Ts = make_body(n_lat=83, n_lon=83)
+    ro_h, rd_h = make_rays(256, 256, dist=1.8, f=443.405 / 2, yaw=0.3, pitch=-0.1)
+    ro, rd = torch.from_numpy(ro_h).to(dev), torch.from_numpy(rd_h).to(dev)
+
+    def frame(rpb=65536, v=verts, T_=Ts):
+        rgb, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch=rpb, requires_grad=False, render_can=False, perturb=False, verts=v, faces=faces,
+                                         Ts=T_, num_steps=32, upsample_steps=32, bound=1.6)
+        return rgb
+
+    # (a) ONE pose repeated (rounds 1 - 5's figure; no temporal seeds: a repeated pose would hand every search its own answer)
+    net.warp_temporal_seeds = False
+
+    def timed(rpb):
+        rgb = frame(rpb); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            rgb = frame(rpb)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / frames, rgb
+    dt8, rgb8 = timed(8192)
+    dt_static, rgb = timed(65536)
+    same = bool(torch.equal(rgb, rgb8))
+    # (b) a 20-frame ANIMATION (synthetic.make_body_sequence: the mesh changes every frame, like render_warp.py's pose sequence): every frame uploads its mesh,
+    # rebuilds the culling structure and renders; with the temporal seeds of the closest-face searches (the product's default) and without.  The headline
+    # posed figure is this sequence with seeds; pixels must be identical frame by frame.
+    from avatarcraft_amd.synthetic import make_body_sequence
+    seq_v, _, seq_T = make_body_sequence(20, 83, 83)
+
+    def sequence(seeds):
+        net.warp_temporal_seeds = seeds
+        net.__dict__.pop("_warp_seed_rows", None)
+        frame(65536, seq_v[-1], seq_T[-1]); torch.cuda.synchronize()          # (warm-up; with seeds: the frame before the first one of the loop)
+        out = []
+        t0 = time.perf_counter()
+        for v, T_ in zip(seq_v, seq_T):
+            out.append(frame(65536, v, T_))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / len(seq_v), out
+    dt_noseed, fr_noseed = sequence(False)
+    dt, fr_seed = sequence(True)
+    seq_same = all(bool(torch.equal(a_, b_)) for a_, b_ in zip(fr_seed, fr_noseed))
+    dt_noseed2, _ = sequence(False)
+    dt2, _ = sequence(True)
+    dt_noseed, dt = min(dt_noseed, dt_noseed2), min(dt, dt2)
+    del fr_seed, fr_noseed
+    net.warp_temporal_seeds = False
+    # ---- what bounds the frame (one instrumented frame outside the timed ones): the two render passes against the HBM roofline on the hash-grid gather
+    # bytes of the tiles they actually evaluate (1024 B per evaluation), the two closest-face searches against the fp64 vector peak on the
+    # exact point-triangle tests they actually run (ac_warp_accel_work), with the phase times from HIP events inside ac_render_rays_warped
+    import ctypes
+    from avatarcraft_amd import nsr_ops, _lib as L
+    wm = nsr_ops.WarpMesh(verts, faces, Ts, dev, 0.05, 0.05, True)
+    L.lib().ac_debug_warped_phases(1)
+    try:
+        fr = nsr_ops.render_rays(net._field(), ro, rd, 32, 32, 1.6, net.forward_variance(), warp=wm, skip_masked=True)
+        ph = (ctypes.c_float * 5)()
+        L.check(L.lib().ac_debug_warped_phase_ms(ctypes.addressof(ph)), "phase_ms")
+    finally:
+        L.lib().ac_debug_warped_phases(0)
+    work = wm.work_counters()
+    n_rays = 65536
+    live_rays = int(n_rays - int(fr["ray_dead"].sum())) if "ray_dead" in fr else n_rays
+    tiles_final = int(fr["mask"].view(n_rays, 4, 16).any(-1).sum())                  # tiles of 16 samples with an unmasked sample: what the final pass evaluates
+    evals_up = live_rays * (32 + 16)                                                   # coarse sdf + the first up-sampling round's new samples (the last round's are not queried)
+    evals_final = tiles_final * 16 * 7
+    bytes_render = (evals_up + evals_final) * 1024
+    ms_setup, ms_s1, ms_up, ms_s2, ms_final = [float(x) for x in ph]
+    ms_render, ms_search = ms_up + ms_final, ms_s1 + ms_s2
+    FLOP_PER_EXACT = 80                # fp64 operations of one point-triangle test (Ericson's closest point, interior path, + the squared distance)
+    FP64_VECTOR_PEAK_TF = 78.6         # MI355X public spec (half the 157.3 TF fp32 vector rate; MI355X_MICROARCH.md lists no fp64 figure)
+    ach_r = bytes_render / (ms_render * 1e-3) / 1e9
+    ach_s = work["exact_tests"] * FLOP_PER_EXACT / (ms_search * 1e-3) / 1e12
+    bytes_frame = 65536 * 496 * 1024
+    res = {"ms_per_frame": dt * 1e3, "rays_per_s": 65536 / dt, "frames": 20, "samples_per_ray": "32+32", "mesh": "synthetic 6891 verts / 13778 faces",
+           "workload": "20-frame synthetic animation (synthetic.make_body_sequence), mesh upload + structure build + render per frame, temporal seeds of the "
+                       "closest-face searches on (the default of the harness); rounds 1 - 5 quoted ms_per_frame_static_pose",
+           "ms_per_frame_seedless": dt_noseed * 1e3, "pixels_identical": seq_same,
+           "ms_per_frame_static_pose": dt_static * 1e3, "static_pose_frames": frames,
+           "skip_masked": True, "rays_per_batch": 65536,
+           "ms_per_frame_8192_ray_batches": dt8 * 1e3, "pixels_identical_across_batch_sizes": same,
+           "covered": float((rgb < 0.999).any(dim=1).float().mean()),
+           "phase_ms": {"near_far_coarse_points_ray_cull": round(ms_setup, 4), "search_coarse": round(ms_s1, 4), "up_sampling_pass": round(ms_up, 4),
+                        "search_fine": round(ms_s2, 4), "final_pass": round(ms_final, 4),
+                        "note": "HIP events inside one ac_render_rays_warped call (65 536 rays); the per-frame mesh upload + structure build is in ms_per_frame, not here"},
+           "roofline": {"bound": "hbm", "achieved": ach_r, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_r / HBM_PEAK_GBS, "kernel": "render_rays_kernel<UPSAMPLE> + <FINAL>",
+                        "kernel_ms": ms_render, "algorithmic_bytes_per_frame": bytes_render, "live_rays": live_rays, "evaluated_tiles_final_pass": tiles_final,
+                        "hash_evaluations": {"up_sampling_pass": evals_up, "final_pass": evals_final},
+                        # the two passes apart ("0.53 against the headline's 0.705 on the same code"): the up-sampling pass evaluates
+                        # SINGLE points (8 gathers per level and evaluation, nothing shared), the final pass 7-point stencils (the seven evaluations of a sample
+                        # share most corners): the request-byte measure prices both at 1024 B per evaluation, so the blend sits between them
+                        "by_pass": {"up_sampling_pass": {"ms": ms_up, "frac": evals_up * 1024 / (ms_up * 1e-3) / 1e9 / HBM_PEAK_GBS, "evaluations_per_s": evals_up / (ms_up * 1e-3)},
+                                    "final_pass": {"ms": ms_final, "frac": evals_final * 1024 / (ms_final * 1e-3) / 1e9 / HBM_PEAK_GBS, "evaluations_per_s": evals_final / (ms_final * 1e-3)},
+                                    "headline_kernel_evaluations_per_s_for_comparison": 4096 * 1008 / 0.746e-3},
+                        "nominal_bytes_per_frame_every_sample_evaluated": bytes_frame,
+                        "note": "render passes only: gather-request bytes (1024 B per hash evaluation) of the rays the cull keeps and the 16-sample tiles the mask "
+                                "leaves, over the two passes' time; the table lives in L2 / MALL, so like the headline this is a request-byte fraction, not HBM traffic",
+                        "traffic": None},
+           "search_roofline": {"bound": "fp64 vector", "achieved": ach_s, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_s / FP64_VECTOR_PEAK_TF,
+                               "kernel": "warp_samples_accel_kernel (two launches: 32 coarse + 64 fine samples per ray)", "kernel_ms": ms_search,
+                               "exact_point_triangle_tests": work["exact_tests"], "flop_per_test": FLOP_PER_EXACT, "work": work,
+                               "samples_searched_nominal": 65536 * 96,
+                               "note": "the fp64 work is the exact tests only; the culling that keeps them few (tile boxes, sub-boxes, bounding discs: fp32, counted in "
+                                       "`work`) is what the time goes into -- the fraction says how far the search is from being bound by its fp64 arithmetic"},
+           "searches_per_s": 65536 * (32 + 64) / dt,
+           "phase_note": "phase_ms / roofline / search_roofline: one instrumented frame of the STATIC pose without seeds (the search's own cost)"}
+    if cpu:
+        from oracle import oracle as O
+        of = oracle_field(p, table)
+        cores = os.cpu_count() or 1
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        wp = dict(verts=verts, faces=faces, Ts=Ts, use_mesh_guide=True)
+        idx = np.arange(0, 65536, 65536 // 256)[:256]            # calibrate on 256 rays, then a sample of >= 4096 rays bounded to ~20 s
+        t0 = time.time(); O.render_rays(of, ro_h[idx], rd_h[idx], 32, 32, 1.6, float(p["inv_s"]), warp=wp, extras=False); dtc = time.time() - t0
+        n = int(min(65536, max(4096, 20.0 / max(dtc, 1e-3) * 256))) // 64 * 64
+        idx = np.arange(0, 65536, max(1, 65536 // n))[:n]
+        t0 = time.time(); O.render_rays(of, ro_h[idx], rd_h[idx], 32, 32, 1.6, float(p["inv_s"]), warp=wp, extras=False); dtc = time.time() - t0
+        res["cpu_baseline"] = dict(value=n / dtc, unit="rays/s", cores=cores, threads=int(os.environ.get("OMP_NUM_THREADS", cores)), kind="port",
+                                   sample=f"{n} rays of the frame (every {max(1, 65536 // n)}-th), 32+32 samples, exhaustive fp64 closest-face search over 13 778 faces "
+                                          f"(OpenMP over rays), {dtc:.1f} s")
+    return res
