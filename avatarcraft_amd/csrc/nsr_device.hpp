@@ -350,6 +350,51 @@ typedef uint32_t u32q __attribute__((ext_vector_type(4)));
                             // the texture-address path is paced by bytes per instruction, a 64-lane dwordx4 costs it what two dwordx2 cost; r04_experiments 7b)
 #endif
 
+#ifndef AC_PK_INTERP
+#define AC_PK_INTERP 0      // 1: the trilinear interpolation on the packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32) -- round 6 experiment: bit-identical, 6.8 % fewer vector
+                            // instructions (6813 -> 6349 static, 10 spilled dwords fewer) and SLOWER: 0.746 -> 0.781 ms (profiles/r06_experiments.txt section 4d)
+#endif
+typedef float f32p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void interp8(const u32x2 (&v)[8], float qx, float qy, float qz, bool oob, float &f0, float &f1)
+{
+#if AC_PK_INTERP
+    // The same 12 multiplications and 16 fused multiply-adds per level as below, in the same order per accumulator -- the same bits -- as 6 + 8 packed
+    // instructions: the weights of the corners (x, x + 1) travel as a pair, a corner's two channels are the pair the gather delivered, and a weight is
+    // broadcast to both channels by the instruction's operand selects (no move).
+    const f32p wx = { 1.0f - qx, qx };
+    const float wy0 = 1.0f - qy, wz0 = 1.0f - qz;
+    const f32p w0 = wx * f32p{ wy0, wy0 }, w1 = wx * f32p{ qy, qy };           // (w00, w10), (w01, w11)
+    f32p acc = { 0.0f, 0.0f };
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        const float z = (c & 4) ? qz : wz0;
+        const f32p wp = ((c & 2) ? w1 : w0) * f32p{ z, z };
+        const f32p a = { __uint_as_float(v[c].x), __uint_as_float(v[c].y) }, b = { __uint_as_float(v[c + 1].x), __uint_as_float(v[c + 1].y) };
+#if AC_PK_INTERP == 2       // the weights packed, the accumulation as two independent scalar chains
+        acc[0] = fma_(wp[0], a[0], acc[0]); acc[1] = fma_(wp[0], a[1], acc[1]);
+        acc[0] = fma_(wp[1], b[0], acc[0]); acc[1] = fma_(wp[1], b[1], acc[1]);
+#else
+        acc = __builtin_elementwise_fma(__builtin_shufflevector(wp, wp, 0, 0), a, acc);
+        acc = __builtin_elementwise_fma(__builtin_shufflevector(wp, wp, 1, 1), b, acc);
+#endif
+    }
+    f0 = oob ? 0.0f : acc[0];
+    f1 = oob ? 0.0f : acc[1];
+#else
+    const float wx0 = 1.0f - qx, wy0 = 1.0f - qy, wz0 = 1.0f - qz;
+    const float w00 = wx0 * wy0, w10 = qx * wy0, w01 = wx0 * qy, w11 = qx * qy;
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float wxy = (c & 2) ? ((c & 1) ? w11 : w01) : ((c & 1) ? w10 : w00);
+        const float w = wxy * ((c & 4) ? qz : wz0);
+        a0 = fma_(w, __uint_as_float(v[c].x), a0);
+        a1 = fma_(w, __uint_as_float(v[c].y), a1);
+    }
+    f0 = oob ? 0.0f : a0;
+    f1 = oob ? 0.0f : a1;
+#endif
+}
 template <int ROUND>
 __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t table, int g, const int (&jmode)[4],
                                         float px, float py, float pz, float bound, float two_bound, float (&f)[4][2])
@@ -400,21 +445,8 @@ __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t ta
             for (int c = 0; c < 8; ++c) v[jj][c] = __builtin_amdgcn_raw_buffer_load_b64(table, AC_GOFF((offset + idx[c]) * 8u), 0, 0);
         }
 #pragma unroll
-        for (int jj = 0; jj < ROUND; ++jj) {
-            const float qx = q[jj][0], qy = q[jj][1], qz = q[jj][2];
-            const float wx0 = 1.0f - qx, wy0 = 1.0f - qy, wz0 = 1.0f - qz;
-            const float w00 = wx0 * wy0, w10 = qx * wy0, w01 = wx0 * qy, w11 = qx * qy;
-            float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float wxy = (c & 2) ? ((c & 1) ? w11 : w01) : ((c & 1) ? w10 : w00);
-                const float w = wxy * ((c & 4) ? qz : wz0);
-                a0 = fma_(w, __uint_as_float(v[jj][c].x), a0);
-                a1 = fma_(w, __uint_as_float(v[jj][c].y), a1);
-            }
-            f[j0 + jj][0] = oob ? 0.0f : a0;
-            f[j0 + jj][1] = oob ? 0.0f : a1;
-        }
+        for (int jj = 0; jj < ROUND; ++jj)
+            interp8(v[jj], q[jj][0], q[jj][1], q[jj][2], oob, f[j0 + jj][0], f[j0 + jj][1]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -590,21 +622,6 @@ __device__ __forceinline__ uint32_t gidx(const LvlC &L, uint32_t tx, uint32_t ty
     if constexpr (GM == 1) return (tx ^ ty ^ tz) & L.mask;
     else if constexpr (GM == 0) return tx + ty + tz;                       // a dense round (every lane's level): index < level size by construction
     else return (L.hashed ? (tx ^ ty ^ tz) : (tx + ty + tz)) & L.mask;
-}
-__device__ __forceinline__ void interp8(const u32x2 (&v)[8], float qx, float qy, float qz, bool oob, float &f0, float &f1)
-{
-    const float wx0 = 1.0f - qx, wy0 = 1.0f - qy, wz0 = 1.0f - qz;
-    const float w00 = wx0 * wy0, w10 = qx * wy0, w01 = wx0 * qy, w11 = qx * qy;
-    float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float wxy = (c & 2) ? ((c & 1) ? w11 : w01) : ((c & 1) ? w10 : w00);
-        const float w = wxy * ((c & 4) ? qz : wz0);
-        a0 = fma_(w, __uint_as_float(v[c].x), a0);
-        a1 = fma_(w, __uint_as_float(v[c].y), a1);
-    }
-    f0 = oob ? 0.0f : a0;
-    f1 = oob ? 0.0f : a1;
 }
 // corner index (0..7) of the i-th corner (i = 0..3, other two axes in increasing order) on face b of axis K
 template <int K> __device__ __forceinline__ constexpr int face_corner(int b, int i)
