@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x4 sdf_tile_r(const float *__restrict__ lds, const
 {
     const int g = lane >> 4;
     float f[4][2];
-    encode4<ROUND>(lds, fc.table, g, fc.jmode, px, py, pz, fc.bound, fc.two_bound, f);
+    encode4<ROUND>(lds, fc.table, g, fc.jmode, px, py, pz, fc.bound, fc.two_bound, f, fc.inv_tb);
     __builtin_amdgcn_sched_barrier(0);
     return sdf_mlp(lds, lane, sel4(g, px, py, pz, 0.0f), f);
 }

@@ -121,6 +121,7 @@ struct RenderArgs {
     int jmode[4];          // per gather round j (levels 4j..4j+3): 0 all dense, 1 all hashed, 2 mixed
     int jfine[4];          // per round: 1 if the FD offset eps can span >= 1 cell on any of its levels
     float bound, two_bound, inv_s, car, one_m_car, eps;
+    float inv_tb;          // RN(1 / two_bound) if the divisor is one of the exhaustively verified ones (unit_div), else 0: IEEE division
     const float *inv_s_dev;     // non-NULL: inv_s is read from device memory (ac_render_opts.inv_s_dev)
     int fast;                   // ac_render_opts.precision
     int skip_masked;            // ac_render_opts.skip_masked (MODE_FINAL only)
@@ -350,6 +351,13 @@ typedef uint32_t u32q __attribute__((ext_vector_type(4)));
                             // the texture-address path is paced by bytes per instruction, a 64-lane dwordx4 costs it what two dwordx2 cost; r04_experiments 7b)
 #endif
 
+// u = a / two_bound, a = p + bound with p clamped to [-bound, bound] (so a in [0, 2 bound], or NaN).  The reference divides ((x + size) / (2 size),
+// hashgrid.py:130) and so does the oracle; an IEEE fp32 division is ~10 vector instructions here, one of them (v_rcp_f32) quarter rate, and a tile of the final
+// pass forms nine quotients per lane.  With inv = RN(1 / d) the sequence  q = a * inv;  r = fma(-q, d, a);  u = fma(r, inv, q)  (Markstein's correction) returns
+// the correctly rounded quotient -- the IEEE division's bits -- for every fp32 a with 1e-30 <= |a| <= 1e30, for +0 and for NaN: verified EXHAUSTIVELY (all 2^32
+// bit patterns) for the divisors fill_args accepts (tests/div_check.c, tests/test_div_check.py).  inv_tb == 0 (any other bound, AC_EXACT_DIV=1): IEEE division.
+__device__ __forceinline__ float unit_div(float a, float d, float inv) { const float q = a * inv; return fma_(fma_(-q, d, a), inv, q); }
+
 #ifndef AC_PK_INTERP
 #define AC_PK_INTERP 0      // 1: the trilinear interpolation on the packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32) -- round 6 experiment: bit-identical, 6.8 % fewer vector
                             // instructions (6813 -> 6349 static, 10 spilled dwords fewer) and SLOWER: 0.746 -> 0.781 ms (profiles/r06_experiments.txt section 4d)
@@ -397,9 +405,11 @@ __device__ __forceinline__ void interp8(const u32x2 (&v)[8], float qx, float qy,
 }
 template <int ROUND>
 __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t table, int g, const int (&jmode)[4],
-                                        float px, float py, float pz, float bound, float two_bound, float (&f)[4][2])
+                                        float px, float py, float pz, float bound, float two_bound, float (&f)[4][2], float inv_tb = 0.0f)
 {
-    const float ux = (px + bound) / two_bound, uy = (py + bound) / two_bound, uz = (pz + bound) / two_bound;
+    float ux, uy, uz;
+    if (inv_tb != 0.0f) { ux = unit_div(px + bound, two_bound, inv_tb); uy = unit_div(py + bound, two_bound, inv_tb); uz = unit_div(pz + bound, two_bound, inv_tb); }
+    else { ux = (px + bound) / two_bound; uy = (py + bound) / two_bound; uz = (pz + bound) / two_bound; }
     const bool oob = (ux < 0.0f) | (ux > 1.0f) | (uy < 0.0f) | (uy > 1.0f) | (uz < 0.0f) | (uz > 1.0f);
 #pragma unroll
     for (int j0 = 0; j0 < 4; j0 += ROUND) {
@@ -452,7 +462,7 @@ __device__ __forceinline__ void encode4(const float *__restrict__ lds, rsrc_t ta
 }
 
 // ---- forward_sdf for a tile of 16 points: returns the 16 outputs as D2^T fragment (o = 4g+r) ----------
-struct FieldCtx { rsrc_t table; int jmode[4]; int jfine[4]; float bound, two_bound; };
+struct FieldCtx { rsrc_t table; int jmode[4]; int jfine[4]; float bound, two_bound, inv_tb; };
 __device__ __forceinline__ rsrc_t table_of(const FieldCtx &fc) { return fc.table; }
 
 // SDF MLP 35-64-16 on the tile's features (f[j][c] = level 4j+g, channel c; bxyz = this lane group's coordinate),
@@ -600,7 +610,7 @@ __device__ __forceinline__ f32x4 sdf_tile(const float *__restrict__ lds, const F
 {
     const int g = lane >> 4;
     float f[4][2];
-    encode4<AC_ENC_ROUND>(lds, fc.table, g, fc.jmode, px, py, pz, fc.bound, fc.two_bound, f);
+    encode4<AC_ENC_ROUND>(lds, fc.table, g, fc.jmode, px, py, pz, fc.bound, fc.two_bound, f, fc.inv_tb);
     __builtin_amdgcn_sched_barrier(0);
     return sdf_mlp(lds, lane, sel4(g, px, py, pz, 0.0f), f);
 }
@@ -904,13 +914,22 @@ __device__ __forceinline__ void encode_stencil(const float *__restrict__ lds, fl
 {
     const int g = lane >> 4;
     const rsrc_t table = fc.table;
-    const float bound = fc.bound, two_bound = fc.two_bound;
-    const float ux = (px + bound) / two_bound, uy = (py + bound) / two_bound, uz = (pz + bound) / two_bound;
+    const float bound = fc.bound, two_bound = fc.two_bound, inv_tb = fc.inv_tb;
+    // normalised coordinates of the centre and of the six offset points (one quotient each, hoisted out of the level loop): unit_div for a verified divisor
+    const float ax = px + bound, ay = py + bound, az = pz + bound;
+    const float axp = clampf(px + eps, -bound, bound) + bound, axm = clampf(px + (-eps), -bound, bound) + bound;
+    const float ayp = clampf(py + eps, -bound, bound) + bound, aym = clampf(py + (-eps), -bound, bound) + bound;
+    const float azp = clampf(pz + eps, -bound, bound) + bound, azm = clampf(pz + (-eps), -bound, bound) + bound;
+    float ux, uy, uz, xp, xm, yp, ym, zp, zm;
+    if (inv_tb != 0.0f) {                                   // wave-uniform
+        ux = unit_div(ax, two_bound, inv_tb); uy = unit_div(ay, two_bound, inv_tb); uz = unit_div(az, two_bound, inv_tb);
+        xp = unit_div(axp, two_bound, inv_tb); xm = unit_div(axm, two_bound, inv_tb); yp = unit_div(ayp, two_bound, inv_tb);
+        ym = unit_div(aym, two_bound, inv_tb); zp = unit_div(azp, two_bound, inv_tb); zm = unit_div(azm, two_bound, inv_tb);
+    } else {
+        ux = ax / two_bound; uy = ay / two_bound; uz = az / two_bound;
+        xp = axp / two_bound; xm = axm / two_bound; yp = ayp / two_bound; ym = aym / two_bound; zp = azp / two_bound; zm = azm / two_bound;
+    }
     const bool oob = (ux < 0.0f) | (ux > 1.0f) | (uy < 0.0f) | (uy > 1.0f) | (uz < 0.0f) | (uz > 1.0f);
-    // normalised coordinate of the six offset points (one division each, hoisted out of the level loop)
-    const float xp = (clampf(px + eps, -bound, bound) + bound) / two_bound, xm = (clampf(px + (-eps), -bound, bound) + bound) / two_bound;
-    const float yp = (clampf(py + eps, -bound, bound) + bound) / two_bound, ym = (clampf(py + (-eps), -bound, bound) + bound) / two_bound;
-    const float zp = (clampf(pz + eps, -bound, bound) + bound) / two_bound, zm = (clampf(pz + (-eps), -bound, bound) + bound) / two_bound;
     // jmode (2 bits each) and jfine (1 bit each) of the four level groups in one scalar register: indexed by the loop counter as arrays they
     // would live in scratch memory, and the load of jfine[j] would sit between the centre's gathers and the offset points' (one more round trip)
     const uint32_t jbits = (uint32_t)fc.jmode[0] | ((uint32_t)fc.jmode[1] << 2) | ((uint32_t)fc.jmode[2] << 4) | ((uint32_t)fc.jmode[3] << 6)
@@ -1116,11 +1135,22 @@ __device__ __forceinline__ FieldCtx make_ctx(const RenderArgs &a)
     fc.table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.table), 0, a.table_bytes, 0x00020000);
     fc.jmode[0] = a.jmode[0]; fc.jmode[1] = a.jmode[1]; fc.jmode[2] = a.jmode[2]; fc.jmode[3] = a.jmode[3];
     fc.jfine[0] = a.jfine[0]; fc.jfine[1] = a.jfine[1]; fc.jfine[2] = a.jfine[2]; fc.jfine[3] = a.jfine[3];
-    fc.bound = a.bound; fc.two_bound = a.two_bound;
+    fc.bound = a.bound; fc.two_bound = a.two_bound; fc.inv_tb = a.inv_tb;
     return fc;
 }
 
 // =====================================================================================================
+
+// divisors for which unit_div equals the IEEE division bit for bit on the whole domain (tests/div_check.c runs over all 2^32 dividends): 2 bound for the
+// reference's bounds -- 1.6 (NSR_BOUND: stylize.py, render_*.py) and 1.0 (raymarching's default).  Any other bound divides.
+static inline float verified_reciprocal(float two_bound)
+{
+    static const int exact = [] { const char *e = getenv("AC_EXACT_DIV"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (exact) return 0.0f;
+    const float ok[] = { 3.2f, 2.0f };
+    for (float d : ok) if (two_bound == d) { volatile float one = 1.0f; return one / d; }
+    return 0.0f;
+}
 
 int fill_args(RenderArgs &a, const ac_field *f, float bound)
 {
@@ -1152,6 +1182,7 @@ int fill_args(RenderArgs &a, const ac_field *f, float bound)
     a.Wsh = f->Wc1_sh;
     a.table = f->table; a.table_bytes = (uint32_t)f->offsets[16] * 8u; a.W1 = f->W1; a.b1 = f->b1; a.W2 = f->W2; a.b2 = f->b2; a.Wc1 = f->Wc1; a.Wc2 = f->Wc2; a.Wc3 = f->Wc3;
     a.bound = bound; a.two_bound = (float)(2.0 * (double)bound);
+    a.inv_tb = verified_reciprocal(a.two_bound);
     return AC_OK;
 }
 
