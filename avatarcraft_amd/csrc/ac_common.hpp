@@ -110,4 +110,16 @@ inline void make_level_table(LevelTable &t, uint32_t L, uint32_t D, float S, uin
     }
 }
 
+// divisors for which unit_div equals the IEEE division bit for bit on the whole domain (tests/div_check.c runs over all 2^32 dividends): 2 bound for the
+// reference's bounds -- 1.6 (NSR_BOUND: stylize.py, render_*.py) and 1.0 (raymarching's default).  Any other bound divides.
+inline float verified_reciprocal(float two_bound)
+{
+    static const int exact = [] { const char *e = getenv("AC_EXACT_DIV"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (exact) return 0.0f;
+    const float ok[] = { 3.2f, 2.0f };
+    for (float d : ok) if (two_bound == d) { volatile float one = 1.0f; return one / d; }
+    return 0.0f;
+}
+
+
 }  // namespace ac

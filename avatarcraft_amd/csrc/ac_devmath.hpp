@@ -128,6 +128,13 @@ __device__ __forceinline__ v2f dv_softplus100_x2(const float *__restrict__ spg, 
     return o;
 }
 
+// u = a / two_bound, a = p + bound with p clamped to [-bound, bound] (so a in [0, 2 bound], or NaN).  The reference divides ((x + size) / (2 size),
+// hashgrid.py:130) and so does the oracle; an IEEE fp32 division is ~10 vector instructions here, one of them (v_rcp_f32) quarter rate, and a tile of the final
+// pass forms nine quotients per lane.  With inv = RN(1 / d) the sequence  q = a * inv;  r = fma(-q, d, a);  u = fma(r, inv, q)  (Markstein's correction) returns
+// the correctly rounded quotient -- the IEEE division's bits -- for every fp32 a with 1e-30 <= |a| <= 1e30, for +0 and for NaN: verified EXHAUSTIVELY (all 2^32
+// bit patterns) for the divisors fill_args accepts (tests/div_check.c, tests/test_div_check.py; the host side: ac::verified_reciprocal, ac_common.hpp).  inv_tb == 0 (any other bound, AC_EXACT_DIV=1): IEEE division.
+__device__ __forceinline__ float unit_div(float a, float d, float inv) { const float q = a * inv; return fma_(fma_(-q, d, a), inv, q); }
+
 // torch.sigmoid
 __device__ __forceinline__ float dv_sigmoid(float x) { return 1.0f / (1.0f + dv_exp(-x)); }
 

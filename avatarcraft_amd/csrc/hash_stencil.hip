@@ -68,9 +68,10 @@ __device__ __forceinline__ uint32_t gindex(const LevelC &L, uint32_t x, uint32_t
 struct Loc { uint32_t pg; float fr; bool oob; };
 
 // world coordinate -> cell + fraction on one axis
-__device__ __forceinline__ Loc locate(float xw, float bound, float two_bound, float scale)
+// inv_tb: RN(1 / two_bound) for a divisor unit_div is verified for (ac::verified_reciprocal), else 0 = IEEE division -- the same bits either way
+__device__ __forceinline__ Loc locate(float xw, float bound, float two_bound, float scale, float inv_tb = 0.0f)
 {
-    const float u = (xw + bound) / two_bound;
+    const float u = inv_tb != 0.0f ? unit_div(xw + bound, two_bound, inv_tb) : (xw + bound) / two_bound;
     Loc r;
     r.oob = (u < 0.0f) | (u > 1.0f);
     const float p = fma_(u, scale, 0.5f);
@@ -514,11 +515,11 @@ __device__ __forceinline__ void scatter8_runs(Sink &sink, const LevelC &L, const
 // fine: eps can reach a non-neighbouring cell on this level -> the seven points scatter independently
 template <class Sink>
 __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, bool fine, const float (&xc)[3], const float2 (&gp)[7], float eps,
-                                                float bound, float two_bound, int lane)
+                                                float bound, float two_bound, int lane, float inv_tb = 0.0f)
 {
     Loc c[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) c[d] = locate(xc[d], bound, two_bound, L.scale);
+    for (int d = 0; d < 3; ++d) c[d] = locate(xc[d], bound, two_bound, L.scale, inv_tb);
     const bool cen_ok = !(c[0].oob | c[1].oob | c[2].oob);
     bool bad = false;
 #pragma unroll
@@ -529,7 +530,7 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
 #pragma unroll
         for (int p = 0; p < 7; ++p) {
             Loc q[3] = { c[0], c[1], c[2] };
-            if (p > 0) { const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale); }
+            if (p > 0) { const int k = (p - 1) >> 1; q[k] = locate(offset_coord(xc[k], (p - 1) & 1, eps, bound), bound, two_bound, L.scale, inv_tb); }
             scatter8_runs(sink, L, q, gp[p].x, gp[p].y, lane, norun);
         }
         return;
@@ -562,7 +563,7 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
 #pragma unroll
     for (int p = 1; p < 7; ++p) {
         const int k = (p - 1) >> 1, sign = (p - 1) & 1;                 // sign 0: + eps, 1: - eps (offset_coord)
-        const Loc q = locate(offset_coord(xc[k], sign, eps, bound), bound, two_bound, L.scale);
+        const Loc q = locate(offset_coord(xc[k], sign, eps, bound), bound, two_bound, L.scale, inv_tb);
         const float live = q.oob ? 0.0f : 1.0f;
         const int delta = (int)q.pg - (int)c[k].pg;
         const float m0 = (delta == 0) ? live : 0.0f, m1 = (delta == (sign ? -1 : 1)) ? live : 0.0f;
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_kernel(const float *__re
 __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const float *__restrict__ grad, const float *__restrict__ x,
                                                                       float *__restrict__ grad_grid, uint32_t B, ac::LevelTable lt, float eps,
                                                                       float bound, float two_bound, uint32_t fine_mask, uint32_t binned_mask,
-                                                                      uint32_t *__restrict__ qcount, Rec *__restrict__ queues, uint32_t cap)
+                                                                      uint32_t *__restrict__ qcount, Rec *__restrict__ queues, uint32_t cap, float inv_tb)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // the finest levels cost 2.5x the coarse ones (every stencil point scatters on its own): dispatch them FIRST, so that the cheap
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
 #if AC_FILL_PREFETCH
         if (grp + gstride < ngroups) request(grp + gstride, nxt);
 #endif
-        stencil_scatter(sink, L, fine, xc, gp, eps, bound, two_bound, lane);
+        stencil_scatter(sink, L, fine, xc, gp, eps, bound, two_bound, lane, inv_tb);
 #if !AC_FILL_PREFETCH
         if (grp + gstride < ngroups) request(grp + gstride, nxt);
 #endif
@@ -1026,7 +1027,7 @@ int hash_stencil_backward_split(const float *grad, const float *x, const int32_t
 #endif
         if (gx > AC_FILL_GX) gx = AC_FILL_GX;            // persistent waves: full record buffers per flush, few partial last ones
         hipLaunchKernelGGL(hash_stencil_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, x, grad_embeddings, B, lt, eps, bound,
-                           two_bound, fine_mask, sc.binned_mask, qcount, queues, sc.cap);
+                           two_bound, fine_mask, sc.binned_mask, qcount, queues, sc.cap, ac::verified_reciprocal(two_bound));
         // binned levels >= split_level have ranks n_lo .. n_binned - 1
         const uint32_t n_lo = (uint32_t)__builtin_popcount(sc.binned_mask & (split_level >= 32 ? 0xffffffffu : ((1u << split_level) - 1u)));
         const bool every_hi_binned = ((all & ~sc.binned_mask) >> (split_level >= 32 ? 31 : split_level)) == 0 && split_level < 32;

@@ -351,13 +351,6 @@ typedef uint32_t u32q __attribute__((ext_vector_type(4)));
                             // the texture-address path is paced by bytes per instruction, a 64-lane dwordx4 costs it what two dwordx2 cost; r04_experiments 7b)
 #endif
 
-// u = a / two_bound, a = p + bound with p clamped to [-bound, bound] (so a in [0, 2 bound], or NaN).  The reference divides ((x + size) / (2 size),
-// hashgrid.py:130) and so does the oracle; an IEEE fp32 division is ~10 vector instructions here, one of them (v_rcp_f32) quarter rate, and a tile of the final
-// pass forms nine quotients per lane.  With inv = RN(1 / d) the sequence  q = a * inv;  r = fma(-q, d, a);  u = fma(r, inv, q)  (Markstein's correction) returns
-// the correctly rounded quotient -- the IEEE division's bits -- for every fp32 a with 1e-30 <= |a| <= 1e30, for +0 and for NaN: verified EXHAUSTIVELY (all 2^32
-// bit patterns) for the divisors fill_args accepts (tests/div_check.c, tests/test_div_check.py).  inv_tb == 0 (any other bound, AC_EXACT_DIV=1): IEEE division.
-__device__ __forceinline__ float unit_div(float a, float d, float inv) { const float q = a * inv; return fma_(fma_(-q, d, a), inv, q); }
-
 #ifndef AC_PK_INTERP
 #define AC_PK_INTERP 0      // 1: the trilinear interpolation on the packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32) -- round 6 experiment: bit-identical, 6.8 % fewer vector
                             // instructions (6813 -> 6349 static, 10 spilled dwords fewer) and SLOWER: 0.746 -> 0.781 ms (profiles/r06_experiments.txt section 4d)
@@ -1141,17 +1134,6 @@ __device__ __forceinline__ FieldCtx make_ctx(const RenderArgs &a)
 
 // =====================================================================================================
 
-// divisors for which unit_div equals the IEEE division bit for bit on the whole domain (tests/div_check.c runs over all 2^32 dividends): 2 bound for the
-// reference's bounds -- 1.6 (NSR_BOUND: stylize.py, render_*.py) and 1.0 (raymarching's default).  Any other bound divides.
-static inline float verified_reciprocal(float two_bound)
-{
-    static const int exact = [] { const char *e = getenv("AC_EXACT_DIV"); return (e && e[0] == '1') ? 1 : 0; }();
-    if (exact) return 0.0f;
-    const float ok[] = { 3.2f, 2.0f };
-    for (float d : ok) if (two_bound == d) { volatile float one = 1.0f; return one / d; }
-    return 0.0f;
-}
-
 int fill_args(RenderArgs &a, const ac_field *f, float bound)
 {
     if (!f || !f->table || !f->W1 || !f->b1 || !f->W2 || !f->b2 || !f->Wc1 || !f->Wc2 || !f->Wc3) {
@@ -1182,7 +1164,7 @@ int fill_args(RenderArgs &a, const ac_field *f, float bound)
     a.Wsh = f->Wc1_sh;
     a.table = f->table; a.table_bytes = (uint32_t)f->offsets[16] * 8u; a.W1 = f->W1; a.b1 = f->b1; a.W2 = f->W2; a.b2 = f->b2; a.Wc1 = f->Wc1; a.Wc2 = f->Wc2; a.Wc3 = f->Wc3;
     a.bound = bound; a.two_bound = (float)(2.0 * (double)bound);
-    a.inv_tb = verified_reciprocal(a.two_bound);
+    a.inv_tb = ac::verified_reciprocal(a.two_bound);
     return AC_OK;
 }
 

@@ -1,4 +1,4 @@
-/* tests/div_check.c -- exhaustive proof obligation of unit_div (avatarcraft_amd/csrc/nsr_device.hpp): for a divisor d and inv = RN(1 / d),
+/* tests/div_check.c -- exhaustive proof obligation of unit_div (avatarcraft_amd/csrc/ac_devmath.hpp): for a divisor d and inv = RN(1 / d),
  *     q = a * inv;  r = fma(-q, d, a);  u = fma(r, inv, q)
  * equals the IEEE-754 fp32 quotient a / d bit for bit.  Every one of the 2^32 dividends is tried; the program prints how many differ, the magnitude range of
  * those that do, and how many of them lie in 1e-30 <= |a| <= 1e30 (the renderer's dividends are p + bound with p clamped to [-bound, bound]: 0, NaN, or a

@@ -1,4 +1,4 @@
-"""unit_div (csrc/nsr_device.hpp): the renderer forms (p + bound) / (2 bound) as a reciprocal multiplication with Markstein's correction for the divisors
+"""unit_div (csrc/ac_devmath.hpp): the renderer forms (p + bound) / (2 bound) as a reciprocal multiplication with Markstein's correction for the divisors
 fill_args accepts -- allowed only because it returns the IEEE quotient's bits.  tests/div_check.c tries ALL 2^32 dividends per divisor."""
 import os
 import re
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _accepted_divisors():
-    src = open(os.path.join(ROOT, "avatarcraft_amd", "csrc", "nsr_device.hpp")).read()
+    src = open(os.path.join(ROOT, "avatarcraft_amd", "csrc", "ac_common.hpp")).read()
     m = re.search(r"const float ok\[\] = \{([^}]*)\};", src)
     assert m, "verified_reciprocal's table not found"
     return [t.strip().rstrip("f") for t in m.group(1).split(",")]
