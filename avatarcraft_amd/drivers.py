@@ -86,7 +86,14 @@ def render_animation(net, body_model, cam_pose, poses=None, render_type="animate
     faces = np.asarray(body_model.faces)
     ro, rd = gen_rays_pose(cam_pose, int(512 / resolution), device=device)
     ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
-    for i in shard_indices(n_frames, rank, world):
+    mine = list(shard_indices(n_frames, rank, world))
+    # one WarpMesh per frame, the next frame's upload + culling structure prepared beside the current frame's render (nsr_ops.warp_mesh_sequence)
+    if torch.device(device).type == "cuda":
+        from . import nsr_ops
+        meshes = nsr_ops.warp_mesh_sequence(((world_verts[i], Ts[i]) for i in mine), faces, device)
+    else:
+        meshes = (None for _ in mine)
+    for i, mesh in zip(mine, meshes):
         # the loop keeps rgb only: samples the warp masks out (alpha * 0) need no field evaluation (bit-identical pixels).  The switch is set around
         # each frame's render and restored (also when the consumer abandons the generator): the caller's net keeps its documented default
         prev = getattr(net, "skip_masked_samples", None)
@@ -94,8 +101,9 @@ def render_animation(net, body_model, cam_pose, poses=None, render_type="animate
             net.skip_masked_samples = True
         try:
             rgb, _, _ = render_instantnsr_naive(net, ro, rd, rays_per_batch, requires_grad=False, bkg_key=WHITE_BKG if white_bkg else BLACK_BKG,
-                                                return_torch=True, perturb=False, return_raw=True, render_can=False, verts=world_verts[i], faces=faces,
-                                                Ts=Ts[i], num_steps=32, upsample_steps=32, bound=NSR_BOUND)
+                                                return_torch=True, perturb=False, return_raw=True, render_can=False,
+                                                verts=mesh if mesh is not None else world_verts[i], faces=faces, Ts=Ts[i], num_steps=32, upsample_steps=32,
+                                                bound=NSR_BOUND)
         finally:
             if prev is not None:
                 net.skip_masked_samples = prev

@@ -446,7 +446,7 @@ class NeRFRenderer(nn.Module):
                 raise NotImplementedError("posed-space rendering under autograd runs through the fused operator only (fused_training = 'core')")
             if not full:
                 raise NotImplementedError("posed-space rendering is built for the default NeRFNetwork (with or without view directions; no curvature term)")
-            if verts is None or faces is None or Ts is None:
+            if verts is None or (not isinstance(verts, nsr_ops.WarpMesh) and (faces is None or Ts is None)):     # (a WarpMesh carries its faces and transforms)
                 raise RuntimeError("render_can=False needs verts, faces and Ts")
             warp = verts if isinstance(verts, nsr_ops.WarpMesh) else nsr_ops.WarpMesh(verts, faces, Ts, device, DEFAULT_GEO_THRESH,
                                                                                       DEFAULT_GEO_THRESH, use_mesh_guide)

@@ -299,10 +299,15 @@ class WarpMesh:
             if not isinstance(a, torch.Tensor):
                 a = torch.from_numpy(np.ascontiguousarray(a))
             return a.to(device=device, dtype=dtype).contiguous()
+        # the index check runs on the HOST copy of the faces (a device tensor's max would wait for everything queued on the device: one stall per frame of an
+        # animation); faces that arrive as a device tensor have been checked by whoever uploaded them (warp_mesh_sequence)
+        fmax = None
+        if not (isinstance(faces, torch.Tensor) and faces.is_cuda):
+            fmax = int(np.asarray(faces.cpu() if isinstance(faces, torch.Tensor) else faces)[:, :3].max()) if len(faces) else -1
         self.verts = dev(verts, _F32).reshape(-1, 3)
         self.faces = dev(faces, torch.int32)[:, :3].contiguous()
         self.T = dev(Ts, torch.float64).reshape(-1, 4, 4)
-        if int(self.faces.max()) >= self.T.shape[0] or self.T.shape[0] < self.verts.shape[0]:
+        if (fmax is not None and fmax >= self.T.shape[0]) or self.T.shape[0] < self.verts.shape[0]:
             raise RuntimeError("WarpMesh: Ts must hold one 4x4 per vertex")
         # exact-culling acceleration structure for the closest-face search (rebuilt per frame: the posed mesh changes)
         self.accel = None
@@ -340,6 +345,58 @@ class WarpMesh:
         out = (C.c_ulonglong * 4)()
         L.check(L.lib().ac_warp_accel_work(self.accel.data_ptr(), C.addressof(out), L.current_stream(self.accel.device)), "warp_accel_work")
         return dict(exact_tests=int(out[0]), disc_tests=int(out[1]), subbox_tests=int(out[2]), box_tests=int(out[3]))
+
+
+_MESH_STREAMS = {}
+
+
+def warp_mesh_sequence(frames, faces, device, threshold=0.05, geo_threshold=0.05, use_mesh_guide=True, overlap=True):
+    """One WarpMesh per frame of an animation (render_warp.py:40-124: the pose sequence is known up front).  frames: an iterable of (verts [V,3], Ts [V,4,4]);
+    faces [F,3] are uploaded and checked ONCE.  With overlap (the default on a GPU) the NEXT frame's upload and structure build (ac_warp_accel_build: five small
+    launches, one of them a single-workgroup sort) are queued on a side stream before the current frame is handed out, so they run beside the current frame's
+    render instead of in front of the next one's; the consumer's stream waits for a frame's mesh through an event.  Same meshes, same pixels."""
+    import numpy as np
+    dev = torch.device(device)
+    fh = np.asarray(faces.cpu() if isinstance(faces, torch.Tensor) else faces)[:, :3]
+    faces_d = torch.from_numpy(np.ascontiguousarray(fh)).to(device=dev, dtype=torch.int32).contiguous()
+    fmax = int(fh.max()) if len(fh) else -1
+    kw = dict(threshold=threshold, geo_threshold=geo_threshold, use_mesh_guide=use_mesh_guide)
+
+    def make(v, T):
+        if fmax >= len(T):
+            raise RuntimeError("WarpMesh: Ts must hold one 4x4 per vertex")
+        return WarpMesh(v, faces_d, T, dev, **kw)
+    it = iter(frames)
+    if not (overlap and dev.type == "cuda"):
+        for v, T in it:
+            yield make(v, T)
+        return
+    side = _MESH_STREAMS.get(str(dev))
+    if side is None:
+        side = _MESH_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+
+    def prepare(v, T):
+        with torch.cuda.stream(side):
+            wm = make(v, T)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return wm, ev
+    nxt = None
+    for v, T in it:
+        nxt = prepare(v, T)
+        break
+    while nxt is not None:
+        cur, ev = nxt
+        nxt = None
+        for v, T in it:                                     # the next frame's mesh is queued BEFORE the consumer renders this one
+            nxt = prepare(v, T)
+            break
+        main = torch.cuda.current_stream(dev)
+        main.wait_event(ev)
+        for t in (cur.verts, cur.T, cur.accel):             # (allocated under the side stream, consumed on the caller's)
+            if t is not None:
+                t.record_stream(main)
+        yield cur
 
 
 _CORE_SCRATCH = {}

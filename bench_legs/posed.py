@@ -44,14 +44,18 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     from avatarcraft_amd.synthetic import make_body_sequence
     seq_v, _, seq_T = make_body_sequence(20, 83, 83)
 
-    def sequence(seeds):
+    from avatarcraft_amd import nsr_ops as _ops
+
+    def sequence(seeds, overlap=True):
+        """the loop of drivers.render_animation: one WarpMesh per frame from nsr_ops.warp_mesh_sequence (overlap: the next frame's upload + structure build
+        queued on a side stream beside this frame's render), the render through the harness"""
         net.warp_temporal_seeds = seeds
         net.__dict__.pop("_warp_seed_rows", None)
         frame(65536, seq_v[-1], seq_T[-1]); torch.cuda.synchronize()          # (warm-up; with seeds: the frame before the first one of the loop)
         out = []
         t0 = time.perf_counter()
-        for v, T_ in zip(seq_v, seq_T):
-            out.append(frame(65536, v, T_))
+        for wm in _ops.warp_mesh_sequence(zip(seq_v, seq_T), faces, dev, overlap=overlap):
+            out.append(frame(65536, wm, None))
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / len(seq_v), out
     dt_noseed, fr_noseed = sequence(False)
@@ -60,7 +64,10 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
     dt_noseed2, _ = sequence(False)
     dt2, _ = sequence(True)
     dt_noseed, dt = min(dt_noseed, dt_noseed2), min(dt, dt2)
-    del fr_seed, fr_noseed
+    dt_serial, fr_serial = sequence(True, overlap=False)      # the mesh of a frame prepared in front of its render, on the same stream (rounds 1 - 5, and this round before the side stream)
+    seq_same = seq_same and all(bool(torch.equal(a_, b_)) for a_, b_ in zip(fr_seed, fr_serial))
+    dt_serial = min(dt_serial, sequence(True, overlap=False)[0])
+    del fr_seed, fr_noseed, fr_serial
     net.warp_temporal_seeds = False
     # ---- what bounds the frame (one instrumented frame outside the timed ones): the two render passes against the HBM roofline on the hash-grid gather
     # bytes of the tiles they actually evaluate (1024 B per evaluation), the two closest-face searches against the fp64 vector peak on the
@@ -93,6 +100,7 @@ def time_posed_frame(dev, p, table, frames, cpu=True):
            "workload": "20-frame synthetic animation (synthetic.make_body_sequence), mesh upload + structure build + render per frame, temporal seeds of the "
                        "closest-face searches on (the default of the harness); rounds 1 - 5 quoted ms_per_frame_static_pose",
            "ms_per_frame_seedless": dt_noseed * 1e3, "pixels_identical": seq_same,
+           "ms_per_frame_mesh_prepared_in_line": dt_serial * 1e3,       # (overlap=False: upload + structure build in front of each frame's render on one stream)
            "ms_per_frame_static_pose": dt_static * 1e3, "static_pose_frames": frames,
            "skip_masked": True, "rays_per_batch": 65536,
            "ms_per_frame_8192_ray_batches": dt8 * 1e3, "pixels_identical_across_batch_sizes": same,

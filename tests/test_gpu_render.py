@@ -638,3 +638,35 @@ def test_temporal_seeds_of_the_closest_face_search_change_no_bit(env, skip):
     with pytest.raises(RuntimeError):
         nsr_ops.WarpMesh(seq_v[0], faces, seq_T[0], d).bind_seeds(torch.zeros(N, 96, device=d))          # (not int32)
     print(f"temporal seeds (skip_masked={skip}): exact tests over 4 frames {work[False]} -> {work[True]}")
+
+
+def test_meshes_prepared_on_the_side_stream_render_the_same_frames(env):
+    """nsr_ops.warp_mesh_sequence (the loop of drivers.render_animation): the next frame's upload + culling structure are queued on a side stream beside the
+    current frame's render.  Six frames of the SMPL-sized animation, no synchronisation between frames (the consumer's stream waits through events only): every
+    output equals the frame rendered from a mesh built in line on the consumer's stream, bit for bit; bad faces are refused on the host, before any upload."""
+    from avatarcraft_amd import nsr_ops
+    from avatarcraft_amd.synthetic import make_body_sequence
+    seq_v, faces, seq_T = make_body_sequence(6, 83, 83)
+    ro, rd = make_rays(96, 96, dist=1.8, f=0.78125 * 96)
+    d = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(d)
+    ro_t, rd_t = t(ro), t(rd)
+    keys = ("image", "weights_sum", "depth", "normal_map", "mask", "can_mid")
+    outs = {}
+    for overlap in (True, False, True):
+        frames = []
+        for wm in nsr_ops.warp_mesh_sequence(zip(seq_v, seq_T), faces, d, overlap=overlap):
+            g = nsr_ops.render_rays(env["f"], ro_t, rd_t, 32, 32, 1.6, float(env["p"]["inv_s"]), extras=True, warp=wm, skip_masked=True, out={})
+            frames.append({k: g[k].clone() for k in keys})              # (no synchronize: the clones are stream-ordered behind the render)
+        torch.cuda.synchronize()
+        outs.setdefault(overlap, []).append(frames)
+    for run in outs[True]:
+        for fi, (a, b) in enumerate(zip(run, outs[False][0])):
+            for k in keys:
+                assert torch.equal(a[k], b[k]), (fi, k)
+    assert not torch.equal(outs[False][0][0]["image"], outs[False][0][5]["image"])       # (the animation moves)
+    bad = np.array(faces, copy=True); bad[7, 1] = seq_v[0].shape[0] + 3
+    with pytest.raises(RuntimeError, match="one 4x4 per vertex"):
+        next(iter(nsr_ops.warp_mesh_sequence(zip(seq_v, seq_T), bad, d)))
+    with pytest.raises(RuntimeError, match="one 4x4 per vertex"):
+        nsr_ops.WarpMesh(seq_v[0], bad, seq_T[0], d)

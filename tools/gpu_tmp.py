@@ -1,43 +1,20 @@
-import numpy as np, torch, sys
+import sys, time, torch, numpy as np
 sys.path.insert(0, "/root/repo")
-from tests.test_gpu_model import golden_net, DEV
-net, _ = golden_net(train=True)
-rs = np.random.RandomState(3)
-x = rs.uniform(-1.5, 1.5, (4096, 3)).astype(np.float32)
-eps, bound = 0.005, 1.6
-for case in ("centre", "grad"):
-    go = torch.from_numpy(rs.normal(0, 1, (4096, 16)).astype(np.float32)).to(DEV) * (1.0 if case == "centre" else 0.0)
-    gg = torch.from_numpy(rs.normal(0, 1, (4096, 3)).astype(np.float32)).to(DEV) * (0.0 if case == "centre" else 1.0)
-    res = {}
-    for mode in ("fused", "generic", "generic_noenc", "generic_encOnly"):
-        net.zero_grad()
-        xt = torch.from_numpy(x).to(DEV).requires_grad_(True)
-        if mode == "fused":
-            net.fused_training = "core"
-            o16, grad = net.forward_sdf_stencil(xt, bound, eps)
-        else:
-            net.fused_training = False
-            def fsdf(xx):
-                xe = xx.detach() if mode == "generic_noenc" else xx
-                xi = xx.detach() if mode == "generic_encOnly" else xx
-                h = net.encoder(xe, bound)
-                h = torch.cat([xi, h], dim=-1)
-                for l in range(net.num_layers):
-                    h = net.sdf_net[l](h)
-                    if l != net.num_layers - 1: h = net.activation(h)
-                return h
-            o16 = fsdf(xt)
-            outs = []
-            for k in range(3):
-                e = torch.zeros(1, 3, device=DEV); e[0, k] = eps
-                outs.append(0.5 * (fsdf((xt + e).clamp(-bound, bound))[:, :1] - fsdf((xt - e).clamp(-bound, bound))[:, :1]) / eps)
-            grad = torch.cat(outs, -1)
-        ((o16 * go).sum() + (grad * gg).sum()).backward()
-        res[mode] = xt.grad.detach().cpu().numpy().astype(np.float64)
-    f, g = res["fused"], res["generic"]
-    print(case, "max|generic|", np.abs(g).max(), "err fused-generic", np.abs(f - g).max(), "noenc share max", np.abs(res["generic_noenc"]).max(), "enc share max", np.abs(res["generic_encOnly"]).max(),
-          "sum of shares - generic", np.abs(res["generic_noenc"] + res["generic_encOnly"] - g).max())
-    i = np.unravel_index(np.abs(f - g).argmax(), f.shape)
-    print("  worst", i, f[i[0]], g[i[0]], res["generic_noenc"][i[0]], res["generic_encOnly"][i[0]])
-    e = np.abs(f - g) / np.abs(g).max()
-    print("  entries > 3e-4:", int((e > 3e-4).sum()), "of", e.size, " > 1e-2:", int((e > 1e-2).sum()), "rows", np.unique(np.argwhere(e > 3e-4)[:, 0])[:20])
+import bench as B
+from avatarcraft_amd import nsr_ops
+from avatarcraft_amd.render_utils import render_instantnsr_naive
+from avatarcraft_amd.synthetic import make_rays, make_body_sequence
+dev = torch.device("cuda:0")
+p, field, table, ro, rd = B.make_inputs(dev, 0)
+net = B.make_net(p, table, dev, False); net.skip_masked_samples = True; net.warp_temporal_seeds = True
+ro_h, rd_h = make_rays(256, 256, dist=1.8, f=443.405 / 2, yaw=0.3, pitch=-0.1)
+ro, rd = torch.from_numpy(ro_h).to(dev), torch.from_numpy(rd_h).to(dev)
+seq_v, faces, seq_T = make_body_sequence(8, 83, 83)
+def run(overlap):
+    t0 = time.perf_counter()
+    for wm in nsr_ops.warp_mesh_sequence(zip(seq_v, seq_T), faces, dev, overlap=overlap):
+        render_instantnsr_naive(net, ro, rd, rays_per_batch=65536, requires_grad=False, render_can=False, perturb=False, verts=wm, faces=None, Ts=None, num_steps=32, upsample_steps=32, bound=1.6)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / len(seq_v) * 1e3
+run(True); run(True)
+print("overlap", run(True), "inline", run(False), "overlap", run(True))
