@@ -20,7 +20,7 @@ import torch
 from . import nsr_ops
 import torch.nn.functional as F
 
-from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG, BLACK_BKG, _background_on
+from .render_utils import render_instantnsr_naive, NSR_BOUND, WHITE_BKG, BLACK_BKG, NOISE_BKG, _background_on, select_background
 
 
 class SyntheticGuidance:
@@ -270,13 +270,15 @@ def _sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_
         early_op = torch.distributed.ReduceOp.SUM
     work_hi = hi_range = None
     # the frozen avatar of the opacity loss (stylize.py:176-190), rendered for its weight_sum alone: for a view of several patches ONE launch before the
-    # patch loop instead of one per patch.  net_gt is in eval mode (no jitter draw); its background never reaches weight_sum, but a RANDOM background
-    # would still be drawn per patch from the host generator in the reference's order -- so the hoist is taken for the constant backgrounds only.
+    # patch loop instead of one per patch.  net_gt is in eval mode (no jitter draw) and its background never reaches weight_sum: the launch gets a constant
+    # one.  A RANDOM background (NOISE_BKG: a third of the views under augment_bkg) is still DRAWN per patch from the host generator where the reference's
+    # render of net_gt would draw it (gt_bkg_draw below) and dropped -- the generator's stream, and with it every later draw of the run, stays the reference's.
     ws_gt_view = None
+    gt_bkg_draw = (bkg_key % 4) == NOISE_BKG
     if (manual and WHOLE_VIEW_RENDERS and n_rays > bs and hasattr(net_gt, "render_view_nograd") and not net_gt.training
-            and (bkg_key % 4) in (WHITE_BKG, BLACK_BKG) and getattr(net_gt, "_fused_supported", lambda: False)() and not getattr(net_gt, "cuda_ray", False)):
+            and getattr(net_gt, "_fused_supported", lambda: False)() and not getattr(net_gt, "cuda_ray", False)):
         _, ws_gt_view = net_gt.render_view_nograd(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND,
-                                                  lambda n: _background_on(rays_o.device, (n, 3), bkg_key), bs, opacity_only=True)
+                                                  lambda n: _background_on(rays_o.device, (n, 3), WHITE_BKG), bs, opacity_only=True)
         mark("render_gt_view")
     whole_bwd = (manual and WHOLE_VIEW_BACKWARD and paired is None and n_rays > bs and n_rays % bs == 0 and hasattr(net_style, "render_view_train")
                  and hasattr(net_gt, "render_view_nograd") and not net_gt.training and getattr(net_gt, "_fused_supported", lambda: False)()
@@ -292,6 +294,8 @@ def _sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_
             b = _background_on(rays_o.device, (n, 3), bkg_key)
             if ws_gt_view is None:
                 gt_bgs.append(_background_on(rays_o.device, (n, 3), bkg_key))
+            elif gt_bkg_draw:
+                select_background((n, 3), bkg_key)                    # (drawn and dropped: see gt_bkg_draw)
             return b
         rgb, eik_p, ws_all = net_style.render_view_train(rays_o, rays_d, num_steps, upsample_steps, NSR_BOUND, draw, bs)
         mark("render_grad_forward")
@@ -338,6 +342,8 @@ def _sds_step(net_style, net_gt, rays_o, rays_d, hw, optimizer, guidance, batch_
         with torch.no_grad():
             if ws_gt_view is not None:
                 ws_gt = ws_gt_view[i:i + bs]
+                if gt_bkg_draw:
+                    select_background((ro.shape[0], 3), bkg_key)          # (the draw the reference's net_gt render makes here; host generator only)
             else:
                 _, _, extra_gt = render_instantnsr_naive(net_gt, ro, rd, requires_grad=False, bkg_key=bkg_key, rays_per_batch=bs, perturb=True,
                                                          return_raw=True, render_can=True, num_steps=num_steps, upsample_steps=upsample_steps,

@@ -463,8 +463,9 @@ def test_fine_view_whole_view_renders_equal_patch_by_patch(bkg):
     """a fine-stage view (several patches) renders render_val and the frozen avatar ONCE per view (NeRFRenderer.render_view_nograd)
     instead of once per patch.  Rays are independent and the random draws are made in the harness's own order, so: render_val and the frozen weight_sum
     bit for bit, hence the guidance input, the flat gradient and the parameters after the step bit for bit -- against the patch-by-patch step (round 4) from
-    the same state and streams.  A random background (drawn per patch from the host generator) keeps the reference's order: the frozen render is then NOT
-    hoisted, render_val still is."""
+    the same state and streams.  A random background is drawn per patch from the host generator in the reference's order; the frozen avatar's render is
+    hoisted all the same (round 6: its background never reaches weight_sum, so the launch gets a constant one and the draw is made -- and dropped -- where the
+    reference's render would make it): the host generator ends the step in the same state as the patch-by-patch step."""
     import avatarcraft_amd.stylize as ST
     from avatarcraft_amd.render_utils import WHITE_BKG, NOISE_BKG, render_instantnsr_naive, _background_on, NSR_BOUND
     ro, rd = make_rays(48, 40, dist=1.8, f=36.0)                      # 1920 rays: 4 patches of 512 (the last one shorter: 384)
@@ -491,10 +492,11 @@ def test_fine_view_whole_view_renders_equal_patch_by_patch(bkg):
         finally:
             ST.WHOLE_VIEW_RENDERS = prev
         net.check_finite()
-        return guide.seen, flat.clone(), {k: v.detach().clone() for k, v in net.named_parameters()}, [n for n, _ in marks], st
-    img_a, g_a, p_a, m_a, s_a = one(True)
-    img_b, g_b, p_b, m_b, s_b = one(False)
-    assert ("render_gt_view" in m_a) == (bkg == "white") and "render_gt_view" not in m_b
+        return guide.seen, flat.clone(), {k: v.detach().clone() for k, v in net.named_parameters()}, [n for n, _ in marks], (st, torch.get_rng_state().clone())
+    img_a, g_a, p_a, m_a, (s_a, rng_a) = one(True)
+    img_b, g_b, p_b, m_b, (s_b, rng_b) = one(False)
+    assert "render_gt_view" in m_a and "render_gt_view" not in m_b
+    assert torch.equal(rng_a, rng_b)                                  # the host generator made the same draws
     assert m_a.count("backward") == m_b.count("backward") == 4
     assert torch.equal(img_a, img_b)                                  # render_val of the view, bit for bit
     assert torch.equal(g_a, g_b) and float(g_a.abs().max()) > 0       # the accumulated gradient of the four patches
