@@ -995,6 +995,9 @@ __device__ __forceinline__ void sample_sh_bias(float *__restrict__ slab, const f
     wave_sync();
 }
 
+#ifndef AC_SH_VALUE_SELECT
+#define AC_SH_VALUE_SELECT 1
+#endif
 // The view-direction bias of layer 1 enters unit u's fma chain at ONE fixed position: after the three coordinates, in the k = 3 slot of the MFMA that
 // carries (x, y, z, -) -- a slot that multiplies 0 by 0 without view directions.  acc = fma(bias[u], 1, acc) there, in both forms:
 //   shb1 (the renderer: one ray per wave): the ray's bias row [64] in the wave's slab becomes that slot's A operand on the lanes of group 3 (B = 1 there):
@@ -1014,9 +1017,15 @@ __device__ __forceinline__ void color_tile(const float *__restrict__ lds, int la
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const float b = s < 4 ? sdfout[s] : (s == 4 ? bxyz : bn);
-            const float *wsrc = lds + OFF_C1F + (t * 6 + s) * 64 + lane;
-            if (s == 4 && shb1) wsrc = g == 3 ? shb1 + 16 * t + (lane & 15) : wsrc;      // (an address select: still one LDS read per lane)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(*wsrc, b, acc, 0, 0, 0);
+            float wv = lds[OFF_C1F + (t * 6 + s) * 64 + lane];
+#if AC_SH_VALUE_SELECT
+            // the ray's bias row for the lanes of group 3 as a second, plainly addressed LDS read and a select of the VALUE (round 6: the address select this
+            // replaces kept a per-lane pointer alive across the tile, which the register allocator answered with a scratch reload inside this block)
+            if (s == 4 && shb1) { const float wb = shb1[16 * t + (lane & 15)]; wv = g == 3 ? wb : wv; }
+#else
+            if (s == 4 && shb1) wv = *(g == 3 ? shb1 + 16 * t + (lane & 15) : lds + OFF_C1F + (t * 6 + s) * 64 + lane);      // (an address select: still one LDS read per lane)
+#endif
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, b, acc, 0, 0, 0);
             if (s == 4 && shb) {
                 const f32x4 bq = *reinterpret_cast<const f32x4 *>(shb + t * tstride);
 #pragma unroll

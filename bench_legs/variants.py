@@ -25,11 +25,13 @@ def time_viewdirs(dev, p, table, ro_t, rd_t, steps=8):
     with torch.no_grad():
         f, inv_s = net._field(), net.forward_variance()
         out = {}
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-        for k in range(24):
+        # (two whole passes over the view's 16 batches after one of warm-up: a batch's launch takes 0.68 - 0.81 ms depending on what its rays see, so a ratio
+        # against the headline -- an average over whole views -- needs whole views on this side as well)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
+        for k in range(48):
             b = k % 16
             sl = slice(b * RAYS_PER_BATCH, (b + 1) * RAYS_PER_BATCH)
-            nsr_ops.render_rays(f, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=out, events=evs[k - 4] if k >= 4 else None)
+            nsr_ops.render_rays(f, ro_t[sl], rd_t[sl], NUM_STEPS, UPSAMPLE_STEPS, 1.6, inv_s, out=out, events=evs[k - 16] if k >= 16 else None)
         torch.cuda.synchronize()
         k_ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs]))
     net, net_gt = make(True), make(False)
