@@ -37,7 +37,7 @@ import torch
 
 from bench_legs.common import BYTES_PER_RAY, FLOP_PER_RAY, H, HBM_PEAK_GBS, NUM_STEPS, RAYS_PER_BATCH, ROOT, UPSAMPLE_STEPS, W, XGMI_LINKS, XGMI_LINK_GBS, make_inputs
 from bench_legs.cpu import cpu_baseline, cpu_baseline_sds
-from bench_legs.sds import time_sds_fine_view, time_sds_step
+from bench_legs.sds import time_sds_fine_view, time_sds_step, time_sds_step_fp32_records
 from bench_legs.posed import time_posed_frame
 from bench_legs.variants import time_geometry, time_occupancy_render, time_viewdirs
 from bench_legs.guidance import time_real_sd_step, time_sd_arch_step
@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-occupancy", action="store_true", help="skip the occupancy-grid render leg (render(cuda_ray=True): a separate figure beside the headline)")
     ap.add_argument("--no-viewdirs", action="store_true", help="skip the use_viewdirs=True leg (the same render launch and SDS step with view directions)")
     ap.add_argument("--whole-view-backward", action="store_true", help="fine-view leg: also time the whole-view training forward + backward (stylize.WHOLE_VIEW_BACKWARD; ~75 GB of scratch)")
+    ap.add_argument("--no-fp32-records", action="store_true", help="skip the child process that times the SDS step on the full-fp32-record library (sds_step.ms_per_step_fp32_records)")
     ap.add_argument("--no-fine-view", action="store_true", help="skip the fine-stage leg (one optimizer step on a full 256 x 256 view = 16 patches)")
     ap.add_argument("--no-geometry", action="store_true", help="skip the mesh-export (512^3 + marching cubes) and density-grid-update legs")
     ap.add_argument("--posed-frames", type=int, default=4, help="also time this many 256x256 posed-space frames (render_warp.py, secondary metric); 0 = skip")
@@ -280,6 +281,10 @@ def main():
         }
         if sds is not None:
             res["sds_step"] = sds
+            if world == 1 and not a.no_fp32_records:
+                fr = time_sds_step_fp32_records(a.sds_steps)
+                sds["ms_per_step_fp32_records"] = fr.get("ms_per_step")
+                sds["fp32_records"] = fr
         if world == 1 and a.posed_frames > 0:
             try:
                 res["posed_frame"] = time_posed_frame(dev, p, table, a.posed_frames, cpu=not a.no_cpu_baseline)
