@@ -37,7 +37,7 @@ def time_real_sd_step(dev, p, table, steps=3):
             "model": why, "dtype": "f32 (the reference loads the pipelines without a dtype)", "phase_ms": {k: round(v, 3) for k, v in phases.items()}}
 
 
-def time_sd_arch_step(dev, p, table, steps=2):
+def time_sd_arch_step(dev, p, table, steps=2, variants=False):
     """What one stylisation step costs WITH a guidance of Stable-Diffusion 1.5's size (models/diffusion.py:92-149: VAE encoder with grad at 512 x 512, UNet
     on two 64 x 64 latents, classifier-free guidance) when the real networks are absent: avatarcraft_amd.sd_arch restates their published architecture
     (859.5 M + 34.2 M parameters, parameter counts equal to the checkpoint's) with RANDOM weights, fp32 like the reference loads them.  A clock, not a
@@ -90,6 +90,15 @@ def time_sd_arch_step(dev, p, table, steps=2):
     breakdown = guidance_breakdown()
     # the same with PyTorch-level settings that keep fp32 (StableDiffusion.tune: NHWC convolutions, MIOpen find mode, SDPA attention) -- VERDICT round 5 item 8
     tuned = None
+    skipped = ("not timed in this run (--sd-arch-variants): MIOpen's find mode alone takes ~60 s on a fresh box; measured in profiles/r06_experiments.txt section 8 -- "
+               "no fp32-preserving setting moves the guidance by more than 1 %; UNet under bf16 autocast: guidance 60.5 -> 57.9 ms")
+    if not variants:
+        return {"ms_per_step": ms, "unet_bf16_autocast": skipped, "guidance_ms": g, "guidance_phase_ms": breakdown, "fp32_tuned": skipped,
+                "render_and_backward_ms": ms - g, "guidance_share": g / ms, "steps": steps, "setup_and_first_step_s": t_setup,
+                "phase_ms": {k: round(v, 3) for k, v in phases.items()},
+                "guidance": f"SD-1.5 ARCHITECTURE stand-in (avatarcraft_amd/sd_arch.py): UNet2DConditionModel {nu} + AutoencoderKL encoder {nv} parameters, random "
+                            "weights, fp32; 512 x 512 VAE encode with grad, UNet on 2 x 4 x 64 x 64 latents with [2, 77, 768] text embeddings -- the real "
+                            "guidance's clock, not its values (the pretrained weights are not on this machine: see real_sd)"}
     try:
         sd.tune()
         sds_step(net, net_gt, ro, rd, (64, 64), opt, guide, batch_size=4096, flat_grad=flat)          # (find mode picks its solvers here)

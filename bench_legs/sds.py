@@ -138,11 +138,12 @@ def time_sds_step_fp32_records(steps):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--repeat", "1", "--sds-steps", str(int(steps)), "--posed-frames", "0",
            "--no-cpu-baseline", "--no-occupancy", "--sd-arch-steps", "0", "--no-fine-view", "--no-viewdirs", "--no-geometry", "--no-fp32-records"]
+    t0 = time.perf_counter()
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     try:
         line = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
         s = line["sds_step"]
-        return {"ms_per_step": s["ms_per_step"], "phase_ms": s.get("phase_ms"), "library": os.path.basename(so),
+        return {"ms_per_step": s["ms_per_step"], "phase_ms": s.get("phase_ms"), "library": os.path.basename(so), "seconds": round(time.perf_counter() - t0, 2),
                 "note": "full-fp32 12-byte scatter records (-DAC_REC8=0): the reference's precision for the table gradient"}
     except Exception as e:                     # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}", "stderr_tail": r.stderr[-300:]}
