@@ -120,6 +120,7 @@ _SIGS = {
     "ac_sdf_stencil_forward": ([C.POINTER(ac_field), vp, u32, f32, f32, vp, vp, vp], C.c_int),
     "ac_sdf_stencil_backward_scratch": ([u32], C.c_size_t),
     "ac_sdf_stencil_backward": ([C.POINTER(ac_field), vp, vp, vp, u32, f32, f32, vp, vp, vp, C.c_size_t, vp], C.c_int),
+    "ac_debug_unit_div_check": ([u32, u32, f32, vp, vp], C.c_int),
     "ac_sdf_stencil_backward_inputs": ([C.POINTER(ac_field), vp, vp, vp, u32, f32, f32, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
     "ac_hash_stencil_input_backward": ([vp, vp, vp, vp, vp, u32, u32, u32, f32, u32, f32, f32, vp], C.c_int),
     "ac_color_forward": ([C.POINTER(ac_field), vp, vp, vp, u32, vp, vp], C.c_int),

@@ -28,6 +28,7 @@
 #ifndef AVATARCRAFT_HIP_H
 #define AVATARCRAFT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -52,6 +53,10 @@ const char *ac_last_error(void);     /* message of the last failing call on this
 /* test utility: `blocks` workgroups of 1024 threads + lds_bytes of LDS each spin for `millis` ms of wall clock on `stream` -- a FOREIGN workload that holds
  * compute units (no memory traffic), for the liveness tests of the kernels that wait for each other (tests/test_gpu_run_cuda.py, tests/test_gpu_render.py) */
 int ac_debug_hold_cus(uint32_t blocks, uint32_t lds_bytes, uint32_t millis, ac_stream_t stream);
+/* test utility: the division-free unit coordinate (q = a * RN(1 / d); r = fma(-q, d, a); u = fma(r, RN(1 / d), q)) against the IEEE quotient a / d
+ * on the device, for EVERY fp32 dividend whose bit pattern lies in [lo_bits, hi_bits]: *mismatches (device, zeroed by the caller) += the number that differ in a
+ * bit (two NaNs count as equal).  tests/test_gpu_ops.py sweeps the renderer's whole dividend domain for the divisors the library accepts. */
+int ac_debug_unit_div_check(uint32_t lo_bits, uint32_t hi_bits, float d, unsigned long long *mismatches, ac_stream_t stream);
 
 /* ---- hash-grid encoder -------------------------------------------------------------------
  * replaces hash_encode_forward (encoder/hashencoder/src/hashencoder.cu:413-436)

@@ -1,5 +1,7 @@
 """-m gpu: the stand-alone operators (hash encoder, SH encoder, raymarching) through the reference-shaped
 Python surface (-> C ABI -> HIP), against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -610,3 +612,28 @@ def test_hash_backward_binned_nonfinite_gradients(oracle):
     big = np.abs(lv(ref, 3)) > 1e-12                                                                                 # level 3: the large record is exact ...
     assert 1 <= big.sum() <= 8 and np.allclose(lv(got, 3)[big], lv(ref, 3)[big], rtol=1e-5, atol=1e-9)
     assert np.abs(lv(got, 3)[~big]).max() <= 1e-19                                                                  # ... and nothing else is invented
+
+
+def test_unit_div_equals_the_ieee_division_on_the_device_over_the_whole_domain():
+    """(x + bound) / (2 bound) without a division for the divisors the library accepts.  tests/test_div_check.py proves the identity on the
+    host (all 2^32 dividends, C fmaf); this sweeps it ON THE DEVICE -- v_mul_f32 / v_fma_f32 against the compiler's IEEE division sequence -- over every fp32
+    dividend from 1e-30 to 1e30 of both signs (2 x 1.67 G values), +0 and the NaNs: the renderer's dividends are 0, NaN or between 1e-7 and 4."""
+    import ctypes
+    import re
+    import struct
+    from avatarcraft_amd import _lib as L
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avatarcraft_amd", "csrc", "ac_common.hpp")).read()
+    divs = [float(t.strip().rstrip("f")) for t in re.search(r"const float ok\[\] = \{([^}]*)\};", src).group(1).split(",")]
+    assert 3.2 in [round(d, 6) for d in divs]
+    bits = lambda f: struct.unpack("<I", struct.pack("<f", f))[0]
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    st = L.current_stream(torch.device(DEV))
+    for d in divs:
+        for lo, hi in ((bits(1e-30), bits(1e30)), (bits(-1e-30), bits(-1e30)), (0, 0), (0x7f800001, 0x7fffffff)):
+            cnt.zero_()
+            L.check(L.lib().ac_debug_unit_div_check(lo, hi, ctypes.c_float(d), cnt.data_ptr(), st), "unit_div_check")
+            assert int(cnt.item()) == 0, (d, hex(lo), hex(hi), int(cnt.item()))
+    # the identity is not a general one (which is why only verified divisors are accepted): it fails on denormal quotients
+    cnt.zero_()
+    L.check(L.lib().ac_debug_unit_div_check(1, bits(1e-37), ctypes.c_float(3.2), cnt.data_ptr(), st), "unit_div_check")
+    assert int(cnt.item()) > 0

@@ -379,3 +379,31 @@ def test_drivers_shard_views_round_robin_over_ranks():
     assert shard_indices(3, 5, 8) == [] and shard_indices(0, 0, 1) == []
     with pytest.raises(ValueError):
         shard_indices(4, 2, 2)
+
+
+def test_header_is_self_contained_c_and_a_c_program_links_against_the_library(tmp_path):
+    """the drop-in boundary is a C ABI: include/avatarcraft_hip.h must compile on its own as C99 and as C++ (round 6 found it leaning on the includer for size_t),
+    and a plain C program that includes nothing else must link against libavatarcraft_hip.so and reach its host-side entry points"""
+    import subprocess
+    from avatarcraft_amd import build as hb, _lib
+    hb.build()
+    hdr = os.path.join(ROOT, "include", "avatarcraft_hip.h")
+    subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-pedantic", "-std=c99", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-fsyntax-only", "-Wall", "-x", "c++", hdr], check=True)
+    src = tmp_path / "abi.c"
+    src.write_text('#include "avatarcraft_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    float scale[16]; uint32_t res[16];\n'
+                   '    ac_hash_level_table(16, 0.46668363f, 16, scale, res);\n'
+                   '    ac_field f; ac_render_opts o; ac_warp_mesh m; ac_core_upstream u;\n'
+                   '    printf("%d %d %u %zu %zu %zu %zu %zu\\n", ac_version(), (int)scale[15], res[0], sizeof f, sizeof o, sizeof m, sizeof u, ac_sdf_stencil_backward_scratch(0));\n'
+                   '    return ac_last_error()[0] != 0;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), _lib.LIB_PATH, f"-Wl,-rpath,{libdir}",
+                    "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    out = r.stdout.split()
+    assert out[0] == "10" and out[1] == "2047" and out[2] == "16"
+    assert [int(v) for v in out[3:7]] == [ctypes.sizeof(_lib.ac_field), ctypes.sizeof(_lib.ac_render_opts), ctypes.sizeof(_lib.ac_warp_mesh), ctypes.sizeof(_lib.ac_core_upstream)]
