@@ -65,6 +65,20 @@ __device__ __forceinline__ uint32_t gindex(const LevelC &L, uint32_t x, uint32_t
     return index;
 }
 
+// the same index from PRE-MULTIPLIED axis terms: ty = y * my, tz = z * mz with (my, mz) = the two hash primes on a hashed level, (stride, stride^2) on a dense one
+// (x + (y + z s) s = x + y s + z s^2 in 32-bit arithmetic).  A cell's corners and its neighbour planes differ from it by +-1 / +2 along an axis, i.e. by multiples of
+// my / mz: their terms are ADDS on the cell's -- two 32-bit multiplications (quarter rate) per point and level instead of two per corner (round 6: the scatter's fill
+// kernel spent a quarter of its vector-pipe time in v_mul_lo_u32, each inside a predicated per-corner block the compiler cannot hoist it out of).  Same bits.
+__device__ __forceinline__ uint32_t gindex_t(const LevelC &L, uint32_t tx, uint32_t ty, uint32_t tz)
+{
+    uint32_t index = L.hashed ? (tx ^ ty ^ tz) : (tx + ty + tz);
+    if (L.mask) index &= L.mask;
+    else if (index >= L.size) index %= L.size;
+    return index;
+}
+__device__ __forceinline__ uint32_t level_my(const LevelC &L) { return L.hashed ? 2654435761u : L.stride1; }
+__device__ __forceinline__ uint32_t level_mz(const LevelC &L) { return L.hashed ? 805459861u : L.stride1 * L.stride1; }
+
 struct Loc { uint32_t pg; float fr; bool oob; };
 
 // world coordinate -> cell + fraction on one axis
@@ -507,7 +521,8 @@ __device__ __forceinline__ void scatter8_runs(Sink &sink, const LevelC &L, const
     bool pred[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) pred[k] = tail && (v[2 * k] != 0.0f || v[2 * k + 1] != 0.0f);
-    sink.add8(pred, [&](int k) { return gindex(L, q[0].pg + ((uint32_t)k & 1u), q[1].pg + (((uint32_t)k >> 1) & 1u), q[2].pg + (((uint32_t)k >> 2) & 1u)); }, v);
+    const uint32_t my = level_my(L), mz = level_mz(L), ty0 = q[1].pg * my, tz0 = q[2].pg * mz;
+    sink.add8(pred, [&](int k) { return gindex_t(L, q[0].pg + ((uint32_t)k & 1u), ty0 + ((((uint32_t)k >> 1) & 1u) ? my : 0u), tz0 + ((((uint32_t)k >> 2) & 1u) ? mz : 0u)); }, v);
     sink.tick(1);
 }
 
@@ -586,11 +601,13 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
     }
     const bool tail = run_reduce<64>(v, run_head(c, true, lane), lane);
     sink.tick(0);
+    // the centre cell's pre-multiplied terms: every one of the 32 entries below is these plus / minus multiples of (1, cmy, cmz) (gindex_t)
+    const uint32_t cmy = level_my(L), cmz = level_mz(L), cty = c[1].pg * cmy, ctz = c[2].pg * cmz;
     {
         bool pred[8]; float vv[16];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { vv[2 * k] = v[2 * k]; vv[2 * k + 1] = v[2 * k + 1]; pred[k] = tail && (v[2 * k] != 0.0f || v[2 * k + 1] != 0.0f); }
-        sink.add8(pred, [&](int k) { return gindex(L, c[0].pg + ((uint32_t)k & 1u), c[1].pg + (((uint32_t)k >> 1) & 1u), c[2].pg + (((uint32_t)k >> 2) & 1u)); }, vv);
+        sink.add8(pred, [&](int k) { return gindex_t(L, c[0].pg + ((uint32_t)k & 1u), cty + ((((uint32_t)k >> 1) & 1u) ? cmy : 0u), ctz + ((((uint32_t)k >> 2) & 1u) ? cmz : 0u)); }, vv);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {                            // the two planes next to the centre cell along axis k: slot n = side * 4 + jm
@@ -602,12 +619,14 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
         }
         sink.add8(pred, [&](int n) {
             const uint32_t jm = (uint32_t)n & 3u, lo = jm & 1u, hi = jm >> 1;
-            uint32_t pl[3];
-            pl[0] = c[0].pg + (k == 0 ? 0u : lo);
-            pl[1] = c[1].pg + (k == 1 ? 0u : (k == 0 ? lo : hi));
-            pl[2] = c[2].pg + (k == 2 ? 0u : hi);
-            pl[k] = (n >> 2) ? c[k].pg + 2u : c[k].pg - 1u;
-            return gindex(L, pl[0], pl[1], pl[2]);
+            const uint32_t m3[3] = { 1u, cmy, cmz };
+            uint32_t t[3];
+            t[0] = c[0].pg + (k == 0 ? 0u : lo);
+            t[1] = cty + ((k == 1 ? 0u : (k == 0 ? lo : hi)) ? cmy : 0u);
+            t[2] = ctz + ((k == 2 ? 0u : hi) ? cmz : 0u);
+            const uint32_t base = k == 0 ? c[0].pg : (k == 1 ? cty : ctz);
+            t[k] = (n >> 2) ? base + 2u * m3[k] : base - m3[k];                  // plane + 2 / - 1 along axis k (32-bit wrap-around like the product's)
+            return gindex_t(L, t[0], t[1], t[2]);
         }, vv);
     }
     sink.tick(1);
