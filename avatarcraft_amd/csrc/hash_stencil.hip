@@ -1042,7 +1042,9 @@ int hash_stencil_backward_split(const float *grad, const float *x, const int32_t
         ac::allow_dynamic_lds(seen2, reinterpret_cast<const void *>(bucket_accumulate_kernel), lds2);
         uint32_t gx = ((B + 63) / 64 + 3) / 4;
 #ifndef AC_FILL_GX
-#define AC_FILL_GX 128     // workgroups per level: 256 -> 128 is 3.66 -> 3.39 ms of backward per step (96: 3.51, 64: 3.53, 32: 3.77; profiles/r02_experiments.txt)
+#define AC_FILL_GX 96      // workgroups per level.  Round 2: 256 -> 128 was 3.66 -> 3.39 ms of backward per step (96: 3.51, 64: 3.53, 32: 3.77; profiles/r02_experiments.txt);
+                           // round 6, after the fill's index arithmetic shrank: 96 = 2.14 ms against 128: 2.18, 112: 2.15, 80: 2.20, 64: 2.21, 160: 2.29 (16 levels x 96 x 4 waves =
+                           // three full rounds of the device's 2048 wave slots; the sums are order-independent, the bits do not depend on this)
 #endif
         if (gx > AC_FILL_GX) gx = AC_FILL_GX;            // persistent waves: full record buffers per flush, few partial last ones
         hipLaunchKernelGGL(hash_stencil_bwd_binned_kernel, dim3(gx, sc.n_binned), dim3(256), lds1, st, grad, x, grad_embeddings, B, lt, eps, bound,
