@@ -459,7 +459,11 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
             if (EX && ex_on && a.out.feat7) {                                     // training render: keep the 7 x 8 features of this lane (the backward streams them back)
                 // layout [tile of 16 samples][14][lane][4]: float k = 8 e + q (evaluation e, slot q = 2 j + channel) of lane (n, g) sits in group k / 4,
                 // component k % 4 -- every store (and every load of the backward) is one 16-byte access per lane, 1 KB contiguous per wave
-                f32x4 *dst = reinterpret_cast<f32x4 *>(a.out.feat7) + (((size_t)exr * (T / 16) + (i >> 4)) * 14) * 64 + lane;
+                // (the lane term enters through an opaque copy: otherwise the per-lane base pointer is hoisted out of the tile loop and, at 256 registers, spilled -- a scratch
+                // reload with a full wait in every tile; formed here it is one scalar product and one 64-bit add.  Round 6, profiles/r06_experiments.txt section 14)
+                int lane_x = lane;
+                asm volatile("" : "+v"(lane_x));
+                f32x4 *dst = reinterpret_cast<f32x4 *>(a.out.feat7) + (((size_t)exr * (T / 16) + (i >> 4)) * 14) * 64 + lane_x;
                 dst[0] = f32x4{ fe0[0][0], fe0[0][1], fe0[1][0], fe0[1][1] };
                 dst[64] = f32x4{ fe0[2][0], fe0[2][1], fe0[3][0], fe0[3][1] };
 #pragma unroll 1
@@ -580,7 +584,11 @@ __global__ __launch_bounds__(BLOCK) void render_rays_kernel(const RenderArgs a)
                 if (EX && ex_on && a.out.gradient) { a.out.gradient[3 * si] = gx; a.out.gradient[3 * si + 1] = gy; a.out.gradient[3 * si + 2] = gz; }
                 if (EX && ex_on && a.out.pts) { a.out.pts[3 * si] = px; a.out.pts[3 * si + 1] = py; a.out.pts[3 * si + 2] = pz; }
             }
-            if (EX && ex_on && a.out.sdf_out16) *reinterpret_cast<f32x4 *>(a.out.sdf_out16 + ((size_t)exr * T + i) * 16 + 4 * g) = oc;     // lane (n, g) holds outputs 4g..4g+3
+            if (EX && ex_on && a.out.sdf_out16) {                                 // lane (n, g) holds outputs 4g..4g+3
+                int g_x = g;
+                asm volatile("" : "+v"(g_x));                                   // (see feat7 above)
+                *reinterpret_cast<f32x4 *>(a.out.sdf_out16 + ((size_t)exr * T + i) * 16 + 4 * g_x) = oc;
+            }
         }
         if (!seg_last) {
             // hand the ray to its next segment: z values (once), the running sums, then the flag -- in that order (the stores are complete in L2
