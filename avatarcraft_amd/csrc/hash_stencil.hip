@@ -382,8 +382,8 @@ struct BinSink {
 #else
     __device__ __forceinline__ void tick(int) {}
 #endif
-    // the bucket histogram and the running max |v| are taken while the record is still in registers: the flush is then ONE pass over
-    // the buffer (three passes over LDS cost 1.2 of the kernel's 1.85 ms, profiles/r01_sds.txt)
+    // the bucket histogram is taken while the record is still in registers: the flush is then ONE pass over the buffer (three passes over LDS cost 1.2 of
+    // the kernel's 1.85 ms, profiles/r01_sds.txt); that pass also rounds the values to the record's precision and tracks the running max |v| (round 6)
     // eight table entries at once (after reserving room for 8 x 64 records): the bucket ranks of all eight are requested first
     // (LDS atomics with return), then the records are written -- one LDS round trip per eight slots instead of eight
     template <class F> __device__ __forceinline__ void add8(const bool (&pred)[8], F index_of, const float (&v)[16])
@@ -405,14 +405,9 @@ struct BinSink {
             if (m[k] == 0ull) continue;
             if (pred[k]) {
                 const uint32_t pos = cnt + (uint32_t)__builtin_popcountll(m[k] & ((1ull << lane) - 1ull));
-#if AC_REC8
-                const float r0 = rec_round(v[2 * k], 7), r1 = rec_round(v[2 * k + 1], 6);
-#else
-                const float r0 = v[2 * k], r1 = v[2 * k + 1];
-#endif
-                ridx[pos] = index[k] | (rank[k] << 19); rv0[pos] = r0; rv1[pos] = r1;
-                const uint32_t a0 = __float_as_uint(r0) & 0x7fffffffu, a1 = __float_as_uint(r1) & 0x7fffffffu;
-                mx = mx > a0 ? mx : a0; mx = mx > a1 ? mx : a1;
+                // (the contribution is stored as it is: its rounding to the record's precision and the running max |v| happen in flush(), on the DENSE record
+                // stream -- here, after the run combining, a tenth to a half of the lanes are live and every instruction costs a full issue slot all the same)
+                ridx[pos] = index[k] | (rank[k] << 19); rv0[pos] = v[2 * k]; rv1[pos] = v[2 * k + 1];
             }
             cnt += (uint32_t)__builtin_popcountll(m[k]);
         }
@@ -449,6 +444,13 @@ struct BinSink {
             for (uint32_t u = 0; u < WU; ++u) {
                 const uint32_t i = i0 + 64 * u, ic = i < cnt ? i : i0;
                 packed[u] = ridx[ic]; v0[u] = rv0[ic]; v1[u] = rv1[ic];
+#if AC_REC8
+                v0[u] = rec_round(v0[u], 7); v1[u] = rec_round(v1[u], 6);             // the record's precision (rec_pack drops nothing after this)
+#endif
+                if (i < cnt) {
+                    const uint32_t a0 = __float_as_uint(v0[u]) & 0x7fffffffu, a1 = __float_as_uint(v1[u]) & 0x7fffffffu;
+                    mx = mx > a0 ? mx : a0; mx = mx > a1 ? mx : a1;
+                }
             }
 #pragma unroll
             for (uint32_t u = 0; u < WU; ++u) bs[u] = base[(packed[u] & 0x7ffffu) >> sh];
