@@ -312,6 +312,7 @@ __device__ __forceinline__ bool run_head(const Loc (&q)[3], bool ok, int lane)
 // one workgroup that sums its queue in LDS (ds_add_f32, ~1000x the global atomic rate) and adds the 64 KB slice to the table
 // without atomics.  Global atomics per record: 2 -> ~1/30.
 struct DirectSink {
+    static constexpr bool packs = false;
     float2 *gg;
     __device__ __forceinline__ void tick(int) const {}
     // eight table entries at once: pred[k] says whether this lane contributes (v[2k], v[2k+1]) to entry index_of(k)
@@ -328,7 +329,16 @@ constexpr int NBUCKET = 64;
 #define AC_RCAP 1536
 #endif
 constexpr int RCAP = AC_RCAP;              // records per wave buffer; add8 reserves room for 8 x 64 records
-constexpr int WAVE_WORDS = 3 * RCAP + 2 * NBUCKET;     // LDS words per wave: ridx, rv0, rv1 [RCAP], hist, base [64]
+#ifndef AC_FILL_PACK
+#define AC_FILL_PACK 1      // coarse levels: the run tails' contributions transposed through LDS so that the records are formed by DENSE lanes (BinSink::add_packed)
+#endif
+#ifndef AC_FILL_PACK_MAX
+#define AC_FILL_PACK_MAX 32  // most run tails per wave for which the packed path is taken (8 per chunk; above ~40 the sparse walk is cheaper)
+#endif
+constexpr int PACK_TAILS = 8;                          // run tails staged per chunk: 8 tails x 8 entries = the wave's 64 lanes
+constexpr int PACK_STRIDE = 20;                        // staged words per tail: 16 values (8 entries x 2 channels) + the cell's three axis terms (+ 1 pad: 16-byte rows)
+constexpr int STAGE_WORDS = AC_FILL_PACK ? PACK_TAILS * PACK_STRIDE : 0;
+constexpr int WAVE_WORDS = 3 * RCAP + 2 * NBUCKET + STAGE_WORDS;     // LDS words per wave: ridx, rv0, rv1 [RCAP], hist, base [64], the packing stage
 static_assert(RCAP % 2 == 0 && RCAP >= 1024, "wave buffer: room for two batches of 8 x 64 records");
 #ifndef AC_REC16
 #define AC_REC16 0          // 1: queue records padded to 16 bytes (one aligned dwordx4 store / load per record instead of three dword accesses; +33 % queue bytes)
@@ -365,6 +375,7 @@ struct Rec { uint32_t idx; float v0, v1; };
 #endif
 
 struct BinSink {
+    static constexpr bool packs = true;
     uint32_t *ridx; float *rv0, *rv1;      // this wave's LDS record buffer [RCAP]; ridx = entry | rank inside its bucket << 19
     uint32_t *hist, *base;                 // this wave's LDS [NBUCKET] each (hist zero between flushes)
     uint32_t cnt;                          // wave-uniform
@@ -376,6 +387,7 @@ struct BinSink {
     uint32_t cap;
     float2 *gg;                            // overflow path: direct atomics
     int lane;
+    float *stage;                          // this wave's LDS [PACK_TAILS][PACK_STRIDE] (AC_FILL_PACK)
 #ifdef AC_PROFILE_FILL                     // s_memtime per phase: 0 stencil combine + run scan, 1 records -> LDS, 2 flush: slot reservation, 3 flush: write-out
     unsigned long long ft, facc[4], nflush;
     __device__ __forceinline__ void tick(int slot) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); facc[slot] += t2 - ft; ft = t2; }
@@ -411,6 +423,19 @@ struct BinSink {
             }
             cnt += (uint32_t)__builtin_popcountll(m[k]);
         }
+    }
+    // one table entry per lane (the packed path: every lane may carry one)
+    __device__ __forceinline__ void add1(bool pred, uint32_t index, float v0, float v1)
+    {
+        if (cnt + 64u > (uint32_t)RCAP) flush();
+        const unsigned long long m = __ballot(pred);
+        if (m == 0ull) return;
+        if (pred) {
+            const uint32_t rank = atomicAdd(&hist[index >> sh], 1u);
+            const uint32_t pos = cnt + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            ridx[pos] = index | (rank << 19); rv0[pos] = v0; rv1[pos] = v1;
+        }
+        cnt += (uint32_t)__builtin_popcountll(m);
     }
     // the level's largest |v| (the fixed-point scale of bucket_accumulate_kernel): one wave reduction and one global atomic per WAVE,
     // after its last flush (it used to be per flush: 0.26 of the fill's 1.8 ms, profiles/r01_sds.txt "without the max pass")
@@ -605,6 +630,52 @@ __device__ __forceinline__ void stencil_scatter(Sink &sink, const LevelC &L, boo
     sink.tick(0);
     // the centre cell's pre-multiplied terms: every one of the 32 entries below is these plus / minus multiples of (1, cmy, cmz) (gindex_t)
     const uint32_t cmy = level_my(L), cmz = level_mz(L), cty = c[1].pg * cmy, ctz = c[2].pg * cmz;
+#if AC_FILL_PACK
+    if constexpr (Sink::packs) {
+        // After the run combining only the TAIL lanes carry anything -- a handful per wave on the coarse levels -- and the four add8 calls below walk 32 entries with
+        // a tenth of the lanes live (half of the fill's time: tools/fill_profile.py, round 6).  With few tails the work is transposed through LDS instead: a chunk of
+        // 8 tails stages, per group of 8 entries, its 16 values (+ once: the cell's axis terms), and lane j of the wave forms the record of (tail j / 8, entry j % 8)
+        // -- one dense pass per group instead of eight sparse ones.  The same (entry, v0, v1) contributions reach the queues (their order does not enter the sums).
+        const unsigned long long T = __ballot(tail);
+        const int nt = __builtin_popcountll(T);
+        if (nt <= AC_FILL_PACK_MAX) {
+            const int myrank = __builtin_popcountll(T & ((1ull << lane) - 1ull));
+            const int t = lane >> 3, k = lane & 7;
+            float *const st = sink.stage;
+            for (int base = 0; base < nt; base += PACK_TAILS) {
+                const bool mine = tail && myrank >= base && myrank < base + PACK_TAILS;
+                float *const row = st + (myrank - base) * PACK_STRIDE;
+                const bool valid = base + t < nt;
+                uint32_t q0 = 0u, qy = 0u, qz = 0u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (mine) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                            *reinterpret_cast<float4 *>(row + 4 * w) = make_float4(v[16 * g + 4 * w], v[16 * g + 4 * w + 1], v[16 * g + 4 * w + 2], v[16 * g + 4 * w + 3]);
+                        if (g == 0) { row[16] = __uint_as_float(c[0].pg); row[17] = __uint_as_float(cty); row[18] = __uint_as_float(ctz); }
+                    }
+                    wave_sync_lds();
+                    const float2 val = *reinterpret_cast<const float2 *>(st + t * PACK_STRIDE + 2 * k);
+                    if (g == 0) { q0 = __float_as_uint(st[t * PACK_STRIDE + 16]); qy = __float_as_uint(st[t * PACK_STRIDE + 17]); qz = __float_as_uint(st[t * PACK_STRIDE + 18]); }
+                    uint32_t tx, ty, tz;
+                    if (g == 0) {                                   // the centre cell's corner k
+                        tx = q0 + ((uint32_t)k & 1u); ty = qy + ((k & 2) ? cmy : 0u); tz = qz + ((k & 4) ? cmz : 0u);
+                    } else {                                        // slot k = side * 4 + jm of the two planes next to the cell along axis g - 1
+                        const bool lo = (k & 1) != 0, hi = (k & 2) != 0, side = (k & 4) != 0;
+                        if (g == 1) { tx = side ? q0 + 2u : q0 - 1u; ty = qy + (lo ? cmy : 0u); tz = qz + (hi ? cmz : 0u); }
+                        else if (g == 2) { tx = q0 + (lo ? 1u : 0u); ty = side ? qy + 2u * cmy : qy - cmy; tz = qz + (hi ? cmz : 0u); }
+                        else { tx = q0 + (lo ? 1u : 0u); ty = qy + (hi ? cmy : 0u); tz = side ? qz + 2u * cmz : qz - cmz; }
+                    }
+                    sink.add1(valid && (val.x != 0.0f || val.y != 0.0f), gindex_t(L, tx, ty, tz), val.x, val.y);
+                    wave_sync_lds();                                // (the next group's values overwrite the rows)
+                }
+            }
+            sink.tick(1);
+            return;
+        }
+    }
+#endif
     {
         bool pred[8]; float vv[16];
 #pragma unroll
@@ -683,6 +754,7 @@ __global__ __launch_bounds__(256) void hash_stencil_bwd_binned_kernel(const floa
     BinSink sink;
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
+    sink.stage = reinterpret_cast<float *>(sink.base + NBUCKET);
     sink.cnt = 0; sink.lane = lane;
     sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
     sink.qcount = qcount + (size_t)ylev * NBUCKET;
@@ -753,6 +825,7 @@ __global__ __launch_bounds__(256) void hash_bwd_binned_kernel(const float *__res
     BinSink sink;
     sink.ridx = wbase; sink.rv0 = reinterpret_cast<float *>(wbase + RCAP); sink.rv1 = reinterpret_cast<float *>(wbase + 2 * RCAP);
     sink.hist = wbase + 3 * RCAP; sink.base = sink.hist + NBUCKET;
+    sink.stage = reinterpret_cast<float *>(sink.base + NBUCKET);
     sink.cnt = 0; sink.lane = lane;
     sink.sh = bucket_shift(lt.size[level]); sink.mx = 0u;
     sink.qcount = qcount + (size_t)ylev * NBUCKET;
